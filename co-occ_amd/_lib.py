@@ -1,0 +1,122 @@
+"""ctypes binding of libcoocc_hip.so (include/coocc_hip.h).
+
+The HIP library is the product: there is NO CPU or eager-PyTorch fallback.  Importing this
+module without a built library, or calling an op with CPU tensors, raises immediately.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcoocc_hip.so")
+
+c_int, c_float, c_void_p, c_size_t, c_int64 = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
+                                               ctypes.c_size_t, ctypes.c_int64)
+
+
+class ConvDesc(ctypes.Structure):
+    """struct coocc_conv_desc (include/coocc_hip.h)."""
+    _fields_ = [(n, c_void_p) for n in ("in_", "w", "out", "scale", "bias", "res", "gather", "out_rows", "ws")] + \
+               [("ws_floats", c_int64)] + \
+               [(n, c_int) for n in ("M", "Cin", "Cout", "taps", "in_stride", "out_stride", "res_stride",
+                                     "B", "Xi", "Yi", "Zi", "Xo", "Yo", "Zo", "ksize", "stride", "pad",
+                                     "relu", "res_mode", "splitk")]
+
+
+P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_int64
+# name -> (restype, argtypes); mirrors include/coocc_hip.h one to one (checked by tests/test_abi.py)
+SIGNATURES = {
+    "coocc_last_error": (ctypes.c_char_p, []),
+    "coocc_abi_version": (I, []),
+    "coocc_ncdhw_to_ndhwc": (I, [P, P, I, I, I, I, I, P]),
+    "coocc_ndhwc_to_ncdhw": (I, [P, P, I, I, I, I, I, P]),
+    "coocc_fuser_prepare": (I, [P, P, P, P, P, I, I, I, P]),
+    "coocc_compact_flags": (I, [P, I, P, P, P, Z, P]),
+    "coocc_lin_to_coords": (I, [P, I, I, I, I, P, P, P]),
+    "coocc_furthest_point_sampling": (I, [I, I, I, P, P, P, P]),
+    "coocc_ball_query": (I, [I, I, I, F, F, I, P, P, P, P]),
+    "coocc_knn_topk": (I, [I, I, I, P, P, P, P, P]),
+    "coocc_knn_assign": (I, [I, I, I, I, F, P, P, P, P, P, P]),
+    "coocc_knn_threshold": (I, [I, F, P, P, P, P]),
+    "coocc_index_rows_i32": (I, [P, I, P, I, P, P]),
+    "coocc_conv_pack_weights": (L, [P, I, I, I, I, P]),
+    "coocc_conv_fwd": (I, [ctypes.POINTER(ConvDesc), P]),
+    "coocc_upsample_add_trilinear": (I, [P, P, I, I, I, I, I, I, I, I, P]),
+    "coocc_occhead_mix": (I, [P, P, I, P, P, I, I, P]),
+    "coocc_argmax_flags": (I, [P, I, I, I, I, P, P]),
+    "coocc_fine_sample_voxel": (I, [P, I, I, I, I, P, I, I, P, P, P, I, P]),
+    "coocc_fine_sample_img": (I, [P, I, I, I, I, P, P, L, P, I, P]),
+    "coocc_groupnorm_rows": (I, [P, L, I, I, I, P, P, F, I, P]),
+    "coocc_groupnorm_nhwc": (I, [P, I, I, I, I, P, P, F, I, P]),
+    "coocc_scatter_fine": (I, [P, L, I, I, P, P, I, I, I, F, P]),
+    "coocc_get_geometry": (I, [P, P, P, P, I, I, I, I, P, P]),
+    "coocc_bev_pool_forward": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
+    "coocc_bev_pool_backward": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
+    "coocc_voxel_pool_ws": (Z, [I, I]),
+    "coocc_voxel_pool": (I, [P, P, I, I, I, P, I, I, I, I, P, I, P, Z, P]),
+    "coocc_bev_pool_coords": (I, [P, P, I, I, I, I, I, I, P, I, P, Z, P]),
+    "coocc_render_nearest": (I, [P, I, I, I, P, P, I, I, I, I, P, P, P]),
+    "coocc_upsample_maps": (I, [P, I, I, I, I, P, P, P]),
+    "coocc_volume_sampling": (I, [P, I, I, I, I, P, I, P, P, P, P]),
+    "coocc_raw2outputs": (I, [P, P, I, I, I, F, F, P, P, P, P]),
+    "coocc_render_losses": (I, [P, P, P, P, L, I, P, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libcoocc_hip.so (built in-tree by __graft_entry__.build()).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "co_occ_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+class CooccError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise CooccError("libcoocc_hip: %s (code %d)" % (load().coocc_last_error().decode(), rc))
+
+
+def call(name, *args):
+    """Call an int-returning entry point on the current torch HIP stream."""
+    check(getattr(load(), name)(*args, stream()))
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous HIP tensor (None -> NULL)."""
+    if t is None:
+        return c_void_p(0)
+    if not t.is_cuda:
+        raise CooccError("co_occ_amd ops run on the GPU only; got a %s tensor (no CPU fallback)" % t.device)
+    if dtype is not None and t.dtype != dtype:
+        raise CooccError("expected %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise CooccError("tensor must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+def host_f32(vals):
+    return (c_float * len(vals))(*[float(v) for v in vals])
+
+
+def host_i32(vals):
+    return (c_int * len(vals))(*[int(v) for v in vals])

@@ -1,0 +1,221 @@
+"""Host-side plumbing shared by the module mirrors: voxel-row views, weight packing
+(eval-mode BN folded into a per-channel scale/bias), and the implicit-GEMM launcher.
+
+Dense volumes travel between modules as channels-last rows ([B*X*Y*Z, C] fp32); to callers
+they look like the reference's [B,C,X,Y,Z] tensors (zero-copy permuted views), so the module
+surface stays drop-in while no layout conversion happens between our own modules.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, call, ptr
+
+_F32 = torch.float32
+
+
+class Rows:
+    """A dense voxel volume as channels-last rows: t[B*X*Y*Z, stride], C channels at `coff`."""
+
+    __slots__ = ("t", "B", "X", "Y", "Z", "C", "coff")
+
+    def __init__(self, t, B, X, Y, Z, C, coff=0):
+        self.t, self.B, self.X, self.Y, self.Z, self.C, self.coff = t, B, X, Y, Z, C, coff
+
+    @property
+    def stride(self):
+        return self.t.shape[1]
+
+    @property
+    def V(self):
+        return self.X * self.Y * self.Z
+
+    def data(self):
+        """ctypes pointer to channel 0 of row 0."""
+        return ctypes.c_void_p(self.t.data_ptr() + 4 * self.coff)
+
+    def as_ncdhw(self):
+        """Reference-layout view [B,C,X,Y,Z] (no copy)."""
+        v = self.t.view(self.B, self.X, self.Y, self.Z, self.stride)
+        if self.coff or self.stride != self.C:
+            v = v[..., self.coff:self.coff + self.C]
+        return v.permute(0, 4, 1, 2, 3)
+
+
+def to_rows(x):
+    """[B,C,X,Y,Z] tensor (any strides) -> Rows, converting with the HIP transpose if needed."""
+    if isinstance(x, Rows):
+        return x
+    if x.dim() != 5:
+        raise ValueError("expected a [B,C,X,Y,Z] tensor")
+    if not x.is_cuda:
+        raise _lib.CooccError("co_occ_amd modules run on the GPU only (no CPU fallback)")
+    B, C, X, Y, Z = x.shape
+    x = x.float()
+    cl = x.permute(0, 2, 3, 4, 1)
+    if cl.is_contiguous():
+        return Rows(cl.reshape(B * X * Y * Z, C), B, X, Y, Z, C)
+    x = x.contiguous()
+    out = torch.empty(B * X * Y * Z, C, device=x.device, dtype=_F32)
+    call("coocc_ncdhw_to_ndhwc", ptr(x), ptr(out), B, C, X * Y * Z, C, 0)
+    return Rows(out, B, X, Y, Z, C)
+
+
+def rows_to_ncdhw_contiguous(r):
+    """Materialise the reference memory layout (only needed by callers that insist on it)."""
+    out = torch.empty(r.B, r.C, r.X, r.Y, r.Z, device=r.t.device, dtype=_F32)
+    call("coocc_ndhwc_to_ncdhw", ptr(r.t), ptr(out), r.B, r.C, r.V, r.stride, r.coff)
+    return out
+
+
+# ------------------------------------------------------------------ weights
+def fold_bn(bn, conv_bias=None):
+    """Eval-mode BatchNorm -> (scale, bias) in fp64, returned fp32."""
+    var = bn.running_var.double()
+    scale = torch.rsqrt(var + bn.eps)
+    if bn.weight is not None:
+        scale = scale * bn.weight.double()
+    bias = -bn.running_mean.double() * scale
+    if bn.bias is not None:
+        bias = bias + bn.bias.double()
+    if conv_bias is not None:
+        bias = bias + conv_bias.double() * scale
+    return scale.float(), bias.float()
+
+
+class PackedConv:
+    """A conv/linear layer in the layout coocc_conv_fwd consumes (+ folded norm)."""
+
+    def __init__(self, weight, bn=None, bias=None, ksize=1, stride=1, pad=0, tap_major=False, taps=None):
+        w = weight.detach().float().cpu().contiguous()
+        self.Cout = w.shape[0]
+        if taps is None:
+            taps = ksize ** 3
+        if tap_major:
+            self.Cin = w.shape[1] // taps
+        else:
+            self.Cin = w.shape[1]
+            w = w.reshape(self.Cout, self.Cin, -1)
+            assert w.shape[2] == taps, "weight does not have ksize^3 taps"
+        self.taps, self.ksize, self.stride, self.pad = taps, ksize, stride, pad
+        lib = _lib.load()
+        n = lib.coocc_conv_pack_weights(ctypes.c_void_p(w.data_ptr()), self.Cout, self.Cin, taps, int(tap_major), None)
+        packed = torch.empty(n, dtype=_F32)
+        lib.coocc_conv_pack_weights(ctypes.c_void_p(w.data_ptr()), self.Cout, self.Cin, taps, int(tap_major),
+                                    ctypes.c_void_p(packed.data_ptr()))
+        dev = weight.device
+        self.w = packed.to(dev)
+        if bn is not None:
+            s, b = fold_bn(bn, bias)
+            self.scale, self.bias = s.to(dev).contiguous(), b.to(dev).contiguous()
+        else:
+            self.scale = None
+            self.bias = bias.detach().float().to(dev).contiguous() if bias is not None else None
+
+
+_ws_cache = {}
+
+
+def workspace(device, nfloats=64 << 20):
+    """Split-K scratch (256 MB by default), one per device, reused by every launch on the stream."""
+    key = (device.index, nfloats)
+    if key not in _ws_cache:
+        _ws_cache[key] = torch.empty(nfloats, device=device, dtype=_F32)
+    return _ws_cache[key]
+
+
+def out_dim(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
+    """out = epi(conv(x)) on Rows.  res: Rows added before ReLU (res_mode 1)."""
+    Xo, Yo, Zo = (out_dim(x.X, pc.ksize, pc.stride, pc.pad), out_dim(x.Y, pc.ksize, pc.stride, pc.pad),
+                  out_dim(x.Z, pc.ksize, pc.stride, pc.pad))
+    M = x.B * Xo * Yo * Zo
+    if out is None:
+        out = Rows(torch.empty(M, pc.Cout, device=x.t.device, dtype=_F32), x.B, Xo, Yo, Zo, pc.Cout)
+    assert x.C == pc.Cin, "channel mismatch: %d vs %d" % (x.C, pc.Cin)
+    ws = workspace(x.t.device)
+    d = ConvDesc()
+    d.in_, d.w, d.out = x.data(), ptr(pc.w), out.data()
+    d.scale, d.bias = ptr(pc.scale), ptr(pc.bias)
+    d.res = res.data() if res is not None else None
+    d.gather = None
+    d.out_rows = None
+    d.ws, d.ws_floats = ptr(ws), ws.numel()
+    d.M, d.Cin, d.Cout, d.taps = M, pc.Cin, pc.Cout, pc.taps
+    d.in_stride, d.out_stride = x.stride, out.stride
+    d.res_stride = res.stride if res is not None else 0
+    d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = x.B, x.X, x.Y, x.Z, Xo, Yo, Zo
+    d.ksize, d.stride, d.pad = pc.ksize, pc.stride, pc.pad
+    d.relu, d.res_mode, d.splitk = int(relu), (res_mode or (1 if res is not None else 0)), splitk
+    _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+    return out
+
+
+def linear_rows(x2d, pc, relu=False, out=None, out_coff=0, in_coff=0, in_C=None):
+    """Row-wise nn.Linear on a [n, stride] tensor via the same kernel (taps = 1)."""
+    n = x2d.shape[0]
+    Cin = in_C if in_C is not None else pc.Cin
+    if out is None:
+        out = torch.empty(n, pc.Cout, device=x2d.device, dtype=_F32)
+    if n == 0:
+        return out
+    ws = workspace(x2d.device)
+    d = ConvDesc()
+    d.in_ = ctypes.c_void_p(x2d.data_ptr() + 4 * in_coff)
+    d.w = ptr(pc.w)
+    d.out = ctypes.c_void_p(out.data_ptr() + 4 * out_coff)
+    d.scale, d.bias = ptr(pc.scale), ptr(pc.bias)
+    d.res = None
+    d.gather = None
+    d.out_rows = None
+    d.ws, d.ws_floats = ptr(ws), ws.numel()
+    d.M, d.Cin, d.Cout, d.taps = n, Cin, pc.Cout, 1
+    d.in_stride, d.out_stride, d.res_stride = x2d.shape[1], out.shape[1], 0
+    d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = 1, n, 1, 1, n, 1, 1
+    d.ksize, d.stride, d.pad = 1, 1, 0
+    d.relu, d.res_mode, d.splitk = int(relu), 0, 0
+    _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+    return out
+
+
+def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_coff, C, relu=True):
+    """GSFusion G1: dst[out_rows[m], dst_coff:+C] = relu(sum_k W_k . src[gather[k,m], src_coff:+C] + b)
+    * dst[out_rows[m], gate_coff:+C]   (bifuser_n.py:138-169).  src/dst: [rows, stride] tensors."""
+    K, M = gather.shape
+    if M == 0:
+        return
+    ws = workspace(src.device)
+    d = ConvDesc()
+    d.in_ = ctypes.c_void_p(src.data_ptr() + 4 * src_coff)
+    d.w = ptr(pc.w)
+    d.out = ctypes.c_void_p(dst.data_ptr() + 4 * dst_coff)
+    d.scale, d.bias = None, ptr(pc.bias)
+    d.res = ctypes.c_void_p(dst.data_ptr() + 4 * gate_coff)
+    d.gather = ptr(gather, torch.int32)
+    d.out_rows = ptr(out_rows, torch.int32)
+    d.ws, d.ws_floats = ptr(ws), ws.numel()
+    d.M, d.Cin, d.Cout, d.taps = M, C, pc.Cout, K
+    d.in_stride, d.out_stride, d.res_stride = src.shape[1], dst.shape[1], dst.shape[1]
+    d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = 1, 1, 1, 1, 1, 1, 1
+    d.ksize, d.stride, d.pad = 1, 1, 0
+    d.relu, d.res_mode, d.splitk = int(relu), 2, 1
+    _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+
+
+class PackCache:
+    """Re-pack lazily when any source parameter/buffer changed (torch `_version` counters)."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, tensors, build):
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors if t is not None)
+        if key != self._key:
+            self._val = build()
+            self._key = key
+        return self._val

@@ -1,0 +1,300 @@
+// fp32 implicit-GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32), one kernel family
+// for: Conv3d k=3/k=1 (+folded eval-mode BN, ReLU, residual) over channels-last voxel rows,
+// nn.Linear (+bias, ReLU), and GSFusion's gather -> knn_enc -> gate -> scatter.
+//
+//   out[orow(m)][n] = epi( sum_{t<taps} sum_{c<Cin} in[src(m,t)][c] * W[n][c][t] )
+//
+// src(m,t) is either geometric (voxel m's neighbour for tap t, zero padding) or a row table.
+// GEMM view: M = output rows, N = Cout, K = taps*Cin.  Block tile BM x BN, K-chunk 32,
+// 4 waves; A (gathered activations) and B (packed weights) tiles are staged in LDS with
+// K contiguous so one ds_read_b128 feeds 4 MFMA k-steps (lane-half h reads k=8q+4h..+3;
+// any permutation of k applied to both operands leaves the sum unchanged).  Global loads
+// for chunk i+1 are issued before the MFMAs of chunk i (register prefetch, LDS double buffer).
+//
+// MFMA 32x32x2 f32 operand maps (MI355X guide): A: lane l holds A[i=l&31][k=l>>5];
+// B: B[k=l>>5][j=l&31]; D: 16 regs, col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5).
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define KC 32      // K chunk (floats)
+#define LDS_ST 36  // LDS row stride in floats: 144 B rows keep ds_read_b128 conflict-free
+#define NPAD_TO 128
+
+struct ConvK {
+  const float* in; const float* w; float* out; const float* scale; const float* bias;
+  const float* res; const int32_t* gather; const int32_t* out_rows; float* ws;
+  int M, Cin, Cout, Npad, taps, kchunks;
+  int in_stride, out_stride, res_stride;
+  int Xi, Yi, Zi, Xo, Yo, Zo, ksize, stride, pad;
+  int relu, res_mode, iters_per_split, total_iters, splitk;
+  int mtiles, ntiles, mtiles_per_xcd;
+};
+
+__device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t rrow) {
+  if (p.scale) v *= p.scale[n];
+  if (p.bias) v += p.bias[n];
+  if (p.res_mode == 1) v += p.res[rrow * p.res_stride + n];
+  if (p.relu) v = fmaxf(v, 0.f);
+  if (p.res_mode == 2) v *= p.res[rrow * p.res_stride + n];
+  return v;
+}
+
+template <int BM, int BN, int WM, int WN, bool TABLE>
+__global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
+  constexpr int WAVES_N = BN / WN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int PA = BM / 32, PB = BN / 32;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+  __shared__ float As[2][BM * LDS_ST];
+  __shared__ float Bs[2][BN * LDS_ST];
+
+  // XCD-aware tile order: block id -> XCD (id & 7); each XCD walks a contiguous slab of
+  // M tiles (neighbouring voxel rows share halo lines in that XCD's L2) and keeps the N
+  // tiles of one M tile on the same XCD.
+  const int id = blockIdx.x;
+  const int xcd = id & 7, slot = id >> 3;
+  const int mt_local = slot / p.ntiles, nt = slot - mt_local * p.ntiles;
+  const int mtile = xcd * p.mtiles_per_xcd + mt_local;
+  if (mt_local >= p.mtiles_per_xcd || mtile >= p.mtiles) return;
+  const int m0 = mtile * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x;
+  const int piece = tid & 7, lrow = tid >> 3;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+  const int li = lane & 31, h = lane >> 5;
+
+  // per-thread A rows
+  int rbase[PA];  // GEOM: packed voxel origin; TABLE: m (or -1)
+  int rix[PA], riy[PA], riz[PA];
+#pragma unroll
+  for (int a = 0; a < PA; ++a) {
+    int m = m0 + lrow + 32 * a;
+    bool ok = m < p.M;
+    if (TABLE) {
+      rbase[a] = ok ? m : -1;
+      rix[a] = riy[a] = riz[a] = 0;
+    } else {
+      int oz = m % p.Zo; int r = m / p.Zo;
+      int oy = r % p.Yo; r /= p.Yo;
+      int ox = r % p.Xo; int b = r / p.Xo;
+      rbase[a] = ok ? b : -1;
+      rix[a] = ox * p.stride - p.pad;
+      riy[a] = oy * p.stride - p.pad;
+      riz[a] = oz * p.stride - p.pad;
+    }
+  }
+
+  const int it0 = blockIdx.y * p.iters_per_split;
+  const int it1 = min(it0 + p.iters_per_split, p.total_iters);
+
+  f32x4 ra[PA], rb[PB];
+  auto gload = [&](int it) {
+    const int t = it / p.kchunks, kc = it - t * p.kchunks;
+    const float* wt = p.w + ((size_t)it * p.Npad + n0) * KC + piece * 4;
+#pragma unroll
+    for (int b = 0; b < PB; ++b) rb[b] = *(const f32x4*)(wt + (size_t)(lrow + 32 * b) * KC);
+    const int cc = kc * KC + piece * 4;
+    const bool cok = cc < p.Cin;
+    int kd = 0, kh = 0, kw = 0;
+    if (!TABLE) {
+      kw = t % p.ksize; int r = t / p.ksize;
+      kh = r % p.ksize; kd = r / p.ksize;
+    }
+#pragma unroll
+    for (int a = 0; a < PA; ++a) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (TABLE) {
+        if (rbase[a] >= 0 && cok) {
+          int src = p.gather[(size_t)t * p.M + rbase[a]];
+          if (src >= 0) v = *(const f32x4*)(p.in + (size_t)src * p.in_stride + cc);
+        }
+      } else {
+        int ix = rix[a] + kd, iy = riy[a] + kh, iz = riz[a] + kw;
+        bool ok = rbase[a] >= 0 && cok && (unsigned)ix < (unsigned)p.Xi && (unsigned)iy < (unsigned)p.Yi &&
+                  (unsigned)iz < (unsigned)p.Zi;
+        if (ok) {
+          size_t row = (((size_t)rbase[a] * p.Xi + ix) * p.Yi + iy) * p.Zi + iz;
+          v = *(const f32x4*)(p.in + row * p.in_stride + cc);
+        }
+      }
+      ra[a] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int a = 0; a < PA; ++a) *(f32x4*)&As[buf][(lrow + 32 * a) * LDS_ST + piece * 4] = ra[a];
+#pragma unroll
+    for (int b = 0; b < PB; ++b) *(f32x4*)&Bs[buf][(lrow + 32 * b) * LDS_ST + piece * 4] = rb[b];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (it0 < it1) {
+    gload(it0);
+    lstore(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int it = it0; it < it1; ++it) {
+    const bool more = it + 1 < it1;
+    if (more) gload(it + 1);
+    const float* Ab = &As[cur][(wm * WM + li) * LDS_ST + h * 4];
+    const float* Bb = &Bs[cur][(wn * WN + li) * LDS_ST + h * 4];
+#pragma unroll
+    for (int q = 0; q < KC / 8; ++q) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(Ab + i * 32 * LDS_ST + q * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(Bb + j * 32 * LDS_ST + q * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: D row = (r&3) + 8*(r>>2) + 4*h, col = li
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r];
+        if (p.splitk > 1) {
+          p.ws[((size_t)blockIdx.y * p.M + m) * p.Npad + n] = v;  // n < Npad always
+        } else if (n < p.Cout) {
+          size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
+          p.out[orow * p.out_stride + n] = epilogue(p, v, n, orow);
+        }
+      }
+    }
+}
+
+// split-K second pass: sum the partial slabs in a fixed order, then the epilogue
+__global__ __launch_bounds__(256) void k_conv_reduce(ConvK p) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)p.M * p.Cout) return;
+  int m = (int)(i / p.Cout), n = (int)(i - (size_t)m * p.Cout);
+  float v = 0.f;
+  for (int z = 0; z < p.splitk; ++z) v += p.ws[((size_t)z * p.M + m) * p.Npad + n];
+  size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
+  p.out[orow * p.out_stride + n] = epilogue(p, v, n, orow);
+}
+
+// ------------------------------------------------------------------ host side
+extern "C" int64_t coocc_conv_pack_weights(const float* w_host, int Cout, int Cin, int taps, int tap_major,
+                                           float* packed_host) {
+  if (Cout <= 0 || Cin <= 0 || taps <= 0) return coocc_set_error(COOCC_EINVAL, "pack_weights: bad dims");
+  const int kch = (Cin + KC - 1) / KC;
+  const int Npad = (Cout + NPAD_TO - 1) / NPAD_TO * NPAD_TO;
+  const int64_t total = (int64_t)taps * kch * Npad * KC;
+  if (!packed_host) return total;
+  if (!w_host) return coocc_set_error(COOCC_EINVAL, "pack_weights: null weights");
+  memset(packed_host, 0, sizeof(float) * (size_t)total);
+  for (int t = 0; t < taps; ++t)
+    for (int n = 0; n < Cout; ++n)
+      for (int c = 0; c < Cin; ++c) {
+        float v = tap_major ? w_host[((size_t)n * taps + t) * Cin + c] : w_host[((size_t)n * Cin + c) * taps + t];
+        packed_host[(((size_t)t * kch + c / KC) * Npad + n) * KC + (c % KC)] = v;
+      }
+  return total;
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_cfg(ConvK& k, bool table, hipStream_t s) {
+  k.mtiles = (k.M + BM - 1) / BM;
+  k.ntiles = (k.Cout + BN - 1) / BN;
+  k.mtiles_per_xcd = (k.mtiles + 7) / 8;
+  dim3 grid(8 * k.mtiles_per_xcd * k.ntiles, k.splitk);
+  if (table)
+    hipLaunchKernelGGL((k_conv<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, k);
+  else
+    hipLaunchKernelGGL((k_conv<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, k);
+}
+
+extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
+  COOCC_CHECK_ARG(d && d->in && d->w && d->out, "conv_fwd: null pointer");
+  COOCC_CHECK_ARG(d->M > 0 && d->Cin > 0 && d->Cout > 0 && d->taps > 0, "conv_fwd: bad sizes");
+  COOCC_CHECK_ARG(d->Cin % 4 == 0 && d->in_stride % 4 == 0, "conv_fwd: Cin and in_stride must be multiples of 4");
+  COOCC_CHECK_ARG(((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->w & 15) == 0, "conv_fwd: in/w must be 16-byte aligned");
+  COOCC_CHECK_ARG(d->res_mode == 0 || d->res, "conv_fwd: res_mode set without res");
+  if (!d->gather) {
+    COOCC_CHECK_ARG(d->taps == d->ksize * d->ksize * d->ksize, "conv_fwd: taps != ksize^3");
+    COOCC_CHECK_ARG((long long)d->B * d->Xo * d->Yo * d->Zo == d->M, "conv_fwd: M != B*Xo*Yo*Zo");
+  }
+  ConvK k;
+  memset(&k, 0, sizeof(k));
+  k.in = d->in; k.w = d->w; k.out = d->out; k.scale = d->scale; k.bias = d->bias; k.res = d->res;
+  k.gather = d->gather; k.out_rows = d->out_rows; k.ws = d->ws;
+  k.M = d->M; k.Cin = d->Cin; k.Cout = d->Cout; k.taps = d->taps;
+  k.kchunks = (d->Cin + KC - 1) / KC;
+  k.Npad = (d->Cout + NPAD_TO - 1) / NPAD_TO * NPAD_TO;
+  k.in_stride = d->in_stride; k.out_stride = d->out_stride; k.res_stride = d->res_stride;
+  k.Xi = d->Xi; k.Yi = d->Yi; k.Zi = d->Zi; k.Xo = d->Xo; k.Yo = d->Yo; k.Zo = d->Zo;
+  k.ksize = d->ksize; k.stride = d->stride; k.pad = d->pad;
+  k.relu = d->relu; k.res_mode = d->res_mode;
+  k.total_iters = k.taps * k.kchunks;
+
+  // tile configuration by problem shape
+  int cfg;  // 0: 128x128 (64x64 waves), 1: 64x128 (32x64), 2: 128x64 (32x64), 3: 128x32 (32x32)
+  if (d->Cout <= 32) cfg = 3;
+  else if (d->Cout <= 64) cfg = 2;
+  else cfg = d->M >= 8192 ? 0 : 1;
+  const int BM = cfg == 1 ? 64 : 128, BN = cfg == 3 ? 32 : (cfg == 2 ? 64 : 128);
+  const long long blocks = (long long)((d->M + BM - 1) / BM) * ((d->Cout + BN - 1) / BN);
+  int splitk = d->splitk;
+  if (splitk <= 0) {
+    splitk = 1;
+    if (blocks < 256 && k.total_iters >= 16 && d->ws) {
+      splitk = (int)((512 + blocks - 1) / blocks);
+      if (splitk > k.total_iters / 8) splitk = k.total_iters / 8;
+      if (splitk > 64) splitk = 64;
+      while (splitk > 1 && (long long)splitk * d->M * k.Npad > d->ws_floats) --splitk;
+      if (splitk < 1) splitk = 1;
+    }
+  }
+  if (splitk > 1) {
+    COOCC_CHECK_ARG(d->ws && (long long)splitk * d->M * k.Npad <= d->ws_floats, "conv_fwd: split-K workspace too small");
+  }
+  k.iters_per_split = (k.total_iters + splitk - 1) / splitk;
+  splitk = (k.total_iters + k.iters_per_split - 1) / k.iters_per_split;  // no empty splits
+  k.splitk = splitk;
+
+  hipStream_t s = as_stream(stream);
+  const bool table = d->gather != nullptr;
+  switch (cfg) {
+    case 0: launch_cfg<128, 128, 64, 64>(k, table, s); break;
+    case 1: launch_cfg<64, 128, 32, 64>(k, table, s); break;
+    case 2: launch_cfg<128, 64, 32, 64>(k, table, s); break;
+    default: launch_cfg<128, 32, 32, 32>(k, table, s); break;
+  }
+  COOCC_LAUNCH_CHECK("k_conv");
+  if (splitk > 1) {
+    hipLaunchKernelGGL(k_conv_reduce, dim3(cdiv((long long)k.M * k.Cout, 256)), dim3(256), 0, s, k);
+    COOCC_LAUNCH_CHECK("k_conv_reduce");
+  }
+  return COOCC_OK;
+}

@@ -1,0 +1,281 @@
+// OccHead cascade ("fine") branch, occ_head.py:173-237 (C4): occupied coarse voxels ->
+// ratio^3 fine coordinates -> trilinear sample of the mixed voxel features + bilinear
+// sample of the 6 camera feature maps -> small MLPs (GEMMs in conv3d.hip) with GroupNorm.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// coarse_occ.argmax(1) != empty_idx (occ_head.py:182); torch.argmax keeps the first maximum
+__global__ __launch_bounds__(256) void k_argmax_flags(const float* __restrict__ logits, int V, int ncls, int stride,
+                                                       int empty_idx, uint8_t* __restrict__ flags) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const float* r = logits + (size_t)v * stride;
+  float best = r[0];
+  int bi = 0;
+  for (int c = 1; c < ncls; ++c)
+    if (r[c] > best) { best = r[c]; bi = c; }
+  flags[v] = bi != empty_idx;
+}
+
+extern "C" int coocc_argmax_flags(const float* logits, int V, int ncls, int stride, int empty_idx, uint8_t* flags,
+                                  void* stream) {
+  COOCC_CHECK_ARG(logits && flags && V > 0 && ncls > 0 && stride >= ncls, "argmax_flags: bad args");
+  hipLaunchKernelGGL(k_argmax_flags, dim3(cdiv(V, 256)), dim3(256), 0, as_stream(stream), logits, V, ncls, stride,
+                     empty_idx, flags);
+  COOCC_LAUNCH_CHECK("k_argmax_flags");
+  return COOCC_OK;
+}
+
+// coarse_to_fine_coordinates (coordinate_transform.py:3-21, eval branch) + the voxel
+// grid_sample of occ_head.py:205-214.  Fine point f = o*n + i (offset-major), offset
+// o = (a*r + b)*r + c.  Normalised coordinate g = (fine/(final-1) - 0.5)*2; the sampled
+// volume is out_voxel_feats.permute(0,1,4,3,2) so grid x walks our X axis, y -> Y, z -> Z.
+// grid_sample(bilinear, zeros, align_corners=False): pix = ((g+1)*size - 1)/2.
+// One wave per fine point, two channels per lane per step.
+__global__ __launch_bounds__(256) void k_fine_sample_voxel(const float* __restrict__ vol, int C, int X, int Y, int Z,
+                                                            const int32_t* __restrict__ coarse_lin, int n, int ratio,
+                                                            float fx1, float fy1, float fz1,
+                                                            int64_t* __restrict__ fine_xyz, float* __restrict__ feat,
+                                                            int out_stride) {
+  const int r3 = ratio * ratio * ratio;
+  const long long nf = (long long)n * r3;
+  const long long f = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (f >= nf) return;
+  const int o = (int)(f / n), i = (int)(f - (long long)o * n);
+  int l = coarse_lin[i];
+  const int cz = l % Z; l /= Z;
+  const int cy = l % Y; const int cx = l / Y;   // B == 1
+  const int oc = o % ratio, ob = (o / ratio) % ratio, oa = o / (ratio * ratio);
+  const int qx = cx * ratio + oa, qy = cy * ratio + ob, qz = cz * ratio + oc;
+  if (lane == 0) { fine_xyz[f] = qx; fine_xyz[nf + f] = qy; fine_xyz[2 * nf + f] = qz; }
+  float gx = ((float)qx / fx1 - 0.5f) * 2.f, gy = ((float)qy / fy1 - 0.5f) * 2.f, gz = ((float)qz / fz1 - 0.5f) * 2.f;
+  float px = ((gx + 1.f) * (float)X - 1.f) / 2.f, py = ((gy + 1.f) * (float)Y - 1.f) / 2.f,
+        pz = ((gz + 1.f) * (float)Z - 1.f) / 2.f;
+  float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+  int x0 = (int)flx, y0 = (int)fly, z0 = (int)flz;
+  float tx = px - flx, ty = py - fly, tz = pz - flz;
+  float wx[2] = {1.f - tx, tx}, wy[2] = {1.f - ty, ty}, wz[2] = {1.f - tz, tz};
+  for (int c = lane * 2; c < C; c += 128) {
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          int x = x0 + a, y = y0 + b, z = z0 + d;
+          if ((unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y && (unsigned)z < (unsigned)Z) {
+            f32x2 v = *(const f32x2*)(vol + (((size_t)x * Y + y) * Z + z) * C + c);
+            acc = acc + v * (wx[a] * wy[b] * wz[d]);
+          }
+        }
+    *(f32x2*)(feat + (size_t)f * out_stride + c) = acc;
+  }
+}
+
+extern "C" int coocc_fine_sample_voxel(const float* vol, int C, int X, int Y, int Z, const int32_t* coarse_lin, int n,
+                                       int ratio, const int* final_size_host, int64_t* fine_xyz, float* feat,
+                                       int out_stride, void* stream) {
+  COOCC_CHECK_ARG(vol && coarse_lin && final_size_host && fine_xyz && feat && C % 2 == 0 && ratio >= 1 && n >= 0,
+                  "fine_sample_voxel: bad args");
+  if (n == 0) return COOCC_OK;
+  long long nf = (long long)n * ratio * ratio * ratio;
+  hipLaunchKernelGGL(k_fine_sample_voxel, dim3(cdiv(nf * 64, 256)), dim3(256), 0, as_stream(stream), vol, C, X, Y, Z,
+                     coarse_lin, n, ratio, (float)(final_size_host[0] - 1), (float)(final_size_host[1] - 1),
+                     (float)(final_size_host[2] - 1), fine_xyz, feat, out_stride);
+  COOCC_LAUNCH_CHECK("k_fine_sample_voxel");
+  return COOCC_OK;
+}
+
+// project_points_on_img (coordinate_transform.py:25-65, nuScenes branch) fused with the
+// per-camera bilinear grid_sample(align_corners=True, zeros) * mask, summed over cameras
+// (occ_head.py:222-234).  params layout (floats):
+//   [0:9] inv(bda)  [9:12] voxel_size  [12:15] range_lo  [15] W_img-1  [16] H_img-1
+//   then per camera 27: inv(rots)[9], trans[3], intrins[9], post_rots[:2,:2][4], post_trans[:2][2]
+#define FINE_CAM_STRIDE 27
+#define FINE_HDR 17
+__global__ __launch_bounds__(256) void k_fine_sample_img(const float* __restrict__ img, int ncam, int Ci, int Hf, int Wf,
+                                                          const float* __restrict__ prm,
+                                                          const int64_t* __restrict__ fine_xyz, long long nf,
+                                                          float* __restrict__ feat, int out_stride) {
+  const long long f = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (f >= nf) return;
+  float p0 = (float)fine_xyz[f] * prm[9] + prm[12];
+  float p1 = (float)fine_xyz[nf + f] * prm[10] + prm[13];
+  float p2 = (float)fine_xyz[2 * nf + f] * prm[11] + prm[14];
+  float bx = prm[0] * p0 + prm[1] * p1 + prm[2] * p2;
+  float by = prm[3] * p0 + prm[4] * p1 + prm[5] * p2;
+  float bz = prm[6] * p0 + prm[7] * p1 + prm[8] * p2;
+  const float wimg1 = prm[15], himg1 = prm[16];
+  f32x2 acc[4];
+  const int nstep = (Ci + 127) / 128;  // <= 4 steps (Ci <= 512)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc[s] = f32x2{0.f, 0.f};
+  for (int cam = 0; cam < ncam; ++cam) {
+    const float* q = prm + FINE_HDR + cam * FINE_CAM_STRIDE;
+    float tx = bx - q[9], ty = by - q[10], tz = bz - q[11];
+    float cx = q[0] * tx + q[1] * ty + q[2] * tz;
+    float cy = q[3] * tx + q[4] * ty + q[5] * tz;
+    float cz = q[6] * tx + q[7] * ty + q[8] * tz;
+    float ix = q[12] * cx + q[13] * cy + q[14] * cz;
+    float iy = q[15] * cx + q[16] * cy + q[17] * cz;
+    float d = q[18] * cx + q[19] * cy + q[20] * cz;
+    float u = ix / (d + 1e-5f), v = iy / (d + 1e-5f);
+    float u2 = q[21] * u + q[22] * v + q[25];
+    float v2 = q[23] * u + q[24] * v + q[26];
+    u2 = (u2 / wimg1 - 0.5f) * 2.f;
+    v2 = (v2 / himg1 - 0.5f) * 2.f;
+    bool m = d > 1e-5f && u2 > -1.f && u2 < 1.f && v2 > -1.f && v2 < 1.f;
+    if (!m) continue;
+    float px = (u2 + 1.f) / 2.f * (float)(Wf - 1), py = (v2 + 1.f) / 2.f * (float)(Hf - 1);
+    float flx = floorf(px), fly = floorf(py);
+    int x0 = (int)flx, y0 = (int)fly;
+    float ax = px - flx, ay = py - fly;
+    const float* base = img + (size_t)cam * Hf * Wf * Ci;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      int c = s * 128 + lane * 2;
+      if (s >= nstep || c >= Ci) continue;
+      f32x2 a = acc[s];
+#pragma unroll
+      for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+        for (int xx = 0; xx < 2; ++xx) {
+          int x = x0 + xx, y = y0 + yy;
+          if ((unsigned)x < (unsigned)Wf && (unsigned)y < (unsigned)Hf) {
+            float w = (xx ? ax : 1.f - ax) * (yy ? ay : 1.f - ay);
+            f32x2 val = *(const f32x2*)(base + ((size_t)y * Wf + x) * Ci + c);
+            a = a + val * w;
+          }
+        }
+      acc[s] = a;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    int c = s * 128 + lane * 2;
+    if (s < nstep && c < Ci) *(f32x2*)(feat + (size_t)f * out_stride + c) = acc[s];
+  }
+}
+
+extern "C" int coocc_fine_sample_img(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf, const float* params,
+                                     const int64_t* fine_xyz, int64_t nfine, float* feat, int out_stride, void* stream) {
+  COOCC_CHECK_ARG(img_nhwc && params && fine_xyz && feat && ncam > 0 && Ci > 0 && Ci % 2 == 0 && Ci <= 512,
+                  "fine_sample_img: bad args (Ci even, <= 512)");
+  if (nfine == 0) return COOCC_OK;
+  hipLaunchKernelGGL(k_fine_sample_img, dim3(cdiv(nfine * 64, 256)), dim3(256), 0, as_stream(stream), img_nhwc, ncam, Ci,
+                     Hf, Wf, params, fine_xyz, (long long)nfine, feat, out_stride);
+  COOCC_LAUNCH_CHECK("k_fine_sample_img");
+  return COOCC_OK;
+}
+
+// nn.GroupNorm over rows [n, C] (2-D input: statistics per row and group) + optional ReLU
+__global__ __launch_bounds__(256) void k_groupnorm_rows(float* __restrict__ x, long long n, int C, int stride, int groups,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, int relu) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * groups) return;
+  long long row = i / groups;
+  int g = (int)(i - row * groups);
+  int cpg = C / groups;
+  float* p = x + row * stride + g * cpg;
+  float mean = 0.f;
+  for (int c = 0; c < cpg; ++c) mean += p[c];
+  mean /= (float)cpg;
+  float var = 0.f;
+  for (int c = 0; c < cpg; ++c) { float d = p[c] - mean; var += d * d; }
+  var /= (float)cpg;
+  float rstd = 1.f / sqrtf(var + eps);
+  for (int c = 0; c < cpg; ++c) {
+    float v = (p[c] - mean) * rstd * gamma[g * cpg + c] + beta[g * cpg + c];
+    p[c] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+extern "C" int coocc_groupnorm_rows(float* x, int64_t n, int C, int stride, int groups, const float* gamma,
+                                    const float* beta, float eps, int relu, void* stream) {
+  COOCC_CHECK_ARG(x && gamma && beta && C > 0 && groups > 0 && C % groups == 0 && stride >= C, "groupnorm_rows: bad args");
+  if (n == 0) return COOCC_OK;
+  hipLaunchKernelGGL(k_groupnorm_rows, dim3(cdiv(n * groups, 256)), dim3(256), 0, as_stream(stream), x, (long long)n, C,
+                     stride, groups, gamma, beta, eps, relu);
+  COOCC_LAUNCH_CHECK("k_groupnorm_rows");
+  return COOCC_OK;
+}
+
+// nn.GroupNorm over an NHWC image batch [N, HW, C]: statistics per (image, group) over
+// HW * C/groups values (occ_head.py:64-68), then normalise (+ReLU).  One block per (n, group).
+__global__ __launch_bounds__(256) void k_groupnorm_nhwc(float* __restrict__ x, int HW, int C, int groups,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, int relu) {
+  __shared__ double s_a[4], s_b[4];
+  __shared__ float s_mean, s_rstd;
+  const int n = blockIdx.y, g = blockIdx.x, cpg = C / groups;
+  float* base = x + (size_t)n * HW * C + g * cpg;
+  const int total = HW * cpg;
+  double sum = 0, sq = 0;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    float v = base[(size_t)(i / cpg) * C + (i % cpg)];
+    sum += v; sq += (double)v * v;
+  }
+  for (int m = 32; m > 0; m >>= 1) { sum += __shfl_xor(sum, m); sq += __shfl_xor(sq, m); }
+  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = sum; s_b[threadIdx.x >> 6] = sq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = s_a[0] + s_a[1] + s_a[2] + s_a[3], b = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+    double mean = a / total, var = b / total - mean * mean;
+    s_mean = (float)mean;
+    s_rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
+  }
+  __syncthreads();
+  const float mean = s_mean, rstd = s_rstd;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    int c = i % cpg;
+    float* p = base + (size_t)(i / cpg) * C + c;
+    float v = (*p - mean) * rstd * gamma[g * cpg + c] + beta[g * cpg + c];
+    *p = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+extern "C" int coocc_groupnorm_nhwc(float* x, int N, int HW, int C, int groups, const float* gamma, const float* beta,
+                                    float eps, int relu, void* stream) {
+  COOCC_CHECK_ARG(x && gamma && beta && N > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "groupnorm_nhwc: bad args");
+  hipLaunchKernelGGL(k_groupnorm_nhwc, dim3(groups, N), dim3(256), 0, as_stream(stream), x, HW, C, groups, gamma, beta, eps,
+                     relu);
+  COOCC_LAUNCH_CHECK("k_groupnorm_nhwc");
+  return COOCC_OK;
+}
+
+// simple_test fine scatter (coocc_ray.py:546-550): grid [ncls,Xf,Yf,Zf] pre-filled with
+// empty_idx, fine logits written at their coordinates.
+__global__ __launch_bounds__(256) void k_fill(float* __restrict__ p, size_t n, float v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(256) void k_scatter_fine(const float* __restrict__ logits, long long nf, int ncls, int stride,
+                                                       const int64_t* __restrict__ fine_xyz, float* __restrict__ grid,
+                                                       int Xf, int Yf, int Zf) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nf * ncls) return;
+  long long f = i / ncls;
+  int c = (int)(i - f * ncls);
+  long long x = fine_xyz[f], y = fine_xyz[nf + f], z = fine_xyz[2 * nf + f];
+  grid[(((size_t)c * Xf + x) * Yf + y) * Zf + z] = logits[f * stride + c];
+}
+
+extern "C" int coocc_scatter_fine(const float* fine_logits, int64_t nfine, int ncls, int stride, const int64_t* fine_xyz,
+                                  float* grid, int Xf, int Yf, int Zf, float empty_val, void* stream) {
+  COOCC_CHECK_ARG(grid && ncls > 0 && Xf > 0 && Yf > 0 && Zf > 0, "scatter_fine: bad args");
+  size_t total = (size_t)ncls * Xf * Yf * Zf;
+  hipLaunchKernelGGL(k_fill, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), grid, total, empty_val);
+  if (nfine > 0) {
+    COOCC_CHECK_ARG(fine_logits && fine_xyz && stride >= ncls, "scatter_fine: null pointer");
+    hipLaunchKernelGGL(k_scatter_fine, dim3(cdiv(nfine * ncls, 256)), dim3(256), 0, as_stream(stream), fine_logits,
+                       (long long)nfine, ncls, stride, fine_xyz, grid, Xf, Yf, Zf);
+  }
+  COOCC_LAUNCH_CHECK("scatter_fine");
+  return COOCC_OK;
+}

@@ -1,0 +1,155 @@
+// Trilinear / bilinear resampling on channels-last rows (F.interpolate, align_corners=False):
+// FPN3D top-down add, OccHead multi-level softmax mix, render-map x16 upsample.
+// Source index rule (ATen area_pixel_compute_source_index): src = max(0, scale*(dst+0.5)-0.5),
+// scale = in/out (fp32), i0 = floor(src), i1 = i0 + (i0 < in-1), lambda = src - i0.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Lin1 { int i0, i1; float w0, w1; };
+
+__device__ __forceinline__ Lin1 lin_src(int dst, int in, int out) {
+  Lin1 r;
+  if (in == out) { r.i0 = r.i1 = dst; r.w0 = 1.f; r.w1 = 0.f; return r; }
+  float scale = (float)in / (float)out;
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  r.i0 = (int)s;
+  r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+  r.w1 = s - (float)r.i0;
+  r.w0 = 1.f - r.w1;
+  return r;
+}
+
+__device__ __forceinline__ f32x4 tri_sample(const float* __restrict__ vol, int b, int C, int X, int Y, int Z,
+                                            const Lin1& lx, const Lin1& ly, const Lin1& lz, int c) {
+  auto at = [&](int x, int y, int z) {
+    return *(const f32x4*)(vol + ((((size_t)b * X + x) * Y + y) * Z + z) * C + c);
+  };
+  f32x4 v000 = at(lx.i0, ly.i0, lz.i0), v001 = at(lx.i0, ly.i0, lz.i1);
+  f32x4 v010 = at(lx.i0, ly.i1, lz.i0), v011 = at(lx.i0, ly.i1, lz.i1);
+  f32x4 v100 = at(lx.i1, ly.i0, lz.i0), v101 = at(lx.i1, ly.i0, lz.i1);
+  f32x4 v110 = at(lx.i1, ly.i1, lz.i0), v111 = at(lx.i1, ly.i1, lz.i1);
+  return lx.w0 * (ly.w0 * (lz.w0 * v000 + lz.w1 * v001) + ly.w1 * (lz.w0 * v010 + lz.w1 * v011)) +
+         lx.w1 * (ly.w0 * (lz.w0 * v100 + lz.w1 * v101) + ly.w1 * (lz.w0 * v110 + lz.w1 * v111));
+}
+
+// fpn3d.py:88-92  laterals[i-1] += interpolate(laterals[i], size=prev_shape, trilinear)
+__global__ __launch_bounds__(256) void k_upsample_add(const float* __restrict__ coarse, float* __restrict__ fine,
+                                                       int B, int C, int Xc, int Yc, int Zc, int Xf, int Yf, int Zf) {
+  const int c4 = C >> 2;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)B * Xf * Yf * Zf * c4;
+  if (i >= total) return;
+  int c = (int)(i % c4) * 4;
+  size_t v = i / c4;
+  int z = (int)(v % Zf); v /= Zf;
+  int y = (int)(v % Yf); v /= Yf;
+  int x = (int)(v % Xf); int b = (int)(v / Xf);
+  Lin1 lx = lin_src(x, Xc, Xf), ly = lin_src(y, Yc, Yf), lz = lin_src(z, Zc, Zf);
+  f32x4 s = tri_sample(coarse, b, C, Xc, Yc, Zc, lx, ly, lz, c);
+  f32x4* o = (f32x4*)(fine + ((((size_t)b * Xf + x) * Yf + y) * Zf + z) * C + c);
+  *o = *o + s;
+}
+
+extern "C" int coocc_upsample_add_trilinear(const float* coarse, float* fine, int B, int C, int Xc, int Yc,
+                                            int Zc, int Xf, int Yf, int Zf, void* stream) {
+  COOCC_CHECK_ARG(coarse && fine && B > 0 && C > 0 && C % 4 == 0, "upsample_add: bad args (C % 4 == 0)");
+  size_t total = (size_t)B * Xf * Yf * Zf * (C / 4);
+  hipLaunchKernelGGL(k_upsample_add, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), coarse, fine, B, C, Xc,
+                     Yc, Zc, Xf, Yf, Zf);
+  COOCC_LAUNCH_CHECK("k_upsample_add");
+  return COOCC_OK;
+}
+
+// occ_head.py:155-166: softmax over the level logits, then
+//   out = sum_l interpolate(occ_l, level-0 size) * w_l      (accumulated in level order)
+struct MixLevels { const float* p[4]; int X[4], Y[4], Z[4]; int L; };
+
+__global__ __launch_bounds__(256) void k_occhead_mix(MixLevels lv, const float* __restrict__ wlogit,
+                                                      float* __restrict__ out, int B, int C) {
+  const int c4 = C >> 2;
+  const int X0 = lv.X[0], Y0 = lv.Y[0], Z0 = lv.Z[0];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)B * X0 * Y0 * Z0 * c4;
+  if (i >= total) return;
+  int c = (int)(i % c4) * 4;
+  size_t v = i / c4;
+  const size_t row = v;
+  int z = (int)(v % Z0); v /= Z0;
+  int y = (int)(v % Y0); v /= Y0;
+  int x = (int)(v % X0); int b = (int)(v / X0);
+  float w[4];
+  float mx = -INFINITY;
+  for (int l = 0; l < lv.L; ++l) { w[l] = wlogit ? wlogit[row * lv.L + l] : 0.f; mx = fmaxf(mx, w[l]); }
+  float sum = 0.f;
+  for (int l = 0; l < lv.L; ++l) { w[l] = expf(w[l] - mx); sum += w[l]; }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int l = 0; l < lv.L; ++l) {
+    Lin1 lx = lin_src(x, lv.X[l], X0), ly = lin_src(y, lv.Y[l], Y0), lz = lin_src(z, lv.Z[l], Z0);
+    f32x4 s = tri_sample(lv.p[l], b, C, lv.X[l], lv.Y[l], lv.Z[l], lx, ly, lz, c);
+    acc = acc + s * (w[l] / sum);
+  }
+  *(f32x4*)(out + row * C + c) = acc;
+}
+
+extern "C" int coocc_occhead_mix(const float* const* levels_host, const int* dims_host, int L, const float* wlogit,
+                                 float* out, int B, int C, void* stream) {
+  COOCC_CHECK_ARG(levels_host && dims_host && out && L >= 1 && L <= 4 && C % 4 == 0, "occhead_mix: bad args");
+  MixLevels lv;
+  lv.L = L;
+  for (int l = 0; l < 4; ++l) {
+    lv.p[l] = l < L ? levels_host[l] : nullptr;
+    lv.X[l] = l < L ? dims_host[l * 3 + 0] : 1;
+    lv.Y[l] = l < L ? dims_host[l * 3 + 1] : 1;
+    lv.Z[l] = l < L ? dims_host[l * 3 + 2] : 1;
+  }
+  size_t total = (size_t)B * lv.X[0] * lv.Y[0] * lv.Z[0] * (C / 4);
+  hipLaunchKernelGGL(k_occhead_mix, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), lv, wlogit, out, B, C);
+  COOCC_LAUNCH_CHECK("k_occhead_mix");
+  return COOCC_OK;
+}
+
+// coocc_ray.py:617-622: F.interpolate(scale_factor=16, mode='bilinear') of depth_map and rgb_map.
+// maps [N,H,W,4] (r,g,b,depth) -> rgbs [N,sH,sW,3], depths [N,sH,sW]; 4 output pixels per lane,
+// written as whole dwordx4 stores (this kernel is the write-bandwidth-bound part of rendering).
+__global__ __launch_bounds__(256) void k_upsample_maps(const float* __restrict__ maps, int N, int H, int W, int scale,
+                                                        float* __restrict__ rgbs, float* __restrict__ depths) {
+  const int oH = H * scale, oW = W * scale;
+  const int q = oW >> 2;  // quads per row
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * oH * q) return;
+  int xq = (int)(i % q);
+  size_t r = i / q;
+  int oy = (int)(r % oH);
+  int n = (int)(r / oH);
+  Lin1 ly = lin_src(oy, H, oH);
+  float o[16];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    Lin1 lx = lin_src(xq * 4 + k, W, oW);
+    const f32x4* m = (const f32x4*)maps + (size_t)n * H * W;
+    f32x4 v00 = m[ly.i0 * W + lx.i0], v01 = m[ly.i0 * W + lx.i1];
+    f32x4 v10 = m[ly.i1 * W + lx.i0], v11 = m[ly.i1 * W + lx.i1];
+    f32x4 v = ly.w0 * (lx.w0 * v00 + lx.w1 * v01) + ly.w1 * (lx.w0 * v10 + lx.w1 * v11);
+    o[k * 3 + 0] = v[0]; o[k * 3 + 1] = v[1]; o[k * 3 + 2] = v[2];
+    o[12 + k] = v[3];
+  }
+  size_t pix = ((size_t)n * oH + oy) * oW + (size_t)xq * 4;
+  f32x4* pr = (f32x4*)(rgbs + pix * 3);
+  pr[0] = f32x4{o[0], o[1], o[2], o[3]};
+  pr[1] = f32x4{o[4], o[5], o[6], o[7]};
+  pr[2] = f32x4{o[8], o[9], o[10], o[11]};
+  *(f32x4*)(depths + pix) = f32x4{o[12], o[13], o[14], o[15]};
+}
+
+extern "C" int coocc_upsample_maps(const float* maps, int N, int H, int W, int scale, float* rgbs, float* depths,
+                                   void* stream) {
+  COOCC_CHECK_ARG(maps && rgbs && depths && N > 0 && H > 0 && W > 0 && scale >= 1, "upsample_maps: bad args");
+  COOCC_CHECK_ARG((W * scale) % 4 == 0, "upsample_maps: output width must be a multiple of 4");
+  size_t total = (size_t)N * H * scale * (W * scale / 4);
+  hipLaunchKernelGGL(k_upsample_maps, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), maps, N, H, W, scale,
+                     rgbs, depths);
+  COOCC_LAUNCH_CHECK("k_upsample_maps");
+  return COOCC_OK;
+}

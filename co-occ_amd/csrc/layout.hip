@@ -1,0 +1,238 @@
+// Layout conversion at the reference boundary ([B,C,X,Y,Z] <-> channels-last voxel rows),
+// the BiFuser_N prologue (K1) and stream compaction (torch.nonzero replacement).
+#include <stdarg.h>
+
+#include "common.h"
+
+// ------------------------------------------------------------------ error state
+static thread_local char g_err[512] = "";
+
+int coocc_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char* coocc_last_error(void) { return g_err; }
+extern "C" int coocc_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------ transposes
+// One block = 64 voxels x (up to) 128 channels staged through LDS so that both the
+// [C][V] side (lanes along V) and the row side (lanes along C) are coalesced.
+#define TV 64
+#define TC 128
+
+__global__ __launch_bounds__(256) void k_ncdhw_to_ndhwc(const float* __restrict__ src,
+                                                         float* __restrict__ dst, int C, int V,
+                                                         int dst_stride, int dst_coff) {
+  __shared__ float tile[TV][TC + 1];
+  const int b = blockIdx.y;
+  const int v0 = blockIdx.x * TV;
+  const int t = threadIdx.x;
+  for (int c0 = 0; c0 < C; c0 += TC) {
+    const int cn = min(TC, C - c0);
+    for (int c = t >> 6; c < cn; c += 4) {
+      int v = v0 + (t & 63);
+      tile[t & 63][c] = v < V ? src[((size_t)b * C + c0 + c) * V + v] : 0.f;
+    }
+    __syncthreads();
+    for (int i = t; i < TV * cn; i += 256) {
+      int v = i / cn, c = i - v * cn;
+      if (v0 + v < V) dst[((size_t)b * V + v0 + v) * dst_stride + dst_coff + c0 + c] = tile[v][c];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ndhwc_to_ncdhw(const float* __restrict__ src,
+                                                         float* __restrict__ dst, int C, int V,
+                                                         int src_stride, int src_coff) {
+  __shared__ float tile[TV][TC + 1];
+  const int b = blockIdx.y;
+  const int v0 = blockIdx.x * TV;
+  const int t = threadIdx.x;
+  for (int c0 = 0; c0 < C; c0 += TC) {
+    const int cn = min(TC, C - c0);
+    for (int i = t; i < TV * cn; i += 256) {
+      int v = i / cn, c = i - v * cn;
+      tile[v][c] = (v0 + v < V) ? src[((size_t)b * V + v0 + v) * src_stride + src_coff + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int c = t >> 6; c < cn; c += 4) {
+      int v = v0 + (t & 63);
+      if (v < V) dst[((size_t)b * C + c0 + c) * V + v] = tile[t & 63][c];
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int coocc_ncdhw_to_ndhwc(const float* src, float* dst, int B, int C, int V, int dst_stride,
+                                    int dst_coff, void* stream) {
+  COOCC_CHECK_ARG(src && dst && B > 0 && C > 0 && V > 0 && dst_stride >= dst_coff + C, "ncdhw_to_ndhwc: bad args");
+  dim3 grid(cdiv(V, TV), B);
+  hipLaunchKernelGGL(k_ncdhw_to_ndhwc, grid, dim3(256), 0, as_stream(stream), src, dst, C, V, dst_stride, dst_coff);
+  COOCC_LAUNCH_CHECK("k_ncdhw_to_ndhwc");
+  return COOCC_OK;
+}
+
+extern "C" int coocc_ndhwc_to_ncdhw(const float* src, float* dst, int B, int C, int V, int src_stride,
+                                    int src_coff, void* stream) {
+  COOCC_CHECK_ARG(src && dst && B > 0 && C > 0 && V > 0 && src_stride >= src_coff + C, "ndhwc_to_ncdhw: bad args");
+  dim3 grid(cdiv(V, TV), B);
+  hipLaunchKernelGGL(k_ndhwc_to_ncdhw, grid, dim3(256), 0, as_stream(stream), src, dst, C, V, src_stride, src_coff);
+  COOCC_LAUNCH_CHECK("k_ndhwc_to_ncdhw");
+  return COOCC_OK;
+}
+
+// ------------------------------------------------------------------ K1 prologue
+// bifuser_n.py:129-135 + the zero-filled halves of :164-168, fused: one read of each
+// input volume, one write of the [img|pts|0|0] rows, and the non-empty flags.
+__global__ __launch_bounds__(256) void k_fuser_prepare(const float* __restrict__ img,
+                                                        const float* __restrict__ pts,
+                                                        float* __restrict__ cat4,
+                                                        uint8_t* __restrict__ flag_img,
+                                                        uint8_t* __restrict__ flag_pts, int C, int V) {
+  __shared__ float tile[TV][TC + 1];
+  const int b = blockIdx.y;
+  const int v0 = blockIdx.x * TV;
+  const int t = threadIdx.x;
+  const int stride = 4 * C;
+  for (int mod = 0; mod < 2; ++mod) {
+    const float* src = mod ? pts : img;
+    uint8_t* flags = mod ? flag_pts : flag_img;
+    float rsum = 0.f;  // channel sum of voxel t (threads 0..63), ascending c, fp32
+    for (int c0 = 0; c0 < C; c0 += TC) {
+      const int cn = min(TC, C - c0);
+      for (int c = t >> 6; c < cn; c += 4) {
+        int v = v0 + (t & 63);
+        tile[t & 63][c] = v < V ? src[((size_t)b * C + c0 + c) * V + v] : 0.f;
+      }
+      __syncthreads();
+      if (t < TV)
+        for (int c = 0; c < cn; ++c) rsum += tile[t][c];
+      for (int i = t; i < TV * cn; i += 256) {
+        int v = i / cn, c = i - v * cn;
+        if (v0 + v < V) cat4[((size_t)b * V + v0 + v) * stride + mod * C + c0 + c] = tile[v][c];
+      }
+      __syncthreads();
+    }
+    if (t < TV && v0 + t < V) flags[(size_t)b * V + v0 + t] = rsum != 0.f ? 1 : 0;
+  }
+  // fused_feats_img / fused_feats_pts start as zeros (bifuser_n.py:164,168)
+  for (int i = t; i < TV * 2 * C; i += 256) {
+    int v = i / (2 * C), c = i - v * 2 * C;
+    if (v0 + v < V) cat4[((size_t)b * V + v0 + v) * stride + 2 * C + c] = 0.f;
+  }
+}
+
+extern "C" int coocc_fuser_prepare(const float* img, const float* pts, float* cat4, uint8_t* flag_img,
+                                   uint8_t* flag_pts, int B, int C, int V, void* stream) {
+  COOCC_CHECK_ARG(img && pts && cat4 && flag_img && flag_pts && B > 0 && C > 0 && V > 0, "fuser_prepare: bad args");
+  dim3 grid(cdiv(V, TV), B);
+  hipLaunchKernelGGL(k_fuser_prepare, grid, dim3(256), 0, as_stream(stream), img, pts, cat4, flag_img, flag_pts, C, V);
+  COOCC_LAUNCH_CHECK("k_fuser_prepare");
+  return COOCC_OK;
+}
+
+// ------------------------------------------------------------------ compaction
+#define CB 1024  // flags per block
+
+__global__ __launch_bounds__(256) void k_flag_count(const uint8_t* __restrict__ flags, int total,
+                                                     int32_t* __restrict__ blk) {
+  __shared__ int wsum[4];
+  int base = blockIdx.x * CB + threadIdx.x * 4;
+  int c = 0;
+  for (int j = 0; j < 4; ++j)
+    if (base + j < total) c += flags[base + j] != 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of nblk block counts by one block; writes total to *count
+__global__ __launch_bounds__(1024) void k_scan_blocks(int32_t* __restrict__ blk, int nblk,
+                                                       int32_t* __restrict__ count) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nblk; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = i < nblk ? blk[i] : 0;
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      int n = __shfl_up(inc, o);
+      if ((threadIdx.x & 63) >= o) inc += n;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+    int carry = carry_s;
+    if (i < nblk) blk[i] = carry + woff + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = carry_s;
+}
+
+__global__ __launch_bounds__(256) void k_flag_write(const uint8_t* __restrict__ flags, int total,
+                                                     const int32_t* __restrict__ blk,
+                                                     int32_t* __restrict__ lin) {
+  __shared__ int wsum[4];
+  int base = blockIdx.x * CB + threadIdx.x * 4;
+  int f[4], c = 0;
+  for (int j = 0; j < 4; ++j) {
+    f[j] = (base + j < total) && flags[base + j] != 0;
+    c += f[j];
+  }
+  int inc = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    int n = __shfl_up(inc, o);
+    if ((threadIdx.x & 63) >= o) inc += n;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  int off = blk[blockIdx.x] + inc - c;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
+  for (int j = 0; j < 4; ++j)
+    if (f[j]) lin[off++] = base + j;
+}
+
+extern "C" int coocc_compact_flags(const uint8_t* flags, int total, int32_t* lin, int32_t* count, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  COOCC_CHECK_ARG(flags && lin && count && ws && total > 0, "compact_flags: bad args");
+  int nblk = (int)cdiv(total, CB);
+  if (ws_bytes < sizeof(int32_t) * (size_t)nblk) return coocc_set_error(COOCC_ENOMEM, "compact_flags: workspace too small");
+  int32_t* blk = (int32_t*)ws;
+  hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, as_stream(stream), blk, nblk, count);
+  hipLaunchKernelGGL(k_flag_write, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk, lin);
+  COOCC_LAUNCH_CHECK("compact_flags");
+  return COOCC_OK;
+}
+
+__global__ void k_lin_to_coords(const int32_t* __restrict__ lin, int n, int X, int Y, int Z,
+                                float* __restrict__ xyz, int64_t* __restrict__ bxyz) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int l = lin[i];
+  int z = l % Z; l /= Z;
+  int y = l % Y; l /= Y;
+  int x = l % X; int b = l / X;
+  if (xyz) { xyz[i * 3 + 0] = (float)x; xyz[i * 3 + 1] = (float)y; xyz[i * 3 + 2] = (float)z; }
+  if (bxyz) { bxyz[i * 4 + 0] = b; bxyz[i * 4 + 1] = x; bxyz[i * 4 + 2] = y; bxyz[i * 4 + 3] = z; }
+}
+
+extern "C" int coocc_lin_to_coords(const int32_t* lin, int n, int X, int Y, int Z, float* xyz, int64_t* bxyz,
+                                   void* stream) {
+  COOCC_CHECK_ARG(lin && n >= 0 && X > 0 && Y > 0 && Z > 0, "lin_to_coords: bad args");
+  if (n == 0) return COOCC_OK;
+  hipLaunchKernelGGL(k_lin_to_coords, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), lin, n, X, Y, Z, xyz, bxyz);
+  COOCC_LAUNCH_CHECK("k_lin_to_coords");
+  return COOCC_OK;
+}

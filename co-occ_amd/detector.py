@@ -1,0 +1,105 @@
+"""``COOCC_Ray`` -- the hot path of P/coocc/detectors/coocc_ray.py between "the encoders have
+produced per-modality voxel features" and "losses / metrics" (SURVEY.md section 1):
+
+    occ_fuser (BiFuser_N) -> semantic_encoder (CustomResNet3D) -> semantic_neck (FPN3D)
+    -> pts_bbox_head (OccHead) -> inline volume-render block (sigma_head / rgb_head)
+
+Child modules are built from the same config dicts through the registries
+(coocc_ray.py:80-83, bevdepth.py:21-34) and keep the reference attribute names, so a
+reference checkpoint's ``occ_fuser.* / semantic_encoder.* / semantic_neck.* / pts_bbox_head.* /
+sigma_head.* / rgb_head.*`` entries load with ``load_state_dict(strict=False)``.  The image and
+LiDAR encoders upstream of the path are out of scope: their config entries are accepted and
+ignored, and the path is fed their outputs.
+"""
+import torch
+from torch import nn
+
+from . import registry
+from .core import to_rows
+from .registry import DETECTORS
+from .render import MLP, render_block, render_losses
+
+
+@DETECTORS.register_module()
+class COOCC_Ray(nn.Module):
+    def __init__(self, voxel_size=None, n_voxels=None, loss_cfg=None, aabb=None, near_far_range=None,
+                 N_samples=40, N_rand=4096, depth_supervise=False, use_nerf_mask=True, nerf_sample_view=3,
+                 nerf_mode='volume', squeeze_scale=4, rgb_supervise=True, nerf_density=False,
+                 rendering_test=False, disable_loss_depth=False, empty_idx=0, scale=16, white_bkgd=True,
+                 occ_fuser=None, occ_encoder_backbone=None, occ_encoder_neck=None, density_encoder=None,
+                 color_encoder=None, semantic_encoder=None, density_neck=None, color_neck=None,
+                 semantic_neck=None, loss_norm=False, use_rendering=False, loss_voxel_ce_weight=1.0,
+                 loss_voxel_sem_scal_weight=1.0, loss_voxel_geo_scal_weight=1.0, loss_voxel_lovasz_weight=1.0,
+                 test_rendering=False, img_view_transformer=None, pts_bbox_head=None, **kwargs):
+        super().__init__()
+        self.ignored_cfg_keys = sorted(kwargs)      # img_backbone, img_neck, pts_* encoders, train/test_cfg ...
+        self.empty_idx, self.scale = empty_idx, scale
+        self.voxel_size, self.n_voxels, self.aabb = voxel_size, n_voxels, aabb
+        self.near_far_range, self.N_samples, self.N_rand = near_far_range, N_samples, N_rand
+        self.white_bkgd, self.loss_norm = white_bkgd, loss_norm
+        self.use_rendering, self.test_rendering = use_rendering, test_rendering
+        self.img_view_transformer = registry.build_neck(img_view_transformer) if img_view_transformer else None
+        self.pts_bbox_head = registry.build_head(pts_bbox_head) if pts_bbox_head else None
+        self.occ_fuser = registry.build_fusion_layer(occ_fuser) if occ_fuser is not None else None
+        self.semantic_encoder = registry.build_backbone(semantic_encoder)
+        self.semantic_neck = registry.build_neck(semantic_neck)
+        if use_rendering:                                      # coocc_ray.py:111-113
+            self.sigma_head = MLP(input_dim=128, output_dim=1, net_depth=1, skip_layer=None)
+            self.rgb_head = MLP(input_dim=128, output_dim=3, net_depth=3, skip_layer=None)
+
+    def fuse(self, img_voxel_feats, pts_voxel_feats):
+        """coocc_ray.py:252-256."""
+        if self.occ_fuser is not None:
+            return self.occ_fuser(img_voxel_feats, pts_voxel_feats)
+        assert (img_voxel_feats is None) or (pts_voxel_feats is None)
+        return img_voxel_feats if pts_voxel_feats is None else pts_voxel_feats
+
+    def forward_hot_path(self, img_voxel_feats, pts_voxel_feats, gemo=None, img_feats=None, transform=None,
+                         render=None, dense_fine=True):
+        """simple_test (coocc_ray.py:520-627) minus encoders and metrics.
+
+        img_voxel_feats / pts_voxel_feats: [1,C,X,Y,Z]; gemo: [1,N,D,fH,fW,3] (get_geometry);
+        img_feats: [[1,N,512,fH,fW]]; transform: img_inputs[1:] (rots, trans, intrins, post_rots,
+        post_trans, bda, ..., (H_img, W_img))."""
+        voxel_feats = self.fuse(img_voxel_feats, pts_voxel_feats)
+        mid = self.semantic_encoder.forward_rows(voxel_feats)
+        sem = self.semantic_neck.forward_rows(mid)
+        output = self.pts_bbox_head(voxel_feats=sem, img_feats=img_feats, transform=transform)
+        res = dict(voxel_feats=voxel_feats, pred_c=output['output_voxels'][0], pred_f=None,
+                   output_voxels_fine=output['output_voxels_fine'], output_coords_fine=output['output_coords_fine'])
+        if output['output_voxels_fine'] is not None and dense_fine:
+            cf = self.pts_bbox_head.cascade_ratio
+            pc = res['pred_c']
+            size = [pc.shape[2] * cf, pc.shape[3] * cf, pc.shape[4] * cf]     # == gt_occ size (coocc_ray.py:549)
+            res['pred_f'] = self.pts_bbox_head.scatter_fine(output['output_voxels_fine'][0],
+                                                            output['output_coords_fine'][0], size)
+        do_render = (self.use_rendering and self.test_rendering) if render is None else render
+        if do_render:
+            rgbs, depths, maps = render_block(self.sigma_head, self.rgb_head, to_rows(voxel_feats), gemo, 16)
+            res.update(rgbs=rgbs, depths=depths, render_maps=maps)
+        return res
+
+    def render_losses(self, rgbs, depths, rgb_gt, depth_gt, D):
+        """coocc_ray.py:423-433."""
+        return render_losses(rgbs, depths, rgb_gt, depth_gt, D)
+
+    def simple_test(self, img_metas=None, img=None, gt_depths=None, points=None, rescale=False, points_occ=None,
+                    gt_occ=None, visible_mask=None, precomputed=None):
+        """Reference signature (coocc_ray.py:520).  The encoders are out of scope, so the
+        per-modality voxel features must be supplied via ``precomputed=dict(img_voxel_feats=...,
+        pts_voxel_feats=..., gemo=..., img_feats=...)``; ``img[1:]`` is the transform."""
+        if precomputed is None:
+            raise NotImplementedError("COOCC_Ray: image/LiDAR encoders are outside the MI355X hot path; pass precomputed=")
+        transform = img[1:] if img is not None else precomputed.get("transform")
+        out = self.forward_hot_path(precomputed["img_voxel_feats"], precomputed["pts_voxel_feats"],
+                                    precomputed.get("gemo"), precomputed.get("img_feats"), transform)
+        out.update(output_voxels=out["pred_c"], target_voxels=gt_occ)
+        return out
+
+    def forward_test(self, img_metas=None, img_inputs=None, **kwargs):
+        return self.simple_test(img_metas, img_inputs, **kwargs)
+
+    def forward(self, return_loss=False, **kwargs):
+        if return_loss:
+            raise NotImplementedError("training (losses + backward) is SURVEY.md 8f 'next', not built yet")
+        return self.forward_test(**kwargs)

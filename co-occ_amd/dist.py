@@ -1,0 +1,88 @@
+"""Multi-GPU layer.  The path shards at sample level (one scene per GPU, the
+reference's own ``samples_per_gpu=1`` data parallelism) and, for rendering, at ray level.  The
+only data-path collective is one RCCL all-gather of the packed rendered maps per step; there is
+none in the reference's eval forward, it is a requirement of the build's
+``north_star``.  One process per GPU, ``torch.distributed`` backend "nccl" (= RCCL over xGMI),
+"gloo" for the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced [lo, hi) slice of n_items for `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_maps(rgbs, depths):
+    """[N,H,W,3] + [N,H,W] -> one contiguous [N,H,W,4] buffer (a single collective per step)."""
+    return torch.cat([rgbs, depths.unsqueeze(-1)], dim=-1).contiguous()
+
+
+def unpack_maps(packed):
+    return packed[..., :3], packed[..., 3]
+
+
+def all_gather_maps(rgbs, depths):
+    """Config 4: every rank rendered its own scene; gather all ranks' maps.
+    Returns (rgbs [world,N,H,W,3], depths [world,N,H,W])."""
+    packed = pack_maps(rgbs, depths)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rgbs.unsqueeze(0), depths.unsqueeze(0)
+    world = dist.get_world_size()
+    out = torch.empty((world,) + tuple(packed.shape), device=packed.device, dtype=packed.dtype)
+    if dist.get_backend() == "gloo":
+        parts = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(parts, packed)
+        out = torch.stack(parts)
+    else:
+        dist.all_gather_into_tensor(out, packed)
+    return unpack_maps(out)
+
+
+def gather_ray_shards(local_maps, n_rows_total):
+    """Config 5 (ray-sharded render of ONE scene): each rank rendered a contiguous chunk of the
+    flattened (camera,row) space; rows are padded to the largest chunk for the collective and
+    trimmed afterwards.  local_maps [rows_local, W, 4] -> [n_rows_total, W, 4]."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_maps
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_range(n_rows_total, r, world) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((mx,) + tuple(local_maps.shape[1:]), device=local_maps.device, dtype=local_maps.dtype)
+    pad[: local_maps.shape[0]] = local_maps
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,146 @@
+"""``BiFuser_N`` (GSFusion) -- MI355X-native mirror of P/coocc/fuser/bifuser_n.py.
+
+Same registry name, constructor, ``forward`` / ``fps_NN_fast`` signatures and ``state_dict``
+keys (``con_enc.{0,1,3,4}.*``, ``knn_enc.0.*``) as the reference; all compute runs in
+libcoocc_hip.so.  Determinism rules the reference leaves open:
+top-K ties ordered by (d^2, key index); duplicate assignment = highest centre ordinal wins;
+FPS ties exactly as the reference block reduction.
+"""
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import call, ptr
+from .core import PackCache, PackedConv, Rows, conv_rows, gather_conv_rows
+from .registry import FUSION_LAYERS
+
+_I32, _F32, _I64 = torch.int32, torch.float32, torch.int64
+
+
+def _fps_nn_xyz(query_xyz, key_xyz, fps_num, radius, max_cluster_samples, dist_thresh, num):
+    """Index search on float xyz rows.  Returns int32 [num, Q] of key ordinals (-1 = none)."""
+    dev = query_xyz.device
+    Q, Nk = query_xyz.shape[0], key_xyz.shape[0]
+    if Q <= fps_num:
+        if num != 1:
+            # the reference indexes a 1-D tensor twice on this branch (bifuser_n.py:90-93)
+            raise IndexError("too many indices for tensor of dimension 1")
+        out = torch.full((1, Q), -1, device=dev, dtype=_I32)
+        if Q == 0 or Nk == 0:
+            return out
+        val = torch.empty(Q, 1, device=dev, dtype=_F32)
+        nn_ = torch.empty(Q, 1, device=dev, dtype=_I32)
+        call("coocc_knn_topk", Q, Nk, 1, ptr(query_xyz), ptr(key_xyz), ptr(val), ptr(nn_))
+        call("coocc_knn_threshold", Q, float(dist_thresh), ptr(val), ptr(nn_), ptr(out))
+        return out
+    repr_idx = torch.empty(1, fps_num, device=dev, dtype=_I32)
+    temp = torch.empty(1, Q, device=dev, dtype=_F32)
+    call("coocc_furthest_point_sampling", 1, Q, fps_num, ptr(query_xyz), ptr(temp), ptr(repr_idx))
+    repr_xyz = query_xyz[repr_idx[0].long()].contiguous()
+    val = torch.empty(fps_num, num, device=dev, dtype=_F32)
+    nn_ = torch.empty(fps_num, num, device=dev, dtype=_I32)
+    call("coocc_knn_topk", fps_num, Nk, num, ptr(repr_xyz), ptr(key_xyz), ptr(val), ptr(nn_))
+    group = torch.empty(fps_num, max_cluster_samples, device=dev, dtype=_I32)
+    # the reference recomputes this identical ball query once per k (bifuser_n.py:109)
+    call("coocc_ball_query", 1, Q, fps_num, 0.0, float(radius), max_cluster_samples, ptr(repr_xyz), ptr(query_xyz),
+         ptr(group))
+    winner = torch.empty(num, Q, device=dev, dtype=_I32)
+    out = torch.empty(num, Q, device=dev, dtype=_I32)
+    call("coocc_knn_assign", fps_num, num, max_cluster_samples, Q, float(dist_thresh), ptr(val), ptr(nn_), ptr(group),
+         ptr(winner), ptr(out))
+    return out
+
+
+@FUSION_LAYERS.register_module()
+class BiFuser_N(nn.Module):
+    def __init__(self, in_channels, out_channels, knum=1, norm_cfg=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.knum = in_channels, out_channels, knum
+        # parameter containers with the reference layout (bifuser_n.py:23-36); norm_cfg is
+        # accepted and ignored exactly as the reference does
+        self.con_enc = nn.Sequential(
+            nn.Conv3d(in_channels * 4, out_channels * 2, 3, padding=1, bias=False),
+            nn.BatchNorm3d(out_channels * 2), nn.ReLU(True),
+            nn.Conv3d(in_channels * 2, out_channels, 3, padding=1, bias=False),
+            nn.BatchNorm3d(out_channels), nn.ReLU(True))
+        self.knn_enc = nn.Sequential(nn.Linear(in_channels * knum, out_channels), nn.ReLU())
+        self._packs = PackCache()
+        self.last_counts = None
+
+    # ---------------------------------------------------------------- packing
+    def _packed(self):
+        srcs = list(self.con_enc.parameters()) + list(self.con_enc.buffers()) + list(self.knn_enc.parameters())
+
+        def build():
+            return dict(
+                c0=PackedConv(self.con_enc[0].weight, bn=self.con_enc[1], ksize=3, pad=1),
+                c3=PackedConv(self.con_enc[3].weight, bn=self.con_enc[4], ksize=3, pad=1),
+                knn=PackedConv(self.knn_enc[0].weight, bias=self.knn_enc[0].bias, tap_major=True, taps=self.knum))
+        return self._packs.get(srcs, build)
+
+    # ---------------------------------------------------------------- K2-K5
+    def fps_NN_fast(self, query, key, fps_num, radius, max_cluster_samples, dist_thresh, num):
+        """bifuser_n.py:38-125.  query [Q,4], key [Nk,4] integer (b,x,y,z) rows ->
+        int64 [Q] (num == 1) or [num,Q]; -1 where no key was assigned."""
+        q = query[:, 1:].float().contiguous()
+        k = key[:, 1:].float().contiguous()
+        out = _fps_nn_xyz(q, k, fps_num, radius, max_cluster_samples, dist_thresh, num).long()
+        return out[0] if num == 1 else out
+
+    # ---------------------------------------------------------------- forward
+    def fuse(self, img_voxel_feats, pts_voxel_feats):
+        """K1..G1: returns the [B*V, 4C] concat rows (img | pts | fused_img | fused_pts)."""
+        B, C, X, Y, Z = img_voxel_feats.shape
+        V, dev = X * Y * Z, img_voxel_feats.device
+        if not img_voxel_feats.is_cuda:
+            raise _lib.CooccError("BiFuser_N runs on the GPU only (no CPU fallback)")
+        img = img_voxel_feats.float().contiguous()
+        pts = pts_voxel_feats.float().contiguous()
+        packs = self._packed()
+        cat4 = torch.empty(B * V, 4 * C, device=dev, dtype=_F32)
+        flags = torch.empty(2, B * V, device=dev, dtype=torch.uint8)
+        call("coocc_fuser_prepare", ptr(img), ptr(pts), ptr(cat4), ptr(flags[0]), ptr(flags[1]), B, C, V)
+        lin = torch.empty(2, B * V, device=dev, dtype=_I32)
+        counts = torch.empty(2, device=dev, dtype=_I32)
+        ws = torch.empty(2, B * V // 1024 + 2, device=dev, dtype=_I32)
+        for i in range(2):
+            call("coocc_compact_flags", ptr(flags[i]), B * V, ptr(lin[i]), ptr(counts[i:i + 1]), ptr(ws[i]),
+                 ws[i].numel() * 4)
+        Ni, Np = (int(v) for v in counts.tolist())     # the one host sync of the path (torch.nonzero does two)
+        self.last_counts = (Ni, Np)
+        lin_img, lin_pts = lin[0, :Ni], lin[1, :Np]
+        xyz = torch.empty(Ni + Np, 3, device=dev, dtype=_F32)
+        if Ni:
+            call("coocc_lin_to_coords", ptr(lin_img), Ni, X, Y, Z, ptr(xyz[:Ni]), None)
+        if Np:
+            call("coocc_lin_to_coords", ptr(lin_pts), Np, X, Y, Z, ptr(xyz[Ni:]), None)
+        xyz_img, xyz_pts = xyz[:Ni], xyz[Ni:]
+        K = self.knum
+        kw = dict(fps_num=2048, radius=6, max_cluster_samples=200, dist_thresh=13.3, num=K)
+        if Np and Ni:
+            # pts queries <- nearest img keys (bifuser_n.py:137-148)
+            near_img = _fps_nn_xyz(xyz_pts, xyz_img, **kw)
+            rows = torch.empty(K, Np, device=dev, dtype=_I32)
+            for k in range(K):
+                call("coocc_index_rows_i32", ptr(lin_img), Ni, ptr(near_img[k]), Np, ptr(rows[k]))
+            gather_conv_rows(cat4, 0, packs["knn"], rows, lin_pts, cat4, 2 * C, C, C)
+            # img queries <- nearest pts keys (:150-162); for knum > 1 the reference indexes
+            # inds_img with the pts ordinals (:158) -- kept
+            near_pts = _fps_nn_xyz(xyz_img, xyz_pts, **kw)
+            rows = torch.empty(K, Ni, device=dev, dtype=_I32)
+            base, nbase = (lin_pts, Np) if K == 1 else (lin_img, Ni)
+            for k in range(K):
+                call("coocc_index_rows_i32", ptr(base), nbase, ptr(near_pts[k]), Ni, ptr(rows[k]))
+            gather_conv_rows(cat4, C, packs["knn"], rows, lin_img, cat4, 3 * C, 0, C)
+            self.last_near = (near_img, near_pts)
+        elif Np or Ni:
+            raise IndexError("BiFuser_N: one modality has no non-empty voxel (the reference fails on empty keys)")
+        return Rows(cat4, B, X, Y, Z, 4 * C), (lin_img, lin_pts)
+
+    def forward(self, img_voxel_feats, pts_voxel_feats):
+        """[B,C,X,Y,Z] x2 -> [B,out,X,Y,Z] (bifuser_n.py:127-174)."""
+        cat4, _ = self.fuse(img_voxel_feats, pts_voxel_feats)
+        packs = self._packed()
+        x = conv_rows(cat4, packs["c0"], relu=True)
+        x = conv_rows(x, packs["c3"], relu=True)
+        return x.as_ncdhw()

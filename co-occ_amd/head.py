@@ -1,0 +1,205 @@
+"""``OccHead`` forward -- mirror of P/coocc/dense_heads/occ_head.py:17-265 (losses are out
+of scope).  Same kwargs, ``forward`` signature/result dict and state_dict
+keys (``occ_convs.{i}.{0,1}.*``, ``occ_pred_conv.{0,1,3}.*``, ``voxel_soft_weights.{0,1,3}.*``,
+``img_mlp_0.*``, ``img_mlp.*``, ``fine_mlp.*``).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import call, host_i32, ptr
+from .backbone import build_bn
+from .core import PackCache, PackedConv, Rows, conv_rows, linear_rows, to_rows
+from .registry import HEADS
+
+_I32, _F32, _I64 = torch.int32, torch.float32, torch.int64
+
+
+def _conv3d(conv_cfg, cin, cout, k, pad):
+    cfg = dict(conv_cfg or dict(type='Conv3d'))
+    t = cfg.pop("type", "Conv3d")
+    if t != "Conv3d":
+        raise NotImplementedError("OccHead: conv type %r" % t)
+    return nn.Conv3d(cin, cout, kernel_size=k, stride=1, padding=pad, **cfg)
+
+
+@HEADS.register_module()
+class OccHead(nn.Module):
+    def __init__(self, in_channels, out_channel, num_level=1, num_img_level=1, soft_weights=False,
+                 loss_weight_cfg=None, conv_cfg=dict(type='Conv3d', bias=False),
+                 norm_cfg=dict(type='GN', num_groups=32, requires_grad=True), fine_topk=20000,
+                 point_cloud_range=[-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], final_occ_size=[256, 256, 20],
+                 empty_idx=0, visible_loss=False, balance_cls_weight=True, cascade_ratio=1,
+                 sample_from_voxel=False, sample_from_img=False, train_cfg=None, test_cfg=None,
+                 padding_mode='border', data_type='nus'):
+        super().__init__()
+        if type(in_channels) is not list:
+            in_channels = [in_channels]
+        if data_type != 'nus':
+            raise NotImplementedError("OccHead: only the nuScenes projection branch is implemented")
+        self.in_channels, self.out_channel, self.num_level = in_channels, out_channel, num_level
+        self.fine_topk = fine_topk
+        self.point_cloud_range = torch.tensor(np.array(point_cloud_range)).float()
+        self.final_occ_size = final_occ_size
+        self.cascade_ratio = cascade_ratio
+        self.sample_from_voxel, self.sample_from_img = sample_from_voxel, sample_from_img
+        self.padding_mode, self.data_type = padding_mode, data_type
+        self.empty_idx, self.soft_weights = empty_idx, soft_weights
+        self.num_img_level, self.num_point_sampling_feat = num_img_level, num_level
+        self.loss_weight_cfg = loss_weight_cfg
+
+        if cascade_ratio != 1 and (sample_from_voxel or sample_from_img):
+            fine_in = 128 if sample_from_voxel else 0
+            if sample_from_img:
+                self.img_mlp_0 = nn.Sequential(nn.Conv2d(512, 128, 1, 1, 0), nn.GroupNorm(16, 128), nn.ReLU(inplace=True))
+                self.img_mlp = nn.Sequential(nn.Linear(128, 64), nn.GroupNorm(16, 64), nn.ReLU(inplace=True))
+                fine_in += 64
+            self.fine_mlp = nn.Sequential(nn.Linear(fine_in, 64), nn.GroupNorm(16, 64), nn.ReLU(inplace=True),
+                                          nn.Linear(64, out_channel))
+        self.occ_convs = nn.ModuleList()
+        for i in range(num_level):
+            mid = in_channels[i] // 2
+            self.occ_convs.append(nn.Sequential(_conv3d(conv_cfg, in_channels[i], mid, 3, 1), build_bn(norm_cfg, mid),
+                                                nn.ReLU(inplace=True)))
+        self.occ_pred_conv = nn.Sequential(_conv3d(conv_cfg, mid, mid // 2, 1, 0), build_bn(norm_cfg, mid // 2),
+                                           nn.ReLU(inplace=True), _conv3d(conv_cfg, mid // 2, out_channel, 1, 0))
+        if soft_weights:
+            self.voxel_soft_weights = nn.Sequential(_conv3d(conv_cfg, mid, mid // 2, 1, 0), build_bn(norm_cfg, mid // 2),
+                                                    nn.ReLU(inplace=True), _conv3d(conv_cfg, mid // 2, num_level, 1, 0))
+        self._packs = PackCache()
+
+    # ---------------------------------------------------------------- packing
+    def _packed(self):
+        srcs = list(self.parameters()) + list(self.buffers())
+
+        def seq2(m):
+            return (PackedConv(m[0].weight, bn=m[1], bias=m[0].bias, ksize=1),
+                    PackedConv(m[3].weight, bias=m[3].bias, ksize=1))
+
+        def build():
+            d = dict(occ=[PackedConv(m[0].weight, bn=m[1], bias=m[0].bias, ksize=3, pad=1) for m in self.occ_convs],
+                     pred=seq2(self.occ_pred_conv))
+            if self.soft_weights:
+                d["soft"] = seq2(self.voxel_soft_weights)
+            if hasattr(self, "fine_mlp"):
+                d["fine0"] = PackedConv(self.fine_mlp[0].weight, bias=self.fine_mlp[0].bias)
+                d["fine3"] = PackedConv(self.fine_mlp[3].weight, bias=self.fine_mlp[3].bias)
+            if hasattr(self, "img_mlp"):
+                d["img0"] = PackedConv(self.img_mlp_0[0].weight.flatten(1), bias=self.img_mlp_0[0].bias)
+                d["img"] = PackedConv(self.img_mlp[0].weight, bias=self.img_mlp[0].bias)
+            return d
+        return self._packs.get(srcs, build)
+
+    # ---------------------------------------------------------------- C3
+    def forward_coarse_rows(self, voxel_feats):
+        """occ_head.py:149-171 on Rows: returns (out_voxel_feats Rows, occ logits Rows)."""
+        p = self._packed()
+        occs = [conv_rows(to_rows(f), p["occ"][i], relu=True) for i, f in enumerate(voxel_feats)]
+        o0 = occs[0]
+        wlogit = None
+        if self.soft_weights:
+            h = conv_rows(o0, p["soft"][0], relu=True)
+            wlogit = conv_rows(h, p["soft"][1], relu=False).t
+        L = len(occs)
+        levels = (_lib.c_void_p * L)(*[o.t.data_ptr() for o in occs])
+        dims = host_i32([v for o in occs for v in (o.X, o.Y, o.Z)])
+        out = Rows(torch.empty_like(o0.t), o0.B, o0.X, o0.Y, o0.Z, o0.C)
+        call("coocc_occhead_mix", levels, dims, L, ptr(wlogit), ptr(out.t), o0.B, o0.C)
+        h = conv_rows(out, p["pred"][0], relu=True)
+        occ = conv_rows(h, p["pred"][1], relu=False)
+        return out, occ
+
+    def forward_coarse_voxel(self, voxel_feats):
+        out, occ = self.forward_coarse_rows(voxel_feats)
+        return {'out_voxel_feats': [out.as_ncdhw()], 'occ': [occ.as_ncdhw()]}
+
+    # ---------------------------------------------------------------- C4
+    def _fine(self, ovf, occ, img_feats, transform):
+        """occ_head.py:180-237, eval branch, B == 1."""
+        p = self._packed()
+        dev = ovf.t.device
+        V, r = ovf.V, self.cascade_ratio
+        assert ovf.B == 1, "OccHead fine branch: B == 1 (as the render block asserts, coocc_ray.py:571)"
+        flags = torch.empty(V, device=dev, dtype=torch.uint8)
+        call("coocc_argmax_flags", ptr(occ.t), V, occ.C, occ.stride, self.empty_idx, ptr(flags))
+        lin = torch.empty(V, device=dev, dtype=_I32)
+        cnt = torch.empty(1, device=dev, dtype=_I32)
+        ws = torch.empty(V // 1024 + 2, device=dev, dtype=_I32)
+        call("coocc_compact_flags", ptr(flags), V, ptr(lin), ptr(cnt), ptr(ws), ws.numel() * 4)
+        n = int(cnt.item())
+        assert n > 0, 'no foreground in coarse voxel'
+        nf = n * r ** 3
+        fine_xyz = torch.empty(3, nf, device=dev, dtype=_I64)
+        cvox = 128 if self.sample_from_voxel else 0
+        cat = torch.empty(nf, cvox + (64 if self.sample_from_img and img_feats is not None else 0), device=dev, dtype=_F32)
+        vox_feat = cat if self.sample_from_voxel else torch.empty(nf, ovf.C, device=dev, dtype=_F32)
+        # fine coordinates are always produced by this kernel (they are an output of the head)
+        call("coocc_fine_sample_voxel", ptr(ovf.t), ovf.C, ovf.X, ovf.Y, ovf.Z, ptr(lin), n, r,
+             host_i32(self.final_occ_size), ptr(fine_xyz), ptr(vox_feat), vox_feat.shape[1])
+        if self.sample_from_img and img_feats is not None:
+            f = img_feats[0]                                    # [B,N,512,fH,fW]
+            _, N_i, C_i, Hf, Wf = f.shape
+            rows = torch.empty(N_i * Hf * Wf, C_i, device=dev, dtype=_F32)
+            call("coocc_ncdhw_to_ndhwc", ptr(f[0].float().contiguous()), ptr(rows), N_i, C_i, Hf * Wf, C_i, 0)
+            g = linear_rows(rows, p["img0"])                    # Conv2d 1x1 (occ_head.py:64)
+            gn = self.img_mlp_0[1]
+            call("coocc_groupnorm_nhwc", ptr(g), N_i, Hf * Wf, g.shape[1], gn.num_groups, ptr(gn.weight.detach()),
+                 ptr(gn.bias.detach()), float(gn.eps), 1)
+            params = self._projection_params(transform, ovf, dev)
+            samp = torch.empty(nf, g.shape[1], device=dev, dtype=_F32)
+            call("coocc_fine_sample_img", ptr(g), N_i, g.shape[1], Hf, Wf, ptr(params), ptr(fine_xyz), nf, ptr(samp),
+                 samp.shape[1])
+            linear_rows(samp, p["img"], out=cat, out_coff=cvox)
+            gn = self.img_mlp[1]
+            sub = cat[:, cvox:]
+            call("coocc_groupnorm_rows", _lib.c_void_p(sub.data_ptr()), nf, 64, cat.shape[1], gn.num_groups,
+                 ptr(gn.weight.detach()), ptr(gn.bias.detach()), float(gn.eps), 1)
+        h = linear_rows(cat, p["fine0"])
+        gn = self.fine_mlp[1]
+        call("coocc_groupnorm_rows", ptr(h), nf, h.shape[1], h.shape[1], gn.num_groups, ptr(gn.weight.detach()),
+             ptr(gn.bias.detach()), float(gn.eps), 1)
+        return linear_rows(h, p["fine3"]), fine_xyz
+
+    def _projection_params(self, transform, ovf, dev):
+        """Per-sample matrices of project_points_on_img (coordinate_transform.py:25-65), b = 0."""
+        rots, trans, intrins, post_rots, post_trans, bda = [t[0].float() for t in transform[:6]]
+        r = self.cascade_ratio
+        W_occ, H_occ, D_occ = ovf.X * r, ovf.Y * r, ovf.Z * r
+        pr = self.point_cloud_range.to(dev)
+        voxel_size = (pr[3:] - pr[:3]) / torch.tensor([W_occ - 1, H_occ - 1, D_occ - 1], device=dev)
+        W_img = float(transform[-1][1][0]) if torch.is_tensor(transform[-1][1]) else float(transform[-1][1])
+        H_img = float(transform[-1][0][0]) if torch.is_tensor(transform[-1][0]) else float(transform[-1][0])
+        hdr = torch.cat([bda.inverse().reshape(-1), voxel_size, pr[:3],
+                         torch.tensor([W_img - 1, H_img - 1], device=dev, dtype=_F32)])
+        cams = torch.cat([rots.inverse().reshape(-1, 9), trans.reshape(-1, 3), intrins.reshape(-1, 9),
+                          post_rots[:, :2, :2].reshape(-1, 4), post_trans[:, :2].reshape(-1, 2)], 1)
+        return torch.cat([hdr, cams.reshape(-1)]).contiguous()
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, voxel_feats, img_feats=None, img_metas=None, pts_feats=None, target_points=None,
+                transform=None, **kwargs):
+        assert type(voxel_feats) is list and len(voxel_feats) == self.num_level
+        if self.training:
+            raise NotImplementedError("OccHead training branch (random top-k + losses) is out of scope (SURVEY 8f)")
+        if target_points:
+            raise NotImplementedError("forward_lidarseg is not on the hot path")
+        ovf, occ = self.forward_coarse_rows(voxel_feats)
+        res = {'output_voxels': [occ.as_ncdhw()], 'output_voxels_fine': None, 'output_coords_fine': None,
+               'output_points': None}
+        if self.cascade_ratio != 1 and (self.sample_from_img or self.sample_from_voxel):
+            fine, xyz = self._fine(ovf, occ, img_feats, transform)
+            res['output_voxels_fine'], res['output_coords_fine'] = [fine], [xyz]
+        self.last_out_voxel_feats = ovf
+        return res
+
+    def scatter_fine(self, fine_pred, fine_coord, out_size):
+        """``pred_f`` of simple_test (coocc_ray.py:546-550): [1,ncls,Xf,Yf,Zf]."""
+        ncls = fine_pred.shape[1]
+        grid = torch.empty(1, ncls, *out_size, device=fine_pred.device, dtype=_F32)
+        call("coocc_scatter_fine", ptr(fine_pred), fine_pred.shape[0], ncls, fine_pred.shape[1], ptr(fine_coord), ptr(grid),
+             out_size[0], out_size[1], out_size[2], float(self.empty_idx))
+        return grid
+
+    def loss(self, *a, **k):
+        raise NotImplementedError("OccHead.loss is out of scope for the forward hot path (SURVEY.md 8a)")

@@ -1,0 +1,62 @@
+"""``FPN3D`` -- mirror of P/coocc/necks/fpn3d.py.  Same kwargs / forward / state_dict keys
+(``lateral_convs.{i}.0.{conv,bn}.*``, ``fpn_convs.{i}.0.{conv,bn}.*``).  1x1x1 laterals and
+3x3x3 output convs are implicit-GEMM launches; the top-down path is one fused
+trilinear-upsample-add kernel per level (fpn3d.py:88-92).
+"""
+from torch import nn
+
+from ._lib import call, ptr
+from .backbone import build_bn
+from .core import PackCache, PackedConv, conv_rows, to_rows
+from .registry import NECKS
+
+
+class ConvModule(nn.Module):
+    """Parameter container with mmcv ConvModule's attribute names (conv, bn, activate)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, padding=0, norm_cfg=None, bias=False):
+        super().__init__()
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, padding=padding, bias=bias)
+        self.bn = build_bn(norm_cfg, out_channels)
+        self.activate = nn.ReLU(inplace=True)
+
+
+@NECKS.register_module()
+class FPN3D(nn.Module):
+    def __init__(self, in_channels=[80, 160, 320, 640], out_channels=256,
+                 norm_cfg=dict(type='GN', num_groups=32, requires_grad=True), conv_cfg=dict(type='Conv3d'),
+                 act_cfg=dict(type='ReLU'), with_cp=False, upsample_cfg=dict(mode='trilinear'), init_cfg=None):
+        super().__init__()
+        if upsample_cfg.get("mode", "trilinear") != "trilinear":
+            raise NotImplementedError("FPN3D: only trilinear upsampling is implemented")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.with_cp, self.upsample_cfg, self.fp16_enabled = with_cp, upsample_cfg, False
+        self.num_out = len(in_channels)
+        self.lateral_convs = nn.ModuleList()
+        self.fpn_convs = nn.ModuleList()
+        for i in range(self.num_out):
+            self.lateral_convs.append(nn.Sequential(ConvModule(in_channels[i], out_channels, 1, 0, norm_cfg)))
+            self.fpn_convs.append(nn.Sequential(ConvModule(out_channels, out_channels, 3, 1, norm_cfg)))
+        self._packs = PackCache()
+
+    def _packed(self):
+        srcs = list(self.parameters()) + list(self.buffers())
+
+        def build():
+            return dict(
+                lat=[PackedConv(m[0].conv.weight, bn=m[0].bn, bias=m[0].conv.bias, ksize=1) for m in self.lateral_convs],
+                out=[PackedConv(m[0].conv.weight, bn=m[0].bn, bias=m[0].conv.bias, ksize=3, pad=1) for m in self.fpn_convs])
+        return self._packs.get(srcs, build)
+
+    def forward_rows(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        p = self._packed()
+        lat = [conv_rows(to_rows(x), p["lat"][i], relu=True) for i, x in enumerate(inputs)]
+        for i in range(self.num_out - 1, 0, -1):
+            c, f = lat[i], lat[i - 1]
+            call("coocc_upsample_add_trilinear", ptr(c.t), ptr(f.t), f.B, f.C, c.X, c.Y, c.Z, f.X, f.Y, f.Z)
+        return [conv_rows(x, p["out"][i], relu=True) for i, x in enumerate(lat)]
+
+    def forward(self, inputs):
+        """list of [B,C_i,...] -> list of [B,out,...] (fpn3d.py:70-108)."""
+        return [r.as_ncdhw() for r in self.forward_rows(inputs)]

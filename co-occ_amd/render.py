@@ -1,0 +1,150 @@
+"""Volume-rendering regulariser (R1-R3, L1): ``MLP`` (P/utils/nerf_mlp.py:14-105), the inline
+render block of ``COOCC_Ray`` (coocc_ray.py:570-627) and the library functions
+``volume_sampling`` / ``raw2outputs`` / ``sample_along_camera_ray`` (P/utils/render_ray.py).
+"""
+import torch
+from torch import nn
+
+from ._lib import call, host_f32, ptr
+from .core import PackCache, PackedConv, Rows, linear_rows
+
+_F32 = torch.float32
+RENDER_BOUNDS = [-50., 50., 1., -50., 50., 1., -5., 3., 1.0]     # hard-coded at coocc_ray.py:577
+
+
+class SinusoidalEncoder(nn.Module):
+    """Only its ``scales`` buffer matters (state_dict key ``posi_encoder.scales``)."""
+
+    def __init__(self, x_dim, min_deg, max_deg, use_identity=True):
+        super().__init__()
+        self.register_buffer("scales", torch.tensor([2 ** i for i in range(min_deg, max_deg)]))
+
+
+class MLP(nn.Module):
+    """nerf_mlp.py:14-105 with the hyper-parameters COOCC_Ray uses (skip_layer=None, ReLU,
+    xavier init, zero bias).  ``forward`` accepts [..., input_dim] HIP tensors."""
+
+    def __init__(self, input_dim, output_dim=None, net_depth=8, net_width=256, skip_layer=4, **kwargs):
+        super().__init__()
+        if skip_layer is not None:
+            raise NotImplementedError("MLP skip connections are never instantiated on the Co-Occ path")
+        self.input_dim, self.output_dim, self.net_depth, self.net_width = input_dim, output_dim, net_depth, net_width
+        self.hidden_layers = nn.ModuleList()
+        self.posi_encoder = SinusoidalEncoder(3, 0, 10, True)
+        in_features = input_dim
+        for _ in range(net_depth):
+            self.hidden_layers.append(nn.Linear(in_features, net_width))
+            in_features = net_width
+        self.output_layer = nn.Linear(in_features, output_dim)
+        for m in list(self.hidden_layers) + [self.output_layer]:
+            nn.init.xavier_uniform_(m.weight)
+            nn.init.zeros_(m.bias)
+        self._packs = PackCache()
+
+    def _packed(self):
+        def build():
+            return [PackedConv(l.weight, bias=l.bias) for l in list(self.hidden_layers) + [self.output_layer]]
+        return self._packs.get(list(self.parameters()), build)
+
+    def forward_rows(self, x2d, out=None, out_coff=0):
+        p = self._packed()
+        for pc in p[:-1]:
+            x2d = linear_rows(x2d, pc, relu=True)
+        return linear_rows(x2d, p[-1], relu=False, out=out, out_coff=out_coff)
+
+    def forward(self, x):
+        shp = x.shape
+        y = self.forward_rows(x.reshape(-1, shp[-1]).float().contiguous())
+        return y.view(*shp[:-1], self.output_dim)
+
+
+def voxel_table(sigma_head, rgb_head, vf):
+    """R1 per voxel: [V,4] = (sigma_head(f), rgb_head(f)) raw outputs (pointwise heads, F5)."""
+    V = vf.t.shape[0]
+    table = torch.empty(V, 4, device=vf.t.device, dtype=_F32)
+    x = vf.t if (vf.coff == 0 and vf.stride == vf.C) else vf.t[:, vf.coff:vf.coff + vf.C].contiguous()
+    sigma_head.forward_rows(x, out=table, out_coff=0)
+    rgb_head.forward_rows(x, out=table, out_coff=1)
+    return table
+
+
+def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16):
+    """coocc_ray.py:570-627: voxel_feats Rows/[1,C,X,Y,Z], gemo [1,N,D,H,W,3] ->
+    rgbs [N,16H,16W,3], depths [N,16H,16W] (+ the pre-upsample maps [N,H,W,4])."""
+    from .core import to_rows
+    vf = to_rows(voxel_feats)
+    B, N, D, H, W, _ = gemo.shape
+    assert B == 1 and vf.B == 1
+    table = voxel_table(sigma_head, rgb_head, vf)
+    g = gemo.reshape(N, D, H, W, 3).float().contiguous()
+    dev = g.device
+    zvals = torch.linspace(0, D, D, device=dev)
+    maps = torch.empty(N, H, W, 4, device=dev, dtype=_F32)
+    call("coocc_render_nearest", ptr(table), vf.X, vf.Y, vf.Z, ptr(g), ptr(zvals), N, D, H, W, host_f32(RENDER_BOUNDS),
+         ptr(maps))
+    rgbs = torch.empty(N, H * scale, W * scale, 3, device=dev, dtype=_F32)
+    depths = torch.empty(N, H * scale, W * scale, device=dev, dtype=_F32)
+    call("coocc_upsample_maps", ptr(maps), N, H, W, scale, ptr(rgbs), ptr(depths))
+    return rgbs, depths, maps
+
+
+def render_losses(rgbs, depths, rgb_gt, depth_gt, D):
+    """coocc_ray.py:423-433 -> dict(loss_depth_render, loss_rgb) (forward values)."""
+    out = torch.empty(2, device=rgbs.device, dtype=_F32)
+    call("coocc_render_losses", ptr(rgbs.contiguous()), ptr(depths.contiguous()), ptr(rgb_gt.float().contiguous()),
+         ptr(depth_gt.float().contiguous()), depths.numel(), int(D), ptr(out))
+    return dict(loss_depth_render=out[0], loss_rgb=out[1])
+
+
+def volume_sampling(sample_pts, features, aabb):
+    """render_ray.py:28-48: features [1,C,D,W,H], sample_pts [N_rays,N_samples,3] ->
+    ([N_rays,N_samples,C], mask [N_rays,N_samples])."""
+    from .core import to_rows
+    B, C, d0, d1, d2 = features.shape
+    assert B == 1
+    vol = to_rows(features)
+    nr, ns, _ = sample_pts.shape
+    pts = sample_pts.reshape(-1, 3).float().contiguous()
+    feat = torch.empty(nr * ns, C, device=pts.device, dtype=_F32)
+    mask = torch.empty(nr * ns, device=pts.device, dtype=torch.uint8)
+    a = [float(v) for v in aabb[0]] + [float(v) for v in aabb[1]]
+    call("coocc_volume_sampling", ptr(vol.t), C, d0, d1, d2, ptr(pts), nr * ns, host_f32(a), ptr(feat), ptr(mask))
+    return feat.view(nr, ns, C), mask.view(nr, ns).bool()
+
+
+def sample_along_camera_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform=False, det=False):
+    """render_ray.py:147-191 (host-side torch: [N_rays, N_samples] arithmetic, no kernel needed)."""
+    near, far = depth_range
+    assert near > 0 and far > 0 and far > near
+    near_d = near * torch.ones_like(ray_d[..., 0])
+    far_d = far * torch.ones_like(ray_d[..., 0])
+    if inv_uniform:
+        start = 1. / near_d
+        step = (1. / far_d - start) / (N_samples - 1)
+        z_vals = 1. / torch.stack([start + i * step for i in range(N_samples)], dim=1)
+    else:
+        step = (far_d - near_d) / (N_samples - 1)
+        z_vals = torch.stack([near_d + i * step for i in range(N_samples)], dim=1)
+    if not det:
+        mids = .5 * (z_vals[:, 1:] + z_vals[:, :-1])
+        upper = torch.cat([mids, z_vals[:, -1:]], dim=-1)
+        lower = torch.cat([z_vals[:, 0:1], mids], dim=-1)
+        z_vals = lower + (upper - lower) * torch.rand_like(z_vals)
+    pts = z_vals.unsqueeze(2) * ray_d.unsqueeze(1) + ray_o.unsqueeze(1)
+    return pts, z_vals
+
+
+def raw2outputs(raw, z_vals, mask=None, white_bkgd=False):
+    """render_ray.py:198-249 -> dict(rgb, depth, weights, mask, z_vals)."""
+    R, S, _ = raw.shape
+    raw = raw.float().contiguous()
+    z = z_vals.float().contiguous()
+    dev = raw.device
+    rgb = torch.empty(R, 3, device=dev, dtype=_F32)
+    depth = torch.empty(R, device=dev, dtype=_F32)
+    weights = torch.empty(R, S, device=dev, dtype=_F32)
+    zmin, zmax = (float(z.min()), float(z.max())) if R else (0.0, 0.0)
+    call("coocc_raw2outputs", ptr(raw), ptr(z), R, S, int(white_bkgd), zmin, zmax, ptr(rgb), ptr(depth), ptr(weights))
+    if mask is not None:
+        mask = mask.float().sum(dim=1) > 8
+    return dict(rgb=rgb, depth=depth, weights=weights, mask=mask, z_vals=z_vals)

@@ -1,0 +1,233 @@
+/*
+ * coocc_hip.h -- C ABI of libcoocc_hip.so, the MI355X (gfx950) implementation of
+ * Co-Occ's fused-voxel hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all
+ *     work is enqueued on it and nothing synchronises unless stated;
+ *   - functions return 0 on success, a negative COOCC_E* code otherwise and never
+ *     exit() (the reference launchers do: ball_query_cuda.cu:73-77);
+ *     coocc_last_error() returns the message of the last failure on this thread;
+ *   - dense voxel volumes inside the library are channels-last ("NDHWC": rows of
+ *     `stride` floats, one row per voxel, voxel order (b,x,y,z)); the reference's
+ *     [B,C,X,Y,Z] layout is converted once at the boundary;
+ *   - "P/" = projects/mmdet3d_plugin/, "M/" = mmdetection3d/mmdet3d/ in the reference.
+ *
+ * The three reference pybind11 extension entry points this library replaces one to
+ * one are marked [EXT]; the remaining entry points replace ATen op sequences of the
+ * reference's Python modules (file:line given per function).
+ */
+#ifndef COOCC_HIP_H
+#define COOCC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COOCC_OK 0
+#define COOCC_EINVAL (-1)  /* bad argument */
+#define COOCC_EHIP (-2)    /* HIP runtime / launch failure */
+#define COOCC_ENOMEM (-3)  /* workspace too small */
+
+const char* coocc_last_error(void);
+int coocc_abi_version(void);
+
+/* ---------------------------------------------------------------- layout / K1 */
+
+/* [B,C,V] (reference NCDHW, V = X*Y*Z) -> rows of `dst_stride` floats at channel
+ * offset `dst_coff` (NDHWC).  Replaces the permute() views of bifuser_n.py:133. */
+int coocc_ncdhw_to_ndhwc(const float* src, float* dst, int B, int C, int V, int dst_stride,
+                         int dst_coff, void* stream);
+/* inverse: NDHWC rows -> [B,C,V] */
+int coocc_ndhwc_to_ncdhw(const float* src, float* dst, int B, int C, int V, int src_stride,
+                         int src_coff, void* stream);
+
+/* BiFuser_N.forward prologue (bifuser_n.py:129-135) in one pass: reads both
+ * [B,C,V] volumes, writes the 4C concat rows [img | pts | 0 | 0] (the zero halves are
+ * the fused_feats_* zero-fills of :164-168) and per-voxel non-empty flags
+ * (feats.sum(1) != 0, channels summed in ascending order in fp32). */
+int coocc_fuser_prepare(const float* img, const float* pts, float* cat4, uint8_t* flag_img,
+                        uint8_t* flag_pts, int B, int C, int V, void* stream);
+
+/* torch.nonzero on a flag volume (bifuser_n.py:130-131): ascending linear voxel ids
+ * (== lexicographic (b,x,y,z)).  lin:[n<=total] i32, count: 1 i32.  ws: >= 4*(total/1024+2) bytes. */
+int coocc_compact_flags(const uint8_t* flags, int total, int32_t* lin, int32_t* count, void* ws,
+                        size_t ws_bytes, void* stream);
+/* lin -> float xyz rows [n,3] and/or int64 (b,x,y,z) rows [n,4] (either may be NULL) */
+int coocc_lin_to_coords(const int32_t* lin, int n, int X, int Y, int Z, float* xyz, int64_t* bxyz,
+                        void* stream);
+
+/* ---------------------------------------------------------------- K2..K5 */
+
+/* [EXT] furthest_point_sampling_wrapper (M/ops/furthest_point_sample/src/
+ * furthest_point_sample.cpp:35-46; kernel furthest_point_sample_cuda.cu:25-141).
+ * points:[b,n,3] f32, temp:[b,n] f32 scratch (initialised to 1e10 here, as
+ * furthest_point_sample.py:29 does), idx:[b,m] i32.  Ties resolve exactly as the
+ * reference block reduction does (block = min(2^floor(log2 n),1024)). */
+int coocc_furthest_point_sampling(int b, int n, int m, const float* points, float* temp,
+                                  int32_t* idx, void* stream);
+
+/* [EXT] ball_query_wrapper (M/ops/ball_query/src/ball_query.cpp:32-45; kernel
+ * ball_query_cuda.cu:11-54).  new_xyz:[b,m,3] centres, xyz:[b,n,3], idx:[b,m,nsample]
+ * i32 (zeroed here, as ball_query.py:35 does). */
+int coocc_ball_query(int b, int n, int m, float min_radius, float max_radius, int nsample,
+                     const float* new_xyz, const float* xyz, int32_t* idx, void* stream);
+
+/* norm + topk(largest=False) of bifuser_n.py:101-103 without the [nq,nk,3] temporary;
+ * ties ordered by (d^2, key index).  q:[nq,3], key:[nk,3]; val:[nq,K] f32 (= sqrt d^2),
+ * idx:[nq,K] i32.  1 <= K <= 8, K <= nk. */
+int coocc_knn_topk(int nq, int nk, int K, const float* q, const float* key, float* val,
+                   int32_t* idx, void* stream);
+
+/* assignment of bifuser_n.py:104-125 (K==1: :73-85): highest valid centre ordinal wins.
+ * val,nn:[nc,K]; group:[nc,ns]; winner:[K,nq] i32 scratch; out:[K,nq] i32 (-1 = none). */
+int coocc_knn_assign(int nc, int K, int ns, int nq, float dist_thresh, const float* val,
+                     const int32_t* nn, const int32_t* group, int32_t* winner, int32_t* out,
+                     void* stream);
+/* small path (Q <= fps_num, K == 1; bifuser_n.py:54-60): out[q] = val<thresh ? nn : -1 */
+int coocc_knn_threshold(int nq, float dist_thresh, const float* val, const int32_t* nn,
+                        int32_t* out, void* stream);
+/* rows = base[sel[i]] (sel < 0 wraps like Python indexing: bifuser_n.py:139-144) */
+int coocc_index_rows_i32(const int32_t* base, int nbase, const int32_t* sel, int n, int32_t* rows,
+                         void* stream);
+
+/* ---------------------------------------------------------------- G1, C0..C3 (implicit GEMM) */
+
+/* Pack a conv / linear weight for coocc_conv_fwd.  w_host layout [Cout][Cin][taps]
+ * (nn.Conv3d weight flattened; nn.Linear(C*K,C) viewed as [Cout][K][C] must be passed
+ * as taps-major via `tap_major=1`: [Cout][taps][Cin]).  Returns required float count
+ * when packed == NULL. */
+int64_t coocc_conv_pack_weights(const float* w_host, int Cout, int Cin, int taps, int tap_major,
+                                float* packed_host);
+
+typedef struct coocc_conv_desc {
+  const float* in;        /* input rows (NDHWC or a row table), already offset to channel 0 */
+  const float* w;         /* packed weights (device) */
+  float* out;
+  const float* scale;     /* [Cout] or NULL (folded eval-mode BN scale) */
+  const float* bias;      /* [Cout] or NULL */
+  const float* res;       /* residual rows (res_mode 1: add before ReLU; 2: multiply after) */
+  const int32_t* gather;  /* NULL: geometric taps; else [taps][M] input row ids */
+  const int32_t* out_rows;/* NULL: identity; else [M] output (and res) row ids */
+  float* ws;              /* split-K workspace or NULL */
+  int64_t ws_floats;      /* capacity of ws in floats (split-K needs splitk*M*roundup(Cout,128)) */
+  int M, Cin, Cout, taps;
+  int in_stride, out_stride, res_stride;
+  int B, Xi, Yi, Zi, Xo, Yo, Zo, ksize, stride, pad;
+  int relu, res_mode;
+  int splitk;             /* 0 = choose automatically */
+} coocc_conv_desc;
+
+/* nn.Conv3d(k=3|1)+BN(eval)+ReLU(+residual) (bifuser_n.py:23-30, resnet3d.py:34-64,
+ * fpn3d.py:46-64, occ_head.py:102-132), nn.Linear (+ReLU) and the gather->knn_enc->gate
+ * ->scatter of bifuser_n.py:138-169 as one fp32-MFMA implicit-GEMM kernel family. */
+int coocc_conv_fwd(const coocc_conv_desc* d, void* stream);
+
+/* FPN3D top-down step (fpn3d.py:88-92): fine += trilinear(coarse -> fine size),
+ * align_corners=False.  Rows NDHWC with C channels. */
+int coocc_upsample_add_trilinear(const float* coarse, float* fine, int B, int C, int Xc, int Yc,
+                                 int Zc, int Xf, int Yf, int Zf, void* stream);
+
+/* OccHead.forward_coarse_voxel mix (occ_head.py:155-166): out = sum_l softmax(wlogit)[l] *
+ * trilinear(level_l -> level-0 size).  levels: up to 4 NDHWC volumes. */
+int coocc_occhead_mix(const float* const* levels_host, const int* dims_host /*[L][3]*/, int L,
+                      const float* wlogit /*[V0,L]*/, float* out, int B, int C, void* stream);
+
+/* ---------------------------------------------------------------- C4 fine branch */
+/* coarse_occ.argmax(1) != empty_idx over [V] rows of `stride` floats (occ_head.py:182) */
+int coocc_argmax_flags(const float* logits, int V, int ncls, int stride, int empty_idx,
+                       uint8_t* flags, void* stream);
+/* coarse_to_fine_coordinates (P/utils/coordinate_transform.py:3-21, eval branch) + trilinear
+ * grid_sample(align_corners=False, zeros) of out_voxel_feats (occ_head.py:205-214), B == 1.
+ * coarse_lin:[n] voxel rows; fine_xyz:[3, r^3*n] i64 (offset-major); feat rows
+ * [r^3*n, out_stride] (first C columns written). */
+int coocc_fine_sample_voxel(const float* vol, int C, int X, int Y, int Z, const int32_t* coarse_lin,
+                            int n, int ratio, const int* final_size_host, int64_t* fine_xyz,
+                            float* feat, int out_stride, void* stream);
+/* project_points_on_img + per-camera bilinear grid_sample(align_corners=True, zeros) * mask,
+ * summed over cameras (coordinate_transform.py:25-65, occ_head.py:217-234).  img_nhwc:
+ * [ncam,Hf,Wf,Ci]; params (device): [0:9] inv(bda), [9:12] voxel_size, [12:15] range_lo,
+ * [15] W_img-1, [16] H_img-1, then per camera 27 floats: inv(rots)[9], trans[3], intrins[9],
+ * post_rots[:2,:2][4], post_trans[:2][2]. */
+int coocc_fine_sample_img(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf,
+                          const float* params, const int64_t* fine_xyz, int64_t nfine, float* feat,
+                          int out_stride, void* stream);
+/* nn.GroupNorm on 2-D rows [n,C] (+ReLU), in place (occ_head.py:70-83) */
+int coocc_groupnorm_rows(float* x, int64_t n, int C, int stride, int groups, const float* gamma,
+                         const float* beta, float eps, int relu, void* stream);
+/* nn.GroupNorm on an NHWC image batch [N,HW,C] (+ReLU), in place (occ_head.py:64-68) */
+int coocc_groupnorm_nhwc(float* x, int N, int HW, int C, int groups, const float* gamma,
+                         const float* beta, float eps, int relu, void* stream);
+/* dense fine grid of simple_test (P/coocc/detectors/coocc_ray.py:546-550):
+ * grid [ncls,Xf,Yf,Zf] = empty_val, then fine logits scattered at fine_xyz. */
+int coocc_scatter_fine(const float* fine_logits, int64_t nfine, int ncls, int stride,
+                       const int64_t* fine_xyz, float* grid, int Xf, int Yf, int Zf, float empty_val,
+                       void* stream);
+
+/* ---------------------------------------------------------------- P1, P2 */
+/* get_geometry (P/coocc/image2bev/ViewTransformerLSSBEVDepth.py:117-150).
+ * mats:[B*N][33] = inv(post_rots)(9), post_trans(3), rots@inv(intrins)(9), trans(3), bda(9);
+ * xs:[fW], ys:[fH], ds:[D] frustum axes of create_frustum (:104-115).  geom:[B*N,D,fH,fW,3]. */
+int coocc_get_geometry(const float* mats, const float* xs, const float* ys, const float* ds, int BN,
+                       int D, int fH, int fW, float* geom, void* stream);
+
+/* [EXT] bev_pool_forward (M/ops/bev_pool/src/bev_pool.cpp:22-47; kernel
+ * bev_pool_cuda.cu:20-42).  x:[n,c] rank-sorted rows, geom:[n,4] (x,y,z,b) i32,
+ * out:[b,d,h,w,c] (zeroed here). */
+int coocc_bev_pool_forward(const float* x, const int32_t* geom, const int32_t* interval_lengths,
+                           const int32_t* interval_starts, int b, int d, int h, int w, int n, int c,
+                           int n_intervals, float* out, void* stream);
+/* [EXT] bev_pool_backward (bev_pool.cpp:60-87; kernel bev_pool_cuda.cu:61-84) */
+int coocc_bev_pool_backward(const float* out_grad, const int32_t* geom,
+                            const int32_t* interval_lengths, const int32_t* interval_starts, int b,
+                            int d, int h, int w, int n, int c, int n_intervals, float* x_grad,
+                            void* stream);
+/* voxel_pooling (P/coocc/image2bev/ViewTransformerLSSVoxel.py:100-123) without argsort:
+ * quantise (truncate, then range filter), stable radix sort of (voxel, point id), each voxel
+ * sums its rows in ascending point id.  x:[npts,C]; geom:[npts,3]; lo_dx_host = {bx-dx/2 (3),
+ * dx (3)}; out: NDHWC rows [B*X*Y*Z, out_stride].  ws >= coocc_voxel_pool_ws(npts, B*X*Y*Z). */
+size_t coocc_voxel_pool_ws(int npts, int nvox);
+int coocc_voxel_pool(const float* x, const float* geom, int npts, int pts_per_batch, int C,
+                     const float* lo_dx_host, int B, int X, int Y, int Z, float* out, int out_stride,
+                     void* ws, size_t ws_bytes, void* stream);
+/* bev_pool(feats, coords, ...) drop-in (M/ops/bev_pool/bev_pool.py:83-97): coords:[n,4]
+ * (x,y,z,b) i64; same sort-and-sum, out NDHWC rows. */
+int coocc_bev_pool_coords(const float* x, const int64_t* coords, int n, int C, int B, int X, int Y,
+                          int Z, float* out, int out_stride, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- R1..R3, L1 */
+/* inline render block, one launch for all cameras (P/coocc/detectors/coocc_ray.py:575-616).
+ * table:[X*Y*Z,4] = raw (sigma, r, g, b) head outputs per voxel -- the heads are pointwise,
+ * so per-voxel evaluation equals the reference's per-sample evaluation; geom:[N,D,H,W,3];
+ * zvals:[D] = linspace(0,D,D) (:614); bounds_host = xbound,ybound,zbound (lo,hi,step) of
+ * :577.  maps:[N,H,W,4] = (r,g,b,depth) before upsampling. */
+int coocc_render_nearest(const float* table, int X, int Y, int Z, const float* geom,
+                         const float* zvals, int N, int D, int H, int W, const float* bounds_host,
+                         float* maps, void* stream);
+/* x`scale` bilinear upsample, align_corners=False (coocc_ray.py:617-622):
+ * maps [N,H,W,4] -> rgbs [N,sH,sW,3], depths [N,sH,sW] */
+int coocc_upsample_maps(const float* maps, int N, int H, int W, int scale, float* rgbs,
+                        float* depths, void* stream);
+/* volume_sampling (P/utils/render_ray.py:28-48): trilinear, align_corners=True, border.
+ * vol: channels-last rows [d0*d1*d2, C] of the reference's [1,C,d0,d1,d2] volume;
+ * pts:[n,3]; aabb_host:[6] = min xyz, max xyz; feat:[n,C]; mask:[n] u8 (may be NULL). */
+int coocc_volume_sampling(const float* vol, int C, int d0, int d1, int d2, const float* pts, int n,
+                          const float* aabb_host, float* feat, uint8_t* mask, void* stream);
+/* raw2outputs (render_ray.py:198-249) == COOCC_Ray.get_weights (coocc_ray.py:199-213) for
+ * the weights: raw:[R,S,4] (rgb, sigma), z:[R,S] -> rgb:[R,3], depth:[R], weights:[R,S]
+ * (may be NULL); zmin/zmax = z_vals.min()/max(). */
+int coocc_raw2outputs(const float* raw, const float* z, int R, int S, int white_bkgd, float zmin,
+                      float zmax, float* rgb, float* depth, float* weights, void* stream);
+/* render losses (coocc_ray.py:423-433): out[0]=loss_depth_render, out[1]=loss_rgb.
+ * rgbs/rgb_gt:[npix,3]; depths/depth_gt:[npix]. */
+int coocc_render_losses(const float* rgbs, const float* depths, const float* rgb_gt,
+                        const float* depth_gt, int64_t npix, int D, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COOCC_HIP_H */
