@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py -- Co-Occ fused-voxel hot path on MI355X, BASELINE.json's metric:
+samples/s (6-cam frame + sweep -> occupancy logits + rendered rgb/depth).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched through torch.distributed.run)
+
+A step is one pass of the hot path over one synthetic sample already resident in HBM:
+BiFuser_N (KNN + gather/encode/scatter + con_enc) -> CustomResNet3D -> FPN3D -> OccHead
+(coarse + cascade fine, scattered into the 200x200x16 grid) -> 6-camera volume render
+(+ for N>1 one RCCL all-gather of the rendered maps).  Workload = the reference config
+coocc_multi_r50_256x704 (configs[1]): fused grid 100x100x8 x 128 ch, final occupancy grid
+200x200x16, 6 cams with 16x44 feature maps -> 6x256x704 maps, knum=2, random weights, fp32.
+Weak scaling: every rank processes its own samples (the reference's samples_per_gpu=1 DP).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: fp32-MFMA implicit-GEMM conv)
+and, at N=1, `cpu_baseline` (the oracle's CPU restatement timed on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import co_occ_amd as pkg  # noqa: E402
+import co_occ_amd.dist as cdist  # noqa: E402
+import co_occ_amd.synth as synth  # noqa: E402
+from co_occ_amd import core  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, fp32-input MFMA (spec)
+HBM_PEAK_GBS = 8000.0          # HBM3E spec
+DOMINANT = "k_conv<128,128,64,64,geom>"
+
+
+def make_inputs(cfgname, seed, dev, model):
+    c = synth.CONFIGS[cfgname]
+    img, pts = synth.voxel_inputs(c["grid"], C=c["C"], seed=seed)
+    fH, fW = c["fmap"]
+    rig = synth.camera_rig(c["ncam"], (fH * 16, fW * 16), seed=seed)
+    r = {k: v.to(dev) for k, v in rig.items() if torch.is_tensor(v)}
+    vt = model.img_view_transformer
+    gemo = vt.get_geometry(r["rots"], r["trans"], r["intrins"], r["post_rots"], r["post_trans"], r["bda"])
+    img_feats = [synth.image_feats(c["ncam"], c["fmap"], 512, seed=seed).to(dev)]
+    transform = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synth.rig_transform(rig))
+    return dict(img=img.to(dev), pts=pts.to(dev), gemo=gemo, img_feats=img_feats, transform=transform,
+                cpu=dict(img=img, pts=pts, rig=rig, img_feats=[img_feats[0].cpu()]))
+
+
+def build_model(cfgname, dev):
+    c = synth.CONFIGS[cfgname]
+    fH, fW = c["fmap"]
+    X, Y, Z = c["grid"]
+    cfg = synth.model_cfg(C=c["C"], knum=c["knum"], final_occ_size=(2 * X, 2 * Y, 2 * Z), input_size=(fH * 16, fW * 16))
+    model = pkg.build_detector(cfg)
+    sd = synth.random_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(sd)
+    return model.to(dev).eval(), sd
+
+
+def step(model, s, world):
+    out = model.forward_hot_path(s["img"], s["pts"], s["gemo"], s["img_feats"], s["transform"], render=True)
+    if world > 1:
+        out["all_rgbs"], out["all_depths"] = cdist.all_gather_maps(out["rgbs"], out["depths"])
+    return out
+
+
+def cpu_baseline(sd, s, cfgname, seconds_cap):
+    """The oracle's literal CPU restatement of the same step (gather-then-MLP render, materialised
+    concat, sort-based pooling is not part of the step) on this host's cores, one sample."""
+    from oracle import ref_cpu
+    c = synth.CONFIGS[cfgname]
+    X, Y, Z = c["grid"]
+    cpu = s["cpu"]
+    rig = cpu["rig"]
+    fr = ref_cpu.create_frustum((c["fmap"][0] * 16, c["fmap"][1] * 16), 16, [2.0, 58.0, 0.5])
+    gemo = ref_cpu.get_geometry(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
+    sdc = {k: v.cpu() for k, v in sd.items()}
+    torch.set_num_threads(os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref_cpu.hot_path_forward(sdc, cpu["img"], cpu["pts"], gemo, cpu["img_feats"], synth.rig_transform(rig), knum=c["knum"],
+                                 cascade_ratio=2, final_occ_size=(2 * X, 2 * Y, 2 * Z), literal_render=True)
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample="1 sample of the %s workload (rank-0 inputs, seed 1234), single run, %.1f s" % (cfgname, dt),
+                seconds=dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="r50", choices=sorted(synth.CONFIGS))
+    ap.add_argument("--streams", type=int, default=2, help="samples in flight (software pipelining over HIP streams)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event timing table to stderr")
+    args = ap.parse_args()
+
+    rank, world, local = cdist.init()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    model, sd = build_model(args.config, dev)
+    samples = [make_inputs(args.config, 1234 + 17 * rank + i, dev, model) for i in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+
+    def run(nsteps, timed):
+        for i in range(nsteps):
+            st = streams[i % len(streams)]
+            with torch.cuda.stream(st), torch.no_grad():
+                step(model, samples[i % len(samples)], world)
+        for st in streams:
+            st.synchronize()
+
+    torch.cuda.synchronize()
+    run(args.warmup, False)
+    core.TIMER.enabled = not args.no_kernel_timing
+    core.TIMER.reset()
+    cdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    cdist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    core.TIMER.enabled = False
+    dt = cdist.max_over_ranks(dt, dev)
+
+    c = synth.CONFIGS[args.config]
+    ksum = core.TIMER.summary()
+    roof = None
+    extra = {}
+    if ksum:
+        tot = sum(v["ms"] for v in ksum.values())
+        if args.kernel_table and rank == 0:
+            for k, v in sorted(ksum.items(), key=lambda kv: -kv[1]["ms"]):
+                unit = v["work"] / (v["ms"] * 1e-3) if v["ms"] else 0
+                print("%-34s launches %5d  total %9.3f ms  avg %8.3f ms  %6.1f%%  work/s %.4g" % (
+                    k, v["launches"], v["ms"], v["ms"] / v["launches"], 100 * v["ms"] / tot, unit), file=sys.stderr)
+        if DOMINANT in ksum:
+            v = ksum[DOMINANT]
+            ach = v["work"] / (v["ms"] * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel=DOMINANT, achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, launches=v["launches"],
+                        avg_launch_ms=round(v["ms"] / v["launches"], 4),
+                        share_of_timed_kernels=round(v["ms"] / tot, 3))
+        rk = [ksum[k] for k in ("k_render_nearest", "k_upsample_maps") if k in ksum]
+        if rk:
+            ms = sum(v["ms"] for v in rk)
+            by = sum(v["work"] for v in rk)
+            ach = by / (ms * 1e-3) / 1e9
+            extra["roofline_render"] = dict(bound="hbm", kernel="k_render_nearest+k_upsample_maps", achieved=round(ach, 1),
+                                            peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                                            avg_ms_per_step=round(ms / max(1, rk[0]["launches"]), 4))
+
+    line = dict(metric="samples/sec (6-cam frame + sweep -> occ+render), 200x200x16 grid", value=round(world * args.steps / dt, 4),
+                unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+                dtype="f32", data="synthetic",
+                config=dict(workload="coocc_multi_r50_256x704 hot path" if args.config == "r50" else args.config,
+                            fused_grid="x".join(map(str, c["grid"])) + "x%d" % c["C"],
+                            occupancy_grid="x".join(str(2 * v) for v in c["grid"]), cams=c["ncam"],
+                            render_maps="%dx%dx%d" % (c["ncam"], c["fmap"][0] * 16, c["fmap"][1] * 16), knum=c["knum"],
+                            parallelism="dp%d (1 scene per GPU, RCCL all-gather of maps)" % world,
+                            samples_in_flight=len(streams), weights="random"),
+                roofline=roof)
+    line.update(extra)
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(sd, samples[0], args.config, 30.0)
+    if rank == 0:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,62 @@ from ._lib import ConvDesc, call, ptr
 _F32 = torch.float32
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing on the launch stream (bench.py's roofline numbers).
+    Disabled by default; when enabled each wrapped launch records an event pair."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    class _Region:
+        def __init__(self, owner, tag, work):
+            self.o, self.tag, self.work = owner, tag, work
+
+        def __enter__(self):
+            if self.o.enabled:
+                self.s = torch.cuda.Event(enable_timing=True)
+                self.e = torch.cuda.Event(enable_timing=True)
+                self.s.record()
+            return self
+
+        def __exit__(self, *a):
+            if self.o.enabled:
+                self.e.record()
+                self.o.records.append((self.tag, self.work, self.s, self.e))
+            return False
+
+    def region(self, tag, work=0.0):
+        return KernelTimer._Region(self, tag, work)
+
+    def summary(self):
+        """{tag: dict(launches, ms, work)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for tag, work, s, e in self.records:
+            d = out.setdefault(tag, dict(launches=0, ms=0.0, work=0.0))
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["work"] += work
+        return out
+
+    def reset(self):
+        self.records = []
+
+
+TIMER = KernelTimer()
+
+
+def conv_kernel_name(M, Cout, table):
+    """Mirror of the tile-configuration rule in csrc/conv3d.hip (coocc_conv_fwd)."""
+    if Cout <= 32:
+        t = "128,32,32,32"
+    elif Cout <= 64:
+        t = "128,64,32,64"
+    else:
+        t = "128,128,64,64" if M >= 8192 else "64,128,32,64"
+    return "k_conv<%s,%s>" % (t, "table" if table else "geom")
+
+
 class Rows:
     """A dense voxel volume as channels-last rows: t[B*X*Y*Z, stride], C channels at `coff`."""
 
@@ -119,7 +175,7 @@ _ws_cache = {}
 
 def workspace(device, nfloats=64 << 20):
     """Split-K scratch (256 MB by default), one per device, reused by every launch on the stream."""
-    key = (device.index, nfloats)
+    key = (device.index, nfloats, torch.cuda.current_stream(device).cuda_stream)   # one per stream: samples overlap
     if key not in _ws_cache:
         _ws_cache[key] = torch.empty(nfloats, device=device, dtype=_F32)
     return _ws_cache[key]
@@ -151,7 +207,8 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
     d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = x.B, x.X, x.Y, x.Z, Xo, Yo, Zo
     d.ksize, d.stride, d.pad = pc.ksize, pc.stride, pc.pad
     d.relu, d.res_mode, d.splitk = int(relu), (res_mode or (1 if res is not None else 0)), splitk
-    _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+    with TIMER.region(conv_kernel_name(M, pc.Cout, False), 2.0 * M * pc.Cin * pc.Cout * pc.taps):
+        _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     return out
 
 
@@ -178,7 +235,8 @@ def linear_rows(x2d, pc, relu=False, out=None, out_coff=0, in_coff=0, in_C=None)
     d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = 1, n, 1, 1, n, 1, 1
     d.ksize, d.stride, d.pad = 1, 1, 0
     d.relu, d.res_mode, d.splitk = int(relu), 0, 0
-    _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+    with TIMER.region(conv_kernel_name(n, pc.Cout, False), 2.0 * n * Cin * pc.Cout):
+        _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     return out
 
 
@@ -203,7 +261,8 @@ def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_co
     d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = 1, 1, 1, 1, 1, 1, 1
     d.ksize, d.stride, d.pad = 1, 1, 0
     d.relu, d.res_mode, d.splitk = int(relu), 2, 1
-    _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+    with TIMER.region(conv_kernel_name(M, pc.Cout, True), 2.0 * M * C * pc.Cout * K):
+        _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
 
 
 class PackCache:

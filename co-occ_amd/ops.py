@@ -81,7 +81,7 @@ _pool_ws = {}
 
 def _pool_workspace(device, npts, nvox):
     need = int(_lib.load().coocc_voxel_pool_ws(npts, nvox))
-    key = device.index
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _pool_ws or _pool_ws[key].numel() < need:
         _pool_ws[key] = torch.empty(need, device=device, dtype=torch.uint8)
     return _pool_ws[key]

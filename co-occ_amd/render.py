@@ -80,11 +80,16 @@ def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16):
     dev = g.device
     zvals = torch.linspace(0, D, D, device=dev)
     maps = torch.empty(N, H, W, 4, device=dev, dtype=_F32)
-    call("coocc_render_nearest", ptr(table), vf.X, vf.Y, vf.Z, ptr(g), ptr(zvals), N, D, H, W, host_f32(RENDER_BOUNDS),
-         ptr(maps))
+    from .core import TIMER
+    # algorithmic HBM bytes: geom read + table read + small maps written, then
+    # small maps read + upsampled maps written
+    with TIMER.region("k_render_nearest", 12.0 * N * D * H * W + 16.0 * vf.V + 16.0 * N * H * W):
+        call("coocc_render_nearest", ptr(table), vf.X, vf.Y, vf.Z, ptr(g), ptr(zvals), N, D, H, W, host_f32(RENDER_BOUNDS),
+             ptr(maps))
     rgbs = torch.empty(N, H * scale, W * scale, 3, device=dev, dtype=_F32)
     depths = torch.empty(N, H * scale, W * scale, device=dev, dtype=_F32)
-    call("coocc_upsample_maps", ptr(maps), N, H, W, scale, ptr(rgbs), ptr(depths))
+    with TIMER.region("k_upsample_maps", 16.0 * N * H * W + 16.0 * N * H * W * scale * scale):
+        call("coocc_upsample_maps", ptr(maps), N, H, W, scale, ptr(rgbs), ptr(depths))
     return rgbs, depths, maps
 
 

@@ -1,0 +1,246 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference modules (imported by path
+from /root/reference through oracle/refshim.py) on the seeded cases of oracle/cases.py, and
+check that oracle/ref_cpu.py reproduces them.  Runs only in the build container:
+
+    python -m oracle.gen_golden            # writes tests/golden/, prints max |ref - oracle|
+
+The reference source never leaves the container; only inputs-by-seed and output arrays do.
+Canonicalisation applied to the reference run: torch.topk is replaced by a
+stable sort (ties by index) and torch runs single-threaded so duplicate-index index_put_ is
+sequential (last writer wins).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import co_occ_amd.synth as synth  # noqa: E402
+from oracle import cases, ref_cpu, refshim  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def stable_topk(x, k, dim=-1, largest=True, sorted=True):
+    assert not largest
+    v, i = torch.sort(x, dim=dim, stable=True)
+    return v.narrow(dim, 0, k), i.narrow(dim, 0, k)
+
+
+def maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max()) if a.numel() else 0.0
+
+
+def save(name, **arrs):
+    os.makedirs(GOLD, exist_ok=True)
+    out = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
+def gen_fuser(R):
+    mod = R["bifuser_n"]
+    for name, c in cases.FUSER_CASES.items():
+        img, pts = cases.fuser_inputs(c)
+        ref = mod.BiFuser_N(c["C"], c["C"], knum=c["knum"]).eval()
+        sd = synth.random_state_dict(ref.state_dict(), seed=c["seed"])
+        ref.load_state_dict(sd)
+        rec = []
+        orig = ref.fps_NN_fast
+        ref.fps_NN_fast = lambda *a, **k: (rec.append(orig(*a, **k)) or rec[-1])
+        real_topk = torch.topk
+        torch.topk = stable_topk
+        try:
+            with torch.no_grad():
+                out = ref(img, pts)
+        finally:
+            torch.topk = real_topk
+        o = ref_cpu.bifuser_fuse(sd, img, pts, c["knum"])
+        oo = ref_cpu.con_enc(sd, o["all_feats"])
+        assert torch.equal(rec[0], o["near_img"]) and torch.equal(rec[1], o["near_pts"]), name + ": index mismatch"
+        d = maxdiff(out, oo)
+        print("%-16s Ni=%d Np=%d  assigned img->pts %.2f pts->img %.2f  |ref-oracle|=%.2e" % (
+            name, o["inds_img"].shape[0], o["inds_pts"].shape[0], float((rec[0] >= 0).float().mean()),
+            float((rec[1] >= 0).float().mean()), d))
+        assert d < 2e-5
+        save(name, near_img=rec[0].int(), near_pts=rec[1].int(), n_img=o["inds_img"].shape[0],
+             n_pts=o["inds_pts"].shape[0], out=out, keys=np.array(sorted(sd.keys())))
+
+
+def gen_knn_parts():
+    """Per-kernel intermediates of the large path (oracle C functions; the FPS / ball-query
+    restatements are pinned by the upstream KATs in tests/test_oracle.py)."""
+    c = cases.FUSER_CASES["fuser_k4"]
+    img, pts = cases.fuser_inputs(c)
+    qi, ki = ref_cpu.voxel_nonzero(pts), ref_cpu.voxel_nonzero(img)
+    p = ref_cpu.fps_nn_fast_parts(qi, ki, num=4)
+    save("knn_parts_k4", repr_idx=p["repr_idx"], val=p["val"], nn=p["nn"].astype(np.int32), group=p["group"])
+
+
+def gen_decoder(R):
+    c = cases.DECODER_CASE
+    x, rig, img_feats = cases.decoder_inputs(c)
+    bn = dict(type='SyncBN', requires_grad=True)
+    enc = R["resnet3d"].CustomResNet3D(depth=18, block_inplanes=list(c["block_inplanes"]), n_input_channels=c["C"],
+                                       out_indices=(0, 1, 2, 3), norm_cfg=bn).eval()
+    neck = R["fpn3d"].FPN3D(in_channels=list(c["block_inplanes"]), out_channels=c["fpn_out"], norm_cfg=bn, with_cp=False).eval()
+    head = R["occ_head"].OccHead(in_channels=[c["fpn_out"]] * 4, out_channel=c["ncls"], num_level=4, soft_weights=True,
+                                 norm_cfg=bn, cascade_ratio=c["cascade_ratio"], sample_from_voxel=True,
+                                 sample_from_img=True, final_occ_size=list(c["final_occ_size"]), empty_idx=0,
+                                 point_cloud_range=list(c["point_cloud_range"])).eval()
+    sds = {}
+    for tag, m in (("enc", enc), ("neck", neck), ("head", head)):
+        sds[tag] = synth.random_state_dict(m.state_dict(), seed=c["seed"])
+        m.load_state_dict(sds[tag])
+    transform = synth.rig_transform(rig)
+    with torch.no_grad():
+        mid = enc(x)
+        sem = neck(mid)
+        co = head.forward_coarse_voxel(sem)
+        res = head(voxel_feats=sem, img_feats=img_feats, transform=transform)
+    o_mid = ref_cpu.resnet3d_forward(sds["enc"], x)
+    o_sem = ref_cpu.fpn3d_forward(sds["neck"], o_mid)
+    o_head = ref_cpu.occhead_forward(sds["head"], o_sem, img_feats, transform, c["cascade_ratio"], c["final_occ_size"],
+                                     c["point_cloud_range"])
+    ds = [maxdiff(a, b) for a, b in zip(mid, o_mid)] + [maxdiff(a, b) for a, b in zip(sem, o_sem)]
+    ds += [maxdiff(res["output_voxels"][0], o_head["output_voxels"]), maxdiff(co["out_voxel_feats"][0], o_head["out_voxel_feats"]),
+           maxdiff(res["output_voxels_fine"][0], o_head["fine_output"])]
+    assert torch.equal(res["output_coords_fine"][0], o_head["fine_coord"])
+    print("decoder           |ref-oracle| per tensor:", " ".join("%.1e" % d for d in ds), " Nf=%d" % o_head["fine_coord"].shape[1])
+    assert max(ds) < 1e-4
+    save("decoder", **{"mid%d" % i: t for i, t in enumerate(mid)}, **{"sem%d" % i: t for i, t in enumerate(sem)},
+         occ=res["output_voxels"][0], out_voxel_feats=co["out_voxel_feats"][0], fine_output=res["output_voxels_fine"][0],
+         fine_coord=res["output_coords_fine"][0],
+         enc_keys=np.array(sorted(sds["enc"])), neck_keys=np.array(sorted(sds["neck"])), head_keys=np.array(sorted(sds["head"])))
+
+
+def gen_pool_geometry(R):
+    c = cases.POOL_CASE
+    rig = synth.camera_rig(c["ncam"], c["input_size"], seed=c["seed"])
+    lb = R["lss_bevdepth"]
+    frustum = ref_cpu.create_frustum(c["input_size"], c["downsample"], c["grid_config"]["dbound"])
+    stub = types.SimpleNamespace(frustum=frustum)
+    with torch.no_grad():
+        geom = lb.ViewTransformerLiftSplatShoot.get_geometry(stub, rig["rots"], rig["trans"], rig["intrins"],
+                                                            rig["post_rots"], rig["post_trans"], rig["bda"])
+    o_geom = ref_cpu.get_geometry(frustum, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
+    D = frustum.shape[0]
+    vol = synth.lifted_volume(c["ncam"], D, c["fmap"], c["C"], seed=c["seed"])
+    dx, bx, nx = ref_cpu.gen_dx_bx(c["grid_config"]["xbound"], c["grid_config"]["ybound"], c["grid_config"]["zbound"])
+    stub2 = types.SimpleNamespace(dx=dx, bx=bx, nx=nx)
+    with torch.no_grad():
+        pooled = R["lss_voxel"].ViewTransformerLiftSplatShootVoxel.voxel_pooling(stub2, geom, vol)
+    o_pooled = ref_cpu.voxel_pooling(geom, vol, dx, bx, nx)
+    print("geometry/pool     |ref-oracle| geom %.1e pooled %.1e  (non-empty voxels %d)" % (
+        maxdiff(geom, o_geom), maxdiff(pooled, o_pooled), int((pooled.abs().sum(1) > 0).sum())))
+    assert maxdiff(geom, o_geom) < 1e-4 and maxdiff(pooled, o_pooled) < 1e-5
+    nz = torch.nonzero(pooled[0].abs().sum(0))
+    save("pool_geometry", geom=geom, pooled_nz_idx=nz.int(), pooled_nz_val=pooled[0][:, nz[:, 0], nz[:, 1], nz[:, 2]].t())
+
+
+class _FProxy:
+    """Stands in for the module-level ``F`` of coocc_ray.py and records F.interpolate calls."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __getattr__(self, k):
+        return getattr(F, k)
+
+    def interpolate(self, x, **kw):
+        y = F.interpolate(x, **kw)
+        self.calls.append((x.clone(), y.clone()))
+        return y
+
+
+def gen_render(R):
+    c = cases.RENDER_CASE
+    vf, rig = cases.render_inputs(c)
+    cr = R["coocc_ray"]
+    frustum = ref_cpu.create_frustum(c["input_size"], c["downsample"], [2.0, 58.0, 0.5])
+    gemo = ref_cpu.get_geometry(frustum, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
+    sig = R["nerf_mlp"].MLP(input_dim=128, output_dim=1, net_depth=1, skip_layer=None).eval()
+    rgb = R["nerf_mlp"].MLP(input_dim=128, output_dim=3, net_depth=3, skip_layer=None).eval()
+    ssd, rsd = synth.random_state_dict(sig.state_dict(), c["seed"]), synth.random_state_dict(rgb.state_dict(), c["seed"] + 1)
+    sig.load_state_dict(ssd)
+    rgb.load_state_dict(rsd)
+    ncam = c["ncam"]
+    H, W = c["input_size"]
+    seen = []
+    stub = types.SimpleNamespace(
+        extract_feat=lambda points, img, img_metas: (vf, None, None, None, gemo, None),
+        semantic_encoder=lambda x: x, semantic_neck=lambda x: x,
+        pts_bbox_head=lambda **k: dict(output_voxels=[torch.zeros(1, 17, 2, 2, 2)], output_voxels_fine=None,
+                                       output_coords_fine=None, output_points=None),
+        evaluation_semantic=lambda *a, **k: (None, None), empty_idx=0, use_rendering=True, test_rendering=True,
+        sigma_head=sig, rgb_head=rgb)
+    proxy = _FProxy()
+    cr.F = proxy
+    cr.compute_psnr = lambda a, b, mask=None: (seen.append(a.clone()) or 0.0)
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        with torch.no_grad():
+            cr.COOCC_Ray.simple_test(stub, None, img=[torch.zeros(1, ncam, 3, H // 4 * 0 + frustum.shape[1] * 16, frustum.shape[2] * 16)],
+                                     points=None, gt_occ=torch.zeros(1, 2, 2, 2))
+    finally:
+        os.chdir(cwd)
+        cr.F = F
+    # per camera: interpolate(depth_map) then interpolate(rgb_map)
+    depth_maps = torch.stack([proxy.calls[2 * i][0][0, 0] for i in range(ncam)])
+    rgb_maps = torch.stack([proxy.calls[2 * i + 1][0][0].permute(1, 2, 0) for i in range(ncam)])
+    depths = torch.stack([proxy.calls[2 * i][1][0, 0] for i in range(ncam)])
+    rgbs = torch.stack(seen)
+    o_rgbs, o_depths = ref_cpu.render_block(ssd, rsd, vf, gemo, literal=True)
+    t_rgbs, t_depths = ref_cpu.render_block(ssd, rsd, vf, gemo, literal=False)
+    print("render            |ref-oracle| rgb %.1e depth %.1e ; per-voxel-table form rgb %.1e depth %.1e" % (
+        maxdiff(rgbs, o_rgbs), maxdiff(depths, o_depths), maxdiff(rgbs, t_rgbs), maxdiff(depths, t_depths)))
+    assert maxdiff(rgbs, o_rgbs) < 1e-5 and maxdiff(depths, o_depths) < 1e-4
+    save("render", rgb_maps=rgb_maps, depth_maps=depth_maps, rgbs=rgbs, depths=depths)
+
+
+def gen_rays(R):
+    c = cases.RAY_CASE
+    vol, o, d, raw = cases.ray_inputs(c)
+    rr = R["render_ray"]
+    pts, z = rr.sample_along_camera_ray(o, d, c["near_far"], c["n_samples"], inv_uniform=False, det=True)
+    pts_i, z_i = rr.sample_along_camera_ray(o, d, c["near_far"], c["n_samples"], inv_uniform=True, det=True)
+    feat, mask = rr.volume_sampling(pts, vol, c["aabb"])
+    r1 = rr.raw2outputs(raw, z, mask, white_bkgd=False)
+    r2 = rr.raw2outputs(raw, z, mask, white_bkgd=True)
+    w = R["coocc_ray"].COOCC_Ray.get_weights(None, raw[..., 3:4], z)
+    o_pts, o_z = ref_cpu.sample_along_camera_ray(o, d, c["near_far"], c["n_samples"])
+    o_feat, o_mask = ref_cpu.volume_sampling(pts, vol, c["aabb"])
+    q1 = ref_cpu.raw2outputs(raw, z, mask, False)
+    ds = [maxdiff(pts, o_pts), maxdiff(feat, o_feat), maxdiff(r1["rgb"], q1["rgb"]), maxdiff(r1["depth"], q1["depth"]),
+          maxdiff(w, ref_cpu.get_weights(raw[..., 3:4], z))]
+    assert torch.equal(mask, o_mask)
+    print("library renderer  |ref-oracle|", " ".join("%.1e" % v for v in ds))
+    assert max(ds) < 1e-5
+    save("rays", pts=pts, z=z, pts_inv=pts_i, z_inv=z_i, feat=feat, mask=mask, rgb=r1["rgb"], depth=r1["depth"],
+         weights=r1["weights"], ray_mask=r1["mask"], rgb_white=r2["rgb"], get_weights=w)
+
+
+def main():
+    torch.set_num_threads(1)
+    R = refshim.install()
+    gen_fuser(R)
+    gen_knn_parts()
+    gen_decoder(R)
+    gen_pool_geometry(R)
+    gen_render(R)
+    gen_rays(R)
+    tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
+    print("golden fixtures: %.2f MB in %s" % (tot / 1e6, GOLD))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/coocc_hip.h declares;
+the ctypes table in co_occ_amd/_lib.py agrees with the header (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from co_occ_amd import _lib
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "coocc_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"typedef struct.*?\}\s*\w+;", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"(?:const char\*|int64_t|size_t|int)\s+(coocc_\w+)\s*\(([^)]*)\)\s*;", src):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return out
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail("libcoocc_hip.so not built: run __graft_entry__.build()")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    fns = header_functions()
+    assert len(fns) >= 30
+    for name in fns:
+        assert hasattr(lib, name), "missing export " + name
+
+
+def test_ctypes_table_matches_header():
+    fns = header_functions()
+    assert set(fns) == set(_lib.SIGNATURES), set(fns) ^ set(_lib.SIGNATURES)
+    for name, nargs in fns.items():
+        assert len(_lib.SIGNATURES[name][1]) == nargs, name
+
+
+def test_conv_desc_layout_matches_header():
+    src = open(os.path.join(ROOT, "include", "coocc_hip.h")).read()
+    body = re.search(r"typedef struct coocc_conv_desc \{(.*?)\} coocc_conv_desc;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ptr = "*" in decl
+        parts = decl.replace("*", " ").split()
+        for n in " ".join(parts[2 if parts[0] == "const" else 1:]).split(","):
+            names.append((n.strip(), ptr))
+    got = [(n.rstrip("_"), t is ctypes.c_void_p) for n, t in _lib.ConvDesc._fields_]
+    assert [n for n, _ in names] == [n for n, _ in got]
+    assert [p for _, p in names] == [p for _, p in got]
+
+
+def test_abi_version_and_error_path():
+    lib = _lib.load()
+    assert lib.coocc_abi_version() == 1
+    # argument validation happens before any launch: exercising it needs no GPU
+    rc = lib.coocc_knn_topk(0, 0, 1, None, None, None, None, None)
+    assert rc == -1 and b"knn_topk" in lib.coocc_last_error()
+
+
+def test_pack_weights_host_layout():
+    """coocc_conv_pack_weights is host code: [taps][ceil(Cin/32)][roundup(Cout,128)][32]."""
+    lib = _lib.load()
+    Cout, Cin, taps = 5, 40, 27
+    w = np.arange(Cout * Cin * taps, dtype=np.float32).reshape(Cout, Cin, taps)
+    n = lib.coocc_conv_pack_weights(w.ctypes.data, Cout, Cin, taps, 0, None)
+    assert n == taps * 2 * 128 * 32
+    packed = np.zeros(n, np.float32)
+    lib.coocc_conv_pack_weights(w.ctypes.data, Cout, Cin, taps, 0, packed.ctypes.data)
+    p = packed.reshape(taps, 2, 128, 32)
+    for t, n_, c in [(0, 0, 0), (26, 4, 39), (13, 2, 31), (5, 3, 32)]:
+        assert p[t, c // 32, n_, c % 32] == w[n_, c, t]
+    assert p[:, :, 5:, :].sum() == 0 and p[:, 1, :, 8:].sum() == 0
+    wl = np.arange(Cout * 3 * 8, dtype=np.float32).reshape(Cout, 3 * 8)            # Linear(C*K -> Cout), K=3, C=8
+    n = lib.coocc_conv_pack_weights(wl.ctypes.data, Cout, 8, 3, 1, None)
+    packed = np.zeros(n, np.float32)
+    lib.coocc_conv_pack_weights(wl.ctypes.data, Cout, 8, 3, 1, packed.ctypes.data)
+    p = packed.reshape(3, 1, 128, 32)
+    assert p[2, 0, 4, 7] == wl[4, 2 * 8 + 7]

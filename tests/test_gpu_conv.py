@@ -1,0 +1,153 @@
+"""fp32-MFMA implicit GEMM (C0-C3, G1, linear layers) and the resampling kernels vs torch CPU
+fp32 references of the same ops (floating point: scale-relative 1e-4, see tests/util.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from co_occ_amd import core
+from co_occ_amd._lib import call, host_i32, ptr
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def rows_of(x, dev):
+    """[B,C,X,Y,Z] cpu tensor -> Rows on dev (through the HIP transpose)."""
+    return core.to_rows(x.to(dev))
+
+
+def bn_like(C, g):
+    bn = torch.nn.BatchNorm3d(C).eval()
+    bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+    bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    bn.weight.data.copy_(torch.rand(C, generator=g) + 0.5)
+    bn.bias.data.copy_(torch.randn(C, generator=g) * 0.1)
+    return bn
+
+
+CASES = [
+    # Cin, Cout, grid, ksize, stride, relu, residual, splitk
+    (16, 32, (9, 7, 4), 3, 1, True, False, 0),       # small, M tail, Cout<=32 config
+    (32, 64, (12, 10, 4), 3, 1, True, True, 0),      # Cout<=64 config, residual
+    (64, 128, (40, 40, 8), 3, 1, True, False, 0),    # 128x128 tiles, M = 12800
+    (128, 256, (20, 20, 4), 3, 2, False, False, 0),  # stride 2, two N tiles, small M (64x128 tiles)
+    (64, 128, (13, 13, 1), 3, 2, True, True, 4),     # forced split-K, odd dims, residual
+    (256, 256, (7, 7, 2), 3, 1, True, False, 0),     # auto split-K path (few blocks, long K)
+    (128, 17, (10, 10, 8), 1, 1, False, False, 0),   # 1x1x1 classifier, Cout = 17
+    (96, 4, (10, 6, 2), 1, 1, False, False, 0),      # Cout = 4
+    (64, 128, (25, 25, 2), 1, 2, False, False, 0),   # 1x1x1 stride-2 shortcut
+    (36, 40, (6, 5, 3), 3, 1, True, False, 0),       # Cin not a multiple of 32
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,grid,k,stride,relu,use_res,splitk", CASES)
+def test_conv3d_bn_relu_residual(dev, Cin, Cout, grid, k, stride, relu, use_res, splitk):
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    X, Y, Z = grid
+    B = 2 if X < 20 else 1
+    x = torch.randn(B, Cin, X, Y, Z, generator=g)
+    w = torch.randn(Cout, Cin, k, k, k, generator=g) * (2.0 / (Cin * k ** 3)) ** 0.5
+    bn = bn_like(Cout, g)
+    pad = k // 2
+    ref = bn(F.conv3d(x, w, stride=stride, padding=pad))
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=k, stride=stride, pad=pad)
+    out = core.conv_rows(rows_of(x, dev), pc, relu=relu, res=rows_of(res, dev) if use_res else None, splitk=splitk)
+    assert (out.X, out.Y, out.Z) == tuple(ref.shape[2:])
+    assert_close(out.as_ncdhw().cpu(), ref.detach(), what="conv")
+
+
+def test_conv_mfma_layout_asymmetric(dev):
+    """A = identity-like probe with an asymmetric weight catches row/col swaps in the D map."""
+    Cin = Cout = 64
+    x = torch.zeros(1, Cin, 4, 4, 4)
+    for c in range(Cin):
+        x[0, c, c % 4, (c // 4) % 4, c // 16] = 1.0 + c
+    w = torch.arange(Cout * Cin, dtype=torch.float32).view(Cout, Cin, 1, 1, 1) / 997.0
+    pc = core.PackedConv(w.to(dev), ksize=1)
+    out = core.conv_rows(rows_of(x, dev), pc, relu=False)
+    assert_close(out.as_ncdhw().cpu(), F.conv3d(x, w), tol=1e-6)
+
+
+def test_linear_rows_bias_relu_offsets(dev):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1000, 192, generator=g)
+    lin = torch.nn.Linear(128, 64)
+    pc = core.PackedConv(lin.weight.to(dev), bias=lin.bias.to(dev))
+    out = torch.zeros(1000, 80, device=dev)
+    core.linear_rows(x.to(dev), pc, relu=True, out=out, out_coff=16, in_coff=64)
+    ref = F.relu(lin(x[:, 64:]))
+    assert_close(out[:, 16:].cpu(), ref.detach())
+    assert float(out[:, :16].abs().max()) == 0.0
+
+
+def test_gather_conv_is_gsfusion_g1(dev):
+    """rows table + tap-major Linear(C*K -> C) + ReLU + gate + scatter (bifuser_n.py:138-169)."""
+    g = torch.Generator().manual_seed(9)
+    V, C, K, M = 5000, 16, 3, 1700
+    cat4 = torch.randn(V, 4 * C, generator=g)
+    lin = torch.nn.Linear(C * K, C)
+    gather = torch.randint(0, V, (K, M), generator=g).int()
+    gather[1, ::7] = -1                                  # out-of-range row -> zeros
+    out_rows = torch.randperm(V, generator=g)[:M].int()
+    feat = torch.cat([torch.where(gather[k][:, None] >= 0, cat4[gather[k].clamp(min=0).long(), :C], torch.zeros(M, C)) for k in range(K)], 1)
+    want = cat4.clone()
+    want[out_rows.long(), 2 * C:3 * C] = F.relu(lin(feat)).detach() * cat4[out_rows.long(), C:2 * C]
+    pc = core.PackedConv(lin.weight.to(dev), bias=lin.bias.to(dev), tap_major=True, taps=K)
+    d = cat4.to(dev)
+    core.gather_conv_rows(d, 0, pc, gather.to(dev), out_rows.to(dev), d, 2 * C, C, C)
+    assert_close(d.cpu(), want)
+
+
+@pytest.mark.parametrize("cs,fs", [((5, 4, 2), (10, 8, 4)), ((13, 13, 1), (25, 25, 2)), ((7, 7, 3), (7, 7, 3))])
+def test_upsample_add_trilinear(dev, cs, fs):
+    g = torch.Generator().manual_seed(sum(cs))
+    c = torch.randn(2, 8, *cs, generator=g)
+    f = torch.randn(2, 8, *fs, generator=g)
+    want = f + F.interpolate(c, size=fs, mode="trilinear", align_corners=False)
+    rc, rf = rows_of(c, dev), rows_of(f, dev)
+    call("coocc_upsample_add_trilinear", ptr(rc.t), ptr(rf.t), 2, 8, *cs, *fs)
+    assert_close(rf.as_ncdhw().cpu(), want, tol=1e-5)
+
+
+def test_occhead_mix_softmax_levels(dev):
+    g = torch.Generator().manual_seed(4)
+    sizes = [(12, 10, 4), (6, 5, 2), (3, 3, 1), (2, 2, 1)]
+    lv = [torch.randn(1, 16, *s, generator=g) for s in sizes]
+    logit = torch.randn(1, 4, *sizes[0], generator=g)
+    w = torch.softmax(logit, 1)
+    want = 0
+    for f, wi in zip(lv, torch.unbind(w, 1)):
+        want = want + F.interpolate(f, size=list(sizes[0]), mode="trilinear", align_corners=False) * wi.unsqueeze(1)
+    rows = [rows_of(t, dev) for t in lv]
+    wl = rows_of(logit, dev)
+    out = torch.empty_like(rows[0].t)
+    import ctypes
+    levels = (ctypes.c_void_p * 4)(*[r.t.data_ptr() for r in rows])
+    call("coocc_occhead_mix", levels, host_i32([v for s in sizes for v in s]), 4, ptr(wl.t), ptr(out), 1, 16)
+    assert_close(out.view(1, *sizes[0], 16).permute(0, 4, 1, 2, 3).cpu(), want, tol=1e-5)
+
+
+def test_conv_linearity_at_full_grid(dev):
+    """Size-independent property at the BASELINE grid (100x100x8, C=128): conv(a*x + y) ==
+    a*conv(x) + conv(y) for the bias-free, ReLU-free 3x3x3 layer; and a checksum of the
+    1-channel all-ones response equals the analytic tap count."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 128, 100, 100, 8, generator=g).to(dev)
+    y = torch.randn(1, 128, 100, 100, 8, generator=g).to(dev)
+    w = (torch.randn(128, 128, 3, 3, 3, generator=g) * 0.02).to(dev)
+    pc = core.PackedConv(w, ksize=3, pad=1)
+    cx = core.conv_rows(core.to_rows(x), pc, relu=False).t
+    cy = core.conv_rows(core.to_rows(y), pc, relu=False).t
+    cz = core.conv_rows(core.to_rows(2.5 * x + y), pc, relu=False).t
+    assert_close(cz.cpu(), (2.5 * cx + cy).cpu(), tol=1e-5)
+    ones = torch.ones(1, 4, 100, 100, 8, device=dev)
+    w1 = torch.ones(4, 4, 3, 3, 3, device=dev)
+    resp = core.conv_rows(core.to_rows(ones), core.PackedConv(w1, ksize=3, pad=1), relu=False).as_ncdhw()
+    taps = (100 * 3 - 2) * (100 * 3 - 2) * (8 * 3 - 2)          # sum over voxels of valid taps = prod (3n-2)
+    assert float(resp[0, 0].double().sum().item()) == pytest.approx(4.0 * taps, rel=1e-6)

@@ -1,0 +1,160 @@
+"""K1-K5 on the GPU through the C ABI vs the oracle (bit-exact: integer / index work)."""
+import numpy as np
+import pytest
+import torch
+
+import co_occ_amd as pkg
+from co_occ_amd import _lib
+from co_occ_amd._lib import call, ptr
+from oracle import cases, native, ref_cpu
+import test_oracle as kat
+
+pytestmark = pytest.mark.gpu
+I32, F32 = torch.int32, torch.float32
+
+
+def T(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t.to(dtype) if dtype else t
+
+
+def test_fps_upstream_kat(dev):
+    idx = pkg.furthest_point_sample(T(kat.FPS_XYZ, dev), 3)
+    assert idx.dtype == I32 and np.array_equal(idx.cpu().numpy(), kat.FPS_EXPECTED)
+
+
+@pytest.mark.parametrize("n,m,hi", [(5, 5, 3), (37, 20, 4), (700, 300, 5), (1024, 64, 6), (3000, 512, 6),
+                                    (9000, 2048, 12), (15000, 2048, 16), (30000, 256, 40)])
+def test_fps_ties_match_reference_block_reduction(dev, n, m, hi):
+    rng = np.random.default_rng(n)
+    pts = rng.integers(0, hi, (2, n, 3)).astype(np.float32)           # integer grid: ties everywhere
+    got = pkg.furthest_point_sample(T(pts, dev), m).cpu().numpy()
+    assert np.array_equal(got, native.fps(pts, m))
+
+
+def test_fps_float_coordinates(dev):
+    rng = np.random.default_rng(7)
+    pts = (rng.integers(-400, 400, (1, 5000, 3)) / 8.0).astype(np.float32)   # exactly representable
+    assert np.array_equal(pkg.furthest_point_sample(T(pts, dev), 128).cpu().numpy(), native.fps(pts, 128))
+
+
+def test_ball_query_upstream_kat(dev):
+    xyz, new = T(kat.BQ_XYZ, dev), T(kat.BQ_NEW, dev)
+    assert np.array_equal(pkg.ball_query(0, 0.2, 5, xyz, new).cpu().numpy(), kat.BQ_EXPECTED_02)
+    assert np.array_equal(pkg.ball_query(0.2, 0.4, 5, xyz, new).cpu().numpy(), kat.BQ_EXPECTED_DILATED)
+
+
+@pytest.mark.parametrize("n,m,ns,r", [(50, 7, 5, 2.0), (3000, 130, 200, 6.0), (9000, 2048, 200, 6.0), (200, 10, 300, 50.0)])
+def test_ball_query_random(dev, n, m, ns, r):
+    rng = np.random.default_rng(n + m)
+    xyz = rng.integers(0, 30, (2, n, 3)).astype(np.float32)
+    ctr = np.concatenate([xyz[:, : m - 2], rng.integers(100, 120, (2, 2, 3)).astype(np.float32)], 1)   # 2 empty balls
+    got = pkg.ball_query(0, r, ns, T(xyz, dev), T(ctr, dev)).cpu().numpy()
+    assert np.array_equal(got, native.ball_query(0, r, ns, xyz, ctr))
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 8])
+def test_knn_topk(dev, K):
+    rng = np.random.default_rng(K)
+    q = rng.integers(0, 40, (300, 3)).astype(np.float32)
+    k = rng.integers(0, 40, (5000, 3)).astype(np.float32)
+    val = torch.empty(300, K, device=dev, dtype=F32)
+    idx = torch.empty(300, K, device=dev, dtype=I32)
+    call("coocc_knn_topk", 300, 5000, K, ptr(T(q, dev)), ptr(T(k, dev)), ptr(val), ptr(idx))
+    v, i = native.knn_topk(q, k, K)
+    assert np.array_equal(idx.cpu().numpy(), i.astype(np.int32))
+    assert np.array_equal(val.cpu().numpy(), v)
+
+
+def test_knn_assign_last_writer(dev):
+    rng = np.random.default_rng(3)
+    nc, K, ns, nq = 256, 3, 50, 4000
+    val = (rng.random((nc, K)) * 20).astype(np.float32)
+    nn = rng.integers(0, 9999, (nc, K)).astype(np.int32)
+    group = rng.integers(0, nq, (nc, ns)).astype(np.int32)
+    winner = torch.empty(K, nq, device=dev, dtype=I32)
+    out = torch.empty(K, nq, device=dev, dtype=I32)
+    call("coocc_knn_assign", nc, K, ns, nq, 13.3, ptr(T(val, dev)), ptr(T(nn, dev)), ptr(T(group, dev)), ptr(winner), ptr(out))
+    assert np.array_equal(out.cpu().numpy(), native.knn_assign(val, nn, group, nq, 13.3).astype(np.int32))
+
+
+@pytest.mark.parametrize("name", sorted(cases.FUSER_CASES) + sorted(cases.ORACLE_ONLY_CASES))
+def test_fps_nn_fast_module_method(dev, name):
+    c = dict(cases.FUSER_CASES, **cases.ORACLE_ONLY_CASES)[name]
+    img, pts = cases.fuser_inputs(c)
+    qi, ki = ref_cpu.voxel_nonzero(pts), ref_cpu.voxel_nonzero(img)
+    f = pkg.BiFuser_N(c["C"], c["C"], c["knum"])
+    kw = dict(fps_num=2048, radius=6, max_cluster_samples=200, dist_thresh=13.3, num=c["knum"])
+    for q, k in ((qi, ki), (ki, qi)):
+        if q.shape[0] <= 2048 and c["knum"] > 1:
+            with pytest.raises(IndexError):
+                f.fps_NN_fast(q.to(dev), k.to(dev), **kw)
+            continue
+        got = f.fps_NN_fast(q.to(dev), k.to(dev), **kw)
+        want = ref_cpu.fps_nn_fast(q, k, **kw)
+        assert got.dtype == torch.int64 and torch.equal(got.cpu(), want)
+
+
+def test_knn_parts_vs_golden(dev, golden):
+    g = golden("knn_parts_k4")
+    c = cases.FUSER_CASES["fuser_k4"]
+    img, pts = cases.fuser_inputs(c)
+    q = ref_cpu.voxel_nonzero(pts)[:, 1:].float().contiguous().to(dev)
+    k = ref_cpu.voxel_nonzero(img)[:, 1:].float().contiguous().to(dev)
+    ridx = pkg.furthest_point_sample(q[None].contiguous(), 2048)[0]
+    assert np.array_equal(ridx.cpu().numpy(), g["repr_idx"])
+    rq = q[ridx.long()].contiguous()
+    grp = pkg.ball_query(0, 6, 200, q[None].contiguous(), rq[None].contiguous())[0]
+    assert np.array_equal(grp.cpu().numpy(), g["group"])
+    val = torch.empty(2048, 4, device=dev, dtype=F32)
+    idx = torch.empty(2048, 4, device=dev, dtype=I32)
+    call("coocc_knn_topk", 2048, k.shape[0], 4, ptr(rq), ptr(k), ptr(val), ptr(idx))
+    assert np.array_equal(idx.cpu().numpy(), g["nn"]) and np.array_equal(val.cpu().numpy(), g["val"])
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 7, 5, 3), (2, 128, 20, 10, 4), (1, 130, 9, 9, 2)])
+def test_layout_and_nonzero(dev, shape):
+    B, C, X, Y, Z = shape
+    g = torch.Generator().manual_seed(C)
+    img = torch.randn(shape, generator=g) * (torch.rand(B, 1, X, Y, Z, generator=g) < 0.6)
+    pts = torch.relu(torch.randn(shape, generator=g)) * (torch.rand(B, 1, X, Y, Z, generator=g) < 0.2)
+    V = X * Y * Z
+    cat4 = torch.empty(B * V, 4 * C, device=dev)
+    flags = torch.empty(2, B * V, device=dev, dtype=torch.uint8)
+    call("coocc_fuser_prepare", ptr(img.to(dev)), ptr(pts.to(dev)), ptr(cat4), ptr(flags[0]), ptr(flags[1]), B, C, V)
+    want = torch.cat([img.permute(0, 2, 3, 4, 1), pts.permute(0, 2, 3, 4, 1), torch.zeros(B, X, Y, Z, 2 * C)], -1).reshape(B * V, 4 * C)
+    assert torch.equal(cat4.cpu(), want)
+    for i, vol in enumerate((img, pts)):
+        nz = torch.nonzero(vol.sum(1))
+        lin = torch.empty(B * V, device=dev, dtype=I32)
+        cnt = torch.empty(1, device=dev, dtype=I32)
+        ws = torch.empty(B * V // 1024 + 2, device=dev, dtype=I32)
+        call("coocc_compact_flags", ptr(flags[i]), B * V, ptr(lin), ptr(cnt), ptr(ws), ws.numel() * 4)
+        n = int(cnt.item())
+        assert n == nz.shape[0]
+        bxyz = torch.empty(n, 4, device=dev, dtype=torch.int64)
+        xyz = torch.empty(n, 3, device=dev)
+        call("coocc_lin_to_coords", ptr(lin[:n]), n, X, Y, Z, ptr(xyz), ptr(bxyz))
+        assert torch.equal(bxyz.cpu(), nz) and torch.equal(xyz.cpu(), nz[:, 1:].float())
+    # generic transposes round-trip
+    rows = torch.empty(B * V, C, device=dev)
+    call("coocc_ncdhw_to_ndhwc", ptr(img.to(dev)), ptr(rows), B, C, V, C, 0)
+    assert torch.equal(rows.cpu(), img.permute(0, 2, 3, 4, 1).reshape(B * V, C))
+    back = torch.empty(B, C, V, device=dev)
+    call("coocc_ndhwc_to_ncdhw", ptr(rows), ptr(back), B, C, V, C, 0)
+    assert torch.equal(back.cpu().view(shape), img)
+
+
+def test_compaction_property_full_size(dev):
+    """BASELINE-size property: 200x200x16 grid, sortedness + count."""
+    total = 200 * 200 * 16
+    g = torch.Generator().manual_seed(1)
+    flags = (torch.rand(total, generator=g) < 0.65).to(torch.uint8).to(dev)
+    lin = torch.empty(total, device=dev, dtype=I32)
+    cnt = torch.empty(1, device=dev, dtype=I32)
+    ws = torch.empty(total // 1024 + 2, device=dev, dtype=I32)
+    call("coocc_compact_flags", ptr(flags), total, ptr(lin), ptr(cnt), ptr(ws), ws.numel() * 4)
+    n = int(cnt.item())
+    assert n == int(flags.sum().item())
+    l = lin[:n].long()
+    assert bool((l[1:] > l[:-1]).all()) and bool(flags[l].all())

@@ -1,0 +1,245 @@
+"""Module mirrors on the GPU vs the golden vectors (produced from the real reference) and the
+oracle: BiFuser_N, CustomResNet3D/FPN3D/OccHead, get_geometry/voxel_pooling/bev_pool, the render
+block, the library renderer, losses, and the whole hot path."""
+import numpy as np
+import pytest
+import torch
+
+import co_occ_amd as pkg
+import co_occ_amd.synth as synth
+from co_occ_amd import core, render as R
+from co_occ_amd._lib import call, ptr
+from oracle import cases, ref_cpu
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def load_seeded(module, seed, dev):
+    sd = synth.random_state_dict(module.state_dict(), seed=seed)
+    module.load_state_dict(sd)
+    return module.to(dev).eval(), sd
+
+
+@pytest.mark.parametrize("name", sorted(cases.FUSER_CASES))
+def test_bifuser_vs_golden(dev, golden, name):
+    c, g = cases.FUSER_CASES[name], golden(name)
+    img, pts = cases.fuser_inputs(c)
+    f, sd = load_seeded(pkg.BiFuser_N(c["C"], c["C"], c["knum"]), c["seed"], dev)
+    with torch.no_grad():
+        out = f(img.to(dev), pts.to(dev))
+    assert f.last_counts == (int(g["n_img"]), int(g["n_pts"]))
+    near_img, near_pts = f.last_near
+    assert np.array_equal(near_img.cpu().numpy().reshape(g["near_img"].shape), g["near_img"])     # bit-exact indices
+    assert np.array_equal(near_pts.cpu().numpy().reshape(g["near_pts"].shape), g["near_pts"])
+    assert tuple(out.shape) == g["out"].shape
+    assert_close(out.cpu(), g["out"], what=name)
+
+
+@pytest.mark.parametrize("name", sorted(cases.ORACLE_ONLY_CASES))
+def test_bifuser_vs_oracle_where_reference_is_broken(dev, name):
+    c = cases.ORACLE_ONLY_CASES[name]
+    img, pts = cases.fuser_inputs(c)
+    f, sd = load_seeded(pkg.BiFuser_N(c["C"], c["C"], c["knum"]), c["seed"], dev)
+    with torch.no_grad():
+        out = f(img.to(dev), pts.to(dev))
+    assert_close(out.cpu(), ref_cpu.bifuser_forward(sd, img, pts, c["knum"]), what=name)
+
+
+def test_bifuser_concat_rows_exact_layout(dev):
+    """K1+G1 intermediate: the 4C concat rows equal the oracle's cat([img,pts,fused_img,fused_pts])."""
+    c = cases.FUSER_CASES["fuser_k2_far"]
+    img, pts = cases.fuser_inputs(c)
+    f, sd = load_seeded(pkg.BiFuser_N(c["C"], c["C"], c["knum"]), c["seed"], dev)
+    cat4, _ = f.fuse(img.to(dev), pts.to(dev))
+    o = ref_cpu.bifuser_fuse(sd, img, pts, c["knum"])
+    assert_close(cat4.t.cpu().view(o["all_feats"].shape), o["all_feats"], tol=1e-5)
+
+
+def test_decoder_vs_golden(dev, golden):
+    c, g = cases.DECODER_CASE, golden("decoder")
+    x, rig, img_feats = cases.decoder_inputs(c)
+    cfg = synth.model_cfg(C=c["C"], block_inplanes=c["block_inplanes"], out_channels=c["fpn_out"],
+                          cascade_ratio=c["cascade_ratio"], final_occ_size=c["final_occ_size"],
+                          point_cloud_range=c["point_cloud_range"])
+    enc, _ = load_seeded(pkg.build_backbone(cfg["semantic_encoder"]), c["seed"], dev)
+    neck, _ = load_seeded(pkg.build_neck(cfg["semantic_neck"]), c["seed"], dev)
+    head, _ = load_seeded(pkg.build_head(cfg["pts_bbox_head"]), c["seed"], dev)
+    tr = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synth.rig_transform(rig))
+    with torch.no_grad():
+        mid = enc(x.to(dev))
+        sem = neck(mid)
+        res = head(voxel_feats=sem, img_feats=[img_feats[0].to(dev)], transform=tr)
+    for i in range(4):
+        assert tuple(mid[i].shape) == g["mid%d" % i].shape
+        assert_close(mid[i].cpu(), g["mid%d" % i], what="mid%d" % i)
+        assert_close(sem[i].cpu(), g["sem%d" % i], what="sem%d" % i)
+    assert_close(res["output_voxels"][0].cpu(), g["occ"], what="occ")
+    assert_close(head.last_out_voxel_feats.as_ncdhw().cpu(), g["out_voxel_feats"], what="out_voxel_feats")
+    assert np.array_equal(res["output_coords_fine"][0].cpu().numpy(), g["fine_coord"])          # bit-exact coords
+    assert_close(res["output_voxels_fine"][0].cpu(), g["fine_output"], what="fine")
+    dense = head.scatter_fine(res["output_voxels_fine"][0], res["output_coords_fine"][0], list(c["final_occ_size"]))
+    want = ref_cpu.scatter_fine(torch.from_numpy(g["fine_output"]), torch.from_numpy(g["fine_coord"]), c["final_occ_size"])
+    assert_close(dense.cpu(), want, what="pred_f")
+
+
+def test_geometry_and_pooling_vs_golden(dev, golden):
+    c, g = cases.POOL_CASE, golden("pool_geometry")
+    rig = synth.camera_rig(c["ncam"], c["input_size"], seed=c["seed"])
+    vt = pkg.ViewTransformerLiftSplatShootVoxel(grid_config=c["grid_config"], data_config=dict(input_size=c["input_size"]),
+                                                downsample=c["downsample"], numC_Trans=c["C"]).to(dev)
+    r = {k: v.to(dev) for k, v in rig.items() if torch.is_tensor(v)}
+    geom = vt.get_geometry(r["rots"], r["trans"], r["intrins"], r["post_rots"], r["post_trans"], r["bda"])
+    assert_close(geom.cpu(), g["geom"], what="geom")
+    vol = synth.lifted_volume(c["ncam"], vt.D, c["fmap"], c["C"], seed=c["seed"])
+    # pooling is tested on the golden geometry so that quantisation sees identical inputs
+    pooled = vt.voxel_pooling(torch.from_numpy(g["geom"]).to(dev), vol.to(dev))[0].cpu()
+    nz = torch.nonzero(pooled.abs().sum(0))
+    assert np.array_equal(nz.numpy(), g["pooled_nz_idx"])
+    assert_close(pooled[:, nz[:, 0], nz[:, 1], nz[:, 2]].t(), g["pooled_nz_val"], tol=1e-5, what="pooled")
+
+
+def test_bev_pool_op_and_ext_vs_oracle(dev):
+    rng = np.random.default_rng(2)
+    n, C, B, X, Y, Z = 20000, 12, 2, 9, 7, 3
+    feats = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32))
+    coords = torch.from_numpy(np.stack([rng.integers(0, X, n), rng.integers(0, Y, n), rng.integers(0, Z, n),
+                                        rng.integers(0, B, n)], 1))
+    want = ref_cpu.bev_pool(feats, coords, B, Z, X, Y)
+    got = pkg.bev_pool(feats.to(dev), coords.to(dev), B, Z, X, Y)
+    assert tuple(got.shape) == (B, C, Z, X, Y)
+    assert torch.equal(got.cpu(), want)                    # same summation order -> bit-exact
+    # ext entry points on pre-sorted intervals (bev_pool.py:37-61)
+    ranks = coords[:, 0] * (Y * Z * B) + coords[:, 1] * (Z * B) + coords[:, 2] * B + coords[:, 3]
+    order = torch.argsort(ranks, stable=True)
+    f2, c2, r2 = feats[order], coords[order], ranks[order]
+    kept = torch.ones(n, dtype=torch.bool); kept[1:] = r2[1:] != r2[:-1]
+    starts = torch.where(kept)[0].int()
+    lengths = torch.zeros_like(starts); lengths[:-1] = starts[1:] - starts[:-1]; lengths[-1] = n - starts[-1]
+    out = pkg.ops.bev_pool_ext.bev_pool_forward(f2.to(dev), c2.int().to(dev), lengths.to(dev), starts.to(dev), B, Z, X, Y)
+    assert torch.equal(out.permute(0, 4, 1, 2, 3).cpu(), want)
+    gout = torch.from_numpy(rng.standard_normal((B, Z, X, Y, C)).astype(np.float32))
+    xg = pkg.ops.bev_pool_ext.bev_pool_backward(gout.to(dev), c2.int().to(dev), lengths.to(dev), starts.to(dev), B, Z, X, Y)
+    assert torch.equal(xg.cpu(), gout[c2[:, 3], c2[:, 2], c2[:, 0], c2[:, 1]])
+
+
+def test_pooling_checksum_full_size(dev):
+    """BASELINE-size property (r50 lift: 6x112x16x44 points, C=128): every kept point lands in
+    exactly one voxel, so column sums are preserved."""
+    cfgm = synth.model_cfg()["img_view_transformer"]
+    cfgm.pop("type")
+    vt = pkg.ViewTransformerLiftSplatShootVoxel(**cfgm).to(dev)
+    rig = {k: v.to(dev) for k, v in synth.camera_rig(6, (256, 704)).items() if torch.is_tensor(v)}
+    geom = vt.get_geometry(rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
+    vol = synth.lifted_volume(6, vt.D, (16, 44), 128).to(dev)
+    pooled = vt.voxel_pooling(geom, vol)
+    g = ((geom - (vt.bx - vt.dx / 2.)) / vt.dx).long().view(-1, 3)
+    kept = ((g >= 0) & (g < vt.nx.long())).all(1)
+    want = vol.view(-1, 128)[kept].double().sum(0)
+    got = pooled.double().sum(dim=(0, 2, 3, 4))
+    assert_close(got.cpu(), want.cpu(), tol=1e-5)
+
+
+def _render_models(c, dev):
+    sig, ssd = load_seeded(R.MLP(128, 1, net_depth=1, skip_layer=None), c["seed"], dev)
+    rgb, rsd = load_seeded(R.MLP(128, 3, net_depth=3, skip_layer=None), c["seed"] + 1, dev)
+    return sig, rgb, ssd, rsd
+
+
+def test_render_block_vs_golden(dev, golden):
+    c, g = cases.RENDER_CASE, golden("render")
+    vf, rig = cases.render_inputs(c)
+    sig, rgb, ssd, rsd = _render_models(c, dev)
+    fr = ref_cpu.create_frustum(c["input_size"], c["downsample"], [2.0, 58.0, 0.5])
+    gemo = ref_cpu.get_geometry(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
+    with torch.no_grad():
+        rgbs, depths, maps = R.render_block(sig, rgb, vf.to(dev), gemo.to(dev), 16)
+    assert_close(maps[..., :3].cpu(), g["rgb_maps"], what="rgb_map")
+    assert_close(maps[..., 3].cpu(), g["depth_maps"], what="depth_map")
+    assert tuple(rgbs.shape) == g["rgbs"].shape and tuple(depths.shape) == g["depths"].shape
+    assert_close(rgbs.cpu(), g["rgbs"], what="rgbs")
+    assert_close(depths.cpu(), g["depths"], what="depths")
+    # MLP module itself (R1)
+    x = vf[0, :, :3, :5, :2].permute(1, 2, 3, 0).contiguous()
+    assert_close(rgb(x.to(dev)).cpu(), ref_cpu.mlp_forward(rsd, x, 3), tol=1e-5)
+
+
+def test_render_properties_full_size(dev):
+    """r101-size property checks (6 x 56 x 100 rays x 112 samples): colours in [0,1], depth in
+    [0,D], upsample of a constant map stays constant, rays entirely outside the grid render
+    rgb = sigmoid(0) weights from voxel (0,0,0)."""
+    c = cases.RENDER_CASE
+    sig, rgb, _, _ = _render_models(c, dev)
+    g = torch.Generator().manual_seed(3)
+    vf = torch.randn(1, 128, 100, 100, 8, generator=g).to(dev)
+    gemo = (torch.rand(1, 6, 112, 56, 100, 3, generator=g) * torch.tensor([130., 130., 12.]) - torch.tensor([65., 65., 6.])).to(dev)
+    gemo[0, 0, :, 0, :, :] = 500.0                                      # one row of rays fully outside
+    with torch.no_grad():
+        rgbs, depths, maps = R.render_block(sig, rgb, vf, gemo, 16)
+    assert tuple(rgbs.shape) == (6, 896, 1600, 3) and tuple(depths.shape) == (6, 896, 1600)
+    assert float(rgbs.min()) >= 0 and float(rgbs.max()) <= 1.0 + 1e-5
+    assert float(depths.min()) >= 0 and float(depths.max()) <= 112 + 1e-3
+    outside = maps[0, 0]                                                 # [W,4]: identical rays
+    assert float((outside - outside[0:1]).abs().max()) == 0.0
+    const = torch.full((1, 4, 5, 4), 0.37, device=dev)
+    r2 = torch.empty(1, 64, 80, 3, device=dev); d2 = torch.empty(1, 64, 80, device=dev)
+    call("coocc_upsample_maps", ptr(const), 1, 4, 5, 16, ptr(r2), ptr(d2))
+    assert float((r2 - 0.37).abs().max()) < 1e-6 and float((d2 - 0.37).abs().max()) < 1e-6
+
+
+def test_library_renderer_vs_golden(dev, golden):
+    c, g = cases.RAY_CASE, golden("rays")
+    vol, o, d, raw = cases.ray_inputs(c)
+    pts, z = R.sample_along_camera_ray(o.to(dev), d.to(dev), c["near_far"], c["n_samples"], det=True)
+    assert_close(pts.cpu(), g["pts"], tol=1e-6)
+    feat, mask = R.volume_sampling(torch.from_numpy(g["pts"]).to(dev), vol.to(dev), c["aabb"])
+    assert np.array_equal(mask.cpu().numpy(), g["mask"])
+    assert_close(feat.cpu(), g["feat"], tol=1e-5)
+    zz = torch.from_numpy(g["z"]).to(dev)
+    r = R.raw2outputs(raw.to(dev), zz, mask, white_bkgd=False)
+    assert_close(r["rgb"].cpu(), g["rgb"], tol=1e-5); assert_close(r["depth"].cpu(), g["depth"], tol=1e-5)
+    assert_close(r["weights"].cpu(), g["weights"], tol=1e-5)
+    assert_close(r["weights"].cpu(), g["get_weights"], tol=1e-5)         # == COOCC_Ray.get_weights
+    assert np.array_equal(r["mask"].cpu().numpy(), g["ray_mask"])
+    assert_close(R.raw2outputs(raw.to(dev), zz, mask, white_bkgd=True)["rgb"].cpu(), g["rgb_white"], tol=1e-5)
+
+
+def test_render_losses_vs_oracle(dev):
+    g = torch.Generator().manual_seed(8)
+    rgbs, depths = torch.rand(2, 32, 48, 3, generator=g), torch.rand(2, 32, 48, generator=g) * 112
+    rgb_gt = torch.rand(2, 32, 48, 3, generator=g)
+    depth_gt = torch.rand(2, 32, 48, generator=g) * 70 * (torch.rand(2, 32, 48, generator=g) < 0.3)
+    want = ref_cpu.render_losses(rgbs, depths, rgb_gt, depth_gt, 112)
+    got = R.render_losses(rgbs.to(dev), depths.to(dev), rgb_gt.to(dev), depth_gt.to(dev), 112)
+    for k in want:
+        assert_close(got[k].cpu(), want[k], tol=1e-5, what=k)
+
+
+def test_hot_path_end_to_end_vs_oracle(dev):
+    """Whole path on a config-1-sized scene (50x50x4, C=128, K=4... with 6 cameras) vs the
+    CPU oracle: coarse logits, fine logits/coords, rendered maps."""
+    grid, C, knum = (50, 50, 8), 128, 2
+    cfg = synth.model_cfg(C=C, knum=knum, final_occ_size=(100, 100, 16), point_cloud_range=(-25, -25, -5.0, 25, 25, 3.0))
+    model = pkg.build_detector(cfg)
+    sd = synth.random_state_dict(model.state_dict(), seed=5)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    img, pts = synth.voxel_inputs(grid, C=C, seed=77)
+    rig = synth.camera_rig(6, (64, 176), seed=77)
+    img_feats = [synth.image_feats(6, (4, 11), 512, seed=77)]
+    tr = synth.rig_transform(rig)
+    with torch.no_grad():
+        out = model.forward_hot_path(img.to(dev), pts.to(dev), None, [img_feats[0].to(dev)],
+                                     tuple(t.to(dev) if torch.is_tensor(t) else t for t in tr), render=False)
+    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    vf = ref_cpu.bifuser_forward(sub("occ_fuser."), img, pts, knum)
+    assert_close(out["voxel_feats"].cpu(), vf, what="voxel_feats")
+    sem = ref_cpu.fpn3d_forward(sub("semantic_neck."), ref_cpu.resnet3d_forward(sub("semantic_encoder."), vf))
+    h = ref_cpu.occhead_forward(sub("pts_bbox_head."), sem, img_feats, tr, 2, (100, 100, 16), (-25, -25, -5.0, 25, 25, 3.0))
+    assert_close(out["pred_c"].cpu(), h["output_voxels"], what="pred_c")
+    # argmax decisions can flip on near-ties; require the occupied sets to agree almost everywhere
+    a = set(map(tuple, out["output_coords_fine"][0].cpu().t().tolist()))
+    b = set(map(tuple, h["fine_coord"].t().tolist()))
+    assert len(a ^ b) <= 0.002 * len(b) + 8
+    if a == b:
+        assert_close(out["output_voxels_fine"][0].cpu(), h["fine_output"], what="fine")

@@ -1,0 +1,133 @@
+"""Host-side logic that needs no GPU: registry / config surface, state_dict keys, BN folding,
+CPU tensors are refused loudly (no fallback), and the multi-process (gloo, world_size 2)
+distributed layer."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import co_occ_amd as pkg
+import co_occ_amd.synth as synth
+from co_occ_amd import core, dist as cdist
+from conftest import ROOT
+
+
+def test_registry_builds_reference_config_names():
+    cfg = synth.model_cfg()
+    m = pkg.build_detector(cfg)
+    assert type(m).__name__ == "COOCC_Ray"
+    assert type(m.occ_fuser).__name__ == "BiFuser_N" and m.occ_fuser.knum == 2
+    assert type(m.semantic_encoder).__name__ == "CustomResNet3D"
+    assert type(m.semantic_neck).__name__ == "FPN3D"
+    assert type(m.pts_bbox_head).__name__ == "OccHead"
+    assert type(m.img_view_transformer).__name__ == "ViewTransformerLiftSplatShootVoxel"
+    for name in ("BiFuser_N",):
+        assert name in pkg.FUSION_LAYERS
+    with pytest.raises(KeyError):
+        pkg.build_backbone(dict(type="NoSuchBackbone"))
+    # encoder configs upstream of the path are accepted and ignored (coocc_multi_r50_256x704.py:96-135)
+    m2 = pkg.build_detector(dict(cfg, img_backbone=dict(type='ResNet', depth=50), pts_voxel_layer=dict(max_num_points=10)))
+    assert "img_backbone" in m2.ignored_cfg_keys
+
+
+def test_state_dict_keys_match_reference_checkpoint_layout():
+    sd = pkg.build_detector(synth.model_cfg()).state_dict()
+    for k in ["occ_fuser.con_enc.0.weight", "occ_fuser.con_enc.4.running_var", "occ_fuser.knn_enc.0.bias",
+              "semantic_encoder.input_proj.0.weight", "semantic_encoder.input_proj.1.running_mean",
+              "semantic_encoder.layers.1.0.downsample.0.weight", "semantic_encoder.layers.3.1.bn2.weight",
+              "semantic_neck.lateral_convs.2.0.conv.weight", "semantic_neck.fpn_convs.0.0.bn.running_var",
+              "pts_bbox_head.occ_convs.3.0.weight", "pts_bbox_head.occ_pred_conv.3.weight",
+              "pts_bbox_head.voxel_soft_weights.1.running_mean", "pts_bbox_head.img_mlp_0.0.bias",
+              "pts_bbox_head.img_mlp.1.weight", "pts_bbox_head.fine_mlp.3.bias",
+              "sigma_head.hidden_layers.0.weight", "sigma_head.output_layer.bias", "sigma_head.posi_encoder.scales",
+              "rgb_head.hidden_layers.2.weight"]:
+        assert k in sd, k
+    assert sd["occ_fuser.con_enc.0.weight"].shape == (256, 512, 3, 3, 3)
+    assert sd["occ_fuser.knn_enc.0.weight"].shape == (128, 256)
+    assert sd["pts_bbox_head.fine_mlp.0.weight"].shape == (64, 192)
+    assert sum(v.numel() for k, v in sd.items() if k.startswith("semantic_encoder") and k.endswith("weight") and v.dim() == 5) > 130e6
+
+
+def test_fold_bn_matches_batchnorm_eval():
+    bn = torch.nn.BatchNorm3d(7).eval()
+    g = torch.Generator().manual_seed(0)
+    bn.running_mean.copy_(torch.randn(7, generator=g)); bn.running_var.copy_(torch.rand(7, generator=g) + 0.5)
+    bn.weight.data.copy_(torch.rand(7, generator=g) + 0.5); bn.bias.data.copy_(torch.randn(7, generator=g))
+    s, b = core.fold_bn(bn)
+    x = torch.randn(2, 7, 3, 3, 3, generator=g)
+    assert torch.allclose(bn(x), x * s.view(1, 7, 1, 1, 1) + b.view(1, 7, 1, 1, 1), atol=1e-6)
+
+
+def test_cpu_tensors_are_refused_not_emulated():
+    f = pkg.build_fusion_layer(dict(type='BiFuser_N', knum=2, in_channels=16, out_channels=16))
+    x = torch.zeros(1, 16, 4, 4, 2)
+    with pytest.raises(Exception) as e:
+        f(x, x)
+    assert "GPU only" in str(e.value) or "no CPU fallback" in str(e.value)
+    with pytest.raises(Exception):
+        pkg.furthest_point_sample(torch.zeros(1, 8, 3), 2)
+
+
+def test_unsupported_reference_options_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        pkg.build_neck(dict(type='FPN3D', in_channels=[8, 16], out_channels=8))          # default GN norm
+    with pytest.raises(NotImplementedError):
+        pkg.build_backbone(dict(type='CustomResNet3D', depth=50, n_input_channels=8))
+
+
+def test_shard_range_partitions_everything():
+    for n in (0, 1, 7, 96, 336):
+        for w in (1, 2, 3, 8):
+            spans = [cdist.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_pack_unpack_maps_roundtrip():
+    r, d = torch.rand(2, 4, 5, 3), torch.rand(2, 4, 5)
+    r2, d2 = cdist.unpack_maps(cdist.pack_maps(r, d))
+    assert torch.equal(r, r2) and torch.equal(d, d2)
+
+
+_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, %(root)r)
+import co_occ_amd.dist as cd
+rank, world, local = cd.init(backend="gloo")
+assert world == 2
+g = torch.Generator().manual_seed(100 + rank)
+rgbs, depths = torch.rand(3, 4, 6, 3, generator=g), torch.rand(3, 4, 6, generator=g)
+R, D = cd.all_gather_maps(rgbs, depths)
+assert R.shape == (2, 3, 4, 6, 3) and D.shape == (2, 3, 4, 6)
+for r in range(2):
+    g = torch.Generator().manual_seed(100 + r)
+    er, ed = torch.rand(3, 4, 6, 3, generator=g), torch.rand(3, 4, 6, generator=g)
+    assert torch.equal(R[r], er) and torch.equal(D[r], ed)
+# ray-sharded render of one scene: 7 rows over 2 ranks
+full = torch.arange(7 * 5 * 4, dtype=torch.float32).view(7, 5, 4)
+lo, hi = cd.shard_range(7, rank, world)
+out = cd.gather_ray_shards(full[lo:hi].clone(), 7)
+assert torch.equal(out, full)
+assert cd.max_over_ranks(float(rank + 1), torch.device("cpu")) == 2.0
+cd.barrier()
+print("OK", rank)
+'''
+
+
+def test_gloo_world_size_2_all_gather(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % dict(root=ROOT))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("OK %d" % rank) in o, o[-2000:]
