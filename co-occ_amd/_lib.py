@@ -35,6 +35,8 @@ SIGNATURES = {
     "coocc_compact_flags": (I, [P, I, P, P, P, Z, P]),
     "coocc_lin_to_coords": (I, [P, I, I, I, I, P, P, P]),
     "coocc_furthest_point_sampling": (I, [I, I, I, P, P, P, P]),
+    "coocc_fps_voxels_ws": (Z, [I, I, I]),
+    "coocc_fps_voxels": (I, [P, I, I, I, I, I, P, P, Z, P]),
     "coocc_ball_query": (I, [I, I, I, F, F, I, P, P, P, P]),
     "coocc_knn_topk": (I, [I, I, I, P, P, P, P, P]),
     "coocc_knn_assign": (I, [I, I, I, I, F, P, P, P, P, P, P]),
@@ -66,6 +68,52 @@ SIGNATURES = {
 _lib = None
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing on the launch stream (bench.py's roofline numbers).
+    Disabled by default; when enabled each wrapped launch records an event pair."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    class _Region:
+        def __init__(self, owner, tag, work):
+            self.o, self.tag, self.work = owner, tag, work
+
+        def __enter__(self):
+            if self.o.enabled:
+                self.s = torch.cuda.Event(enable_timing=True)
+                self.e = torch.cuda.Event(enable_timing=True)
+                self.s.record()
+            return self
+
+        def __exit__(self, *a):
+            if self.o.enabled:
+                self.e.record()
+                self.o.records.append((self.tag, self.work, self.s, self.e))
+            return False
+
+    def region(self, tag, work=0.0):
+        return KernelTimer._Region(self, tag, work)
+
+    def summary(self):
+        """{tag: dict(launches, ms, work)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for tag, work, s, e in self.records:
+            d = out.setdefault(tag, dict(launches=0, ms=0.0, work=0.0))
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["work"] += work
+        return out
+
+    def reset(self):
+        self.records = []
+
+
+TIMER = KernelTimer()
+
+
+
 def load():
     """Load libcoocc_hip.so (built in-tree by __graft_entry__.build()).  Fails loudly."""
     global _lib
@@ -79,6 +127,8 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export it
         fn.restype, fn.argtypes = res, args
+    if os.environ.get("COOCC_FPS_THREADS"):        # tuning knob of the voxel FPS kernel (256 | 512 | 1024)
+        lib.coocc_fps_voxels_set_threads(int(os.environ["COOCC_FPS_THREADS"]))
     _lib = lib
     return lib
 
@@ -94,11 +144,18 @@ def check(rc):
 
 def call(name, *args):
     """Call an int-returning entry point on the current torch HIP stream."""
-    check(getattr(load(), name)(*args, stream()))
+    with TIMER.region(name):
+        check(getattr(load(), name)(*args, stream()))
 
 
 def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class DevPtr(ctypes.c_void_p):
+    """c_void_p that keeps its tensor alive until the foreign call has been issued, so that
+    temporaries such as ``ptr(x.contiguous())`` cannot be recycled by the caching allocator
+    while later arguments of the same call are still being built."""
 
 
 def ptr(t, dtype=None):
@@ -111,7 +168,9 @@ def ptr(t, dtype=None):
         raise CooccError("expected %s, got %s" % (dtype, t.dtype))
     if not t.is_contiguous():
         raise CooccError("tensor must be contiguous")
-    return c_void_p(t.data_ptr())
+    p = DevPtr(t.data_ptr())
+    p._keep = t
+    return p
 
 
 def host_f32(vals):

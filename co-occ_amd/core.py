@@ -15,49 +15,7 @@ from ._lib import ConvDesc, call, ptr
 _F32 = torch.float32
 
 
-class KernelTimer:
-    """Optional per-launch HIP-event timing on the launch stream (bench.py's roofline numbers).
-    Disabled by default; when enabled each wrapped launch records an event pair."""
-
-    def __init__(self):
-        self.enabled = False
-        self.records = []
-
-    class _Region:
-        def __init__(self, owner, tag, work):
-            self.o, self.tag, self.work = owner, tag, work
-
-        def __enter__(self):
-            if self.o.enabled:
-                self.s = torch.cuda.Event(enable_timing=True)
-                self.e = torch.cuda.Event(enable_timing=True)
-                self.s.record()
-            return self
-
-        def __exit__(self, *a):
-            if self.o.enabled:
-                self.e.record()
-                self.o.records.append((self.tag, self.work, self.s, self.e))
-            return False
-
-    def region(self, tag, work=0.0):
-        return KernelTimer._Region(self, tag, work)
-
-    def summary(self):
-        """{tag: dict(launches, ms, work)} -- call after torch.cuda.synchronize()."""
-        out = {}
-        for tag, work, s, e in self.records:
-            d = out.setdefault(tag, dict(launches=0, ms=0.0, work=0.0))
-            d["launches"] += 1
-            d["ms"] += s.elapsed_time(e)
-            d["work"] += work
-        return out
-
-    def reset(self):
-        self.records = []
-
-
-TIMER = KernelTimer()
+from ._lib import TIMER, KernelTimer  # noqa: E402,F401
 
 
 def conv_kernel_name(M, Cout, table):

@@ -11,19 +11,42 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
   hi = __shfl_xor(hi, m);
   return ((u64)hi << 32) | lo;
 }
+// Wave-wide max/min of a 64-bit key without the LDS crossbar: four DPP steps reduce each row
+// of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror), four v_readlane pairs
+// combine the rows on the scalar unit.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+  int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return ((u64)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
+  unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l);
+  unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((u64)hi << 32) | lo;
+}
+#define U64MAX(a, b) ((a) > (b) ? (a) : (b))
+#define U64MIN(a, b) ((a) < (b) ? (a) : (b))
 __device__ __forceinline__ u64 wave_max_u64(u64 v) {
-  for (int m = 32; m > 0; m >>= 1) {
-    u64 o = shfl_xor_u64(v, m);
-    v = o > v ? o : v;
-  }
-  return v;
+  u64 o;
+  o = dpp_u64<0xB1>(v); v = U64MAX(v, o);
+  o = dpp_u64<0x4E>(v); v = U64MAX(v, o);
+  o = dpp_u64<0x141>(v); v = U64MAX(v, o);
+  o = dpp_u64<0x140>(v); v = U64MAX(v, o);
+  u64 a = readlane_u64(v, 0), b = readlane_u64(v, 16), c = readlane_u64(v, 32), d = readlane_u64(v, 48);
+  a = U64MAX(a, b); c = U64MAX(c, d);
+  return U64MAX(a, c);
 }
 __device__ __forceinline__ u64 wave_min_u64(u64 v) {
-  for (int m = 32; m > 0; m >>= 1) {
-    u64 o = shfl_xor_u64(v, m);
-    v = o < v ? o : v;
-  }
-  return v;
+  u64 o;
+  o = dpp_u64<0xB1>(v); v = U64MIN(v, o);
+  o = dpp_u64<0x4E>(v); v = U64MIN(v, o);
+  o = dpp_u64<0x141>(v); v = U64MIN(v, o);
+  o = dpp_u64<0x140>(v); v = U64MIN(v, o);
+  u64 a = readlane_u64(v, 0), b = readlane_u64(v, 16), c = readlane_u64(v, 32), d = readlane_u64(v, 48);
+  a = U64MIN(a, b); c = U64MIN(c, d);
+  return U64MIN(a, c);
 }
 
 // ------------------------------------------------------------------ K2: FPS
@@ -120,6 +143,228 @@ extern "C" int coocc_furthest_point_sampling(int b, int n, int m, const float* p
   return COOCC_OK;
 }
 
+// ------------------------------------------------------------------ K2 on voxel lists (fused path)
+// Exact FPS for points that are distinct voxels of one X*Y*Z grid (what BiFuser_N feeds in:
+// bifuser_n.py:130-131,97).  Same selections as k_fps_f32 / the reference kernel, but the
+// per-iteration work is pruned: voxels are grouped in 4x4x8 tiles ("buckets", 128 positions,
+// coordinates implicit); every bucket caches the best key of its points in LDS.  A new sample s
+// can only lower temps of points closer than their current temp, so a bucket whose box is at
+// squared distance >= its cached maximal temp is skipped untouched (temps are minima, the skipped
+// values would not change).  Per iteration: (A) each lane tests its buckets and appends the
+// dirty ones to an LDS list (wave ballot compaction), (B) one wave per dirty bucket refreshes
+// its 128 positions (2 per lane, coalesced temp/index rows from L2) and its cached key with a
+// wave max, (C) block-wide max over the bucket keys.  After a few dozen samples only a handful
+// of buckets is dirty, so an iteration costs three barriers instead of a pass over all points.
+#define FT_X 4
+#define FT_Y 4
+#define FT_Z 8
+#define FT_P 128
+
+struct FpsCell { float temp; int k; };   // one voxel position of a bucket: running temp, list ordinal (-1 = empty)
+
+__global__ __launch_bounds__(256) void k_fpsv_scatter(const int32_t* __restrict__ lin, int n, int Y, int Z, int NBY,
+                                                       int NBZ, FpsCell* __restrict__ cell) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int l = lin[k];
+  int z = l % Z; l /= Z;
+  int y = l % Y; int x = l / Y;
+  int b = ((x / FT_X) * NBY + y / FT_Y) * NBZ + z / FT_Z;
+  int p = ((x % FT_X) * FT_Y + (y % FT_Y)) * FT_Z + (z % FT_Z);
+  cell[(size_t)b * FT_P + p] = FpsCell{1e10f, k};
+}
+
+// Buckets are owned by waves (bucket b -> wave b % NW), so the dirty test and the refresh of a
+// wave's buckets need no block-level list: lanes test up to 64 owned buckets, a ballot walks the
+// dirty ones.  Two barriers per sample: after the refresh, and after the per-wave maxima.
+// LDS-only barrier: the refresh stores to `cell` are consumed later by the SAME wave only, so the
+// block barrier must not wait for them (a plain __syncthreads() drains vmcnt and would put the L2
+// write latency on every iteration's critical path).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Bucket b is owned by lane ((b / NW) % 64) of wave (b % NW), slot (b / NW) / 64: its cached best
+// key, the position of that point and the bucket origin live in that lane's VGPRs, so the dirty
+// test, the refresh bookkeeping and the per-wave maximum need no LDS at all.  One block barrier
+// per sample (publishing the NW per-wave maxima, double-buffered by parity).
+template <int THREADS, int FPS_RMAX>
+__global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int Z, int NBY, int NBZ, int NB,
+                                                         const int32_t* __restrict__ lin, FpsCell* __restrict__ cell,
+                                                         int32_t* __restrict__ idx, int L, long long* dbg) {
+  constexpr int NW = THREADS / 64;
+  __shared__ u64 wbest[2][NW];
+  __shared__ int wloc[2][NW];   // packed sample coordinates x | y << 10 | z << 20 of the wave's best point
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned blockmask = (1u << L) - 1u;
+  const u64 init_hi = (u64)__float_as_uint(1e10f) << 32;
+  long long tA = 0, tM = 0, tB = 0, tT = 0, nd = 0;
+
+  u64 key[FPS_RMAX];    // best key of the owned bucket (0 = empty / no bucket)
+  int org[FPS_RMAX];    // bucket origin x | y << 10 | z << 20
+  int pos[FPS_RMAX];    // position (0..127) of the best point inside the bucket
+#pragma unroll
+  for (int r = 0; r < FPS_RMAX; ++r) {
+    const int b = (lane + 64 * r) * NW + wave;
+    key[r] = 0; pos[r] = 0; org[r] = 0;
+    if (b < NB) {                                  // the only divisions of the kernel
+      int bz = b % NBZ; int q = b / NBZ;
+      org[r] = ((q / NBY) * FT_X) | (((q % NBY) * FT_Y) << 10) | ((bz * FT_Z) << 20);
+    }
+  }
+  // initial keys (temp = 1e10 everywhere): the wave walks its buckets, lanes = positions
+#pragma unroll
+  for (int r = 0; r < FPS_RMAX; ++r) {
+    for (int src = 0; src < 64; ++src) {
+      const int b = (src + 64 * r) * NW + wave;    // wave-uniform
+      if (b >= NB) break;
+      u64 best = 0;
+      int bp = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int k = cell[(size_t)b * FT_P + lane + 64 * h].k;
+        u64 kk = k >= 0 ? (init_hi | (u64)(~fps_tiebreak(k, L, blockmask))) : 0ull;
+        if (kk > best) { best = kk; bp = lane + 64 * h; }
+      }
+      u64 wb = wave_max_u64(best);
+      u64 own = __ballot(best == wb);
+      int wp = __builtin_amdgcn_readlane(bp, (int)__ffsll((long long)own) - 1);
+      if (lane == src) { key[r] = wb; pos[r] = wp; }
+    }
+  }
+  if (tid == 0) idx[0] = 0;
+  int sx, sy, sz;
+  {
+    int l = lin[0];                                // sample 0 is list entry 0 (furthest_point_sample_cuda.cu:46-47)
+    sz = l % Z; l /= Z;
+    sy = l % Y; sx = l / Y;
+  }
+
+  for (int j = 1; j < m; ++j) {
+    long long c0 = dbg ? clock64() : 0;
+    // (A) dirty test + refresh of the owned buckets
+#pragma unroll
+    for (int r = 0; r < FPS_RMAX; ++r) {
+      if (r * 64 * NW >= NB) break;
+      bool d = false;
+      if (key[r]) {
+        int x0 = org[r] & 1023, y0 = (org[r] >> 10) & 1023, z0 = org[r] >> 20;
+        int dx = max(max(x0 - sx, sx - (x0 + FT_X - 1)), 0);
+        int dy = max(max(y0 - sy, sy - (y0 + FT_Y - 1)), 0);
+        int dz = max(max(z0 - sz, sz - (z0 + FT_Z - 1)), 0);
+        d = (float)(dx * dx + dy * dy + dz * dz) < __uint_as_float((unsigned)(key[r] >> 32));
+      }
+      u64 bal = __ballot(d);
+      nd += __popcll(bal);
+      while (bal) {
+        const int src = (int)__ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        const int bb = (src + 64 * r) * NW + wave;              // wave-uniform
+        const int o = __builtin_amdgcn_readlane(org[r], src);
+        const int x0 = o & 1023, y0 = (o >> 10) & 1023, z0 = o >> 20;
+        FpsCell* cp = cell + (size_t)bb * FT_P;
+        FpsCell c0_ = cp[lane], c1_ = cp[lane + 64];
+        u64 best = 0;
+        int bp = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const FpsCell c = h ? c1_ : c0_;
+          const int p = lane + 64 * h;
+          if (c.k >= 0) {
+            int ex = x0 + (p >> 5) - sx, ey = y0 + ((p >> 3) & 3) - sy, ez = z0 + (p & 7) - sz;
+            float t = fminf((float)(ex * ex + ey * ey + ez * ez), c.temp);
+            cp[p].temp = t;
+            u64 kk = ((u64)__float_as_uint(t) << 32) | (u64)(~fps_tiebreak(c.k, L, blockmask));
+            if (kk > best) { best = kk; bp = p; }
+          }
+        }
+        u64 wb = wave_max_u64(best);
+        u64 own = __ballot(best == wb);                          // exactly one lane: keys embed k
+        int wp = __builtin_amdgcn_readlane(bp, (int)__ffsll((long long)own) - 1);
+        if (lane == src) { key[r] = wb; pos[r] = wp; }
+      }
+    }
+    long long c1 = dbg ? clock64() : 0;
+    // (B) wave maximum over the owned buckets, published with the sample coordinates
+    u64 best = 0;
+    int bo = 0, bpz = 0;
+#pragma unroll
+    for (int r = 0; r < FPS_RMAX; ++r) {
+      if (key[r] > best) { best = key[r]; bo = org[r]; bpz = pos[r]; }
+    }
+    // origin fields never carry into each other: x0 + 3 < 1024 etc.
+    const int loc = bo + (bpz >> 5) + (((bpz >> 3) & 3) << 10) + ((bpz & 7) << 20);
+    u64 wb = wave_max_u64(best);
+    if (best == wb && wb) { wbest[j & 1][wave] = wb; wloc[j & 1][wave] = loc; }
+    if (!wb && lane == 0) wbest[j & 1][wave] = 0;
+    long long c2 = dbg ? clock64() : 0;
+    lds_barrier();
+    long long c3 = dbg ? clock64() : 0;
+    u64 g = wbest[j & 1][0];
+    int gw = 0;
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      u64 o = wbest[j & 1][w];
+      if (o > g) { g = o; gw = w; }
+    }
+    const int gl = wloc[j & 1][gw];
+    sx = gl & 1023; sy = (gl >> 10) & 1023; sz = gl >> 20;
+    if (tid == 0) idx[j] = (int)((~(unsigned)g) & ((1u << FPS_KBITS) - 1u));
+    // wbest/wloc parity j&1 is rewritten two iterations later, i.e. after one more barrier that
+    // every reader of these values has already passed.
+    if (dbg) { long long c4 = clock64(); tA += c1 - c0; tM += c2 - c1; tB += c3 - c2; tT += c4 - c3; }
+  }
+  if (dbg && lane == 0) {
+    long long* o = dbg + wave * 8;
+    o[0] = tA; o[1] = tM; o[2] = tB; o[3] = tT; o[4] = 0; o[5] = nd;
+  }
+}
+
+extern "C" size_t coocc_fps_voxels_ws(int X, int Y, int Z) {
+  size_t nb = (size_t)((X + FT_X - 1) / FT_X) * ((Y + FT_Y - 1) / FT_Y) * ((Z + FT_Z - 1) / FT_Z);
+  return nb * FT_P * sizeof(FpsCell);
+}
+
+static int g_fps_threads = 256;
+static long long* g_fps_dbg = nullptr;
+extern "C" void coocc_fps_voxels_set_debug(long long* p) { g_fps_dbg = p; }
+extern "C" void coocc_fps_voxels_set_threads(int t) { g_fps_threads = t; }
+
+extern "C" int coocc_fps_voxels(const int32_t* lin, int n, int X, int Y, int Z, int m, int32_t* idx, void* ws,
+                                size_t ws_bytes, void* stream) {
+  COOCC_CHECK_ARG(lin && idx && ws && n > 0 && m >= 0 && X > 0 && Y > 0 && Z > 0, "fps_voxels: bad args");
+  COOCC_CHECK_ARG(n < (1 << FPS_KBITS), "fps_voxels: n must be < 2^22");
+  COOCC_CHECK_ARG(X <= 1020 && Y <= 1020 && Z <= 1016, "fps_voxels: grid dims must fit 10-bit packed coordinates");
+  if (m == 0) return COOCC_OK;
+  const int NBX = (X + FT_X - 1) / FT_X, NBY = (Y + FT_Y - 1) / FT_Y, NBZ = (Z + FT_Z - 1) / FT_Z;
+  const long long NB = (long long)NBX * NBY * NBZ;
+  // 4 waves (one per SIMD) keep the per-sample instruction stream short; larger bucket tables
+  // spread over more waves so that a lane owns at most 8 buckets.
+  int threads = g_fps_threads;
+  while (NB > 8ll * threads && threads < 1024) threads *= 2;
+  COOCC_CHECK_ARG(NB <= 8ll * threads, "fps_voxels: grid has too many buckets (use coocc_furthest_point_sampling)");
+  if (ws_bytes < coocc_fps_voxels_ws(X, Y, Z)) return coocc_set_error(COOCC_ENOMEM, "fps_voxels: workspace too small");
+  const int R = (int)((NB + threads - 1) / threads);
+  FpsCell* cell = (FpsCell*)ws;
+  hipStream_t s = as_stream(stream);
+  COOCC_HIP(hipMemsetAsync(cell, 0xFF, sizeof(FpsCell) * (size_t)NB * FT_P, s));
+  hipLaunchKernelGGL(k_fpsv_scatter, dim3(cdiv(n, 256)), dim3(256), 0, s, lin, n, Y, Z, NBY, NBZ, cell);
+  int L = 0;
+  while ((2 << L) <= n && L < 10) ++L;
+#define FPS_LAUNCH(T, RM) \
+  hipLaunchKernelGGL((k_fps_voxels<T, RM>), dim3(1), dim3(T), 0, s, n, m, Y, Z, NBY, NBZ, (int)NB, lin, cell, idx, L, g_fps_dbg)
+#define FPS_PICK(T)                       \
+  do {                                    \
+    if (R <= 2) FPS_LAUNCH(T, 2);         \
+    else if (R <= 3) FPS_LAUNCH(T, 3);    \
+    else if (R <= 4) FPS_LAUNCH(T, 4);    \
+    else FPS_LAUNCH(T, 8);                \
+  } while (0)
+  if (threads == 256) FPS_PICK(256);
+  else if (threads == 512) FPS_PICK(512);
+  else FPS_PICK(1024);
+  COOCC_LAUNCH_CHECK("k_fps_voxels");
+  return COOCC_OK;
+}
+
 // ------------------------------------------------------------------ K4: ball query
 // ball_query_kernel (ball_query_cuda.cu:11-54): serial scan per centre, keep the first
 // `nsample` hits in index order, pad with the first hit, zeros when there is none.
@@ -201,7 +446,7 @@ __global__ __launch_bounds__(256) void k_knn_topk(int nq, int nk, const float* _
       best[K - 1] = ~0ull;
     }
     if (lane == 0) {
-      val[(size_t)r * K + o] = __fsqrt_rn(__uint_as_float((unsigned)(mn >> 32)));
+      val[(size_t)r * K + o] = (float)__dsqrt_rn((double)__uint_as_float((unsigned)(mn >> 32)));  // correctly rounded
       idx[(size_t)r * K + o] = (int32_t)(unsigned)mn;
     }
   }

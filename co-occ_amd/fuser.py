@@ -17,8 +17,36 @@ from .registry import FUSION_LAYERS
 _I32, _F32, _I64 = torch.int32, torch.float32, torch.int64
 
 
-def _fps_nn_xyz(query_xyz, key_xyz, fps_num, radius, max_cluster_samples, dist_thresh, num):
-    """Index search on float xyz rows.  Returns int32 [num, Q] of key ordinals (-1 = none)."""
+_fps_ws = {}
+_side = {}
+
+
+def _side_stream(dev, cur):
+    key = (dev.index, cur.cuda_stream)
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=dev)
+    return _side[key]
+
+FPS_MAX_BUCKETS = 8 * 1024     # FPS_RMAX * threads of csrc/knn.hip k_fps_voxels
+
+
+def _fps_voxels(q_lin, grid, fps_num):
+    """FPS on a voxel list with the bucket-pruned kernel (same result as the generic one)."""
+    dev = q_lin.device
+    X, Y, Z = grid
+    need = int(_lib.load().coocc_fps_voxels_ws(X, Y, Z))
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    if key not in _fps_ws or _fps_ws[key].numel() < need:
+        _fps_ws[key] = torch.empty(need, device=dev, dtype=torch.uint8)
+    ws = _fps_ws[key]
+    out = torch.empty(1, fps_num, device=dev, dtype=_I32)
+    call("coocc_fps_voxels", ptr(q_lin), q_lin.numel(), X, Y, Z, fps_num, ptr(out), ptr(ws), ws.numel())
+    return out
+
+
+def _fps_nn_xyz(query_xyz, key_xyz, fps_num, radius, max_cluster_samples, dist_thresh, num, q_lin=None, grid=None):
+    """Index search on float xyz rows.  Returns int32 [num, Q] of key ordinals (-1 = none).
+    q_lin/grid: the queries as distinct voxels of one grid -> pruned FPS kernel."""
     dev = query_xyz.device
     Q, Nk = query_xyz.shape[0], key_xyz.shape[0]
     if Q <= fps_num:
@@ -33,9 +61,12 @@ def _fps_nn_xyz(query_xyz, key_xyz, fps_num, radius, max_cluster_samples, dist_t
         call("coocc_knn_topk", Q, Nk, 1, ptr(query_xyz), ptr(key_xyz), ptr(val), ptr(nn_))
         call("coocc_knn_threshold", Q, float(dist_thresh), ptr(val), ptr(nn_), ptr(out))
         return out
-    repr_idx = torch.empty(1, fps_num, device=dev, dtype=_I32)
-    temp = torch.empty(1, Q, device=dev, dtype=_F32)
-    call("coocc_furthest_point_sampling", 1, Q, fps_num, ptr(query_xyz), ptr(temp), ptr(repr_idx))
+    if q_lin is not None and grid is not None and (grid[0] + 3) // 4 * ((grid[1] + 3) // 4) * ((grid[2] + 7) // 8) <= FPS_MAX_BUCKETS:
+        repr_idx = _fps_voxels(q_lin, grid, fps_num)
+    else:
+        repr_idx = torch.empty(1, fps_num, device=dev, dtype=_I32)
+        temp = torch.empty(1, Q, device=dev, dtype=_F32)
+        call("coocc_furthest_point_sampling", 1, Q, fps_num, ptr(query_xyz), ptr(temp), ptr(repr_idx))
     repr_xyz = query_xyz[repr_idx[0].long()].contiguous()
     val = torch.empty(fps_num, num, device=dev, dtype=_F32)
     nn_ = torch.empty(fps_num, num, device=dev, dtype=_I32)
@@ -118,20 +149,30 @@ class BiFuser_N(nn.Module):
         K = self.knum
         kw = dict(fps_num=2048, radius=6, max_cluster_samples=200, dist_thresh=13.3, num=K)
         if Np and Ni:
+            vox = (X, Y, Z) if B == 1 else None
+            # The two search directions are independent (each is a 2047-step dependent chain on
+            # one CU): the img->pts search runs on a side stream next to the pts->img one.
+            cur = torch.cuda.current_stream(dev)
+            side = _side_stream(dev, cur)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                # img queries <- nearest pts keys (:150-162); for knum > 1 the reference indexes
+                # inds_img with the pts ordinals (:158) -- kept
+                near_pts = _fps_nn_xyz(xyz_img, xyz_pts, q_lin=lin_img if vox else None, grid=vox, **kw)
+                rows_p = torch.empty(K, Ni, device=dev, dtype=_I32)
+                base, nbase = (lin_pts, Np) if K == 1 else (lin_img, Ni)
+                for k in range(K):
+                    call("coocc_index_rows_i32", ptr(base), nbase, ptr(near_pts[k]), Ni, ptr(rows_p[k]))
             # pts queries <- nearest img keys (bifuser_n.py:137-148)
-            near_img = _fps_nn_xyz(xyz_pts, xyz_img, **kw)
+            near_img = _fps_nn_xyz(xyz_pts, xyz_img, q_lin=lin_pts if vox else None, grid=vox, **kw)
             rows = torch.empty(K, Np, device=dev, dtype=_I32)
             for k in range(K):
                 call("coocc_index_rows_i32", ptr(lin_img), Ni, ptr(near_img[k]), Np, ptr(rows[k]))
             gather_conv_rows(cat4, 0, packs["knn"], rows, lin_pts, cat4, 2 * C, C, C)
-            # img queries <- nearest pts keys (:150-162); for knum > 1 the reference indexes
-            # inds_img with the pts ordinals (:158) -- kept
-            near_pts = _fps_nn_xyz(xyz_img, xyz_pts, **kw)
-            rows = torch.empty(K, Ni, device=dev, dtype=_I32)
-            base, nbase = (lin_pts, Np) if K == 1 else (lin_img, Ni)
-            for k in range(K):
-                call("coocc_index_rows_i32", ptr(base), nbase, ptr(near_pts[k]), Ni, ptr(rows[k]))
-            gather_conv_rows(cat4, C, packs["knn"], rows, lin_img, cat4, 3 * C, 0, C)
+            cur.wait_stream(side)
+            for t in (near_pts, rows_p):
+                t.record_stream(cur)
+            gather_conv_rows(cat4, C, packs["knn"], rows_p, lin_img, cat4, 3 * C, 0, C)
             self.last_near = (near_img, near_pts)
         elif Np or Ni:
             raise IndexError("BiFuser_N: one modality has no non-empty voxel (the reference fails on empty keys)")

@@ -71,6 +71,13 @@ int coocc_lin_to_coords(const int32_t* lin, int n, int X, int Y, int Z, float* x
 int coocc_furthest_point_sampling(int b, int n, int m, const float* points, float* temp,
                                   int32_t* idx, void* stream);
 
+/* Same selection as coocc_furthest_point_sampling for a list of DISTINCT voxels of one X*Y*Z
+ * grid (lin:[n] ascending linear ids, batch 0) -- what bifuser_n.py:97 passes in -- with
+ * bucket pruning (4x4x8 voxel tiles cached in LDS).  ws >= coocc_fps_voxels_ws(X,Y,Z) bytes. */
+size_t coocc_fps_voxels_ws(int X, int Y, int Z);
+int coocc_fps_voxels(const int32_t* lin, int n, int X, int Y, int Z, int m, int32_t* idx, void* ws,
+                     size_t ws_bytes, void* stream);
+
 /* [EXT] ball_query_wrapper (M/ops/ball_query/src/ball_query.cpp:32-45; kernel
  * ball_query_cuda.cu:11-54).  new_xyz:[b,m,3] centres, xyz:[b,n,3], idx:[b,m,nsample]
  * i32 (zeroed here, as ball_query.py:35 does). */

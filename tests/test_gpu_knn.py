@@ -32,6 +32,23 @@ def test_fps_ties_match_reference_block_reduction(dev, n, m, hi):
     assert np.array_equal(got, native.fps(pts, m))
 
 
+@pytest.mark.parametrize("grid,p,m", [((40, 40, 4), 0.7, 2048), ((100, 100, 8), 0.65, 2048), ((100, 100, 8), 0.12, 2048),
+                                      ((33, 21, 5), 0.5, 700), ((200, 200, 16), 0.3, 512), ((7, 5, 3), 1.0, 105)])
+def test_fps_voxels_bucketed_equals_reference_rule(dev, grid, p, m):
+    """The pruned voxel kernel must select exactly what the reference block reduction selects."""
+    X, Y, Z = grid
+    g = torch.Generator().manual_seed(X * 7 + Z)
+    lin = torch.nonzero(torch.rand(X * Y * Z, generator=g) < p)[:, 0].int()
+    n = lin.numel()
+    m = min(m, n)
+    xyz = torch.stack([lin // (Y * Z), (lin // Z) % Y, lin % Z], 1).float()
+    want = native.fps(xyz[None].numpy(), m)[0]
+    from co_occ_amd.fuser import _fps_voxels
+    got = _fps_voxels(lin.to(dev), grid, m)[0].cpu().numpy()
+    assert np.array_equal(got, want)
+    assert np.array_equal(pkg.furthest_point_sample(xyz[None].contiguous().to(dev), m)[0].cpu().numpy(), want)
+
+
 def test_fps_float_coordinates(dev):
     rng = np.random.default_rng(7)
     pts = (rng.integers(-400, 400, (1, 5000, 3)) / 8.0).astype(np.float32)   # exactly representable

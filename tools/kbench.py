@@ -1,0 +1,113 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmarks at the r50 workload's shapes (HIP events on the launch stream).
+    python tools/kbench.py [fps] [knn] [conv] [render] [pool]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import co_occ_amd as pkg  # noqa: E402
+import co_occ_amd.synth as synth  # noqa: E402
+from co_occ_amd import core, fuser  # noqa: E402
+from co_occ_amd._lib import call, ptr  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, n=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+def voxel_lists(grid=(100, 100, 8)):
+    img, pts = synth.voxel_inputs(grid, C=4, seed=1234)
+    li = torch.nonzero(img.sum(1).flatten())[:, 0].int().to(dev)
+    lp = torch.nonzero(pts.sum(1).flatten())[:, 0].int().to(dev)
+    return li, lp
+
+
+def bench_fps():
+    for grid in ((100, 100, 8), (200, 200, 16)):
+        li, lp = voxel_lists(grid)
+        for name, lin in (("img", li), ("pts", lp)):
+            X, Y, Z = grid
+            xyz = torch.stack([lin // (Y * Z), (lin // Z) % Y, lin % Z], 1).float().contiguous()
+            t_v = timeit(lambda: fuser._fps_voxels(lin, grid, 2048))
+            t_g = timeit(lambda: pkg.furthest_point_sample(xyz[None], 2048), n=2, warm=1)
+            a = fuser._fps_voxels(lin, grid, 2048)
+            b = pkg.furthest_point_sample(xyz[None], 2048)
+            print("fps %s %-4s n=%6d  voxel-bucket %.3f ms (%.2f us/iter)  generic %.3f ms  equal=%s" % (
+                "x".join(map(str, grid)), name, lin.numel(), t_v, 1e3 * t_v / 2047, t_g, bool(torch.equal(a, b))))
+
+
+def bench_knn():
+    li, lp = voxel_lists()
+    grid = (100, 100, 8)
+    X, Y, Z = grid
+    for qn, q, k in (("pts->img", lp, li), ("img->pts", li, lp)):
+        qx = torch.stack([q // (Y * Z), (q // Z) % Y, q % Z], 1).float().contiguous()
+        kx = torch.stack([k // (Y * Z), (k // Z) % Y, k % Z], 1).float().contiguous()
+        rq = qx[fuser._fps_voxels(q, grid, 2048)[0].long()].contiguous()
+        val = torch.empty(2048, 2, device=dev)
+        idx = torch.empty(2048, 2, device=dev, dtype=torch.int32)
+        t1 = timeit(lambda: call("coocc_knn_topk", 2048, kx.shape[0], 2, ptr(rq), ptr(kx), ptr(val), ptr(idx)))
+        grp = torch.empty(2048, 200, device=dev, dtype=torch.int32)
+        t2 = timeit(lambda: call("coocc_ball_query", 1, qx.shape[0], 2048, 0.0, 6.0, 200, ptr(rq), ptr(qx), ptr(grp)))
+        print("%s: topk %.3f ms  ball_query %.3f ms" % (qn, t1, t2))
+
+
+def bench_conv():
+    shapes = [  # (name, Cin, Cout, grid, k, stride)
+        ("con_enc.0", 512, 256, (100, 100, 8), 3, 1), ("con_enc.3", 256, 128, (100, 100, 8), 3, 1),
+        ("enc.l0.conv", 128, 128, (100, 100, 8), 3, 1), ("enc.l1.conv1", 128, 256, (100, 100, 8), 3, 2),
+        ("enc.l1.conv2", 256, 256, (50, 50, 4), 3, 1), ("enc.l2.conv2", 512, 512, (25, 25, 2), 3, 1),
+        ("enc.l3.conv2", 1024, 1024, (13, 13, 1), 3, 1), ("fpn.out0", 256, 256, (100, 100, 8), 3, 1),
+        ("head.occ0", 256, 128, (100, 100, 8), 3, 1), ("lat0 1x1", 128, 256, (100, 100, 8), 1, 1),
+        ("pred 1x1", 128, 64, (100, 100, 8), 1, 1), ("cls 1x1", 64, 17, (100, 100, 8), 1, 1),
+    ]
+    tot = 0
+    for name, ci, co, g, k, st in shapes:
+        x = core.Rows(torch.randn(g[0] * g[1] * g[2], ci, device=dev), 1, g[0], g[1], g[2], ci)
+        pc = core.PackedConv(torch.randn(co, ci, k, k, k, device=dev) * 0.02, ksize=k, stride=st, pad=k // 2)
+        t = timeit(lambda: core.conv_rows(x, pc, relu=True), n=3, warm=1)
+        M = (core.out_dim(g[0], k, st, k // 2) * core.out_dim(g[1], k, st, k // 2) * core.out_dim(g[2], k, st, k // 2))
+        fl = 2.0 * M * ci * co * k ** 3
+        print("%-14s %4d->%4d %-11s k%d s%d  %8.3f ms  %6.1f TFLOP/s  [%s]" % (
+            name, ci, co, "x".join(map(str, g)), k, st, t, fl / t / 1e9, core.conv_kernel_name(M, co, False)))
+
+
+
+
+def bench_fpsdbg():
+    import ctypes
+    from co_occ_amd import _lib
+    lib = _lib.load()
+    li, lp = voxel_lists((100, 100, 8))
+    dbg = torch.zeros(16 * 8, device=dev, dtype=torch.int64)
+    lib.coocc_fps_voxels_set_debug(ctypes.c_void_p(dbg.data_ptr()))
+    for name, lin in (("img", li), ("pts", lp)):
+        dbg.zero_()
+        fuser._fps_voxels(lin, (100, 100, 8), 2048)
+        torch.cuda.synchronize()
+        d = dbg.view(16, 8).cpu()
+        print(name, "per-iteration cycles by wave [test+refresh, wave max, barrier, tail | dirty buckets total]")
+        for w in range(16):
+            if int(d[w].sum()):
+                print("  wave %2d: %s  dirty=%d" % (w, " ".join("%7.0f" % (float(v) / 2047) for v in d[w, :4]), int(d[w, 5])))
+    lib.coocc_fps_voxels_set_debug(ctypes.c_void_p(0))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["fps", "knn", "conv"]
+    with torch.no_grad():
+        for w in which:
+            globals()["bench_" + w]()
