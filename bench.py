@@ -68,6 +68,23 @@ def step(model, s, world):
     return out
 
 
+def usable_cores():
+    """Host cores this process may actually use: the cgroup CPU quota when there is one (the GPU
+    box exposes 256 logical CPUs but caps the container; oversubscribing OpenMP thrashes)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(sd, s, cfgname, seconds_cap):
     """The oracle's literal CPU restatement of the same step (gather-then-MLP render, materialised
     concat, sort-based pooling is not part of the step) on this host's cores, one sample."""
@@ -79,7 +96,7 @@ def cpu_baseline(sd, s, cfgname, seconds_cap):
     fr = ref_cpu.create_frustum((c["fmap"][0] * 16, c["fmap"][1] * 16), 16, [2.0, 58.0, 0.5])
     gemo = ref_cpu.get_geometry(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
     sdc = {k: v.cpu() for k, v in sd.items()}
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(usable_cores())
     t0 = time.perf_counter()
     with torch.no_grad():
         ref_cpu.hot_path_forward(sdc, cpu["img"], cpu["pts"], gemo, cpu["img_feats"], synth.rig_transform(rig), knum=c["knum"],
@@ -174,8 +191,14 @@ def main():
         if DOMINANT in ksum:
             v = ksum[DOMINANT]
             ach = v["work"] / (v["ms"] * 1e-3) / 1e12
+            traffic = None
+            try:   # HBM bytes per launch from the committed PMC passes (cannot be collected inside this process)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+                traffic = tj[DOMINANT]["bytes_per_launch"] if args.config == "r50" else None
+            except Exception:
+                pass
             roof = dict(bound="mfma", kernel=DOMINANT, achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, launches=v["launches"],
+                        frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=traffic, launches=v["launches"],
                         avg_launch_ms=round(v["ms"] / v["launches"], 4),
                         share_of_timed_kernels=round(v["ms"] / tot, 3))
         rk = [ksum[k] for k in ("k_render_nearest", "k_upsample_maps") if k in ksum]
