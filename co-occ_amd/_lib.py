@@ -21,7 +21,7 @@ class ConvDesc(ctypes.Structure):
                [("ws_floats", c_int64)] + \
                [(n, c_int) for n in ("M", "Cin", "Cout", "taps", "in_stride", "out_stride", "res_stride",
                                      "B", "Xi", "Yi", "Zi", "Xo", "Yo", "Zo", "ksize", "stride", "pad",
-                                     "relu", "res_mode", "splitk")]
+                                     "relu", "res_mode", "splitk", "tile_hint")]
 
 
 P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_int64

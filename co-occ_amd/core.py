@@ -18,14 +18,26 @@ _F32 = torch.float32
 from ._lib import TIMER, KernelTimer  # noqa: E402,F401
 
 
+TILE_HINT = int(__import__("os").environ.get("COOCC_CONV_TILE", "0"))   # 0 auto | 128 | 160 (tuning knob)
+CONV_V2 = int(__import__("os").environ.get("COOCC_CONV_V2", "1"))       # mirrors csrc/conv3d.hip
+
+
 def conv_kernel_name(M, Cout, table):
     """Mirror of the tile-configuration rule in csrc/conv3d.hip (coocc_conv_fwd)."""
     if Cout <= 32:
         t = "128,32,32,32"
     elif Cout <= 64:
         t = "128,64,32,64"
+    elif M < 8192:
+        t = "64,128,32,64"
     else:
-        t = "128,128,64,64" if M >= 8192 else "64,128,32,64"
+        def util(bm):
+            tiles = -(-M // bm) * (-(-Cout // 128))
+            return tiles * bm / float(-(-tiles // 512) * 512)
+        big = TILE_HINT == 160 or (TILE_HINT == 0 and util(160) > util(128) * 1.02)
+        if not table and CONV_V2:
+            return "k_conv2<%d>" % (160 if big else 128)      # software-pipelined large-layer kernel
+        t = "160,128,160,32" if big else "128,128,64,64"
     return "k_conv<%s,%s>" % (t, "table" if table else "geom")
 
 
@@ -165,6 +177,7 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
     d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = x.B, x.X, x.Y, x.Z, Xo, Yo, Zo
     d.ksize, d.stride, d.pad = pc.ksize, pc.stride, pc.pad
     d.relu, d.res_mode, d.splitk = int(relu), (res_mode or (1 if res is not None else 0)), splitk
+    d.tile_hint = TILE_HINT
     with TIMER.region(conv_kernel_name(M, pc.Cout, False), 2.0 * M * pc.Cin * pc.Cout * pc.taps):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     return out
@@ -193,6 +206,7 @@ def linear_rows(x2d, pc, relu=False, out=None, out_coff=0, in_coff=0, in_C=None)
     d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = 1, n, 1, 1, n, 1, 1
     d.ksize, d.stride, d.pad = 1, 1, 0
     d.relu, d.res_mode, d.splitk = int(relu), 0, 0
+    d.tile_hint = TILE_HINT
     with TIMER.region(conv_kernel_name(n, pc.Cout, False), 2.0 * n * Cin * pc.Cout):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     return out
@@ -219,6 +233,7 @@ def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_co
     d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = 1, 1, 1, 1, 1, 1, 1
     d.ksize, d.stride, d.pad = 1, 1, 0
     d.relu, d.res_mode, d.splitk = int(relu), 2, 1
+    d.tile_hint = TILE_HINT
     with TIMER.region(conv_kernel_name(M, pc.Cout, True), 2.0 * M * C * pc.Cout * K):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
 

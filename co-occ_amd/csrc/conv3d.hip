@@ -25,6 +25,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS_ST 36  // LDS row stride in floats: 144 B rows keep ds_read_b128 conflict-free
 #define NPAD_TO 128
 
+// Packed weight layout ("fragment-major"): for K-chunk c = tap*kchunks + kc and 128-column group g,
+// one 16 KB block [wn 0..3][q 0..3][lane 0..63][4]: lane (h = lane>>5, li = lane&31) of wave wn holds
+// W[n = 128g + 32wn + li][k = 32c' + 8q + 4h + 0..3] -- exactly the B operand of four MFMA k-steps, so
+// k_conv2 loads B fragments straight from global memory (no LDS), and k_conv stages the same block.
+__host__ __device__ inline size_t wfrag_index(size_t chunk, int ngroups, int n, int kk) {
+  const int g = n >> 7, wn = (n >> 5) & 3, li = n & 31, q = kk >> 3, h = (kk >> 2) & 1, e = kk & 3;
+  return ((chunk * ngroups + g) * 4 + wn) * 1024 + (size_t)q * 256 + (size_t)(h * 32 + li) * 4 + e;
+}
+
 struct ConvK {
   const float* in; const float* w; float* out; const float* scale; const float* bias;
   const float* res; const int32_t* gather; const int32_t* out_rows; float* ws;
@@ -33,6 +42,9 @@ struct ConvK {
   int Xi, Yi, Zi, Xo, Yo, Zo, ksize, stride, pad;
   int relu, res_mode, iters_per_split, total_iters, splitk;
   int mtiles, ntiles, mtiles_per_xcd;
+  int dephase;   // s_sleep units for the second workgroup of each CU (see k_conv)
+  int flags;     // bit0: s_setprio(1) around the MFMA cluster
+  unsigned in_bytes, w_bytes;   // buffer sizes for the buffer_load variant (k_conv2)
 };
 
 __device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t rrow) {
@@ -50,8 +62,10 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int PA = BM / 32, PB = BN / 32;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
-  __shared__ float As[2][BM * LDS_ST];
-  __shared__ float Bs[2][BN * LDS_ST];
+  // two LDS buffers when two workgroups still fit a CU (160 KB), else one buffer + a second barrier
+  constexpr int NBUF = (2 * 2 * (BM + BN) * LDS_ST * 4 <= 160 * 1024) ? 2 : 1;
+  __shared__ float As[NBUF][BM * LDS_ST];
+  __shared__ float Bs[NBUF][BN * LDS_ST];
 
   // XCD-aware tile order: block id -> XCD (id & 7); each XCD walks a contiguous slab of
   // M tiles (neighbouring voxel rows share halo lines in that XCD's L2) and keeps the N
@@ -62,6 +76,12 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
   const int mtile = xcd * p.mtiles_per_xcd + mt_local;
   if (mt_local >= p.mtiles_per_xcd || mtile >= p.mtiles) return;
   const int m0 = mtile * BM, n0 = nt * BN;
+  // Two workgroups share a CU and run the same loop at the same speed; started together they stay
+  // in phase (both load, then both fight for the matrix pipe).  Delaying every second one by about
+  // half a K-chunk lets one workgroup's loads/barriers sit under the other's MFMAs.
+  if (p.dephase > 0 && ((slot >> 5) & 1)) {
+    for (int i = 0; i < p.dephase; i += 64) __builtin_amdgcn_s_sleep(64);
+  }
 
   const int tid = threadIdx.x;
   const int piece = tid & 7, lrow = tid >> 3;
@@ -96,9 +116,9 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
   f32x4 ra[PA], rb[PB];
   auto gload = [&](int it) {
     const int t = it / p.kchunks, kc = it - t * p.kchunks;
-    const float* wt = p.w + ((size_t)it * p.Npad + n0) * KC + piece * 4;
 #pragma unroll
-    for (int b = 0; b < PB; ++b) rb[b] = *(const f32x4*)(wt + (size_t)(lrow + 32 * b) * KC);
+    for (int b = 0; b < PB; ++b)
+      rb[b] = *(const f32x4*)(p.w + wfrag_index((size_t)it, p.Npad >> 7, n0 + lrow + 32 * b, piece * 4));
     const int cc = kc * KC + piece * 4;
     const bool cok = cc < p.Cin;
     int kd = 0, kh = 0, kw = 0;
@@ -152,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
     if (more) gload(it + 1);
     const float* Ab = &As[cur][(wm * WM + li) * LDS_ST + h * 4];
     const float* Bb = &Bs[cur][(wn * WN + li) * LDS_ST + h * 4];
+    if (p.flags & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int q = 0; q < KC / 8; ++q) {
       f32x4 a[TM], b[TN];
@@ -167,9 +188,16 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     }
-    if (more) lstore(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    if (p.flags & 1) __builtin_amdgcn_s_setprio(0);
+    if (NBUF == 2) {
+      if (more) lstore(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    } else {
+      __syncthreads();          // every wave is done reading the tile
+      if (more) lstore(0);
+      __syncthreads();
+    }
   }
 
   // epilogue: D row = (r&3) + 8*(r>>2) + 4*h, col = li
@@ -191,6 +219,169 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
         }
       }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv2: software-pipelined variant for the large geometric layers (Cout >= 128, M >= 8192).
+// Ablation of the phase-structured k_conv on MI355X (profiles/r1_conv_ablation.txt): MFMAs alone
+// 142 TFLOP/s, + fragment reads 139, + LDS stores and barrier 125, + global loads 108.  A lone wave
+// keeps its SIMD's matrix pipe busy only if the other work of a K-chunk is issued BETWEEN its 80
+// MFMAs, and barrier skew is only hidden by a second resident workgroup.  Hence:
+//   * B (weights) never touches LDS: the packed layout is fragment-major, each wave loads its own
+//     4 x 16 B per lane per chunk with buffer_load, one chunk ahead.  LDS holds only the A tile
+//     (160 x 32, double-buffered 46 KB) -> two workgroups per CU (500 tiles = one round of 512 slots
+//     for M = 80000, N = 128);
+//   * A loads are branch-free: buffer_load with an out-of-range offset returns 0 (zero padding, M and
+//     Cin tails), so the loop body is one basic block;
+//   * 1 x 4 wave layout (each wave BM x 32), A fragments double-buffered in VGPRs: the LDS reads of
+//     k-group q+1 are issued under the MFMAs of group q;
+//   * the barrier sits before the last MFMA group: LDS stores of chunk i+1, the barrier and the first
+//     fragment reads of chunk i+1 are covered by MFMAs of chunk i.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+template <int BM, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
+  constexpr int TM = BM / 32, PA = BM / 32;
+  __shared__ float As[2][BM * LDS_ST];
+
+  const int id = blockIdx.x;
+  const int xcd = id & 7, slot = id >> 3;
+  const int mt_local = slot / p.ntiles, nt = slot - mt_local * p.ntiles;
+  const int mtile = xcd * p.mtiles_per_xcd + mt_local;
+  if (mt_local >= p.mtiles_per_xcd || mtile >= p.mtiles) return;
+  const int m0 = mtile * BM, n0 = nt * 128;
+
+  const int tid = threadIdx.x;
+  const int piece = tid & 7, lrow = tid >> 3;
+  // wave index as an SGPR: it feeds the scalar offset of the B loads (a VGPR there makes hipcc
+  // wrap every buffer_load in a waterfall loop)
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, h = lane >> 5;
+
+  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  // per-thread A rows: voxel coordinates of tap (0,0,0) and its row index; rows past M are parked
+  // outside the grid so every tap fails the bounds test
+  int cx[PA], cy[PA], cz[PA], rrow[PA];
+#pragma unroll
+  for (int a = 0; a < PA; ++a) {
+    int m = m0 + lrow + 32 * a;
+    int oz = m % p.Zo; int r = m / p.Zo;
+    int oy = r % p.Yo; r /= p.Yo;
+    int ox = r % p.Xo; int b = r / p.Xo;
+    bool ok = m < p.M;
+    cx[a] = ok ? ox * p.stride - p.pad : -4096;
+    cy[a] = oy * p.stride - p.pad;
+    cz[a] = oz * p.stride - p.pad;
+    rrow[a] = ((b * p.Xi + cx[a]) * p.Yi + cy[a]) * p.Zi + cz[a];
+  }
+  const unsigned voffB = (unsigned)(lane * 16);
+  const int ngroups = p.Npad >> 7;
+
+  const int it0 = blockIdx.y * p.iters_per_split;
+  const int it1 = min(it0 + p.iters_per_split, p.total_iters);
+  if (it0 >= it1) return;
+
+  f32x4 ra[PA], bnext[4], bcur[4];
+  // uniform cursor (tap (kd,kh,kw), channel chunk kc, chunk index lc) of the chunk being LOADED
+  int lc = it0, lt = it0 / p.kchunks, lkc = it0 - lt * p.kchunks;
+  int lkw = lt % p.ksize, lkh = (lt / p.ksize) % p.ksize, lkd = lt / (p.ksize * p.ksize);
+  auto issue_loads = [&](bool live) {
+    const unsigned soff = (unsigned)(((((size_t)lc * ngroups + nt) * 4 + wn) * 1024) * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bnext[q] = buf_load4(rs_w, live ? voffB + q * 1024u : 0xFFFFFFF0u, soff);
+    const int drow = (lkd * p.Yi + lkh) * p.Zi + lkw;
+    const int cc = lkc * KC + piece * 4;
+    const bool cok = live & (cc < p.Cin);
+#pragma unroll
+    for (int a = 0; a < PA; ++a) {
+      // bitwise, not short-circuit: keeps the body free of control flow
+      const bool ok = cok & ((unsigned)(cx[a] + lkd) < (unsigned)p.Xi) & ((unsigned)(cy[a] + lkh) < (unsigned)p.Yi) &
+                      ((unsigned)(cz[a] + lkw) < (unsigned)p.Zi);
+      unsigned voff = ok ? (unsigned)((rrow[a] + drow) * p.in_stride + cc) * 4u : 0xFFFFFFF0u;
+      ra[a] = buf_load4(rs_in, voff, 0);
+    }
+    // advance the cursor (scalar, branch-free so the loop body stays one basic block)
+    lc += 1; lkc += 1;
+    const int w1 = lkc == p.kchunks;
+    lkc = w1 ? 0 : lkc; lkw += w1;
+    const int w2 = lkw == p.ksize;
+    lkw = w2 ? 0 : lkw; lkh += w2;
+    const int w3 = lkh == p.ksize;
+    lkh = w3 ? 0 : lkh; lkd += w3;
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int a = 0; a < PA; ++a) *(f32x4*)&As[buf][(lrow + 32 * a) * LDS_ST + piece * 4] = ra[a];
+  };
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  f32x4 fa[2][TM];
+  auto lfrag = [&](int buf, int q, int slot_) {
+    const float* Ab = &As[buf][li * LDS_ST + h * 4 + q * 8];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[slot_][i] = *(const f32x4*)(Ab + i * 32 * LDS_ST);
+  };
+  auto mma = [&](int slot_, int q) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot_][i][s], bcur[q][s], acc[i], 0, 0, 0);
+  };
+
+  issue_loads(true);
+  lstore(0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bcur[q] = bnext[q];
+  __syncthreads();
+  lfrag(0, 0, 0);
+  int cur = 0;
+  for (int it = it0; it < it1; ++it) {
+    if (DBG < 3) lfrag(cur, 1, 1);
+    if (DBG < 1) issue_loads(it + 1 < it1);   // chunk it+1 -> registers (all-zero dummy on the last pass)
+    __builtin_amdgcn_sched_barrier(0);        // every load is in flight before the first MFMA (hipcc sinks them otherwise)
+    mma(0, 0);
+    if (DBG < 3) lfrag(cur, 2, 0);
+    mma(1, 1);
+    if (DBG < 3) lfrag(cur, 3, 1);
+    mma(0, 2);
+    if (DBG < 2) lstore(cur ^ 1);             // A tile of chunk it+1 -> other LDS buffer
+    if (DBG < 2) __syncthreads();
+    if (DBG < 3) lfrag(cur ^ 1, 0, 0);        // first fragments of chunk it+1, under the last MFMA group
+    mma(1, 3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bcur[q] = bnext[q];
+    cur ^= 1;
+  }
+
+  // epilogue: D row = (r&3) + 8*(r>>2) + 4*h, col = li
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int n = n0 + wn * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m >= p.M) continue;
+      float v = acc[i][r];
+      if (p.splitk > 1) {
+        p.ws[((size_t)blockIdx.y * p.M + m) * p.Npad + n] = v;
+      } else if (n < p.Cout) {
+        size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
+        p.out[orow * p.out_stride + n] = epilogue(p, v, n, orow);
+      }
+    }
+  }
 }
 
 // split-K second pass: sum the partial slabs in a fixed order, then the epilogue
@@ -218,7 +409,7 @@ extern "C" int64_t coocc_conv_pack_weights(const float* w_host, int Cout, int Ci
     for (int n = 0; n < Cout; ++n)
       for (int c = 0; c < Cin; ++c) {
         float v = tap_major ? w_host[((size_t)n * taps + t) * Cin + c] : w_host[((size_t)n * Cin + c) * taps + t];
-        packed_host[(((size_t)t * kch + c / KC) * Npad + n) * KC + (c % KC)] = v;
+        packed_host[wfrag_index((size_t)t * kch + c / KC, Npad >> 7, n, c % KC)] = v;
       }
   return total;
 }
@@ -229,10 +420,11 @@ static void launch_cfg(ConvK& k, bool table, hipStream_t s) {
   k.ntiles = (k.Cout + BN - 1) / BN;
   k.mtiles_per_xcd = (k.mtiles + 7) / 8;
   dim3 grid(8 * k.mtiles_per_xcd * k.ntiles, k.splitk);
+  static const int extra_lds = getenv("COOCC_CONV_EXTRA_LDS") ? atoi(getenv("COOCC_CONV_EXTRA_LDS")) : 0;  // experiments only
   if (table)
-    hipLaunchKernelGGL((k_conv<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, k);
+    hipLaunchKernelGGL((k_conv<BM, BN, WM, WN, true>), grid, dim3(256), extra_lds, s, k);
   else
-    hipLaunchKernelGGL((k_conv<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, k);
+    hipLaunchKernelGGL((k_conv<BM, BN, WM, WN, false>), grid, dim3(256), extra_lds, s, k);
 }
 
 extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
@@ -257,13 +449,25 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   k.ksize = d->ksize; k.stride = d->stride; k.pad = d->pad;
   k.relu = d->relu; k.res_mode = d->res_mode;
   k.total_iters = k.taps * k.kchunks;
+  { const char* e = getenv("COOCC_CONV_DEPHASE"); k.dephase = e ? atoi(e) : 0; }
+  { const char* e = getenv("COOCC_CONV_FLAGS"); k.flags = e ? atoi(e) : 0; }
 
   // tile configuration by problem shape
-  int cfg;  // 0: 128x128 (64x64 waves), 1: 64x128 (32x64), 2: 128x64 (32x64), 3: 128x32 (32x32)
+  int cfg;  // 0: 128x128 (64x64 waves), 1: 64x128 (32x64), 2: 128x64 (32x64), 3: 128x32 (32x32), 4: 160x128 (160x32)
   if (d->Cout <= 32) cfg = 3;
   else if (d->Cout <= 64) cfg = 2;
   else cfg = d->M >= 8192 ? 0 : 1;
-  const int BM = cfg == 1 ? 64 : 128, BN = cfg == 3 ? 32 : (cfg == 2 ? 64 : 128);
+  if (cfg == 0 && d->tile_hint != 128) {
+    // 256 CUs x 2 resident workgroups: pick the M tile (128 or 160) that fills whole rounds of 512 slots
+    // (M = 80000, N = 128: 625 tiles = 1.22 rounds with 128-row tiles, 500 = 0.98 rounds with 160-row tiles)
+    auto util = [&](int bm) {
+      long long t = (long long)((d->M + bm - 1) / bm) * ((d->Cout + 127) / 128);
+      long long rounds = (t + 511) / 512;
+      return (double)t * bm / (double)(rounds * 512) ;   // rows of useful work per slot-round
+    };
+    if (d->tile_hint == 160 || (d->tile_hint == 0 && util(160) > util(128) * 1.02)) cfg = 4;
+  }
+  const int BM = cfg == 1 ? 64 : (cfg == 4 ? 160 : 128), BN = cfg == 3 ? 32 : (cfg == 2 ? 64 : 128);
   const long long blocks = (long long)((d->M + BM - 1) / BM) * ((d->Cout + BN - 1) / BN);
   int splitk = d->splitk;
   if (splitk <= 0) {
@@ -285,10 +489,36 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
 
   hipStream_t s = as_stream(stream);
   const bool table = d->gather != nullptr;
+  // software-pipelined kernel for the large geometric layers (COOCC_CONV_V2=0 switches it off)
+  static const int v2mode = getenv("COOCC_CONV_V2") ? atoi(getenv("COOCC_CONV_V2")) : 1;
+  const unsigned long long in_bytes = (unsigned long long)d->B * d->Xi * d->Yi * d->Zi * d->in_stride * 4ull;
+  const unsigned long long w_bytes = (unsigned long long)k.taps * k.kchunks * k.Npad * KC * 4ull;
+  if (v2mode && !table && (cfg == 0 || cfg == 4) && in_bytes < 0xFFFFFF00ull && w_bytes < 0xFFFFFF00ull) {
+    k.in_bytes = (unsigned)in_bytes;
+    k.w_bytes = (unsigned)w_bytes;
+    const int BMv = cfg == 4 ? 160 : 128;
+    k.mtiles = (k.M + BMv - 1) / BMv;
+    k.ntiles = (k.Cout + 127) / 128;
+    k.mtiles_per_xcd = (k.mtiles + 7) / 8;
+    dim3 grid(8 * k.mtiles_per_xcd * k.ntiles, k.splitk);
+    static const int dbg = getenv("COOCC_CONV_DBG") ? atoi(getenv("COOCC_CONV_DBG")) : 0;   // timing experiments only (wrong results)
+    if (cfg == 4 && dbg == 1) hipLaunchKernelGGL((k_conv2<160, 1>), grid, dim3(256), 0, s, k);
+    else if (cfg == 4 && dbg == 2) hipLaunchKernelGGL((k_conv2<160, 2>), grid, dim3(256), 0, s, k);
+    else if (cfg == 4 && dbg == 3) hipLaunchKernelGGL((k_conv2<160, 3>), grid, dim3(256), 0, s, k);
+    else if (cfg == 4) hipLaunchKernelGGL((k_conv2<160>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((k_conv2<128>), grid, dim3(256), 0, s, k);
+    COOCC_LAUNCH_CHECK("k_conv2");
+    if (splitk > 1) {
+      hipLaunchKernelGGL(k_conv_reduce, dim3(cdiv((long long)k.M * k.Cout, 256)), dim3(256), 0, s, k);
+      COOCC_LAUNCH_CHECK("k_conv_reduce");
+    }
+    return COOCC_OK;
+  }
   switch (cfg) {
     case 0: launch_cfg<128, 128, 64, 64>(k, table, s); break;
     case 1: launch_cfg<64, 128, 32, 64>(k, table, s); break;
     case 2: launch_cfg<128, 64, 32, 64>(k, table, s); break;
+    case 4: launch_cfg<160, 128, 160, 32>(k, table, s); break;
     default: launch_cfg<128, 32, 32, 32>(k, table, s); break;
   }
   COOCC_LAUNCH_CHECK("k_conv");

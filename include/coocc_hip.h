@@ -127,6 +127,7 @@ typedef struct coocc_conv_desc {
   int B, Xi, Yi, Zi, Xo, Yo, Zo, ksize, stride, pad;
   int relu, res_mode;
   int splitk;             /* 0 = choose automatically */
+  int tile_hint;          /* 0 = choose automatically; 128 / 160 force the M tile of the large configuration */
 } coocc_conv_desc;
 
 /* nn.Conv3d(k=3|1)+BN(eval)+ReLU(+residual) (bifuser_n.py:23-30, resnet3d.py:34-64,

@@ -65,22 +65,26 @@ def test_abi_version_and_error_path():
     assert rc == -1 and b"knn_topk" in lib.coocc_last_error()
 
 
+def _wfrag_index(chunk, ngroups, n, kk):
+    """csrc/conv3d.hip wfrag_index: [chunk][128-col group][wn][q][lane = 32h + li][4]."""
+    g, wn, li, q, h, e = n >> 7, (n >> 5) & 3, n & 31, kk >> 3, (kk >> 2) & 1, kk & 3
+    return ((chunk * ngroups + g) * 4 + wn) * 1024 + q * 256 + (h * 32 + li) * 4 + e
+
+
 def test_pack_weights_host_layout():
-    """coocc_conv_pack_weights is host code: [taps][ceil(Cin/32)][roundup(Cout,128)][32]."""
+    """coocc_conv_pack_weights is host code: fragment-major blocks of 128 columns x 32 k."""
     lib = _lib.load()
-    Cout, Cin, taps = 5, 40, 27
+    Cout, Cin, taps = 133, 40, 27
     w = np.arange(Cout * Cin * taps, dtype=np.float32).reshape(Cout, Cin, taps)
     n = lib.coocc_conv_pack_weights(w.ctypes.data, Cout, Cin, taps, 0, None)
-    assert n == taps * 2 * 128 * 32
+    assert n == taps * 2 * 256 * 32                       # ceil(40/32) chunks, Cout padded to 256
     packed = np.zeros(n, np.float32)
     lib.coocc_conv_pack_weights(w.ctypes.data, Cout, Cin, taps, 0, packed.ctypes.data)
-    p = packed.reshape(taps, 2, 128, 32)
-    for t, n_, c in [(0, 0, 0), (26, 4, 39), (13, 2, 31), (5, 3, 32)]:
-        assert p[t, c // 32, n_, c % 32] == w[n_, c, t]
-    assert p[:, :, 5:, :].sum() == 0 and p[:, 1, :, 8:].sum() == 0
-    wl = np.arange(Cout * 3 * 8, dtype=np.float32).reshape(Cout, 3 * 8)            # Linear(C*K -> Cout), K=3, C=8
-    n = lib.coocc_conv_pack_weights(wl.ctypes.data, Cout, 8, 3, 1, None)
+    for t, n_, c in [(0, 0, 0), (26, 4, 39), (13, 2, 31), (5, 132, 32), (7, 127, 17), (9, 128, 3)]:
+        assert packed[_wfrag_index(t * 2 + c // 32, 2, n_, c % 32)] == w[n_, c, t]
+    assert np.count_nonzero(packed) == np.count_nonzero(w)   # everything else is zero padding
+    wl = np.arange(5 * 3 * 8, dtype=np.float32).reshape(5, 3 * 8)                  # Linear(C*K -> Cout), K=3, C=8
+    n = lib.coocc_conv_pack_weights(wl.ctypes.data, 5, 8, 3, 1, None)
     packed = np.zeros(n, np.float32)
-    lib.coocc_conv_pack_weights(wl.ctypes.data, Cout, 8, 3, 1, packed.ctypes.data)
-    p = packed.reshape(3, 1, 128, 32)
-    assert p[2, 0, 4, 7] == wl[4, 2 * 8 + 7]
+    lib.coocc_conv_pack_weights(wl.ctypes.data, 5, 8, 3, 1, packed.ctypes.data)
+    assert packed[_wfrag_index(2, 1, 4, 7)] == wl[4, 2 * 8 + 7]

@@ -62,6 +62,26 @@ def test_conv3d_bn_relu_residual(dev, Cin, Cout, grid, k, stride, relu, use_res,
     assert_close(out.as_ncdhw().cpu(), ref.detach(), what="conv")
 
 
+@pytest.mark.parametrize("hint", [128, 160])
+def test_conv_large_tile_variants(dev, hint):
+    """Both M-tile variants of the large configuration (128x128 / 160x128) on a grid whose row count
+    is a multiple of neither, with residual + ReLU."""
+    g = torch.Generator().manual_seed(hint)
+    x = torch.randn(1, 64, 37, 29, 8, generator=g)          # M = 8584 >= 8192
+    w = torch.randn(160, 64, 3, 3, 3, generator=g) * 0.03    # two N tiles, ragged Cout
+    bn = bn_like(160, g)
+    res = torch.randn(1, 160, 37, 29, 8, generator=g)
+    ref = F.relu(bn(F.conv3d(x, w, padding=1)) + res)
+    pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=3, pad=1)
+    old = core.TILE_HINT
+    core.TILE_HINT = hint
+    try:
+        out = core.conv_rows(rows_of(x, dev), pc, relu=True, res=rows_of(res, dev))
+    finally:
+        core.TILE_HINT = old
+    assert_close(out.as_ncdhw().cpu(), ref.detach(), what="tile %d" % hint)
+
+
 def test_conv_mfma_layout_asymmetric(dev):
     """A = identity-like probe with an asymmetric weight catches row/col swaps in the D map."""
     Cin = Cout = 64
