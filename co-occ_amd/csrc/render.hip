@@ -8,108 +8,146 @@
 // sigma (:586,:597) and get rgb = sigmoid(0) (:595-596); step length is the distance
 // between consecutive TRUNCATED voxel indices (:600-601), last step 1e10 (:603);
 // z_vals = linspace(0, D, D) (:614); bounds hard-coded (:577).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define RT 32  // rays (consecutive w) per block
+#define RT_MAX 32  // rays (consecutive w) per block
 
+// Wave-wide float sum without the LDS crossbar: DPP inside rows of 16 lanes, v_readlane across rows.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
-  return v;
+  v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);   // row_half_mirror
+  v += dpp_f32<0x140>(v);   // row_mirror
+  float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (a + b) + (c + d);
 }
 
-// Block = (camera n, row h, tile of RT rays).  Phase 1: lane per sample, lanes along w so the
-// geom reads of one depth bin are one contiguous segment; per-sample (packed voxel index,
-// relu(sigma), sigmoid(rgb)) go to LDS transposed to [ray][D+1].  Phase 2: one wave per ray,
-// lanes along depth (CH consecutive samples per lane), exclusive transmittance product by a
-// wave-level multiplicative scan (shuffles), weighted sums by wave reductions.
-__global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict__ table, int X, int Y, int Z,
+// sums of the two half-waves (lanes 0-31 -> lo, lanes 32-63 -> hi), wave-uniform results
+__device__ __forceinline__ void half_sums(float v, float& lo, float& hi) {
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x141>(v);
+  v += dpp_f32<0x140>(v);
+  float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  lo = a + b;
+  hi = c + d;
+}
+
+struct __attribute__((packed, aligned(4))) Geo3 { float x, y, z; };
+
+// Block = (camera n, row h, tile of rt <= 32 consecutive rays).
+// Phase 1, lane per sample with lanes along w: one 12-byte load per sample (a depth bin of the tile
+// is one contiguous segment of geom), quantise, store the packed voxel index (bit 31 = outside the
+// bounds) transposed to LDS [ray][D+1] -- 4 bytes per sample, so ~10 workgroups fit a CU and their
+// load latencies overlap.
+// Phase 2, one wave per ray with lanes along depth (CH consecutive samples per lane): 16-byte gather
+// of the voxel's (sigma, rgb) from the L2-resident table, alpha, exclusive transmittance by a
+// wave-level multiplicative scan, weighted sums by DPP wave reductions.
+__global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict__ table, int Y, int Z,
                                                          const float* __restrict__ geom,
-                                                         const float* __restrict__ zvals, int N, int D, int H, int W,
+                                                         const float* __restrict__ zvals, int D, int H, int W, int rt,
                                                          float lox, float loy, float loz, float dx, float dy, float dz,
-                                                         float nx, float ny, float nz, float* __restrict__ maps) {
-  extern __shared__ float sm[];
+                                                         float nx, float ny, float nz, float* __restrict__ maps, int dbg) {
+  extern __shared__ int s_pos[];    // [rt][D+1]
   const int DS = D + 1;
-  int* s_pos = (int*)sm;            // [RT][DS]
-  float* s_sig = sm + RT * DS;      // [RT][DS]
-  float* s_r = s_sig + RT * DS;
-  float* s_g = s_r + RT * DS;
-  float* s_b = s_g + RT * DS;
   const int wt = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
-  const int w0 = wt * RT;
-  const int nray = min(RT, W - w0);
+  const int w0 = wt * rt;
+  const int nray = min(rt, W - w0);
   const int tid = threadIdx.x;
 
-  for (int i = tid; i < D * RT; i += 256) {
-    int d = i / RT, r = i - d * RT;
+  // lane -> (ray r = tid & 31, depth phase tid >> 5): no integer division in the loop
+#pragma unroll 4
+  for (int d = tid >> 5, r = tid & 31; d < D; d += 8) {
     if (r >= nray) continue;
-    const float* g = geom + ((((size_t)n * D + d) * H + h) * W + w0 + r) * 3;
-    float gx = __fdiv_rn(g[0] - lox, dx), gy = __fdiv_rn(g[1] - loy, dy), gz = __fdiv_rn(g[2] - loz, dz);
+    Geo3 g = {1.f * d, 2.f * r, 0.5f};
+    if (!(dbg & 1)) g = *(const Geo3*)(geom + ((((size_t)n * D + d) * H + h) * W + w0 + r) * 3);
+    float gx = __fdiv_rn(g.x - lox, dx), gy = __fdiv_rn(g.y - loy, dy), gz = __fdiv_rn(g.z - loz, dz);
     bool in = gx >= 0.f && gx < nx && gy >= 0.f && gy < ny && gz >= 0.f && gz < nz;
     int ix = in ? (int)gx : 0, iy = in ? (int)gy : 0, iz = in ? (int)gz : 0;
-    f32x4 t = *(const f32x4*)(table + (((size_t)ix * Y + iy) * Z + iz) * 4);
-    s_pos[r * DS + d] = ix | (iy << 10) | (iz << 20);
-    s_sig[r * DS + d] = fmaxf(t[0], 0.f);
-    s_r[r * DS + d] = in ? 1.f / (1.f + expf(-t[1])) : 0.5f;
-    s_g[r * DS + d] = in ? 1.f / (1.f + expf(-t[2])) : 0.5f;
-    s_b[r * DS + d] = in ? 1.f / (1.f + expf(-t[3])) : 0.5f;
+    s_pos[r * DS + d] = ix | (iy << 10) | (iz << 20) | (in ? 0 : (1 << 31));
   }
   __syncthreads();
+  if (dbg & 2) { if (tid < nray) *(f32x4*)(maps + (((size_t)n * H + h) * W + w0 + tid) * 4) = f32x4{0.f, 0.f, 0.f, (float)s_pos[tid * DS]}; return; }
 
-  const int lane = tid & 63, wave = tid >> 6;
-  const int CH = (D + 63) / 64;
-  for (int r = wave; r < nray; r += 4) {
-    const int d0 = lane * CH;
-    // pass 1: per-sample alpha, local product of (1 - alpha + 1e-10)
-    float prod = 1.f;
-    for (int j = 0; j < CH; ++j) {
-      int d = d0 + j;
-      if (d < D) {
+  // Phase 2: each HALF-wave (32 lanes) composites one ray, lanes along depth with CH consecutive
+  // samples per lane -- two rays per wave instruction stream, a 5-step scan and row-local DPP
+  // reductions instead of 64-lane ones (the phase is instruction-bound, not memory-bound:
+  // profiles/r1_render_ablation.txt).
+  const int lane = tid & 63, wave = tid >> 6, hl = lane & 31, half = lane >> 5;
+  const int CH = (D + 31) / 32;                  // <= 8 (D <= 256)
+  const int d0 = hl * CH;
+  float zv[8];                                   // this lane's z_vals, shared by every ray
+#pragma unroll
+  for (int j = 0; j < 8; ++j) zv[j] = (j < CH && d0 + j < D) ? zvals[d0 + j] : 0.f;
+  for (int r0 = wave * 2; r0 < nray; r0 += 8) {
+    const int r = r0 + half;
+    const bool live = r < nray;
+    float al[8], cr[8], cg[8], cb[8], prod = 1.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      al[j] = 0.f; cr[j] = cg[j] = cb[j] = 0.f;
+      const int d = d0 + j;
+      if (j < CH && d < D && live) {
+        const int p0 = s_pos[r * DS + d];
+        const int x0 = p0 & 1023, y0 = (p0 >> 10) & 1023, z0 = (p0 >> 20) & 1023;
+        f32x4 t = {0.3f * x0, 0.1f * y0, 0.2f * z0, 0.5f};
+        if (!(dbg & 4)) t = *(const f32x4*)(table + (((size_t)x0 * Y + y0) * Z + z0) * 4);
         float dist = 1e10f;
         if (d + 1 < D) {
-          int p0 = s_pos[r * DS + d], p1 = s_pos[r * DS + d + 1];
-          float ex = (float)((p1 & 1023) - (p0 & 1023));
-          float ey = (float)(((p1 >> 10) & 1023) - ((p0 >> 10) & 1023));
-          float ez = (float)((p1 >> 20) - (p0 >> 20));
-          dist = sqrtf(ex * ex + ey * ey + ez * ez);
+          const int p1 = s_pos[r * DS + d + 1];
+          float ex = (float)((p1 & 1023) - x0), ey = (float)(((p1 >> 10) & 1023) - y0), ez = (float)(((p1 >> 20) & 1023) - z0);
+          dist = __fsqrt_rn(ex * ex + ey * ey + ez * ez);
         }
-        float alpha = 1.f - expf(-fmaxf(s_sig[r * DS + d] * dist, 0.f));
-        prod *= 1.f - alpha + 1e-10f;
+        const bool in = p0 >= 0;
+        // hardware exp / rcp (<= 1 ulp-class error, far inside the 1e-4 parity bound)
+        al[j] = 1.f - __expf(-fmaxf(fmaxf(t[0], 0.f) * dist, 0.f));
+        cr[j] = in ? __frcp_rn(1.f + __expf(-t[1])) : 0.5f;
+        cg[j] = in ? __frcp_rn(1.f + __expf(-t[2])) : 0.5f;
+        cb[j] = in ? __frcp_rn(1.f + __expf(-t[3])) : 0.5f;
+        prod *= 1.f - al[j] + 1e-10f;
       }
     }
-    // exclusive multiplicative scan across lanes
+    // exclusive multiplicative scan inside each half-wave
     float inc = prod;
-    for (int o = 1; o < 64; o <<= 1) {
-      float v = __shfl_up(inc, o);
-      if (lane >= o) inc *= v;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      float v = __shfl_up(inc, o, 32);
+      if (hl >= o) inc *= v;
     }
-    float T = __shfl_up(inc, 1);
-    if (lane == 0) T = 1.f;
-    // pass 2: weights and sums
+    float T = __shfl_up(inc, 1, 32);
+    if (hl == 0) T = 1.f;
     float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f;
-    for (int j = 0; j < CH; ++j) {
-      int d = d0 + j;
-      if (d < D) {
-        float dist = 1e10f;
-        if (d + 1 < D) {
-          int p0 = s_pos[r * DS + d], p1 = s_pos[r * DS + d + 1];
-          float ex = (float)((p1 & 1023) - (p0 & 1023));
-          float ey = (float)(((p1 >> 10) & 1023) - ((p0 >> 10) & 1023));
-          float ez = (float)((p1 >> 20) - (p0 >> 20));
-          dist = sqrtf(ex * ex + ey * ey + ez * ez);
-        }
-        float alpha = 1.f - expf(-fmaxf(s_sig[r * DS + d] * dist, 0.f));
-        float wgt = alpha * T;
-        ar += wgt * s_r[r * DS + d];
-        ag += wgt * s_g[r * DS + d];
-        ab += wgt * s_b[r * DS + d];
-        ad += wgt * zvals[d];
-        T *= 1.f - alpha + 1e-10f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = d0 + j;
+      if (j < CH && d < D) {
+        float wgt = al[j] * T;
+        ar += wgt * cr[j]; ag += wgt * cg[j]; ab += wgt * cb[j];
+        ad += wgt * zv[j];
+        T *= 1.f - al[j] + 1e-10f;
       }
     }
-    ar = wave_sum(ar); ag = wave_sum(ag); ab = wave_sum(ab); ad = wave_sum(ad);
-    if (lane == 0) *(f32x4*)(maps + (((size_t)n * H + h) * W + w0 + r) * 4) = f32x4{ar, ag, ab, ad};
+    float r_lo, r_hi, g_lo, g_hi, b_lo, b_hi, d_lo, d_hi;
+    half_sums(ar, r_lo, r_hi); half_sums(ag, g_lo, g_hi); half_sums(ab, b_lo, b_hi); half_sums(ad, d_lo, d_hi);
+    if (lane == 0) {
+      float* o = maps + (((size_t)n * H + h) * W + w0 + r0) * 4;
+      *(f32x4*)o = f32x4{r_lo, g_lo, b_lo, d_lo};
+      if (r0 + 1 < nray) *(f32x4*)(o + 4) = f32x4{r_hi, g_hi, b_hi, d_hi};
+    }
   }
 }
 
@@ -127,10 +165,13 @@ extern "C" int coocc_render_nearest(const float* table, int X, int Y, int Z, con
   // the reference would raise IndexError where the hard-coded bounds exceed the volume
   COOCC_CHECK_ARG(nx <= (float)X && ny <= (float)Y && nz <= (float)Z && X <= 1024 && Y <= 1024 && Z <= 1024,
                   "render_nearest: render bounds exceed the voxel volume");
-  size_t lds = sizeof(float) * 5 * RT * (size_t)(D + 1);
-  dim3 grid(cdiv(W, RT), H, N);
-  hipLaunchKernelGGL(k_render_nearest, grid, dim3(256), lds, as_stream(stream), table, X, Y, Z, geom, zvals, N, D, H, W,
-                     lox, loy, loz, dx, dy, dz, nx, ny, nz, maps);
+  const int tiles = (W + RT_MAX - 1) / RT_MAX;
+  const int rt = (W + tiles - 1) / tiles;            // balanced tiles: W = 100 -> 4 x 25, W = 44 -> 2 x 22
+  size_t lds = sizeof(int) * (size_t)rt * (D + 1);
+  static const int dbg = getenv("COOCC_RENDER_DBG") ? atoi(getenv("COOCC_RENDER_DBG")) : 0;   // timing experiments only
+  dim3 grid(tiles, H, N);
+  hipLaunchKernelGGL(k_render_nearest, grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
+                     lox, loy, loz, dx, dy, dz, nx, ny, nz, maps, dbg);
   COOCC_LAUNCH_CHECK("k_render_nearest");
   return COOCC_OK;
 }

@@ -87,6 +87,28 @@ def bench_conv():
 
 
 
+def bench_render():
+    """R2 at r50 / r101 sizes: ray kernel + x16 upsample vs their algorithmic HBM bytes."""
+    from co_occ_amd import render as R
+    g = torch.Generator().manual_seed(3)
+    table = torch.randn(80000, 4, generator=g).to(dev)
+    for name, (fH, fW) in (("r50", (16, 44)), ("r101", (56, 100))):
+        N, D = 6, 112
+        gemo = (torch.rand(N, D, fH, fW, 3, generator=g) * torch.tensor([120., 120., 10.]) - torch.tensor([60., 60., 5.5])).to(dev)
+        zv = torch.linspace(0, D, D, device=dev)
+        maps = torch.empty(N, fH, fW, 4, device=dev)
+        rgbs = torch.empty(N, fH * 16, fW * 16, 3, device=dev)
+        dep = torch.empty(N, fH * 16, fW * 16, device=dev)
+        from co_occ_amd._lib import host_f32
+        b = host_f32(R.RENDER_BOUNDS)
+        t1 = timeit(lambda: call("coocc_render_nearest", ptr(table), 100, 100, 8, ptr(gemo), ptr(zv), N, D, fH, fW, b, ptr(maps)), n=20)
+        t2 = timeit(lambda: call("coocc_upsample_maps", ptr(maps), N, fH, fW, 16, ptr(rgbs), ptr(dep)), n=20)
+        by1 = 12.0 * N * D * fH * fW + 16.0 * 80000 + 16.0 * N * fH * fW
+        by2 = 16.0 * N * fH * fW + 16.0 * N * fH * fW * 256
+        print("render %-4s rays %.3f ms (%.0f GB/s of %.1f MB)  upsample %.3f ms (%.0f GB/s of %.1f MB)  total %.0f GB/s = %.3f of 8 TB/s" % (
+            name, t1, by1 / t1 / 1e6, by1 / 1e6, t2, by2 / t2 / 1e6, by2 / 1e6, (by1 + by2) / (t1 + t2) / 1e6, (by1 + by2) / (t1 + t2) / 1e6 / 8000))
+
+
 def bench_fpsdbg():
     import ctypes
     from co_occ_amd import _lib
