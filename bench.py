@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="r50", choices=sorted(synth.CONFIGS))
-    ap.add_argument("--streams", type=int, default=2, help="samples in flight (software pipelining over HIP streams)")
+    ap.add_argument("--streams", type=int, default=3, help="samples in flight (software pipelining over HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event timing table to stderr")

@@ -29,6 +29,8 @@ def conv_kernel_name(M, Cout, table):
     elif Cout <= 64:
         t = "128,64,32,64"
     elif M < 8192:
+        if M >= 512 and not table and CONV_V2:
+            return "k_conv2<128>"
         t = "64,128,32,64"
     else:
         def util(bm):

@@ -48,6 +48,7 @@ struct ConvK {
 };
 
 __device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t rrow) {
+  if (p.res_mode == 3) v += p.res[rrow * p.res_stride + n];   // raw partial sum of an earlier K-slice pass
   if (p.scale) v *= p.scale[n];
   if (p.bias) v += p.bias[n];
   if (p.res_mode == 1) v += p.res[rrow * p.res_stride + n];
@@ -71,10 +72,17 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
   // M tiles (neighbouring voxel rows share halo lines in that XCD's L2) and keeps the N
   // tiles of one M tile on the same XCD.
   const int id = blockIdx.x;
-  const int xcd = id & 7, slot = id >> 3;
-  const int mt_local = slot / p.ntiles, nt = slot - mt_local * p.ntiles;
-  const int mtile = xcd * p.mtiles_per_xcd + mt_local;
-  if (mt_local >= p.mtiles_per_xcd || mtile >= p.mtiles) return;
+  int mtile, nt, slot = id >> 3;
+  if (p.mtiles_per_xcd > 0) {
+    const int xcd = id & 7;
+    const int mt_local = slot / p.ntiles;
+    nt = slot - mt_local * p.ntiles;
+    mtile = xcd * p.mtiles_per_xcd + mt_local;
+    if (mt_local >= p.mtiles_per_xcd || mtile >= p.mtiles) return;
+  } else {   // few M tiles: plain order, consecutive ids (= different XCDs) take different tiles
+    mtile = id / p.ntiles;
+    nt = id - mtile * p.ntiles;
+  }
   const int m0 = mtile * BM, n0 = nt * BN;
   // Two workgroups share a CU and run the same loop at the same speed; started together they stay
   // in phase (both load, then both fight for the matrix pipe).  Delaying every second one by about
@@ -243,16 +251,27 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 
-template <int BM, int DBG = 0>
+// PF = chunks in flight between a chunk's global loads and its use.  vmcnt retires in order, so A and
+// B loads share one depth: waiting for chunk i+1's A rows must not drain younger loads.  PF = 1 is
+// enough while the weights stay cache-resident (many M tiles re-read them); the weight-streaming
+// layers (few M tiles, up to 113 MB of weights each) need the HBM latency of 2-3 chunks covered.
+template <int BM, int PF = 1, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
   constexpr int TM = BM / 32, PA = BM / 32;
   __shared__ float As[2][BM * LDS_ST];
 
   const int id = blockIdx.x;
-  const int xcd = id & 7, slot = id >> 3;
-  const int mt_local = slot / p.ntiles, nt = slot - mt_local * p.ntiles;
-  const int mtile = xcd * p.mtiles_per_xcd + mt_local;
-  if (mt_local >= p.mtiles_per_xcd || mtile >= p.mtiles) return;
+  int mtile, nt, slot = id >> 3;
+  if (p.mtiles_per_xcd > 0) {
+    const int xcd = id & 7;
+    const int mt_local = slot / p.ntiles;
+    nt = slot - mt_local * p.ntiles;
+    mtile = xcd * p.mtiles_per_xcd + mt_local;
+    if (mt_local >= p.mtiles_per_xcd || mtile >= p.mtiles) return;
+  } else {   // few M tiles: plain order, consecutive ids (= different XCDs) take different tiles
+    mtile = id / p.ntiles;
+    nt = id - mtile * p.ntiles;
+  }
   const int m0 = mtile * BM, n0 = nt * 128;
 
   const int tid = threadIdx.x;
@@ -287,14 +306,14 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
   const int it1 = min(it0 + p.iters_per_split, p.total_iters);
   if (it0 >= it1) return;
 
-  f32x4 ra[PA], bnext[4], bcur[4];
+  f32x4 rq[PF][PA], bq[PF][4], bcur[4];   // slot 0 = chunk it+1 (oldest) ... slot PF-1 = chunk it+PF (just issued)
   // uniform cursor (tap (kd,kh,kw), channel chunk kc, chunk index lc) of the chunk being LOADED
   int lc = it0, lt = it0 / p.kchunks, lkc = it0 - lt * p.kchunks;
   int lkw = lt % p.ksize, lkh = (lt / p.ksize) % p.ksize, lkd = lt / (p.ksize * p.ksize);
-  auto issue_loads = [&](bool live) {
+  auto issue_loads = [&](bool live, int slot_) {
     const unsigned soff = (unsigned)(((((size_t)lc * ngroups + nt) * 4 + wn) * 1024) * 4);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bnext[q] = buf_load4(rs_w, live ? voffB + q * 1024u : 0xFFFFFFF0u, soff);
+    for (int q = 0; q < 4; ++q) bq[slot_][q] = buf_load4(rs_w, live ? voffB + q * 1024u : 0xFFFFFFF0u, soff);
     const int drow = (lkd * p.Yi + lkh) * p.Zi + lkw;
     const int cc = lkc * KC + piece * 4;
     const bool cok = live & (cc < p.Cin);
@@ -304,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
       const bool ok = cok & ((unsigned)(cx[a] + lkd) < (unsigned)p.Xi) & ((unsigned)(cy[a] + lkh) < (unsigned)p.Yi) &
                       ((unsigned)(cz[a] + lkw) < (unsigned)p.Zi);
       unsigned voff = ok ? (unsigned)((rrow[a] + drow) * p.in_stride + cc) * 4u : 0xFFFFFFF0u;
-      ra[a] = buf_load4(rs_in, voff, 0);
+      rq[slot_][a] = buf_load4(rs_in, voff, 0);
     }
     // advance the cursor (scalar, branch-free so the loop body stays one basic block)
     lc += 1; lkc += 1;
@@ -317,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int a = 0; a < PA; ++a) *(f32x4*)&As[buf][(lrow + 32 * a) * LDS_ST + piece * 4] = ra[a];
+    for (int a = 0; a < PA; ++a) *(f32x4*)&As[buf][(lrow + 32 * a) * LDS_ST + piece * 4] = rq[0][a];
   };
 
   f32x16 acc[TM];
@@ -340,16 +359,19 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot_][i][s], bcur[q][s], acc[i], 0, 0, 0);
   };
 
-  issue_loads(true);
+  // prologue: chunk it0 -> LDS / bcur, chunks it0+1 .. it0+PF-1 -> queue slots 0 .. PF-2
+  issue_loads(true, 0);
   lstore(0);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) bcur[q] = bnext[q];
+  for (int q = 0; q < 4; ++q) bcur[q] = bq[0][q];
+#pragma unroll
+  for (int s_ = 0; s_ + 1 < PF; ++s_) issue_loads(it0 + 1 + s_ < it1, s_);
   __syncthreads();
   lfrag(0, 0, 0);
   int cur = 0;
   for (int it = it0; it < it1; ++it) {
     if (DBG < 3) lfrag(cur, 1, 1);
-    if (DBG < 1) issue_loads(it + 1 < it1);   // chunk it+1 -> registers (all-zero dummy on the last pass)
+    if (DBG < 1) issue_loads(it + PF < it1, PF - 1);   // chunk it+PF -> newest slot (all-zero dummy past the end)
     __builtin_amdgcn_sched_barrier(0);        // every load is in flight before the first MFMA (hipcc sinks them otherwise)
     mma(0, 0);
     if (DBG < 3) lfrag(cur, 2, 0);
@@ -361,7 +383,14 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
     if (DBG < 3) lfrag(cur ^ 1, 0, 0);        // first fragments of chunk it+1, under the last MFMA group
     mma(1, 3);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bcur[q] = bnext[q];
+    for (int q = 0; q < 4; ++q) bcur[q] = bq[0][q];
+#pragma unroll
+    for (int s_ = 0; s_ + 1 < PF; ++s_) {       // rotate the queue (register moves, ~1 % of the chunk)
+#pragma unroll
+      for (int a = 0; a < PA; ++a) rq[s_][a] = rq[s_ + 1][a];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[s_][q] = bq[s_ + 1][q];
+    }
     cur ^= 1;
   }
 
@@ -418,8 +447,8 @@ template <int BM, int BN, int WM, int WN>
 static void launch_cfg(ConvK& k, bool table, hipStream_t s) {
   k.mtiles = (k.M + BM - 1) / BM;
   k.ntiles = (k.Cout + BN - 1) / BN;
-  k.mtiles_per_xcd = (k.mtiles + 7) / 8;
-  dim3 grid(8 * k.mtiles_per_xcd * k.ntiles, k.splitk);
+  k.mtiles_per_xcd = k.mtiles >= 64 ? (k.mtiles + 7) / 8 : 0;   // XCD slabs only pay with many M tiles
+  dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
   static const int extra_lds = getenv("COOCC_CONV_EXTRA_LDS") ? atoi(getenv("COOCC_CONV_EXTRA_LDS")) : 0;  // experiments only
   if (table)
     hipLaunchKernelGGL((k_conv<BM, BN, WM, WN, true>), grid, dim3(256), extra_lds, s, k);
@@ -467,13 +496,17 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
     };
     if (d->tile_hint == 160 || (d->tile_hint == 0 && util(160) > util(128) * 1.02)) cfg = 4;
   }
-  const int BM = cfg == 1 ? 64 : (cfg == 4 ? 160 : 128), BN = cfg == 3 ? 32 : (cfg == 2 ? 64 : 128);
+  // mid-size layers (512 <= M < 8192) also run the pipelined kernel with 128-row tiles + split-K;
+  // below that the 64-row tile wastes fewer padded rows (M = 169 at the deepest stage)
+  const bool v2small = d->M >= 512;
+  const int BM = (cfg == 1 && !(v2small && !d->gather)) ? 64 : (cfg == 4 ? 160 : 128), BN = cfg == 3 ? 32 : (cfg == 2 ? 64 : 128);
   const long long blocks = (long long)((d->M + BM - 1) / BM) * ((d->Cout + BN - 1) / BN);
   int splitk = d->splitk;
   if (splitk <= 0) {
     splitk = 1;
     if (blocks < 256 && k.total_iters >= 16 && d->ws) {
-      splitk = (int)((512 + blocks - 1) / blocks);
+      // fill (at most) one round of 512 resident workgroups: one more would double the time
+      splitk = (int)(512 / blocks);
       if (splitk > k.total_iters / 8) splitk = k.total_iters / 8;
       if (splitk > 64) splitk = 64;
       while (splitk > 1 && (long long)splitk * d->M * k.Npad > d->ws_floats) --splitk;
@@ -493,20 +526,25 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   static const int v2mode = getenv("COOCC_CONV_V2") ? atoi(getenv("COOCC_CONV_V2")) : 1;
   const unsigned long long in_bytes = (unsigned long long)d->B * d->Xi * d->Yi * d->Zi * d->in_stride * 4ull;
   const unsigned long long w_bytes = (unsigned long long)k.taps * k.kchunks * k.Npad * KC * 4ull;
-  if (v2mode && !table && (cfg == 0 || cfg == 4) && in_bytes < 0xFFFFFF00ull && w_bytes < 0xFFFFFF00ull) {
+  if (v2mode && !table && (cfg == 0 || cfg == 4 || (cfg == 1 && v2small)) && in_bytes < 0xFFFFFF00ull && w_bytes < 0xFFFFFF00ull) {
     k.in_bytes = (unsigned)in_bytes;
     k.w_bytes = (unsigned)w_bytes;
     const int BMv = cfg == 4 ? 160 : 128;
     k.mtiles = (k.M + BMv - 1) / BMv;
     k.ntiles = (k.Cout + 127) / 128;
-    k.mtiles_per_xcd = (k.mtiles + 7) / 8;
-    dim3 grid(8 * k.mtiles_per_xcd * k.ntiles, k.splitk);
+    k.mtiles_per_xcd = k.mtiles >= 64 ? (k.mtiles + 7) / 8 : 0;
+    dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
     static const int dbg = getenv("COOCC_CONV_DBG") ? atoi(getenv("COOCC_CONV_DBG")) : 0;   // timing experiments only (wrong results)
-    if (cfg == 4 && dbg == 1) hipLaunchKernelGGL((k_conv2<160, 1>), grid, dim3(256), 0, s, k);
-    else if (cfg == 4 && dbg == 2) hipLaunchKernelGGL((k_conv2<160, 2>), grid, dim3(256), 0, s, k);
-    else if (cfg == 4 && dbg == 3) hipLaunchKernelGGL((k_conv2<160, 3>), grid, dim3(256), 0, s, k);
-    else if (cfg == 4) hipLaunchKernelGGL((k_conv2<160>), grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((k_conv2<128>), grid, dim3(256), 0, s, k);
+    static const int pf160 = getenv("COOCC_CONV_PF160") ? atoi(getenv("COOCC_CONV_PF160")) : 2;
+    static const int pf128 = getenv("COOCC_CONV_PF128") ? atoi(getenv("COOCC_CONV_PF128")) : 3;
+    if (cfg == 4 && dbg == 1) hipLaunchKernelGGL((k_conv2<160, 1, 1>), grid, dim3(256), 0, s, k);
+    else if (cfg == 4 && dbg == 2) hipLaunchKernelGGL((k_conv2<160, 1, 2>), grid, dim3(256), 0, s, k);
+    else if (cfg == 4 && dbg == 3) hipLaunchKernelGGL((k_conv2<160, 1, 3>), grid, dim3(256), 0, s, k);
+    else if (cfg == 4 && pf160 == 2) hipLaunchKernelGGL((k_conv2<160, 2>), grid, dim3(256), 0, s, k);
+    else if (cfg == 4) hipLaunchKernelGGL((k_conv2<160, 1>), grid, dim3(256), 0, s, k);
+    else if (pf128 == 3) hipLaunchKernelGGL((k_conv2<128, 3>), grid, dim3(256), 0, s, k);
+    else if (pf128 == 2) hipLaunchKernelGGL((k_conv2<128, 2>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((k_conv2<128, 1>), grid, dim3(256), 0, s, k);
     COOCC_LAUNCH_CHECK("k_conv2");
     if (splitk > 1) {
       hipLaunchKernelGGL(k_conv_reduce, dim3(cdiv((long long)k.M * k.Cout, 256)), dim3(256), 0, s, k);

@@ -160,10 +160,17 @@ extern "C" int coocc_furthest_point_sampling(int b, int n, int m, const float* p
 #define FT_Z 8
 #define FT_P 128
 
-struct FpsCell { float temp; int k; };   // one voxel position of a bucket: running temp, list ordinal (-1 = empty)
+// One voxel position of a bucket: running temp (integer squared distance, saturated at the key's
+// maximum) and the tie rank of the point (-1 = empty position).
+// Tie rank: the reference's winner among equal temps is min (bitrev_L(k mod block), k) (see K2 above);
+// r(k) = bitrev_L(k mod block) * q + (k >> L), q = ceil(n / block), is that order as one integer
+// < block * q, so a key (temp << RB) | (rmask - r) is totally ordered like the 64-bit key of k_fps_f32
+// and fits 32 bits for the nuScenes grids (temp < 2^15, r < 2^16): half the DPP/compare work of
+// every reduction on the per-sample critical path.
+struct FpsCell { int temp; int r; };
 
 __global__ __launch_bounds__(256) void k_fpsv_scatter(const int32_t* __restrict__ lin, int n, int Y, int Z, int NBY,
-                                                       int NBZ, FpsCell* __restrict__ cell) {
+                                                       int NBZ, int L, int q, int tinit, FpsCell* __restrict__ cell) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   int l = lin[k];
@@ -171,34 +178,48 @@ __global__ __launch_bounds__(256) void k_fpsv_scatter(const int32_t* __restrict_
   int y = l % Y; int x = l / Y;
   int b = ((x / FT_X) * NBY + y / FT_Y) * NBZ + z / FT_Z;
   int p = ((x % FT_X) * FT_Y + (y % FT_Y)) * FT_Z + (z % FT_Z);
-  cell[(size_t)b * FT_P + p] = FpsCell{1e10f, k};
+  unsigned rev = L ? (__brev((unsigned)k & ((1u << L) - 1u)) >> (32 - L)) : 0u;
+  cell[(size_t)b * FT_P + p] = FpsCell{tinit, (int)(rev * (unsigned)q + ((unsigned)k >> L))};
 }
 
-// Buckets are owned by waves (bucket b -> wave b % NW), so the dirty test and the refresh of a
-// wave's buckets need no block-level list: lanes test up to 64 owned buckets, a ballot walks the
-// dirty ones.  Two barriers per sample: after the refresh, and after the per-wave maxima.
 // LDS-only barrier: the refresh stores to `cell` are consumed later by the SAME wave only, so the
 // block barrier must not wait for them (a plain __syncthreads() drains vmcnt and would put the L2
 // write latency on every iteration's critical path).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ unsigned wave_max_key(unsigned v) {
+  v = max(v, dpp_u32<0xB1>(v));
+  v = max(v, dpp_u32<0x4E>(v));
+  v = max(v, dpp_u32<0x141>(v));
+  v = max(v, dpp_u32<0x140>(v));
+  unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+  unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ u64 wave_max_key(u64 v) { return wave_max_u64(v); }
+
 // Bucket b is owned by lane ((b / NW) % 64) of wave (b % NW), slot (b / NW) / 64: its cached best
 // key, the position of that point and the bucket origin live in that lane's VGPRs, so the dirty
 // test, the refresh bookkeeping and the per-wave maximum need no LDS at all.  One block barrier
-// per sample (publishing the NW per-wave maxima, double-buffered by parity).
-template <int THREADS, int FPS_RMAX>
+// per sample (publishing the NW per-wave maxima, double-buffered by parity).  Dirty buckets are
+// refreshed two at a time so that their L2 loads and reductions overlap.
+template <int THREADS, int FPS_RMAX, typename KT>
 __global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int Z, int NBY, int NBZ, int NB,
                                                          const int32_t* __restrict__ lin, FpsCell* __restrict__ cell,
-                                                         int32_t* __restrict__ idx, int L, long long* dbg) {
+                                                         int32_t* __restrict__ idx, int L, int q, int RB, long long* dbg) {
   constexpr int NW = THREADS / 64;
-  __shared__ u64 wbest[2][NW];
+  __shared__ KT wbest[2][NW];
   __shared__ int wloc[2][NW];   // packed sample coordinates x | y << 10 | z << 20 of the wave's best point
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned blockmask = (1u << L) - 1u;
-  const u64 init_hi = (u64)__float_as_uint(1e10f) << 32;
+  const KT rmask = (KT)(((KT)1 << RB) - 1);
+  const int tmax = sizeof(KT) == 4 ? (int)((1u << (32 - RB)) - 1u) : 0x7FFFFFFF;
   long long tA = 0, tM = 0, tB = 0, tT = 0, nd = 0;
 
-  u64 key[FPS_RMAX];    // best key of the owned bucket (0 = empty / no bucket)
+  KT key[FPS_RMAX];     // best key of the owned bucket (0 = empty / no bucket)
   int org[FPS_RMAX];    // bucket origin x | y << 10 | z << 20
   int pos[FPS_RMAX];    // position (0..127) of the best point inside the bucket
 #pragma unroll
@@ -206,25 +227,25 @@ __global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int
     const int b = (lane + 64 * r) * NW + wave;
     key[r] = 0; pos[r] = 0; org[r] = 0;
     if (b < NB) {                                  // the only divisions of the kernel
-      int bz = b % NBZ; int q = b / NBZ;
-      org[r] = ((q / NBY) * FT_X) | (((q % NBY) * FT_Y) << 10) | ((bz * FT_Z) << 20);
+      int bz = b % NBZ; int qq = b / NBZ;
+      org[r] = ((qq / NBY) * FT_X) | (((qq % NBY) * FT_Y) << 10) | ((bz * FT_Z) << 20);
     }
   }
-  // initial keys (temp = 1e10 everywhere): the wave walks its buckets, lanes = positions
+  // initial keys (temp = tmax everywhere): the wave walks its buckets, lanes = positions
 #pragma unroll
   for (int r = 0; r < FPS_RMAX; ++r) {
     for (int src = 0; src < 64; ++src) {
       const int b = (src + 64 * r) * NW + wave;    // wave-uniform
       if (b >= NB) break;
-      u64 best = 0;
+      KT best = 0;
       int bp = 0;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        int k = cell[(size_t)b * FT_P + lane + 64 * h].k;
-        u64 kk = k >= 0 ? (init_hi | (u64)(~fps_tiebreak(k, L, blockmask))) : 0ull;
+        int rr = cell[(size_t)b * FT_P + lane + 64 * h].r;
+        KT kk = rr >= 0 ? (KT)(((KT)tmax << RB) | (rmask - (KT)rr)) : (KT)0;
         if (kk > best) { best = kk; bp = lane + 64 * h; }
       }
-      u64 wb = wave_max_u64(best);
+      KT wb = wave_max_key(best);
       u64 own = __ballot(best == wb);
       int wp = __builtin_amdgcn_readlane(bp, (int)__ffsll((long long)own) - 1);
       if (lane == src) { key[r] = wb; pos[r] = wp; }
@@ -238,6 +259,24 @@ __global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int
     sy = l % Y; sx = l / Y;
   }
 
+  // refresh of ONE bucket's two positions in this lane: new temps, lane-best key and its position
+  auto refresh = [&](FpsCell* cp, const FpsCell& c0_, const FpsCell& c1_, int o, KT& best, int& bp) {
+    const int x0 = o & 1023, y0 = (o >> 10) & 1023, z0 = o >> 20;
+    best = 0; bp = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const FpsCell c = h ? c1_ : c0_;
+      const int p = lane + 64 * h;
+      if (c.r >= 0) {
+        int ex = x0 + (p >> 5) - sx, ey = y0 + ((p >> 3) & 3) - sy, ez = z0 + (p & 7) - sz;
+        int t = min(ex * ex + ey * ey + ez * ez, c.temp);
+        cp[p].temp = t;
+        KT kk = (KT)(((KT)t << RB) | (rmask - (KT)c.r));
+        if (kk > best) { best = kk; bp = p; }
+      }
+    }
+  };
+
   for (int j = 1; j < m; ++j) {
     long long c0 = dbg ? clock64() : 0;
     // (A) dirty test + refresh of the owned buckets
@@ -250,41 +289,38 @@ __global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int
         int dx = max(max(x0 - sx, sx - (x0 + FT_X - 1)), 0);
         int dy = max(max(y0 - sy, sy - (y0 + FT_Y - 1)), 0);
         int dz = max(max(z0 - sz, sz - (z0 + FT_Z - 1)), 0);
-        d = (float)(dx * dx + dy * dy + dz * dz) < __uint_as_float((unsigned)(key[r] >> 32));
+        d = (dx * dx + dy * dy + dz * dz) < (int)(key[r] >> RB);
       }
       u64 bal = __ballot(d);
       nd += __popcll(bal);
       while (bal) {
-        const int src = (int)__ffsll((long long)bal) - 1;
+        const int s0 = (int)__ffsll((long long)bal) - 1;
         bal &= bal - 1;
-        const int bb = (src + 64 * r) * NW + wave;              // wave-uniform
-        const int o = __builtin_amdgcn_readlane(org[r], src);
-        const int x0 = o & 1023, y0 = (o >> 10) & 1023, z0 = o >> 20;
-        FpsCell* cp = cell + (size_t)bb * FT_P;
-        FpsCell c0_ = cp[lane], c1_ = cp[lane + 64];
-        u64 best = 0;
-        int bp = 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const FpsCell c = h ? c1_ : c0_;
-          const int p = lane + 64 * h;
-          if (c.k >= 0) {
-            int ex = x0 + (p >> 5) - sx, ey = y0 + ((p >> 3) & 3) - sy, ez = z0 + (p & 7) - sz;
-            float t = fminf((float)(ex * ex + ey * ey + ez * ez), c.temp);
-            cp[p].temp = t;
-            u64 kk = ((u64)__float_as_uint(t) << 32) | (u64)(~fps_tiebreak(c.k, L, blockmask));
-            if (kk > best) { best = kk; bp = p; }
-          }
+        const bool two = bal != 0;                                // wave-uniform
+        const int s1 = two ? (int)__ffsll((long long)bal) - 1 : s0;
+        bal &= bal - 1;
+        FpsCell* cp0 = cell + (size_t)((s0 + 64 * r) * NW + wave) * FT_P;
+        FpsCell* cp1 = cell + (size_t)((s1 + 64 * r) * NW + wave) * FT_P;
+        const FpsCell a0 = cp0[lane], a1 = cp0[lane + 64];
+        FpsCell b0 = a0, b1 = a1;
+        if (two) { b0 = cp1[lane]; b1 = cp1[lane + 64]; }
+        KT best0, best1 = 0;
+        int bp0, bp1 = 0;
+        refresh(cp0, a0, a1, __builtin_amdgcn_readlane(org[r], s0), best0, bp0);
+        if (two) refresh(cp1, b0, b1, __builtin_amdgcn_readlane(org[r], s1), best1, bp1);
+        const KT wb0 = wave_max_key(best0);
+        const KT wb1 = two ? wave_max_key(best1) : (KT)0;
+        const int wp0 = __builtin_amdgcn_readlane(bp0, (int)__ffsll((long long)__ballot(best0 == wb0)) - 1);
+        if (lane == s0) { key[r] = wb0; pos[r] = wp0; }
+        if (two) {
+          const int wp1 = __builtin_amdgcn_readlane(bp1, (int)__ffsll((long long)__ballot(best1 == wb1)) - 1);
+          if (lane == s1) { key[r] = wb1; pos[r] = wp1; }
         }
-        u64 wb = wave_max_u64(best);
-        u64 own = __ballot(best == wb);                          // exactly one lane: keys embed k
-        int wp = __builtin_amdgcn_readlane(bp, (int)__ffsll((long long)own) - 1);
-        if (lane == src) { key[r] = wb; pos[r] = wp; }
       }
     }
     long long c1 = dbg ? clock64() : 0;
     // (B) wave maximum over the owned buckets, published with the sample coordinates
-    u64 best = 0;
+    KT best = 0;
     int bo = 0, bpz = 0;
 #pragma unroll
     for (int r = 0; r < FPS_RMAX; ++r) {
@@ -292,22 +328,27 @@ __global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int
     }
     // origin fields never carry into each other: x0 + 3 < 1024 etc.
     const int loc = bo + (bpz >> 5) + (((bpz >> 3) & 3) << 10) + ((bpz & 7) << 20);
-    u64 wb = wave_max_u64(best);
+    KT wb = wave_max_key(best);
     if (best == wb && wb) { wbest[j & 1][wave] = wb; wloc[j & 1][wave] = loc; }
     if (!wb && lane == 0) wbest[j & 1][wave] = 0;
     long long c2 = dbg ? clock64() : 0;
     lds_barrier();
     long long c3 = dbg ? clock64() : 0;
-    u64 g = wbest[j & 1][0];
+    KT g = wbest[j & 1][0];
     int gw = 0;
 #pragma unroll
     for (int w = 1; w < NW; ++w) {
-      u64 o = wbest[j & 1][w];
+      KT o = wbest[j & 1][w];
       if (o > g) { g = o; gw = w; }
     }
     const int gl = wloc[j & 1][gw];
     sx = gl & 1023; sy = (gl >> 10) & 1023; sz = gl >> 20;
-    if (tid == 0) idx[j] = (int)((~(unsigned)g) & ((1u << FPS_KBITS) - 1u));
+    if (tid == 0) {   // list ordinal of the winner from its tie rank (off the critical path)
+      const unsigned rr = (unsigned)(rmask - (g & rmask));
+      const unsigned hi = rr / (unsigned)q, lo = rr - hi * (unsigned)q;
+      const unsigned rev = L ? (__brev(hi) >> (32 - L)) : 0u;
+      idx[j] = (int)((lo << L) | rev);
+    }
     // wbest/wloc parity j&1 is rewritten two iterations later, i.e. after one more barrier that
     // every reader of these values has already passed.
     if (dbg) { long long c4 = clock64(); tA += c1 - c0; tM += c2 - c1; tB += c3 - c2; tT += c4 - c3; }
@@ -323,7 +364,7 @@ extern "C" size_t coocc_fps_voxels_ws(int X, int Y, int Z) {
   return nb * FT_P * sizeof(FpsCell);
 }
 
-static int g_fps_threads = 256;
+static int g_fps_threads = 1024;   // measured on MI355X (100x100x8 grid, 52 k voxels): 256 -> 3.8 ms, 512 -> 3.4 ms, 1024 -> 3.0 ms
 static long long* g_fps_dbg = nullptr;
 extern "C" void coocc_fps_voxels_set_debug(long long* p) { g_fps_dbg = p; }
 extern "C" void coocc_fps_voxels_set_threads(int t) { g_fps_threads = t; }
@@ -343,20 +384,32 @@ extern "C" int coocc_fps_voxels(const int32_t* lin, int n, int X, int Y, int Z, 
   COOCC_CHECK_ARG(NB <= 8ll * threads, "fps_voxels: grid has too many buckets (use coocc_furthest_point_sampling)");
   if (ws_bytes < coocc_fps_voxels_ws(X, Y, Z)) return coocc_set_error(COOCC_ENOMEM, "fps_voxels: workspace too small");
   const int R = (int)((NB + threads - 1) / threads);
+  int L = 0;
+  while ((2 << L) <= n && L < 10) ++L;            // block = min(2^floor(log2 n), 1024) = 1 << L
+  const int q = (n + (1 << L) - 1) >> L;          // tie ranks live in [0, q << L)
+  int RB = L;
+  while ((1ll << RB) <= ((long long)q << L)) ++RB;   // strict: rank rmask is never used, key 0 stays "empty"
+  const long long d2max = (long long)(X - 1) * (X - 1) + (long long)(Y - 1) * (Y - 1) + (long long)(Z - 1) * (Z - 1);
+  const bool key32 = RB < 31 && d2max + 1 < (1ll << (32 - RB)) - 1;
+  const int tinit = key32 ? (int)((1u << (32 - RB)) - 1u) : 0x7FFFFFFF;
   FpsCell* cell = (FpsCell*)ws;
   hipStream_t s = as_stream(stream);
   COOCC_HIP(hipMemsetAsync(cell, 0xFF, sizeof(FpsCell) * (size_t)NB * FT_P, s));
-  hipLaunchKernelGGL(k_fpsv_scatter, dim3(cdiv(n, 256)), dim3(256), 0, s, lin, n, Y, Z, NBY, NBZ, cell);
-  int L = 0;
-  while ((2 << L) <= n && L < 10) ++L;
-#define FPS_LAUNCH(T, RM) \
-  hipLaunchKernelGGL((k_fps_voxels<T, RM>), dim3(1), dim3(T), 0, s, n, m, Y, Z, NBY, NBZ, (int)NB, lin, cell, idx, L, g_fps_dbg)
-#define FPS_PICK(T)                       \
-  do {                                    \
-    if (R <= 2) FPS_LAUNCH(T, 2);         \
-    else if (R <= 3) FPS_LAUNCH(T, 3);    \
-    else if (R <= 4) FPS_LAUNCH(T, 4);    \
-    else FPS_LAUNCH(T, 8);                \
+  hipLaunchKernelGGL(k_fpsv_scatter, dim3(cdiv(n, 256)), dim3(256), 0, s, lin, n, Y, Z, NBY, NBZ, L, q, tinit, cell);
+#define FPS_LAUNCH(T, RM, KT) \
+  hipLaunchKernelGGL((k_fps_voxels<T, RM, KT>), dim3(1), dim3(T), 0, s, n, m, Y, Z, NBY, NBZ, (int)NB, lin, cell, idx, L, q, \
+                     key32 ? RB : 32, g_fps_dbg)
+#define FPS_PICK_R(T, KT)                     \
+  do {                                        \
+    if (R <= 2) FPS_LAUNCH(T, 2, KT);         \
+    else if (R <= 3) FPS_LAUNCH(T, 3, KT);    \
+    else if (R <= 4) FPS_LAUNCH(T, 4, KT);    \
+    else FPS_LAUNCH(T, 8, KT);                \
+  } while (0)
+#define FPS_PICK(T)                           \
+  do {                                        \
+    if (key32) FPS_PICK_R(T, unsigned);       \
+    else FPS_PICK_R(T, u64);                  \
   } while (0)
   if (threads == 256) FPS_PICK(256);
   else if (threads == 512) FPS_PICK(512);

@@ -21,8 +21,13 @@ _fps_ws = {}
 _side = {}
 
 
-def _side_stream(dev, cur):
-    key = (dev.index, cur.cuda_stream)
+# measured on MI355X: running the KNN-independent half of con_enc.0 under the FPS chains is a net loss
+# while the FPS workgroup shares its CU with convolution waves (22.5 -> 25.2 ms/sample); off by default
+SPLIT_CON_ENC = int(__import__("os").environ.get("COOCC_SPLIT_CON_ENC", "0"))
+
+
+def _side_stream(dev, cur, which=0):
+    key = (dev.index, cur.cuda_stream, which)
     if key not in _side:
         _side[key] = torch.cuda.Stream(device=dev)
     return _side[key]
@@ -105,6 +110,9 @@ class BiFuser_N(nn.Module):
         def build():
             return dict(
                 c0=PackedConv(self.con_enc[0].weight, bn=self.con_enc[1], ksize=3, pad=1),
+                # con_enc.0 split along its input channels: [img | pts] does not depend on the KNN search
+                c0a=PackedConv(self.con_enc[0].weight[:, :2 * self.in_channels].contiguous(), ksize=3, pad=1),
+                c0b=PackedConv(self.con_enc[0].weight[:, 2 * self.in_channels:].contiguous(), bn=self.con_enc[1], ksize=3, pad=1),
                 c3=PackedConv(self.con_enc[3].weight, bn=self.con_enc[4], ksize=3, pad=1),
                 knn=PackedConv(self.knn_enc[0].weight, bias=self.knn_enc[0].bias, tap_major=True, taps=self.knum))
         return self._packs.get(srcs, build)
@@ -119,8 +127,10 @@ class BiFuser_N(nn.Module):
         return out[0] if num == 1 else out
 
     # ---------------------------------------------------------------- forward
-    def fuse(self, img_voxel_feats, pts_voxel_feats):
-        """K1..G1: returns the [B*V, 4C] concat rows (img | pts | fused_img | fused_pts)."""
+    def fuse(self, img_voxel_feats, pts_voxel_feats, early=None):
+        """K1..G1: returns the [B*V, 4C] concat rows (img | pts | fused_img | fused_pts).
+        early(cat4): optional callback launched (on a third stream) as soon as the img|pts halves of
+        the rows are in place and the two searches are in flight."""
         B, C, X, Y, Z = img_voxel_feats.shape
         V, dev = X * Y * Z, img_voxel_feats.device
         if not img_voxel_feats.is_cuda:
@@ -131,6 +141,10 @@ class BiFuser_N(nn.Module):
         cat4 = torch.empty(B * V, 4 * C, device=dev, dtype=_F32)
         flags = torch.empty(2, B * V, device=dev, dtype=torch.uint8)
         call("coocc_fuser_prepare", ptr(img), ptr(pts), ptr(cat4), ptr(flags[0]), ptr(flags[1]), B, C, V)
+        rows_ready = None
+        if early is not None:
+            rows_ready = torch.cuda.Event()
+            rows_ready.record()
         lin = torch.empty(2, B * V, device=dev, dtype=_I32)
         counts = torch.empty(2, device=dev, dtype=_I32)
         ws = torch.empty(2, B * V // 1024 + 2, device=dev, dtype=_I32)
@@ -165,6 +179,8 @@ class BiFuser_N(nn.Module):
                     call("coocc_index_rows_i32", ptr(base), nbase, ptr(near_pts[k]), Ni, ptr(rows_p[k]))
             # pts queries <- nearest img keys (bifuser_n.py:137-148)
             near_img = _fps_nn_xyz(xyz_pts, xyz_img, q_lin=lin_pts if vox else None, grid=vox, **kw)
+            if early is not None:
+                early(Rows(cat4, B, X, Y, Z, 4 * C), rows_ready)
             rows = torch.empty(K, Np, device=dev, dtype=_I32)
             for k in range(K):
                 call("coocc_index_rows_i32", ptr(lin_img), Ni, ptr(near_img[k]), Np, ptr(rows[k]))
@@ -179,9 +195,35 @@ class BiFuser_N(nn.Module):
         return Rows(cat4, B, X, Y, Z, 4 * C), (lin_img, lin_pts)
 
     def forward(self, img_voxel_feats, pts_voxel_feats):
-        """[B,C,X,Y,Z] x2 -> [B,out,X,Y,Z] (bifuser_n.py:127-174)."""
-        cat4, _ = self.fuse(img_voxel_feats, pts_voxel_feats)
+        """[B,C,X,Y,Z] x2 -> [B,out,X,Y,Z] (bifuser_n.py:127-174).
+
+        con_enc.0 is linear in its 4C input channels, and the first 2C (the raw img / pts features)
+        do not depend on the index search: that half of the convolution runs on a third stream under
+        the two serial FPS chains, the other half accumulates onto its raw partial sums (res_mode 3)
+        and applies BN + ReLU."""
+        if not img_voxel_feats.is_cuda:
+            raise _lib.CooccError("BiFuser_N runs on the GPU only (no CPU fallback)")
         packs = self._packed()
-        x = conv_rows(cat4, packs["c0"], relu=True)
+        C = self.in_channels
+        dev = img_voxel_feats.device
+        cur = torch.cuda.current_stream(dev)
+        state = {}
+
+        def early(cat4, rows_ready):
+            side = _side_stream(dev, cur, 1)
+            side.wait_event(rows_ready)                 # img | pts halves of the rows are written; do NOT wait for the searches
+            with torch.cuda.stream(side):
+                half = Rows(cat4.t, cat4.B, cat4.X, cat4.Y, cat4.Z, 2 * C, 0)
+                state["partial"] = conv_rows(half, packs["c0a"], relu=False)
+            state["side"] = side
+
+        cat4, _ = self.fuse(img_voxel_feats, pts_voxel_feats, early=early if SPLIT_CON_ENC else None)
+        if "partial" in state:
+            cur.wait_stream(state["side"])
+            state["partial"].t.record_stream(cur)
+            half = Rows(cat4.t, cat4.B, cat4.X, cat4.Y, cat4.Z, 2 * C, 2 * C)
+            x = conv_rows(half, packs["c0b"], relu=True, res=state["partial"], res_mode=3)
+        else:
+            x = conv_rows(cat4, packs["c0"], relu=True)
         x = conv_rows(x, packs["c3"], relu=True)
         return x.as_ncdhw()

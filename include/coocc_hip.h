@@ -117,7 +117,8 @@ typedef struct coocc_conv_desc {
   float* out;
   const float* scale;     /* [Cout] or NULL (folded eval-mode BN scale) */
   const float* bias;      /* [Cout] or NULL */
-  const float* res;       /* residual rows (res_mode 1: add before ReLU; 2: multiply after) */
+  const float* res;       /* res_mode 1: residual added before ReLU; 2: gate multiplied after ReLU;
+                             3: raw partial sums of an earlier K-slice pass, added before scale/bias */
   const int32_t* gather;  /* NULL: geometric taps; else [taps][M] input row ids */
   const int32_t* out_rows;/* NULL: identity; else [M] output (and res) row ids */
   float* ws;              /* split-K workspace or NULL */
