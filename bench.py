@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0          # HBM3E spec
 
 def make_inputs(cfgname, seed, dev, model):
     c = synth.CONFIGS[cfgname]
-    img, pts = synth.voxel_inputs(c["grid"], C=c["C"], seed=seed)
+    img, pts = synth.voxel_inputs(c["grid"], C=c["C"], seed=seed, p_img=c.get("p_img", 0.65), p_pts=c.get("p_pts", 0.12))
     fH, fW = c["fmap"]
     rig = synth.camera_rig(c["ncam"], (fH * 16, fW * 16), seed=seed)
     r = {k: v.to(dev) for k, v in rig.items() if torch.is_tensor(v)}
@@ -61,7 +61,11 @@ def build_model(cfgname, dev):
 
 
 def step(model, s, world):
-    out = model.forward_hot_path(s["img"], s["pts"], s["gemo"], s["img_feats"], s["transform"], render=True)
+    # the reference hard-codes the render bounds to a 100x100x8 volume (coocc_ray.py:577): smaller test grids
+    # (config1) cannot be rendered there either
+    X, Y, Z = s["img"].shape[2:]
+    out = model.forward_hot_path(s["img"], s["pts"], s["gemo"], s["img_feats"], s["transform"],
+                                 render=(X >= 100 and Y >= 100 and Z >= 8))
     if world > 1:
         out["all_rgbs"], out["all_depths"] = cdist.all_gather_maps(out["rgbs"], out["depths"])
     return out
@@ -112,7 +116,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="r50", choices=sorted(synth.CONFIGS))
-    ap.add_argument("--streams", type=int, default=3, help="samples in flight (software pipelining over HIP streams)")
+    ap.add_argument("--streams", type=int, default=1, help="samples in flight (software pipelining over HIP streams)")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="CUs set aside for the FPS chains (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event timing table to stderr")
@@ -124,7 +129,13 @@ def main():
     torch.cuda.set_device(dev)
     model, sd = build_model(args.config, dev)
     samples = [make_inputs(args.config, 1234 + 17 * rank + i, dev, model) for i in range(2)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    if args.reserve_cus > 0:
+        # CU partition: the FPS chains get private CUs, everything else runs on the remaining ones
+        from co_occ_amd import streams as cstreams
+        parts = [cstreams.partition(dev, reserved=args.reserve_cus) for _ in range(max(1, args.streams))]
+        streams = [p.main for p in parts]
+    else:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
     import threading
 

@@ -29,6 +29,9 @@ P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_int64
 SIGNATURES = {
     "coocc_last_error": (ctypes.c_char_p, []),
     "coocc_abi_version": (I, []),
+    "coocc_device_cu_count": (I, [P]),
+    "coocc_stream_create_cu_mask": (I, [P, I, P]),
+    "coocc_stream_destroy": (I, [P]),
     "coocc_ncdhw_to_ndhwc": (I, [P, P, I, I, I, I, I, P]),
     "coocc_ndhwc_to_ncdhw": (I, [P, P, I, I, I, I, I, P]),
     "coocc_fuser_prepare": (I, [P, P, P, P, P, I, I, I, P]),

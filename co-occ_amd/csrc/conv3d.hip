@@ -25,7 +25,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS_ST 36  // LDS row stride in floats: 144 B rows keep ds_read_b128 conflict-free
 #define NPAD_TO 128
 
-// Packed weight layout ("fragment-major"): for K-chunk c = tap*kchunks + kc and 128-column group g,
+// K-chunks are ordered channel-chunk major, tap minor (c = kc*taps + tap): all 27 taps of one 32-channel
+// slice are consumed back to back, so the activation lines they share are re-read from L2 at a reuse
+// distance of one tile-slab slice (~1.5 MB) instead of a whole channel sweep.
+// Packed weight layout ("fragment-major"): for K-chunk c and 128-column group g,
 // one 16 KB block [wn 0..3][q 0..3][lane 0..63][4]: lane (h = lane>>5, li = lane&31) of wave wn holds
 // W[n = 128g + 32wn + li][k = 32c' + 8q + 4h + 0..3] -- exactly the B operand of four MFMA k-steps, so
 // k_conv2 loads B fragments straight from global memory (no LDS), and k_conv stages the same block.
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
 
   f32x4 ra[PA], rb[PB];
   auto gload = [&](int it) {
-    const int t = it / p.kchunks, kc = it - t * p.kchunks;
+    const int kc = it / p.taps, t = it - kc * p.taps;
 #pragma unroll
     for (int b = 0; b < PB; ++b)
       rb[b] = *(const f32x4*)(p.w + wfrag_index((size_t)it, p.Npad >> 7, n0 + lrow + 32 * b, piece * 4));
@@ -308,8 +311,9 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
 
   f32x4 rq[PF][PA], bq[PF][4], bcur[4];   // slot 0 = chunk it+1 (oldest) ... slot PF-1 = chunk it+PF (just issued)
   // uniform cursor (tap (kd,kh,kw), channel chunk kc, chunk index lc) of the chunk being LOADED
-  int lc = it0, lt = it0 / p.kchunks, lkc = it0 - lt * p.kchunks;
-  int lkw = lt % p.ksize, lkh = (lt / p.ksize) % p.ksize, lkd = lt / (p.ksize * p.ksize);
+  int lc = it0, lkc = it0 / p.taps;
+  const int lt0 = it0 - lkc * p.taps;
+  int lkw = lt0 % p.ksize, lkh = (lt0 / p.ksize) % p.ksize, lkd = lt0 / (p.ksize * p.ksize);
   auto issue_loads = [&](bool live, int slot_) {
     const unsigned soff = (unsigned)(((((size_t)lc * ngroups + nt) * 4 + wn) * 1024) * 4);
 #pragma unroll
@@ -326,13 +330,13 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
       rq[slot_][a] = buf_load4(rs_in, voff, 0);
     }
     // advance the cursor (scalar, branch-free so the loop body stays one basic block)
-    lc += 1; lkc += 1;
-    const int w1 = lkc == p.kchunks;
-    lkc = w1 ? 0 : lkc; lkw += w1;
+    lc += 1; lkw += 1;                         // taps innermost, then the next channel chunk
     const int w2 = lkw == p.ksize;
     lkw = w2 ? 0 : lkw; lkh += w2;
     const int w3 = lkh == p.ksize;
     lkh = w3 ? 0 : lkh; lkd += w3;
+    const int w4 = lkd == p.ksize;
+    lkd = w4 ? 0 : lkd; lkc += w4;
   };
   auto lstore = [&](int buf) {
 #pragma unroll
@@ -438,7 +442,7 @@ extern "C" int64_t coocc_conv_pack_weights(const float* w_host, int Cout, int Ci
     for (int n = 0; n < Cout; ++n)
       for (int c = 0; c < Cin; ++c) {
         float v = tap_major ? w_host[((size_t)n * taps + t) * Cin + c] : w_host[((size_t)n * Cin + c) * taps + t];
-        packed_host[wfrag_index((size_t)t * kch + c / KC, Npad >> 7, n, c % KC)] = v;
+        packed_host[wfrag_index((size_t)(c / KC) * taps + t, Npad >> 7, n, c % KC)] = v;
       }
   return total;
 }

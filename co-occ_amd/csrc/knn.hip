@@ -212,6 +212,8 @@ __global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int
                                                          const int32_t* __restrict__ lin, FpsCell* __restrict__ cell,
                                                          int32_t* __restrict__ idx, int L, int q, int RB, long long* dbg) {
   constexpr int NW = THREADS / 64;
+  // latency-bound serial chain: when convolution waves share the CU, win every issue arbitration
+  __builtin_amdgcn_s_setprio(3);
   __shared__ KT wbest[2][NW];
   __shared__ int wloc[2][NW];   // packed sample coordinates x | y << 10 | z << 20 of the wave's best point
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -236,3 +236,31 @@ extern "C" int coocc_lin_to_coords(const int32_t* lin, int n, int X, int Y, int 
   COOCC_LAUNCH_CHECK("k_lin_to_coords");
   return COOCC_OK;
 }
+
+// ------------------------------------------------------------------ CU-partitioned streams
+// The FPS chains are latency-bound single workgroups; sharing a CU with convolution waves doubles
+// their time (measured).  hipExtStreamCreateWithCUMask gives them private CUs: one stream restricted
+// to a few reserved CUs for the FPS kernels, one stream restricted to all the others for the rest.
+extern "C" int coocc_device_cu_count(int* n) {
+  COOCC_CHECK_ARG(n, "device_cu_count: null");
+  int dev = 0;
+  COOCC_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  COOCC_HIP(hipGetDeviceProperties(&prop, dev));
+  *n = prop.multiProcessorCount;
+  return COOCC_OK;
+}
+
+extern "C" int coocc_stream_create_cu_mask(const uint32_t* mask_host, int nwords, void** stream_out) {
+  COOCC_CHECK_ARG(mask_host && nwords > 0 && stream_out, "stream_create_cu_mask: bad args");
+  hipStream_t s = nullptr;
+  COOCC_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask_host));
+  *stream_out = (void*)s;
+  return COOCC_OK;
+}
+
+extern "C" int coocc_stream_destroy(void* stream) {
+  COOCC_CHECK_ARG(stream, "stream_destroy: null");
+  COOCC_HIP(hipStreamDestroy(as_stream(stream)));
+  return COOCC_OK;
+}

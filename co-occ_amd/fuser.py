@@ -9,7 +9,7 @@ FPS ties exactly as the reference block reduction.
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, streams
 from ._lib import call, ptr
 from .core import PackCache, PackedConv, Rows, conv_rows, gather_conv_rows
 from .registry import FUSION_LAYERS
@@ -29,14 +29,31 @@ SPLIT_CON_ENC = int(__import__("os").environ.get("COOCC_SPLIT_CON_ENC", "0"))
 def _side_stream(dev, cur, which=0):
     key = (dev.index, cur.cuda_stream, which)
     if key not in _side:
-        _side[key] = torch.cuda.Stream(device=dev)
+        _side[key] = streams.side_stream_for(cur, which) or torch.cuda.Stream(device=dev)
     return _side[key]
 
 FPS_MAX_BUCKETS = 8 * 1024     # FPS_RMAX * threads of csrc/knn.hip k_fps_voxels
 
 
-def _fps_voxels(q_lin, grid, fps_num):
-    """FPS on a voxel list with the bucket-pruned kernel (same result as the generic one)."""
+def _fps_voxels(q_lin, grid, fps_num, which=0, home=None):
+    """FPS on a voxel list with the bucket-pruned kernel (same result as the generic one).
+    When the pipeline runs on CU-partitioned streams (co_occ_amd.streams) the kernel is issued on
+    the reserved-CU stream paired with `home` (the pipeline's main stream) and joined back."""
+    dev = q_lin.device
+    cur = torch.cuda.current_stream(dev)
+    fstream = streams.fps_stream_for(home if home is not None else cur, which)
+    if fstream is not None:
+        fstream.wait_stream(cur)
+        with torch.cuda.stream(fstream):
+            out = _fps_voxels_on_current(q_lin, grid, fps_num)
+        cur.wait_stream(fstream)
+        out.record_stream(cur)
+        q_lin.record_stream(fstream)
+        return out
+    return _fps_voxels_on_current(q_lin, grid, fps_num)
+
+
+def _fps_voxels_on_current(q_lin, grid, fps_num):
     dev = q_lin.device
     X, Y, Z = grid
     need = int(_lib.load().coocc_fps_voxels_ws(X, Y, Z))
@@ -49,7 +66,8 @@ def _fps_voxels(q_lin, grid, fps_num):
     return out
 
 
-def _fps_nn_xyz(query_xyz, key_xyz, fps_num, radius, max_cluster_samples, dist_thresh, num, q_lin=None, grid=None):
+def _fps_nn_xyz(query_xyz, key_xyz, fps_num, radius, max_cluster_samples, dist_thresh, num, q_lin=None, grid=None,
+                which=0, home=None):
     """Index search on float xyz rows.  Returns int32 [num, Q] of key ordinals (-1 = none).
     q_lin/grid: the queries as distinct voxels of one grid -> pruned FPS kernel."""
     dev = query_xyz.device
@@ -67,7 +85,7 @@ def _fps_nn_xyz(query_xyz, key_xyz, fps_num, radius, max_cluster_samples, dist_t
         call("coocc_knn_threshold", Q, float(dist_thresh), ptr(val), ptr(nn_), ptr(out))
         return out
     if q_lin is not None and grid is not None and (grid[0] + 3) // 4 * ((grid[1] + 3) // 4) * ((grid[2] + 7) // 8) <= FPS_MAX_BUCKETS:
-        repr_idx = _fps_voxels(q_lin, grid, fps_num)
+        repr_idx = _fps_voxels(q_lin, grid, fps_num, which, home)
     else:
         repr_idx = torch.empty(1, fps_num, device=dev, dtype=_I32)
         temp = torch.empty(1, Q, device=dev, dtype=_F32)
@@ -172,13 +190,13 @@ class BiFuser_N(nn.Module):
             with torch.cuda.stream(side):
                 # img queries <- nearest pts keys (:150-162); for knum > 1 the reference indexes
                 # inds_img with the pts ordinals (:158) -- kept
-                near_pts = _fps_nn_xyz(xyz_img, xyz_pts, q_lin=lin_img if vox else None, grid=vox, **kw)
+                near_pts = _fps_nn_xyz(xyz_img, xyz_pts, q_lin=lin_img if vox else None, grid=vox, which=1, home=cur, **kw)
                 rows_p = torch.empty(K, Ni, device=dev, dtype=_I32)
                 base, nbase = (lin_pts, Np) if K == 1 else (lin_img, Ni)
                 for k in range(K):
                     call("coocc_index_rows_i32", ptr(base), nbase, ptr(near_pts[k]), Ni, ptr(rows_p[k]))
             # pts queries <- nearest img keys (bifuser_n.py:137-148)
-            near_img = _fps_nn_xyz(xyz_pts, xyz_img, q_lin=lin_pts if vox else None, grid=vox, **kw)
+            near_img = _fps_nn_xyz(xyz_pts, xyz_img, q_lin=lin_pts if vox else None, grid=vox, which=0, home=cur, **kw)
             if early is not None:
                 early(Rows(cat4, B, X, Y, Z, 4 * C), rows_ready)
             rows = torch.empty(K, Np, device=dev, dtype=_I32)

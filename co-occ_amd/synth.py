@@ -11,7 +11,8 @@ import torch
 
 CONFIGS = {
     # name: fused grid, cams, feature map (fH,fW), knum, channels
-    "config1": dict(grid=(50, 50, 4), ncam=1, fmap=(16, 44), knum=4, C=128),
+    # configs[0]: dense enough that both voxel lists exceed 2048 (knum > 1 needs the large path)
+    "config1": dict(grid=(50, 50, 4), ncam=1, fmap=(16, 44), knum=4, C=128, p_img=0.8, p_pts=0.5),
     "r50": dict(grid=(100, 100, 8), ncam=6, fmap=(16, 44), knum=2, C=128),          # coocc_multi_r50_256x704
     "r101": dict(grid=(100, 100, 8), ncam=6, fmap=(56, 100), knum=2, C=128),        # coocc_multi_r101_896x1600
     "stress200": dict(grid=(200, 200, 16), ncam=6, fmap=(16, 44), knum=2, C=128),   # north_star stress grid

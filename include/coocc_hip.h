@@ -36,6 +36,13 @@ extern "C" {
 const char* coocc_last_error(void);
 int coocc_abi_version(void);
 
+/* ---------------------------------------------------------------- CU-partitioned streams */
+/* hipExtStreamCreateWithCUMask wrappers (mask_host: bit i = CU i enabled, nwords 32-bit words).
+ * Used to give the single-workgroup FPS chains private CUs next to the convolution stream. */
+int coocc_device_cu_count(int* n);
+int coocc_stream_create_cu_mask(const uint32_t* mask_host, int nwords, void** stream_out);
+int coocc_stream_destroy(void* stream);
+
 /* ---------------------------------------------------------------- layout / K1 */
 
 /* [B,C,V] (reference NCDHW, V = X*Y*Z) -> rows of `dst_stride` floats at channel

@@ -81,7 +81,7 @@ def test_pack_weights_host_layout():
     packed = np.zeros(n, np.float32)
     lib.coocc_conv_pack_weights(w.ctypes.data, Cout, Cin, taps, 0, packed.ctypes.data)
     for t, n_, c in [(0, 0, 0), (26, 4, 39), (13, 2, 31), (5, 132, 32), (7, 127, 17), (9, 128, 3)]:
-        assert packed[_wfrag_index(t * 2 + c // 32, 2, n_, c % 32)] == w[n_, c, t]
+        assert packed[_wfrag_index((c // 32) * taps + t, 2, n_, c % 32)] == w[n_, c, t]      # chunk = kc*taps + tap
     assert np.count_nonzero(packed) == np.count_nonzero(w)   # everything else is zero padding
     wl = np.arange(5 * 3 * 8, dtype=np.float32).reshape(5, 3 * 8)                  # Linear(C*K -> Cout), K=3, C=8
     n = lib.coocc_conv_pack_weights(wl.ctypes.data, 5, 8, 3, 1, None)
