@@ -60,12 +60,15 @@ SIGNATURES = {
     "coocc_bev_pool_backward": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
     "coocc_voxel_pool_ws": (Z, [I, I]),
     "coocc_voxel_pool": (I, [P, P, I, I, I, P, I, I, I, I, P, I, P, Z, P]),
+    "coocc_lift_splat": (I, [P, P, P, I, I, I, I, I, I, P, I, I, I, I, P, I, P, Z, P]),
+    "coocc_lift_splat_cams": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, I, I, I, I, P, I, P, Z, P]),
     "coocc_bev_pool_coords": (I, [P, P, I, I, I, I, I, I, P, I, P, Z, P]),
     "coocc_render_nearest": (I, [P, I, I, I, P, P, I, I, I, I, P, P, P]),
     "coocc_upsample_maps": (I, [P, I, I, I, I, P, P, P]),
     "coocc_volume_sampling": (I, [P, I, I, I, I, P, I, P, P, P, P]),
     "coocc_raw2outputs": (I, [P, P, I, I, I, F, F, P, P, P, P]),
     "coocc_render_losses": (I, [P, P, P, P, L, I, P, P]),
+    "coocc_eval_semantic": (I, [P, L, L, L, L, I, I, I, I, P, P, I, I, I, I, I, P, P]),
 }
 
 _lib = None
@@ -161,15 +164,16 @@ class DevPtr(ctypes.c_void_p):
     while later arguments of the same call are still being built."""
 
 
-def ptr(t, dtype=None):
-    """Device pointer of a contiguous HIP tensor (None -> NULL)."""
+def ptr(t, dtype=None, strided=False):
+    """Device pointer of a contiguous HIP tensor (None -> NULL).  ``strided=True`` is for entry points that
+    take element strides explicitly."""
     if t is None:
         return c_void_p(0)
     if not t.is_cuda:
         raise CooccError("co_occ_amd ops run on the GPU only; got a %s tensor (no CPU fallback)" % t.device)
     if dtype is not None and t.dtype != dtype:
         raise CooccError("expected %s, got %s" % (dtype, t.dtype))
-    if not t.is_contiguous():
+    if not strided and not t.is_contiguous():
         raise CooccError("tensor must be contiguous")
     p = DevPtr(t.data_ptr())
     p._keep = t

@@ -17,12 +17,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ViewTransformerLSSBEVDepth.py:117-150.  mats[cam] = {A=inv(post_rots)[9], post_trans[3],
 // Cm=rots@inv(intrins)[9], trans[3], bda[9]} (33 floats); xs/ys/ds = the frustum axes of
 // create_frustum (:104-115) computed by the host with the same torch calls.
-__global__ __launch_bounds__(256) void k_get_geometry(const float* __restrict__ mats, const float* __restrict__ xs,
-                                                       const float* __restrict__ ys, const float* __restrict__ ds,
-                                                       int BN, int D, int fH, int fW, float* __restrict__ geom) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)BN * D * fH * fW;
-  if (i >= total) return;
+__device__ __forceinline__ void geometry_point(const float* __restrict__ mats, const float* __restrict__ xs,
+                                               const float* __restrict__ ys, const float* __restrict__ ds, size_t i, int D,
+                                               int fH, int fW, float& gx, float& gy, float& gz) {
   int w = (int)(i % fW); size_t r = i / fW;
   int h = (int)(r % fH); r /= fH;
   int d = (int)(r % D); int cam = (int)(r / D);
@@ -35,10 +32,19 @@ __global__ __launch_bounds__(256) void k_get_geometry(const float* __restrict__ 
   float ex = m[12] * qx + m[13] * qy + m[14] * qz + m[21];
   float ey = m[15] * qx + m[16] * qy + m[17] * qz + m[22];
   float ez = m[18] * qx + m[19] * qy + m[20] * qz + m[23];
+  gx = m[24] * ex + m[25] * ey + m[26] * ez;
+  gy = m[27] * ex + m[28] * ey + m[29] * ez;
+  gz = m[30] * ex + m[31] * ey + m[32] * ez;
+}
+
+__global__ __launch_bounds__(256) void k_get_geometry(const float* __restrict__ mats, const float* __restrict__ xs,
+                                                       const float* __restrict__ ys, const float* __restrict__ ds,
+                                                       int BN, int D, int fH, int fW, float* __restrict__ geom) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)BN * D * fH * fW;
+  if (i >= total) return;
   float* o = geom + i * 3;
-  o[0] = m[24] * ex + m[25] * ey + m[26] * ez;
-  o[1] = m[27] * ex + m[28] * ey + m[29] * ez;
-  o[2] = m[30] * ex + m[31] * ey + m[32] * ez;
+  geometry_point(mats, xs, ys, ds, i, D, fH, fW, o[0], o[1], o[2]);
 }
 
 extern "C" int coocc_get_geometry(const float* mats, const float* xs, const float* ys, const float* ds, int BN, int D,
@@ -113,21 +119,38 @@ extern "C" int coocc_bev_pool_backward(const float* out_grad, const int32_t* geo
 
 // ------------------------------------------------------------------ P2: sort-by-voxel pooling
 // keys: voxel row (b,x,y,z order) or nvox for dropped points
+// ((geom - (bx - dx/2)) / dx).long(): truncation toward zero BEFORE the range filter
+// (ViewTransformerLSSVoxel.py:107,113-115), so (-1,0) lands in voxel 0.
+__device__ __forceinline__ uint32_t voxel_key(float x, float y, float z, int b, float lox, float loy, float loz, float dx,
+                                              float dy, float dz, int X, int Y, int Z, int nvox) {
+  float gx = __fdiv_rn(x - lox, dx), gy = __fdiv_rn(y - loy, dy), gz = __fdiv_rn(z - loz, dz);
+  long long ix = (long long)gx, iy = (long long)gy, iz = (long long)gz;
+  bool kept = ix >= 0 && ix < X && iy >= 0 && iy < Y && iz >= 0 && iz < Z;
+  return kept ? (uint32_t)((((size_t)b * X + ix) * Y + iy) * Z + iz) : (uint32_t)nvox;
+}
+
 __global__ __launch_bounds__(256) void k_quantize_geom(const float* __restrict__ geom, int npts, int pts_per_batch,
                                                         float lox, float loy, float loz, float dx, float dy, float dz,
                                                         int X, int Y, int Z, int nvox, uint32_t* __restrict__ keys,
                                                         uint32_t* __restrict__ ids) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npts) return;
-  // ((geom - (bx - dx/2)) / dx).long(): truncation toward zero BEFORE the range filter
-  // (ViewTransformerLSSVoxel.py:107,113-115), so (-1,0) lands in voxel 0.
-  float gx = __fdiv_rn(geom[(size_t)i * 3 + 0] - lox, dx);
-  float gy = __fdiv_rn(geom[(size_t)i * 3 + 1] - loy, dy);
-  float gz = __fdiv_rn(geom[(size_t)i * 3 + 2] - loz, dz);
-  long long ix = (long long)gx, iy = (long long)gy, iz = (long long)gz;
-  bool kept = ix >= 0 && ix < X && iy >= 0 && iy < Y && iz >= 0 && iz < Z;
-  int b = i / pts_per_batch;
-  keys[i] = kept ? (uint32_t)((((size_t)b * X + ix) * Y + iy) * Z + iz) : (uint32_t)nvox;
+  keys[i] = voxel_key(geom[(size_t)i * 3 + 0], geom[(size_t)i * 3 + 1], geom[(size_t)i * 3 + 2], i / pts_per_batch, lox,
+                      loy, loz, dx, dy, dz, X, Y, Z, nvox);
+  ids[i] = (uint32_t)i;
+}
+
+// geometry computed in-kernel from the camera matrices (no [npts,3] geom tensor)
+__global__ __launch_bounds__(256) void k_quantize_cams(const float* __restrict__ mats, const float* __restrict__ xs,
+                                                        const float* __restrict__ ys, const float* __restrict__ ds, int D,
+                                                        int fH, int fW, int npts, int pts_per_batch, float lox, float loy,
+                                                        float loz, float dx, float dy, float dz, int X, int Y, int Z,
+                                                        int nvox, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npts) return;
+  float gx, gy, gz;
+  geometry_point(mats, xs, ys, ds, (size_t)i, D, fH, fW, gx, gy, gz);
+  keys[i] = voxel_key(gx, gy, gz, i / pts_per_batch, lox, loy, loz, dx, dy, dz, X, Y, Z, nvox);
   ids[i] = (uint32_t)i;
 }
 
@@ -153,19 +176,57 @@ __global__ __launch_bounds__(256) void k_segment_bounds(const uint32_t* __restri
   if (k < (uint32_t)nvox && (i == npts - 1 || keys[i + 1] != k)) seg_end[k] = i + 1;
 }
 
-// one wave per voxel row; 4 channels per lane per step; rows summed in sorted (= ascending id) order
+// One wave per voxel row, 4 channels per lane.  Rows are summed in sorted (= ascending id) order with a
+// single accumulator, the association of the reference's interval kernel, but the loads run ahead: the
+// wave fetches 64 ids at once, broadcasts them through SGPRs (v_readlane) and keeps POOL_BATCH independent
+// row loads in flight before the dependent adds.  The longest voxel holds 484 (r50) / 2576 (r101) points,
+// so the serial chain, not bandwidth, bounds this kernel.
+constexpr int POOL_BATCH = 16;
+
+template <bool LIFT>
+__device__ __forceinline__ void pool_row(const float* __restrict__ x, const float* __restrict__ depth,
+                                         const uint32_t* __restrict__ ids, int s, int e, int lane, int C, int D, int HW,
+                                         float* __restrict__ orow) {
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool lane_on = c < C;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int base = s; base < e; base += 64) {
+      const int nb = min(64, e - base);
+      const uint32_t myid = ids[base + min(lane, nb - 1)];
+      for (int j0 = 0; j0 < nb; j0 += POOL_BATCH) {
+        f32x4 r[POOL_BATCH];
+#pragma unroll
+        for (int j = 0; j < POOL_BATCH; ++j) {
+#pragma clang fp contract(off)  // LIFT: the product is rounded before the add, as the materialised volume is
+          const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)myid, min(j0 + j, nb - 1));
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (LIFT) {
+            const uint32_t n = id / (uint32_t)(D * HW), hw = id % (uint32_t)HW;
+            const float dp = depth[id];
+            if (lane_on) v = *(const f32x4*)(x + ((size_t)n * HW + hw) * C + c);
+            v = dp * v;
+          } else {
+            if (lane_on) v = *(const f32x4*)(x + (size_t)id * C + c);
+          }
+          r[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < POOL_BATCH; ++j)
+          if (j0 + j < nb) acc = acc + r[j];
+      }
+    }
+    if (lane_on) *(f32x4*)(orow + c) = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_pool_sum(const float* __restrict__ x, const uint32_t* __restrict__ ids,
                                                    const int32_t* __restrict__ seg_start,
                                                    const int32_t* __restrict__ seg_end, int nvox, int C,
                                                    float* __restrict__ out, int out_stride) {
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   if (v >= nvox) return;
-  const int s = seg_start[v], e = seg_end[v];
-  for (int c = lane * 4; c < C; c += 256) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int i = s; i < e; ++i) acc = acc + *(const f32x4*)(x + (size_t)ids[i] * C + c);
-    *(f32x4*)(out + (size_t)v * out_stride + c) = acc;
-  }
+  pool_row<false>(x, nullptr, ids, seg_start[v], seg_end[v], lane, C, 0, 0, out + (size_t)v * out_stride);
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -227,6 +288,73 @@ extern "C" int coocc_voxel_pool(const float* x, const float* geom, int npts, int
                      l[3], l[4], l[5], X, Y, Z, nvox, p.k_in, p.i_in);
   return pool_sorted(x, npts, C, nvox, out, out_stride, p.k_in, p.k_out, p.i_in, p.i_out, p.seg_s, p.seg_e, p.tmp,
                      p.tmp_bytes, s);
+}
+
+// ------------------------------------------------------------------ fused lift (x) splat
+// ViewTransformerLSSVoxel.py:135-143 computes volume = depth_prob[n,d,h,w] * img_feat[n,c,h,w] (242 MB at
+// r50, 1.93 GB at r101) and pools it.  Here the product is formed on the fly inside the per-voxel sum:
+// point id = ((n*D + d)*H + h)*W + w indexes depth directly and selects the context row (n,h,w).
+// Products are rounded to fp32 before the add (no FMA), in ascending point id: bit-equal to pooling the
+// materialised volume with the stable order.
+__global__ __launch_bounds__(256) void k_lift_pool_sum(const float* __restrict__ depth, const float* __restrict__ feat,
+                                                        const uint32_t* __restrict__ ids,
+                                                        const int32_t* __restrict__ seg_start,
+                                                        const int32_t* __restrict__ seg_end, int nvox, int C, int D, int HW,
+                                                        float* __restrict__ out, int out_stride) {
+  const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  if (v >= nvox) return;
+  pool_row<true>(feat, depth, ids, seg_start[v], seg_end[v], lane, C, D, HW, out + (size_t)v * out_stride);
+}
+
+static int lift_splat_impl(const float* depth, const float* feat_nhwc, const float* geom, const float* mats,
+                           const float* xs, const float* ys, const float* ds, int N, int D, int H, int W, int C,
+                           int pts_per_batch, const float* lo_dx_host, int B, int X, int Y, int Z, float* out,
+                           int out_stride, void* ws, size_t ws_bytes, void* stream) {
+  COOCC_CHECK_ARG(depth && feat_nhwc && out && lo_dx_host && N > 0 && D > 0 && H > 0 && W > 0, "lift_splat: bad args");
+  COOCC_CHECK_ARG(geom || (mats && xs && ys && ds), "lift_splat: geometry missing");
+  COOCC_CHECK_ARG(C > 0 && C % 4 == 0 && ((uintptr_t)feat_nhwc & 15) == 0 && out_stride % 4 == 0 && out_stride >= C &&
+                      ((uintptr_t)out & 15) == 0,
+                  "lift_splat: C % 4 == 0 and 16-byte aligned rows");
+  const long long npts_ll = (long long)N * D * H * W, nvox_ll = (long long)B * X * Y * Z;
+  COOCC_CHECK_ARG(npts_ll < (1ll << 31) && nvox_ll > 0 && nvox_ll < (1ll << 31) && pts_per_batch > 0, "lift_splat: sizes");
+  const int npts = (int)npts_ll, nvox = (int)nvox_ll;
+  PoolWs p;
+  int rc = carve(ws, ws_bytes, npts, nvox, &p);
+  if (rc) return rc;
+  hipStream_t s = as_stream(stream);
+  const float* l = lo_dx_host;
+  if (geom)
+    hipLaunchKernelGGL(k_quantize_geom, dim3(cdiv(npts, 256)), dim3(256), 0, s, geom, npts, pts_per_batch, l[0], l[1], l[2],
+                       l[3], l[4], l[5], X, Y, Z, nvox, p.k_in, p.i_in);
+  else
+    hipLaunchKernelGGL(k_quantize_cams, dim3(cdiv(npts, 256)), dim3(256), 0, s, mats, xs, ys, ds, D, H, W, npts,
+                       pts_per_batch, l[0], l[1], l[2], l[3], l[4], l[5], X, Y, Z, nvox, p.k_in, p.i_in);
+  int bits = 1;
+  while ((1ll << bits) <= nvox) ++bits;
+  COOCC_HIP(rocprim::radix_sort_pairs(p.tmp, p.tmp_bytes, p.k_in, p.k_out, p.i_in, p.i_out, (size_t)npts, 0, bits, s));
+  COOCC_HIP(hipMemsetAsync(p.seg_s, 0, 2 * align256(sizeof(int32_t) * (size_t)nvox), s));
+  hipLaunchKernelGGL(k_segment_bounds, dim3(cdiv(npts, 256)), dim3(256), 0, s, p.k_out, npts, nvox, p.seg_s, p.seg_e);
+  hipLaunchKernelGGL(k_lift_pool_sum, dim3(cdiv(nvox, 4)), dim3(256), 0, s, depth, feat_nhwc, p.i_out, p.seg_s, p.seg_e,
+                     nvox, C, D, H * W, out, out_stride);
+  COOCC_LAUNCH_CHECK("lift_splat");
+  return COOCC_OK;
+}
+
+extern "C" int coocc_lift_splat(const float* depth, const float* feat_nhwc, const float* geom, int N, int D, int H, int W,
+                                int C, int pts_per_batch, const float* lo_dx_host, int B, int X, int Y, int Z, float* out,
+                                int out_stride, void* ws, size_t ws_bytes, void* stream) {
+  COOCC_CHECK_ARG(geom, "lift_splat: null geom");
+  return lift_splat_impl(depth, feat_nhwc, geom, nullptr, nullptr, nullptr, nullptr, N, D, H, W, C, pts_per_batch,
+                         lo_dx_host, B, X, Y, Z, out, out_stride, ws, ws_bytes, stream);
+}
+
+extern "C" int coocc_lift_splat_cams(const float* depth, const float* feat_nhwc, const float* mats, const float* xs,
+                                     const float* ys, const float* ds, int N, int D, int H, int W, int C,
+                                     int pts_per_batch, const float* lo_dx_host, int B, int X, int Y, int Z, float* out,
+                                     int out_stride, void* ws, size_t ws_bytes, void* stream) {
+  COOCC_CHECK_ARG(mats && xs && ys && ds, "lift_splat_cams: null camera data");
+  return lift_splat_impl(depth, feat_nhwc, nullptr, mats, xs, ys, ds, N, D, H, W, C, pts_per_batch, lo_dx_host, B, X, Y,
+                         Z, out, out_stride, ws, ws_bytes, stream);
 }
 
 extern "C" int coocc_bev_pool_coords(const float* x, const int64_t* coords, int n, int C, int B, int X, int Y, int Z,

@@ -94,7 +94,20 @@ class COOCC_Ray(nn.Module):
         out = self.forward_hot_path(precomputed["img_voxel_feats"], precomputed["pts_voxel_feats"],
                                     precomputed.get("gemo"), precomputed.get("img_feats"), transform)
         out.update(output_voxels=out["pred_c"], target_voxels=gt_occ)
+        if gt_occ is not None:   # coocc_ray.py:540-554, one kernel per prediction, histograms stay on the device
+            from .evaluation import semantic_histograms, split_histograms
+            C = out["pred_c"].shape[1]
+            sc, ssc, occ = split_histograms(semantic_histograms(out["pred_c"], gt_occ, visible_mask, self.empty_idx), C)
+            out.update(SC_metric=sc, SSC_metric=ssc, SSC_occ_metric=occ if visible_mask is not None else None)
+            if out.get("pred_f") is not None:
+                sc, ssc, occ = split_histograms(semantic_histograms(out["pred_f"], gt_occ, visible_mask, self.empty_idx), C)
+                out.update(SC_metric=sc, SSC_metric_fine=ssc, SSC_occ_metric_fine=occ if visible_mask is not None else None)
         return out
+
+    def evaluation_semantic(self, pred, gt, eval_type, visible_mask=None):
+        """coocc_ray.py:659-684 on the device (no .cpu().numpy())."""
+        from .evaluation import evaluation_semantic
+        return evaluation_semantic(pred, gt, eval_type, visible_mask, self.empty_idx)
 
     def forward_test(self, img_metas=None, img_inputs=None, **kwargs):
         return self.simple_test(img_metas, img_inputs, **kwargs)

@@ -57,21 +57,26 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         ys = torch.linspace(0, ogfH - 1, fH, dtype=torch.float).view(1, fH, 1).expand(D, fH, fW)
         return nn.Parameter(torch.stack((xs, ys, ds), -1), requires_grad=False)
 
+    def _camera_mats(self, rots, trans, intrins, post_rots, post_trans, bda):
+        """Per-camera constants of the geometry chain (33 floats each) + the frustum axes."""
+        B, N, _ = trans.shape
+        if intrins.shape[3] == 4 or bda.shape[-1] == 4:
+            raise NotImplementedError("KITTI 3x4 intrinsics / 4x4 bda are not on the nuScenes path")
+        fr = self.frustum.to(trans.device)
+        xs, ys, ds = fr[0, 0, :, 0].contiguous(), fr[0, :, 0, 1].contiguous(), fr[:, 0, 0, 2].contiguous()
+        mats = torch.cat([torch.inverse(post_rots).reshape(B * N, 9), post_trans.reshape(B * N, 3),
+                          rots.matmul(torch.inverse(intrins)).reshape(B * N, 9), trans.reshape(B * N, 3),
+                          bda.view(B, 1, 9).expand(B, N, 9).reshape(B * N, 9)], 1).float().contiguous()
+        return mats, xs, ys, ds
+
     def get_geometry(self, rots, trans, intrins, post_rots, post_trans, bda):
         """ViewTransformerLSSBEVDepth.py:117-150 -> [B,N,D,fH,fW,3].  The 3x3 inverses and the
         rots @ inv(intrins) product are host-side torch (6 tiny matrices); the per-point chain
         runs in one HIP kernel."""
         B, N, _ = trans.shape
-        if intrins.shape[3] == 4 or bda.shape[-1] == 4:
-            raise NotImplementedError("KITTI 3x4 intrinsics / 4x4 bda are not on the nuScenes path")
-        dev = trans.device
-        fr = self.frustum.to(dev)
-        D, fH, fW, _ = fr.shape
-        xs, ys, ds = fr[0, 0, :, 0].contiguous(), fr[0, :, 0, 1].contiguous(), fr[:, 0, 0, 2].contiguous()
-        mats = torch.cat([torch.inverse(post_rots).reshape(B * N, 9), post_trans.reshape(B * N, 3),
-                          rots.matmul(torch.inverse(intrins)).reshape(B * N, 9), trans.reshape(B * N, 3),
-                          bda.view(B, 1, 9).expand(B, N, 9).reshape(B * N, 9)], 1).float().contiguous()
-        geom = torch.empty(B, N, D, fH, fW, 3, device=dev, dtype=_F32)
+        mats, xs, ys, ds = self._camera_mats(rots, trans, intrins, post_rots, post_trans, bda)
+        D, fH, fW = ds.numel(), ys.numel(), xs.numel()
+        geom = torch.empty(B, N, D, fH, fW, 3, device=trans.device, dtype=_F32)
         call("coocc_get_geometry", ptr(mats), ptr(xs), ptr(ys), ptr(ds), B * N, D, fH, fW, ptr(geom))
         return geom
 
@@ -89,6 +94,36 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         ws = _pool_workspace(x.device, Nprime, B * X * Y * Z)
         call("coocc_voxel_pool", ptr(xf), ptr(g), Nprime, Nprime // B, C, host_f32(lo + self.dx.tolist()), B, X, Y, Z,
              ptr(out), C, ptr(ws), ws.numel())
+        return out.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
+
+    def lift_splat(self, depth_prob, img_feat, geom_feats=None, cams=None):
+        """Fused Lift + Splat (ViewTransformerLSSVoxel.py:135-145 without the [B,N,D,H,W,C] volume):
+        depth_prob [B*N,D,H,W], img_feat [B*N,C,H,W] -> [B,C,X,Y,Z].  Geometry is either the tensor
+        get_geometry returned ([B,N,D,H,W,3]) or, with cams=(rots, trans, intrins, post_rots, post_trans,
+        bda), computed inside the key kernel so it never exists in HBM."""
+        BN, C, H, W = img_feat.shape
+        D = depth_prob.shape[1]
+        assert tuple(depth_prob.shape) == (BN, D, H, W) and (geom_feats is None) != (cams is None)
+        B = geom_feats.shape[0] if cams is None else cams[1].shape[0]
+        X, Y, Z = (int(v) for v in self.nx.tolist())
+        dev = img_feat.device
+        feat = torch.empty(BN * H * W, C, device=dev, dtype=_F32)
+        call("coocc_ncdhw_to_ndhwc", ptr(img_feat.float().contiguous()), ptr(feat), BN, C, H * W, C, 0)
+        lo = host_f32((self.bx - self.dx / 2.).tolist() + self.dx.tolist())
+        npts = BN * D * H * W
+        out = torch.empty(B * X * Y * Z, C, device=dev, dtype=_F32)
+        ws = _pool_workspace(dev, npts, B * X * Y * Z)
+        dp = depth_prob.float().contiguous()
+        if cams is None:
+            assert geom_feats.numel() == npts * 3
+            g = geom_feats.reshape(-1, 3).float().contiguous()
+            call("coocc_lift_splat", ptr(dp), ptr(feat), ptr(g), BN, D, H, W, C, npts // B, lo, B, X, Y, Z, ptr(out), C,
+                 ptr(ws), ws.numel())
+        else:
+            mats, xs, ys, ds = self._camera_mats(*cams)
+            assert (ds.numel(), ys.numel(), xs.numel()) == (D, H, W)
+            call("coocc_lift_splat_cams", ptr(dp), ptr(feat), ptr(mats), ptr(xs), ptr(ys), ptr(ds), BN, D, H, W, C,
+                 npts // B, lo, B, X, Y, Z, ptr(out), C, ptr(ws), ws.numel())
         return out.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
 
     def forward(self, input):

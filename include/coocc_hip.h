@@ -210,6 +210,18 @@ size_t coocc_voxel_pool_ws(int npts, int nvox);
 int coocc_voxel_pool(const float* x, const float* geom, int npts, int pts_per_batch, int C,
                      const float* lo_dx_host, int B, int X, int Y, int Z, float* out, int out_stride,
                      void* ws, size_t ws_bytes, void* stream);
+/* Fused lift (x) splat (ViewTransformerLSSVoxel.py:135-143 + voxel_pooling): the lifted
+ * volume depth_prob[n,d,h,w] * img_feat[n,c,h,w] is never materialised.  depth:[N,D,H,W]; feat_nhwc:
+ * [N,H,W,C]; geom:[N*D*H*W,3]; out NDHWC rows; same workspace as coocc_voxel_pool(N*D*H*W, B*X*Y*Z).
+ * Bit-equal to pooling the materialised volume (products rounded before the add, ascending point id). */
+int coocc_lift_splat(const float* depth, const float* feat_nhwc, const float* geom, int N, int D, int H, int W,
+                     int C, int pts_per_batch, const float* lo_dx_host, int B, int X, int Y, int Z, float* out,
+                     int out_stride, void* ws, size_t ws_bytes, void* stream);
+/* Same, with the geometry of coocc_get_geometry computed inside the key kernel (no [npts,3] tensor in HBM). */
+int coocc_lift_splat_cams(const float* depth, const float* feat_nhwc, const float* mats, const float* xs,
+                          const float* ys, const float* ds, int N, int D, int H, int W, int C,
+                          int pts_per_batch, const float* lo_dx_host, int B, int X, int Y, int Z, float* out,
+                          int out_stride, void* ws, size_t ws_bytes, void* stream);
 /* bev_pool(feats, coords, ...) drop-in (M/ops/bev_pool/bev_pool.py:83-97): coords:[n,4]
  * (x,y,z,b) i64; same sort-and-sum, out NDHWC rows. */
 int coocc_bev_pool_coords(const float* x, const int64_t* coords, int n, int C, int B, int X, int Y,
@@ -242,6 +254,17 @@ int coocc_raw2outputs(const float* raw, const float* z, int R, int S, int white_
  * rgbs/rgb_gt:[npix,3]; depths/depth_gt:[npix]. */
 int coocc_render_losses(const float* rgbs, const float* depths, const float* rgb_gt,
                         const float* depth_gt, int64_t npix, int D, float* out, void* stream);
+
+/* On-device evaluation: COOCC_Ray.evaluation_semantic coocc_ray.py:659-684 + fast_hist
+ * :726-730 without the device->host copy.  pred: class logits on an h x w x d grid addressed by element strides
+ * (so both the channels-last pred_c rows and the NCDHW pred_f grid work); gt:[H,W,D] u8 labels (255 = noise);
+ * visible:[H,W,D] u8 or NULL.  hist (int64, device) = [ SC 2x2 | SSC CxC | OCC CxC ], each indexed
+ * [label][pred]; SC bins are (label != empty_idx, pred != empty_idx).  accumulate != 0 adds to hist instead
+ * of overwriting it (whole-dataset accumulation with one read-back).  C <= 32. */
+int coocc_eval_semantic(const float* pred, int64_t stride_c, int64_t stride_x, int64_t stride_y,
+                        int64_t stride_z, int C, int h, int w, int d, const uint8_t* gt,
+                        const uint8_t* visible, int H, int W, int D, int empty_idx, int accumulate,
+                        int64_t* hist, void* stream);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,22 @@ RAY_CASE = dict(vol=(10, 24, 20), C=8, n_rays=48, n_samples=16, aabb=([-12., -10
                 near_far=(0.5, 14.0), seed=51)
 
 
+EVAL_CASE = dict(coarse=(10, 12, 4), gt=(20, 24, 8), ncls=17, p_noise=0.05, p_visible=0.6, seed=61)
+
+
+def eval_inputs(c, same_size=False):
+    """logits [1,C,h,w,d], gt [1,H,W,D] u8 with 255 noise, visible [1,H,W,D] u8."""
+    g = np.random.default_rng(c["seed"] + (1 if same_size else 0))
+    H, W, D = c["gt"]
+    shape = c["gt"] if same_size else c["coarse"]
+    pred = torch.from_numpy(g.standard_normal((1, c["ncls"]) + tuple(shape), dtype=np.float32) * 2)
+    gt = g.integers(0, c["ncls"], (1, H, W, D)).astype(np.uint8)
+    gt[g.random((1, H, W, D)) < 0.5] = 0                      # mostly free space, as in nuScenes-Occ
+    gt[g.random((1, H, W, D)) < c["p_noise"]] = 255
+    vis = (g.random((1, H, W, D)) < c["p_visible"]).astype(np.uint8)
+    return pred, torch.from_numpy(gt), torch.from_numpy(vis)
+
+
 def fuser_inputs(c):
     img, pts = synth.voxel_inputs(c["grid"], C=c["C"], seed=c["seed"], p_img=c["p_img"], p_pts=c["p_pts"])
     if "img_x_below" in c:

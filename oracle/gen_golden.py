@@ -229,6 +229,27 @@ def gen_rays(R):
          weights=r1["weights"], ray_mask=r1["mask"], rgb_white=r2["rgb"], get_weights=w)
 
 
+def gen_eval(R):
+    """COOCC_Ray.evaluation_semantic run unmodified (np.int restored for numpy 2) on a coarse and a
+    gt-sized prediction; the oracle must give the same three confusion matrices."""
+    c = cases.EVAL_CASE
+    cr = R["coocc_ray"]
+    if not hasattr(np, "int"):
+        np.int = int
+    stub = types.SimpleNamespace(empty_idx=0)
+    out = {}
+    for tag, same in (("coarse", False), ("full", True)):
+        pred, gt, vis = cases.eval_inputs(c, same)
+        sc, _ = cr.COOCC_Ray.evaluation_semantic(stub, pred, gt.clone(), 'SC', visible_mask=vis)
+        ssc, occ = cr.COOCC_Ray.evaluation_semantic(stub, pred, gt.clone(), 'SSC', visible_mask=vis)
+        o_sc = ref_cpu.evaluation_semantic(pred, gt, 'SC', vis)[0]
+        o_ssc, o_occ, _ = ref_cpu.evaluation_semantic(pred, gt, 'SSC', vis)
+        assert np.array_equal(sc, o_sc) and np.array_equal(ssc, o_ssc) and np.array_equal(occ, o_occ), tag
+        out.update({tag + "_sc": sc, tag + "_ssc": ssc, tag + "_occ": occ})
+    print("evaluation        ref == oracle (SC, SSC, visible SSC) on coarse and gt-sized logits; %d voxels" % gt.numel())
+    save("eval", **out)
+
+
 def main():
     torch.set_num_threads(1)
     R = refshim.install()
@@ -238,6 +259,7 @@ def main():
     gen_pool_geometry(R)
     gen_render(R)
     gen_rays(R)
+    gen_eval(R)
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print("golden fixtures: %.2f MB in %s" % (tot / 1e6, GOLD))
 

@@ -485,3 +485,29 @@ def hot_path_forward(sd, img_voxel_feats, pts_voxel_feats, gemo, img_feats, tran
     rgbs, depths = render_block(_sub(sd, "sigma_head."), _sub(sd, "rgb_head."), vf, gemo, literal_render)
     return dict(voxel_feats=vf, output_voxels=head["output_voxels"], fine_output=head["fine_output"],
                 fine_coord=head["fine_coord"], rgbs=rgbs, depths=depths)
+
+
+def fast_hist(pred, label, max_label=18):
+    """coocc_ray.py:726-730."""
+    bc = np.bincount(max_label * label.flatten().astype(int) + pred.flatten(), minlength=max_label ** 2)
+    return bc[:max_label ** 2].reshape(max_label, max_label)
+
+
+def evaluation_semantic(pred, gt, eval_type, visible_mask=None, empty_idx=0):
+    """coocc_ray.py:659-684: trilinear resample to the gt size, argmax, confusion matrices over gt != 255.
+    Also returns the resampled logits so tests can bound argmax flips by the top-2 margin."""
+    _, H, W, D = gt.shape
+    up = F.interpolate(pred, size=[H, W, D], mode='trilinear', align_corners=False).contiguous()
+    p = torch.argmax(up[0], dim=0).numpy()
+    g = gt[0].numpy().astype(int)
+    noise_mask = g != 255
+    if eval_type == 'SC':
+        g = g.copy()
+        g[g != empty_idx] = 1
+        p[p != empty_idx] = 1
+        return fast_hist(p[noise_mask], g[noise_mask], max_label=2), None, up
+    hist_occ = None
+    if visible_mask is not None:
+        mask = noise_mask & (visible_mask[0].numpy() != 0)
+        hist_occ = fast_hist(p[mask], g[mask], max_label=17)
+    return fast_hist(p[noise_mask], g[noise_mask], max_label=17), hist_occ, up

@@ -99,6 +99,33 @@ def test_geometry_and_pooling_vs_golden(dev, golden):
     assert_close(pooled[:, nz[:, 0], nz[:, 1], nz[:, 2]].t(), g["pooled_nz_val"], tol=1e-5, what="pooled")
 
 
+def test_fused_lift_splat_equals_materialised_volume(dev):
+    """lift (x) splat without the lifted tensor, bit-equal to the oracle pooling the
+    materialised volume (LSSVoxel.py:135-145)."""
+    c = cases.POOL_CASE
+    rig = synth.camera_rig(c["ncam"], c["input_size"], seed=c["seed"])
+    vt = pkg.ViewTransformerLiftSplatShootVoxel(grid_config=c["grid_config"], data_config=dict(input_size=c["input_size"]),
+                                                downsample=c["downsample"], numC_Trans=c["C"]).to(dev)
+    fr = ref_cpu.create_frustum(c["input_size"], c["downsample"], c["grid_config"]["dbound"])
+    geom = ref_cpu.get_geometry(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
+    g = torch.Generator().manual_seed(5)
+    N, D, (H, W), C = c["ncam"], fr.shape[0], c["fmap"], 16
+    depth = torch.softmax(torch.randn(N, D, H, W, generator=g) * 2, dim=1)
+    feat = torch.randn(N, C, H, W, generator=g)
+    volume = (depth.unsqueeze(1) * feat.unsqueeze(2)).view(1, N, C, D, H, W).permute(0, 1, 3, 4, 5, 2)
+    dx, bx, nx = ref_cpu.gen_dx_bx(c["grid_config"]["xbound"], c["grid_config"]["ybound"], c["grid_config"]["zbound"])
+    want = ref_cpu.voxel_pooling(geom, volume, dx, bx, nx)
+    got = vt.lift_splat(depth.to(dev), feat.to(dev), geom.to(dev))
+    assert tuple(got.shape) == tuple(want.shape)
+    assert torch.equal(got.cpu(), want)
+    # geometry in-kernel == our own get_geometry tensor fed to the same splat, bit for bit
+    cams = tuple(rig[k].to(dev) for k in ("rots", "trans", "intrins", "post_rots", "post_trans", "bda"))
+    via_tensor = vt.lift_splat(depth.to(dev), feat.to(dev), vt.get_geometry(*cams))
+    in_kernel = vt.lift_splat(depth.to(dev), feat.to(dev), cams=cams)
+    assert torch.equal(via_tensor, in_kernel)
+    assert_close(in_kernel.cpu(), want, 1e-4, "lift_splat_cams")
+
+
 def test_bev_pool_op_and_ext_vs_oracle(dev):
     rng = np.random.default_rng(2)
     n, C, B, X, Y, Z = 20000, 12, 2, 9, 7, 3
@@ -243,3 +270,61 @@ def test_hot_path_end_to_end_vs_oracle(dev):
     assert len(a ^ b) <= 0.002 * len(b) + 8
     if a == b:
         assert_close(out["output_voxels_fine"][0].cpu(), h["fine_output"], what="fine")
+
+
+def _flip_budget(up, tol=1e-4):
+    """Voxels whose top-2 logit margin is below the float tolerance: the only places where an argmax
+    computed from a 1e-4-close resampling may legitimately differ."""
+    top2 = torch.topk(up[0], 2, dim=0).values
+    scale = max(1.0, float(up.abs().max()))
+    return int(((top2[0] - top2[1]) < 2 * tol * scale).sum())
+
+
+def _check_eval(pred_dev, pred, gt, vis, want=None, exact=False):
+    from co_occ_amd import evaluation as ev
+    sc, _ = ev.evaluation_semantic(pred_dev, gt.to(pred_dev.device), 'SC', vis.to(pred_dev.device))
+    ssc, occ = ev.evaluation_semantic(pred_dev, gt.to(pred_dev.device), 'SSC', vis.to(pred_dev.device))
+    o_sc = ref_cpu.evaluation_semantic(pred, gt, 'SC', vis)[0]
+    o_ssc, o_occ, up = ref_cpu.evaluation_semantic(pred, gt, 'SSC', vis)
+    if want is not None:
+        assert np.array_equal(o_sc, want[0]) and np.array_equal(o_ssc, want[1]) and np.array_equal(o_occ, want[2])
+    budget = 0 if exact else _flip_budget(up)      # no resampling -> no float step -> exact
+    for got, ref in ((sc, o_sc), (ssc, o_ssc), (occ, o_occ)):
+        got = got.cpu().numpy()
+        assert got.sum() == ref.sum()                       # every non-noise voxel counted exactly once
+        assert np.abs(got - ref).sum() <= 2 * budget, (np.abs(got - ref).sum(), budget)
+        assert np.array_equal(got.sum(1), ref.sum(1))       # label marginals never depend on the argmax
+    return budget
+
+
+def test_eval_semantic_vs_golden_and_oracle(dev, golden):
+    """on-device evaluation_semantic; integer histograms equal the reference's except
+    at voxels inside the float tolerance of an argmax tie (bounded by the measured margin count)."""
+    c, g = cases.EVAL_CASE, golden("eval")
+    for tag, same in (("coarse", False), ("full", True)):
+        pred, gt, vis = cases.eval_inputs(c, same)
+        want = (g[tag + "_sc"], g[tag + "_ssc"], g[tag + "_occ"])
+        _check_eval(pred.to(dev), pred, gt, vis, want, exact=same)
+        # channels-last logits (the layout OccHead hands over) give the same counts
+        cl = pred.to(dev).permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)
+        assert not cl.is_contiguous()
+        _check_eval(cl, pred, gt, vis, want, exact=same)
+
+
+def test_eval_semantic_full_size_and_accumulation(dev):
+    """nuScenes-Occ sizes (100x100x8 logits -> 200x200x16 labels) and whole-dataset accumulation."""
+    from co_occ_amd import evaluation as ev
+    c = dict(cases.EVAL_CASE, coarse=(100, 100, 8), gt=(200, 200, 16), seed=62)
+    pred, gt, vis = cases.eval_inputs(c)
+    _check_eval(pred.to(dev), pred, gt, vis)
+    acc = ev.SemanticEvaluator(17, 0, dev)
+    for _ in range(3):
+        acc.update(pred.to(dev), gt.to(dev), vis.to(dev))
+    one = ev.semantic_histograms(pred.to(dev), gt.to(dev), vis.to(dev))
+    assert torch.equal(acc.hist, 3 * one)
+    m = acc.compute()
+    ssc = m["SSC_metric"].astype(np.float64)
+    tp = np.diag(ssc)
+    assert np.allclose(m["class_ious"], tp / (ssc.sum(0) + ssc.sum(1) - tp))
+    # no visible mask -> OCC block untouched and None returned, as upstream
+    assert ev.evaluation_semantic(pred.to(dev), gt.to(dev), 'SSC')[1] is None

@@ -161,3 +161,15 @@ def test_rays_oracle_vs_golden(golden):
     assert np.allclose(r["rgb"].numpy(), g["rgb"], atol=1e-6) and np.allclose(r["depth"].numpy(), g["depth"], atol=1e-6)
     assert np.allclose(ref_cpu.raw2outputs(raw, z, mask, True)["rgb"].numpy(), g["rgb_white"], atol=1e-6)
     assert np.allclose(ref_cpu.get_weights(raw[..., 3:4], z).numpy(), g["get_weights"], atol=1e-6)
+
+
+def test_eval_oracle_vs_golden(golden):
+    """coocc_ray.py:659-684,726-730: SC / SSC / visible-SSC confusion matrices of the unmodified reference."""
+    c, g = cases.EVAL_CASE, golden("eval")
+    for tag, same in (("coarse", False), ("full", True)):
+        pred, gt, vis = cases.eval_inputs(c, same)
+        sc = ref_cpu.evaluation_semantic(pred, gt, 'SC', vis)[0]
+        ssc, occ, _ = ref_cpu.evaluation_semantic(pred, gt, 'SSC', vis)
+        assert np.array_equal(sc, g[tag + "_sc"]) and np.array_equal(ssc, g[tag + "_ssc"])
+        assert np.array_equal(occ, g[tag + "_occ"])
+        assert ssc.sum() == int((gt != 255).sum()) and sc.sum() == ssc.sum()

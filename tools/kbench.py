@@ -109,6 +109,51 @@ def bench_render():
             name, t1, by1 / t1 / 1e6, by1 / 1e6, t2, by2 / t2 / 1e6, by2 / 1e6, (by1 + by2) / (t1 + t2) / 1e6, (by1 + by2) / (t1 + t2) / 1e6 / 8000))
 
 
+def bench_pool():
+    """P2 at r50 / r101: materialised volume + voxel_pool vs fused lift (x) splat."""
+    cfg = dict(xbound=[-50, 50, 1.0], ybound=[-50, 50, 1.0], zbound=[-5.0, 3.0, 1.0], dbound=[2.0, 58.0, 0.5])
+    g = torch.Generator().manual_seed(4)
+    for name, size, (fH, fW) in (("r50", (256, 704), (16, 44)), ("r101", (896, 1600), (56, 100))):
+        N, D, C = 6, 112, 128
+        rig = synth.camera_rig(N, size, seed=7)
+        vt = pkg.ViewTransformerLiftSplatShootVoxel(grid_config=cfg, data_config=dict(input_size=size), downsample=16,
+                                                    numC_Trans=C).to(dev)
+        cams = tuple(rig[k].to(dev) for k in ("rots", "trans", "intrins", "post_rots", "post_trans", "bda"))
+        depth = torch.softmax(torch.randn(N, D, fH, fW, generator=g), 1).to(dev)
+        feat = torch.randn(N, C, fH, fW, generator=g).to(dev)
+        geom = vt.get_geometry(*cams)
+        kept = float(((geom[..., 0].abs() < 50) & (geom[..., 1].abs() < 50) & (geom[..., 2] >= -5) & (geom[..., 2] < 3)).float().mean())
+        t_f = timeit(lambda: vt.lift_splat(depth, feat, cams=cams), n=10)
+        t_g = timeit(lambda: vt.lift_splat(depth, feat, geom), n=10)
+        npts = N * D * fH * fW
+        by_f = 4.0 * npts + 4.0 * N * fH * fW * C + 4.0 * 80000 * C
+        line = "pool %-4s kept %.2f  fused(cams) %.3f ms  fused(geom tensor) %.3f ms  = %.0f GB/s of %.1f MB algorithmic" % (
+            name, kept, t_f, t_g, by_f / t_f / 1e6, by_f / 1e6)
+        if name == "r50":
+            def materialised():
+                vol = depth.view(1, N, 1, D, fH, fW) * feat.view(1, N, C, 1, fH, fW)
+                return vt.voxel_pooling(geom, vol.permute(0, 1, 3, 4, 5, 2))
+            t_m = timeit(materialised, n=5)
+            a, b = materialised(), vt.lift_splat(depth, feat, geom)
+            line += "  | materialised volume + voxel_pool %.3f ms, equal=%s" % (t_m, bool(torch.equal(a, b)))
+        print(line)
+
+
+def bench_eval():
+    from co_occ_amd import evaluation as ev
+    g = torch.Generator().manual_seed(5)
+    pred = torch.randn(1, 17, 100, 100, 8, generator=g).to(dev)
+    gt = torch.randint(0, 17, (1, 200, 200, 16), generator=g).to(torch.uint8).to(dev)
+    vis = torch.randint(0, 2, (1, 200, 200, 16), generator=g).to(torch.uint8).to(dev)
+    out = torch.zeros(4 + 2 * 17 * 17, dtype=torch.int64, device=dev)
+    t = timeit(lambda: ev.semantic_histograms(pred, gt, vis, out=out, accumulate=True), n=20)
+    def upstream():
+        up = torch.nn.functional.interpolate(pred, size=[200, 200, 16], mode='trilinear', align_corners=False)
+        return torch.argmax(up[0], 0).cpu().numpy(), gt[0].cpu().numpy()
+    t_u = timeit(upstream, n=5)
+    print("eval  coarse->200x200x16: on-device SC+SSC+OCC %.3f ms ; upstream's interpolate+argmax+.cpu() alone %.3f ms (before 3 bincounts)" % (t, t_u))
+
+
 def bench_fpsdbg():
     import ctypes
     from co_occ_amd import _lib
