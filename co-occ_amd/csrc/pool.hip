@@ -183,32 +183,41 @@ __global__ __launch_bounds__(256) void k_segment_bounds(const uint32_t* __restri
 // so the serial chain, not bandwidth, bounds this kernel.
 constexpr int POOL_BATCH = 16;
 
-template <bool LIFT>
+template <int VEC> struct PoolVec;
+template <> struct PoolVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct PoolVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+// A lone wave issues roughly one instruction per 5 cycles, so the per-point instruction count matters as
+// much as the load latency: the id -> (context row, depth) decode is done once per 64 ids in the vector
+// lanes and broadcast with v_readlane (3 per point); VEC = 2 keeps all 64 lanes busy at C <= 128.
+template <bool LIFT, int VEC>
 __device__ __forceinline__ void pool_row(const float* __restrict__ x, const float* __restrict__ depth,
                                          const uint32_t* __restrict__ ids, int s, int e, int lane, int C, int D, int HW,
                                          float* __restrict__ orow) {
-  for (int c0 = 0; c0 < C; c0 += 256) {
-    const int c = c0 + lane * 4;
+  typedef typename PoolVec<VEC>::type vec;
+  for (int c0 = 0; c0 < C; c0 += 64 * VEC) {
+    const int c = c0 + lane * VEC;
     const bool lane_on = c < C;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* xc = x + (lane_on ? c : 0);   // idle lanes re-read channel 0 instead of branching
+    vec acc = (vec)(0.f);
     for (int base = s; base < e; base += 64) {
       const int nb = min(64, e - base);
       const uint32_t myid = ids[base + min(lane, nb - 1)];
+      uint32_t myrow = myid;
+      float mydp = 1.f;
+      if (LIFT) {
+        myrow = (myid / (uint32_t)(D * HW)) * (uint32_t)HW + myid % (uint32_t)HW;
+        mydp = depth[myid];
+      }
       for (int j0 = 0; j0 < nb; j0 += POOL_BATCH) {
-        f32x4 r[POOL_BATCH];
+        vec r[POOL_BATCH];
 #pragma unroll
         for (int j = 0; j < POOL_BATCH; ++j) {
 #pragma clang fp contract(off)  // LIFT: the product is rounded before the add, as the materialised volume is
-          const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)myid, min(j0 + j, nb - 1));
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (LIFT) {
-            const uint32_t n = id / (uint32_t)(D * HW), hw = id % (uint32_t)HW;
-            const float dp = depth[id];
-            if (lane_on) v = *(const f32x4*)(x + ((size_t)n * HW + hw) * C + c);
-            v = dp * v;
-          } else {
-            if (lane_on) v = *(const f32x4*)(x + (size_t)id * C + c);
-          }
+          const int jj = min(j0 + j, nb - 1);
+          const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)myrow, jj);
+          vec v = *(const vec*)(xc + (size_t)row * C);
+          if (LIFT) v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mydp), jj)) * v;
           r[j] = v;
         }
 #pragma unroll
@@ -216,7 +225,7 @@ __device__ __forceinline__ void pool_row(const float* __restrict__ x, const floa
           if (j0 + j < nb) acc = acc + r[j];
       }
     }
-    if (lane_on) *(f32x4*)(orow + c) = acc;
+    if (lane_on) *(vec*)(orow + c) = acc;
   }
 }
 
@@ -226,7 +235,8 @@ __global__ __launch_bounds__(256) void k_pool_sum(const float* __restrict__ x, c
                                                    float* __restrict__ out, int out_stride) {
   const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   if (v >= nvox) return;
-  pool_row<false>(x, nullptr, ids, seg_start[v], seg_end[v], lane, C, 0, 0, out + (size_t)v * out_stride);
+  if (C <= 128) pool_row<false, 2>(x, nullptr, ids, seg_start[v], seg_end[v], lane, C, 0, 0, out + (size_t)v * out_stride);
+  else pool_row<false, 4>(x, nullptr, ids, seg_start[v], seg_end[v], lane, C, 0, 0, out + (size_t)v * out_stride);
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -303,7 +313,8 @@ __global__ __launch_bounds__(256) void k_lift_pool_sum(const float* __restrict__
                                                         float* __restrict__ out, int out_stride) {
   const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   if (v >= nvox) return;
-  pool_row<true>(feat, depth, ids, seg_start[v], seg_end[v], lane, C, D, HW, out + (size_t)v * out_stride);
+  if (C <= 128) pool_row<true, 2>(feat, depth, ids, seg_start[v], seg_end[v], lane, C, D, HW, out + (size_t)v * out_stride);
+  else pool_row<true, 4>(feat, depth, ids, seg_start[v], seg_end[v], lane, C, D, HW, out + (size_t)v * out_stride);
 }
 
 static int lift_splat_impl(const float* depth, const float* feat_nhwc, const float* geom, const float* mats,

@@ -139,6 +139,20 @@ def bench_pool():
         print(line)
 
 
+def bench_poolprof():
+    """lift_splat only (for rocprofv3 --kernel-trace --stats): r101, geometry tensor prebuilt."""
+    cfg = dict(xbound=[-50, 50, 1.0], ybound=[-50, 50, 1.0], zbound=[-5.0, 3.0, 1.0], dbound=[2.0, 58.0, 0.5])
+    g = torch.Generator().manual_seed(4)
+    N, D, C, size, (fH, fW) = 6, 112, 128, (896, 1600), (56, 100)
+    rig = synth.camera_rig(N, size, seed=7)
+    vt = pkg.ViewTransformerLiftSplatShootVoxel(grid_config=cfg, data_config=dict(input_size=size), downsample=16, numC_Trans=C).to(dev)
+    cams = tuple(rig[k].to(dev) for k in ("rots", "trans", "intrins", "post_rots", "post_trans", "bda"))
+    depth = torch.softmax(torch.randn(N, D, fH, fW, generator=g), 1).to(dev)
+    feat = torch.randn(N, C, fH, fW, generator=g).to(dev)
+    geom = vt.get_geometry(*cams)
+    print("lift_splat r101 %.3f ms" % timeit(lambda: vt.lift_splat(depth, feat, geom), n=10))
+
+
 def bench_eval():
     from co_occ_amd import evaluation as ev
     g = torch.Generator().manual_seed(5)
