@@ -1,0 +1,261 @@
+// Backward of the implicit-GEMM conv family: data gradient, weight gradient and the
+// epilogue (folded-BN scale, ReLU, residual) gradient, for frozen-statistics BN (eval-mode BN folded into
+// scale/bias, as the forward).
+//
+//   forward   out[o][n]  = relu( scale[n] * sum_{t,c} in[src(o,t)][c] W[n][c][t] + bias[n] + res[o][n] )
+//   epilogue  dpre       = dout * (out > 0);   dres = dpre;   dacc = dpre * scale;   dbias = sum_o dpre
+//   dgrad     din[i][c]  = sum_{t,n} dacc[o(i,t)][n] W[n][c][t]     -> the FORWARD kernel (coocc_conv_fwd) on
+//             re-packed weights: stride 1 = taps flipped (mode 2); stride 2 = a row table o(i,t) (mode 3)
+//   wgrad     dW[n][c][t] = sum_o in[src(o,t)][c] dacc[o][n]       -> k_wgrad below (K = M on the MFMA)
+#include "conv_layout.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ device-side weight packing
+// mode 0: w[Cout][Cin][taps] (torch Conv3d)        -> forward pack
+// mode 1: w[Cout][taps][Cin] (tap-major Linear)    -> forward pack
+// mode 2: dgrad pack, taps flipped:   W'[n' = c][c' = n][t' = taps-1-t] = w[n][c][t]   (stride-1 convs)
+// mode 3: dgrad pack, taps unflipped: W'[n' = c][c' = n][t' = t]        = w[n][c][t]   (row-table dgrad)
+__global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ w, int Cout, int Cin, int taps, int mode,
+                                                       int Npad, float* __restrict__ packed) {
+  const size_t total = (size_t)Cout * Cin * taps;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int n, c, t;
+  if (mode == 1) { c = (int)(i % Cin); size_t r = i / Cin; t = (int)(r % taps); n = (int)(r / taps); }
+  else { t = (int)(i % taps); size_t r = i / taps; c = (int)(r % Cin); n = (int)(r / Cin); }
+  const float v = w[i];
+  if (mode <= 1) packed[wfrag_index((size_t)(c / KC) * taps + t, Npad >> 7, n, c % KC)] = v;
+  else {
+    const int tt = mode == 2 ? taps - 1 - t : t;
+    packed[wfrag_index((size_t)(n / KC) * taps + tt, Npad >> 7, c, n % KC)] = v;
+  }
+}
+
+extern "C" int64_t coocc_conv_pack_weights_dev(const float* w, int Cout, int Cin, int taps, int mode, float* packed,
+                                               void* stream) {
+  if (Cout <= 0 || Cin <= 0 || taps <= 0 || mode < 0 || mode > 3) return coocc_set_error(COOCC_EINVAL, "pack_weights_dev: bad args");
+  const int N = mode >= 2 ? Cin : Cout, K = mode >= 2 ? Cout : Cin;
+  const int kch = (K + KC - 1) / KC, Npad = (N + NPAD_TO - 1) / NPAD_TO * NPAD_TO;
+  const int64_t total = (int64_t)taps * kch * Npad * KC;
+  if (!packed) return total;
+  if (!w) return coocc_set_error(COOCC_EINVAL, "pack_weights_dev: null weights");
+  hipStream_t s = as_stream(stream);
+  if (hipMemsetAsync(packed, 0, sizeof(float) * (size_t)total, s) != hipSuccess)
+    return coocc_set_error(COOCC_EHIP, "pack_weights_dev: memset failed");
+  hipLaunchKernelGGL(k_pack_weights, dim3(cdiv((long long)Cout * Cin * taps, 256)), dim3(256), 0, s, w, Cout, Cin, taps, mode,
+                     Npad, packed);
+  if (hipGetLastError() != hipSuccess) return coocc_set_error(COOCC_EHIP, "pack_weights_dev: launch failed");
+  return total;
+}
+
+// ------------------------------------------------------------------ row tables
+// fwd table  [taps][Mo]: input row read by output voxel o for tap t (or -1: zero padding)
+// dgrad table[taps][Mi]: output row o with o*stride - pad + t == i (or -1)
+__global__ __launch_bounds__(256) void k_tap_table(int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int ksize,
+                                                    int stride, int pad, int dgrad, int32_t* __restrict__ table) {
+  const int M = dgrad ? B * Xi * Yi * Zi : B * Xo * Yo * Zo;
+  const int taps = ksize * ksize * ksize;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)M * taps) return;
+  const int t = (int)(i / M), m = (int)(i % M);
+  const int kw = t % ksize, kh = (t / ksize) % ksize, kd = t / (ksize * ksize);
+  int r = -1;
+  if (!dgrad) {
+    const int z = m % Zo, y = (m / Zo) % Yo, x = (m / (Zo * Yo)) % Xo, b = m / (Zo * Yo * Xo);
+    const int ix = x * stride - pad + kd, iy = y * stride - pad + kh, iz = z * stride - pad + kw;
+    if ((unsigned)ix < (unsigned)Xi && (unsigned)iy < (unsigned)Yi && (unsigned)iz < (unsigned)Zi)
+      r = ((b * Xi + ix) * Yi + iy) * Zi + iz;
+  } else {
+    const int z = m % Zi, y = (m / Zi) % Yi, x = (m / (Zi * Yi)) % Xi, b = m / (Zi * Yi * Xi);
+    const int ox = x + pad - kd, oy = y + pad - kh, oz = z + pad - kw;
+    if (ox >= 0 && oy >= 0 && oz >= 0 && ox % stride == 0 && oy % stride == 0 && oz % stride == 0 && ox / stride < Xo &&
+        oy / stride < Yo && oz / stride < Zo)
+      r = ((b * Xo + ox / stride) * Yo + oy / stride) * Zo + oz / stride;
+  }
+  table[i] = r;
+}
+
+extern "C" int coocc_conv_tap_table(int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int ksize, int stride, int pad,
+                                    int dgrad, int32_t* table, void* stream) {
+  COOCC_CHECK_ARG(table && B > 0 && Xi > 0 && Yi > 0 && Zi > 0 && Xo > 0 && Yo > 0 && Zo > 0 && ksize > 0 && stride > 0 && pad >= 0,
+                  "conv_tap_table: bad args");
+  const long long M = dgrad ? (long long)B * Xi * Yi * Zi : (long long)B * Xo * Yo * Zo;
+  COOCC_CHECK_ARG(M * ksize * ksize * ksize < (1ll << 31) && (long long)B * Xi * Yi * Zi < (1ll << 31), "conv_tap_table: too large");
+  hipLaunchKernelGGL(k_tap_table, dim3(cdiv(M * ksize * ksize * ksize, 256)), dim3(256), 0, as_stream(stream), B, Xi, Yi, Zi, Xo,
+                     Yo, Zo, ksize, stride, pad, dgrad, table);
+  COOCC_LAUNCH_CHECK("k_tap_table");
+  return COOCC_OK;
+}
+
+// ------------------------------------------------------------------ epilogue backward
+// one thread per 4 channels; dbias partials: per-block column sums -> second pass
+__global__ __launch_bounds__(256) void k_epilogue_bwd(const float* __restrict__ dout, int dout_stride,
+                                                       const float* __restrict__ out, int out_stride,
+                                                       const float* __restrict__ scale, int M, int C, int relu,
+                                                       float* __restrict__ dacc, int dacc_stride, float* __restrict__ dres,
+                                                       int dres_stride, int dres_accumulate) {
+  const int c4 = (C + 3) >> 2;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)M * c4) return;
+  const int m = (int)(i / c4), c = (int)(i % c4) * 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (c + e >= C) break;
+    float g = dout[(size_t)m * dout_stride + c + e];
+    if (relu && !(out[(size_t)m * out_stride + c + e] > 0.f)) g = 0.f;
+    if (dres) {
+      float* d = dres + (size_t)m * dres_stride + c + e;
+      *d = dres_accumulate ? *d + g : g;
+    }
+    if (dacc) dacc[(size_t)m * dacc_stride + c + e] = scale ? g * scale[c + e] : g;
+  }
+}
+
+// deterministic column sums of dpre = dout * (out > 0): 256 rows per block, then one block sums the partials
+__global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ dout, int dout_stride,
+                                                      const float* __restrict__ out, int out_stride, int M, int C, int relu,
+                                                      float* __restrict__ part) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int m0 = blockIdx.x * 256, m1 = min(M, m0 + 256);
+  float s = 0.f;
+  for (int m = m0; m < m1; ++m) {
+    float g = dout[(size_t)m * dout_stride + c];
+    if (relu && !(out[(size_t)m * out_stride + c] > 0.f)) g = 0.f;
+    s += g;
+  }
+  part[(size_t)blockIdx.x * C + c] = s;
+}
+
+__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ part, int nparts, int C,
+                                                       float* __restrict__ dbias, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * C + c];
+  dbias[c] = accumulate ? dbias[c] + s : s;
+}
+
+extern "C" int coocc_conv_epilogue_bwd(const float* dout, int dout_stride, const float* out, int out_stride,
+                                       const float* scale, int M, int C, int relu, float* dacc, int dacc_stride,
+                                       float* dres, int dres_stride, int dres_accumulate, float* dbias,
+                                       int dbias_accumulate, float* ws, int64_t ws_floats, void* stream) {
+  COOCC_CHECK_ARG(dout && M > 0 && C > 0 && (!relu || out), "conv_epilogue_bwd: bad args");
+  hipStream_t s = as_stream(stream);
+  if (dacc || dres) {
+    hipLaunchKernelGGL(k_epilogue_bwd, dim3(cdiv((long long)M * ((C + 3) / 4), 256)), dim3(256), 0, s, dout, dout_stride, out,
+                       out_stride, scale, M, C, relu, dacc, dacc_stride, dres, dres_stride, dres_accumulate);
+    COOCC_LAUNCH_CHECK("k_epilogue_bwd");
+  }
+  if (dbias) {
+    const int nparts = (M + 255) / 256;
+    COOCC_CHECK_ARG(ws && ws_floats >= (int64_t)nparts * C, "conv_epilogue_bwd: workspace too small for dbias");
+    hipLaunchKernelGGL(k_colsum_part, dim3(nparts, cdiv(C, 256)), dim3(256), 0, s, dout, dout_stride, out, out_stride, M, C,
+                       relu, ws);
+    hipLaunchKernelGGL(k_colsum_final, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, nparts, C, dbias, dbias_accumulate);
+    COOCC_LAUNCH_CHECK("k_colsum");
+  }
+  return COOCC_OK;
+}
+
+// ------------------------------------------------------------------ weight gradient
+// GEMM view: D[c][n] (Cin x Cout, per tap) = sum_m A[m][c] * Bm[m][n], A = gathered input rows, Bm = dacc rows;
+// the reduction index is the voxel m, so both MFMA operands are read along their contiguous channel axis
+// straight from global memory (lane (li,h): A[m+h][c0+li], Bm[m+h][n0+li]) -- no LDS, no transposition.
+// Workgroup = 4 waves (2 x 2), tile 128 (Cin) x 128 (Cout) for one tap and one M-slice; each wave owns
+// 64 x 64 = 2 x 2 MFMA blocks; UNR k-steps (2 voxels each) are loaded ahead of their 4*UNR MFMAs.
+// M-slices write partial slabs that k_wgrad_reduce sums in slice order (deterministic) into the torch
+// weight layout [Cout][Cin][taps].
+constexpr int WG_UNR = 4;
+
+__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ in, int in_stride, const float* __restrict__ dacc,
+                                                int dacc_stride, const int32_t* __restrict__ table, int M, int Cin, int Cout,
+                                                int taps, int ctiles, int ntiles, int mslice, float* __restrict__ slabs) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  int tile = blockIdx.x;
+  const int nt = tile % ntiles; tile /= ntiles;
+  const int ct = tile % ctiles; const int t = tile / ctiles;
+  const int c0 = ct * 128 + (wave >> 1) * 64, n0 = nt * 128 + (wave & 1) * 64;
+  const int mbeg = blockIdx.y * mslice, mend = min(M, mbeg + mslice);
+  const int32_t* tb = table ? table + (size_t)t * M : nullptr;
+  const bool cok0 = c0 + li < Cin, cok1 = c0 + 32 + li < Cin, nok0 = n0 + li < Cout, nok1 = n0 + 32 + li < Cout;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int m = mbeg; m < mend; m += 2 * WG_UNR) {
+    float a[WG_UNR][2], b[WG_UNR][2];
+#pragma unroll
+    for (int u = 0; u < WG_UNR; ++u) {
+      const int mm = m + 2 * u + h;
+      const bool mok = mm < mend;
+      int row = mok ? (tb ? tb[mm] : mm) : -1;
+      const float* ar = in + (size_t)max(row, 0) * in_stride + c0 + li;
+      const float* br = dacc + (size_t)(mok ? mm : 0) * dacc_stride + n0 + li;
+      a[u][0] = (row >= 0 && cok0) ? ar[0] : 0.f;
+      a[u][1] = (row >= 0 && cok1) ? ar[32] : 0.f;
+      b[u][0] = (mok && nok0) ? br[0] : 0.f;
+      b[u][1] = (mok && nok1) ? br[32] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < WG_UNR; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+  }
+  // slab layout [slice][t][Cin][Cout]
+  float* sl = slabs + ((size_t)blockIdx.y * taps + t) * (size_t)Cin * Cout;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n = n0 + j * 32 + li;
+        if (c < Cin && n < Cout) sl[(size_t)c * Cout + n] = acc[i][j][r];
+      }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, int nslices, int Cin, int Cout,
+                                                       int taps, float* __restrict__ dw, int accumulate) {
+  const size_t per = (size_t)taps * Cin * Cout;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // index in [t][c][n]
+  if (i >= per) return;
+  float s = 0.f;
+  for (int p = 0; p < nslices; ++p) s += slabs[(size_t)p * per + i];
+  const int n = (int)(i % Cout); const size_t r = i / Cout;
+  const int c = (int)(r % Cin), t = (int)(r / Cin);
+  float* d = dw + ((size_t)n * Cin + c) * taps + t;
+  *d = accumulate ? *d + s : s;
+}
+
+extern "C" int coocc_conv_wgrad(const float* in, int in_stride, const float* dacc, int dacc_stride, const int32_t* table,
+                                int M, int Cin, int Cout, int taps, float* dw, int accumulate, float* ws,
+                                int64_t ws_floats, void* stream) {
+  COOCC_CHECK_ARG(in && dacc && dw && ws && M > 0 && Cin > 0 && Cout > 0 && taps > 0, "conv_wgrad: bad args");
+  COOCC_CHECK_ARG(table || taps == 1, "conv_wgrad: taps > 1 needs the forward row table (coocc_conv_tap_table)");
+  const int ctiles = (Cin + 127) / 128, ntiles = (Cout + 127) / 128;
+  const long long tiles = (long long)ctiles * ntiles * taps;
+  const int64_t per = (int64_t)taps * Cin * Cout;
+  long long nslices = (1024 + tiles - 1) / tiles;                       // ~4 workgroups per CU
+  nslices = std::min<long long>(nslices, (M + 255) / 256);              // >= 256 voxels per slice
+  nslices = std::min<long long>(nslices, ws_floats / per);
+  COOCC_CHECK_ARG(nslices >= 1, "conv_wgrad: workspace smaller than one weight slab");
+  int mslice = (int)((M + nslices - 1) / nslices);
+  mslice = (mslice + 2 * WG_UNR - 1) / (2 * WG_UNR) * (2 * WG_UNR);
+  nslices = (M + mslice - 1) / mslice;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(k_wgrad, dim3((unsigned)tiles, (unsigned)nslices), dim3(256), 0, s, in, in_stride, dacc, dacc_stride,
+                     table, M, Cin, Cout, taps, ctiles, ntiles, mslice, ws);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(per, 256)), dim3(256), 0, s, ws, (int)nslices, Cin, Cout, taps, dw, accumulate);
+  COOCC_LAUNCH_CHECK("k_wgrad");
+  return COOCC_OK;
+}

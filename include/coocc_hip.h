@@ -143,6 +143,30 @@ typedef struct coocc_conv_desc {
  * ->scatter of bifuser_n.py:138-169 as one fp32-MFMA implicit-GEMM kernel family. */
 int coocc_conv_fwd(const coocc_conv_desc* d, void* stream);
 
+/* ---------------------------------------------------------------- backward of the conv family
+ * Frozen-statistics BN (scale/shift constants), as the forward.  torch.autograd computes these through
+ * cudnn/MIOpen conv backward upstream (the reference has no kernel of its own for them). */
+/* Device-side packing into the layout coocc_conv_fwd consumes.  mode 0: w[Cout][Cin][taps]; 1: w[Cout][taps][Cin];
+ * 2: data-gradient pack with taps flipped (stride-1 convs: run coocc_conv_fwd on dacc with pad' = k-1-pad);
+ * 3: data-gradient pack, taps unflipped (use with a dgrad row table).  packed == NULL returns the float count. */
+int64_t coocc_conv_pack_weights_dev(const float* w, int Cout, int Cin, int taps, int mode, float* packed,
+                                    void* stream);
+/* Row tables of a conv geometry: dgrad == 0: [taps][Mo] input row read by output o for tap t (-1 = padding);
+ * dgrad != 0: [taps][Mi] output row o with o*stride - pad + t == i (-1 = none). */
+int coocc_conv_tap_table(int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int ksize, int stride, int pad,
+                         int dgrad, int32_t* table, void* stream);
+/* dpre = dout * (out > 0 if relu);  dres (+)= dpre;  dacc = dpre * scale;  dbias (+)= column sums of dpre
+ * (deterministic two-pass; ws >= ceil(M/256)*C floats).  Any of dacc / dres / dbias may be NULL. */
+int coocc_conv_epilogue_bwd(const float* dout, int dout_stride, const float* out, int out_stride,
+                            const float* scale, int M, int C, int relu, float* dacc, int dacc_stride,
+                            float* dres, int dres_stride, int dres_accumulate, float* dbias,
+                            int dbias_accumulate, float* ws, int64_t ws_floats, void* stream);
+/* dw[Cout][Cin][taps] (+)= sum_m in[table[t][m]][c] * dacc[m][n]  (table NULL: identity rows, taps == 1).
+ * fp32 MFMA with the voxel index as K; M-slices reduced in slice order (deterministic). */
+int coocc_conv_wgrad(const float* in, int in_stride, const float* dacc, int dacc_stride, const int32_t* table,
+                     int M, int Cin, int Cout, int taps, float* dw, int accumulate, float* ws,
+                     int64_t ws_floats, void* stream);
+
 /* FPN3D top-down step (fpn3d.py:88-92): fine += trilinear(coarse -> fine size),
  * align_corners=False.  Rows NDHWC with C channels. */
 int coocc_upsample_add_trilinear(const float* coarse, float* fine, int B, int C, int Xc, int Yc,
