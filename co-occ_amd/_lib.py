@@ -71,7 +71,14 @@ SIGNATURES = {
     "coocc_conv_pack_weights_dev": (L, [P, I, I, I, I, P, P]),
     "coocc_conv_tap_table": (I, [I, I, I, I, I, I, I, I, I, I, I, P, P]),
     "coocc_conv_epilogue_bwd": (I, [P, I, P, I, P, I, I, I, P, I, P, I, I, P, I, P, L, P]),
-    "coocc_conv_wgrad": (I, [P, I, P, I, P, I, I, I, I, P, I, P, L, P]),
+    "coocc_conv_wgrad": (I, [P, I, I, P, I, P, I, I, I, I, P, I, P, L, P]),
+    "coocc_gather_rows": (I, [P, I, P, I, I, P, I, P]),
+    "coocc_scatter_add_rows": (I, [P, I, P, I, I, P, I, P]),
+    "coocc_voxel_pool_bwd": (I, [P, I, P, I, I, I, P, I, I, I, I, P, P]),
+    "coocc_lift_splat_bwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P, I, I, I, I, P, P, P]),
+    "coocc_render_nearest_bwd": (I, [P, I, I, I, P, P, I, I, I, I, P, P, P, P]),
+    "coocc_upsample_maps_bwd": (I, [P, P, I, I, I, I, P, P]),
+    "coocc_render_losses_bwd": (I, [P, P, P, P, L, I, P, P, P, P, P]),
     "coocc_eval_semantic": (I, [P, L, L, L, L, I, I, I, I, P, P, I, I, I, I, I, P, P]),
 }
 

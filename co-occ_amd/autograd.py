@@ -49,7 +49,7 @@ def pack_weights_dev(w, Cout, Cin, taps, mode):
 
 
 def _conv_launch(x2d, in_C, w_packed, out2d, Cout, taps, geom_in, geom_out, ksize, stride, pad, scale, shift, res2d, relu,
-                 table=None):
+                 table=None, tag="conv_fwd"):
     d = ConvDesc()
     ws = workspace(x2d.device)
     d.in_, d.w, d.out = ptr(x2d), ptr(w_packed), ptr(out2d)
@@ -67,7 +67,7 @@ def _conv_launch(x2d, in_C, w_packed, out2d, Cout, taps, geom_in, geom_out, ksiz
     d.ksize, d.stride, d.pad = ksize, stride, pad
     d.relu, d.res_mode, d.splitk = int(relu), (1 if res2d is not None else 0), 0
     d.tile_hint = TILE_HINT
-    with _lib.TIMER.region("conv_fwd(autograd)", 2.0 * d.M * in_C * Cout * taps):
+    with _lib.TIMER.region(tag, 2.0 * d.M * in_C * Cout * taps):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
 
 
@@ -121,17 +121,18 @@ class ConvRowsFn(torch.autograd.Function):
             w3 = weight.reshape(Cout, Cin, taps)
             if stride == 1:
                 wp = pack_weights_dev(w3, Cout, Cin, taps, 2)
-                _conv_launch(dacc, Cp, wp, dx, Cin, taps, geom_out, geom, ksize, 1, ksize - 1 - pad, None, None, None, False)
+                _conv_launch(dacc, Cp, wp, dx, Cin, taps, geom_out, geom, ksize, 1, ksize - 1 - pad, None, None, None, False,
+                             tag="conv_dgrad")
             else:
                 wp = pack_weights_dev(w3, Cout, Cin, taps, 3)
                 tb = tap_table(dev, B, Xi, Yi, Zi, ksize, stride, pad, True)
                 _conv_launch(dacc, Cp, wp, dx, Cin, taps, geom_out, geom, ksize, stride, pad, None, None, None, False,
-                             table=tb)
+                             table=tb, tag="conv_dgrad")
         if need_w:
             dw = torch.empty(Cout, Cin, taps, device=dev, dtype=_F32)
             tb = tap_table(dev, B, Xi, Yi, Zi, ksize, stride, pad, False) if (taps > 1 or stride > 1) else None
             with _lib.TIMER.region("k_wgrad", 2.0 * Mo * Cin * Cout * taps):
-                call("coocc_conv_wgrad", ptr(x2d), Cin, ptr(dacc), Cp, ptr(tb), Mo, Cin, Cout, taps, ptr(dw), 0, ptr(ws),
+                call("coocc_conv_wgrad", ptr(x2d), Mi, Cin, ptr(dacc), Cp, ptr(tb), Mo, Cin, Cout, taps, ptr(dw), 0, ptr(ws),
                      ws.numel())
             dw = dw.view_as(weight)
         return dx, dw, dbias, dres, None, None, None, None, None, None, None
@@ -157,3 +158,200 @@ def linear_rows(x2d, weight, bias=None, relu=False):
     """Differentiable nn.Linear (+ReLU) on rows through the same kernels."""
     n = x2d.shape[0]
     return ConvRowsFn.apply(x2d.contiguous(), weight, bias, None, None, None, (1, n, 1, 1), 1, 1, 0, relu)
+
+
+# ----------------------------------------------------------------------------- G1 gather
+class GatherRowsFn(torch.autograd.Function):
+    """out[r] = src[idx[r]] (zeros where idx < 0); backward scatter-adds (bifuser_n.py:138-169 feature grads)."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        assert src.dim() == 2 and src.shape[1] % 4 == 0 and idx.dtype == torch.int32
+        out = torch.empty(idx.numel(), src.shape[1], device=src.device, dtype=_F32)
+        call("coocc_gather_rows", ptr(src.contiguous()), src.shape[1], ptr(idx.contiguous()), idx.numel(), src.shape[1],
+             ptr(out), src.shape[1])
+        ctx.save_for_backward(idx)
+        ctx.nrows = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        C = dout.shape[1]
+        dsrc = torch.zeros(ctx.nrows, C, device=dout.device, dtype=_F32)
+        call("coocc_scatter_add_rows", ptr(dout.float().contiguous()), C, ptr(idx.contiguous()), idx.numel(), C, ptr(dsrc), C)
+        return dsrc, None
+
+
+def gather_rows(src, idx):
+    return GatherRowsFn.apply(src, idx)
+
+
+# ----------------------------------------------------------------------------- P2 pooling
+class LiftSplatFn(torch.autograd.Function):
+    """Fused lift (x) splat (view_transformer.lift_splat) with gradients for depth_prob and the context features."""
+
+    @staticmethod
+    def forward(ctx, vt, depth_prob, img_feat, geom_feats):
+        from ._lib import host_f32
+        from .ops import _pool_workspace
+        BN, C, H, W = img_feat.shape
+        D = depth_prob.shape[1]
+        B = geom_feats.shape[0]
+        X, Y, Z = (int(v) for v in vt.nx.tolist())
+        dev = img_feat.device
+        feat = torch.empty(BN * H * W, C, device=dev, dtype=_F32)
+        call("coocc_ncdhw_to_ndhwc", ptr(img_feat.float().contiguous()), ptr(feat), BN, C, H * W, C, 0)
+        lo = (vt.bx - vt.dx / 2.).tolist() + vt.dx.tolist()
+        npts = BN * D * H * W
+        out = torch.empty(B * X * Y * Z, C, device=dev, dtype=_F32)
+        ws = _pool_workspace(dev, npts, B * X * Y * Z)
+        dp = depth_prob.float().contiguous()
+        g = geom_feats.reshape(-1, 3).float().contiguous()
+        call("coocc_lift_splat", ptr(dp), ptr(feat), ptr(g), BN, D, H, W, C, npts // B, host_f32(lo), B, X, Y, Z, ptr(out), C,
+             ptr(ws), ws.numel())
+        ctx.save_for_backward(dp, feat, g)
+        ctx.cfg = (BN, D, H, W, C, npts // B, lo, B, X, Y, Z)
+        return out.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from ._lib import host_f32
+        dp, feat, g = ctx.saved_tensors
+        BN, D, H, W, C, ppb, lo, B, X, Y, Z = ctx.cfg
+        dev = dp.device
+        drows = dout.permute(0, 2, 3, 4, 1).reshape(-1, C).float().contiguous()
+        d_depth = torch.empty_like(dp)
+        d_feat = torch.empty_like(feat)
+        call("coocc_lift_splat_bwd", ptr(drows), C, ptr(dp), ptr(feat), ptr(g), BN, D, H, W, C, ppb, host_f32(lo), B, X, Y, Z,
+             ptr(d_depth), ptr(d_feat))
+        d_img = torch.empty(BN, C, H, W, device=dev, dtype=_F32)
+        call("coocc_ndhwc_to_ncdhw", ptr(d_feat), ptr(d_img), BN, C, H * W, C, 0)
+        return None, d_depth, d_img, None
+
+
+def lift_splat(vt, depth_prob, img_feat, geom_feats):
+    return LiftSplatFn.apply(vt, depth_prob, img_feat, geom_feats)
+
+
+class VoxelPoolFn(torch.autograd.Function):
+    """voxel_pooling (ViewTransformerLSSVoxel.py:100-123) with the gradient of bev_pool_cuda.cu:61-84."""
+
+    @staticmethod
+    def forward(ctx, vt, geom_feats, x):
+        out = vt.voxel_pooling(geom_feats, x)
+        ctx.save_for_backward(geom_feats.reshape(-1, 3).float().contiguous())
+        ctx.vt, ctx.shape = vt, tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from ._lib import host_f32
+        (g,) = ctx.saved_tensors
+        vt = ctx.vt
+        B, N, D, H, W, C = ctx.shape
+        X, Y, Z = (int(v) for v in vt.nx.tolist())
+        drows = dout.permute(0, 2, 3, 4, 1).reshape(-1, C).float().contiguous()
+        npts = B * N * D * H * W
+        dx = torch.empty(npts, C, device=dout.device, dtype=_F32)
+        lo = (vt.bx - vt.dx / 2.).tolist() + vt.dx.tolist()
+        call("coocc_voxel_pool_bwd", ptr(drows), C, ptr(g), npts, npts // B, C, host_f32(lo), B, X, Y, Z, ptr(dx))
+        return None, None, dx.view(B, N, D, H, W, C)
+
+
+def voxel_pooling(vt, geom_feats, x):
+    return VoxelPoolFn.apply(vt, geom_feats, x)
+
+
+# ----------------------------------------------------------------------------- R2 render
+class RenderNearestFn(torch.autograd.Function):
+    """table [V,4] (sigma, rgb logits per voxel) -> composited maps [N,H,W,4] (coocc_ray.py:574-617)."""
+
+    @staticmethod
+    def forward(ctx, table, gemo, grid):
+        from ._lib import host_f32
+        from .render import RENDER_BOUNDS
+        X, Y, Z = grid
+        N, D, H, W, _ = gemo.shape
+        zvals = torch.linspace(0, D, D, device=table.device)
+        maps = torch.empty(N, H, W, 4, device=table.device, dtype=_F32)
+        t = table.float().contiguous()
+        call("coocc_render_nearest", ptr(t), X, Y, Z, ptr(gemo), ptr(zvals), N, D, H, W, host_f32(RENDER_BOUNDS), ptr(maps))
+        ctx.save_for_backward(t, gemo, zvals)
+        ctx.grid = grid
+        return maps
+
+    @staticmethod
+    def backward(ctx, dmaps):
+        from ._lib import host_f32
+        from .render import RENDER_BOUNDS
+        t, gemo, zvals = ctx.saved_tensors
+        X, Y, Z = ctx.grid
+        N, D, H, W, _ = gemo.shape
+        dtable = torch.empty_like(t)
+        call("coocc_render_nearest_bwd", ptr(t), X, Y, Z, ptr(gemo), ptr(zvals), N, D, H, W, host_f32(RENDER_BOUNDS),
+             ptr(dmaps.float().contiguous()), ptr(dtable))
+        return dtable, None, None
+
+
+class UpsampleMapsFn(torch.autograd.Function):
+    """maps [N,H,W,4] -> (rgbs [N,sH,sW,3], depths [N,sH,sW]) (coocc_ray.py:619-625)."""
+
+    @staticmethod
+    def forward(ctx, maps, scale):
+        N, H, W, _ = maps.shape
+        rgbs = torch.empty(N, H * scale, W * scale, 3, device=maps.device, dtype=_F32)
+        depths = torch.empty(N, H * scale, W * scale, device=maps.device, dtype=_F32)
+        call("coocc_upsample_maps", ptr(maps.contiguous()), N, H, W, scale, ptr(rgbs), ptr(depths))
+        ctx.cfg = (N, H, W, scale)
+        return rgbs, depths
+
+    @staticmethod
+    def backward(ctx, drgbs, ddepths):
+        N, H, W, scale = ctx.cfg
+        dmaps = torch.empty(N, H, W, 4, device=drgbs.device if drgbs is not None else ddepths.device, dtype=_F32)
+        call("coocc_upsample_maps_bwd", ptr(drgbs.float().contiguous()) if drgbs is not None else None,
+             ptr(ddepths.float().contiguous()) if ddepths is not None else None, N, H, W, scale, ptr(dmaps))
+        return dmaps, None
+
+
+class RenderLossesFn(torch.autograd.Function):
+    """-> tensor [2] = (loss_depth_render, loss_rgb) (coocc_ray.py:423-433)."""
+
+    @staticmethod
+    def forward(ctx, rgbs, depths, rgb_gt, depth_gt, D):
+        out = torch.empty(3, device=rgbs.device, dtype=_F32)
+        r, d = rgbs.contiguous(), depths.contiguous()
+        rg, dg = rgb_gt.float().contiguous(), depth_gt.float().contiguous()
+        call("coocc_render_losses", ptr(r), ptr(d), ptr(rg), ptr(dg), d.numel(), int(D), ptr(out))
+        ctx.save_for_backward(r, d, rg, dg, out)
+        ctx.D = int(D)
+        return out[:2].clone()
+
+    @staticmethod
+    def backward(ctx, gl):
+        r, d, rg, dg, out = ctx.saved_tensors
+        drgbs, ddepths = torch.empty_like(r), torch.empty_like(d)
+        call("coocc_render_losses_bwd", ptr(r), ptr(d), ptr(rg), ptr(dg), d.numel(), ctx.D, ptr(out), ptr(gl.float().contiguous()),
+             ptr(drgbs), ptr(ddepths))
+        return drgbs, ddepths, None, None, None
+
+
+def render_block_train(sigma_head, rgb_head, feats2d, grid, gemo, scale=16):
+    """Differentiable render block: feats2d [X*Y*Z, C] rows -> (rgbs, depths).  The per-voxel heads run through
+    ConvRowsFn (Linear+ReLU layers), so gradients reach the voxel features and both MLPs."""
+    def mlp(m, x):
+        for l in m.hidden_layers:
+            x = linear_rows(x, l.weight, l.bias, relu=True)
+        return linear_rows(x, m.output_layer.weight, m.output_layer.bias, relu=False)
+    sig = mlp(sigma_head, feats2d)                       # [V,1]
+    rgb = mlp(rgb_head, feats2d)                         # [V,3]
+    table = torch.cat([sig, rgb], 1)                     # plumbing: 16 B per voxel
+    N, D, H, W = gemo.shape[-5:-1]
+    maps = RenderNearestFn.apply(table, gemo.reshape(N, D, H, W, 3).float().contiguous(), tuple(grid))
+    return UpsampleMapsFn.apply(maps, scale)
+
+
+def render_losses(rgbs, depths, rgb_gt, depth_gt, D):
+    out = RenderLossesFn.apply(rgbs, depths, rgb_gt, depth_gt, D)
+    return dict(loss_depth_render=out[0], loss_rgb=out[1])

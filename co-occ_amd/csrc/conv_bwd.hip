@@ -168,10 +168,17 @@ extern "C" int coocc_conv_epilogue_bwd(const float* dout, int dout_stride, const
 // 64 x 64 = 2 x 2 MFMA blocks; UNR k-steps (2 voxels each) are loaded ahead of their 4*UNR MFMAs.
 // M-slices write partial slabs that k_wgrad_reduce sums in slice order (deterministic) into the torch
 // weight layout [Cout][Cin][taps].
-constexpr int WG_UNR = 4;
+constexpr int WG_UNR = 8;
 
-__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ in, int in_stride, const float* __restrict__ dacc,
-                                                int dacc_stride, const int32_t* __restrict__ table, int M, int Cin, int Cout,
+__device__ __forceinline__ float bload_f32(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+constexpr unsigned OOB = 0xFFFFFFFFu;   // beyond num_records: the buffer load returns 0 without a branch
+
+template <bool TABLE>
+__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ in, int in_stride, unsigned in_bytes,
+                                                const float* __restrict__ dacc, int dacc_stride, unsigned dacc_bytes,
+                                                const int32_t* __restrict__ table, int M, int Cin, int Cout,
                                                 int taps, int ctiles, int ntiles, int mslice, float* __restrict__ slabs) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 31, h = lane >> 5;
@@ -180,8 +187,16 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ in, int
   const int ct = tile % ctiles; const int t = tile / ctiles;
   const int c0 = ct * 128 + (wave >> 1) * 64, n0 = nt * 128 + (wave & 1) * 64;
   const int mbeg = blockIdx.y * mslice, mend = min(M, mbeg + mslice);
-  const int32_t* tb = table ? table + (size_t)t * M : nullptr;
-  const bool cok0 = c0 + li < Cin, cok1 = c0 + 32 + li < Cin, nok0 = n0 + li < Cout, nok1 = n0 + 32 + li < Cout;
+  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_da = __builtin_amdgcn_make_buffer_rsrc((void*)dacc, 0, dacc_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_tb = __builtin_amdgcn_make_buffer_rsrc((void*)(table ? table + (size_t)t * M : nullptr), 0,
+                                                                    table ? (unsigned)M * 4u : 0u, 0x00020000);
+  // per-lane channel byte offsets + all-ones masks for channels beyond the tensor.  Validity is folded into the
+  // offset with shifts and ORs (no compares): a select here makes hipcc sink the address math into divergent
+  // branches around every load.
+  const unsigned ca0 = (unsigned)(c0 + li) * 4u, ca1 = ca0 + 128u, nb0 = (unsigned)(n0 + li) * 4u, nb1 = nb0 + 128u;
+  const unsigned cm0 = (unsigned)((Cin - 1 - (c0 + li)) >> 31), cm1 = (unsigned)((Cin - 1 - (c0 + 32 + li)) >> 31);
+  const unsigned nm0 = (unsigned)((Cout - 1 - (n0 + li)) >> 31), nm1 = (unsigned)((Cout - 1 - (n0 + 32 + li)) >> 31);
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -190,26 +205,48 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ in, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int m = mbeg; m < mend; m += 2 * WG_UNR) {
-    float a[WG_UNR][2], b[WG_UNR][2];
+  // three-stage software pipeline: row ids two steps ahead, operands one step ahead of their MFMAs
+  constexpr int STEP = 2 * WG_UNR;
+  int rows[WG_UNR];
+  float a0[WG_UNR][2], b0[WG_UNR][2], a1[WG_UNR][2], b1[WG_UNR][2];   // two statically named operand sets
+  auto load_rows = [&](int m) {
 #pragma unroll
     for (int u = 0; u < WG_UNR; ++u) {
       const int mm = m + 2 * u + h;
-      const bool mok = mm < mend;
-      int row = mok ? (tb ? tb[mm] : mm) : -1;
-      const float* ar = in + (size_t)max(row, 0) * in_stride + c0 + li;
-      const float* br = dacc + (size_t)(mok ? mm : 0) * dacc_stride + n0 + li;
-      a[u][0] = (row >= 0 && cok0) ? ar[0] : 0.f;
-      a[u][1] = (row >= 0 && cok1) ? ar[32] : 0.f;
-      b[u][0] = (mok && nok0) ? br[0] : 0.f;
-      b[u][1] = (mok && nok1) ? br[32] : 0.f;
+      const int r = TABLE ? __builtin_amdgcn_raw_buffer_load_b32(rs_tb, (int)((unsigned)min(mm, M - 1) * 4u), 0, 0) : mm;
+      rows[u] = r | ((mend - 1 - mm) >> 31);          // -1 beyond the slice
     }
+  };
+  auto load_ops = [&](int m, float (&a)[WG_UNR][2], float (&b)[WG_UNR][2]) {
+#pragma unroll
+    for (int u = 0; u < WG_UNR; ++u) {
+      const int mm = m + 2 * u + h;
+      const unsigned rmask = (unsigned)(rows[u] >> 31), mmask = (unsigned)((mend - 1 - mm) >> 31);
+      const unsigned ra = (unsigned)rows[u] * (unsigned)in_stride * 4u, rb = (unsigned)mm * (unsigned)dacc_stride * 4u;
+      a[u][0] = bload_f32(rs_in, (ra + ca0) | rmask | cm0);
+      a[u][1] = bload_f32(rs_in, (ra + ca1) | rmask | cm1);
+      b[u][0] = bload_f32(rs_da, (rb + nb0) | mmask | nm0);
+      b[u][1] = bload_f32(rs_da, (rb + nb1) | mmask | nm1);
+    }
+  };
+  auto mfmas = [&](const float (&a)[WG_UNR][2], const float (&b)[WG_UNR][2]) {
 #pragma unroll
     for (int u = 0; u < WG_UNR; ++u)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+  };
+  load_rows(mbeg);
+  load_ops(mbeg, a0, b0);
+  load_rows(mbeg + STEP);
+  for (int m = mbeg; m < mend; m += 2 * STEP) {
+    load_ops(m + STEP, a1, b1);      // uses the row ids fetched one step ago
+    load_rows(m + 2 * STEP);
+    mfmas(a0, b0);
+    load_ops(m + 2 * STEP, a0, b0);
+    load_rows(m + 3 * STEP);
+    mfmas(a1, b1);                   // beyond mend these operands are all zeros
   }
   // slab layout [slice][t][Cin][Cout]
   float* sl = slabs + ((size_t)blockIdx.y * taps + t) * (size_t)Cin * Cout;
@@ -237,10 +274,13 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   *d = accumulate ? *d + s : s;
 }
 
-extern "C" int coocc_conv_wgrad(const float* in, int in_stride, const float* dacc, int dacc_stride, const int32_t* table,
-                                int M, int Cin, int Cout, int taps, float* dw, int accumulate, float* ws,
-                                int64_t ws_floats, void* stream) {
-  COOCC_CHECK_ARG(in && dacc && dw && ws && M > 0 && Cin > 0 && Cout > 0 && taps > 0, "conv_wgrad: bad args");
+extern "C" int coocc_conv_wgrad(const float* in, int in_rows, int in_stride, const float* dacc, int dacc_stride,
+                                const int32_t* table, int M, int Cin, int Cout, int taps, float* dw, int accumulate,
+                                float* ws, int64_t ws_floats, void* stream) {
+  COOCC_CHECK_ARG(in && dacc && dw && ws && M > 0 && Cin > 0 && Cout > 0 && taps > 0 && in_rows > 0, "conv_wgrad: bad args");
+  const unsigned long long in_bytes = (unsigned long long)in_rows * in_stride * 4ull, da_bytes = (unsigned long long)M * dacc_stride * 4ull;
+  COOCC_CHECK_ARG(in_bytes < 0xFFFFFF00ull && da_bytes < 0xFFFFFF00ull, "conv_wgrad: operand larger than 4 GB");
+  COOCC_CHECK_ARG(table || in_rows >= M, "conv_wgrad: identity rows need in_rows >= M");
   COOCC_CHECK_ARG(table || taps == 1, "conv_wgrad: taps > 1 needs the forward row table (coocc_conv_tap_table)");
   const int ctiles = (Cin + 127) / 128, ntiles = (Cout + 127) / 128;
   const long long tiles = (long long)ctiles * ntiles * taps;
@@ -253,8 +293,14 @@ extern "C" int coocc_conv_wgrad(const float* in, int in_stride, const float* dac
   mslice = (mslice + 2 * WG_UNR - 1) / (2 * WG_UNR) * (2 * WG_UNR);
   nslices = (M + mslice - 1) / mslice;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(k_wgrad, dim3((unsigned)tiles, (unsigned)nslices), dim3(256), 0, s, in, in_stride, dacc, dacc_stride,
-                     table, M, Cin, Cout, taps, ctiles, ntiles, mslice, ws);
+  if (table)
+    hipLaunchKernelGGL(k_wgrad<true>, dim3((unsigned)tiles, (unsigned)nslices), dim3(256), 0, s, in, in_stride,
+                       (unsigned)in_bytes, dacc, dacc_stride, (unsigned)da_bytes, table, M, Cin, Cout, taps, ctiles, ntiles,
+                       mslice, ws);
+  else
+    hipLaunchKernelGGL(k_wgrad<false>, dim3((unsigned)tiles, (unsigned)nslices), dim3(256), 0, s, in, in_stride,
+                       (unsigned)in_bytes, dacc, dacc_stride, (unsigned)da_bytes, table, M, Cin, Cout, taps, ctiles, ntiles,
+                       mslice, ws);
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(per, 256)), dim3(256), 0, s, ws, (int)nslices, Cin, Cout, taps, dw, accumulate);
   COOCC_LAUNCH_CHECK("k_wgrad");
   return COOCC_OK;

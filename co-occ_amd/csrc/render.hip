@@ -310,6 +310,7 @@ __global__ __launch_bounds__(1024) void k_render_losses(const float* __restrict_
     for (int w = 0; w < 16; ++w) { a += s_d[w]; b += s_c[w]; c += s_n[w]; }
     out[0] = (float)(a / c);           // mean over the foreground pixels (NaN when there are none, like torch)
     out[1] = (float)(b / (3.0 * (double)npix));
+    out[2] = (float)c;                 // foreground count (consumed by coocc_render_losses_bwd)
   }
 }
 

@@ -95,7 +95,7 @@ def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16):
 
 def render_losses(rgbs, depths, rgb_gt, depth_gt, D):
     """coocc_ray.py:423-433 -> dict(loss_depth_render, loss_rgb) (forward values)."""
-    out = torch.empty(2, device=rgbs.device, dtype=_F32)
+    out = torch.empty(3, device=rgbs.device, dtype=_F32)
     call("coocc_render_losses", ptr(rgbs.contiguous()), ptr(depths.contiguous()), ptr(rgb_gt.float().contiguous()),
          ptr(depth_gt.float().contiguous()), depths.numel(), int(D), ptr(out))
     return dict(loss_depth_render=out[0], loss_rgb=out[1])

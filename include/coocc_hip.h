@@ -162,10 +162,39 @@ int coocc_conv_epilogue_bwd(const float* dout, int dout_stride, const float* out
                             float* dres, int dres_stride, int dres_accumulate, float* dbias,
                             int dbias_accumulate, float* ws, int64_t ws_floats, void* stream);
 /* dw[Cout][Cin][taps] (+)= sum_m in[table[t][m]][c] * dacc[m][n]  (table NULL: identity rows, taps == 1).
- * fp32 MFMA with the voxel index as K; M-slices reduced in slice order (deterministic). */
-int coocc_conv_wgrad(const float* in, int in_stride, const float* dacc, int dacc_stride, const int32_t* table,
-                     int M, int Cin, int Cout, int taps, float* dw, int accumulate, float* ws,
-                     int64_t ws_floats, void* stream);
+ * in has in_rows rows; fp32 MFMA with the voxel index as K; M-slices reduced in slice order (deterministic). */
+int coocc_conv_wgrad(const float* in, int in_rows, int in_stride, const float* dacc, int dacc_stride,
+                     const int32_t* table, int M, int Cin, int Cout, int taps, float* dw, int accumulate,
+                     float* ws, int64_t ws_floats, void* stream);
+
+/* ---- backward of the HBM-bound ops (torch autograd over eager index_put / cumprod / interpolate upstream) */
+/* dst[r] = src[idx[r]] (zeros for idx < 0) and its adjoint dst[idx[r]] += src[r] (fp32 atomics): the G1 row
+ * gather of bifuser_n.py:138-169 and its feature gradient. */
+int coocc_gather_rows(const float* src, int src_stride, const int32_t* idx, int n, int C, float* dst,
+                      int dst_stride, void* stream);
+int coocc_scatter_add_rows(const float* src, int src_stride, const int32_t* idx, int n, int C, float* dst,
+                           int dst_stride, void* stream);
+/* voxel_pooling backward (bev_pool_grad_kernel, bev_pool_cuda.cu:61-84, without the sort):
+ * dx[p] = dout[voxel(p)] for kept points, 0 otherwise.  dout: NDHWC rows; dx:[npts,C]. */
+int coocc_voxel_pool_bwd(const float* dout, int dout_stride, const float* geom, int npts, int pts_per_batch,
+                         int C, const float* lo_dx_host, int B, int X, int Y, int Z, float* dx, void* stream);
+/* coocc_lift_splat backward: d_depth[N,D,H,W] and d_feat_nhwc[N,H,W,C] in one deterministic pass. */
+int coocc_lift_splat_bwd(const float* dout, int dout_stride, const float* depth, const float* feat_nhwc,
+                         const float* geom, int N, int D, int H, int W, int C, int pts_per_batch,
+                         const float* lo_dx_host, int B, int X, int Y, int Z, float* d_depth,
+                         float* d_feat_nhwc, void* stream);
+/* coocc_render_nearest backward: dmaps:[N,H,W,4] (d rgb, d depth) -> dtable:[X*Y*Z,4] (zeroed here, then
+ * accumulated with fp32 atomics).  Same arguments as the forward. */
+int coocc_render_nearest_bwd(const float* table, int X, int Y, int Z, const float* geom, const float* zvals,
+                             int N, int D, int H, int W, const float* bounds_host, const float* dmaps,
+                             float* dtable, void* stream);
+/* coocc_upsample_maps backward (bilinear adjoint, deterministic gather): drgbs / ddepths may be NULL. */
+int coocc_upsample_maps_bwd(const float* drgbs, const float* ddepths, int N, int H, int W, int scale,
+                            float* dmaps, void* stream);
+/* coocc_render_losses backward: losses_out = the forward's out[3]; gl:[2] (device) upstream gradients. */
+int coocc_render_losses_bwd(const float* rgbs, const float* depths, const float* rgb_gt, const float* depth_gt,
+                            int64_t npix, int D, const float* losses_out, const float* gl, float* drgbs,
+                            float* ddepths, void* stream);
 
 /* FPN3D top-down step (fpn3d.py:88-92): fine += trilinear(coarse -> fine size),
  * align_corners=False.  Rows NDHWC with C channels. */
@@ -274,8 +303,8 @@ int coocc_volume_sampling(const float* vol, int C, int d0, int d1, int d2, const
  * (may be NULL); zmin/zmax = z_vals.min()/max(). */
 int coocc_raw2outputs(const float* raw, const float* z, int R, int S, int white_bkgd, float zmin,
                       float zmax, float* rgb, float* depth, float* weights, void* stream);
-/* render losses (coocc_ray.py:423-433): out[0]=loss_depth_render, out[1]=loss_rgb.
- * rgbs/rgb_gt:[npix,3]; depths/depth_gt:[npix]. */
+/* render losses (coocc_ray.py:423-433): out[0]=loss_depth_render, out[1]=loss_rgb, out[2]=number of
+ * foreground pixels (kept for the backward).  rgbs/rgb_gt:[npix,3]; depths/depth_gt:[npix]. */
 int coocc_render_losses(const float* rgbs, const float* depths, const float* rgb_gt,
                         const float* depth_gt, int64_t npix, int D, float* out, void* stream);
 

@@ -94,3 +94,169 @@ def test_linear_backward_and_chain(dev):
     y.square().sum().backward()
     for a, b, name in zip(got, ref, ("dx", "dw1", "db1", "dw2", "db2")):
         assert_close(a.grad.cpu(), b.grad, what=name)
+
+
+def test_gather_rows_backward(dev):
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(50, 16, generator=g)
+    idx = torch.randint(-1, 50, (200,), generator=g).int()
+    gout = torch.randn(200, 16, generator=g)
+    sr = src.clone().requires_grad_()
+    ref = torch.where(idx[:, None] >= 0, sr[idx.clamp(min=0).long()], torch.zeros(()))
+    ref.backward(gout)
+    sd = src.to(dev).requires_grad_()
+    out = ag.gather_rows(sd, idx.to(dev))
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    out.backward(gout.to(dev))
+    assert_close(sd.grad.cpu(), sr.grad, what="gather dsrc")
+
+
+def _pool_ref(vt_cfg, geom, vol_rows, B):
+    """voxel_pooling with torch ops only (differentiable): truncate-then-filter keys + index_add."""
+    lo = torch.tensor([vt_cfg["xbound"][0], vt_cfg["ybound"][0], vt_cfg["zbound"][0]])
+    dx = torch.tensor([vt_cfg["xbound"][2], vt_cfg["ybound"][2], vt_cfg["zbound"][2]])
+    nx = [int(round((vt_cfg[k][1] - vt_cfg[k][0]) / vt_cfg[k][2])) for k in ("xbound", "ybound", "zbound")]
+    q = ((geom.reshape(-1, 3) - lo) / dx).long()
+    kept = ((q >= 0) & (q < torch.tensor(nx))).all(1)
+    b = torch.arange(q.shape[0]) // (q.shape[0] // B)
+    key = ((b * nx[0] + q[:, 0]) * nx[1] + q[:, 1]) * nx[2] + q[:, 2]
+    out = torch.zeros(B * nx[0] * nx[1] * nx[2], vol_rows.shape[1])
+    return out.index_add(0, key[kept], vol_rows[kept]), nx
+
+
+def test_lift_splat_and_voxel_pool_backward(dev):
+    from oracle import cases, ref_cpu
+    import co_occ_amd.synth as synth
+    c = cases.POOL_CASE
+    rig = synth.camera_rig(c["ncam"], c["input_size"], seed=c["seed"])
+    vt = pkg.ViewTransformerLiftSplatShootVoxel(grid_config=c["grid_config"], data_config=dict(input_size=c["input_size"]),
+                                                downsample=c["downsample"], numC_Trans=c["C"]).to(dev)
+    fr = ref_cpu.create_frustum(c["input_size"], c["downsample"], c["grid_config"]["dbound"])
+    geom = ref_cpu.get_geometry(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
+    g = torch.Generator().manual_seed(8)
+    N, D, (H, W), C = c["ncam"], fr.shape[0], c["fmap"], 12
+    depth = torch.softmax(torch.randn(N, D, H, W, generator=g) * 2, dim=1)
+    feat = torch.randn(N, C, H, W, generator=g)
+    # reference
+    dr, fr_ = depth.clone().requires_grad_(), feat.clone().requires_grad_()
+    vol = (dr.unsqueeze(1) * fr_.unsqueeze(2)).permute(0, 2, 3, 4, 1).reshape(-1, C)     # rows in (n,d,h,w) order
+    ref, nx = _pool_ref(c["grid_config"], geom, vol, 1)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    # fused
+    dd, fd = depth.to(dev).requires_grad_(), feat.to(dev).requires_grad_()
+    out = ag.lift_splat(vt, dd, fd, geom.to(dev))
+    rows = out.permute(0, 2, 3, 4, 1).reshape(-1, C)
+    assert_close(rows.detach().cpu(), ref.detach(), what="lift_splat fwd")
+    rows.backward(gout.to(dev))
+    assert_close(dd.grad.cpu(), dr.grad, what="d depth")
+    assert_close(fd.grad.cpu(), fr_.grad, what="d feat")
+    # plain voxel pooling of a materialised volume: dx[p] = dout[voxel(p)]
+    vol_d = vol.detach().view(1, N, D, H, W, C).to(dev).requires_grad_()
+    vr = vol.detach().clone().requires_grad_()
+    ref2, _ = _pool_ref(c["grid_config"], geom, vr, 1)
+    ref2.backward(gout)
+    out2 = ag.voxel_pooling(vt, geom.to(dev), vol_d)
+    out2.permute(0, 2, 3, 4, 1).reshape(-1, C).backward(gout.to(dev))
+    assert torch.equal(vol_d.grad.reshape(-1, C).cpu(), vr.grad)
+
+
+def _render_ref(sig_pre, rgb_logit, gemo, grid, scale):
+    """coocc_ray.py:574-625 in its per-voxel-table form, plain torch on the CPU (differentiable)."""
+    X, Y, Z = grid
+    N, D, H, W, _ = gemo.shape
+    lo, nx = torch.tensor([-50., -50., -5.]), torch.tensor([100., 100., 8.])
+    g = gemo - lo
+    inside = ((g >= 0) & (g < nx)).all(-1)
+    pts = (g * inside[..., None]).long()
+    lin = (pts[..., 0] * Y + pts[..., 1]) * Z + pts[..., 2]
+    rgb = torch.sigmoid(rgb_logit[lin] * inside[..., None])
+    sigma = F.relu(sig_pre[lin])
+    pf = pts.float()
+    dists = torch.norm(pf[:, 1:] - pf[:, :-1], dim=-1)
+    dists = torch.cat([dists, torch.full_like(dists[:, :1], 1e10)], 1)
+    alpha = 1. - torch.exp(-F.relu(sigma * dists))
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1. - alpha + 1e-10], 1), 1)[:, :-1]
+    w = alpha * T
+    rgb_map = (w[..., None] * rgb).sum(1)                               # [N,H,W,3]
+    z = torch.linspace(0, D, D).view(1, D, 1, 1)
+    depth_map = (w * z).sum(1)
+    rgbs = F.interpolate(rgb_map.permute(0, 3, 1, 2), scale_factor=scale, mode='bilinear').permute(0, 2, 3, 1)
+    depths = F.interpolate(depth_map.unsqueeze(1), scale_factor=scale, mode='bilinear').squeeze(1)
+    return rgbs, depths
+
+
+def test_render_block_backward(dev):
+    """R2 + x16 upsample + render losses: d table through the composite (prefix product / suffix sum) and the
+    bilinear adjoint, against torch autograd of the same formulas."""
+    g = torch.Generator().manual_seed(21)
+    grid, (N, D, H, W), scale = (100, 100, 8), (2, 24, 3, 5), 16
+    V = grid[0] * grid[1] * grid[2]
+    sig = torch.randn(V, generator=g) * 0.3
+    rgbl = torch.randn(V, 3, generator=g)
+    # rays marching outwards through the volume, some samples leaving it
+    o = torch.tensor([0., 0., -1.]) + torch.randn(N, 1, H, W, 3, generator=g) * 0.3
+    d = torch.randn(N, 1, H, W, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True) * torch.tensor([1., 1., 0.15])
+    t = torch.linspace(0.5, 70, D).view(1, D, 1, 1, 1)
+    gemo = (o + d * t).contiguous()
+    rgb_gt = torch.rand(N, H * scale, W * scale, 3, generator=g)
+    depth_gt = torch.rand(N, H * scale, W * scale, generator=g) * 60
+    depth_gt[depth_gt < 10] = 0     # background pixels
+    sr, rr = sig.clone().requires_grad_(), rgbl.clone().requires_grad_()
+    rgbs_r, depths_r = _render_ref(sr, rr, gemo, grid, scale)
+    dg = ((depth_gt - 1.75) / 0.5).clip(0, D)
+    fg = dg > 0
+    loss_r = F.mse_loss(depths_r[fg] / D, dg[fg] / D) * 0.7 + F.mse_loss(rgbs_r, rgb_gt) * 1.3
+    loss_r.backward()
+
+    table = torch.cat([sig[:, None], rgbl], 1).to(dev).requires_grad_()
+    maps = ag.RenderNearestFn.apply(table, gemo.to(dev), grid)
+    rgbs, depths = ag.UpsampleMapsFn.apply(maps, scale)
+    assert_close(rgbs.detach().cpu(), rgbs_r.detach(), what="rgbs")
+    assert_close(depths.detach().cpu(), depths_r.detach(), what="depths")
+    L = ag.render_losses(rgbs, depths, rgb_gt.to(dev), depth_gt.to(dev), D)
+    loss = L["loss_depth_render"] * 0.7 + L["loss_rgb"] * 1.3
+    assert_close(loss.detach().cpu(), loss_r.detach(), what="loss")
+    loss.backward()
+    want = torch.cat([sr.grad[:, None], rr.grad], 1)
+    assert float(want.abs().max()) > 0
+    assert_close(table.grad.cpu() / want.abs().max(), want / want.abs().max(), what="d table")
+
+
+def test_render_block_train_reaches_features_and_heads(dev):
+    """render_block_train: gradients flow through the per-voxel MLP heads (ConvRowsFn) to the voxel features."""
+    g = torch.Generator().manual_seed(5)
+    grid, (N, D, H, W) = (100, 100, 8), (1, 16, 2, 4)
+    V, C = 80000, 32
+    feats = (torch.randn(V, C, generator=g) * 0.5)
+    sig_head = pkg.MLP(input_dim=C, output_dim=1, net_depth=1, net_width=16, skip_layer=None)
+    rgb_head = pkg.MLP(input_dim=C, output_dim=3, net_depth=2, net_width=16, skip_layer=None)
+    for m in (sig_head, rgb_head):
+        for p in m.parameters():
+            p.data.copy_(torch.randn(p.shape, generator=g) * 0.2)
+    o = torch.tensor([0., 0., -1.]) + torch.randn(N, 1, H, W, 3, generator=g) * 0.3
+    d = torch.randn(N, 1, H, W, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True) * torch.tensor([1., 1., 0.15])
+    gemo = (o + d * torch.linspace(0.5, 40, D).view(1, D, 1, 1, 1)).contiguous()
+
+    def mlp_ref(m, x):
+        for l in m.hidden_layers:
+            x = F.relu(F.linear(x, l.weight, l.bias))
+        return F.linear(x, m.output_layer.weight, m.output_layer.bias)
+    fr = feats.clone().requires_grad_()
+    rgbs_r, depths_r = _render_ref(mlp_ref(sig_head, fr)[:, 0], mlp_ref(rgb_head, fr), gemo, grid, 16)
+    (rgbs_r.square().mean() + depths_r.mean()).backward()
+    ref_grads = [p.grad.clone() for p in list(sig_head.parameters()) + list(rgb_head.parameters())]
+    for p in list(sig_head.parameters()) + list(rgb_head.parameters()):
+        p.grad = None
+    sig_head, rgb_head = sig_head.to(dev), rgb_head.to(dev)
+    fd = feats.to(dev).requires_grad_()
+    rgbs, depths = ag.render_block_train(sig_head, rgb_head, fd, grid, gemo.to(dev)[None])
+    (rgbs.square().mean() + depths.mean()).backward()
+    s = float(fr.grad.abs().max())
+    assert s > 0
+    assert_close(fd.grad.cpu() / s, fr.grad / s, what="d voxel feats")
+    for p, r in zip(list(sig_head.parameters()) + list(rgb_head.parameters()), ref_grads):
+        sc = max(float(r.abs().max()), 1e-12)
+        assert_close(p.grad.cpu() / sc, r / sc, what="d head params")

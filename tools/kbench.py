@@ -153,6 +153,37 @@ def bench_poolprof():
     print("lift_splat r101 %.3f ms" % timeit(lambda: vt.lift_splat(depth, feat, geom), n=10))
 
 
+def bench_bwd():
+    """Conv backward at the r50 decoder shapes: forward, dgrad, wgrad (each 2*M*Cin*Cout*taps flop)."""
+    from co_occ_amd import autograd as ag
+    from co_occ_amd import _lib
+    g = torch.Generator().manual_seed(6)
+    for name, Cin, Cout, grid, k, stride in (("enc.l0", 128, 128, (100, 100, 8), 3, 1), ("fpn.out0", 256, 256, (100, 100, 8), 3, 1),
+                                              ("con_enc.0", 512, 256, (100, 100, 8), 3, 1), ("enc.l1.conv1", 128, 256, (100, 100, 8), 3, 2),
+                                              ("lat0 1x1", 128, 256, (100, 100, 8), 1, 1)):
+        X, Y, Z = grid
+        x = torch.randn(X * Y * Z, Cin, generator=g).to(dev).requires_grad_()
+        w = (torch.randn(Cout, Cin, k, k, k, generator=g) / (Cin * k ** 3) ** 0.5).to(dev).requires_grad_()
+        out, geom = ag.conv3d_rows(x, w, (1, X, Y, Z), stride=stride, relu=True)
+        go = torch.randn_like(out)
+        flop = 2.0 * out.shape[0] * Cin * Cout * k ** 3
+        t_f = timeit(lambda: ag.conv3d_rows(x, w, (1, X, Y, Z), stride=stride, relu=True), n=5)
+        _lib.TIMER.enabled = True
+        _lib.TIMER.reset()
+        for _ in range(3):
+            x.grad = w.grad = None
+            out.backward(go, retain_graph=True)
+        torch.cuda.synchronize()
+        rows = _lib.TIMER.summary()
+        _lib.TIMER.enabled = False
+        parts = []
+        for key in ("conv_dgrad", "k_wgrad", "coocc_conv_epilogue_bwd"):
+            if key in rows:
+                ms = rows[key]["ms"] / rows[key]["launches"]
+                parts.append("%s %.3f ms%s" % (key.replace("coocc_conv_", ""), ms, " (%.0f TF)" % (flop / ms / 1e9) if key != "coocc_conv_epilogue_bwd" else ""))
+        print("bwd %-13s %4d->%4d k%d s%d  fwd(+pack) %.3f ms | backward: %s" % (name, Cin, Cout, k, stride, t_f, "  ".join(parts)))
+
+
 def bench_eval():
     from co_occ_amd import evaluation as ev
     g = torch.Generator().manual_seed(5)
@@ -191,4 +222,5 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["fps", "knn", "conv"]
     with torch.no_grad():
         for w in which:
-            globals()["bench_" + w]()
+            with torch.set_grad_enabled(w == "bwd"):
+                globals()["bench_" + w]()
