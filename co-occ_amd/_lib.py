@@ -79,6 +79,7 @@ SIGNATURES = {
     "coocc_render_nearest_bwd": (I, [P, I, I, I, P, P, I, I, I, I, P, P, P, P]),
     "coocc_upsample_maps_bwd": (I, [P, P, I, I, I, I, P, P]),
     "coocc_render_losses_bwd": (I, [P, P, P, P, L, I, P, P, P, P, P]),
+    "coocc_upsample_trilinear_bwd": (I, [P, P, I, I, I, I, I, I, I, I, I, P]),
     "coocc_eval_semantic": (I, [P, L, L, L, L, I, I, I, I, P, P, I, I, I, I, I, P, P]),
 }
 

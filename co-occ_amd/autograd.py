@@ -355,3 +355,64 @@ def render_block_train(sigma_head, rgb_head, feats2d, grid, gemo, scale=16):
 def render_losses(rgbs, depths, rgb_gt, depth_gt, D):
     out = RenderLossesFn.apply(rgbs, depths, rgb_gt, depth_gt, D)
     return dict(loss_depth_render=out[0], loss_rgb=out[1])
+
+
+# ----------------------------------------------------------------------------- FPN top-down step
+class UpsampleAddFn(torch.autograd.Function):
+    """fine + trilinear(coarse -> fine size) on rows (fpn3d.py:88-92)."""
+
+    @staticmethod
+    def forward(ctx, coarse2d, fine2d, gc, gf):
+        B, Xc, Yc, Zc = gc
+        _, Xf, Yf, Zf = gf
+        C = fine2d.shape[1]
+        out = fine2d.clone()
+        call("coocc_upsample_add_trilinear", ptr(coarse2d.contiguous()), ptr(out), B, C, Xc, Yc, Zc, Xf, Yf, Zf)
+        ctx.cfg = (B, C, Xc, Yc, Zc, Xf, Yf, Zf)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C, Xc, Yc, Zc, Xf, Yf, Zf = ctx.cfg
+        dout = dout.float().contiguous()
+        dc = torch.empty(B * Xc * Yc * Zc, C, device=dout.device, dtype=_F32)
+        call("coocc_upsample_trilinear_bwd", ptr(dout), ptr(dc), B, C, Xc, Yc, Zc, Xf, Yf, Zf, 0)
+        return dc, dout, None, None
+
+
+def upsample_add(coarse2d, fine2d, gc, gf):
+    return UpsampleAddFn.apply(coarse2d, fine2d, tuple(gc), tuple(gf))
+
+
+# ----------------------------------------------------------------------------- decoder trunk (C0 + C1 + C2)
+def _cm(x, geom, m, relu=True):
+    """mmcv-style ConvModule (conv, bn) on rows."""
+    return conv3d_rows(x, m.conv.weight, geom, bias=m.conv.bias, bn=m.bn, relu=relu)
+
+
+def trunk_forward_train(con_enc, backbone, neck, x2d, geom):
+    """Differentiable con_enc -> CustomResNet3D -> FPN3D on rows (bifuser_n.py:23-30, resnet3d.py:196-205,
+    fpn3d.py:70-108) with frozen-statistics BN.  x2d: [B*X*Y*Z, 4C] fused rows.  Returns [(rows, geom)] per level.
+    The modules are the inference modules: parameters (and state_dict keys) are shared."""
+    if con_enc is not None:     # Sequential(Conv3d, BN, ReLU, Conv3d, BN, ReLU)
+        x2d, geom = conv3d_rows(x2d, con_enc[0].weight, geom, bias=con_enc[0].bias, bn=con_enc[1], relu=True)
+        x2d, geom = conv3d_rows(x2d, con_enc[3].weight, geom, bias=con_enc[3].bias, bn=con_enc[4], relu=True)
+    x, g = conv3d_rows(x2d, backbone.input_proj[0].weight, geom, bn=backbone.input_proj[1], relu=True)
+    feats = []
+    for i, layer in enumerate(backbone.layers):
+        for blk in layer:
+            out, go = conv3d_rows(x, blk.conv1.weight, g, bn=blk.bn1, stride=blk.stride, relu=True)
+            if blk.downsample is not None:
+                res, _ = conv3d_rows(x, blk.downsample[0].weight, g, bn=blk.downsample[1], stride=blk.stride, pad=0, relu=False)
+            else:
+                res = x
+            x, g = conv3d_rows(out, blk.conv2.weight, go, bn=blk.bn2, relu=True, res2d=res)
+        if i in backbone.out_indices:
+            feats.append((x, g))
+    if neck is None:
+        return feats
+    lat = [_cm(x, g, neck.lateral_convs[i][0]) for i, (x, g) in enumerate(feats)]
+    for i in range(len(lat) - 1, 0, -1):
+        (c, gc), (f, gf) = lat[i], lat[i - 1]
+        lat[i - 1] = (upsample_add(c, f, gc, gf), gf)
+    return [_cm(x, g, neck.fpn_convs[i][0]) for i, (x, g) in enumerate(lat)]

@@ -336,3 +336,69 @@ extern "C" int coocc_render_losses_bwd(const float* rgbs, const float* depths, c
   COOCC_LAUNCH_CHECK("k_render_losses_bwd");
   return COOCC_OK;
 }
+
+// ------------------------------------------------------------------ FPN trilinear upsample-add backward
+// forward (interp.hip k_upsample_add, fpn3d.py:88-92): fine += trilinear(coarse -> fine size).  The fine
+// gradient passes through unchanged; the coarse gradient is the adjoint of the interpolation, gathered per
+// coarse voxel from the <= MAXC^3 fine voxels whose two taps per axis include it (deterministic).
+constexpr int MAXC = 10;
+
+__device__ __forceinline__ int axis_weights(int c, int in, int out, int& lo, float* w) {
+  // fine indices d in [lo, lo+n) with weight w[d-lo] onto coarse index c
+  const float inv = (float)out / (float)in;
+  int dlo = in == out ? c : max(0, (int)floorf(((float)c - 0.5f) * inv - 0.5f) - 1);
+  int dhi = in == out ? c : min(out - 1, (int)ceilf(((float)c + 1.5f) * inv - 0.5f) + 1);
+  if (c == 0) dlo = 0;
+  if (c == in - 1) dhi = out - 1;
+  int first = -1, n = 0;
+  for (int d = dlo; d <= dhi; ++d) {
+    const LinB l = lin_srcb(d, in, out);
+    const float wt = (l.i0 == c ? l.w0 : 0.f) + (l.i1 == c ? l.w1 : 0.f);
+    if (wt != 0.f || first >= 0) {
+      if (first < 0) first = d;
+      if (d - first < MAXC) { w[d - first] = wt; n = d - first + 1; }
+    }
+  }
+  lo = first < 0 ? 0 : first;
+  return n;
+}
+
+__global__ __launch_bounds__(256) void k_upsample_trilinear_bwd(const float* __restrict__ dfine, float* __restrict__ dcoarse,
+                                                                 int B, int C, int Xc, int Yc, int Zc, int Xf, int Yf,
+                                                                 int Zf, int accumulate) {
+  const int c4 = C >> 2;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * Xc * Yc * Zc * c4) return;
+  const int c = (int)(i % c4) * 4;
+  long long v = i / c4;
+  const int z = (int)(v % Zc); v /= Zc;
+  const int y = (int)(v % Yc); v /= Yc;
+  const int x = (int)(v % Xc); const int b = (int)(v / Xc);
+  float wx[MAXC], wy[MAXC], wz[MAXC];
+  int x0, y0, z0;
+  const int nx = axis_weights(x, Xc, Xf, x0, wx), ny = axis_weights(y, Yc, Yf, y0, wy), nz = axis_weights(z, Zc, Zf, z0, wz);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < nx; ++a)
+    for (int bb = 0; bb < ny; ++bb) {
+      const float wxy = wx[a] * wy[bb];
+      if (wxy == 0.f) continue;
+      for (int cc = 0; cc < nz; ++cc) {
+        const float wt = wxy * wz[cc];
+        if (wt != 0.f)
+          acc = acc + wt * *(const f32x4*)(dfine + ((((size_t)b * Xf + x0 + a) * Yf + y0 + bb) * Zf + z0 + cc) * C + c);
+      }
+    }
+  f32x4* o = (f32x4*)(dcoarse + ((((size_t)b * Xc + x) * Yc + y) * Zc + z) * C + c);
+  *o = accumulate ? *o + acc : acc;
+}
+
+extern "C" int coocc_upsample_trilinear_bwd(const float* dfine, float* dcoarse, int B, int C, int Xc, int Yc, int Zc, int Xf,
+                                            int Yf, int Zf, int accumulate, void* stream) {
+  COOCC_CHECK_ARG(dfine && dcoarse && B > 0 && C > 0 && C % 4 == 0, "upsample_trilinear_bwd: bad args (C % 4 == 0)");
+  COOCC_CHECK_ARG(Xf <= 4 * Xc && Yf <= 4 * Yc && Zf <= 4 * Zc && Xf >= Xc && Yf >= Yc && Zf >= Zc,
+                  "upsample_trilinear_bwd: supports upsampling factors up to 4");
+  hipLaunchKernelGGL(k_upsample_trilinear_bwd, dim3(cdiv((long long)B * Xc * Yc * Zc * (C / 4), 256)), dim3(256), 0,
+                     as_stream(stream), dfine, dcoarse, B, C, Xc, Yc, Zc, Xf, Yf, Zf, accumulate);
+  COOCC_LAUNCH_CHECK("k_upsample_trilinear_bwd");
+  return COOCC_OK;
+}

@@ -196,6 +196,11 @@ int coocc_render_losses_bwd(const float* rgbs, const float* depths, const float*
                             int64_t npix, int D, const float* losses_out, const float* gl, float* drgbs,
                             float* ddepths, void* stream);
 
+/* coocc_upsample_add_trilinear backward w.r.t. the coarse volume (the fine gradient passes through):
+ * dcoarse (+)= adjoint-trilinear(dfine).  Upsampling factors up to 4 per axis. */
+int coocc_upsample_trilinear_bwd(const float* dfine, float* dcoarse, int B, int C, int Xc, int Yc, int Zc, int Xf,
+                                 int Yf, int Zf, int accumulate, void* stream);
+
 /* FPN3D top-down step (fpn3d.py:88-92): fine += trilinear(coarse -> fine size),
  * align_corners=False.  Rows NDHWC with C channels. */
 int coocc_upsample_add_trilinear(const float* coarse, float* fine, int B, int C, int Xc, int Yc,

@@ -260,3 +260,49 @@ def test_render_block_train_reaches_features_and_heads(dev):
     for p, r in zip(list(sig_head.parameters()) + list(rgb_head.parameters()), ref_grads):
         sc = max(float(r.abs().max()), 1e-12)
         assert_close(p.grad.cpu() / sc, r / sc, what="d head params")
+
+
+def test_decoder_trunk_backward_vs_oracle_autograd(dev):
+    """con_enc -> CustomResNet3D(18) -> FPN3D: every conv weight gradient and the input gradient of the
+    differentiable trunk vs torch autograd through the oracle's restatement (frozen BN statistics)."""
+    from oracle import ref_cpu
+    import co_occ_amd.synth as synth
+    C, planes, fpn_out, grid = 8, [16, 32, 64, 128], 32, (12, 10, 4)
+    bn = dict(type="BN3d")           # eps 1e-5, the value the oracle restates
+    fuser = pkg.BiFuser_N(C, C, knum=2).eval()
+    enc = pkg.CustomResNet3D(depth=18, block_inplanes=planes, n_input_channels=C, norm_cfg=bn).eval()
+    neck = pkg.FPN3D(in_channels=planes, out_channels=fpn_out, norm_cfg=bn).eval()
+    for i, m in enumerate((fuser, enc, neck)):
+        m.load_state_dict(synth.random_state_dict(m.state_dict(), seed=70 + i))
+    g = torch.Generator().manual_seed(77)
+    X, Y, Z = grid
+    x = torch.randn(1, X, Y, Z, 4 * C, generator=g)
+
+    # oracle with autograd: leaf copies of every tensor
+    def leaf(sd):
+        return {k: (v.clone().float().requires_grad_() if (v.is_floating_point() and "running_" not in k) else v.clone())
+                for k, v in sd.items()}
+    sd_f, sd_e, sd_n = leaf(fuser.state_dict()), leaf(enc.state_dict()), leaf(neck.state_dict())
+    xr = x.clone().requires_grad_()
+    outs_r = ref_cpu.fpn3d_forward(sd_n, ref_cpu.resnet3d_forward(sd_e, ref_cpu.con_enc(sd_f, xr)))
+    gouts = [torch.randn(o.shape, generator=g) for o in outs_r]
+    sum((o * go).sum() for o, go in zip(outs_r, gouts)).backward()
+
+    fuser, enc, neck = fuser.to(dev), enc.to(dev), neck.to(dev)
+    xd = x.reshape(-1, 4 * C).to(dev).requires_grad_()
+    outs = ag.trunk_forward_train(fuser.con_enc, enc, neck, xd, (1, X, Y, Z))
+    loss = 0
+    for (o, geo), o_r, go in zip(outs, outs_r, gouts):
+        assert tuple(geo[1:]) == tuple(o_r.shape[2:])
+        assert_close(_vol(o.detach().cpu(), *geo), o_r.detach(), what="trunk forward")
+        loss = loss + (o * _rows(go).to(dev)).sum()
+    loss.backward()
+    assert_close(xd.grad.cpu().view(1, X, Y, Z, 4 * C), xr.grad, what="d input")
+    n = 0
+    for mod, sd in ((fuser, sd_f), (enc, sd_e), (neck, sd_n)):
+        for name, p in mod.named_parameters():
+            if p.dim() == 5:                  # conv weights (BN affine parameters are frozen)
+                assert p.grad is not None, name
+                assert_close(p.grad.cpu(), sd[name].grad, what=name)
+                n += 1
+    assert n == 2 + 1 + 16 + 3 + 8           # con_enc, input_proj, 8 blocks x 2, 3 downsamples, FPN 4 + 4
