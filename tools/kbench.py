@@ -184,6 +184,37 @@ def bench_bwd():
         print("bwd %-13s %4d->%4d k%d s%d  fwd(+pack) %.3f ms | backward: %s" % (name, Cin, Cout, k, stride, t_f, "  ".join(parts)))
 
 
+def bench_trunk():
+    """Training step of the decoder trunk at the r50 workload: con_enc -> ResNet3D-18 -> FPN3D forward + backward
+    (frozen-statistics BN), per-kernel-family times from the C-ABI timer."""
+    from co_occ_amd import autograd as ag
+    from co_occ_amd import _lib
+    cfg = synth.model_cfg()
+    model = pkg.build_detector(cfg).to(dev).eval()
+    X, Y, Z = 100, 100, 8
+    C = model.occ_fuser.in_channels
+    x = torch.randn(X * Y * Z, 4 * C, device=dev).requires_grad_()
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        x.grad = None
+        outs = ag.trunk_forward_train(model.occ_fuser.con_enc, model.semantic_encoder, model.semantic_neck, x, (1, X, Y, Z))
+        loss = sum(o.square().mean() for o, _ in outs)
+        loss.backward()
+    t = timeit(step, n=3, warm=1)
+    _lib.TIMER.enabled = True
+    _lib.TIMER.reset()
+    step()
+    torch.cuda.synchronize()
+    rows = _lib.TIMER.summary()
+    _lib.TIMER.enabled = False
+    print("trunk train step (fwd+bwd, r50 100x100x8): %.1f ms" % t)
+    for k in ("conv_fwd", "conv_dgrad", "k_wgrad", "coocc_conv_epilogue_bwd", "coocc_upsample_trilinear_bwd", "coocc_upsample_add_trilinear"):
+        if k in rows:
+            r = rows[k]
+            print("   %-32s %3d launches %8.2f ms%s" % (k, r["launches"], r["ms"], "  %.0f TFLOP/s" % (r["work"] / r["ms"] / 1e9) if r["work"] else ""))
+
+
 def bench_eval():
     from co_occ_amd import evaluation as ev
     g = torch.Generator().manual_seed(5)
@@ -222,5 +253,5 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["fps", "knn", "conv"]
     with torch.no_grad():
         for w in which:
-            with torch.set_grad_enabled(w == "bwd"):
+            with torch.set_grad_enabled(w in ("bwd", "trunk")):
                 globals()["bench_" + w]()
