@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="r50", choices=sorted(synth.CONFIGS))
     ap.add_argument("--streams", type=int, default=1, help="samples in flight (software pipelining over HIP streams)")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="with --streams > 1: serialise the dense stages, overlap only the index search of the next sample")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs set aside for the FPS chains (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -144,10 +146,12 @@ def main():
         path has two small device->host reads per sample (voxel counts), so samples are kept in
         flight from independent host threads (torch drops the GIL while it waits)."""
         errs = []
+        gate = core.DenseGate() if args.pipeline else None
 
         def worker(si):
             try:
                 torch.cuda.set_device(dev)
+                core.set_dense_gate(gate)
                 with torch.cuda.stream(streams[si]), torch.no_grad():
                     for i in range(si, nsteps, len(streams)):
                         step(model, samples[i % len(samples)], world)

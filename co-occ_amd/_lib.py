@@ -21,7 +21,8 @@ class ConvDesc(ctypes.Structure):
                [("ws_floats", c_int64)] + \
                [(n, c_int) for n in ("M", "Cin", "Cout", "taps", "in_stride", "out_stride", "res_stride",
                                      "B", "Xi", "Yi", "Zi", "Xo", "Yo", "Zo", "ksize", "stride", "pad",
-                                     "relu", "res_mode", "splitk", "tile_hint")]
+                                     "relu", "res_mode", "splitk", "tile_hint", "kx", "ky", "kz", "px", "py", "pz",
+                                     "wgroup_rows")]
 
 
 P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_int64
@@ -80,6 +81,8 @@ SIGNATURES = {
     "coocc_upsample_maps_bwd": (I, [P, P, I, I, I, I, P, P]),
     "coocc_render_losses_bwd": (I, [P, P, P, P, L, I, P, P, P, P, P]),
     "coocc_upsample_trilinear_bwd": (I, [P, P, I, I, I, I, I, I, I, I, I, P]),
+    "coocc_wino_input": (I, [P, I, I, I, I, I, I, P, L, P]),
+    "coocc_wino_output": (I, [P, L, I, I, I, I, I, P, I, P, P, P, I, I, P]),
     "coocc_eval_semantic": (I, [P, L, L, L, L, I, I, I, I, P, P, I, I, I, I, I, P, P]),
 }
 

@@ -20,6 +20,11 @@ from ._lib import TIMER, KernelTimer  # noqa: E402,F401
 
 TILE_HINT = int(__import__("os").environ.get("COOCC_CONV_TILE", "0"))   # 0 auto | 128 | 160 (tuning knob)
 CONV_V2 = int(__import__("os").environ.get("COOCC_CONV_V2", "1"))       # mirrors csrc/conv3d.hip
+# Winograd F(2x2,3x3) over (x,y) for the 3x3x3 stride-1 convs (csrc/winograd.hip): 0 off | 1 on for layers
+# with at least WINO_MIN_ROWS output rows (the transforms cost two extra HBM passes; small layers are
+# weight-bandwidth-bound and gain nothing)
+WINO = int(__import__("os").environ.get("COOCC_WINO", "1"))
+WINO_MIN_ROWS = int(__import__("os").environ.get("COOCC_WINO_MIN_ROWS", "20000"))
 
 
 def conv_kernel_name(M, Cout, table):
@@ -127,6 +132,9 @@ class PackedConv:
             w = w.reshape(self.Cout, self.Cin, -1)
             assert w.shape[2] == taps, "weight does not have ksize^3 taps"
         self.taps, self.ksize, self.stride, self.pad = taps, ksize, stride, pad
+        # raw weights kept on the host for the lazily built Winograd packs
+        self._w_raw = w if (ksize == 3 and stride == 1 and pad == 1 and not tap_major and taps == 27) else None
+        self._wino = None
         lib = _lib.load()
         n = lib.coocc_conv_pack_weights(ctypes.c_void_p(w.data_ptr()), self.Cout, self.Cin, taps, int(tap_major), None)
         packed = torch.empty(n, dtype=_F32)
@@ -142,7 +150,81 @@ class PackedConv:
             self.bias = bias.detach().float().to(dev).contiguous() if bias is not None else None
 
 
+    def wino_pack(self):
+        """16 packs (one per transform point p = 4*xi + eta) of U[p][dz] = (G g G^T)[xi][eta][dz], taps = 3 (z)."""
+        if self._wino is None:
+            G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], dtype=torch.float64)
+            w = self._w_raw.double().view(self.Cout, self.Cin, 3, 3, 3)                 # [n, c, kx, ky, kz]
+            U = torch.einsum("pa,qb,ncabz->pqncz", G, G, w).reshape(16, self.Cout, self.Cin, 3).float().contiguous()
+            lib = _lib.load()
+            n = lib.coocc_conv_pack_weights(ctypes.c_void_p(U[0].data_ptr()), self.Cout, self.Cin, 3, 0, None)
+            packed = torch.empty(16, n, dtype=_F32)
+            for p in range(16):
+                lib.coocc_conv_pack_weights(ctypes.c_void_p(U[p].data_ptr()), self.Cout, self.Cin, 3, 0,
+                                            ctypes.c_void_p(packed[p].data_ptr()))
+            self._wino = packed.to(self.w.device)
+        return self._wino
+
+
 _ws_cache = {}
+_wino_ws = {}
+
+
+def _wino_buffer(device, kind, nfloats):
+    key = (device.index, kind, torch.cuda.current_stream(device).cuda_stream)
+    t = _wino_ws.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.zeros(nfloats, device=device, dtype=_F32)     # padded rows stay zero
+        _wino_ws[key] = t
+    return t
+
+
+def _lcm(a, b):
+    import math
+    return a * b // math.gcd(a, b)
+
+
+def wino_eligible(x, pc, M, res_mode):
+    if not WINO or pc._w_raw is None or M < WINO_MIN_ROWS or res_mode not in (0, 1):
+        return False
+    Tx, Ty = (x.X + 1) // 2, (x.Y + 1) // 2
+    rows = x.B * Tx * Ty * x.Z
+    g = _lcm(640, x.Z)
+    G = -(-rows // g) * g
+    return 16 * G * max(pc.Cin, pc.Cout) * 4 < 0xFFFFFF00 and pc.Cin % 4 == 0
+
+
+def conv_rows_wino(x, pc, out, relu, res):
+    """3x3x3 stride-1 conv as Winograd F(2x2,3x3) over (x,y) + direct z taps: input transform, one grouped
+    GEMM launch (16 transform points), output transform with the epilogue."""
+    dev = x.t.device
+    Tx, Ty = (x.X + 1) // 2, (x.Y + 1) // 2
+    rows = x.B * Tx * Ty * x.Z
+    g = _lcm(640, x.Z)
+    G = -(-rows // g) * g
+    V = _wino_buffer(dev, "V", 16 * G * pc.Cin)
+    Mb = _wino_buffer(dev, "M", 16 * G * pc.Cout)
+    wp = pc.wino_pack()
+    with TIMER.region("k_wino_in", 4.0 * x.V * pc.Cin + 64.0 * rows * pc.Cin):
+        call("coocc_wino_input", x.data(), x.stride, x.B, x.X, x.Y, x.Z, pc.Cin, ptr(V), G)
+    d = ConvDesc()
+    ws = workspace(dev)
+    d.in_, d.w, d.out = ptr(V), ptr(wp), ptr(Mb)
+    d.scale = d.bias = d.res = d.gather = d.out_rows = None
+    d.ws, d.ws_floats = ptr(ws), ws.numel()
+    d.M, d.Cin, d.Cout, d.taps = 16 * G, pc.Cin, pc.Cout, 3
+    d.in_stride, d.out_stride, d.res_stride = pc.Cin, pc.Cout, 0
+    d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = 16 * G // x.Z, 1, 1, x.Z, 1, 1, x.Z
+    d.ksize, d.stride, d.pad = 3, 1, 1
+    d.kx, d.ky, d.kz, d.px, d.py, d.pz = 1, 1, 3, 0, 0, 1
+    d.wgroup_rows = G
+    d.relu, d.res_mode, d.splitk, d.tile_hint = 0, 0, 1, TILE_HINT
+    with TIMER.region(conv_kernel_name(16 * G, pc.Cout, False) + " wino", 2.0 * 16 * rows * pc.Cin * pc.Cout * 3):
+        _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+    with TIMER.region("k_wino_out", 64.0 * rows * pc.Cout + 4.0 * x.V * pc.Cout):
+        call("coocc_wino_output", ptr(Mb), G, x.B, x.X, x.Y, x.Z, pc.Cout, out.data(), out.stride, ptr(pc.scale), ptr(pc.bias),
+             res.data() if res is not None else None, res.stride if res is not None else 0, int(relu))
+    return out
 
 
 def workspace(device, nfloats=64 << 20):
@@ -165,6 +247,9 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
     if out is None:
         out = Rows(torch.empty(M, pc.Cout, device=x.t.device, dtype=_F32), x.B, Xo, Yo, Zo, pc.Cout)
     assert x.C == pc.Cin, "channel mismatch: %d vs %d" % (x.C, pc.Cin)
+    rm = res_mode or (1 if res is not None else 0)
+    if wino_eligible(x, pc, M, rm):
+        return conv_rows_wino(x, pc, out, relu, res)
     ws = workspace(x.t.device)
     d = ConvDesc()
     d.in_, d.w, d.out = x.data(), ptr(pc.w), out.data()
@@ -238,6 +323,44 @@ def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_co
     d.tile_hint = TILE_HINT
     with TIMER.region(conv_kernel_name(M, pc.Cout, True), 2.0 * M * C * pc.Cout * K):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+
+
+class DenseGate:
+    """Cross-sample software pipeline for samples kept in flight on different HIP streams / host threads:
+    the index search of a sample (2 x 2047 dependent FPS steps on one CU each, ~3.8 ms with 254 CUs idle)
+    may overlap anything, but the dense stage (gather-GEMM onwards, every launch fills the chip) of two
+    samples must not interleave -- it only thrashes L2.  ``enter`` blocks the host until the previous
+    sample's dense stage is fully enqueued and makes the current stream wait for its completion event."""
+
+    def __init__(self):
+        import threading
+        self.lock = threading.Lock()
+        self.done = None
+
+    def enter(self):
+        self.lock.acquire()
+        if self.done is not None:
+            torch.cuda.current_stream().wait_event(self.done)
+
+    def exit(self):
+        if self.lock.locked():
+            ev = torch.cuda.Event()
+            ev.record()
+            self.done = ev
+            self.lock.release()
+
+
+import threading as _threading
+_tls = _threading.local()
+
+
+def set_dense_gate(gate):
+    """Per host thread: the gate consulted by BiFuser_N.fuse / COOCC_Ray.forward_hot_path (None = no pipelining)."""
+    _tls.gate = gate
+
+
+def dense_gate():
+    return getattr(_tls, "gate", None)
 
 
 class PackCache:

@@ -28,7 +28,10 @@ struct ConvK {
   const float* res; const int32_t* gather; const int32_t* out_rows; float* ws;
   int M, Cin, Cout, Npad, taps, kchunks;
   int in_stride, out_stride, res_stride;
-  int Xi, Yi, Zi, Xo, Yo, Zo, ksize, stride, pad;
+  int Xi, Yi, Zi, Xo, Yo, Zo, stride;
+  int kx, ky, kz, px, py, pz;   // per-axis kernel extent / padding (taps = kx*ky*kz, tap index t = (dx*ky + dy)*kz + dz)
+  int wgroup_rows;              // > 0: output rows [g*wgroup_rows, (g+1)*wgroup_rows) use weight pack g (Winograd points)
+  size_t wgroup_floats;         // floats per weight pack
   int relu, res_mode, iters_per_split, total_iters, splitk;
   int mtiles, ntiles, mtiles_per_xcd;
   int dephase;   // s_sleep units for the second workgroup of each CU (see k_conv)
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
   const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
   const int li = lane & 31, h = lane >> 5;
 
+  const float* wbase = p.wgroup_rows > 0 ? p.w + (size_t)(m0 / p.wgroup_rows) * p.wgroup_floats : p.w;
   // per-thread A rows
   int rbase[PA];  // GEOM: packed voxel origin; TABLE: m (or -1)
   int rix[PA], riy[PA], riz[PA];
@@ -101,9 +105,9 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
       int oy = r % p.Yo; r /= p.Yo;
       int ox = r % p.Xo; int b = r / p.Xo;
       rbase[a] = ok ? b : -1;
-      rix[a] = ox * p.stride - p.pad;
-      riy[a] = oy * p.stride - p.pad;
-      riz[a] = oz * p.stride - p.pad;
+      rix[a] = ox * p.stride - p.px;
+      riy[a] = oy * p.stride - p.py;
+      riz[a] = oz * p.stride - p.pz;
     }
   }
 
@@ -115,13 +119,13 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
     const int kc = it / p.taps, t = it - kc * p.taps;
 #pragma unroll
     for (int b = 0; b < PB; ++b)
-      rb[b] = *(const f32x4*)(p.w + wfrag_index((size_t)it, p.Npad >> 7, n0 + lrow + 32 * b, piece * 4));
+      rb[b] = *(const f32x4*)(wbase + wfrag_index((size_t)it, p.Npad >> 7, n0 + lrow + 32 * b, piece * 4));
     const int cc = kc * KC + piece * 4;
     const bool cok = cc < p.Cin;
     int kd = 0, kh = 0, kw = 0;
     if (!TABLE) {
-      kw = t % p.ksize; int r = t / p.ksize;
-      kh = r % p.ksize; kd = r / p.ksize;
+      kw = t % p.kz; int r = t / p.kz;
+      kh = r % p.ky; kd = r / p.ky;
     }
 #pragma unroll
     for (int a = 0; a < PA; ++a) {
@@ -271,7 +275,8 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
   const int li = lane & 31, h = lane >> 5;
 
   __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  const float* wbase = p.wgroup_rows > 0 ? p.w + (size_t)(m0 / p.wgroup_rows) * p.wgroup_floats : p.w;
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, p.w_bytes, 0x00020000);
 
   // per-thread A rows: voxel coordinates of tap (0,0,0) and its row index; rows past M are parked
   // outside the grid so every tap fails the bounds test
@@ -283,9 +288,9 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
     int oy = r % p.Yo; r /= p.Yo;
     int ox = r % p.Xo; int b = r / p.Xo;
     bool ok = m < p.M;
-    cx[a] = ok ? ox * p.stride - p.pad : -4096;
-    cy[a] = oy * p.stride - p.pad;
-    cz[a] = oz * p.stride - p.pad;
+    cx[a] = ok ? ox * p.stride - p.px : -4096;
+    cy[a] = oy * p.stride - p.py;
+    cz[a] = oz * p.stride - p.pz;
     rrow[a] = ((b * p.Xi + cx[a]) * p.Yi + cy[a]) * p.Zi + cz[a];
   }
   const unsigned voffB = (unsigned)(lane * 16);
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
   // uniform cursor (tap (kd,kh,kw), channel chunk kc, chunk index lc) of the chunk being LOADED
   int lc = it0, lkc = it0 / p.taps;
   const int lt0 = it0 - lkc * p.taps;
-  int lkw = lt0 % p.ksize, lkh = (lt0 / p.ksize) % p.ksize, lkd = lt0 / (p.ksize * p.ksize);
+  int lkw = lt0 % p.kz, lkh = (lt0 / p.kz) % p.ky, lkd = lt0 / (p.kz * p.ky);
   auto issue_loads = [&](bool live, int slot_) {
     const unsigned soff = (unsigned)(((((size_t)lc * ngroups + nt) * 4 + wn) * 1024) * 4);
 #pragma unroll
@@ -317,11 +322,11 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
     }
     // advance the cursor (scalar, branch-free so the loop body stays one basic block)
     lc += 1; lkw += 1;                         // taps innermost, then the next channel chunk
-    const int w2 = lkw == p.ksize;
+    const int w2 = lkw == p.kz;
     lkw = w2 ? 0 : lkw; lkh += w2;
-    const int w3 = lkh == p.ksize;
+    const int w3 = lkh == p.ky;
     lkh = w3 ? 0 : lkh; lkd += w3;
-    const int w4 = lkd == p.ksize;
+    const int w4 = lkd == p.kx;
     lkd = w4 ? 0 : lkd; lkc += w4;
   };
   auto lstore = [&](int buf) {
@@ -453,7 +458,8 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   COOCC_CHECK_ARG(((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->w & 15) == 0, "conv_fwd: in/w must be 16-byte aligned");
   COOCC_CHECK_ARG(d->res_mode == 0 || d->res, "conv_fwd: res_mode set without res");
   if (!d->gather) {
-    COOCC_CHECK_ARG(d->taps == d->ksize * d->ksize * d->ksize, "conv_fwd: taps != ksize^3");
+    if (d->kx > 0) COOCC_CHECK_ARG(d->ky > 0 && d->kz > 0 && d->taps == d->kx * d->ky * d->kz, "conv_fwd: taps != kx*ky*kz");
+    else COOCC_CHECK_ARG(d->taps == d->ksize * d->ksize * d->ksize, "conv_fwd: taps != ksize^3");
     COOCC_CHECK_ARG((long long)d->B * d->Xo * d->Yo * d->Zo == d->M, "conv_fwd: M != B*Xo*Yo*Zo");
   }
   ConvK k;
@@ -465,7 +471,11 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   k.Npad = (d->Cout + NPAD_TO - 1) / NPAD_TO * NPAD_TO;
   k.in_stride = d->in_stride; k.out_stride = d->out_stride; k.res_stride = d->res_stride;
   k.Xi = d->Xi; k.Yi = d->Yi; k.Zi = d->Zi; k.Xo = d->Xo; k.Yo = d->Yo; k.Zo = d->Zo;
-  k.ksize = d->ksize; k.stride = d->stride; k.pad = d->pad;
+  k.stride = d->stride;
+  if (d->kx > 0) { k.kx = d->kx; k.ky = d->ky; k.kz = d->kz; k.px = d->px; k.py = d->py; k.pz = d->pz; }
+  else { k.kx = k.ky = k.kz = d->ksize; k.px = k.py = k.pz = d->pad; }
+  k.wgroup_rows = d->wgroup_rows;
+  k.wgroup_floats = (size_t)k.taps * k.kchunks * k.Npad * KC;
   k.relu = d->relu; k.res_mode = d->res_mode;
   k.total_iters = k.taps * k.kchunks;
   { const char* e = getenv("COOCC_CONV_DEPHASE"); k.dephase = e ? atoi(e) : 0; }
@@ -490,6 +500,8 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   // below that the 64-row tile wastes fewer padded rows (M = 169 at the deepest stage)
   const bool v2small = d->M >= 512;
   const int BM = (cfg == 1 && !(v2small && !d->gather)) ? 64 : (cfg == 4 ? 160 : 128), BN = cfg == 3 ? 32 : (cfg == 2 ? 64 : 128);
+  COOCC_CHECK_ARG(d->wgroup_rows == 0 || (d->wgroup_rows % BM == 0 && !d->gather),
+                  "conv_fwd: wgroup_rows must be a multiple of the M tile (use a multiple of 640)");
   const long long blocks = (long long)((d->M + BM - 1) / BM) * ((d->Cout + BN - 1) / BN);
   int splitk = d->splitk;
   if (splitk <= 0) {

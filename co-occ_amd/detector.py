@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from . import registry
-from .core import to_rows
+from .core import dense_gate, to_rows
 from .registry import DETECTORS
 from .render import MLP, render_block, render_losses
 
@@ -61,6 +61,14 @@ class COOCC_Ray(nn.Module):
         img_voxel_feats / pts_voxel_feats: [1,C,X,Y,Z]; gemo: [1,N,D,fH,fW,3] (get_geometry);
         img_feats: [[1,N,512,fH,fW]]; transform: img_inputs[1:] (rots, trans, intrins, post_rots,
         post_trans, bda, ..., (H_img, W_img))."""
+        try:
+            return self._hot_path(img_voxel_feats, pts_voxel_feats, gemo, img_feats, transform, render, dense_fine)
+        finally:
+            gate = dense_gate()
+            if gate is not None:
+                gate.exit()        # entered by BiFuser_N.fuse when samples are pipelined across streams
+
+    def _hot_path(self, img_voxel_feats, pts_voxel_feats, gemo, img_feats, transform, render, dense_fine):
         voxel_feats = self.fuse(img_voxel_feats, pts_voxel_feats)
         mid = self.semantic_encoder.forward_rows(voxel_feats)
         sem = self.semantic_neck.forward_rows(mid)

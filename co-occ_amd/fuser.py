@@ -11,7 +11,7 @@ from torch import nn
 
 from . import _lib, streams
 from ._lib import call, ptr
-from .core import PackCache, PackedConv, Rows, conv_rows, gather_conv_rows
+from .core import PackCache, PackedConv, Rows, conv_rows, dense_gate, gather_conv_rows
 from .registry import FUSION_LAYERS
 
 _I32, _F32, _I64 = torch.int32, torch.float32, torch.int64
@@ -202,6 +202,9 @@ class BiFuser_N(nn.Module):
             rows = torch.empty(K, Np, device=dev, dtype=_I32)
             for k in range(K):
                 call("coocc_index_rows_i32", ptr(lin_img), Ni, ptr(near_img[k]), Np, ptr(rows[k]))
+            gate = dense_gate()
+            if gate is not None:
+                gate.enter()       # dense stage starts here; released by COOCC_Ray.forward_hot_path
             gather_conv_rows(cat4, 0, packs["knn"], rows, lin_pts, cat4, 2 * C, C, C)
             cur.wait_stream(side)
             for t in (near_pts, rows_p):

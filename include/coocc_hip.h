@@ -136,12 +136,27 @@ typedef struct coocc_conv_desc {
   int relu, res_mode;
   int splitk;             /* 0 = choose automatically */
   int tile_hint;          /* 0 = choose automatically; 128 / 160 force the M tile of the large configuration */
+  int kx, ky, kz;         /* kx > 0: per-axis kernel extents (taps = kx*ky*kz, tap t = (dx*ky + dy)*kz + dz) */
+  int px, py, pz;         /*         and paddings, overriding ksize / pad */
+  int wgroup_rows;        /* > 0: output rows [g*wgroup_rows, (g+1)*wgroup_rows) use the g-th weight pack of `w`
+                             (consecutive packs of taps*ceil(Cin/32)*roundup(Cout,128)*32 floats); must be a
+                             multiple of 640.  Used by the Winograd path: one launch, 16 transform points. */
 } coocc_conv_desc;
 
 /* nn.Conv3d(k=3|1)+BN(eval)+ReLU(+residual) (bifuser_n.py:23-30, resnet3d.py:34-64,
  * fpn3d.py:46-64, occ_head.py:102-132), nn.Linear (+ReLU) and the gather->knn_enc->gate
  * ->scatter of bifuser_n.py:138-169 as one fp32-MFMA implicit-GEMM kernel family. */
 int coocc_conv_fwd(const coocc_conv_desc* d, void* stream);
+
+/* Winograd F(2x2,3x3) over (x,y) for 3x3x3 stride-1 pad-1 convs (z stays a direct 3-tap conv): input transform,
+ * then ONE coocc_conv_fwd launch over 16 x group_rows rows (kx=ky=1, kz=3, pz=1, wgroup_rows=group_rows, weights =
+ * 16 packs of G g G^T), then output transform + epilogue.  V / Mb: [16][group_rows][C]; row = ((b*Tx+tx)*Ty+ty)*Z+z,
+ * Tx = ceil(X/2); group_rows a multiple of lcm(640, Z) >= B*Tx*Ty*Z.  2.25x fewer multiplies than the direct form. */
+int coocc_wino_input(const float* in, int in_stride, int B, int X, int Y, int Z, int C, float* V,
+                     int64_t group_rows, void* stream);
+int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, float* out,
+                      int out_stride, const float* scale, const float* bias, const float* res, int res_stride,
+                      int relu, void* stream);
 
 /* ---------------------------------------------------------------- backward of the conv family
  * Frozen-statistics BN (scale/shift constants), as the forward.  torch.autograd computes these through

@@ -171,3 +171,70 @@ def test_conv_linearity_at_full_grid(dev):
     resp = core.conv_rows(core.to_rows(ones), core.PackedConv(w1, ksize=3, pad=1), relu=False).as_ncdhw()
     taps = (100 * 3 - 2) * (100 * 3 - 2) * (8 * 3 - 2)          # sum over voxels of valid taps = prod (3n-2)
     assert float(resp[0, 0].double().sum().item()) == pytest.approx(4.0 * taps, rel=1e-6)
+
+
+WINO_CASES = [
+    # Cin, Cout, grid, B, relu, residual
+    (16, 32, (9, 7, 4), 2, True, False),       # odd X, Y (partial tiles), two batches
+    (64, 128, (12, 10, 4), 1, True, True),     # residual + ReLU in the output transform
+    (36, 40, (6, 5, 3), 1, False, False),      # Cin not a multiple of 32, Z = 3 (group rows = lcm(640, 3))
+    (128, 17, (8, 8, 2), 1, False, False),     # Cout % 4 != 0
+    (128, 128, (40, 40, 8), 1, True, False),   # 160-row tiles, M = 16 * 3200
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,grid,B,relu,use_res", WINO_CASES)
+def test_conv3d_winograd_path(dev, monkeypatch, Cin, Cout, grid, B, relu, use_res):
+    """The Winograd F(2x2,3x3) + direct-z path (csrc/winograd.hip) against torch's direct fp32 conv, and against
+    our own direct path (both inside the 1e-4 bound)."""
+    g = torch.Generator().manual_seed(Cin * 77 + Cout)
+    X, Y, Z = grid
+    x = torch.randn(B, Cin, X, Y, Z, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (2.0 / (Cin * 27)) ** 0.5
+    bn = bn_like(Cout, g)
+    ref = bn(F.conv3d(x, w, padding=1))
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=3, stride=1, pad=1)
+    rr = rows_of(res, dev) if use_res else None
+    monkeypatch.setattr(core, "WINO", 1)
+    monkeypatch.setattr(core, "WINO_MIN_ROWS", 0)
+    assert core.wino_eligible(rows_of(x, dev), pc, B * X * Y * Z, 1 if use_res else 0)
+    out = core.conv_rows(rows_of(x, dev), pc, relu=relu, res=rr)
+    assert_close(out.as_ncdhw().cpu(), ref.detach(), what="winograd conv")
+    monkeypatch.setattr(core, "WINO", 0)
+    direct = core.conv_rows(rows_of(x, dev), pc, relu=relu, res=rr)
+    assert_close(out.as_ncdhw().cpu(), direct.as_ncdhw().cpu(), what="winograd vs direct")
+
+
+def test_conv_anisotropic_taps_and_weight_groups(dev):
+    """coocc_conv_desc kx/ky/kz + wgroup_rows: a (1,1,3) conv along z with a different weight set per row group."""
+    import ctypes
+    from co_occ_amd import _lib
+    g = torch.Generator().manual_seed(4)
+    groups, cols, Z, Cin, Cout = 3, 80, 8, 32, 48          # 640 rows per group
+    x = torch.randn(groups, cols, Z, Cin, generator=g)
+    w = torch.randn(groups, Cout, Cin, 3, generator=g) / (3 * Cin) ** 0.5
+    ref = torch.stack([F.conv1d(x[i].permute(0, 2, 1), w[i], padding=1).permute(0, 2, 1) for i in range(groups)])
+    lib = _lib.load()
+    n = lib.coocc_conv_pack_weights(ctypes.c_void_p(w[0].contiguous().data_ptr()), Cout, Cin, 3, 0, None)
+    packed = torch.empty(groups, n)
+    for i in range(groups):
+        wi = w[i].contiguous()
+        lib.coocc_conv_pack_weights(ctypes.c_void_p(wi.data_ptr()), Cout, Cin, 3, 0, ctypes.c_void_p(packed[i].data_ptr()))
+    xd, pd = x.reshape(-1, Cin).contiguous().to(dev), packed.to(dev)
+    out = torch.empty(groups * cols * Z, Cout, device=dev)
+    d = _lib.ConvDesc()
+    d.in_, d.w, d.out = ptr(xd), ptr(pd), ptr(out)
+    d.M, d.Cin, d.Cout, d.taps = out.shape[0], Cin, Cout, 3
+    d.in_stride, d.out_stride = Cin, Cout
+    d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = groups * cols, 1, 1, Z, 1, 1, Z
+    d.ksize, d.stride, d.pad = 3, 1, 1
+    d.kx, d.ky, d.kz, d.px, d.py, d.pz = 1, 1, 3, 0, 0, 1
+    d.wgroup_rows = cols * Z
+    d.splitk = 1
+    _lib.check(lib.coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+    assert_close(out.cpu().view(groups, cols, Z, Cout), ref, what="grouped z-conv")
