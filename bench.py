@@ -206,17 +206,24 @@ def main():
         dom = max(convs, key=lambda k: convs[k]["ms"]) if convs else None
         if dom:
             v = ksum[dom]
-            ach = v["work"] / (v["ms"] * 1e-3) / 1e12
+            ach = v["work"] / (v["ms"] * 1e-3) / 1e12      # flops the matrix cores execute (Winograd-domain for "wino")
             traffic = None
             try:   # HBM bytes per launch from the committed PMC passes (cannot be collected inside this process)
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
                 traffic = tj[dom]["bytes_per_launch"] if args.config == "r50" else None
             except Exception:
                 pass
+            # direct-convolution-equivalent rate of the same launches: F(m x m,3x3) needs 9 m^2/(m+2)^2 x fewer multiplies
+            equiv = {"wino2": 2.25, "wino4": 4.0}.get(dom.split()[-1], 1.0)
             roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=traffic, launches=v["launches"],
                         avg_launch_ms=round(v["ms"] / v["launches"], 4),
-                        share_of_timed_kernels=round(v["ms"] / tot, 3))
+                        share_of_timed_kernels=round(v["ms"] / tot, 3),
+                        flops="executed on the MFMA pipe (direct-conv-equivalent x%.2f = %.1f TFLOP/s)" % (equiv, ach * equiv))
+            allc = sum(v2["work"] for v2 in convs.values()) / (sum(v2["ms"] for v2 in convs.values()) * 1e-3) / 1e12
+            extra["roofline_all_convs"] = dict(bound="mfma", kernel="every k_conv* launch", achieved=round(allc, 2),
+                                               peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(allc / MFMA_F32_PEAK_TFLOPS, 4),
+                                               ms_per_step=round(sum(v2["ms"] for v2 in convs.values()) / args.steps, 3))
         rk = [ksum[k] for k in ("k_render_nearest", "k_upsample_maps") if k in ksum]
         if rk:
             ms = sum(v["ms"] for v in rk)

@@ -20,11 +20,12 @@ from ._lib import TIMER, KernelTimer  # noqa: E402,F401
 
 TILE_HINT = int(__import__("os").environ.get("COOCC_CONV_TILE", "0"))   # 0 auto | 128 | 160 (tuning knob)
 CONV_V2 = int(__import__("os").environ.get("COOCC_CONV_V2", "1"))       # mirrors csrc/conv3d.hip
-# Winograd F(2x2,3x3) over (x,y) for the 3x3x3 stride-1 convs (csrc/winograd.hip): 0 off | 1 on for layers
-# with at least WINO_MIN_ROWS output rows (the transforms cost two extra HBM passes; small layers are
-# weight-bandwidth-bound and gain nothing)
+# Winograd F(m x m,3x3) over (x,y) for the 3x3x3 stride-1 convs (csrc/winograd.hip): 0 off | 1 on for layers
+# with at least WINO_MIN_ROWS output rows (the transforms cost two extra HBM passes and (m+2)^2/9 x the
+# weight bytes; the small deep layers are weight-bandwidth-bound and gain nothing)
 WINO = int(__import__("os").environ.get("COOCC_WINO", "1"))
-WINO_MIN_ROWS = int(__import__("os").environ.get("COOCC_WINO_MIN_ROWS", "20000"))
+WINO_MIN_ROWS = int(__import__("os").environ.get("COOCC_WINO_MIN_ROWS", "8192"))
+WINO_TILE = int(__import__("os").environ.get("COOCC_WINO_TILE", "4"))   # F(4x4,3x3) where X, Y >= 8, else F(2x2,3x3)
 
 
 def conv_kernel_name(M, Cout, table):
@@ -134,7 +135,8 @@ class PackedConv:
         self.taps, self.ksize, self.stride, self.pad = taps, ksize, stride, pad
         # raw weights kept on the host for the lazily built Winograd packs
         self._w_raw = w if (ksize == 3 and stride == 1 and pad == 1 and not tap_major and taps == 27) else None
-        self._wino = None
+        self._wino = {}
+        self.wino_tile = None        # per-layer override of WINO_TILE (2 | 4)
         lib = _lib.load()
         n = lib.coocc_conv_pack_weights(ctypes.c_void_p(w.data_ptr()), self.Cout, self.Cin, taps, int(tap_major), None)
         packed = torch.empty(n, dtype=_F32)
@@ -150,20 +152,27 @@ class PackedConv:
             self.bias = bias.detach().float().to(dev).contiguous() if bias is not None else None
 
 
-    def wino_pack(self):
-        """16 packs (one per transform point p = 4*xi + eta) of U[p][dz] = (G g G^T)[xi][eta][dz], taps = 3 (z)."""
-        if self._wino is None:
-            G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], dtype=torch.float64)
+    def wino_pack(self, tile):
+        """(tile+2)^2 packs (one per transform point p = (tile+2)*xi + eta) of U[p][dz] = (G g G^T)[xi][eta][dz],
+        taps = 3 (z).  G: F(2,3) / F(4,3) Toom-Cook matrices, products in fp64."""
+        if tile not in self._wino:
+            if tile == 2:
+                G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], dtype=torch.float64)
+            else:
+                # Toom-Cook points (0, 1, -1, 1/2, -2, inf), matching Wino<6> in csrc/winograd.hip
+                G = torch.tensor([[1, 0, 0], [1 / 3, 1 / 3, 1 / 3], [-1 / 3, 1 / 3, -1 / 3], [-16 / 15, -8 / 15, -4 / 15],
+                                  [1 / 15, -2 / 15, 4 / 15], [0, 0, 1]], dtype=torch.float64)
+            n2 = G.shape[0] ** 2
             w = self._w_raw.double().view(self.Cout, self.Cin, 3, 3, 3)                 # [n, c, kx, ky, kz]
-            U = torch.einsum("pa,qb,ncabz->pqncz", G, G, w).reshape(16, self.Cout, self.Cin, 3).float().contiguous()
+            U = torch.einsum("pa,qb,ncabz->pqncz", G, G, w).reshape(n2, self.Cout, self.Cin, 3).float().contiguous()
             lib = _lib.load()
             n = lib.coocc_conv_pack_weights(ctypes.c_void_p(U[0].data_ptr()), self.Cout, self.Cin, 3, 0, None)
-            packed = torch.empty(16, n, dtype=_F32)
-            for p in range(16):
+            packed = torch.empty(n2, n, dtype=_F32)
+            for p in range(n2):
                 lib.coocc_conv_pack_weights(ctypes.c_void_p(U[p].data_ptr()), self.Cout, self.Cin, 3, 0,
                                             ctypes.c_void_p(packed[p].data_ptr()))
-            self._wino = packed.to(self.w.device)
-        return self._wino
+            self._wino[tile] = packed.to(self.w.device)
+        return self._wino[tile]
 
 
 _ws_cache = {}
@@ -184,46 +193,52 @@ def _lcm(a, b):
     return a * b // math.gcd(a, b)
 
 
+def wino_plan(x, pc, M, res_mode):
+    """None, or (tile, points, Tx, Ty, rows, G) for the Winograd path of this layer."""
+    if not WINO or pc._w_raw is None or M < WINO_MIN_ROWS or res_mode not in (0, 1) or pc.Cin % 4:
+        return None
+    tile = 4 if ((pc.wino_tile or WINO_TILE) == 4 and min(x.X, x.Y) >= 8) else 2
+    Tx, Ty = -(-x.X // tile), -(-x.Y // tile)
+    rows = x.B * Tx * Ty * x.Z
+    g = _lcm(640, x.Z)
+    G = -(-rows // g) * g
+    pts = (tile + 2) ** 2
+    if pts * G * max(pc.Cin, pc.Cout) * 4 >= 0xFFFFFF00:
+        return None     # the pipelined GEMM addresses its operands with 32-bit buffer offsets
+    return tile, pts, Tx, Ty, rows, G
+
+
 def wino_eligible(x, pc, M, res_mode):
-    if not WINO or pc._w_raw is None or M < WINO_MIN_ROWS or res_mode not in (0, 1):
-        return False
-    Tx, Ty = (x.X + 1) // 2, (x.Y + 1) // 2
-    rows = x.B * Tx * Ty * x.Z
-    g = _lcm(640, x.Z)
-    G = -(-rows // g) * g
-    return 16 * G * max(pc.Cin, pc.Cout) * 4 < 0xFFFFFF00 and pc.Cin % 4 == 0
+    return wino_plan(x, pc, M, res_mode) is not None
 
 
-def conv_rows_wino(x, pc, out, relu, res):
-    """3x3x3 stride-1 conv as Winograd F(2x2,3x3) over (x,y) + direct z taps: input transform, one grouped
-    GEMM launch (16 transform points), output transform with the epilogue."""
+def conv_rows_wino(x, pc, out, relu, res, plan):
+    """3x3x3 stride-1 conv as Winograd F(m x m,3x3) over (x,y) + direct z taps: input transform, one grouped
+    GEMM launch (one weight pack per transform point), output transform with the epilogue."""
     dev = x.t.device
-    Tx, Ty = (x.X + 1) // 2, (x.Y + 1) // 2
-    rows = x.B * Tx * Ty * x.Z
-    g = _lcm(640, x.Z)
-    G = -(-rows // g) * g
-    V = _wino_buffer(dev, "V", 16 * G * pc.Cin)
-    Mb = _wino_buffer(dev, "M", 16 * G * pc.Cout)
-    wp = pc.wino_pack()
-    with TIMER.region("k_wino_in", 4.0 * x.V * pc.Cin + 64.0 * rows * pc.Cin):
-        call("coocc_wino_input", x.data(), x.stride, x.B, x.X, x.Y, x.Z, pc.Cin, ptr(V), G)
+    tile, pts, Tx, Ty, rows, G = plan
+    V = _wino_buffer(dev, "V", pts * G * pc.Cin)
+    Mb = _wino_buffer(dev, "M", pts * G * pc.Cout)
+    wp = pc.wino_pack(tile)
+    with TIMER.region("k_wino_in", 4.0 * x.V * pc.Cin + 4.0 * pts * rows * pc.Cin):
+        call("coocc_wino_input", x.data(), x.stride, x.B, x.X, x.Y, x.Z, pc.Cin, tile, ptr(V), G)
     d = ConvDesc()
     ws = workspace(dev)
     d.in_, d.w, d.out = ptr(V), ptr(wp), ptr(Mb)
     d.scale = d.bias = d.res = d.gather = d.out_rows = None
     d.ws, d.ws_floats = ptr(ws), ws.numel()
-    d.M, d.Cin, d.Cout, d.taps = 16 * G, pc.Cin, pc.Cout, 3
+    d.M, d.Cin, d.Cout, d.taps = pts * G, pc.Cin, pc.Cout, 3
     d.in_stride, d.out_stride, d.res_stride = pc.Cin, pc.Cout, 0
-    d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = 16 * G // x.Z, 1, 1, x.Z, 1, 1, x.Z
+    d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = pts * G // x.Z, 1, 1, x.Z, 1, 1, x.Z
     d.ksize, d.stride, d.pad = 3, 1, 1
     d.kx, d.ky, d.kz, d.px, d.py, d.pz = 1, 1, 3, 0, 0, 1
     d.wgroup_rows = G
     d.relu, d.res_mode, d.splitk, d.tile_hint = 0, 0, 1, TILE_HINT
-    with TIMER.region(conv_kernel_name(16 * G, pc.Cout, False) + " wino", 2.0 * 16 * rows * pc.Cin * pc.Cout * 3):
+    with TIMER.region(conv_kernel_name(pts * G, pc.Cout, False) + " wino%d" % tile, 2.0 * pts * rows * pc.Cin * pc.Cout * 3):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
-    with TIMER.region("k_wino_out", 64.0 * rows * pc.Cout + 4.0 * x.V * pc.Cout):
-        call("coocc_wino_output", ptr(Mb), G, x.B, x.X, x.Y, x.Z, pc.Cout, out.data(), out.stride, ptr(pc.scale), ptr(pc.bias),
-             res.data() if res is not None else None, res.stride if res is not None else 0, int(relu))
+    with TIMER.region("k_wino_out", 4.0 * pts * rows * pc.Cout + 4.0 * x.V * pc.Cout):
+        call("coocc_wino_output", ptr(Mb), G, x.B, x.X, x.Y, x.Z, pc.Cout, tile, out.data(), out.stride, ptr(pc.scale),
+             ptr(pc.bias), res.data() if res is not None else None, res.stride if res is not None else 0, int(relu))
     return out
 
 
@@ -248,8 +263,9 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
         out = Rows(torch.empty(M, pc.Cout, device=x.t.device, dtype=_F32), x.B, Xo, Yo, Zo, pc.Cout)
     assert x.C == pc.Cin, "channel mismatch: %d vs %d" % (x.C, pc.Cin)
     rm = res_mode or (1 if res is not None else 0)
-    if wino_eligible(x, pc, M, rm):
-        return conv_rows_wino(x, pc, out, relu, res)
+    plan = wino_plan(x, pc, M, rm)
+    if plan is not None:
+        return conv_rows_wino(x, pc, out, relu, res, plan)
     ws = workspace(x.t.device)
     d = ConvDesc()
     d.in_, d.w, d.out = x.data(), ptr(pc.w), out.data()

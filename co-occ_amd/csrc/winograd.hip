@@ -1,22 +1,55 @@
-// Winograd F(2x2, 3x3) over the (x, y) axes of the 3x3x3 stride-1 convolutions; the z axis stays a direct
-// 3-tap convolution.  Multiplies per output drop from 27*Cin to (16/4)*3*Cin = 12*Cin (2.25x).
+// Winograd F(m x m, 3x3), m = 2 or 4, over the (x, y) axes of the 3x3x3 stride-1 convolutions; the z axis
+// stays a direct 3-tap convolution.  Multiplies per output: 27*Cin direct, 12*Cin (m = 2), 6.75*Cin (m = 4).
 //
-//   V[p]   = B^T d B        input transform  (this file)     d: 4x4 (x,y) patch at (2tx-1, 2ty-1), fixed z
-//   M[p]   = sum_{dz,ci} V[p][.., z+dz-1, ci] U[p][dz][ci][co]   ONE coocc_conv_fwd launch: rows = 16 x (tiles*Z),
-//                                                                 kx=ky=1, kz=3, weight pack selected per
-//                                                                 transform point (wgroup_rows)
+//   V[p]   = B^T d B        input transform  (this file)     d: (m+2)^2 (x,y) patch at (m*tx-1, m*ty-1), fixed z
+//   M[p]   = sum_{dz,ci} V[p][.., z+dz-1, ci] U[p][dz][ci][co]   ONE coocc_conv_fwd launch: rows = (m+2)^2 x
+//                                                                 (tiles*Z), kx=ky=1, kz=3, weight pack selected
+//                                                                 per transform point (wgroup_rows)
 //   Y      = A^T M A        output transform + the conv epilogue (scale, bias, residual, ReLU)  (this file)
 //
-// with U[p] = G g G^T computed once per weight version on the host in fp64.  The transforms are exact
-// in fp32 up to rounding (entries of B, A are 0/+-1); measured end-to-end error stays inside the 1e-4
-// scale-relative parity bound (tests/test_gpu_conv.py).
-// Layout: V / M are [16][Gpad][C] with row = ((b*Tx + tx)*Ty + ty)*Z + z and Gpad = roundup(rows, lcm(640, Z)).
+// with U[p] = G g G^T computed once per weight version on the host in fp64 (Toom-Cook matrices; see Wino<6>).
+// fp32 error of F(4x4,3x3) at K = 3*512: ~4e-6 of the output scale, inside the 1e-4 parity bound
+// (tests/test_gpu_conv.py checks both tile sizes against torch's direct conv).
+// Layout: V / M are [(m+2)^2][Gpad][C], p = a*(m+2) + e (a along x), row = ((b*Tx + tx)*Ty + ty)*Z + z,
+// Tx = ceil(X/m), Gpad = roundup(rows, lcm(640, Z)).
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+template <int N> struct Wino;
+template <> struct Wino<4> {   // F(2,3)
+  static constexpr int M = 2;
+  template <typename T> static __device__ __forceinline__ void bt(const T* d, T* t) {
+    t[0] = d[0] - d[2]; t[1] = d[1] + d[2]; t[2] = d[2] - d[1]; t[3] = d[1] - d[3];
+  }
+  template <typename T> static __device__ __forceinline__ void at(const T* m, T* y) {
+    y[0] = m[0] + m[1] + m[2]; y[1] = m[1] - m[2] - m[3];
+  }
+};
+template <> struct Wino<6> {   // F(4,3) on the points (0, 1, -1, 1/2, -2, inf): ~2.2x lower fp32 error than the
+  static constexpr int M = 4;  // textbook (0, +-1, +-2, inf) set (measured; cf. Barabasz et al., "Error analysis and
+                               // improving the accuracy of Winograd convolution")
+  template <typename T> static __device__ __forceinline__ void bt(const T* d, T* t) {
+    t[0] = d[0] - 1.5f * d[1] - 2.f * d[2] + 1.5f * d[3] + d[4];
+    t[1] = -d[1] + 0.5f * d[2] + 2.5f * d[3] + d[4];
+    t[2] = d[1] - 2.5f * d[2] + 0.5f * d[3] + d[4];
+    t[3] = 2.f * (d[3] - d[1]) - d[2] + d[4];
+    t[4] = 0.5f * (d[1] - d[3]) - d[2] + d[4];
+    t[5] = d[1] - 1.5f * d[2] - 2.f * d[3] + 1.5f * d[4] + d[5];
+  }
+  template <typename T> static __device__ __forceinline__ void at(const T* m, T* y) {
+    const T s12 = m[1] + m[2], d12 = m[1] - m[2];
+    y[0] = m[0] + s12 + m[3] + m[4];
+    y[1] = d12 + 0.5f * m[3] - 2.f * m[4];
+    y[2] = s12 + 0.25f * m[3] + 4.f * m[4];
+    y[3] = d12 + 0.125f * m[3] - 8.f * m[4] + m[5];
+  }
+};
+
+template <int N>
 __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ in, int in_stride, int B, int X, int Y, int Z,
                                                   int C, int Tx, int Ty, size_t gstride, float* __restrict__ V) {
+  constexpr int MO = Wino<N>::M;
   const int c4 = C >> 2;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long rows = (long long)B * Tx * Ty * Z;
@@ -27,51 +60,57 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ in, i
   const int z = (int)(r % Z); r /= Z;
   const int ty = (int)(r % Ty); r /= Ty;
   const int tx = (int)(r % Tx); const int b = (int)(r / Tx);
-  f32x4 d[4][4];
+  f32x4 t[N][N];   // t[a][e]: x-transformed, column e of the patch
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int e = 0; e < N; ++e) {
+    f32x4 d[N], q[N];
+    const int y = MO * ty - 1 + e;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int x = 2 * tx - 1 + a, y = 2 * ty - 1 + e;
+    for (int a = 0; a < N; ++a) {
+      const int x = MO * tx - 1 + a;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if ((unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y)
         v = *(const f32x4*)(in + ((((size_t)b * X + x) * Y + y) * Z + z) * in_stride + c);
-      d[a][e] = v;
+      d[a] = v;
     }
-  f32x4 t[4][4];
+    Wino<N>::bt(d, q);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    t[0][e] = d[0][e] - d[2][e];
-    t[1][e] = d[1][e] + d[2][e];
-    t[2][e] = d[2][e] - d[1][e];
-    t[3][e] = d[1][e] - d[3][e];
+    for (int a = 0; a < N; ++a) t[a][e] = q[a];
   }
   float* o = V + (size_t)row * C + c;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    *(f32x4*)(o + (size_t)(a * 4 + 0) * gstride) = t[a][0] - t[a][2];
-    *(f32x4*)(o + (size_t)(a * 4 + 1) * gstride) = t[a][1] + t[a][2];
-    *(f32x4*)(o + (size_t)(a * 4 + 2) * gstride) = t[a][2] - t[a][1];
-    *(f32x4*)(o + (size_t)(a * 4 + 3) * gstride) = t[a][1] - t[a][3];
+  for (int a = 0; a < N; ++a) {
+    f32x4 q[N];
+    Wino<N>::bt(t[a], q);
+#pragma unroll
+    for (int e = 0; e < N; ++e) *(f32x4*)(o + (size_t)(a * N + e) * gstride) = q[e];
   }
 }
 
-extern "C" int coocc_wino_input(const float* in, int in_stride, int B, int X, int Y, int Z, int C, float* V,
+extern "C" int coocc_wino_input(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, float* V,
                                 int64_t group_rows, void* stream) {
   COOCC_CHECK_ARG(in && V && B > 0 && X > 0 && Y > 0 && Z > 0 && C > 0 && C % 4 == 0 && in_stride % 4 == 0, "wino_input: bad args");
-  const int Tx = (X + 1) / 2, Ty = (Y + 1) / 2;
+  COOCC_CHECK_ARG(tile == 2 || tile == 4, "wino_input: tile must be 2 or 4");
+  const int Tx = (X + tile - 1) / tile, Ty = (Y + tile - 1) / tile;
   const long long rows = (long long)B * Tx * Ty * Z;
-  COOCC_CHECK_ARG(group_rows >= rows, "wino_input: group_rows smaller than B*ceil(X/2)*ceil(Y/2)*Z");
-  hipLaunchKernelGGL(k_wino_in, dim3(cdiv(rows * (C / 4), 256)), dim3(256), 0, as_stream(stream), in, in_stride, B, X, Y, Z, C,
-                     Tx, Ty, (size_t)group_rows * C, V);
+  COOCC_CHECK_ARG(group_rows >= rows, "wino_input: group_rows smaller than B*ceil(X/tile)*ceil(Y/tile)*Z");
+  const dim3 grid(cdiv(rows * (C / 4), 256));
+  if (tile == 2)
+    hipLaunchKernelGGL(k_wino_in<4>, grid, dim3(256), 0, as_stream(stream), in, in_stride, B, X, Y, Z, C, Tx, Ty,
+                       (size_t)group_rows * C, V);
+  else
+    hipLaunchKernelGGL(k_wino_in<6>, grid, dim3(256), 0, as_stream(stream), in, in_stride, B, X, Y, Z, C, Tx, Ty,
+                       (size_t)group_rows * C, V);
   COOCC_LAUNCH_CHECK("k_wino_in");
   return COOCC_OK;
 }
 
+template <int N>
 __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ Mb, size_t gstride, int B, int X, int Y, int Z,
                                                    int C, int Tx, int Ty, float* __restrict__ out, int out_stride,
                                                    const float* __restrict__ scale, const float* __restrict__ bias,
                                                    const float* __restrict__ res, int res_stride, int relu) {
+  constexpr int MO = Wino<N>::M;
   const int c4 = (C + 3) >> 2;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long rows = (long long)B * Tx * Ty * Z;
@@ -83,55 +122,75 @@ __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ Mb, 
   const int ty = (int)(r % Ty); r /= Ty;
   const int tx = (int)(r % Tx); const int b = (int)(r / Tx);
   const int nc = min(4, C - c);
-  float m[16][4];
+  const bool vec = (C & 3) == 0;
   const float* src = Mb + (size_t)row * C + c;
+  f32x4 s[MO][N];   // s[a][e]: x-reduced (A^T M), column e
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    if (nc == 4 && (C & 3) == 0) {
-      const f32x4 v = *(const f32x4*)(src + (size_t)p * gstride);
-      m[p][0] = v[0]; m[p][1] = v[1]; m[p][2] = v[2]; m[p][3] = v[3];
-    } else {
+  for (int e = 0; e < N; ++e) {
+    f32x4 m[N], q[MO];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) m[p][e] = e < nc ? src[(size_t)p * gstride + e] : 0.f;
+    for (int a = 0; a < N; ++a) {
+      const float* p = src + (size_t)(a * N + e) * gstride;
+      if (vec) m[a] = *(const f32x4*)p;
+      else m[a] = f32x4{p[0], nc > 1 ? p[1] : 0.f, nc > 2 ? p[2] : 0.f, nc > 3 ? p[3] : 0.f};
     }
+    Wino<N>::at(m, q);
+#pragma unroll
+    for (int a = 0; a < MO; ++a) s[a][e] = q[a];
   }
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    if (e >= nc) break;
-    float s0[4], s1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s0[j] = m[0 * 4 + j][e] + m[1 * 4 + j][e] + m[2 * 4 + j][e];
-      s1[j] = m[1 * 4 + j][e] - m[2 * 4 + j][e] - m[3 * 4 + j][e];
+  for (int e = 0; e < 4; ++e)
+    if (e < nc) {
+      if (scale) sc[e] = scale[c + e];
+      if (bias) bi[e] = bias[c + e];
     }
-    const float y[2][2] = {{s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3]}, {s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]}};
-    const int n = c + e;
-    const float sc = scale ? scale[n] : 1.f, bi = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MO; ++a) {
+    f32x4 y[MO];
+    Wino<N>::at(s[a], y);
+    const int x = MO * tx + a;
+    if (x >= X) continue;
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        const int x = 2 * tx + a, yy = 2 * ty + bb;
-        if (x < X && yy < Y) {
-          const size_t orow = (((size_t)b * X + x) * Y + yy) * Z + z;
-          float v = y[a][bb] * sc + bi;
-          if (res) v += res[orow * res_stride + n];
-          if (relu) v = fmaxf(v, 0.f);
-          out[orow * out_stride + n] = v;
-        }
+    for (int bb = 0; bb < MO; ++bb) {
+      const int yy = MO * ty + bb;
+      if (yy >= Y) continue;
+      const size_t orow = (((size_t)b * X + x) * Y + yy) * Z + z;
+      f32x4 v = y[bb] * sc + bi;
+      float* o = out + orow * out_stride + c;
+      const float* rr = res ? res + orow * res_stride + c : nullptr;
+      if (vec && (out_stride & 3) == 0 && (!res || (res_stride & 3) == 0)) {
+        if (rr) v = v + *(const f32x4*)rr;
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *(f32x4*)o = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nc) {
+            float u = v[e] + (rr ? rr[e] : 0.f);
+            o[e] = relu ? fmaxf(u, 0.f) : u;
+          }
       }
+    }
   }
 }
 
-extern "C" int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, float* out,
+extern "C" int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, int tile, float* out,
                                  int out_stride, const float* scale, const float* bias, const float* res, int res_stride,
                                  int relu, void* stream) {
   COOCC_CHECK_ARG(Mb && out && B > 0 && X > 0 && Y > 0 && Z > 0 && C > 0, "wino_output: bad args");
-  const int Tx = (X + 1) / 2, Ty = (Y + 1) / 2;
+  COOCC_CHECK_ARG(tile == 2 || tile == 4, "wino_output: tile must be 2 or 4");
+  COOCC_CHECK_ARG(((uintptr_t)out & 15) == 0 && (!res || ((uintptr_t)res & 15) == 0), "wino_output: out/res must be 16-byte aligned");
+  const int Tx = (X + tile - 1) / tile, Ty = (Y + tile - 1) / tile;
   const long long rows = (long long)B * Tx * Ty * Z;
   COOCC_CHECK_ARG(group_rows >= rows, "wino_output: group_rows too small");
-  hipLaunchKernelGGL(k_wino_out, dim3(cdiv(rows * ((C + 3) / 4), 256)), dim3(256), 0, as_stream(stream), Mb,
-                     (size_t)group_rows * C, B, X, Y, Z, C, Tx, Ty, out, out_stride, scale, bias, res, res_stride, relu);
+  const dim3 grid(cdiv(rows * ((C + 3) / 4), 256));
+  if (tile == 2)
+    hipLaunchKernelGGL(k_wino_out<4>, grid, dim3(256), 0, as_stream(stream), Mb, (size_t)group_rows * C, B, X, Y, Z, C, Tx, Ty,
+                       out, out_stride, scale, bias, res, res_stride, relu);
+  else
+    hipLaunchKernelGGL(k_wino_out<6>, grid, dim3(256), 0, as_stream(stream), Mb, (size_t)group_rows * C, B, X, Y, Z, C, Tx, Ty,
+                       out, out_stride, scale, bias, res, res_stride, relu);
   COOCC_LAUNCH_CHECK("k_wino_out");
   return COOCC_OK;
 }

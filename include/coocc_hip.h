@@ -148,13 +148,14 @@ typedef struct coocc_conv_desc {
  * ->scatter of bifuser_n.py:138-169 as one fp32-MFMA implicit-GEMM kernel family. */
 int coocc_conv_fwd(const coocc_conv_desc* d, void* stream);
 
-/* Winograd F(2x2,3x3) over (x,y) for 3x3x3 stride-1 pad-1 convs (z stays a direct 3-tap conv): input transform,
- * then ONE coocc_conv_fwd launch over 16 x group_rows rows (kx=ky=1, kz=3, pz=1, wgroup_rows=group_rows, weights =
- * 16 packs of G g G^T), then output transform + epilogue.  V / Mb: [16][group_rows][C]; row = ((b*Tx+tx)*Ty+ty)*Z+z,
- * Tx = ceil(X/2); group_rows a multiple of lcm(640, Z) >= B*Tx*Ty*Z.  2.25x fewer multiplies than the direct form. */
-int coocc_wino_input(const float* in, int in_stride, int B, int X, int Y, int Z, int C, float* V,
+/* Winograd F(m x m, 3x3), m = tile = 2 or 4, over (x,y) for 3x3x3 stride-1 pad-1 convs (z stays a direct 3-tap
+ * conv): input transform, then ONE coocc_conv_fwd launch over (m+2)^2 x group_rows rows (kx=ky=1, kz=3, pz=1,
+ * wgroup_rows=group_rows, weights = (m+2)^2 packs of G g G^T), then output transform + epilogue.  V / Mb:
+ * [(m+2)^2][group_rows][C]; row = ((b*Tx+tx)*Ty+ty)*Z+z, Tx = ceil(X/m); group_rows a multiple of lcm(640, Z)
+ * >= B*Tx*Ty*Z.  12*Cin (m=2) / 6.75*Cin (m=4) multiplies per output instead of 27*Cin. */
+int coocc_wino_input(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, float* V,
                      int64_t group_rows, void* stream);
-int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, float* out,
+int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, int tile, float* out,
                       int out_stride, const float* scale, const float* bias, const float* res, int res_stride,
                       int relu, void* stream);
 

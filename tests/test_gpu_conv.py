@@ -153,10 +153,13 @@ def test_occhead_mix_softmax_levels(dev):
     assert_close(out.view(1, *sizes[0], 16).permute(0, 4, 1, 2, 3).cpu(), want, tol=1e-5)
 
 
-def test_conv_linearity_at_full_grid(dev):
+@pytest.mark.parametrize("wino,tol", [(0, 1e-5), (1, 1e-4)])
+def test_conv_linearity_at_full_grid(dev, monkeypatch, wino, tol):
     """Size-independent property at the BASELINE grid (100x100x8, C=128): conv(a*x + y) ==
     a*conv(x) + conv(y) for the bias-free, ReLU-free 3x3x3 layer; and a checksum of the
-    1-channel all-ones response equals the analytic tap count."""
+    1-channel all-ones response equals the analytic tap count.  Direct path and the Winograd
+    F(4x4,3x3) path the production dispatch picks at this size."""
+    monkeypatch.setattr(core, "WINO", wino)
     g = torch.Generator().manual_seed(2)
     x = torch.randn(1, 128, 100, 100, 8, generator=g).to(dev)
     y = torch.randn(1, 128, 100, 100, 8, generator=g).to(dev)
@@ -165,12 +168,12 @@ def test_conv_linearity_at_full_grid(dev):
     cx = core.conv_rows(core.to_rows(x), pc, relu=False).t
     cy = core.conv_rows(core.to_rows(y), pc, relu=False).t
     cz = core.conv_rows(core.to_rows(2.5 * x + y), pc, relu=False).t
-    assert_close(cz.cpu(), (2.5 * cx + cy).cpu(), tol=1e-5)
+    assert_close(cz.cpu(), (2.5 * cx + cy).cpu(), tol=tol)
     ones = torch.ones(1, 4, 100, 100, 8, device=dev)
     w1 = torch.ones(4, 4, 3, 3, 3, device=dev)
     resp = core.conv_rows(core.to_rows(ones), core.PackedConv(w1, ksize=3, pad=1), relu=False).as_ncdhw()
     taps = (100 * 3 - 2) * (100 * 3 - 2) * (8 * 3 - 2)          # sum over voxels of valid taps = prod (3n-2)
-    assert float(resp[0, 0].double().sum().item()) == pytest.approx(4.0 * taps, rel=1e-6)
+    assert float(resp[0, 0].double().sum().item()) == pytest.approx(4.0 * taps, rel=1e-6 if not wino else 1e-5)
 
 
 WINO_CASES = [
@@ -183,8 +186,9 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("Cin,Cout,grid,B,relu,use_res", WINO_CASES)
-def test_conv3d_winograd_path(dev, monkeypatch, Cin, Cout, grid, B, relu, use_res):
+@pytest.mark.parametrize("tile", [2, 4])
+@pytest.mark.parametrize("Cin,Cout,grid,B,relu,use_res", WINO_CASES + [(512, 128, (16, 12, 4), 1, True, False)])
+def test_conv3d_winograd_path(dev, monkeypatch, Cin, Cout, grid, B, relu, use_res, tile):
     """The Winograd F(2x2,3x3) + direct-z path (csrc/winograd.hip) against torch's direct fp32 conv, and against
     our own direct path (both inside the 1e-4 bound)."""
     g = torch.Generator().manual_seed(Cin * 77 + Cout)
@@ -202,6 +206,7 @@ def test_conv3d_winograd_path(dev, monkeypatch, Cin, Cout, grid, B, relu, use_re
     rr = rows_of(res, dev) if use_res else None
     monkeypatch.setattr(core, "WINO", 1)
     monkeypatch.setattr(core, "WINO_MIN_ROWS", 0)
+    monkeypatch.setattr(core, "WINO_TILE", tile)
     assert core.wino_eligible(rows_of(x, dev), pc, B * X * Y * Z, 1 if use_res else 0)
     out = core.conv_rows(rows_of(x, dev), pc, relu=relu, res=rr)
     assert_close(out.as_ncdhw().cpu(), ref.detach(), what="winograd conv")

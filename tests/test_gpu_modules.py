@@ -22,7 +22,10 @@ def load_seeded(module, seed, dev):
 
 
 @pytest.mark.parametrize("name", sorted(cases.FUSER_CASES))
-def test_bifuser_vs_golden(dev, golden, name):
+@pytest.mark.parametrize("conv_path", ["direct", "winograd"])
+def test_bifuser_vs_golden(dev, golden, name, monkeypatch, conv_path):
+    monkeypatch.setattr(core, "WINO", 1 if conv_path == "winograd" else 0)
+    monkeypatch.setattr(core, "WINO_MIN_ROWS", 0)
     c, g = cases.FUSER_CASES[name], golden(name)
     img, pts = cases.fuser_inputs(c)
     f, sd = load_seeded(pkg.BiFuser_N(c["C"], c["C"], c["knum"]), c["seed"], dev)
@@ -56,7 +59,12 @@ def test_bifuser_concat_rows_exact_layout(dev):
     assert_close(cat4.t.cpu().view(o["all_feats"].shape), o["all_feats"], tol=1e-5)
 
 
-def test_decoder_vs_golden(dev, golden):
+@pytest.mark.parametrize("conv_path", ["direct", "winograd"])
+def test_decoder_vs_golden(dev, golden, monkeypatch, conv_path):
+    """conv_path=winograd forces every eligible 3x3x3 stride-1 layer through csrc/winograd.hip (the production
+    dispatch only does so from 20000 output rows up): the reference's golden outputs must still hold."""
+    monkeypatch.setattr(core, "WINO", 1 if conv_path == "winograd" else 0)
+    monkeypatch.setattr(core, "WINO_MIN_ROWS", 0)
     c, g = cases.DECODER_CASE, golden("decoder")
     x, rig, img_feats = cases.decoder_inputs(c)
     cfg = synth.model_cfg(C=c["C"], block_inplanes=c["block_inplanes"], out_channels=c["fpn_out"],
