@@ -202,10 +202,20 @@ def main():
                 unit = v["work"] / (v["ms"] * 1e-3) if v["ms"] else 0
                 print("%-34s launches %5d  total %9.3f ms  avg %8.3f ms  %6.1f%%  work/s %.4g" % (
                     k, v["launches"], v["ms"], v["ms"] / v["launches"], 100 * v["ms"] / tot, unit), file=sys.stderr)
-        convs = {k: v for k, v in ksum.items() if k.startswith("k_conv")}
+        # one entry per kernel symbol: the Winograd-domain launches of either tile size are the same instantiation
+        # (k_conv2<BM,PF,0,true>); keep their direct-convolution-equivalent flops alongside the executed ones
+        convs = {}
+        for k, v in ksum.items():
+            if not k.startswith("k_conv"):
+                continue
+            sym = k.split(" wino")[0] + (",wg> wino" if " wino" in k else "")
+            sym = sym.replace(">,wg>", ",wg>")
+            c_ = convs.setdefault(sym, dict(launches=0, ms=0.0, work=0.0, equiv=0.0))
+            c_["launches"] += v["launches"]; c_["ms"] += v["ms"]; c_["work"] += v["work"]
+            c_["equiv"] += v["work"] * {"wino2": 2.25, "wino4": 4.0}.get(k.split()[-1], 1.0)
         dom = max(convs, key=lambda k: convs[k]["ms"]) if convs else None
         if dom:
-            v = ksum[dom]
+            v = convs[dom]
             ach = v["work"] / (v["ms"] * 1e-3) / 1e12      # flops the matrix cores execute (Winograd-domain for "wino")
             traffic = None
             try:   # HBM bytes per launch from the committed PMC passes (cannot be collected inside this process)
@@ -214,7 +224,7 @@ def main():
             except Exception:
                 pass
             # direct-convolution-equivalent rate of the same launches: F(m x m,3x3) needs 9 m^2/(m+2)^2 x fewer multiplies
-            equiv = {"wino2": 2.25, "wino4": 4.0}.get(dom.split()[-1], 1.0)
+            equiv = v["equiv"] / v["work"]
             roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=traffic, launches=v["launches"],
                         avg_launch_ms=round(v["ms"] / v["launches"], 4),

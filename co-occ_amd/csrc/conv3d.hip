@@ -248,7 +248,9 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // B loads share one depth: waiting for chunk i+1's A rows must not drain younger loads.  PF = 1 is
 // enough while the weights stay cache-resident (many M tiles re-read them); the weight-streaming
 // layers (few M tiles, up to 113 MB of weights each) need the HBM latency of 2-3 chunks covered.
-template <int BM, int PF = 1, int DBG = 0>
+// WG = true: the weight-grouped launch of the Winograd path (one weight pack per transform point); a separate
+// instantiation so that profilers list it under its own name.
+template <int BM, int PF = 1, int DBG = 0, bool WG = false>
 __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
   constexpr int TM = BM / 32, PA = BM / 32;
   __shared__ float As[2][BM * LDS_ST];
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
   const int li = lane & 31, h = lane >> 5;
 
   __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-  const float* wbase = p.wgroup_rows > 0 ? p.w + (size_t)(m0 / p.wgroup_rows) * p.wgroup_floats : p.w;
+  const float* wbase = WG ? p.w + (size_t)(m0 / p.wgroup_rows) * p.wgroup_floats : p.w;
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, p.w_bytes, 0x00020000);
 
   // per-thread A rows: voxel coordinates of tap (0,0,0) and its row index; rows past M are parked
@@ -539,7 +541,11 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
     static const int dbg = getenv("COOCC_CONV_DBG") ? atoi(getenv("COOCC_CONV_DBG")) : 0;   // timing experiments only (wrong results)
     static const int pf160 = getenv("COOCC_CONV_PF160") ? atoi(getenv("COOCC_CONV_PF160")) : 2;
     static const int pf128 = getenv("COOCC_CONV_PF128") ? atoi(getenv("COOCC_CONV_PF128")) : 3;
-    if (cfg == 4 && dbg == 1) hipLaunchKernelGGL((k_conv2<160, 1, 1>), grid, dim3(256), 0, s, k);
+    if (k.wgroup_rows > 0) {
+      if (cfg == 4) hipLaunchKernelGGL((k_conv2<160, 2, 0, true>), grid, dim3(256), 0, s, k);
+      else hipLaunchKernelGGL((k_conv2<128, 3, 0, true>), grid, dim3(256), 0, s, k);
+    }
+    else if (cfg == 4 && dbg == 1) hipLaunchKernelGGL((k_conv2<160, 1, 1>), grid, dim3(256), 0, s, k);
     else if (cfg == 4 && dbg == 2) hipLaunchKernelGGL((k_conv2<160, 1, 2>), grid, dim3(256), 0, s, k);
     else if (cfg == 4 && dbg == 3) hipLaunchKernelGGL((k_conv2<160, 1, 3>), grid, dim3(256), 0, s, k);
     else if (cfg == 4 && pf160 == 2) hipLaunchKernelGGL((k_conv2<160, 2>), grid, dim3(256), 0, s, k);

@@ -336,14 +336,32 @@ __global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int
     long long c2 = dbg ? clock64() : 0;
     lds_barrier();
     long long c3 = dbg ? clock64() : 0;
-    KT g = wbest[j & 1][0];
-    int gw = 0;
+    // global winner: lanes 0..NW-1 each fetch one wave's candidate, one 16-lane DPP max + two readlanes
+    // (16 waves x a 15-step compare/select chain was ~1/3 of the per-sample critical path)
+    KT g;
+    int gl;
+    if constexpr (sizeof(KT) == 4 && NW <= 16) {
+      const int li = lane & 15;
+      const KT mine = li < NW ? wbest[j & 1][li] : (KT)0;
+      const int ml = li < NW ? wloc[j & 1][li] : 0;
+      KT v = mine;
+      v = max(v, (KT)dpp_u32<0xB1>(v));
+      v = max(v, (KT)dpp_u32<0x4E>(v));
+      v = max(v, (KT)dpp_u32<0x141>(v));
+      v = max(v, (KT)dpp_u32<0x140>(v));
+      g = (KT)__builtin_amdgcn_readfirstlane((int)v);
+      const u64 own = __ballot(mine == g) & 0xFFFFull;
+      gl = __builtin_amdgcn_readlane(ml, (int)__ffsll((long long)own) - 1);
+    } else {
+      g = wbest[j & 1][0];
+      int gw = 0;
 #pragma unroll
-    for (int w = 1; w < NW; ++w) {
-      KT o = wbest[j & 1][w];
-      if (o > g) { g = o; gw = w; }
+      for (int w = 1; w < NW; ++w) {
+        KT o = wbest[j & 1][w];
+        if (o > g) { g = o; gw = w; }
+      }
+      gl = wloc[j & 1][gw];
     }
-    const int gl = wloc[j & 1][gw];
     sx = gl & 1023; sy = (gl >> 10) & 1023; sz = gl >> 20;
     if (tid == 0) {   // list ordinal of the winner from its tie rank (off the critical path)
       const unsigned rr = (unsigned)(rmask - (g & rmask));
