@@ -76,6 +76,77 @@ __global__ __launch_bounds__(256) void k_fine_sample_voxel(const float* __restri
   }
 }
 
+// ratio == 2: one wave per COARSE voxel computes its 8 children together.  Their 8-corner stencils overlap in a
+// 3x3x3 neighbourhood, which is read once (27 rows instead of 64), and the volume is streamed once instead of once
+// per child offset (the offset-major point order made the one-wave-per-point kernel re-read it 8 times: 808 MB
+// of HBM fetch for a 41 MB volume).  Output order is unchanged (f = o*n + i).
+__global__ __launch_bounds__(256, 4) void k_fine_sample_voxel_r2(const float* __restrict__ vol, int C, int X, int Y, int Z,
+                                                               const int32_t* __restrict__ coarse_lin, int n,
+                                                               float fx1, float fy1, float fz1,
+                                                               int64_t* __restrict__ fine_xyz, float* __restrict__ feat,
+                                                               int out_stride) {
+  const int i = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const long long nf = (long long)n * 8;
+  int l = coarse_lin[i];
+  const int cz = l % Z; l /= Z;
+  const int cy = l % Y; const int cx = l / Y;   // B == 1
+  // per axis and child bit: base index and fraction, with the expressions of k_fine_sample_voxel
+  int i0[3][2]; float t[3][2];
+  const int cc[3] = {cx, cy, cz}; const float f1[3] = {fx1, fy1, fz1}; const int S[3] = {X, Y, Z};
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int q = cc[ax] * 2 + a;
+      const float g = ((float)q / f1[ax] - 0.5f) * 2.f;
+      const float p = ((g + 1.f) * (float)S[ax] - 1.f) / 2.f;
+      const float fl = floorf(p);
+      i0[ax][a] = (int)fl; t[ax][a] = p - fl;
+    }
+  if (lane < 8) {
+    const int oa = lane >> 2, ob = (lane >> 1) & 1, oc = lane & 1;
+    const long long f = (long long)lane * n + i;
+    fine_xyz[f] = cx * 2 + oa; fine_xyz[nf + f] = cy * 2 + ob; fine_xyz[2 * nf + f] = cz * 2 + oc;
+  }
+  // tap weight of window position x for a child with base index b0 and fraction t
+  auto tapw = [](int b0, float t, int x) { return (x == b0 ? 1.f - t : 0.f) + (x == b0 + 1 ? t : 0.f); };
+  const int wx0 = min(i0[0][0], i0[0][1]), wy0 = min(i0[1][0], i0[1][1]), wz0 = min(i0[2][0], i0[2][1]);
+  for (int c = lane * 2; c < C; c += 128) {
+    f32x2 acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = f32x2{0.f, 0.f};
+    // runtime loops on purpose: fully unrolled, hipcc hoists 216 weight products and spills
+#pragma unroll 1
+    for (int kx = 0; kx < 3; ++kx) {
+      const int x = wx0 + kx;
+      if ((unsigned)x >= (unsigned)X) continue;
+      const float ax0 = tapw(i0[0][0], t[0][0], x), ax1 = tapw(i0[0][1], t[0][1], x);
+#pragma unroll 1
+      for (int ky = 0; ky < 3; ++ky) {
+        const int y = wy0 + ky;
+        if ((unsigned)y >= (unsigned)Y) continue;
+        const float by0 = tapw(i0[1][0], t[1][0], y), by1 = tapw(i0[1][1], t[1][1], y);
+        const float w00 = ax0 * by0, w01 = ax0 * by1, w10 = ax1 * by0, w11 = ax1 * by1;
+        const float* rowp = vol + (((size_t)x * Y + y) * Z) * C + c;
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+          const int z = wz0 + kz;
+          if ((unsigned)z >= (unsigned)Z) continue;
+          const float cz0 = tapw(i0[2][0], t[2][0], z), cz1 = tapw(i0[2][1], t[2][1], z);
+          const f32x2 v = *(const f32x2*)(rowp + (size_t)z * C);
+          acc[0] = acc[0] + v * (w00 * cz0); acc[1] = acc[1] + v * (w00 * cz1);
+          acc[2] = acc[2] + v * (w01 * cz0); acc[3] = acc[3] + v * (w01 * cz1);
+          acc[4] = acc[4] + v * (w10 * cz0); acc[5] = acc[5] + v * (w10 * cz1);
+          acc[6] = acc[6] + v * (w11 * cz0); acc[7] = acc[7] + v * (w11 * cz1);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) *(f32x2*)(feat + ((size_t)o * n + i) * out_stride + c) = acc[o];
+  }
+}
+
 extern "C" int coocc_fine_sample_voxel(const float* vol, int C, int X, int Y, int Z, const int32_t* coarse_lin, int n,
                                        int ratio, const int* final_size_host, int64_t* fine_xyz, float* feat,
                                        int out_stride, void* stream) {
@@ -83,6 +154,15 @@ extern "C" int coocc_fine_sample_voxel(const float* vol, int C, int X, int Y, in
                   "fine_sample_voxel: bad args");
   if (n == 0) return COOCC_OK;
   long long nf = (long long)n * ratio * ratio * ratio;
+  // the 3-wide window of the grouped kernel needs floor(p) of the two children of an axis to differ by <= 1:
+  // true for final == ratio * coarse (p = q*S/(2S-1) - 1/2)
+  if (ratio == 2 && final_size_host[0] == 2 * X && final_size_host[1] == 2 * Y && final_size_host[2] == 2 * Z) {
+    hipLaunchKernelGGL(k_fine_sample_voxel_r2, dim3(cdiv((long long)n * 64, 256)), dim3(256), 0, as_stream(stream), vol, C, X,
+                       Y, Z, coarse_lin, n, (float)(final_size_host[0] - 1), (float)(final_size_host[1] - 1),
+                       (float)(final_size_host[2] - 1), fine_xyz, feat, out_stride);
+    COOCC_LAUNCH_CHECK("k_fine_sample_voxel_r2");
+    return COOCC_OK;
+  }
   hipLaunchKernelGGL(k_fine_sample_voxel, dim3(cdiv(nf * 64, 256)), dim3(256), 0, as_stream(stream), vol, C, X, Y, Z,
                      coarse_lin, n, ratio, (float)(final_size_host[0] - 1), (float)(final_size_host[1] - 1),
                      (float)(final_size_host[2] - 1), fine_xyz, feat, out_stride);
@@ -162,11 +242,93 @@ __global__ __launch_bounds__(256) void k_fine_sample_img(const float* __restrict
   }
 }
 
+// Grouped form for the offset-major fine list of the head (f = o*n + i, 8 children per coarse voxel): one wave per
+// coarse voxel.  Lane o*ncam + cam projects child o into camera cam (the 8*ncam projections run in parallel
+// instead of every lane repeating all of them); then lanes = channels and the (child, camera) pairs that see the
+// point are walked with wave-uniform readlanes.  Same expressions and accumulation order as k_fine_sample_img.
+__global__ __launch_bounds__(256) void k_fine_sample_img_g8(const float* __restrict__ img, int ncam, int Ci, int Hf, int Wf,
+                                                             const float* __restrict__ prm,
+                                                             const int64_t* __restrict__ fine_xyz, int n,
+                                                             float* __restrict__ feat, int out_stride) {
+  const int i = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const long long nf = (long long)n * 8;
+  int m = 0, x0 = 0, y0 = 0;
+  float ax = 0.f, ay = 0.f;
+  if (lane < 8 * ncam) {
+    const int o = lane / ncam, cam = lane - o * ncam;
+    const long long f = (long long)o * n + i;
+    float p0 = (float)fine_xyz[f] * prm[9] + prm[12];
+    float p1 = (float)fine_xyz[nf + f] * prm[10] + prm[13];
+    float p2 = (float)fine_xyz[2 * nf + f] * prm[11] + prm[14];
+    float bx = prm[0] * p0 + prm[1] * p1 + prm[2] * p2;
+    float by = prm[3] * p0 + prm[4] * p1 + prm[5] * p2;
+    float bz = prm[6] * p0 + prm[7] * p1 + prm[8] * p2;
+    const float wimg1 = prm[15], himg1 = prm[16];
+    const float* q = prm + FINE_HDR + cam * FINE_CAM_STRIDE;
+    float tx = bx - q[9], ty = by - q[10], tz = bz - q[11];
+    float cx = q[0] * tx + q[1] * ty + q[2] * tz;
+    float cy = q[3] * tx + q[4] * ty + q[5] * tz;
+    float cz = q[6] * tx + q[7] * ty + q[8] * tz;
+    float ix = q[12] * cx + q[13] * cy + q[14] * cz;
+    float iy = q[15] * cx + q[16] * cy + q[17] * cz;
+    float d = q[18] * cx + q[19] * cy + q[20] * cz;
+    float u = ix / (d + 1e-5f), v = iy / (d + 1e-5f);
+    float u2 = q[21] * u + q[22] * v + q[25];
+    float v2 = q[23] * u + q[24] * v + q[26];
+    u2 = (u2 / wimg1 - 0.5f) * 2.f;
+    v2 = (v2 / himg1 - 0.5f) * 2.f;
+    m = (d > 1e-5f && u2 > -1.f && u2 < 1.f && v2 > -1.f && v2 < 1.f) ? 1 : 0;
+    float px = (u2 + 1.f) / 2.f * (float)(Wf - 1), py = (v2 + 1.f) / 2.f * (float)(Hf - 1);
+    float flx = floorf(px), fly = floorf(py);
+    x0 = (int)flx; y0 = (int)fly;
+    ax = px - flx; ay = py - fly;
+  }
+  const unsigned long long seen = __ballot(m != 0);
+  for (int c = lane; c < Ci; c += 64) {
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      acc[o] = 0.f;
+      for (int cam = 0; cam < ncam; ++cam) {
+        const int k = o * ncam + cam;
+        if (!((seen >> k) & 1ull)) continue;                       // wave-uniform
+        const int xk = __builtin_amdgcn_readlane(x0, k), yk = __builtin_amdgcn_readlane(y0, k);
+        const float axk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ax), k));
+        const float ayk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ay), k));
+        const float* base = img + (size_t)cam * Hf * Wf * Ci;
+        float a = acc[o];
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+          for (int xx = 0; xx < 2; ++xx) {
+            const int x = xk + xx, y = yk + yy;
+            if ((unsigned)x < (unsigned)Wf && (unsigned)y < (unsigned)Hf) {
+              const float w = (xx ? axk : 1.f - axk) * (yy ? ayk : 1.f - ayk);
+              a = a + base[((size_t)y * Wf + x) * Ci + c] * w;
+            }
+          }
+        acc[o] = a;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) feat[((size_t)o * n + i) * out_stride + c] = acc[o];
+  }
+}
+
 extern "C" int coocc_fine_sample_img(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf, const float* params,
-                                     const int64_t* fine_xyz, int64_t nfine, float* feat, int out_stride, void* stream) {
+                                     const int64_t* fine_xyz, int64_t nfine, float* feat, int out_stride, int group8,
+                                     void* stream) {
   COOCC_CHECK_ARG(img_nhwc && params && fine_xyz && feat && ncam > 0 && Ci > 0 && Ci % 2 == 0 && Ci <= 512,
                   "fine_sample_img: bad args (Ci even, <= 512)");
   if (nfine == 0) return COOCC_OK;
+  if (group8 && nfine % 8 == 0 && ncam <= 8 && nfine / 8 < (1ll << 31)) {
+    const int n = (int)(nfine / 8);
+    hipLaunchKernelGGL(k_fine_sample_img_g8, dim3(cdiv((long long)n * 64, 256)), dim3(256), 0, as_stream(stream), img_nhwc, ncam,
+                       Ci, Hf, Wf, params, fine_xyz, n, feat, out_stride);
+    COOCC_LAUNCH_CHECK("k_fine_sample_img_g8");
+    return COOCC_OK;
+  }
   hipLaunchKernelGGL(k_fine_sample_img, dim3(cdiv(nfine * 64, 256)), dim3(256), 0, as_stream(stream), img_nhwc, ncam, Ci,
                      Hf, Wf, params, fine_xyz, (long long)nfine, feat, out_stride);
   COOCC_LAUNCH_CHECK("k_fine_sample_img");

@@ -127,17 +127,11 @@ class OccHead(nn.Module):
         cnt = torch.empty(1, device=dev, dtype=_I32)
         ws = torch.empty(V // 1024 + 2, device=dev, dtype=_I32)
         call("coocc_compact_flags", ptr(flags), V, ptr(lin), ptr(cnt), ptr(ws), ws.numel() * 4)
-        n = int(cnt.item())
-        assert n > 0, 'no foreground in coarse voxel'
-        nf = n * r ** 3
-        fine_xyz = torch.empty(3, nf, device=dev, dtype=_I64)
-        cvox = 128 if self.sample_from_voxel else 0
-        cat = torch.empty(nf, cvox + (64 if self.sample_from_img and img_feats is not None else 0), device=dev, dtype=_F32)
-        vox_feat = cat if self.sample_from_voxel else torch.empty(nf, ovf.C, device=dev, dtype=_F32)
-        # fine coordinates are always produced by this kernel (they are an output of the head)
-        call("coocc_fine_sample_voxel", ptr(ovf.t), ovf.C, ovf.X, ovf.Y, ovf.Z, ptr(lin), n, r,
-             host_i32(self.final_occ_size), ptr(fine_xyz), ptr(vox_feat), vox_feat.shape[1])
-        if self.sample_from_img and img_feats is not None:
+        # everything that does not depend on the foreground count is enqueued BEFORE the host reads it: the
+        # image-feature branch (1x1 conv + GroupNorm) and the camera matrices (a dozen tiny torch launches)
+        # then run under the device->host round trip instead of after it
+        use_img = self.sample_from_img and img_feats is not None
+        if use_img:
             f = img_feats[0]                                    # [B,N,512,fH,fW]
             _, N_i, C_i, Hf, Wf = f.shape
             rows = torch.empty(N_i * Hf * Wf, C_i, device=dev, dtype=_F32)
@@ -147,9 +141,20 @@ class OccHead(nn.Module):
             call("coocc_groupnorm_nhwc", ptr(g), N_i, Hf * Wf, g.shape[1], gn.num_groups, ptr(gn.weight.detach()),
                  ptr(gn.bias.detach()), float(gn.eps), 1)
             params = self._projection_params(transform, ovf, dev)
+        n = int(cnt.item())
+        assert n > 0, 'no foreground in coarse voxel'
+        nf = n * r ** 3
+        fine_xyz = torch.empty(3, nf, device=dev, dtype=_I64)
+        cvox = 128 if self.sample_from_voxel else 0
+        cat = torch.empty(nf, cvox + (64 if use_img else 0), device=dev, dtype=_F32)
+        vox_feat = cat if self.sample_from_voxel else torch.empty(nf, ovf.C, device=dev, dtype=_F32)
+        # fine coordinates are always produced by this kernel (they are an output of the head)
+        call("coocc_fine_sample_voxel", ptr(ovf.t), ovf.C, ovf.X, ovf.Y, ovf.Z, ptr(lin), n, r,
+             host_i32(self.final_occ_size), ptr(fine_xyz), ptr(vox_feat), vox_feat.shape[1])
+        if use_img:
             samp = torch.empty(nf, g.shape[1], device=dev, dtype=_F32)
             call("coocc_fine_sample_img", ptr(g), N_i, g.shape[1], Hf, Wf, ptr(params), ptr(fine_xyz), nf, ptr(samp),
-                 samp.shape[1])
+                 samp.shape[1], 1 if r == 2 else 0)
             linear_rows(samp, p["img"], out=cat, out_coff=cvox)
             gn = self.img_mlp[1]
             sub = cat[:, cvox:]
