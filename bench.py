@@ -60,12 +60,12 @@ def build_model(cfgname, dev):
     return model.to(dev).eval(), sd
 
 
-def step(model, s, world):
+def step(model, s, world, search=None):
     # the reference hard-codes the render bounds to a 100x100x8 volume (coocc_ray.py:577): smaller test grids
     # (config1) cannot be rendered there either
     X, Y, Z = s["img"].shape[2:]
     out = model.forward_hot_path(s["img"], s["pts"], s["gemo"], s["img_feats"], s["transform"],
-                                 render=(X >= 100 and Y >= 100 and Z >= 8))
+                                 render=(X >= 100 and Y >= 100 and Z >= 8), search=search)
     if world > 1:
         out["all_rgbs"], out["all_depths"] = cdist.all_gather_maps(out["rgbs"], out["depths"])
     return out
@@ -117,8 +117,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="r50", choices=sorted(synth.CONFIGS))
     ap.add_argument("--streams", type=int, default=1, help="samples in flight (software pipelining over HIP streams)")
-    ap.add_argument("--pipeline", type=int, default=0,
-                    help="with --streams > 1: serialise the dense stages, overlap only the index search of the next sample")
+    ap.add_argument("--prefetch", type=int, default=1,
+                    help="issue the index search of sample i+1 (helper host thread + stream) under the dense stage of sample i")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs set aside for the FPS chains (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -140,18 +140,24 @@ def main():
         streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
     import threading
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(1) if (args.prefetch and len(streams) == 1) else None
+    # high priority: a lone 1024-thread FPS workgroup must win a CU slot against the queue of convolution workgroups
+    search_stream = torch.cuda.Stream(device=dev, priority=-1)
+
+    def do_search(s):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(search_stream), torch.no_grad():
+            return model.search(s["img"], s["pts"])
 
     def run(nsteps, timed):
         """`nsteps` samples round-robin over len(streams) host threads, one HIP stream each: the
         path has two small device->host reads per sample (voxel counts), so samples are kept in
         flight from independent host threads (torch drops the GIL while it waits)."""
         errs = []
-        gate = core.DenseGate() if args.pipeline else None
-
         def worker(si):
             try:
                 torch.cuda.set_device(dev)
-                core.set_dense_gate(gate)
                 with torch.cuda.stream(streams[si]), torch.no_grad():
                     for i in range(si, nsteps, len(streams)):
                         step(model, samples[i % len(samples)], world)
@@ -159,11 +165,17 @@ def main():
             except Exception as e:  # surface worker failures in the main thread
                 errs.append(e)
         if len(streams) == 1 or world > 1:
-            # collectives must be issued in the same order on every rank: single driver thread
+            # collectives must be issued in the same order on every rank: single driver thread.  With --prefetch the
+            # index search of sample i+1 (no collective, one device->host read) runs on a helper thread and its own
+            # stream under the dense stage of sample i; dense stages never overlap each other.
             with torch.no_grad():
+                fut = pool.submit(do_search, samples[0]) if (pool and nsteps) else None
                 for i in range(nsteps):
+                    sr = fut.result() if fut is not None else None
+                    if pool and i + 1 < nsteps:
+                        fut = pool.submit(do_search, samples[(i + 1) % len(samples)])
                     with torch.cuda.stream(streams[i % len(streams)]):
-                        step(model, samples[i % len(samples)], world)
+                        step(model, samples[i % len(samples)], world, search=sr)
             for st in streams:
                 st.synchronize()
             return
@@ -252,7 +264,7 @@ def main():
                             occupancy_grid="x".join(str(2 * v) for v in c["grid"]), cams=c["ncam"],
                             render_maps="%dx%dx%d" % (c["ncam"], c["fmap"][0] * 16, c["fmap"][1] * 16), knum=c["knum"],
                             parallelism="dp%d (1 scene per GPU, RCCL all-gather of maps)" % world,
-                            samples_in_flight=len(streams), weights="random"),
+                            samples_in_flight=len(streams), prefetched_search=bool(pool), weights="random"),
                 roofline=roof)
     line.update(extra)
     if world == 1 and not args.no_cpu_baseline:

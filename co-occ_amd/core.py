@@ -341,44 +341,6 @@ def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_co
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
 
 
-class DenseGate:
-    """Cross-sample software pipeline for samples kept in flight on different HIP streams / host threads:
-    the index search of a sample (2 x 2047 dependent FPS steps on one CU each, ~3.8 ms with 254 CUs idle)
-    may overlap anything, but the dense stage (gather-GEMM onwards, every launch fills the chip) of two
-    samples must not interleave -- it only thrashes L2.  ``enter`` blocks the host until the previous
-    sample's dense stage is fully enqueued and makes the current stream wait for its completion event."""
-
-    def __init__(self):
-        import threading
-        self.lock = threading.Lock()
-        self.done = None
-
-    def enter(self):
-        self.lock.acquire()
-        if self.done is not None:
-            torch.cuda.current_stream().wait_event(self.done)
-
-    def exit(self):
-        if self.lock.locked():
-            ev = torch.cuda.Event()
-            ev.record()
-            self.done = ev
-            self.lock.release()
-
-
-import threading as _threading
-_tls = _threading.local()
-
-
-def set_dense_gate(gate):
-    """Per host thread: the gate consulted by BiFuser_N.fuse / COOCC_Ray.forward_hot_path (None = no pipelining)."""
-    _tls.gate = gate
-
-
-def dense_gate():
-    return getattr(_tls, "gate", None)
-
-
 class PackCache:
     """Re-pack lazily when any source parameter/buffer changed (torch `_version` counters)."""
 

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from . import registry
-from .core import dense_gate, to_rows
+from .core import to_rows
 from .registry import DETECTORS
 from .render import MLP, render_block, render_losses
 
@@ -47,29 +47,26 @@ class COOCC_Ray(nn.Module):
             self.sigma_head = MLP(input_dim=128, output_dim=1, net_depth=1, skip_layer=None)
             self.rgb_head = MLP(input_dim=128, output_dim=3, net_depth=3, skip_layer=None)
 
-    def fuse(self, img_voxel_feats, pts_voxel_feats):
+    def fuse(self, img_voxel_feats, pts_voxel_feats, search=None):
         """coocc_ray.py:252-256."""
         if self.occ_fuser is not None:
-            return self.occ_fuser(img_voxel_feats, pts_voxel_feats)
+            return self.occ_fuser(img_voxel_feats, pts_voxel_feats, search=search)
         assert (img_voxel_feats is None) or (pts_voxel_feats is None)
         return img_voxel_feats if pts_voxel_feats is None else pts_voxel_feats
 
+    def search(self, img_voxel_feats, pts_voxel_feats):
+        """Index-search stage of the fuser for one sample (``BiFuser_N.search``): may be issued for sample i+1 on
+        another stream / host thread while sample i runs ``forward_hot_path(..., search=...)``."""
+        return self.occ_fuser.search(img_voxel_feats, pts_voxel_feats)
+
     def forward_hot_path(self, img_voxel_feats, pts_voxel_feats, gemo=None, img_feats=None, transform=None,
-                         render=None, dense_fine=True):
+                         render=None, dense_fine=True, search=None):
         """simple_test (coocc_ray.py:520-627) minus encoders and metrics.
 
         img_voxel_feats / pts_voxel_feats: [1,C,X,Y,Z]; gemo: [1,N,D,fH,fW,3] (get_geometry);
         img_feats: [[1,N,512,fH,fW]]; transform: img_inputs[1:] (rots, trans, intrins, post_rots,
         post_trans, bda, ..., (H_img, W_img))."""
-        try:
-            return self._hot_path(img_voxel_feats, pts_voxel_feats, gemo, img_feats, transform, render, dense_fine)
-        finally:
-            gate = dense_gate()
-            if gate is not None:
-                gate.exit()        # entered by BiFuser_N.fuse when samples are pipelined across streams
-
-    def _hot_path(self, img_voxel_feats, pts_voxel_feats, gemo, img_feats, transform, render, dense_fine):
-        voxel_feats = self.fuse(img_voxel_feats, pts_voxel_feats)
+        voxel_feats = self.fuse(img_voxel_feats, pts_voxel_feats, search)
         mid = self.semantic_encoder.forward_rows(voxel_feats)
         sem = self.semantic_neck.forward_rows(mid)
         output = self.pts_bbox_head(voxel_feats=sem, img_feats=img_feats, transform=transform)

@@ -11,7 +11,7 @@ from torch import nn
 
 from . import _lib, streams
 from ._lib import call, ptr
-from .core import PackCache, PackedConv, Rows, conv_rows, dense_gate, gather_conv_rows
+from .core import PackCache, PackedConv, Rows, conv_rows, gather_conv_rows
 from .registry import FUSION_LAYERS
 
 _I32, _F32, _I64 = torch.int32, torch.float32, torch.int64
@@ -21,16 +21,15 @@ _fps_ws = {}
 _side = {}
 
 
-# measured on MI355X: running the KNN-independent half of con_enc.0 under the FPS chains is a net loss
-# while the FPS workgroup shares its CU with convolution waves (22.5 -> 25.2 ms/sample); off by default
-SPLIT_CON_ENC = int(__import__("os").environ.get("COOCC_SPLIT_CON_ENC", "0"))
 
 
 def _side_stream(dev, cur, which=0):
     key = (dev.index, cur.cuda_stream, which)
     if key not in _side:
-        _side[key] = streams.side_stream_for(cur, which) or torch.cuda.Stream(device=dev)
+        # same scheduling priority as its parent: a search stage prefetched on a high-priority stream keeps it
+        _side[key] = streams.side_stream_for(cur, which) or torch.cuda.Stream(device=dev, priority=getattr(cur, "priority", 0))
     return _side[key]
+
 
 FPS_MAX_BUCKETS = 8 * 1024     # FPS_RMAX * threads of csrc/knn.hip k_fps_voxels
 
@@ -105,6 +104,22 @@ def _fps_nn_xyz(query_xyz, key_xyz, fps_num, radius, max_cluster_samples, dist_t
     return out
 
 
+class SearchResult:
+    """Output of ``BiFuser_N.search``: the concat rows (img | pts halves written), the non-empty voxel lists and
+    the neighbour row tables of both directions, with the events that mark them ready."""
+
+    def __init__(self, cat4, lin_img, lin_pts):
+        self.cat4, self.lin_img, self.lin_pts = cat4, lin_img, lin_pts
+        self.rows = self.rows_p = self.near_img = self.near_pts = None
+        self.done_main = self.done_side = None
+        self.keep = ()
+
+    def tensors(self):
+        out = [self.cat4.t, self.lin_img, self.lin_pts]
+        out += [t for t in (self.rows, self.rows_p, self.near_img, self.near_pts) if t is not None]
+        return out + [t for t in self.keep if torch.is_tensor(t)]
+
+
 @FUSION_LAYERS.register_module()
 class BiFuser_N(nn.Module):
     def __init__(self, in_channels, out_channels, knum=1, norm_cfg=None):
@@ -130,16 +145,13 @@ class BiFuser_N(nn.Module):
             # con_enc opens the decoder: its rounding error is amplified by every later layer (measured on the
             # 50x50x8 end-to-end case: F(4x4) here lifts the fine-logit error from 7e-5 to 1.1e-4, anywhere
             # later it does not move it), so these two layers keep the F(2x2) transform
-            for k in ("c0", "c0a", "c0b", "c3"):
+            for k in ("c0", "c3"):
                 d[k].wino_tile = 2
             return d
 
         def build_packs():
             return dict(
                 c0=PackedConv(self.con_enc[0].weight, bn=self.con_enc[1], ksize=3, pad=1),
-                # con_enc.0 split along its input channels: [img | pts] does not depend on the KNN search
-                c0a=PackedConv(self.con_enc[0].weight[:, :2 * self.in_channels].contiguous(), ksize=3, pad=1),
-                c0b=PackedConv(self.con_enc[0].weight[:, 2 * self.in_channels:].contiguous(), bn=self.con_enc[1], ksize=3, pad=1),
                 c3=PackedConv(self.con_enc[3].weight, bn=self.con_enc[4], ksize=3, pad=1),
                 knn=PackedConv(self.knn_enc[0].weight, bias=self.knn_enc[0].bias, tap_major=True, taps=self.knum))
         return self._packs.get(srcs, build)
@@ -154,31 +166,28 @@ class BiFuser_N(nn.Module):
         return out[0] if num == 1 else out
 
     # ---------------------------------------------------------------- forward
-    def fuse(self, img_voxel_feats, pts_voxel_feats, early=None):
-        """K1..G1: returns the [B*V, 4C] concat rows (img | pts | fused_img | fused_pts).
-        early(cat4): optional callback launched (on a third stream) as soon as the img|pts halves of
-        the rows are in place and the two searches are in flight."""
+    def search(self, img_voxel_feats, pts_voxel_feats):
+        """K1..K5 on the current stream: concat rows with the img | pts halves in place, non-empty voxel lists,
+        both index searches (the second on a side stream).  Returns a ``SearchResult``; nothing downstream of
+        the indices has been launched, so a caller may run this for sample i+1 on its own stream (and host
+        thread: there is one device->host read of the two voxel counts) while sample i is in its dense stage
+        -- the 2 x 2047 dependent FPS steps occupy one CU each and overlap everything."""
         B, C, X, Y, Z = img_voxel_feats.shape
         V, dev = X * Y * Z, img_voxel_feats.device
         if not img_voxel_feats.is_cuda:
             raise _lib.CooccError("BiFuser_N runs on the GPU only (no CPU fallback)")
         img = img_voxel_feats.float().contiguous()
         pts = pts_voxel_feats.float().contiguous()
-        packs = self._packed()
         cat4 = torch.empty(B * V, 4 * C, device=dev, dtype=_F32)
         flags = torch.empty(2, B * V, device=dev, dtype=torch.uint8)
         call("coocc_fuser_prepare", ptr(img), ptr(pts), ptr(cat4), ptr(flags[0]), ptr(flags[1]), B, C, V)
-        rows_ready = None
-        if early is not None:
-            rows_ready = torch.cuda.Event()
-            rows_ready.record()
         lin = torch.empty(2, B * V, device=dev, dtype=_I32)
         counts = torch.empty(2, device=dev, dtype=_I32)
         ws = torch.empty(2, B * V // 1024 + 2, device=dev, dtype=_I32)
         for i in range(2):
             call("coocc_compact_flags", ptr(flags[i]), B * V, ptr(lin[i]), ptr(counts[i:i + 1]), ptr(ws[i]),
                  ws[i].numel() * 4)
-        Ni, Np = (int(v) for v in counts.tolist())     # the one host sync of the path (torch.nonzero does two)
+        Ni, Np = (int(v) for v in counts.tolist())     # the one host sync of the stage (torch.nonzero does two)
         self.last_counts = (Ni, Np)
         lin_img, lin_pts = lin[0, :Ni], lin[1, :Np]
         xyz = torch.empty(Ni + Np, 3, device=dev, dtype=_F32)
@@ -189,71 +198,65 @@ class BiFuser_N(nn.Module):
         xyz_img, xyz_pts = xyz[:Ni], xyz[Ni:]
         K = self.knum
         kw = dict(fps_num=2048, radius=6, max_cluster_samples=200, dist_thresh=13.3, num=K)
+        sr = SearchResult(Rows(cat4, B, X, Y, Z, 4 * C), lin_img, lin_pts)
+        cur = torch.cuda.current_stream(dev)
         if Np and Ni:
             vox = (X, Y, Z) if B == 1 else None
             # The two search directions are independent (each is a 2047-step dependent chain on
             # one CU): the img->pts search runs on a side stream next to the pts->img one.
-            cur = torch.cuda.current_stream(dev)
             side = _side_stream(dev, cur)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 # img queries <- nearest pts keys (:150-162); for knum > 1 the reference indexes
                 # inds_img with the pts ordinals (:158) -- kept
-                near_pts = _fps_nn_xyz(xyz_img, xyz_pts, q_lin=lin_img if vox else None, grid=vox, which=1, home=cur, **kw)
-                rows_p = torch.empty(K, Ni, device=dev, dtype=_I32)
+                sr.near_pts = _fps_nn_xyz(xyz_img, xyz_pts, q_lin=lin_img if vox else None, grid=vox, which=1, home=cur, **kw)
+                sr.rows_p = torch.empty(K, Ni, device=dev, dtype=_I32)
                 base, nbase = (lin_pts, Np) if K == 1 else (lin_img, Ni)
                 for k in range(K):
-                    call("coocc_index_rows_i32", ptr(base), nbase, ptr(near_pts[k]), Ni, ptr(rows_p[k]))
+                    call("coocc_index_rows_i32", ptr(base), nbase, ptr(sr.near_pts[k]), Ni, ptr(sr.rows_p[k]))
+                sr.done_side = torch.cuda.Event()
+                sr.done_side.record()
             # pts queries <- nearest img keys (bifuser_n.py:137-148)
-            near_img = _fps_nn_xyz(xyz_pts, xyz_img, q_lin=lin_pts if vox else None, grid=vox, which=0, home=cur, **kw)
-            if early is not None:
-                early(Rows(cat4, B, X, Y, Z, 4 * C), rows_ready)
-            rows = torch.empty(K, Np, device=dev, dtype=_I32)
+            sr.near_img = _fps_nn_xyz(xyz_pts, xyz_img, q_lin=lin_pts if vox else None, grid=vox, which=0, home=cur, **kw)
+            sr.rows = torch.empty(K, Np, device=dev, dtype=_I32)
             for k in range(K):
-                call("coocc_index_rows_i32", ptr(lin_img), Ni, ptr(near_img[k]), Np, ptr(rows[k]))
-            gate = dense_gate()
-            if gate is not None:
-                gate.enter()       # dense stage starts here; released by COOCC_Ray.forward_hot_path
-            gather_conv_rows(cat4, 0, packs["knn"], rows, lin_pts, cat4, 2 * C, C, C)
-            cur.wait_stream(side)
-            for t in (near_pts, rows_p):
-                t.record_stream(cur)
-            gather_conv_rows(cat4, C, packs["knn"], rows_p, lin_img, cat4, 3 * C, 0, C)
-            self.last_near = (near_img, near_pts)
+                call("coocc_index_rows_i32", ptr(lin_img), Ni, ptr(sr.near_img[k]), Np, ptr(sr.rows[k]))
+            sr.keep = (xyz, lin, img, pts)       # referenced by kernels still in flight on the side stream
         elif Np or Ni:
             raise IndexError("BiFuser_N: one modality has no non-empty voxel (the reference fails on empty keys)")
-        return Rows(cat4, B, X, Y, Z, 4 * C), (lin_img, lin_pts)
+        sr.done_main = torch.cuda.Event()
+        sr.done_main.record()
+        return sr
 
-    def forward(self, img_voxel_feats, pts_voxel_feats):
-        """[B,C,X,Y,Z] x2 -> [B,out,X,Y,Z] (bifuser_n.py:127-174).
+    def finish(self, sr):
+        """G1 on the current stream: the two gather -> knn_enc -> gate -> scatter GEMMs that complete the concat
+        rows of a ``SearchResult`` (bifuser_n.py:138-169).  Returns (rows [B*V,4C], (lin_img, lin_pts))."""
+        cat4 = sr.cat4.t
+        dev = cat4.device
+        C = self.in_channels
+        cur = torch.cuda.current_stream(dev)
+        packs = self._packed()
+        cur.wait_event(sr.done_main)
+        for t in sr.tensors():
+            t.record_stream(cur)             # allocated on the search stream(s), consumed here
+        if sr.rows is not None:
+            gather_conv_rows(cat4, 0, packs["knn"], sr.rows, sr.lin_pts, cat4, 2 * C, C, C)
+            cur.wait_event(sr.done_side)
+            gather_conv_rows(cat4, C, packs["knn"], sr.rows_p, sr.lin_img, cat4, 3 * C, 0, C)
+            self.last_near = (sr.near_img, sr.near_pts)
+        return sr.cat4, (sr.lin_img, sr.lin_pts)
 
-        con_enc.0 is linear in its 4C input channels, and the first 2C (the raw img / pts features)
-        do not depend on the index search: that half of the convolution runs on a third stream under
-        the two serial FPS chains, the other half accumulates onto its raw partial sums (res_mode 3)
-        and applies BN + ReLU."""
+    def fuse(self, img_voxel_feats, pts_voxel_feats, search=None):
+        """K1..G1: returns the [B*V, 4C] concat rows (img | pts | fused_img | fused_pts)."""
+        return self.finish(search if search is not None else self.search(img_voxel_feats, pts_voxel_feats))
+
+    def forward(self, img_voxel_feats, pts_voxel_feats, search=None):
+        """[B,C,X,Y,Z] x2 -> [B,out,X,Y,Z] (bifuser_n.py:127-174).  ``search``: a ``SearchResult`` of the same
+        inputs computed ahead of time (cross-sample pipelining)."""
         if not img_voxel_feats.is_cuda:
             raise _lib.CooccError("BiFuser_N runs on the GPU only (no CPU fallback)")
         packs = self._packed()
-        C = self.in_channels
-        dev = img_voxel_feats.device
-        cur = torch.cuda.current_stream(dev)
-        state = {}
-
-        def early(cat4, rows_ready):
-            side = _side_stream(dev, cur, 1)
-            side.wait_event(rows_ready)                 # img | pts halves of the rows are written; do NOT wait for the searches
-            with torch.cuda.stream(side):
-                half = Rows(cat4.t, cat4.B, cat4.X, cat4.Y, cat4.Z, 2 * C, 0)
-                state["partial"] = conv_rows(half, packs["c0a"], relu=False)
-            state["side"] = side
-
-        cat4, _ = self.fuse(img_voxel_feats, pts_voxel_feats, early=early if SPLIT_CON_ENC else None)
-        if "partial" in state:
-            cur.wait_stream(state["side"])
-            state["partial"].t.record_stream(cur)
-            half = Rows(cat4.t, cat4.B, cat4.X, cat4.Y, cat4.Z, 2 * C, 2 * C)
-            x = conv_rows(half, packs["c0b"], relu=True, res=state["partial"], res_mode=3)
-        else:
-            x = conv_rows(cat4, packs["c0"], relu=True)
+        cat4, _ = self.fuse(img_voxel_feats, pts_voxel_feats, search)
+        x = conv_rows(cat4, packs["c0"], relu=True)
         x = conv_rows(x, packs["c3"], relu=True)
         return x.as_ncdhw()

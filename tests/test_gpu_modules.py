@@ -336,3 +336,40 @@ def test_eval_semantic_full_size_and_accumulation(dev):
     assert np.allclose(m["class_ious"], tp / (ssc.sum(0) + ssc.sum(1) - tp))
     # no visible mask -> OCC block untouched and None returned, as upstream
     assert ev.evaluation_semantic(pred.to(dev), gt.to(dev), 'SSC')[1] is None
+
+
+def test_prefetched_search_matches_sequential(dev):
+    """Cross-sample pipelining (bench.py --prefetch): the index search of the NEXT sample issued from a helper thread
+    on its own high-priority stream while the current sample runs its dense stage must give bit-identical outputs."""
+    from concurrent.futures import ThreadPoolExecutor
+    grid, C = (50, 50, 8), 32        # both modalities keep > 2048 voxels (the large search path, as at full size)
+    cfg = synth.model_cfg(C=C, knum=2, final_occ_size=(100, 100, 16), point_cloud_range=(-25, -25, -5.0, 25, 25, 3.0))
+    model, _ = load_seeded(pkg.build_detector(cfg), 11, dev)
+    samples = []
+    for seed in (3, 4, 5):
+        img, pts = synth.voxel_inputs(grid, C=C, seed=seed)
+        rig = synth.camera_rig(6, (64, 176), seed=seed)
+        tr = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synth.rig_transform(rig))
+        samples.append((img.to(dev), pts.to(dev), [synth.image_feats(6, (4, 11), 512, seed=seed).to(dev)], tr))
+    with torch.no_grad():
+        want = [model.forward_hot_path(s[0], s[1], None, s[2], s[3], render=False) for s in samples]
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=dev, priority=-1)
+
+        def do_search(s):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(side), torch.no_grad():
+                return model.search(s[0], s[1])
+        pool = ThreadPoolExecutor(1)
+        fut = pool.submit(do_search, samples[0])
+        got = []
+        for i, s in enumerate(samples):
+            sr = fut.result()
+            if i + 1 < len(samples):
+                fut = pool.submit(do_search, samples[i + 1])
+            got.append(model.forward_hot_path(s[0], s[1], None, s[2], s[3], render=False, search=sr))
+        torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a["pred_c"], b["pred_c"]) and torch.equal(a["voxel_feats"], b["voxel_feats"])
+        assert torch.equal(a["output_coords_fine"][0], b["output_coords_fine"][0])
+        assert torch.equal(a["output_voxels_fine"][0], b["output_voxels_fine"][0])
