@@ -28,8 +28,9 @@ WINO_MIN_ROWS = int(__import__("os").environ.get("COOCC_WINO_MIN_ROWS", "8192"))
 WINO_TILE = int(__import__("os").environ.get("COOCC_WINO_TILE", "4"))   # F(4x4,3x3) where X, Y >= 8, else F(2x2,3x3)
 
 
-def conv_kernel_name(M, Cout, table):
+def conv_kernel_name(M, Cout, table, hint=0):
     """Mirror of the tile-configuration rule in csrc/conv3d.hip (coocc_conv_fwd)."""
+    hint = hint or TILE_HINT
     if Cout <= 32:
         t = "128,32,32,32"
     elif Cout <= 64:
@@ -42,7 +43,7 @@ def conv_kernel_name(M, Cout, table):
         def util(bm):
             tiles = -(-M // bm) * (-(-Cout // 128))
             return tiles * bm / float(-(-tiles // 512) * 512)
-        big = TILE_HINT == 160 or (TILE_HINT == 0 and util(160) > util(128) * 1.02)
+        big = hint == 160 or (hint == 0 and util(160) > util(128) * 1.02)
         if not table and CONV_V2:
             return "k_conv2<%d>" % (160 if big else 128)      # software-pipelined large-layer kernel
         t = "160,128,160,32" if big else "128,128,64,64"
@@ -194,18 +195,21 @@ def _lcm(a, b):
 
 
 def wino_plan(x, pc, M, res_mode):
-    """None, or (tile, points, Tx, Ty, rows, G) for the Winograd path of this layer."""
+    """None, or (tile, points, Tx, Ty, rows, G, tile_hint) for the Winograd path of this layer."""
     if not WINO or pc._w_raw is None or M < WINO_MIN_ROWS or res_mode not in (0, 1) or pc.Cin % 4:
         return None
     tile = 4 if ((pc.wino_tile or WINO_TILE) == 4 and min(x.X, x.Y) >= 8) else 2
     Tx, Ty = -(-x.X // tile), -(-x.Y // tile)
     rows = x.B * Tx * Ty * x.Z
-    g = _lcm(640, x.Z)
-    G = -(-rows // g) * g
+    # group rows: a multiple of the GEMM's M tile and of Z.  640 = lcm(128, 160) leaves the tile choice to the
+    # kernel; when that would pad much more than a 128-row granule (50x50x4: 676 -> 1280 vs 768), pin 128-row tiles
+    g640, g128 = _lcm(640, x.Z), _lcm(128, x.Z)
+    G640, G128 = -(-rows // g640) * g640, -(-rows // g128) * g128
+    G, hint = (G640, 0) if G640 <= 1.05 * G128 else (G128, 128)
     pts = (tile + 2) ** 2
     if pts * G * max(pc.Cin, pc.Cout) * 4 >= 0xFFFFFF00:
         return None     # the pipelined GEMM addresses its operands with 32-bit buffer offsets
-    return tile, pts, Tx, Ty, rows, G
+    return tile, pts, Tx, Ty, rows, G, hint
 
 
 def wino_eligible(x, pc, M, res_mode):
@@ -216,7 +220,7 @@ def conv_rows_wino(x, pc, out, relu, res, plan):
     """3x3x3 stride-1 conv as Winograd F(m x m,3x3) over (x,y) + direct z taps: input transform, one grouped
     GEMM launch (one weight pack per transform point), output transform with the epilogue."""
     dev = x.t.device
-    tile, pts, Tx, Ty, rows, G = plan
+    tile, pts, Tx, Ty, rows, G, hint = plan
     V = _wino_buffer(dev, "V", pts * G * pc.Cin)
     Mb = _wino_buffer(dev, "M", pts * G * pc.Cout)
     wp = pc.wino_pack(tile)
@@ -233,8 +237,8 @@ def conv_rows_wino(x, pc, out, relu, res, plan):
     d.ksize, d.stride, d.pad = 3, 1, 1
     d.kx, d.ky, d.kz, d.px, d.py, d.pz = 1, 1, 3, 0, 0, 1
     d.wgroup_rows = G
-    d.relu, d.res_mode, d.splitk, d.tile_hint = 0, 0, 1, TILE_HINT
-    with TIMER.region(conv_kernel_name(pts * G, pc.Cout, False) + " wino%d" % tile, 2.0 * pts * rows * pc.Cin * pc.Cout * 3):
+    d.relu, d.res_mode, d.splitk, d.tile_hint = 0, 0, 1, (hint or TILE_HINT)
+    with TIMER.region(conv_kernel_name(pts * G, pc.Cout, False, hint) + " wino%d" % tile, 2.0 * pts * rows * pc.Cin * pc.Cout * 3):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     with TIMER.region("k_wino_out", 4.0 * pts * rows * pc.Cout + 4.0 * x.V * pc.Cout):
         call("coocc_wino_output", ptr(Mb), G, x.B, x.X, x.Y, x.Z, pc.Cout, tile, out.data(), out.stride, ptr(pc.scale),
