@@ -242,6 +242,52 @@ __global__ __launch_bounds__(256) void k_fine_sample_img(const float* __restrict
   }
 }
 
+// Parameter block of k_fine_sample_img built on the device: the 3x3 inverses (adjugate in fp64) and the packing
+// that the host used to do with ~20 tiny torch launches and a torch.inverse (which synchronises to read its
+// status word and so stalled the whole enqueue-ahead pipeline in the middle of the fine branch).
+__device__ __forceinline__ void inv3x3(const float* __restrict__ m, float* __restrict__ o) {
+  const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const double det = a * A + b * B + c * C, r = 1.0 / det;
+  o[0] = (float)(A * r); o[1] = (float)(-(b * i - c * h) * r); o[2] = (float)((b * f - c * e) * r);
+  o[3] = (float)(B * r); o[4] = (float)((a * i - c * g) * r);  o[5] = (float)(-(a * f - c * d) * r);
+  o[6] = (float)(C * r); o[7] = (float)(-(a * h - b * g) * r); o[8] = (float)((a * e - b * d) * r);
+}
+
+__global__ void k_projection_params(const float* __restrict__ rots, const float* __restrict__ trans,
+                                    const float* __restrict__ intrins, const float* __restrict__ post_rots,
+                                    const float* __restrict__ post_trans, const float* __restrict__ bda, int ncam,
+                                    float vs0, float vs1, float vs2, float lo0, float lo1, float lo2, float wimg1,
+                                    float himg1, float* __restrict__ prm) {
+  const int t = threadIdx.x;
+  if (t == 0) {
+    inv3x3(bda, prm);
+    prm[9] = vs0; prm[10] = vs1; prm[11] = vs2; prm[12] = lo0; prm[13] = lo1; prm[14] = lo2;
+    prm[15] = wimg1; prm[16] = himg1;
+  } else if (t <= ncam) {
+    const int cam = t - 1;
+    float* q = prm + FINE_HDR + cam * FINE_CAM_STRIDE;
+    inv3x3(rots + cam * 9, q);
+    for (int k = 0; k < 3; ++k) q[9 + k] = trans[cam * 3 + k];
+    for (int k = 0; k < 9; ++k) q[12 + k] = intrins[cam * 9 + k];
+    q[21] = post_rots[cam * 9 + 0]; q[22] = post_rots[cam * 9 + 1];
+    q[23] = post_rots[cam * 9 + 3]; q[24] = post_rots[cam * 9 + 4];
+    q[25] = post_trans[cam * 3 + 0]; q[26] = post_trans[cam * 3 + 1];
+  }
+}
+
+extern "C" int coocc_projection_params(const float* rots, const float* trans, const float* intrins, const float* post_rots,
+                                       const float* post_trans, const float* bda, int ncam, const float* hdr_host,
+                                       float* params, void* stream) {
+  COOCC_CHECK_ARG(rots && trans && intrins && post_rots && post_trans && bda && hdr_host && params && ncam > 0 && ncam < 64,
+                  "projection_params: bad args");
+  const float* h = hdr_host;
+  hipLaunchKernelGGL(k_projection_params, dim3(1), dim3(64), 0, as_stream(stream), rots, trans, intrins, post_rots, post_trans,
+                     bda, ncam, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], params);
+  COOCC_LAUNCH_CHECK("k_projection_params");
+  return COOCC_OK;
+}
+
 // Grouped form for the offset-major fine list of the head (f = o*n + i, 8 children per coarse voxel): one wave per
 // coarse voxel.  Lane o*ncam + cam projects child o into camera cam (the 8*ncam projections run in parallel
 // instead of every lane repeating all of them); then lanes = channels and the (child, camera) pairs that see the

@@ -8,7 +8,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import call, host_i32, ptr
+from ._lib import call, host_f32, host_i32, ptr
 from .backbone import build_bn
 from .core import PackCache, PackedConv, Rows, conv_rows, linear_rows, to_rows
 from .registry import HEADS
@@ -167,19 +167,20 @@ class OccHead(nn.Module):
         return linear_rows(h, p["fine3"]), fine_xyz
 
     def _projection_params(self, transform, ovf, dev):
-        """Per-sample matrices of project_points_on_img (coordinate_transform.py:25-65), b = 0."""
-        rots, trans, intrins, post_rots, post_trans, bda = [t[0].float() for t in transform[:6]]
+        """Per-sample matrices of project_points_on_img (coordinate_transform.py:25-65), b = 0, packed by one
+        device kernel (no torch.inverse: it synchronises with the host)."""
+        rots, trans, intrins, post_rots, post_trans, bda = [t[0].float().contiguous() for t in transform[:6]]
         r = self.cascade_ratio
         W_occ, H_occ, D_occ = ovf.X * r, ovf.Y * r, ovf.Z * r
-        pr = self.point_cloud_range.to(dev)
-        voxel_size = (pr[3:] - pr[:3]) / torch.tensor([W_occ - 1, H_occ - 1, D_occ - 1], device=dev)
+        pr = self.point_cloud_range                      # CPU tensor: fp32 arithmetic as the reference's
+        voxel_size = (pr[3:] - pr[:3]) / torch.tensor([W_occ - 1, H_occ - 1, D_occ - 1], dtype=_F32)
         W_img = float(transform[-1][1][0]) if torch.is_tensor(transform[-1][1]) else float(transform[-1][1])
         H_img = float(transform[-1][0][0]) if torch.is_tensor(transform[-1][0]) else float(transform[-1][0])
-        hdr = torch.cat([bda.inverse().reshape(-1), voxel_size, pr[:3],
-                         torch.tensor([W_img - 1, H_img - 1], device=dev, dtype=_F32)])
-        cams = torch.cat([rots.inverse().reshape(-1, 9), trans.reshape(-1, 3), intrins.reshape(-1, 9),
-                          post_rots[:, :2, :2].reshape(-1, 4), post_trans[:, :2].reshape(-1, 2)], 1)
-        return torch.cat([hdr, cams.reshape(-1)]).contiguous()
+        ncam = rots.shape[0]
+        params = torch.empty(17 + 27 * ncam, device=dev, dtype=_F32)
+        call("coocc_projection_params", ptr(rots), ptr(trans), ptr(intrins), ptr(post_rots), ptr(post_trans), ptr(bda), ncam,
+             host_f32(voxel_size.tolist() + pr[:3].tolist() + [W_img - 1, H_img - 1]), ptr(params))
+        return params
 
     # ---------------------------------------------------------------- forward
     def forward(self, voxel_feats, img_feats=None, img_metas=None, pts_feats=None, target_points=None,

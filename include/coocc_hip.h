@@ -247,6 +247,12 @@ int coocc_fine_sample_voxel(const float* vol, int C, int X, int Y, int Z, const 
 int coocc_fine_sample_img(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf,
                           const float* params, const int64_t* fine_xyz, int64_t nfine, float* feat,
                           int out_stride, int group8, void* stream);
+/* Builds the `params` block of coocc_fine_sample_img on the device (3x3 inverses included, no host sync):
+ * rots/intrins/post_rots:[ncam,3,3], trans/post_trans:[ncam,3], bda:[3,3] (device); hdr_host:[8] = voxel_size(3),
+ * range_lo(3), W_img-1, H_img-1; params:[17 + 27*ncam] (device). */
+int coocc_projection_params(const float* rots, const float* trans, const float* intrins, const float* post_rots,
+                            const float* post_trans, const float* bda, int ncam, const float* hdr_host,
+                            float* params, void* stream);
 /* nn.GroupNorm on 2-D rows [n,C] (+ReLU), in place (occ_head.py:70-83) */
 int coocc_groupnorm_rows(float* x, int64_t n, int C, int stride, int groups, const float* gamma,
                          const float* beta, float eps, int relu, void* stream);
