@@ -191,7 +191,8 @@ def main():
         step(model, samples[0], world)          # packs weights, sizes workspaces (untimed, extra to --warmup)
     torch.cuda.synchronize()
     run(args.warmup, False)
-    core.TIMER.enabled = not args.no_kernel_timing
+    core.TIMER.enabled = 0 if args.no_kernel_timing else (2 if args.kernel_table else 1)
+    core.TIMER.only = ("k_conv", "k_render_nearest", "k_upsample_maps")      # what the roofline objects below need
     core.TIMER.reset()
     cdist.barrier()
     torch.cuda.synchronize()

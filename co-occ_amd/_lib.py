@@ -92,10 +92,14 @@ _lib = None
 
 class KernelTimer:
     """Optional per-launch HIP-event timing on the launch stream (bench.py's roofline numbers).
-    Disabled by default; when enabled each wrapped launch records an event pair."""
+    Disabled by default.  ``enabled`` = 1 (True): only the regions that declare their work (the MFMA GEMMs, the
+    Winograd transforms, the render pair) record an event pair; 2: every C-ABI call does (bench.py --kernel-table).
+    Each pair costs host time and a barrier packet on the stream, so level 2 perturbs the throughput it measures
+    (r50: 90.7 samples/s untimed, 81 at level 2)."""
 
     def __init__(self):
         self.enabled = False
+        self.only = None          # level 1: optional tuple of tag prefixes to restrict the timed regions further
         self.records = []
 
     class _Region:
@@ -103,14 +107,16 @@ class KernelTimer:
             self.o, self.tag, self.work = owner, tag, work
 
         def __enter__(self):
-            if self.o.enabled:
+            lvl = int(self.o.enabled)
+            self.on = lvl >= 2 or (lvl == 1 and self.work > 0 and (self.o.only is None or self.tag.startswith(self.o.only)))
+            if self.on:
                 self.s = torch.cuda.Event(enable_timing=True)
                 self.e = torch.cuda.Event(enable_timing=True)
                 self.s.record()
             return self
 
         def __exit__(self, *a):
-            if self.o.enabled:
+            if self.on:
                 self.e.record()
                 self.o.records.append((self.tag, self.work, self.s, self.e))
             return False
