@@ -276,7 +276,7 @@ class RenderNearestFn(torch.autograd.Function):
         zvals = torch.linspace(0, D, D, device=table.device)
         maps = torch.empty(N, H, W, 4, device=table.device, dtype=_F32)
         t = table.float().contiguous()
-        call("coocc_render_nearest", ptr(t), X, Y, Z, ptr(gemo), ptr(zvals), N, D, H, W, host_f32(RENDER_BOUNDS), ptr(maps))
+        call("coocc_render_nearest", ptr(t), X, Y, Z, ptr(gemo), ptr(zvals), N, D, H, W, host_f32(RENDER_BOUNDS), 0, ptr(maps))
         ctx.save_for_backward(t, gemo, zvals)
         ctx.grid = grid
         return maps

@@ -57,6 +57,11 @@ struct __attribute__((packed, aligned(4))) Geo3 { float x, y, z; };
 // Phase 2, one wave per ray with lanes along depth (CH consecutive samples per lane): 16-byte gather
 // of the voxel's (sigma, rgb) from the L2-resident table, alpha, exclusive transmittance by a
 // wave-level multiplicative scan, weighted sums by DPP wave reductions.
+// ACT = 1: the table already holds sigmoid(rgb) (coocc_render_activate_table: 3 exp + 3 rcp per VOXEL instead of
+// per ray sample); ACT = 0: raw logits (the form the backward kernel differentiates).
+// (A persistent variant that prefetched the next tile's geometry into registers under phase 2 was measured
+// slower -- 38-48 us vs 32 at r101: the 48 extra VGPRs cost more occupancy than the overlap returned.)
+template <int ACT>
 __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict__ table, int Y, int Z,
                                                          const float* __restrict__ geom,
                                                          const float* __restrict__ zvals, int D, int H, int W, int rt,
@@ -115,9 +120,13 @@ __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict_
         const bool in = p0 >= 0;
         // hardware exp / rcp (<= 1 ulp-class error, far inside the 1e-4 parity bound)
         al[j] = 1.f - __expf(-fmaxf(fmaxf(t[0], 0.f) * dist, 0.f));
-        cr[j] = in ? __frcp_rn(1.f + __expf(-t[1])) : 0.5f;
-        cg[j] = in ? __frcp_rn(1.f + __expf(-t[2])) : 0.5f;
-        cb[j] = in ? __frcp_rn(1.f + __expf(-t[3])) : 0.5f;
+        if (ACT) {
+          cr[j] = in ? t[1] : 0.5f; cg[j] = in ? t[2] : 0.5f; cb[j] = in ? t[3] : 0.5f;
+        } else {
+          cr[j] = in ? __frcp_rn(1.f + __expf(-t[1])) : 0.5f;
+          cg[j] = in ? __frcp_rn(1.f + __expf(-t[2])) : 0.5f;
+          cb[j] = in ? __frcp_rn(1.f + __expf(-t[3])) : 0.5f;
+        }
         prod *= 1.f - al[j] + 1e-10f;
       }
     }
@@ -151,9 +160,27 @@ __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict_
   }
 }
 
+// sigmoid of the rgb logits once per voxel (in place on columns 1..3 of the [V,4] table)
+__global__ __launch_bounds__(256) void k_render_activate_table(float* __restrict__ table, int V) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  f32x4 t = *(f32x4*)(table + (size_t)v * 4);
+  t[1] = __frcp_rn(1.f + __expf(-t[1]));
+  t[2] = __frcp_rn(1.f + __expf(-t[2]));
+  t[3] = __frcp_rn(1.f + __expf(-t[3]));
+  *(f32x4*)(table + (size_t)v * 4) = t;
+}
+
+extern "C" int coocc_render_activate_table(float* table, int V, void* stream) {
+  COOCC_CHECK_ARG(table && V > 0, "render_activate_table: bad args");
+  hipLaunchKernelGGL(k_render_activate_table, dim3(cdiv(V, 256)), dim3(256), 0, as_stream(stream), table, V);
+  COOCC_LAUNCH_CHECK("k_render_activate_table");
+  return COOCC_OK;
+}
+
 extern "C" int coocc_render_nearest(const float* table, int X, int Y, int Z, const float* geom,
                                     const float* zvals, int N, int D, int H, int W, const float* bounds_host,
-                                    float* maps, void* stream) {
+                                    int activated, float* maps, void* stream) {
   COOCC_CHECK_ARG(table && geom && zvals && maps && bounds_host, "render_nearest: null pointer");
   COOCC_CHECK_ARG(N > 0 && D > 0 && D <= 256 && H > 0 && W > 0, "render_nearest: bad sizes (D <= 256)");
   const float* bd = bounds_host;  // xbound(3), ybound(3), zbound(3) = lo, hi, step (coocc_ray.py:577)
@@ -165,13 +192,20 @@ extern "C" int coocc_render_nearest(const float* table, int X, int Y, int Z, con
   // the reference would raise IndexError where the hard-coded bounds exceed the volume
   COOCC_CHECK_ARG(nx <= (float)X && ny <= (float)Y && nz <= (float)Z && X <= 1024 && Y <= 1024 && Z <= 1024,
                   "render_nearest: render bounds exceed the voxel volume");
-  const int tiles = (W + RT_MAX - 1) / RT_MAX;
-  const int rt = (W + tiles - 1) / tiles;            // balanced tiles: W = 100 -> 4 x 25, W = 44 -> 2 x 22
+  // full 32-ray tiles plus one remainder tile (W = 100 -> 32,32,32,4): phase 1 keeps all 32 lanes of a depth
+  // phase busy and phase 2 walks 8 rays per step, so 25-ray balanced tiles wasted 22 % of both (4 steps for 25 rays)
+  static const int rt_env = getenv("COOCC_RENDER_RT") ? atoi(getenv("COOCC_RENDER_RT")) : 0;
+  const int rt = rt_env > 0 ? min(rt_env, RT_MAX) : (W < RT_MAX ? W : RT_MAX);
+  const int tiles = (W + rt - 1) / rt;
   size_t lds = sizeof(int) * (size_t)rt * (D + 1);
   static const int dbg = getenv("COOCC_RENDER_DBG") ? atoi(getenv("COOCC_RENDER_DBG")) : 0;   // timing experiments only
   dim3 grid(tiles, H, N);
-  hipLaunchKernelGGL(k_render_nearest, grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
-                     lox, loy, loz, dx, dy, dz, nx, ny, nz, maps, dbg);
+  if (activated)
+    hipLaunchKernelGGL(k_render_nearest<1>, grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
+                       lox, loy, loz, dx, dy, dz, nx, ny, nz, maps, dbg);
+  else
+    hipLaunchKernelGGL(k_render_nearest<0>, grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
+                       lox, loy, loz, dx, dy, dz, nx, ny, nz, maps, dbg);
   COOCC_LAUNCH_CHECK("k_render_nearest");
   return COOCC_OK;
 }

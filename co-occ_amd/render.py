@@ -10,6 +10,17 @@ from .core import PackCache, PackedConv, Rows, linear_rows
 
 _F32 = torch.float32
 RENDER_BOUNDS = [-50., 50., 1., -50., 50., 1., -5., 3., 1.0]     # hard-coded at coocc_ray.py:577
+# camera chunks for overlapping the ALU-bound ray kernel with the store-bound upsample on a side stream.  Measured: the
+# extra launches / events cost more host time than the overlap returns at 6 cameras (r101 pair 70 -> 138 us at 2 chunks)
+RENDER_CHUNKS = int(__import__("os").environ.get("COOCC_RENDER_CHUNKS", "1"))
+_render_sides = {}
+
+
+def _render_side(dev, cur):
+    key = (dev.index, cur.cuda_stream)
+    if key not in _render_sides:
+        _render_sides[key] = torch.cuda.Stream(device=dev, priority=getattr(cur, "priority", 0))
+    return _render_sides[key]
 
 
 class SinusoidalEncoder(nn.Module):
@@ -81,15 +92,36 @@ def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16):
     zvals = torch.linspace(0, D, D, device=dev)
     maps = torch.empty(N, H, W, 4, device=dev, dtype=_F32)
     from .core import TIMER
-    # algorithmic HBM bytes: geom read + table read + small maps written, then
-    # small maps read + upsampled maps written
-    with TIMER.region("k_render_nearest", 12.0 * N * D * H * W + 16.0 * vf.V + 16.0 * N * H * W):
-        call("coocc_render_nearest", ptr(table), vf.X, vf.Y, vf.Z, ptr(g), ptr(zvals), N, D, H, W, host_f32(RENDER_BOUNDS),
-             ptr(maps))
     rgbs = torch.empty(N, H * scale, W * scale, 3, device=dev, dtype=_F32)
     depths = torch.empty(N, H * scale, W * scale, device=dev, dtype=_F32)
-    with TIMER.region("k_upsample_maps", 16.0 * N * H * W + 16.0 * N * H * W * scale * scale):
-        call("coocc_upsample_maps", ptr(maps), N, H, W, scale, ptr(rgbs), ptr(depths))
+    call("coocc_render_activate_table", ptr(table), vf.V)           # sigmoid(rgb) once per voxel, not per ray sample
+    # algorithmic HBM bytes: geom read + table read + small maps written, then small maps read +
+    # upsampled maps written.  The ray kernel is ALU-bound (alpha, scan), the x16 upsample store-bound: cameras are
+    # processed in chunks and the upsample of chunk c runs on a side stream under the rays of chunk c+1.
+    chunks = max(1, min(RENDER_CHUNKS, N))
+    per = -(-N // chunks)
+    cur = torch.cuda.current_stream(dev)
+    side = _render_side(dev, cur) if chunks > 1 else None
+    by_rays = 12.0 * N * D * H * W + 16.0 * vf.V + 16.0 * N * H * W
+    by_up = 16.0 * N * H * W + 16.0 * N * H * W * scale * scale
+    with TIMER.region("k_render_nearest+k_upsample_maps", by_rays + by_up):
+        for c0 in range(0, N, per):
+            nc = min(per, N - c0)
+            call("coocc_render_nearest", ptr(table), vf.X, vf.Y, vf.Z, ptr(g[c0:c0 + nc]), ptr(zvals), nc, D, H, W,
+                 host_f32(RENDER_BOUNDS), 1, ptr(maps[c0:c0 + nc]))
+            if side is None:
+                call("coocc_upsample_maps", ptr(maps[c0:c0 + nc]), nc, H, W, scale, ptr(rgbs[c0:c0 + nc]), ptr(depths[c0:c0 + nc]))
+            else:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    call("coocc_upsample_maps", ptr(maps[c0:c0 + nc]), nc, H, W, scale, ptr(rgbs[c0:c0 + nc]),
+                         ptr(depths[c0:c0 + nc]))
+        if side is not None:
+            cur.wait_stream(side)
+            for t in (maps, rgbs, depths):
+                t.record_stream(side)
     return rgbs, depths, maps
 
 

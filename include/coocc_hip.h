@@ -313,10 +313,14 @@ int coocc_bev_pool_coords(const float* x, const int64_t* coords, int n, int C, i
  * table:[X*Y*Z,4] = raw (sigma, r, g, b) head outputs per voxel -- the heads are pointwise,
  * so per-voxel evaluation equals the reference's per-sample evaluation; geom:[N,D,H,W,3];
  * zvals:[D] = linspace(0,D,D) (:614); bounds_host = xbound,ybound,zbound (lo,hi,step) of
- * :577.  maps:[N,H,W,4] = (r,g,b,depth) before upsampling. */
+ * :577.  maps:[N,H,W,4] = (r,g,b,depth) before upsampling.  activated != 0: columns 1..3 of the table
+ * already hold sigmoid(rgb) (coocc_render_activate_table). */
 int coocc_render_nearest(const float* table, int X, int Y, int Z, const float* geom,
                          const float* zvals, int N, int D, int H, int W, const float* bounds_host,
-                         float* maps, void* stream);
+                         int activated, float* maps, void* stream);
+/* sigmoid of the rgb logits once per voxel, in place on columns 1..3 of table:[V,4] (3 exp + 3 rcp per voxel
+ * instead of per ray sample). */
+int coocc_render_activate_table(float* table, int V, void* stream);
 /* x`scale` bilinear upsample, align_corners=False (coocc_ray.py:617-622):
  * maps [N,H,W,4] -> rgbs [N,sH,sW,3], depths [N,sH,sW] */
 int coocc_upsample_maps(const float* maps, int N, int H, int W, int scale, float* rgbs,

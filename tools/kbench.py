@@ -101,10 +101,27 @@ def bench_render():
         dep = torch.empty(N, fH * 16, fW * 16, device=dev)
         from co_occ_amd._lib import host_f32
         b = host_f32(R.RENDER_BOUNDS)
-        t1 = timeit(lambda: call("coocc_render_nearest", ptr(table), 100, 100, 8, ptr(gemo), ptr(zv), N, D, fH, fW, b, ptr(maps)), n=20)
+        call("coocc_render_activate_table", ptr(table), 80000)
+        t1 = timeit(lambda: call("coocc_render_nearest", ptr(table), 100, 100, 8, ptr(gemo), ptr(zv), N, D, fH, fW, b, 1, ptr(maps)), n=20)
         t2 = timeit(lambda: call("coocc_upsample_maps", ptr(maps), N, fH, fW, 16, ptr(rgbs), ptr(dep)), n=20)
         by1 = 12.0 * N * D * fH * fW + 16.0 * 80000 + 16.0 * N * fH * fW
         by2 = 16.0 * N * fH * fW + 16.0 * N * fH * fW * 256
+        from co_occ_amd import render as Rm
+        class _VF:      # the table is passed in directly: stub the per-voxel heads
+            pass
+        def pair(chunks):
+            Rm.RENDER_CHUNKS = chunks
+            saved = Rm.voxel_table
+            Rm.voxel_table = lambda a, b, vf: table.clone()
+            try:
+                vfr = core.Rows(torch.empty(80000, 4, device=dev), 1, 100, 100, 8, 4)
+                return timeit(lambda: Rm.render_block(None, None, vfr, gemo[None], 16), n=20)
+            finally:
+                Rm.voxel_table = saved
+        tp = {c: pair(c) for c in (1, 2, 3, 6)}
+        print("render %-4s pair via render_block (activate + rays + upsample, incl. table clone): %s  -> best %.0f GB/s = %.3f of 8 TB/s" % (
+            name, "  ".join("chunks=%d %.3f ms" % kv for kv in tp.items()), (by1 + by2) / min(tp.values()) / 1e6,
+            (by1 + by2) / min(tp.values()) / 1e6 / 8000))
         print("render %-4s rays %.3f ms (%.0f GB/s of %.1f MB)  upsample %.3f ms (%.0f GB/s of %.1f MB)  total %.0f GB/s = %.3f of 8 TB/s" % (
             name, t1, by1 / t1 / 1e6, by1 / 1e6, t2, by2 / t2 / 1e6, by2 / 1e6, (by1 + by2) / (t1 + t2) / 1e6, (by1 + by2) / (t1 + t2) / 1e6 / 8000))
 
