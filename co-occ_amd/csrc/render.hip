@@ -21,6 +21,11 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+// DPP move whose lanes without a valid source keep the multiplicative identity
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32_id(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3F800000, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
   v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict_
         if (d + 1 < D) {
           const int p1 = s_pos[r * DS + d + 1];
           float ex = (float)((p1 & 1023) - x0), ey = (float)(((p1 >> 10) & 1023) - y0), ez = (float)(((p1 >> 20) & 1023) - z0);
-          dist = __fsqrt_rn(ex * ex + ey * ey + ez * ez);
+          dist = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);   // v_sqrt_f32 (1 ulp) on small integers
         }
         const bool in = p0 >= 0;
         // hardware exp / rcp (<= 1 ulp-class error, far inside the 1e-4 parity bound)
@@ -130,14 +135,16 @@ __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict_
         prod *= 1.f - al[j] + 1e-10f;
       }
     }
-    // exclusive multiplicative scan inside each half-wave
+    // exclusive multiplicative scan inside each half-wave, all in DPP (no LDS crossbar): row_shr 1/2/4/8 inside the
+    // rows of 16 lanes (lanes without a source keep the identity 1.0), row_bcast:15 carries row 0 -> 1 and 2 -> 3,
+    // wave_shr:1 turns the inclusive scan into the exclusive one (the first lane of each half restarts at 1)
     float inc = prod;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-      float v = __shfl_up(inc, o, 32);
-      if (hl >= o) inc *= v;
-    }
-    float T = __shfl_up(inc, 1, 32);
+    inc *= dpp_f32_id<0x111>(inc);
+    inc *= dpp_f32_id<0x112>(inc);
+    inc *= dpp_f32_id<0x114>(inc);
+    inc *= dpp_f32_id<0x118>(inc);
+    inc *= __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3F800000, __builtin_bit_cast(int, inc), 0x142, 0xA, 0xF, false));
+    float T = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3F800000, __builtin_bit_cast(int, inc), 0x138, 0xF, 0xF, false));
     if (hl == 0) T = 1.f;
     float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f;
 #pragma unroll
