@@ -34,8 +34,6 @@ struct ConvK {
   size_t wgroup_floats;         // floats per weight pack
   int relu, res_mode, iters_per_split, total_iters, splitk;
   int mtiles, ntiles, mtiles_per_xcd;
-  int dephase;   // s_sleep units for the second workgroup of each CU (see k_conv)
-  int flags;     // bit0: s_setprio(1) around the MFMA cluster
   unsigned in_bytes, w_bytes;   // buffer sizes for the buffer_load variant (k_conv2)
 };
 
@@ -76,13 +74,6 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
     nt = id - mtile * p.ntiles;
   }
   const int m0 = mtile * BM, n0 = nt * BN;
-  // Two workgroups share a CU and run the same loop at the same speed; started together they stay
-  // in phase (both load, then both fight for the matrix pipe).  Delaying every second one by about
-  // half a K-chunk lets one workgroup's loads/barriers sit under the other's MFMAs.
-  if (p.dephase > 0 && ((slot >> 5) & 1)) {
-    for (int i = 0; i < p.dephase; i += 64) __builtin_amdgcn_s_sleep(64);
-  }
-
   const int tid = threadIdx.x;
   const int piece = tid & 7, lrow = tid >> 3;
   const int wave = tid >> 6, lane = tid & 63;
@@ -173,7 +164,6 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
     if (more) gload(it + 1);
     const float* Ab = &As[cur][(wm * WM + li) * LDS_ST + h * 4];
     const float* Bb = &Bs[cur][(wn * WN + li) * LDS_ST + h * 4];
-    if (p.flags & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int q = 0; q < KC / 8; ++q) {
       f32x4 a[TM], b[TN];
@@ -189,7 +179,6 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     }
-    if (p.flags & 1) __builtin_amdgcn_s_setprio(0);
     if (NBUF == 2) {
       if (more) lstore(cur ^ 1);
       __syncthreads();
@@ -250,7 +239,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // layers (few M tiles, up to 113 MB of weights each) need the HBM latency of 2-3 chunks covered.
 // WG = true: the weight-grouped launch of the Winograd path (one weight pack per transform point); a separate
 // instantiation so that profilers list it under its own name.
-template <int BM, int PF = 1, int DBG = 0, bool WG = false>
+template <int BM, int PF = 1, bool WG = false>
 __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
   constexpr int TM = BM / 32, PA = BM / 32;
   __shared__ float As[2][BM * LDS_ST];
@@ -367,17 +356,17 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
   lfrag(0, 0, 0);
   int cur = 0;
   for (int it = it0; it < it1; ++it) {
-    if (DBG < 3) lfrag(cur, 1, 1);
-    if (DBG < 1) issue_loads(it + PF < it1, PF - 1);   // chunk it+PF -> newest slot (all-zero dummy past the end)
+    lfrag(cur, 1, 1);
+    issue_loads(it + PF < it1, PF - 1);   // chunk it+PF -> newest slot (all-zero dummy past the end)
     __builtin_amdgcn_sched_barrier(0);        // every load is in flight before the first MFMA (hipcc sinks them otherwise)
     mma(0, 0);
-    if (DBG < 3) lfrag(cur, 2, 0);
+    lfrag(cur, 2, 0);
     mma(1, 1);
-    if (DBG < 3) lfrag(cur, 3, 1);
+    lfrag(cur, 3, 1);
     mma(0, 2);
-    if (DBG < 2) lstore(cur ^ 1);             // A tile of chunk it+1 -> other LDS buffer
-    if (DBG < 2) __syncthreads();
-    if (DBG < 3) lfrag(cur ^ 1, 0, 0);        // first fragments of chunk it+1, under the last MFMA group
+    lstore(cur ^ 1);             // A tile of chunk it+1 -> other LDS buffer
+    __syncthreads();
+    lfrag(cur ^ 1, 0, 0);        // first fragments of chunk it+1, under the last MFMA group
     mma(1, 3);
 #pragma unroll
     for (int q = 0; q < 4; ++q) bcur[q] = bq[0][q];
@@ -446,11 +435,10 @@ static void launch_cfg(ConvK& k, bool table, hipStream_t s) {
   k.ntiles = (k.Cout + BN - 1) / BN;
   k.mtiles_per_xcd = k.mtiles >= 64 ? (k.mtiles + 7) / 8 : 0;   // XCD slabs only pay with many M tiles
   dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
-  static const int extra_lds = getenv("COOCC_CONV_EXTRA_LDS") ? atoi(getenv("COOCC_CONV_EXTRA_LDS")) : 0;  // experiments only
   if (table)
-    hipLaunchKernelGGL((k_conv<BM, BN, WM, WN, true>), grid, dim3(256), extra_lds, s, k);
+    hipLaunchKernelGGL((k_conv<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, k);
   else
-    hipLaunchKernelGGL((k_conv<BM, BN, WM, WN, false>), grid, dim3(256), extra_lds, s, k);
+    hipLaunchKernelGGL((k_conv<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, k);
 }
 
 extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
@@ -480,8 +468,6 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   k.wgroup_floats = (size_t)k.taps * k.kchunks * k.Npad * KC;
   k.relu = d->relu; k.res_mode = d->res_mode;
   k.total_iters = k.taps * k.kchunks;
-  { const char* e = getenv("COOCC_CONV_DEPHASE"); k.dephase = e ? atoi(e) : 0; }
-  { const char* e = getenv("COOCC_CONV_FLAGS"); k.flags = e ? atoi(e) : 0; }
 
   // tile configuration by problem shape
   int cfg;  // 0: 128x128 (64x64 waves), 1: 64x128 (32x64), 2: 128x64 (32x64), 3: 128x32 (32x32), 4: 160x128 (160x32)
@@ -538,16 +524,12 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
     k.ntiles = (k.Cout + 127) / 128;
     k.mtiles_per_xcd = k.mtiles >= 64 ? (k.mtiles + 7) / 8 : 0;
     dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
-    static const int dbg = getenv("COOCC_CONV_DBG") ? atoi(getenv("COOCC_CONV_DBG")) : 0;   // timing experiments only (wrong results)
     static const int pf160 = getenv("COOCC_CONV_PF160") ? atoi(getenv("COOCC_CONV_PF160")) : 2;
     static const int pf128 = getenv("COOCC_CONV_PF128") ? atoi(getenv("COOCC_CONV_PF128")) : 3;
     if (k.wgroup_rows > 0) {
-      if (cfg == 4) hipLaunchKernelGGL((k_conv2<160, 2, 0, true>), grid, dim3(256), 0, s, k);
-      else hipLaunchKernelGGL((k_conv2<128, 3, 0, true>), grid, dim3(256), 0, s, k);
+      if (cfg == 4) hipLaunchKernelGGL((k_conv2<160, 2, true>), grid, dim3(256), 0, s, k);
+      else hipLaunchKernelGGL((k_conv2<128, 3, true>), grid, dim3(256), 0, s, k);
     }
-    else if (cfg == 4 && dbg == 1) hipLaunchKernelGGL((k_conv2<160, 1, 1>), grid, dim3(256), 0, s, k);
-    else if (cfg == 4 && dbg == 2) hipLaunchKernelGGL((k_conv2<160, 1, 2>), grid, dim3(256), 0, s, k);
-    else if (cfg == 4 && dbg == 3) hipLaunchKernelGGL((k_conv2<160, 1, 3>), grid, dim3(256), 0, s, k);
     else if (cfg == 4 && pf160 == 2) hipLaunchKernelGGL((k_conv2<160, 2>), grid, dim3(256), 0, s, k);
     else if (cfg == 4) hipLaunchKernelGGL((k_conv2<160, 1>), grid, dim3(256), 0, s, k);
     else if (pf128 == 3) hipLaunchKernelGGL((k_conv2<128, 3>), grid, dim3(256), 0, s, k);

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict_
                                                          const float* __restrict__ geom,
                                                          const float* __restrict__ zvals, int D, int H, int W, int rt,
                                                          float lox, float loy, float loz, float dx, float dy, float dz,
-                                                         float nx, float ny, float nz, float* __restrict__ maps, int dbg) {
+                                                         float nx, float ny, float nz, float* __restrict__ maps) {
   extern __shared__ int s_pos[];    // [rt][D+1]
   const int DS = D + 1;
   const int wt = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
@@ -83,15 +83,13 @@ __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict_
 #pragma unroll 4
   for (int d = tid >> 5, r = tid & 31; d < D; d += 8) {
     if (r >= nray) continue;
-    Geo3 g = {1.f * d, 2.f * r, 0.5f};
-    if (!(dbg & 1)) g = *(const Geo3*)(geom + ((((size_t)n * D + d) * H + h) * W + w0 + r) * 3);
+    const Geo3 g = *(const Geo3*)(geom + ((((size_t)n * D + d) * H + h) * W + w0 + r) * 3);
     float gx = __fdiv_rn(g.x - lox, dx), gy = __fdiv_rn(g.y - loy, dy), gz = __fdiv_rn(g.z - loz, dz);
     bool in = gx >= 0.f && gx < nx && gy >= 0.f && gy < ny && gz >= 0.f && gz < nz;
     int ix = in ? (int)gx : 0, iy = in ? (int)gy : 0, iz = in ? (int)gz : 0;
     s_pos[r * DS + d] = ix | (iy << 10) | (iz << 20) | (in ? 0 : (1 << 31));
   }
   __syncthreads();
-  if (dbg & 2) { if (tid < nray) *(f32x4*)(maps + (((size_t)n * H + h) * W + w0 + tid) * 4) = f32x4{0.f, 0.f, 0.f, (float)s_pos[tid * DS]}; return; }
 
   // Phase 2: each HALF-wave (32 lanes) composites one ray, lanes along depth with CH consecutive
   // samples per lane -- two rays per wave instruction stream, a 5-step scan and row-local DPP
@@ -114,8 +112,7 @@ __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict_
       if (j < CH && d < D && live) {
         const int p0 = s_pos[r * DS + d];
         const int x0 = p0 & 1023, y0 = (p0 >> 10) & 1023, z0 = (p0 >> 20) & 1023;
-        f32x4 t = {0.3f * x0, 0.1f * y0, 0.2f * z0, 0.5f};
-        if (!(dbg & 4)) t = *(const f32x4*)(table + (((size_t)x0 * Y + y0) * Z + z0) * 4);
+        const f32x4 t = *(const f32x4*)(table + (((size_t)x0 * Y + y0) * Z + z0) * 4);
         float dist = 1e10f;
         if (d + 1 < D) {
           const int p1 = s_pos[r * DS + d + 1];
@@ -201,18 +198,16 @@ extern "C" int coocc_render_nearest(const float* table, int X, int Y, int Z, con
                   "render_nearest: render bounds exceed the voxel volume");
   // full 32-ray tiles plus one remainder tile (W = 100 -> 32,32,32,4): phase 1 keeps all 32 lanes of a depth
   // phase busy and phase 2 walks 8 rays per step, so 25-ray balanced tiles wasted 22 % of both (4 steps for 25 rays)
-  static const int rt_env = getenv("COOCC_RENDER_RT") ? atoi(getenv("COOCC_RENDER_RT")) : 0;
-  const int rt = rt_env > 0 ? min(rt_env, RT_MAX) : (W < RT_MAX ? W : RT_MAX);
+  const int rt = W < RT_MAX ? W : RT_MAX;
   const int tiles = (W + rt - 1) / rt;
   size_t lds = sizeof(int) * (size_t)rt * (D + 1);
-  static const int dbg = getenv("COOCC_RENDER_DBG") ? atoi(getenv("COOCC_RENDER_DBG")) : 0;   // timing experiments only
   dim3 grid(tiles, H, N);
   if (activated)
     hipLaunchKernelGGL(k_render_nearest<1>, grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
-                       lox, loy, loz, dx, dy, dz, nx, ny, nz, maps, dbg);
+                       lox, loy, loz, dx, dy, dz, nx, ny, nz, maps);
   else
     hipLaunchKernelGGL(k_render_nearest<0>, grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
-                       lox, loy, loz, dx, dy, dz, nx, ny, nz, maps, dbg);
+                       lox, loy, loz, dx, dy, dz, nx, ny, nz, maps);
   COOCC_LAUNCH_CHECK("k_render_nearest");
   return COOCC_OK;
 }
