@@ -207,8 +207,8 @@ def wino_plan(x, pc, M, res_mode):
     G640, G128 = -(-rows // g640) * g640, -(-rows // g128) * g128
     G, hint = (G640, 0) if G640 <= 1.05 * G128 else (G128, 128)
     pts = (tile + 2) ** 2
-    if pts * G * max(pc.Cin, pc.Cout) * 4 >= 0xFFFFFF00:
-        return None     # the pipelined GEMM addresses its operands with 32-bit buffer offsets
+    if pts * G >= 1 << 31:
+        return None     # row indices are 32-bit
     return tile, pts, Tx, Ty, rows, G, hint
 
 

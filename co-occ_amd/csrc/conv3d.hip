@@ -34,7 +34,8 @@ struct ConvK {
   size_t wgroup_floats;         // floats per weight pack
   int relu, res_mode, iters_per_split, total_iters, splitk;
   int mtiles, ntiles, mtiles_per_xcd;
-  unsigned in_bytes, w_bytes;   // buffer sizes for the buffer_load variant (k_conv2)
+  size_t in_bytes;              // total input bytes (k_conv2 bases its buffer descriptor at the tile's first row)
+  unsigned w_bytes;             // bytes of one weight pack
 };
 
 __device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t rrow) {
@@ -265,13 +266,13 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 31, h = lane >> 5;
 
-  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
   const float* wbase = WG ? p.w + (size_t)(m0 / p.wgroup_rows) * p.wgroup_floats : p.w;
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, p.w_bytes, 0x00020000);
 
   // per-thread A rows: voxel coordinates of tap (0,0,0) and its row index; rows past M are parked
   // outside the grid so every tap fails the bounds test
   int cx[PA], cy[PA], cz[PA], rrow[PA];
+  size_t base_off;
 #pragma unroll
   for (int a = 0; a < PA; ++a) {
     int m = m0 + lrow + 32 * a;
@@ -284,6 +285,23 @@ __global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
     cz[a] = oz * p.stride - p.pz;
     rrow[a] = ((b * p.Xi + cx[a]) * p.Yi + cy[a]) * p.Zi + cz[a];
   }
+  // Tile-relative addressing: input rows are visited in the lexicographic order of the outputs, so every row this
+  // tile touches lies in a short window above the row of (m0, tap 0).  The buffer descriptor is based there
+  // (64-bit pointer) and the per-lane offsets stay 32-bit for inputs of any size (the Winograd V buffer of a
+  // 200x200x16x512 volume is 5.2 GB).
+  {
+    int oz = m0 % p.Zo; int r = m0 / p.Zo;
+    int oy = r % p.Yo; r /= p.Yo;
+    int ox = r % p.Xo; int b = r / p.Xo;
+    int row0 = ((b * p.Xi + ox * p.stride - p.px) * p.Yi + oy * p.stride - p.py) * p.Zi + oz * p.stride - p.pz;
+    row0 = max(row0, 0);
+#pragma unroll
+    for (int a = 0; a < PA; ++a) rrow[a] -= row0;
+    base_off = (size_t)row0 * p.in_stride * 4;
+  }
+  const size_t remain = p.in_bytes > base_off ? p.in_bytes - base_off : 0;
+  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.in + base_off), 0,
+                                                                    (unsigned)(remain < 0xFFFFFF00ull ? remain : 0xFFFFFF00ull), 0x00020000);
   const unsigned voffB = (unsigned)(lane * 16);
   const int ngroups = p.Npad >> 7;
 
@@ -516,8 +534,11 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   static const int v2mode = getenv("COOCC_CONV_V2") ? atoi(getenv("COOCC_CONV_V2")) : 1;
   const unsigned long long in_bytes = (unsigned long long)d->B * d->Xi * d->Yi * d->Zi * d->in_stride * 4ull;
   const unsigned long long w_bytes = (unsigned long long)k.taps * k.kchunks * k.Npad * KC * 4ull;
-  if (v2mode && !table && (cfg == 0 || cfg == 4 || (cfg == 1 && v2small)) && in_bytes < 0xFFFFFF00ull && w_bytes < 0xFFFFFF00ull) {
-    k.in_bytes = (unsigned)in_bytes;
+  // rows a tile can touch above its first one (bound: stride-2 outputs advance the input rows up to 8x faster)
+  const unsigned long long window_rows = 8ull * 160 + (unsigned long long)k.kx * d->Yi * d->Zi + (unsigned long long)k.ky * d->Zi + k.kz + 8;
+  const bool window_ok = window_rows * d->in_stride * 4ull < 0xFFFFFF00ull && (long long)d->B * d->Xi * d->Yi * d->Zi < (1ll << 31);
+  if (v2mode && !table && (cfg == 0 || cfg == 4 || (cfg == 1 && v2small)) && window_ok && w_bytes < 0xFFFFFF00ull) {
+    k.in_bytes = (size_t)in_bytes;
     k.w_bytes = (unsigned)w_bytes;
     const int BMv = cfg == 4 ? 160 : 128;
     k.mtiles = (k.M + BMv - 1) / BMv;

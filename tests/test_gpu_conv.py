@@ -243,3 +243,32 @@ def test_conv_anisotropic_taps_and_weight_groups(dev):
     d.splitk = 1
     _lib.check(lib.coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     assert_close(out.cpu().view(groups, cols, Z, Cout), ref, what="grouped z-conv")
+
+
+def test_conv_large_volume_beyond_4gb_offsets(dev, monkeypatch):
+    """200x200x16 x 512 channels: the Winograd V buffer is 5.2 GB (F(2x2)), past 32-bit buffer offsets -- the GEMM
+    bases its descriptor at each tile's first row.  Winograd (both tile sizes) vs the direct path, and a spot check
+    of both against torch on cropped neighbourhoods."""
+    g = torch.Generator().manual_seed(12)
+    Cin, Cout, (X, Y, Z) = 512, 128, (200, 200, 16)
+    x = torch.randn(1, Cin, X, Y, Z, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (2.0 / (Cin * 27)) ** 0.5
+    pc = core.PackedConv(w.to(dev), ksize=3, pad=1)
+    xr = rows_of(x, dev)
+    monkeypatch.setattr(core, "WINO", 0)
+    direct = core.conv_rows(xr, pc, relu=False).as_ncdhw()
+    monkeypatch.setattr(core, "WINO", 1)
+    monkeypatch.setattr(core, "WINO_MIN_ROWS", 0)
+    for tile in (2, 4):
+        monkeypatch.setattr(core, "WINO_TILE", tile)
+        plan = core.wino_plan(xr, pc, X * Y * Z, 0)
+        assert plan is not None and plan[0] == tile
+        if tile == 2:
+            assert plan[1] * plan[5] * Cin * 4 > 2 ** 32          # V really is past 4 GB
+        out = core.conv_rows(xr, pc, relu=False).as_ncdhw()
+        assert_close(out.cpu(), direct.cpu(), what="winograd F(%d) vs direct at 200x200x16" % tile)
+    for (cx, cy, cz) in ((0, 0, 0), (199, 199, 15), (100, 57, 8), (3, 198, 1)):
+        x0, y0, z0 = max(cx - 1, 0), max(cy - 1, 0), max(cz - 1, 0)
+        crop = x[:, :, x0:cx + 2, y0:cy + 2, z0:cz + 2]
+        ref = F.conv3d(crop, w, padding=1)[0, :, cx - x0, cy - y0, cz - z0]
+        assert_close(direct[0, :, cx, cy, cz].cpu(), ref, what="direct vs torch at %s" % ((cx, cy, cz),))
