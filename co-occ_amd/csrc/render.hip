@@ -64,9 +64,11 @@ struct __attribute__((packed, aligned(4))) Geo3 { float x, y, z; };
 // wave-level multiplicative scan, weighted sums by DPP wave reductions.
 // ACT = 1: the table already holds sigmoid(rgb) (coocc_render_activate_table: 3 exp + 3 rcp per VOXEL instead of
 // per ray sample); ACT = 0: raw logits (the form the backward kernel differentiates).
-// (A persistent variant that prefetched the next tile's geometry into registers under phase 2 was measured
-// slower -- 38-48 us vs 32 at r101: the 48 extra VGPRs cost more occupancy than the overlap returned.)
-template <int ACT>
+// (Two persistent variants were measured slower at r101, 1344 tiles: prefetching the next tile's geometry into
+// registers under phase 2 -- 38-48 us vs 27, the 48 extra VGPRs cost more occupancy than the overlap returned --
+// and swapping the two phases between wave pairs over a double-buffered LDS tile -- 38 us at 2 tiles per
+// workgroup, 59 at 4: with so few tiles, one workgroup per tile, all resident at once, is the better use of the chip.)
+template <int ACT, int CHT>
 __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict__ table, int Y, int Z,
                                                          const float* __restrict__ geom,
                                                          const float* __restrict__ zvals, int D, int H, int W, int rt,
@@ -96,26 +98,29 @@ __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict_
   // reductions instead of 64-lane ones (the phase is instruction-bound, not memory-bound:
   // profiles/r1_render_ablation.txt).
   const int lane = tid & 63, wave = tid >> 6, hl = lane & 31, half = lane >> 5;
-  const int CH = (D + 31) / 32;                  // <= 8 (D <= 256)
+  const int CH = (D + 31) / 32;                  // <= CHT
   const int d0 = hl * CH;
-  float zv[8];                                   // this lane's z_vals, shared by every ray
+  float zv[CHT];                                 // this lane's z_vals, shared by every ray
 #pragma unroll
-  for (int j = 0; j < 8; ++j) zv[j] = (j < CH && d0 + j < D) ? zvals[d0 + j] : 0.f;
+  for (int j = 0; j < CHT; ++j) zv[j] = (j < CH && d0 + j < D) ? zvals[d0 + j] : 0.f;
   for (int r0 = wave * 2; r0 < nray; r0 += 8) {
     const int r = r0 + half;
     const bool live = r < nray;
-    float al[8], cr[8], cg[8], cb[8], prod = 1.f;
+    int pk[CHT + 1];                              // this lane's CH packed positions + the one after (for the step length)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j <= CHT; ++j) pk[j] = (j <= CH && d0 + j < D && live) ? s_pos[r * DS + d0 + j] : 0;
+    float al[CHT], cr[CHT], cg[CHT], cb[CHT], prod = 1.f;
+#pragma unroll
+    for (int j = 0; j < CHT; ++j) {
       al[j] = 0.f; cr[j] = cg[j] = cb[j] = 0.f;
       const int d = d0 + j;
       if (j < CH && d < D && live) {
-        const int p0 = s_pos[r * DS + d];
+        const int p0 = pk[j];
         const int x0 = p0 & 1023, y0 = (p0 >> 10) & 1023, z0 = (p0 >> 20) & 1023;
         const f32x4 t = *(const f32x4*)(table + (((size_t)x0 * Y + y0) * Z + z0) * 4);
         float dist = 1e10f;
         if (d + 1 < D) {
-          const int p1 = s_pos[r * DS + d + 1];
+          const int p1 = pk[j + 1];
           float ex = (float)((p1 & 1023) - x0), ey = (float)(((p1 >> 10) & 1023) - y0), ez = (float)(((p1 >> 20) & 1023) - z0);
           dist = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);   // v_sqrt_f32 (1 ulp) on small integers
         }
@@ -143,24 +148,29 @@ __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict_
     inc *= __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3F800000, __builtin_bit_cast(int, inc), 0x142, 0xA, 0xF, false));
     float T = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3F800000, __builtin_bit_cast(int, inc), 0x138, 0xF, 0xF, false));
     if (hl == 0) T = 1.f;
-    float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};             // r, g, b, depth
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < CHT; ++j) {
       const int d = d0 + j;
       if (j < CH && d < D) {
-        float wgt = al[j] * T;
-        ar += wgt * cr[j]; ag += wgt * cg[j]; ab += wgt * cb[j];
-        ad += wgt * zv[j];
+        const float wgt = al[j] * T;
+        acc = acc + wgt * f32x4{cr[j], cg[j], cb[j], zv[j]};
         T *= 1.f - al[j] + 1e-10f;
       }
     }
-    float r_lo, r_hi, g_lo, g_hi, b_lo, b_hi, d_lo, d_hi;
-    half_sums(ar, r_lo, r_hi); half_sums(ag, g_lo, g_hi); half_sums(ab, b_lo, b_hi); half_sums(ad, d_lo, d_hi);
-    if (lane == 0) {
-      float* o = maps + (((size_t)n * H + h) * W + w0 + r0) * 4;
-      *(f32x4*)o = f32x4{r_lo, g_lo, b_lo, d_lo};
-      if (r0 + 1 < nray) *(f32x4*)(o + 4) = f32x4{r_hi, g_hi, b_hi, d_hi};
+    // half-wave sums without leaving the vector lanes: row totals (4 DPP steps), then row 0 -> row 1 and row 2 -> row 3
+    // (row_bcast:15); lanes 16 and 48 hold the totals of their half and store them
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = acc[k];
+      v += dpp_f32<0xB1>(v);
+      v += dpp_f32<0x4E>(v);
+      v += dpp_f32<0x141>(v);
+      v += dpp_f32<0x140>(v);
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+      acc[k] = v;
     }
+    if (hl == 16 && live) *(f32x4*)(maps + (((size_t)n * H + h) * W + w0 + r) * 4) = acc;
   }
 }
 
@@ -202,11 +212,18 @@ extern "C" int coocc_render_nearest(const float* table, int X, int Y, int Z, con
   const int tiles = (W + rt - 1) / rt;
   size_t lds = sizeof(int) * (size_t)rt * (D + 1);
   dim3 grid(tiles, H, N);
-  if (activated)
-    hipLaunchKernelGGL(k_render_nearest<1>, grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
+  if (D > 128) {     // up to 8 samples per lane
+    if (activated)
+      hipLaunchKernelGGL((k_render_nearest<1, 8>), grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
+                         lox, loy, loz, dx, dy, dz, nx, ny, nz, maps);
+    else
+      hipLaunchKernelGGL((k_render_nearest<0, 8>), grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
+                         lox, loy, loz, dx, dy, dz, nx, ny, nz, maps);
+  } else if (activated)
+    hipLaunchKernelGGL((k_render_nearest<1, 4>), grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
                        lox, loy, loz, dx, dy, dz, nx, ny, nz, maps);
   else
-    hipLaunchKernelGGL(k_render_nearest<0>, grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
+    hipLaunchKernelGGL((k_render_nearest<0, 4>), grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
                        lox, loy, loz, dx, dy, dz, nx, ny, nz, maps);
   COOCC_LAUNCH_CHECK("k_render_nearest");
   return COOCC_OK;
