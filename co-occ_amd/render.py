@@ -125,6 +125,43 @@ def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16):
     return rgbs, depths, maps
 
 
+def render_block_sharded(sigma_head, rgb_head, voxel_feats, gemo, scale=16, rank=None, world=None):
+    """Config 5: ONE scene rendered by `world` ranks.  The flattened (camera, row) space of the
+    feature-map rays is cut into `world` contiguous chunks (6 cameras do not divide 8 GPUs); every rank holds the
+    fused volume, evaluates the per-voxel table, composites its chunk of rays, the 16-byte-per-ray maps are
+    all-gathered (dist.gather_ray_shards, RCCL) and every rank upsamples the full maps (35 us at r101).
+    Returns the same (rgbs, depths, maps) as render_block."""
+    from . import dist as cdist
+    from .core import to_rows
+    import torch.distributed as tdist
+    vf = to_rows(voxel_feats)
+    B, N, D, H, W, _ = gemo.shape
+    assert B == 1 and vf.B == 1
+    if world is None:
+        world = tdist.get_world_size() if (tdist.is_available() and tdist.is_initialized()) else 1
+        rank = tdist.get_rank() if world > 1 else 0
+    dev = gemo.device
+    table = voxel_table(sigma_head, rgb_head, vf)
+    call("coocc_render_activate_table", ptr(table), vf.V)
+    zvals = torch.linspace(0, D, D, device=dev)
+    lo, hi = cdist.shard_range(N * H, rank, world)
+    g = gemo.reshape(N, D, H, W, 3).float()
+    local = torch.empty(hi - lo, W, 4, device=dev, dtype=_F32)
+    r = lo
+    while r < hi:                                   # one launch per camera the chunk touches
+        cam, h0 = divmod(r, H)
+        h1 = min(H, h0 + (hi - r))
+        piece = g[cam:cam + 1, :, h0:h1].contiguous()            # [1, D, rows, W, 3]
+        call("coocc_render_nearest", ptr(table), vf.X, vf.Y, vf.Z, ptr(piece), ptr(zvals), 1, D, h1 - h0, W,
+             host_f32(RENDER_BOUNDS), 1, ptr(local[r - lo:r - lo + (h1 - h0)]))
+        r += h1 - h0
+    maps = cdist.gather_ray_shards(local, N * H).view(N, H, W, 4).contiguous()
+    rgbs = torch.empty(N, H * scale, W * scale, 3, device=dev, dtype=_F32)
+    depths = torch.empty(N, H * scale, W * scale, device=dev, dtype=_F32)
+    call("coocc_upsample_maps", ptr(maps), N, H, W, scale, ptr(rgbs), ptr(depths))
+    return rgbs, depths, maps
+
+
 def render_losses(rgbs, depths, rgb_gt, depth_gt, D):
     """coocc_ray.py:423-433 -> dict(loss_depth_render, loss_rgb) (forward values)."""
     out = torch.empty(3, device=rgbs.device, dtype=_F32)

@@ -373,3 +373,33 @@ def test_prefetched_search_matches_sequential(dev):
         assert torch.equal(a["pred_c"], b["pred_c"]) and torch.equal(a["voxel_feats"], b["voxel_feats"])
         assert torch.equal(a["output_coords_fine"][0], b["output_coords_fine"][0])
         assert torch.equal(a["output_voxels_fine"][0], b["output_voxels_fine"][0])
+
+
+def test_ray_sharded_render_equals_whole_render(dev):
+    """Config 5: the (camera,row) space cut into 8 chunks (6 cameras do not divide 8), each chunk rendered as its
+    own launches, stitched -> identical maps to the one-launch render (the collective itself is covered by the gloo
+    test in test_host.py; here every "rank" runs on this GPU)."""
+    from co_occ_amd import dist as cdist
+    c = cases.RENDER_CASE
+    vf, rig = cases.render_inputs(c)
+    fr = ref_cpu.create_frustum(c["input_size"], c["downsample"], [2.0, 58.0, 0.5])
+    gemo = ref_cpu.get_geometry(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"]).to(dev)
+    sig, _ = load_seeded(pkg.MLP(input_dim=128, output_dim=1, net_depth=1, skip_layer=None), c["seed"], dev)
+    rgb, _ = load_seeded(pkg.MLP(input_dim=128, output_dim=3, net_depth=3, skip_layer=None), c["seed"] + 1, dev)
+    with torch.no_grad():
+        rgbs, depths, maps = R.render_block(sig, rgb, vf.to(dev), gemo)
+        N, H, W = maps.shape[:3]
+        world = 8
+        parts = []
+        orig = cdist.gather_ray_shards
+        try:
+            cdist.gather_ray_shards = lambda local, n: (parts.append(local.clone()) or torch.zeros(n, W, 4, device=dev))
+            for rank in range(world):
+                R.render_block_sharded(sig, rgb, vf.to(dev), gemo, rank=rank, world=world)
+        finally:
+            cdist.gather_ray_shards = orig
+    stitched = torch.cat(parts, 0).view(N, H, W, 4)
+    assert sum(p.shape[0] for p in parts) == N * H
+    assert torch.equal(stitched, maps)
+    one = R.render_block_sharded(sig, rgb, vf.to(dev), gemo, rank=0, world=1)
+    assert torch.equal(one[0], rgbs) and torch.equal(one[1], depths)
