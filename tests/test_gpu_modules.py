@@ -403,3 +403,27 @@ def test_ray_sharded_render_equals_whole_render(dev):
     assert torch.equal(stitched, maps)
     one = R.render_block_sharded(sig, rgb, vf.to(dev), gemo, rank=0, world=1)
     assert torch.equal(one[0], rgbs) and torch.equal(one[1], depths)
+
+
+def test_occhead_cascade_ratio_4_vs_oracle(dev):
+    """OpenOccupancy-style head (config 5: coarse grid x4 -> fine grid, `coocc_multi_r101_openoccupancy.py`): 64 children
+    per occupied coarse voxel through the generic (one wave per fine point) sampling kernels."""
+    c = cases.DECODER_CASE
+    grid, ratio = (8, 8, 4), 4
+    final = tuple(v * ratio for v in grid)
+    cfg = synth.model_cfg(C=c["C"], block_inplanes=c["block_inplanes"], out_channels=c["fpn_out"], cascade_ratio=ratio,
+                          final_occ_size=final, point_cloud_range=c["point_cloud_range"])
+    head, sd = load_seeded(pkg.build_head(cfg["pts_bbox_head"]), 31, dev)
+    g = torch.Generator().manual_seed(9)
+    sem = [torch.randn(1, c["fpn_out"], *[max(1, -(-v // 2 ** l)) for v in grid], generator=g) for l in range(4)]
+    rig = synth.camera_rig(c["ncam"], c["input_size"], seed=9)
+    img_feats = [synth.image_feats(c["ncam"], c["fmap"], 512, seed=9)]
+    tr = synth.rig_transform(rig)
+    want = ref_cpu.occhead_forward({k: v.cpu() for k, v in sd.items()}, sem, img_feats, tr, ratio, final, c["point_cloud_range"])
+    with torch.no_grad():
+        res = head(voxel_feats=[t.to(dev) for t in sem], img_feats=[img_feats[0].to(dev)],
+                   transform=tuple(t.to(dev) if torch.is_tensor(t) else t for t in tr))
+    assert_close(res["output_voxels"][0].cpu(), want["output_voxels"], what="occ")
+    assert np.array_equal(res["output_coords_fine"][0].cpu().numpy(), want["fine_coord"].numpy())
+    assert res["output_coords_fine"][0].shape[1] % 64 == 0
+    assert_close(res["output_voxels_fine"][0].cpu(), want["fine_output"], what="fine (ratio 4)")
