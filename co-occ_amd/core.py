@@ -28,8 +28,8 @@ WINO_MIN_ROWS = int(__import__("os").environ.get("COOCC_WINO_MIN_ROWS", "8192"))
 WINO_TILE = int(__import__("os").environ.get("COOCC_WINO_TILE", "4"))   # F(4x4,3x3) where X, Y >= 8, else F(2x2,3x3)
 
 
-def conv_kernel_name(M, Cout, table, hint=0):
-    """Mirror of the tile-configuration rule in csrc/conv3d.hip (coocc_conv_fwd)."""
+def conv_kernel_name(M, Cout, table, hint=0, iters=1 << 30):
+    """Mirror of the tile-configuration rule in csrc/conv3d.hip (coocc_conv_fwd).  iters = taps * ceil(Cin/32)."""
     hint = hint or TILE_HINT
     if Cout <= 32:
         t = "128,32,32,32"
@@ -44,6 +44,8 @@ def conv_kernel_name(M, Cout, table, hint=0):
             tiles = -(-M // bm) * (-(-Cout // 128))
             return tiles * bm / float(-(-tiles // 512) * 512)
         big = hint == 160 or (hint == 0 and util(160) > util(128) * 1.02)
+        if iters <= 24 and hint != 160:
+            big = False        # short K: 128-row tiles at 3 workgroups per CU
         if not table and CONV_V2:
             return "k_conv2<%d>" % (160 if big else 128)      # software-pipelined large-layer kernel
         t = "160,128,160,32" if big else "128,128,64,64"
@@ -238,7 +240,7 @@ def conv_rows_wino(x, pc, out, relu, res, plan):
     d.kx, d.ky, d.kz, d.px, d.py, d.pz = 1, 1, 3, 0, 0, 1
     d.wgroup_rows = G
     d.relu, d.res_mode, d.splitk, d.tile_hint = 0, 0, 1, (hint or TILE_HINT)
-    with TIMER.region(conv_kernel_name(pts * G, pc.Cout, False, hint) + " wino%d" % tile, 2.0 * pts * rows * pc.Cin * pc.Cout * 3):
+    with TIMER.region(conv_kernel_name(pts * G, pc.Cout, False, hint, 3 * -(-pc.Cin // 32)) + " wino%d" % tile, 2.0 * pts * rows * pc.Cin * pc.Cout * 3):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     with TIMER.region("k_wino_out", 4.0 * pts * rows * pc.Cout + 4.0 * x.V * pc.Cout):
         call("coocc_wino_output", ptr(Mb), G, x.B, x.X, x.Y, x.Z, pc.Cout, tile, out.data(), out.stride, ptr(pc.scale),
@@ -285,7 +287,7 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
     d.ksize, d.stride, d.pad = pc.ksize, pc.stride, pc.pad
     d.relu, d.res_mode, d.splitk = int(relu), (res_mode or (1 if res is not None else 0)), splitk
     d.tile_hint = TILE_HINT
-    with TIMER.region(conv_kernel_name(M, pc.Cout, False), 2.0 * M * pc.Cin * pc.Cout * pc.taps):
+    with TIMER.region(conv_kernel_name(M, pc.Cout, False, 0, pc.taps * -(-pc.Cin // 32)), 2.0 * M * pc.Cin * pc.Cout * pc.taps):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     return out
 
@@ -314,7 +316,7 @@ def linear_rows(x2d, pc, relu=False, out=None, out_coff=0, in_coff=0, in_C=None)
     d.ksize, d.stride, d.pad = 1, 1, 0
     d.relu, d.res_mode, d.splitk = int(relu), 0, 0
     d.tile_hint = TILE_HINT
-    with TIMER.region(conv_kernel_name(n, pc.Cout, False), 2.0 * n * Cin * pc.Cout):
+    with TIMER.region(conv_kernel_name(n, pc.Cout, False, 0, -(-Cin // 32)), 2.0 * n * Cin * pc.Cout):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     return out
 

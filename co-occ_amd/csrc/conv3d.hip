@@ -240,8 +240,8 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // layers (few M tiles, up to 113 MB of weights each) need the HBM latency of 2-3 chunks covered.
 // WG = true: the weight-grouped launch of the Winograd path (one weight pack per transform point); a separate
 // instantiation so that profilers list it under its own name.
-template <int BM, int PF = 1, bool WG = false>
-__global__ __launch_bounds__(256, 2) void k_conv2(ConvK p) {
+template <int BM, int PF = 1, bool WG = false, int MINW = 2>
+__global__ __launch_bounds__(256, MINW) void k_conv2(ConvK p) {
   constexpr int TM = BM / 32, PA = BM / 32;
   __shared__ float As[2][BM * LDS_ST];
 
@@ -502,6 +502,8 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
     };
     if (d->tile_hint == 160 || (d->tile_hint == 0 && util(160) > util(128) * 1.02)) cfg = 4;
   }
+  const bool short_k = k.total_iters <= 24;
+  if (short_k && cfg == 4 && d->tile_hint != 160 && !(d->wgroup_rows > 0 && d->wgroup_rows % 128 != 0)) cfg = 0;   // 128-row tiles, 3 per CU
   // mid-size layers (512 <= M < 8192) also run the pipelined kernel with 128-row tiles + split-K;
   // below that the 64-row tile wastes fewer padded rows (M = 169 at the deepest stage)
   const bool v2small = d->M >= 512;
@@ -549,8 +551,12 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
     static const int pf128 = getenv("COOCC_CONV_PF128") ? atoi(getenv("COOCC_CONV_PF128")) : 3;
     if (k.wgroup_rows > 0) {
       if (cfg == 4) hipLaunchKernelGGL((k_conv2<160, 2, true>), grid, dim3(256), 0, s, k);
+      // short K (3*Cin/32 <= 24 chunks per tile): the per-tile prologue/epilogue weighs as much as the loop, so
+      // trade prefetch depth for occupancy -- PF = 1 fits 168 VGPRs = 3 workgroups per CU (0.179 -> 0.158 ms)
+      else if (short_k) hipLaunchKernelGGL((k_conv2<128, 1, true, 3>), grid, dim3(256), 0, s, k);
       else hipLaunchKernelGGL((k_conv2<128, 3, true>), grid, dim3(256), 0, s, k);
     }
+    else if (cfg != 4 && short_k && splitk == 1) hipLaunchKernelGGL((k_conv2<128, 1, false, 3>), grid, dim3(256), 0, s, k);
     else if (cfg == 4 && pf160 == 2) hipLaunchKernelGGL((k_conv2<160, 2>), grid, dim3(256), 0, s, k);
     else if (cfg == 4) hipLaunchKernelGGL((k_conv2<160, 1>), grid, dim3(256), 0, s, k);
     else if (pf128 == 3) hipLaunchKernelGGL((k_conv2<128, 3>), grid, dim3(256), 0, s, k);
