@@ -139,7 +139,7 @@ class PackedConv:
         # raw weights kept on the host for the lazily built Winograd packs
         self._w_raw = w if (ksize == 3 and stride == 1 and pad == 1 and not tap_major and taps == 27) else None
         self._wino = {}
-        self.wino_tile = None        # per-layer override of WINO_TILE (2 | 4)
+        self.wino_tile = None        # per-layer override of WINO_TILE (2 | 3 | 4)
         lib = _lib.load()
         n = lib.coocc_conv_pack_weights(ctypes.c_void_p(w.data_ptr()), self.Cout, self.Cin, taps, int(tap_major), None)
         packed = torch.empty(n, dtype=_F32)
@@ -161,6 +161,10 @@ class PackedConv:
         if tile not in self._wino:
             if tile == 2:
                 G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], dtype=torch.float64)
+            elif tile == 3:
+                # Toom-Cook points (0, -1, 2, 1/2, inf), matching Wino<5>
+                G = torch.tensor([[1, 0, 0], [-2 / 9, 2 / 9, -2 / 9], [1 / 9, 2 / 9, 4 / 9], [-8 / 9, -4 / 9, -2 / 9], [0, 0, 1]],
+                                 dtype=torch.float64)
             else:
                 # Toom-Cook points (0, 1, -1, 1/2, -2, inf), matching Wino<6> in csrc/winograd.hip
                 G = torch.tensor([[1, 0, 0], [1 / 3, 1 / 3, 1 / 3], [-1 / 3, 1 / 3, -1 / 3], [-16 / 15, -8 / 15, -4 / 15],
@@ -200,7 +204,9 @@ def wino_plan(x, pc, M, res_mode):
     """None, or (tile, points, Tx, Ty, rows, G, tile_hint) for the Winograd path of this layer."""
     if not WINO or pc._w_raw is None or M < WINO_MIN_ROWS or res_mode not in (0, 1) or pc.Cin % 4:
         return None
-    tile = 4 if ((pc.wino_tile or WINO_TILE) == 4 and min(x.X, x.Y) >= 8) else 2
+    tile = pc.wino_tile or WINO_TILE
+    if tile not in (2, 3, 4) or min(x.X, x.Y) < 2 * tile:
+        tile = 2
     Tx, Ty = -(-x.X // tile), -(-x.Y // tile)
     rows = x.B * Tx * Ty * x.Z
     # group rows: a multiple of the GEMM's M tile and of Z.  640 = lcm(128, 160) leaves the tile choice to the

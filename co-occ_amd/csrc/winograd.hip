@@ -1,5 +1,6 @@
-// Winograd F(m x m, 3x3), m = 2 or 4, over the (x, y) axes of the 3x3x3 stride-1 convolutions; the z axis
-// stays a direct 3-tap convolution.  Multiplies per output: 27*Cin direct, 12*Cin (m = 2), 6.75*Cin (m = 4).
+// Winograd F(m x m, 3x3), m = 2, 3 or 4, over the (x, y) axes of the 3x3x3 stride-1 convolutions; the z axis
+// stays a direct 3-tap convolution.  Multiplies per output: 27*Cin direct, 12*Cin (m = 2), 8.33*Cin (m = 3),
+// 6.75*Cin (m = 4).
 //
 //   V[p]   = B^T d B        input transform  (this file)     d: (m+2)^2 (x,y) patch at (m*tx-1, m*ty-1), fixed z
 //   M[p]   = sum_{dz,ci} V[p][.., z+dz-1, ci] U[p][dz][ci][co]   ONE coocc_conv_fwd launch: rows = (m+2)^2 x
@@ -24,6 +25,21 @@ template <> struct Wino<4> {   // F(2,3)
   }
   template <typename T> static __device__ __forceinline__ void at(const T* m, T* y) {
     y[0] = m[0] + m[1] + m[2]; y[1] = m[1] - m[2] - m[3];
+  }
+};
+template <> struct Wino<5> {   // F(3,3) on the points (0, -1, 2, 1/2, inf): rms error 1.7e-6 of the output scale, between
+  static constexpr int M = 3;  // F(2,3) (0.75e-6) and F(4,3) (3.5e-6); 8.33*Cin multiplies per output
+  template <typename T> static __device__ __forceinline__ void bt(const T* d, T* t) {
+    t[0] = d[0] - 1.5f * (d[1] + d[2]) + d[3];
+    t[1] = d[1] - 2.5f * d[2] + d[3];
+    t[2] = 0.5f * (d[2] - d[1]) + d[3];
+    t[3] = -2.f * d[1] - d[2] + d[3];
+    t[4] = d[1] - 1.5f * (d[2] + d[3]) + d[4];
+  }
+  template <typename T> static __device__ __forceinline__ void at(const T* m, T* y) {
+    y[0] = m[0] + m[1] + m[2] + m[3];
+    y[1] = 2.f * m[2] - m[1] + 0.5f * m[3];
+    y[2] = m[1] + 4.f * m[2] + 0.25f * m[3] + m[4];
   }
 };
 template <> struct Wino<6> {   // F(4,3) on the points (0, 1, -1, 1/2, -2, inf): ~2.2x lower fp32 error than the
@@ -90,13 +106,16 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ in, i
 extern "C" int coocc_wino_input(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, float* V,
                                 int64_t group_rows, void* stream) {
   COOCC_CHECK_ARG(in && V && B > 0 && X > 0 && Y > 0 && Z > 0 && C > 0 && C % 4 == 0 && in_stride % 4 == 0, "wino_input: bad args");
-  COOCC_CHECK_ARG(tile == 2 || tile == 4, "wino_input: tile must be 2 or 4");
+  COOCC_CHECK_ARG(tile >= 2 && tile <= 4, "wino_input: tile must be 2, 3 or 4");
   const int Tx = (X + tile - 1) / tile, Ty = (Y + tile - 1) / tile;
   const long long rows = (long long)B * Tx * Ty * Z;
   COOCC_CHECK_ARG(group_rows >= rows, "wino_input: group_rows smaller than B*ceil(X/tile)*ceil(Y/tile)*Z");
   const dim3 grid(cdiv(rows * (C / 4), 256));
   if (tile == 2)
     hipLaunchKernelGGL(k_wino_in<4>, grid, dim3(256), 0, as_stream(stream), in, in_stride, B, X, Y, Z, C, Tx, Ty,
+                       (size_t)group_rows * C, V);
+  else if (tile == 3)
+    hipLaunchKernelGGL(k_wino_in<5>, grid, dim3(256), 0, as_stream(stream), in, in_stride, B, X, Y, Z, C, Tx, Ty,
                        (size_t)group_rows * C, V);
   else
     hipLaunchKernelGGL(k_wino_in<6>, grid, dim3(256), 0, as_stream(stream), in, in_stride, B, X, Y, Z, C, Tx, Ty,
@@ -179,7 +198,7 @@ extern "C" int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int
                                  int out_stride, const float* scale, const float* bias, const float* res, int res_stride,
                                  int relu, void* stream) {
   COOCC_CHECK_ARG(Mb && out && B > 0 && X > 0 && Y > 0 && Z > 0 && C > 0, "wino_output: bad args");
-  COOCC_CHECK_ARG(tile == 2 || tile == 4, "wino_output: tile must be 2 or 4");
+  COOCC_CHECK_ARG(tile >= 2 && tile <= 4, "wino_output: tile must be 2, 3 or 4");
   COOCC_CHECK_ARG(((uintptr_t)out & 15) == 0 && (!res || ((uintptr_t)res & 15) == 0), "wino_output: out/res must be 16-byte aligned");
   const int Tx = (X + tile - 1) / tile, Ty = (Y + tile - 1) / tile;
   const long long rows = (long long)B * Tx * Ty * Z;
@@ -187,6 +206,9 @@ extern "C" int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int
   const dim3 grid(cdiv(rows * ((C + 3) / 4), 256));
   if (tile == 2)
     hipLaunchKernelGGL(k_wino_out<4>, grid, dim3(256), 0, as_stream(stream), Mb, (size_t)group_rows * C, B, X, Y, Z, C, Tx, Ty,
+                       out, out_stride, scale, bias, res, res_stride, relu);
+  else if (tile == 3)
+    hipLaunchKernelGGL(k_wino_out<5>, grid, dim3(256), 0, as_stream(stream), Mb, (size_t)group_rows * C, B, X, Y, Z, C, Tx, Ty,
                        out, out_stride, scale, bias, res, res_stride, relu);
   else
     hipLaunchKernelGGL(k_wino_out<6>, grid, dim3(256), 0, as_stream(stream), Mb, (size_t)group_rows * C, B, X, Y, Z, C, Tx, Ty,

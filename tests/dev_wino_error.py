@@ -38,7 +38,7 @@ print("fuser pack keys", list(f.keys()))
 def set_tiles(con, enc, fpn):
     for k, v in f.items():
         if hasattr(v, "wino_tile"):
-            v.wino_tile = con
+            v.wino_tile = (3 if k == "c0" else 2) if con == "c0=3" else con
     for pc in P["enc"]:
         pc.wino_tile = enc
     for pc in P["fpn"]:
@@ -46,7 +46,8 @@ def set_tiles(con, enc, fpn):
 
 for name, wino, tile, tiles in (("direct", 0, 4, None), ("F2 all", 1, 2, None), ("F4 all", 1, 4, None),
                                 ("con F2, rest F4", 1, 4, (2, 4, 4)), ("con F4, rest F2", 1, 2, (4, 2, 2)),
-                                ("con+enc F2, fpn/head F4", 1, 4, (2, 2, 4)), ("con.. F4, fpn F2", 1, 4, (4, 4, 2))):
+                                ("con+enc F2, fpn/head F4", 1, 4, (2, 2, 4)), ("con.. F4, fpn F2", 1, 4, (4, 4, 2)), ("con F3, rest F4", 1, 4, (3, 4, 4)),
+                                ("con.0 F3, con.3 F2, rest F4", 1, 4, ("c0=3", 4, 4)), ("F3 all", 1, 3, None)):
     core.WINO, core.WINO_TILE, core.WINO_MIN_ROWS = wino, tile, 0
     set_tiles(*(tiles or (None, None, None)))
     with torch.no_grad():

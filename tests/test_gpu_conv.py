@@ -186,7 +186,7 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [2, 4])
+@pytest.mark.parametrize("tile", [2, 3, 4])
 @pytest.mark.parametrize("Cin,Cout,grid,B,relu,use_res", WINO_CASES + [(512, 128, (16, 12, 4), 1, True, False)])
 def test_conv3d_winograd_path(dev, monkeypatch, Cin, Cout, grid, B, relu, use_res, tile):
     """The Winograd F(2x2,3x3) + direct-z path (csrc/winograd.hip) against torch's direct fp32 conv, and against
