@@ -85,6 +85,7 @@ SIGNATURES = {
     "coocc_wino_input": (I, [P, I, I, I, I, I, I, I, P, L, P]),
     "coocc_wino_output": (I, [P, L, I, I, I, I, I, I, P, I, P, P, P, I, I, P]),
     "coocc_projection_params": (I, [P, P, P, P, P, P, I, P, P, P]),
+    "coocc_occhead_mix_bwd": (I, [P, P, I, P, P, P, P, I, I, P]),
     "coocc_eval_semantic": (I, [P, L, L, L, L, I, I, I, I, P, P, I, I, I, I, I, P, P]),
 }
 

@@ -416,3 +416,75 @@ def trunk_forward_train(con_enc, backbone, neck, x2d, geom):
         (c, gc), (f, gf) = lat[i], lat[i - 1]
         lat[i - 1] = (upsample_add(c, f, gc, gf), gf)
     return [_cm(x, g, neck.fpn_convs[i][0]) for i, (x, g) in enumerate(lat)]
+
+
+# ----------------------------------------------------------------------------- OccHead coarse mix (C3)
+class OccHeadMixFn(torch.autograd.Function):
+    """out[v] = sum_l softmax(wlogit[v])_l * trilinear(level_l -> level-0 size)[v]   (occ_head.py:155-166)."""
+
+    @staticmethod
+    def forward(ctx, wlogit, geoms, *levels):
+        from ._lib import host_i32
+        L = len(levels)
+        B, X0, Y0, Z0 = geoms[0]
+        C = levels[0].shape[1]
+        lv = [t.contiguous() for t in levels]
+        arr = (_lib.c_void_p * L)(*[t.data_ptr() for t in lv])
+        dims = host_i32([v for g in geoms for v in g[1:]])
+        out = torch.empty(B * X0 * Y0 * Z0, C, device=lv[0].device, dtype=_F32)
+        wl = wlogit.contiguous() if wlogit is not None else None
+        call("coocc_occhead_mix", arr, dims, L, ptr(wl), ptr(out), B, C)
+        ctx.save_for_backward(*( [wl] if wl is not None else [] ), *lv)
+        ctx.cfg = (geoms, wl is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from ._lib import host_i32
+        geoms, has_w = ctx.cfg
+        saved = ctx.saved_tensors
+        wl = saved[0] if has_w else None
+        lv = saved[1:] if has_w else saved
+        L = len(lv)
+        B, X0, Y0, Z0 = geoms[0]
+        C = lv[0].shape[1]
+        dev = dout.device
+        dout = dout.float().contiguous()
+        V0 = B * X0 * Y0 * Z0
+        g = [torch.empty(V0, C, device=dev, dtype=_F32) for _ in range(L)]
+        dwl = torch.empty(V0, L, device=dev, dtype=_F32) if has_w else None
+        arr = (_lib.c_void_p * L)(*[t.data_ptr() for t in lv])
+        garr = (_lib.c_void_p * L)(*[t.data_ptr() for t in g])
+        dims = host_i32([v for gg in geoms for v in gg[1:]])
+        call("coocc_occhead_mix_bwd", arr, dims, L, ptr(wl), ptr(dout), garr, ptr(dwl), B, C)
+        grads = [g[0]]
+        for l in range(1, L):
+            _, Xl, Yl, Zl = geoms[l]
+            if (Xl, Yl, Zl) == (X0, Y0, Z0):
+                grads.append(g[l])
+                continue
+            dl = torch.empty(B * Xl * Yl * Zl, C, device=dev, dtype=_F32)
+            call("coocc_upsample_trilinear_bwd", ptr(g[l]), ptr(dl), B, C, Xl, Yl, Zl, X0, Y0, Z0, 0)
+            grads.append(dl)
+        return (dwl, None) + tuple(grads)
+
+
+def occhead_coarse_train(head, feats):
+    """Differentiable OccHead.forward_coarse_voxel on rows: feats = [(rows, geom)] per level (from
+    trunk_forward_train) -> (out_voxel_feats rows, occupancy logits rows [V0, num_cls])."""
+    occs = []
+    for i, (x, g) in enumerate(feats):
+        m = head.occ_convs[i]
+        o, go = conv3d_rows(x, m[0].weight, g, bias=m[0].bias, bn=m[1], relu=True)
+        occs.append((o, go))
+    wlogit = None
+    g0 = occs[0][1]
+    if head.soft_weights:
+        sw = head.voxel_soft_weights
+        h, _ = conv3d_rows(occs[0][0], sw[0].weight, g0, bias=sw[0].bias, bn=sw[1], relu=True)
+        wlogit, _ = conv3d_rows(h, sw[3].weight, g0, bias=sw[3].bias, relu=False)
+    out = OccHeadMixFn.apply(wlogit, tuple(g for _, g in occs), *[o for o, _ in occs])
+    pc = head.occ_pred_conv
+    h, _ = conv3d_rows(out, pc[0].weight, g0, bias=pc[0].bias, bn=pc[1], relu=True)
+    occ, _ = conv3d_rows(h, pc[3].weight, g0, bias=pc[3].bias, relu=False)
+    return out, occ

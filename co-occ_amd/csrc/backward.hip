@@ -341,7 +341,7 @@ extern "C" int coocc_render_losses_bwd(const float* rgbs, const float* depths, c
 // forward (interp.hip k_upsample_add, fpn3d.py:88-92): fine += trilinear(coarse -> fine size).  The fine
 // gradient passes through unchanged; the coarse gradient is the adjoint of the interpolation, gathered per
 // coarse voxel from the <= MAXC^3 fine voxels whose two taps per axis include it (deterministic).
-constexpr int MAXC = 10;
+constexpr int MAXC = 20;   // fine taps per coarse index and axis: up to ~2x the upsampling factor + 2 (factor <= 8)
 
 __device__ __forceinline__ int axis_weights(int c, int in, int out, int& lo, float* w) {
   // fine indices d in [lo, lo+n) with weight w[d-lo] onto coarse index c
@@ -395,10 +395,79 @@ __global__ __launch_bounds__(256) void k_upsample_trilinear_bwd(const float* __r
 extern "C" int coocc_upsample_trilinear_bwd(const float* dfine, float* dcoarse, int B, int C, int Xc, int Yc, int Zc, int Xf,
                                             int Yf, int Zf, int accumulate, void* stream) {
   COOCC_CHECK_ARG(dfine && dcoarse && B > 0 && C > 0 && C % 4 == 0, "upsample_trilinear_bwd: bad args (C % 4 == 0)");
-  COOCC_CHECK_ARG(Xf <= 4 * Xc && Yf <= 4 * Yc && Zf <= 4 * Zc && Xf >= Xc && Yf >= Yc && Zf >= Zc,
-                  "upsample_trilinear_bwd: supports upsampling factors up to 4");
+  COOCC_CHECK_ARG(Xf <= 8 * Xc && Yf <= 8 * Yc && Zf <= 8 * Zc && Xf >= Xc && Yf >= Yc && Zf >= Zc,
+                  "upsample_trilinear_bwd: supports upsampling factors up to 8");
   hipLaunchKernelGGL(k_upsample_trilinear_bwd, dim3(cdiv((long long)B * Xc * Yc * Zc * (C / 4), 256)), dim3(256), 0,
                      as_stream(stream), dfine, dcoarse, B, C, Xc, Yc, Zc, Xf, Yf, Zf, accumulate);
   COOCC_LAUNCH_CHECK("k_upsample_trilinear_bwd");
+  return COOCC_OK;
+}
+
+// ------------------------------------------------------------------ OccHead multi-level mix backward
+// forward (interp.hip k_occhead_mix, occ_head.py:155-166): out[v] = sum_l softmax(wlogit[v])_l * up_l(level_l)[v].
+// One wave per level-0 voxel, lanes along channels: dot_l = <dout[v], up_l[v]> (wave reduction), softmax backward
+//   dwlogit_l = w_l (dot_l - sum_k w_k dot_k),
+// and the per-level scaled gradients g_l[v] = w_l * dout[v] (level 0 is written straight into dlevel0; the others
+// go to scratch rows and are pulled down by coocc_upsample_trilinear_bwd, the adjoint gather).
+struct MixLevelsB { const float* p[4]; float* g[4]; int X[4], Y[4], Z[4]; int L; };
+
+__global__ __launch_bounds__(256) void k_occhead_mix_bwd(MixLevelsB lv, const float* __restrict__ wlogit,
+                                                          const float* __restrict__ dout, float* __restrict__ dwlogit,
+                                                          int B, int C) {
+  const int X0 = lv.X[0], Y0 = lv.Y[0], Z0 = lv.Z[0];
+  const long long V0 = (long long)B * X0 * Y0 * Z0;
+  const long long v = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (v >= V0) return;
+  long long r = v;
+  const int z = (int)(r % Z0); r /= Z0;
+  const int y = (int)(r % Y0); r /= Y0;
+  const int x = (int)(r % X0); const int b = (int)(r / X0);
+  float w[4], dot[4] = {0.f, 0.f, 0.f, 0.f};
+  float mx = -INFINITY;
+  for (int l = 0; l < lv.L; ++l) { w[l] = wlogit ? wlogit[v * lv.L + l] : 0.f; mx = fmaxf(mx, w[l]); }
+  float sum = 0.f;
+  for (int l = 0; l < lv.L; ++l) { w[l] = expf(w[l] - mx); sum += w[l]; }
+  for (int l = 0; l < lv.L; ++l) w[l] /= sum;
+  for (int c = lane * 4; c < C; c += 256) {
+    const f32x4 g = *(const f32x4*)(dout + v * C + c);
+    for (int l = 0; l < lv.L; ++l) {
+      const LinB lx = lin_srcb(x, lv.X[l], X0), ly = lin_srcb(y, lv.Y[l], Y0), lz = lin_srcb(z, lv.Z[l], Z0);
+      const float* vol = lv.p[l];
+      const int Xl = lv.X[l], Yl = lv.Y[l], Zl = lv.Z[l];
+      auto at = [&](int xx, int yy, int zz) { return *(const f32x4*)(vol + ((((size_t)b * Xl + xx) * Yl + yy) * Zl + zz) * C + c); };
+      const f32x4 s = lx.w0 * (ly.w0 * (lz.w0 * at(lx.i0, ly.i0, lz.i0) + lz.w1 * at(lx.i0, ly.i0, lz.i1)) +
+                                ly.w1 * (lz.w0 * at(lx.i0, ly.i1, lz.i0) + lz.w1 * at(lx.i0, ly.i1, lz.i1))) +
+                      lx.w1 * (ly.w0 * (lz.w0 * at(lx.i1, ly.i0, lz.i0) + lz.w1 * at(lx.i1, ly.i0, lz.i1)) +
+                                ly.w1 * (lz.w0 * at(lx.i1, ly.i1, lz.i0) + lz.w1 * at(lx.i1, ly.i1, lz.i1)));
+      dot[l] += g[0] * s[0] + g[1] * s[1] + g[2] * s[2] + g[3] * s[3];
+      *(f32x4*)(lv.g[l] + v * C + c) = w[l] * g;
+    }
+  }
+  for (int l = 0; l < lv.L; ++l)
+    for (int m = 32; m > 0; m >>= 1) dot[l] += __shfl_xor(dot[l], m);
+  if (lane == 0 && dwlogit) {
+    float mean = 0.f;
+    for (int l = 0; l < lv.L; ++l) mean += w[l] * dot[l];
+    for (int l = 0; l < lv.L; ++l) dwlogit[v * lv.L + l] = w[l] * (dot[l] - mean);
+  }
+}
+
+extern "C" int coocc_occhead_mix_bwd(const float* const* levels_host, const int* dims_host, int L, const float* wlogit,
+                                     const float* dout, float* const* glevels_host, float* dwlogit, int B, int C,
+                                     void* stream) {
+  COOCC_CHECK_ARG(levels_host && dims_host && dout && glevels_host && L >= 1 && L <= 4 && C % 4 == 0, "occhead_mix_bwd: bad args");
+  MixLevelsB lv;
+  lv.L = L;
+  for (int l = 0; l < 4; ++l) {
+    lv.p[l] = l < L ? levels_host[l] : nullptr;
+    lv.g[l] = l < L ? glevels_host[l] : nullptr;
+    lv.X[l] = l < L ? dims_host[l * 3 + 0] : 1;
+    lv.Y[l] = l < L ? dims_host[l * 3 + 1] : 1;
+    lv.Z[l] = l < L ? dims_host[l * 3 + 2] : 1;
+  }
+  const long long V0 = (long long)B * lv.X[0] * lv.Y[0] * lv.Z[0];
+  hipLaunchKernelGGL(k_occhead_mix_bwd, dim3(cdiv(V0 * 64, 256)), dim3(256), 0, as_stream(stream), lv, wlogit, dout, dwlogit, B, C);
+  COOCC_LAUNCH_CHECK("k_occhead_mix_bwd");
   return COOCC_OK;
 }

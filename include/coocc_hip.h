@@ -217,6 +217,12 @@ int coocc_render_losses_bwd(const float* rgbs, const float* depths, const float*
 int coocc_upsample_trilinear_bwd(const float* dfine, float* dcoarse, int B, int C, int Xc, int Yc, int Zc, int Xf,
                                  int Yf, int Zf, int accumulate, void* stream);
 
+/* coocc_occhead_mix backward: dout:[V0,C].  glevels_host[l]: scratch rows [V0,C] receiving softmax(w)_l * dout (level 0:
+ * this IS d level_0; levels >= 1 are pulled down with coocc_upsample_trilinear_bwd); dwlogit:[V0,L] (may be NULL). */
+int coocc_occhead_mix_bwd(const float* const* levels_host, const int* dims_host, int L, const float* wlogit,
+                          const float* dout, float* const* glevels_host, float* dwlogit, int B, int C,
+                          void* stream);
+
 /* FPN3D top-down step (fpn3d.py:88-92): fine += trilinear(coarse -> fine size),
  * align_corners=False.  Rows NDHWC with C channels. */
 int coocc_upsample_add_trilinear(const float* coarse, float* fine, int B, int C, int Xc, int Yc,

@@ -306,3 +306,52 @@ def test_decoder_trunk_backward_vs_oracle_autograd(dev):
                 assert_close(p.grad.cpu(), sd[name].grad, what=name)
                 n += 1
     assert n == 2 + 1 + 16 + 3 + 8           # con_enc, input_proj, 8 blocks x 2, 3 downsamples, FPN 4 + 4
+
+
+def test_decoder_with_coarse_head_backward_vs_oracle_autograd(dev):
+    """con_enc -> ResNet3D -> FPN3D -> OccHead coarse branch (3x3x3 per level, softmax-weighted multi-level trilinear mix,
+    1x1 prediction stack): logits and every conv weight gradient vs torch autograd through the oracle."""
+    from oracle import ref_cpu
+    import co_occ_amd.synth as synth
+    C, planes, fpn_out, grid = 8, [16, 32, 64, 128], 32, (16, 12, 8)
+    cfg = synth.model_cfg(C=C, block_inplanes=planes, out_channels=fpn_out)
+    bn = dict(type="BN3d")
+    fuser = pkg.BiFuser_N(C, C, knum=2).eval()
+    enc = pkg.CustomResNet3D(depth=18, block_inplanes=planes, n_input_channels=C, norm_cfg=bn).eval()
+    neck = pkg.FPN3D(in_channels=planes, out_channels=fpn_out, norm_cfg=bn).eval()
+    hcfg = dict(cfg["pts_bbox_head"], norm_cfg=bn, sample_from_img=False, sample_from_voxel=False, cascade_ratio=1)
+    head = pkg.build_head(hcfg).eval()
+    for i, m in enumerate((fuser, enc, neck, head)):
+        m.load_state_dict(synth.random_state_dict(m.state_dict(), seed=80 + i))
+    g = torch.Generator().manual_seed(81)
+    X, Y, Z = grid
+    x = torch.randn(1, X, Y, Z, 4 * C, generator=g)
+
+    def leaf(sd):
+        return {k: (v.clone().float().requires_grad_() if (v.is_floating_point() and "running_" not in k) else v.clone())
+                for k, v in sd.items()}
+    sds = [leaf(m.state_dict()) for m in (fuser, enc, neck, head)]
+    xr = x.clone().requires_grad_()
+    sem_r = ref_cpu.fpn3d_forward(sds[2], ref_cpu.resnet3d_forward(sds[1], ref_cpu.con_enc(sds[0], xr)))
+    hr = ref_cpu.occhead_coarse(sds[3], sem_r, soft_weights=True)
+    gocc = torch.randn(hr["occ"].shape, generator=g)
+    gfeat = torch.randn(hr["out_voxel_feats"].shape, generator=g) * 0.1
+    ((hr["occ"] * gocc).sum() + (hr["out_voxel_feats"] * gfeat).sum()).backward()
+
+    mods = [m.to(dev) for m in (fuser, enc, neck, head)]
+    xd = x.reshape(-1, 4 * C).to(dev).requires_grad_()
+    feats = ag.trunk_forward_train(mods[0].con_enc, mods[1], mods[2], xd, (1, X, Y, Z))
+    ovf, occ = ag.occhead_coarse_train(mods[3], feats)
+    assert_close(_vol(occ.detach().cpu(), 1, X, Y, Z), hr["occ"].detach(), what="coarse logits")
+    assert_close(_vol(ovf.detach().cpu(), 1, X, Y, Z), hr["out_voxel_feats"].detach(), what="out_voxel_feats")
+    ((occ * _rows(gocc).to(dev)).sum() + (ovf * _rows(gfeat).to(dev)).sum()).backward()
+    assert_close(xd.grad.cpu().view(1, X, Y, Z, 4 * C), xr.grad, what="d input")
+    n = 0
+    for mod, sd in zip(mods, sds):
+        for name, p in mod.named_parameters():
+            if p.dim() == 5 and sd[name].grad is not None:
+                assert p.grad is not None, name
+                sc = max(1.0, float(sd[name].grad.abs().max()))
+                assert_close(p.grad.cpu() / sc, sd[name].grad / sc, what=name)
+                n += 1
+    assert n == 30 + 4 + 2 + 2           # trunk, 4 occ_convs, 2 soft-weight convs, 2 prediction convs
