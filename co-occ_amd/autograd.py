@@ -488,3 +488,73 @@ def occhead_coarse_train(head, feats):
     h, _ = conv3d_rows(out, pc[0].weight, g0, bias=pc[0].bias, bn=pc[1], relu=True)
     occ, _ = conv3d_rows(h, pc[3].weight, g0, bias=pc[3].bias, relu=False)
     return out, occ
+
+
+# ----------------------------------------------------------------------------- fine branch (C4)
+class FineSampleVoxelFn(torch.autograd.Function):
+    """Trilinear grid_sample of out_voxel_feats at the fine children of the selected coarse voxels (occ_head.py:205-214).
+    vol2d [X*Y*Z, C] rows, coarse_lin int32 [n] -> (feat [r^3*n, C], fine_xyz int64 [3, r^3*n])."""
+
+    @staticmethod
+    def forward(ctx, vol2d, coarse_lin, geom, ratio, final_size):
+        from ._lib import host_i32
+        _, X, Y, Z = geom
+        C = vol2d.shape[1]
+        n = coarse_lin.numel()
+        nf = n * ratio ** 3
+        fine_xyz = torch.empty(3, nf, device=vol2d.device, dtype=torch.int64)
+        feat = torch.empty(nf, C, device=vol2d.device, dtype=_F32)
+        call("coocc_fine_sample_voxel", ptr(vol2d.contiguous()), C, X, Y, Z, ptr(coarse_lin), n, ratio, host_i32(final_size),
+             ptr(fine_xyz), ptr(feat), C)
+        ctx.save_for_backward(fine_xyz)
+        ctx.cfg = (X, Y, Z, C, tuple(final_size))
+        ctx.mark_non_differentiable(fine_xyz)
+        return feat, fine_xyz
+
+    @staticmethod
+    def backward(ctx, dfeat, _):
+        from ._lib import host_i32
+        (fine_xyz,) = ctx.saved_tensors
+        X, Y, Z, C, final_size = ctx.cfg
+        dvol = torch.empty(X * Y * Z, C, device=dfeat.device, dtype=_F32)
+        call("coocc_fine_sample_voxel_bwd", ptr(dfeat.float().contiguous()), C, C, X, Y, Z, ptr(fine_xyz), fine_xyz.shape[1],
+             host_i32(final_size), ptr(dvol))
+        return dvol, None, None, None, None
+
+
+class GroupNormRowsFn(torch.autograd.Function):
+    """nn.GroupNorm on rows [n, C] followed by ReLU (occ_head.py:70-83), differentiable in x, gamma, beta."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu):
+        y = x.float().contiguous().clone()
+        n, C = y.shape
+        call("coocc_groupnorm_rows", ptr(y), n, C, C, groups, ptr(gamma.detach().float().contiguous()),
+             ptr(beta.detach().float().contiguous()), float(eps), int(relu))
+        ctx.save_for_backward(x.float().contiguous(), y, gamma.detach().float().contiguous())
+        ctx.cfg = (groups, float(eps), int(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma = ctx.saved_tensors
+        groups, eps, relu = ctx.cfg
+        n, C = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, device=x.device, dtype=_F32)
+        dbeta = torch.empty(C, device=x.device, dtype=_F32)
+        call("coocc_groupnorm_rows_bwd", ptr(x), ptr(y), ptr(dy.float().contiguous()), n, C, C, groups, ptr(gamma), eps, relu,
+             ptr(dx), ptr(dgamma), ptr(dbeta))
+        return dx, dgamma, dbeta, None, None, None
+
+
+def fine_branch_train(head, out_voxel_rows, geom, coarse_lin):
+    """Differentiable fine branch for voxel-only sampling (sample_from_img=False): the selected coarse voxels' children
+    sample out_voxel_feats trilinearly, then fine_mlp = Linear -> GroupNorm -> ReLU -> Linear (occ_head.py:180-237).
+    The selection itself (argmax != empty, or the training-time random top-k) is an index and not differentiated."""
+    feat, fine_xyz = FineSampleVoxelFn.apply(out_voxel_rows, coarse_lin, tuple(geom), head.cascade_ratio,
+                                             tuple(int(v) for v in head.final_occ_size))
+    h = linear_rows(feat, head.fine_mlp[0].weight, head.fine_mlp[0].bias, relu=False)
+    gn = head.fine_mlp[1]
+    h = GroupNormRowsFn.apply(h, gn.weight, gn.bias, gn.num_groups, gn.eps, True)
+    return linear_rows(h, head.fine_mlp[3].weight, head.fine_mlp[3].bias, relu=False), fine_xyz

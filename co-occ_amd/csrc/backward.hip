@@ -471,3 +471,116 @@ extern "C" int coocc_occhead_mix_bwd(const float* const* levels_host, const int*
   COOCC_LAUNCH_CHECK("k_occhead_mix_bwd");
   return COOCC_OK;
 }
+
+// ------------------------------------------------------------------ fine branch backward (C4)
+// coocc_fine_sample_voxel backward: trilinear grid_sample(align_corners=False, zeros) adjoint.  One wave per fine
+// point, lanes along channels; the 8 corner rows of dvol receive w * dfeat[f] with hardware fp32 atomics.
+__global__ __launch_bounds__(256) void k_fine_sample_voxel_bwd(const float* __restrict__ dfeat, int dfeat_stride, int C, int X,
+                                                                int Y, int Z, const int64_t* __restrict__ fine_xyz,
+                                                                long long nf, float fx1, float fy1, float fz1,
+                                                                float* __restrict__ dvol) {
+  const long long f = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (f >= nf) return;
+  const int qx = (int)fine_xyz[f], qy = (int)fine_xyz[nf + f], qz = (int)fine_xyz[2 * nf + f];
+  float gx = ((float)qx / fx1 - 0.5f) * 2.f, gy = ((float)qy / fy1 - 0.5f) * 2.f, gz = ((float)qz / fz1 - 0.5f) * 2.f;
+  float px = ((gx + 1.f) * (float)X - 1.f) / 2.f, py = ((gy + 1.f) * (float)Y - 1.f) / 2.f, pz = ((gz + 1.f) * (float)Z - 1.f) / 2.f;
+  float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+  int x0 = (int)flx, y0 = (int)fly, z0 = (int)flz;
+  float tx = px - flx, ty = py - fly, tz = pz - flz;
+  float wx[2] = {1.f - tx, tx}, wy[2] = {1.f - ty, ty}, wz[2] = {1.f - tz, tz};
+  for (int c = lane; c < C; c += 64) {
+    const float g = dfeat[(size_t)f * dfeat_stride + c];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          int x = x0 + a, y = y0 + b, z = z0 + d;
+          if ((unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y && (unsigned)z < (unsigned)Z)
+            unsafeAtomicAdd(dvol + (((size_t)x * Y + y) * Z + z) * C + c, g * (wx[a] * wy[b] * wz[d]));
+        }
+  }
+}
+
+extern "C" int coocc_fine_sample_voxel_bwd(const float* dfeat, int dfeat_stride, int C, int X, int Y, int Z,
+                                           const int64_t* fine_xyz, int64_t nfine, const int* final_size_host, float* dvol,
+                                           void* stream) {
+  COOCC_CHECK_ARG(dfeat && fine_xyz && final_size_host && dvol && C > 0 && nfine >= 0, "fine_sample_voxel_bwd: bad args");
+  hipStream_t s = as_stream(stream);
+  COOCC_HIP(hipMemsetAsync(dvol, 0, sizeof(float) * (size_t)X * Y * Z * C, s));
+  if (nfine == 0) return COOCC_OK;
+  hipLaunchKernelGGL(k_fine_sample_voxel_bwd, dim3(cdiv(nfine * 64, 256)), dim3(256), 0, s, dfeat, dfeat_stride, C, X, Y, Z, fine_xyz,
+                     (long long)nfine, (float)(final_size_host[0] - 1), (float)(final_size_host[1] - 1),
+                     (float)(final_size_host[2] - 1), dvol);
+  COOCC_LAUNCH_CHECK("k_fine_sample_voxel_bwd");
+  return COOCC_OK;
+}
+
+// nn.GroupNorm over rows [n, C] (+ReLU) backward.  y = relu(xhat * gamma + beta), xhat = (x - mean) * rstd per (row, group).
+//   dxhat = dy * [y > 0] * gamma;   dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat))
+//   dgamma = sum_rows dy' * xhat,   dbeta = sum_rows dy'     (column sums: per-block partials in LDS, then fp32 atomics)
+// x is the PRE-norm input (the forward kernel works in place, so the caller keeps a copy), y the post-ReLU output.
+__global__ __launch_bounds__(256) void k_groupnorm_rows_bwd(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ dy, long long n, int C, int stride,
+                                                             int groups, const float* __restrict__ gamma, float eps, int relu,
+                                                             float* __restrict__ dx, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+  extern __shared__ float s_part[];   // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) s_part[i] = 0.f;
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * groups) {
+    const long long row = i / groups;
+    const int g = (int)(i - row * groups);
+    const int cpg = C / groups;
+    const float* px = x + row * stride + g * cpg;
+    const float* pdy = dy + row * stride + g * cpg;
+    const float* py = y + row * stride + g * cpg;
+    float mean = 0.f;
+    for (int c = 0; c < cpg; ++c) mean += px[c];
+    mean /= (float)cpg;
+    float var = 0.f;
+    for (int c = 0; c < cpg; ++c) { float d = px[c] - mean; var += d * d; }
+    var /= (float)cpg;
+    const float rstd = 1.f / sqrtf(var + eps);
+    float m1 = 0.f, m2 = 0.f;
+    for (int c = 0; c < cpg; ++c) {
+      const float xh = (px[c] - mean) * rstd;
+      float g_ = pdy[c];
+      if (relu && !(py[c] > 0.f)) g_ = 0.f;
+      atomicAdd(&s_part[g * cpg + c], g_ * xh);
+      atomicAdd(&s_part[C + g * cpg + c], g_);
+      const float dxh = g_ * gamma[g * cpg + c];
+      m1 += dxh; m2 += dxh * xh;
+    }
+    m1 /= (float)cpg; m2 /= (float)cpg;
+    for (int c = 0; c < cpg; ++c) {
+      const float xh = (px[c] - mean) * rstd;
+      float g_ = pdy[c];
+      if (relu && !(py[c] > 0.f)) g_ = 0.f;
+      dx[row * stride + g * cpg + c] = rstd * (g_ * gamma[g * cpg + c] - m1 - xh * m2);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    if (dgamma) unsafeAtomicAdd(dgamma + c, s_part[c]);
+    if (dbeta) unsafeAtomicAdd(dbeta + c, s_part[C + c]);
+  }
+}
+
+extern "C" int coocc_groupnorm_rows_bwd(const float* x, const float* y, const float* dy, int64_t n, int C, int stride, int groups,
+                                        const float* gamma, float eps, int relu, float* dx, float* dgamma, float* dbeta,
+                                        void* stream) {
+  COOCC_CHECK_ARG(x && y && dy && gamma && dx && C > 0 && groups > 0 && C % groups == 0 && stride >= C && C <= 4096,
+                  "groupnorm_rows_bwd: bad args");
+  hipStream_t s = as_stream(stream);
+  if (dgamma) COOCC_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * C, s));
+  if (dbeta) COOCC_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * C, s));
+  if (n == 0) return COOCC_OK;
+  hipLaunchKernelGGL(k_groupnorm_rows_bwd, dim3(cdiv(n * groups, 256)), dim3(256), 2 * C * sizeof(float), s, x, y, dy, (long long)n, C,
+                     stride, groups, gamma, eps, relu, dx, dgamma, dbeta);
+  COOCC_LAUNCH_CHECK("k_groupnorm_rows_bwd");
+  return COOCC_OK;
+}

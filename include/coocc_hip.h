@@ -223,6 +223,16 @@ int coocc_occhead_mix_bwd(const float* const* levels_host, const int* dims_host,
                           const float* dout, float* const* glevels_host, float* dwlogit, int B, int C,
                           void* stream);
 
+/* coocc_fine_sample_voxel backward: dvol:[X*Y*Z,C] (zeroed here) += trilinear weights * dfeat rows (fp32 atomics). */
+int coocc_fine_sample_voxel_bwd(const float* dfeat, int dfeat_stride, int C, int X, int Y, int Z,
+                                const int64_t* fine_xyz, int64_t nfine, const int* final_size_host, float* dvol,
+                                void* stream);
+/* coocc_groupnorm_rows backward.  x: rows BEFORE the (in-place) forward, y: rows after it, dy: upstream gradient, all
+ * [n, stride] with C normalised channels; dx same layout; dgamma/dbeta:[C] (zeroed here; may be NULL). */
+int coocc_groupnorm_rows_bwd(const float* x, const float* y, const float* dy, int64_t n, int C, int stride, int groups,
+                             const float* gamma, float eps, int relu, float* dx, float* dgamma, float* dbeta,
+                             void* stream);
+
 /* FPN3D top-down step (fpn3d.py:88-92): fine += trilinear(coarse -> fine size),
  * align_corners=False.  Rows NDHWC with C channels. */
 int coocc_upsample_add_trilinear(const float* coarse, float* fine, int B, int C, int Xc, int Yc,

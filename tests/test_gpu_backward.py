@@ -355,3 +355,62 @@ def test_decoder_with_coarse_head_backward_vs_oracle_autograd(dev):
                 assert_close(p.grad.cpu() / sc, sd[name].grad / sc, what=name)
                 n += 1
     assert n == 30 + 4 + 2 + 2           # trunk, 4 occ_convs, 2 soft-weight convs, 2 prediction convs
+
+
+def test_groupnorm_rows_backward(dev):
+    g = torch.Generator().manual_seed(17)
+    n, C, groups = 333, 64, 16
+    x = torch.randn(n, C, generator=g)
+    gn = torch.nn.GroupNorm(groups, C)
+    gn.weight.data.copy_(torch.rand(C, generator=g) + 0.5)
+    gn.bias.data.copy_(torch.randn(C, generator=g) * 0.2)
+    gout = torch.randn(n, C, generator=g)
+    xr = x.clone().requires_grad_()
+    F.relu(gn(xr)).backward(gout)
+    xd = x.to(dev).requires_grad_()
+    wd, bd = gn.weight.detach().clone().to(dev).requires_grad_(), gn.bias.detach().clone().to(dev).requires_grad_()
+    y = ag.GroupNormRowsFn.apply(xd, wd, bd, groups, gn.eps, True)
+    assert_close(y.detach().cpu(), F.relu(gn(x)).detach(), what="gn forward")
+    y.backward(gout.to(dev))
+    assert_close(xd.grad.cpu(), xr.grad, what="gn dx")
+    assert_close(wd.grad.cpu(), gn.weight.grad, what="gn dgamma")
+    assert_close(bd.grad.cpu(), gn.bias.grad, what="gn dbeta")
+
+
+def test_fine_branch_backward_vs_torch(dev):
+    """Voxel-only fine branch: trilinear grid_sample adjoint (atomics) + Linear + GroupNorm + ReLU + Linear against torch
+    autograd of F.grid_sample (align_corners=False, zeros) with the reference's coordinate normalisation."""
+    import co_occ_amd.synth as synth
+    g = torch.Generator().manual_seed(23)
+    C, (X, Y, Z), r = 128, (6, 5, 4), 2
+    cfg = synth.model_cfg(C=8, block_inplanes=(16, 32, 64, 128), out_channels=256, final_occ_size=(X * r, Y * r, Z * r))
+    head = pkg.build_head(dict(cfg["pts_bbox_head"], norm_cfg=dict(type="BN3d"), sample_from_img=False)).eval()
+    head.load_state_dict(synth.random_state_dict(head.state_dict(), seed=3))
+    vol = torch.randn(1, C, X, Y, Z, generator=g)
+    sel = torch.randperm(X * Y * Z, generator=g)[:37].sort().values.int()
+    gout = torch.randn(37 * r ** 3, 17, generator=g)
+    # torch reference (occ_head.py:199-214): fine coords, normalise by (final - 1), grid_sample on the permuted volume
+    vr = vol.clone().requires_grad_()
+    cz, cy, cx = sel % Z, (sel // Z) % Y, sel // (Y * Z)
+    offs = torch.stack(torch.meshgrid(torch.arange(r), torch.arange(r), torch.arange(r), indexing="ij"), -1).view(-1, 3)
+    fine = torch.cat([torch.stack([cx * r + o[0], cy * r + o[1], cz * r + o[2]], 0) for o in offs], 1)     # [3, r^3 n], offset-major
+    norm = (fine.float() / torch.tensor([X * r - 1, Y * r - 1, Z * r - 1.0]).view(3, 1) - 0.5) * 2
+    grid = norm.t().view(1, 1, 1, -1, 3)
+    samp = F.grid_sample(vr.permute(0, 1, 4, 3, 2), grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    feat_r = samp[0, :, 0, 0].t()
+    fm = head.fine_mlp
+    out_r = fm[3](F.relu(fm[1](fm[0](feat_r))))
+    out_r.backward(gout)
+    ref_grads = [p.grad.clone() for p in fm.parameters()]
+    for p in fm.parameters():
+        p.grad = None
+    head = head.to(dev)
+    vd = _rows(vol).to(dev).requires_grad_()
+    out, fine_xyz = ag.fine_branch_train(head, vd, (1, X, Y, Z), sel.to(dev))
+    assert torch.equal(fine_xyz.cpu(), fine.long())
+    assert_close(out.detach().cpu(), out_r.detach(), what="fine logits")
+    out.backward(gout.to(dev))
+    assert_close(_vol(vd.grad.cpu(), 1, X, Y, Z), vr.grad, what="d out_voxel_feats")
+    for p, rg in zip(head.fine_mlp.parameters(), ref_grads):
+        sc = max(1.0, float(rg.abs().max()))
+        assert_close(p.grad.cpu() / sc, rg / sc, what="fine_mlp grads")
