@@ -88,6 +88,8 @@ SIGNATURES = {
     "coocc_occhead_mix_bwd": (I, [P, P, I, P, P, P, P, I, I, P]),
     "coocc_fine_sample_voxel_bwd": (I, [P, I, I, I, I, I, P, L, P, P, P]),
     "coocc_groupnorm_rows_bwd": (I, [P, P, P, L, I, I, I, P, F, I, P, P, P, P]),
+    "coocc_fine_sample_img_bwd": (I, [P, I, I, I, I, I, P, P, L, P, P]),
+    "coocc_groupnorm_nhwc_bwd": (I, [P, P, P, I, I, I, I, P, F, I, P, P, P, P]),
     "coocc_eval_semantic": (I, [P, L, L, L, L, I, I, I, I, P, P, I, I, I, I, I, P, P]),
 }
 

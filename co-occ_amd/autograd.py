@@ -548,13 +548,83 @@ class GroupNormRowsFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None
 
 
-def fine_branch_train(head, out_voxel_rows, geom, coarse_lin):
-    """Differentiable fine branch for voxel-only sampling (sample_from_img=False): the selected coarse voxels' children
-    sample out_voxel_feats trilinearly, then fine_mlp = Linear -> GroupNorm -> ReLU -> Linear (occ_head.py:180-237).
-    The selection itself (argmax != empty, or the training-time random top-k) is an index and not differentiated."""
-    feat, fine_xyz = FineSampleVoxelFn.apply(out_voxel_rows, coarse_lin, tuple(geom), head.cascade_ratio,
+class FineSampleImgFn(torch.autograd.Function):
+    """Camera branch of C4: project fine points into the cameras and sum the bilinear samples of img rows
+    [ncam*Hf*Wf, Ci] (occ_head.py:217-234); gradient w.r.t. the image features."""
+
+    @staticmethod
+    def forward(ctx, img_rows, params, fine_xyz, ncam, Hf, Wf, ratio):
+        Ci = img_rows.shape[1]
+        nf = fine_xyz.shape[1]
+        samp = torch.empty(nf, Ci, device=img_rows.device, dtype=_F32)
+        call("coocc_fine_sample_img", ptr(img_rows.contiguous()), ncam, Ci, Hf, Wf, ptr(params), ptr(fine_xyz), nf, ptr(samp), Ci,
+             1 if ratio == 2 else 0)
+        ctx.save_for_backward(params, fine_xyz)
+        ctx.cfg = (ncam, Ci, Hf, Wf)
+        return samp
+
+    @staticmethod
+    def backward(ctx, dsamp):
+        params, fine_xyz = ctx.saved_tensors
+        ncam, Ci, Hf, Wf = ctx.cfg
+        dimg = torch.empty(ncam * Hf * Wf, Ci, device=dsamp.device, dtype=_F32)
+        call("coocc_fine_sample_img_bwd", ptr(dsamp.float().contiguous()), Ci, ncam, Ci, Hf, Wf, ptr(params), ptr(fine_xyz),
+             fine_xyz.shape[1], ptr(dimg))
+        return dimg, None, None, None, None, None, None
+
+
+class GroupNormNHWCFn(torch.autograd.Function):
+    """nn.GroupNorm over [N, HW, C] image rows followed by ReLU (occ_head.py:64-68)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, N, HW, groups, eps, relu):
+        y = x.float().contiguous().clone()
+        C = y.shape[1]
+        call("coocc_groupnorm_nhwc", ptr(y), N, HW, C, groups, ptr(gamma.detach().float().contiguous()),
+             ptr(beta.detach().float().contiguous()), float(eps), int(relu))
+        ctx.save_for_backward(x.float().contiguous(), y, gamma.detach().float().contiguous())
+        ctx.cfg = (N, HW, groups, float(eps), int(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma = ctx.saved_tensors
+        N, HW, groups, eps, relu = ctx.cfg
+        C = x.shape[1]
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, device=x.device, dtype=_F32)
+        dbeta = torch.empty(C, device=x.device, dtype=_F32)
+        call("coocc_groupnorm_nhwc_bwd", ptr(x), ptr(y), ptr(dy.float().contiguous()), N, HW, C, groups, ptr(gamma), eps, relu,
+             ptr(dx), ptr(dgamma), ptr(dbeta))
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def fine_branch_train(head, out_voxel_rows, geom, coarse_lin, img_feats=None, transform=None):
+    """Differentiable fine branch (occ_head.py:180-237): the selected coarse voxels' children sample out_voxel_feats
+    trilinearly and, with sample_from_img, the image features through the cameras; fine_mlp = Linear -> GroupNorm ->
+    ReLU -> Linear.  The selection itself (argmax != empty, or the training-time random top-k) is an index and not
+    differentiated.  img_feats: [[1,N,Cimg,Hf,Wf]] (a leaf may require grad); transform: img_inputs[1:]."""
+    r = head.cascade_ratio
+    feat, fine_xyz = FineSampleVoxelFn.apply(out_voxel_rows, coarse_lin, tuple(geom), r,
                                              tuple(int(v) for v in head.final_occ_size))
-    h = linear_rows(feat, head.fine_mlp[0].weight, head.fine_mlp[0].bias, relu=False)
+    parts = [feat] if head.sample_from_voxel else []
+    if head.sample_from_img and img_feats is not None:
+        f = img_feats[0]
+        _, N_i, C_i, Hf, Wf = f.shape
+        rows = f[0].permute(0, 2, 3, 1).reshape(N_i * Hf * Wf, C_i)            # NHWC rows (a view + copy: plumbing)
+        m0 = head.img_mlp_0
+        g = linear_rows(rows, m0[0].weight.flatten(1), m0[0].bias, relu=False)
+        g = GroupNormNHWCFn.apply(g, m0[1].weight, m0[1].bias, N_i, Hf * Wf, m0[1].num_groups, m0[1].eps, True)
+
+        class _G:       # geometry holder for the parameter block
+            X, Y, Z = geom[1], geom[2], geom[3]
+        params = head._projection_params(transform, _G, out_voxel_rows.device)
+        samp = FineSampleImgFn.apply(g, params, fine_xyz, N_i, Hf, Wf, r)
+        m1 = head.img_mlp
+        s_ = linear_rows(samp, m1[0].weight, m1[0].bias, relu=False)
+        parts.append(GroupNormRowsFn.apply(s_, m1[1].weight, m1[1].bias, m1[1].num_groups, m1[1].eps, True))
+    x = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
+    h = linear_rows(x, head.fine_mlp[0].weight, head.fine_mlp[0].bias, relu=False)
     gn = head.fine_mlp[1]
     h = GroupNormRowsFn.apply(h, gn.weight, gn.bias, gn.num_groups, gn.eps, True)
     return linear_rows(h, head.fine_mlp[3].weight, head.fine_mlp[3].bias, relu=False), fine_xyz

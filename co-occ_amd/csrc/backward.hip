@@ -584,3 +584,142 @@ extern "C" int coocc_groupnorm_rows_bwd(const float* x, const float* y, const fl
   COOCC_LAUNCH_CHECK("k_groupnorm_rows_bwd");
   return COOCC_OK;
 }
+
+// coocc_fine_sample_img backward: adjoint of the per-camera bilinear grid_sample(align_corners=True, zeros) * mask summed
+// over cameras.  Same projection as the forward (fine.hip), one wave per fine point, lanes along channels, fp32 atomics
+// into dimg:[ncam,Hf,Wf,Ci].  params: the block built by coocc_projection_params.
+__global__ __launch_bounds__(256) void k_fine_sample_img_bwd(const float* __restrict__ dfeat, int dfeat_stride, int ncam, int Ci,
+                                                              int Hf, int Wf, const float* __restrict__ prm,
+                                                              const int64_t* __restrict__ fine_xyz, long long nf,
+                                                              float* __restrict__ dimg) {
+  const long long f = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (f >= nf) return;
+  float p0 = (float)fine_xyz[f] * prm[9] + prm[12];
+  float p1 = (float)fine_xyz[nf + f] * prm[10] + prm[13];
+  float p2 = (float)fine_xyz[2 * nf + f] * prm[11] + prm[14];
+  float bx = prm[0] * p0 + prm[1] * p1 + prm[2] * p2;
+  float by = prm[3] * p0 + prm[4] * p1 + prm[5] * p2;
+  float bz = prm[6] * p0 + prm[7] * p1 + prm[8] * p2;
+  const float wimg1 = prm[15], himg1 = prm[16];
+  for (int cam = 0; cam < ncam; ++cam) {
+    const float* q = prm + 17 + cam * 27;
+    float tx = bx - q[9], ty = by - q[10], tz = bz - q[11];
+    float cx = q[0] * tx + q[1] * ty + q[2] * tz;
+    float cy = q[3] * tx + q[4] * ty + q[5] * tz;
+    float cz = q[6] * tx + q[7] * ty + q[8] * tz;
+    float ix = q[12] * cx + q[13] * cy + q[14] * cz;
+    float iy = q[15] * cx + q[16] * cy + q[17] * cz;
+    float d = q[18] * cx + q[19] * cy + q[20] * cz;
+    float u = ix / (d + 1e-5f), v = iy / (d + 1e-5f);
+    float u2 = q[21] * u + q[22] * v + q[25];
+    float v2 = q[23] * u + q[24] * v + q[26];
+    u2 = (u2 / wimg1 - 0.5f) * 2.f;
+    v2 = (v2 / himg1 - 0.5f) * 2.f;
+    bool m = d > 1e-5f && u2 > -1.f && u2 < 1.f && v2 > -1.f && v2 < 1.f;
+    if (!m) continue;
+    float px = (u2 + 1.f) / 2.f * (float)(Wf - 1), py = (v2 + 1.f) / 2.f * (float)(Hf - 1);
+    float flx = floorf(px), fly = floorf(py);
+    int x0 = (int)flx, y0 = (int)fly;
+    float ax = px - flx, ay = py - fly;
+    float* base = dimg + (size_t)cam * Hf * Wf * Ci;
+    for (int c = lane; c < Ci; c += 64) {
+      const float g = dfeat[(size_t)f * dfeat_stride + c];
+#pragma unroll
+      for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+        for (int xx = 0; xx < 2; ++xx) {
+          int x = x0 + xx, y = y0 + yy;
+          if ((unsigned)x < (unsigned)Wf && (unsigned)y < (unsigned)Hf)
+            unsafeAtomicAdd(base + ((size_t)y * Wf + x) * Ci + c, g * ((xx ? ax : 1.f - ax) * (yy ? ay : 1.f - ay)));
+        }
+    }
+  }
+}
+
+extern "C" int coocc_fine_sample_img_bwd(const float* dfeat, int dfeat_stride, int ncam, int Ci, int Hf, int Wf,
+                                         const float* params, const int64_t* fine_xyz, int64_t nfine, float* dimg,
+                                         void* stream) {
+  COOCC_CHECK_ARG(dfeat && params && fine_xyz && dimg && ncam > 0 && Ci > 0 && nfine >= 0, "fine_sample_img_bwd: bad args");
+  hipStream_t s = as_stream(stream);
+  COOCC_HIP(hipMemsetAsync(dimg, 0, sizeof(float) * (size_t)ncam * Hf * Wf * Ci, s));
+  if (nfine == 0) return COOCC_OK;
+  hipLaunchKernelGGL(k_fine_sample_img_bwd, dim3(cdiv(nfine * 64, 256)), dim3(256), 0, s, dfeat, dfeat_stride, ncam, Ci, Hf, Wf, params,
+                     fine_xyz, (long long)nfine, dimg);
+  COOCC_LAUNCH_CHECK("k_fine_sample_img_bwd");
+  return COOCC_OK;
+}
+
+// nn.GroupNorm over an NHWC image batch (+ReLU) backward: statistics per (image, group) over HW * C/groups values.
+// One block per (group, image), like the forward.  x = input before the in-place forward, y = output after it.
+__global__ __launch_bounds__(256) void k_groupnorm_nhwc_bwd(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ dy, int HW, int C, int groups,
+                                                             const float* __restrict__ gamma, float eps, int relu,
+                                                             float* __restrict__ dx, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+  __shared__ double s_r[4][4];
+  __shared__ float s_stat[4];      // mean, rstd, m1, m2
+  __shared__ float s_g[64], s_b[64];
+  const int n = blockIdx.y, g = blockIdx.x, cpg = C / groups;
+  const size_t off = (size_t)n * HW * C + g * cpg;
+  const int total = HW * cpg;
+  auto block_sum2 = [&](double a, double b, double& ra, double& rb) {
+    for (int m = 32; m > 0; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s_r[threadIdx.x >> 6][0] = a; s_r[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    ra = s_r[0][0] + s_r[1][0] + s_r[2][0] + s_r[3][0];
+    rb = s_r[0][1] + s_r[1][1] + s_r[2][1] + s_r[3][1];
+  };
+  if (threadIdx.x < 64) { s_g[threadIdx.x] = 0.f; s_b[threadIdx.x] = 0.f; }
+  double sum = 0, sq = 0;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    float v = x[off + (size_t)(i / cpg) * C + (i % cpg)];
+    sum += v; sq += (double)v * v;
+  }
+  double a, b;
+  block_sum2(sum, sq, a, b);
+  const double meand = a / total, vard = b / total - meand * meand;
+  const float mean = (float)meand, rstd = (float)(1.0 / sqrt((vard > 0 ? vard : 0) + (double)eps));
+  double m1 = 0, m2 = 0;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int c = i % cpg;
+    const size_t idx = off + (size_t)(i / cpg) * C + c;
+    const float xh = (x[idx] - mean) * rstd;
+    float g_ = dy[idx];
+    if (relu && !(y[idx] > 0.f)) g_ = 0.f;
+    atomicAdd(&s_g[c], g_ * xh);
+    atomicAdd(&s_b[c], g_);
+    const float dxh = g_ * gamma[g * cpg + c];
+    m1 += dxh; m2 += (double)dxh * xh;
+  }
+  block_sum2(m1, m2, a, b);
+  const float fm1 = (float)(a / total), fm2 = (float)(b / total);
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int c = i % cpg;
+    const size_t idx = off + (size_t)(i / cpg) * C + c;
+    const float xh = (x[idx] - mean) * rstd;
+    float g_ = dy[idx];
+    if (relu && !(y[idx] > 0.f)) g_ = 0.f;
+    dx[idx] = rstd * (g_ * gamma[g * cpg + c] - fm1 - xh * fm2);
+  }
+  __syncthreads();
+  if (threadIdx.x < cpg) {
+    if (dgamma) unsafeAtomicAdd(dgamma + g * cpg + threadIdx.x, s_g[threadIdx.x]);
+    if (dbeta) unsafeAtomicAdd(dbeta + g * cpg + threadIdx.x, s_b[threadIdx.x]);
+  }
+}
+
+extern "C" int coocc_groupnorm_nhwc_bwd(const float* x, const float* y, const float* dy, int N, int HW, int C, int groups,
+                                        const float* gamma, float eps, int relu, float* dx, float* dgamma, float* dbeta,
+                                        void* stream) {
+  COOCC_CHECK_ARG(x && y && dy && gamma && dx && N > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && C / groups <= 64,
+                  "groupnorm_nhwc_bwd: bad args (channels per group <= 64)");
+  hipStream_t s = as_stream(stream);
+  if (dgamma) COOCC_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * C, s));
+  if (dbeta) COOCC_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * C, s));
+  hipLaunchKernelGGL(k_groupnorm_nhwc_bwd, dim3(groups, N), dim3(256), 0, s, x, y, dy, HW, C, groups, gamma, eps, relu, dx, dgamma,
+                     dbeta);
+  COOCC_LAUNCH_CHECK("k_groupnorm_nhwc_bwd");
+  return COOCC_OK;
+}

@@ -233,6 +233,15 @@ int coocc_groupnorm_rows_bwd(const float* x, const float* y, const float* dy, in
                              const float* gamma, float eps, int relu, float* dx, float* dgamma, float* dbeta,
                              void* stream);
 
+/* coocc_fine_sample_img backward: dimg:[ncam,Hf,Wf,Ci] (zeroed here) += bilinear weights * mask * dfeat rows. */
+int coocc_fine_sample_img_bwd(const float* dfeat, int dfeat_stride, int ncam, int Ci, int Hf, int Wf,
+                              const float* params, const int64_t* fine_xyz, int64_t nfine, float* dimg,
+                              void* stream);
+/* coocc_groupnorm_nhwc backward (x before / y after the in-place forward, [N,HW,C]); dgamma/dbeta:[C] zeroed here. */
+int coocc_groupnorm_nhwc_bwd(const float* x, const float* y, const float* dy, int N, int HW, int C, int groups,
+                             const float* gamma, float eps, int relu, float* dx, float* dgamma, float* dbeta,
+                             void* stream);
+
 /* FPN3D top-down step (fpn3d.py:88-92): fine += trilinear(coarse -> fine size),
  * align_corners=False.  Rows NDHWC with C channels. */
 int coocc_upsample_add_trilinear(const float* coarse, float* fine, int B, int C, int Xc, int Yc,

@@ -414,3 +414,68 @@ def test_fine_branch_backward_vs_torch(dev):
     for p, rg in zip(head.fine_mlp.parameters(), ref_grads):
         sc = max(1.0, float(rg.abs().max()))
         assert_close(p.grad.cpu() / sc, rg / sc, what="fine_mlp grads")
+
+
+def test_full_head_backward_vs_oracle_autograd(dev):
+    """OccHead coarse + fine (voxel and camera sampling) from FPN levels to fine logits: gradients w.r.t. the level inputs,
+    the image features and every head parameter vs torch autograd through the oracle (occ_head.py:149-237)."""
+    from oracle import cases, ref_cpu
+    import co_occ_amd.synth as synth
+    from co_occ_amd._lib import call as ccall, ptr as cptr
+    c = cases.DECODER_CASE
+    grid = (8, 6, 4)
+    final = tuple(2 * v for v in grid)
+    # the head hard-codes 128 voxel channels into fine_mlp (occ_head.py:96), i.e. FPN levels of 256 channels
+    cfg = synth.model_cfg(C=c["C"], block_inplanes=c["block_inplanes"], out_channels=256, cascade_ratio=2, final_occ_size=final,
+                          point_cloud_range=c["point_cloud_range"])
+    head = pkg.build_head(dict(cfg["pts_bbox_head"], norm_cfg=dict(type="BN3d"))).eval()
+    head.load_state_dict(synth.random_state_dict(head.state_dict(), seed=41))
+    g = torch.Generator().manual_seed(42)
+    sem = [torch.randn(1, 256, *[max(1, -(-v // 2 ** l)) for v in grid], generator=g) for l in range(4)]
+    rig = synth.camera_rig(c["ncam"], c["input_size"], seed=42)
+    img = synth.image_feats(c["ncam"], c["fmap"], 512, seed=42)
+    tr = synth.rig_transform(rig)
+    sd = {k: (v.clone().float().requires_grad_() if (v.is_floating_point() and "running_" not in k) else v.clone())
+          for k, v in head.state_dict().items()}
+    sem_r = [t.clone().requires_grad_() for t in sem]
+    img_r = img.clone().requires_grad_()
+    want = ref_cpu.occhead_forward(sd, sem_r, [img_r], tr, 2, final, c["point_cloud_range"])
+    gfine = torch.randn(want["fine_output"].shape, generator=g)
+    gocc = torch.randn(want["output_voxels"].shape, generator=g)
+    ((want["fine_output"] * gfine).sum() + (want["output_voxels"] * gocc).sum()).backward()
+
+    head = head.to(dev)
+    X, Y, Z = grid
+    feats = []
+    sem_d = []
+    for t in sem:
+        rows = _rows(t).to(dev).requires_grad_()
+        sem_d.append(rows)
+        feats.append((rows, (1,) + tuple(t.shape[2:])))
+    img_d = img.to(dev).requires_grad_()
+    ovf, occ = ag.occhead_coarse_train(head, feats)
+    # selection as in the inference head: argmax != empty -> ascending coarse voxel list (index work, no gradient)
+    flags = torch.empty(X * Y * Z, device=dev, dtype=torch.uint8)
+    occ_c = occ.detach().contiguous()
+    ccall("coocc_argmax_flags", cptr(occ_c), X * Y * Z, occ_c.shape[1], occ_c.shape[1], 0, cptr(flags))
+    lin = torch.nonzero(flags)[:, 0].int()
+    fine, fine_xyz = ag.fine_branch_train(head, ovf, (1, X, Y, Z), lin, [img_d[None] if img_d.dim() == 4 else img_d],
+                                          tuple(t.to(dev) if torch.is_tensor(t) else t for t in tr))
+    assert np.array_equal(fine_xyz.cpu().numpy(), want["fine_coord"].numpy())
+    assert_close(fine.detach().cpu(), want["fine_output"].detach(), what="fine logits")
+    ((fine * gfine.to(dev)).sum() + (occ * _rows(gocc).to(dev)).sum()).backward()
+    for a, b, l in zip(sem_d, sem_r, range(4)):
+        sc = max(1.0, float(b.grad.abs().max()))
+        assert_close(_vol(a.grad.cpu(), 1, *b.shape[2:]) / sc, b.grad / sc, what="d sem level %d" % l)
+    sc = max(1e-12, float(img_r.grad.abs().max()))
+    assert_close(img_d.grad.cpu() / sc, img_r.grad / sc, what="d img_feats")
+    n = 0
+    for name, p in head.named_parameters():
+        rg = sd[name].grad
+        if rg is None or "bn" in name or (".1." in name and p.dim() == 1 and "mlp" not in name):
+            continue                      # frozen BatchNorm affine parameters
+        assert p.grad is not None, name
+        sc = max(1e-12, float(rg.abs().max()))
+        assert_close(p.grad.cpu().view_as(rg) / sc, rg / sc, what=name)
+        n += 1
+    assert n >= 8 + 6 + 6        # conv weights/biases, three Linear layers, three GroupNorms
