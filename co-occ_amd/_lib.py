@@ -90,6 +90,13 @@ SIGNATURES = {
     "coocc_groupnorm_rows_bwd": (I, [P, P, P, L, I, I, I, P, F, I, P, P, P, P]),
     "coocc_fine_sample_img_bwd": (I, [P, I, I, I, I, I, P, P, L, P, P]),
     "coocc_groupnorm_nhwc_bwd": (I, [P, P, P, I, I, I, I, P, F, I, P, P, P, P]),
+    "coocc_voxelize_ws": (Z, [I]),
+    "coocc_voxelize_hard": (I, [P, I, I, P, P, I, I, P, P, P, P, P, Z, P]),
+    "coocc_vfe_mean": (I, [P, P, I, I, I, I, P, I, P]),
+    "coocc_sparse_index_map": (I, [P, I, I, I, I, P, P]),
+    "coocc_sparse_conv_table": (I, [P, I, I, I, I, I, I, I, P, P, P]),
+    "coocc_sparse_down_flags": (I, [P, I, I, I, I, I, I, I, P, P]),
+    "coocc_sparse_lin_to_coors": (I, [P, I, I, I, I, P, P, P]),
     "coocc_eval_semantic": (I, [P, L, L, L, L, I, I, I, I, P, P, I, I, I, I, I, P, P]),
 }
 

@@ -1,0 +1,284 @@
+"""LiDAR-side producer of ``pts_voxel_feats``: ``Voxelization`` (hard mode,
+mmdet3d/ops/voxel/voxelize.py:13-138), ``HardSimpleVFE`` (mmdet3d/models/voxel_encoders/voxel_encoder.py:14-45) and
+``SparseLiDAREnc8x`` / ``SparseLiDAREnc4x`` (P/coocc/voxel_encoder/sparse_lidar_enc.py:66-190).
+
+spconv 2.3.6 is an un-vendored dependency of the reference; its SubMConv3d / SparseConv3d semantics are restated:
+a rule book is a [27, M] table of input rows and every sparse convolution (+ folded eval-mode BN, ReLU, residual) is one
+launch of the row-table GEMM that GSFusion already uses (``coocc_conv_fwd`` with ``gather``).  Weights keep spconv 2.x's
+[Cout, kd, kh, kw, Cin] layout and the reference's state_dict keys.  Batch size 1 (the reference hard-codes it)."""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import ConvDesc, call, host_f32, ptr
+from .backbone import build_bn
+from .core import PackCache, PackedConv, Rows, TILE_HINT, fold_bn, workspace
+from .registry import Registry
+
+_F32, _I32 = torch.float32, torch.int32
+VOXEL_LAYERS = Registry("voxel_layer")
+VOXEL_ENCODERS = Registry("voxel_encoder")
+MIDDLE_ENCODERS = Registry("middle_encoder")
+
+
+# ----------------------------------------------------------------------------- voxelisation + VFE
+class Voxelization(nn.Module):
+    """Hard voxelisation: forward(points [N,F]) -> (voxels [M,max_points,F], coors [M,3] (z,y,x) int32, num_points [M])."""
+
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000, deterministic=True):
+        super().__init__()
+        self.voxel_size, self.point_cloud_range = list(voxel_size), list(point_cloud_range)
+        self.max_num_points = max_num_points
+        self.max_voxels = tuple(max_voxels) if isinstance(max_voxels, (tuple, list)) else (max_voxels, max_voxels)
+        self._ws = {}
+
+    def forward(self, points):
+        if not points.is_cuda:
+            raise _lib.CooccError("Voxelization runs on the GPU only (no CPU fallback)")
+        pts = points.float().contiguous()
+        n, F = pts.shape
+        mv = self.max_voxels[0] if self.training else self.max_voxels[1]
+        dev = pts.device
+        voxels = torch.empty(mv, self.max_num_points, F, device=dev, dtype=_F32)
+        coors = torch.empty(mv, 3, device=dev, dtype=_I32)
+        num = torch.empty(mv, device=dev, dtype=_I32)
+        count = torch.empty(1, device=dev, dtype=_I32)
+        need = int(_lib.load().coocc_voxelize_ws(n))
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        if key not in self._ws or self._ws[key].numel() < need:
+            self._ws[key] = torch.empty(need, device=dev, dtype=torch.uint8)
+        ws = self._ws[key]
+        call("coocc_voxelize_hard", ptr(pts), n, F, host_f32(self.point_cloud_range), host_f32(self.voxel_size),
+             self.max_num_points, mv, ptr(voxels), ptr(coors), ptr(num), ptr(count), ptr(ws), ws.numel())
+        m = int(count.item())
+        return voxels[:m], coors[:m], num[:m]
+
+
+VOXEL_LAYERS.register_module(name="Voxelization", module=Voxelization)
+
+
+@VOXEL_ENCODERS.register_module()
+class HardSimpleVFE(nn.Module):
+    def __init__(self, num_features=4):
+        super().__init__()
+        self.num_features = num_features
+
+    def forward(self, features, num_points, coors=None):
+        M, P, F = features.shape
+        nf = min(self.num_features, F)
+        out = torch.empty(M, nf, device=features.device, dtype=_F32)
+        call("coocc_vfe_mean", ptr(features.float().contiguous()), ptr(num_points.int().contiguous()), M, P, F, nf, ptr(out), nf)
+        return out
+
+
+# ----------------------------------------------------------------------------- sparse tensors and rule books
+class SparseRows:
+    """Active voxels of one resolution: feats [M,C], coors [M,3] (z,y,x) int32, spatial shape (D,H,W); rule books cached
+    by indice key as spconv does."""
+
+    def __init__(self, feats, coors, shape, books=None):
+        self.feats, self.coors, self.shape = feats, coors, tuple(shape)
+        self.books = books if books is not None else {}
+        self._map = None
+
+    def index_map(self):
+        if self._map is None:
+            D, H, W = self.shape
+            self._map = torch.empty(D * H * W, device=self.coors.device, dtype=_I32)
+            call("coocc_sparse_index_map", ptr(self.coors), self.coors.shape[0], D, H, W, ptr(self._map))
+        return self._map
+
+    def subm_table(self, key, ksize=3):
+        if key not in self.books:
+            D, H, W = self.shape
+            M = self.coors.shape[0]
+            t = torch.empty(ksize ** 3, M, device=self.coors.device, dtype=_I32)
+            call("coocc_sparse_conv_table", ptr(self.coors), M, D, H, W, ksize, 1, ksize // 2, ptr(self.index_map()), ptr(t))
+            self.books[key] = t
+        return self.books[key]
+
+    def downsample(self, ksize, stride, pad):
+        """Active set + rule book of SparseConv3d(ksize, stride, pad): (coors_out, shape_out, table [k^3, Mo])."""
+        D, H, W = self.shape
+        Do, Ho, Wo = ((v + 2 * pad - ksize) // stride + 1 for v in (D, H, W))
+        dev = self.coors.device
+        flags = torch.empty(Do * Ho * Wo, device=dev, dtype=torch.uint8)
+        call("coocc_sparse_down_flags", ptr(self.coors), self.coors.shape[0], ksize, stride, pad, Do, Ho, Wo, ptr(flags))
+        lin = torch.empty(Do * Ho * Wo, device=dev, dtype=_I32)
+        cnt = torch.empty(1, device=dev, dtype=_I32)
+        ws = torch.empty(Do * Ho * Wo // 1024 + 2, device=dev, dtype=_I32)
+        call("coocc_compact_flags", ptr(flags), Do * Ho * Wo, ptr(lin), ptr(cnt), ptr(ws), ws.numel() * 4)
+        Mo = int(cnt.item())
+        coors = torch.empty(Mo, 3, device=dev, dtype=_I32)
+        call("coocc_sparse_lin_to_coors", ptr(lin[:Mo]), Mo, Do, Ho, Wo, ptr(coors), None)
+        table = torch.empty(ksize ** 3, Mo, device=dev, dtype=_I32)
+        call("coocc_sparse_conv_table", ptr(coors), Mo, D, H, W, ksize, stride, pad, ptr(self.index_map()), ptr(table))
+        return coors, (Do, Ho, Wo), table
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def sparse_conv(feats, Cin, pc, table, relu=True, res=None, out=None, out_rows=None):
+    """out[o] = epi(sum_t W_t . feats[table[t][o]]): one row-table GEMM launch (BN folded into pc.scale/bias)."""
+    taps, Mo = table.shape
+    dev = feats.device
+    if out is None:
+        out = torch.empty(Mo, pc.Cout, device=dev, dtype=_F32)
+    if Mo == 0:
+        return out
+    ws = workspace(dev)
+    d = ConvDesc()
+    d.in_, d.w, d.out = ptr(feats), ptr(pc.w), ptr(out)
+    d.scale, d.bias = ptr(pc.scale), ptr(pc.bias)
+    d.res = ptr(res)
+    d.gather = ptr(table, _I32)
+    d.out_rows = ptr(out_rows, _I32) if out_rows is not None else None
+    d.ws, d.ws_floats = ptr(ws), ws.numel()
+    d.M, d.Cin, d.Cout, d.taps = Mo, Cin, pc.Cout, taps
+    d.in_stride, d.out_stride = feats.shape[1], out.shape[1]
+    d.res_stride = res.shape[1] if res is not None else 0
+    d.B = d.Xi = d.Yi = d.Zi = d.Xo = d.Yo = d.Zo = 1
+    d.ksize, d.stride, d.pad = 1, 1, 0
+    d.relu, d.res_mode, d.splitk, d.tile_hint = int(relu), (1 if res is not None else 0), 1, TILE_HINT
+    with _lib.TIMER.region("k_conv<sparse table>", 2.0 * Mo * Cin * pc.Cout * taps):
+        _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+    return out
+
+
+class _SpConv(nn.Module):
+    """Parameter holder with spconv 2.x's weight layout [Cout, k, k, k, Cin] (key ``weight``)."""
+
+    def __init__(self, cin, cout, ksize=3, bias=False):
+        super().__init__()
+        self.cin, self.cout, self.ksize = cin, cout, ksize
+        self.weight = nn.Parameter(torch.empty(cout, ksize, ksize, ksize, cin))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+
+    def packed(self, bn=None):
+        cin_p = _pad4(self.cin)
+        w = self.weight.detach().reshape(self.cout, self.ksize ** 3, self.cin)
+        if cin_p != self.cin:       # rows are padded to a multiple of 4 channels for the 16-byte gathers
+            w = torch.cat([w, w.new_zeros(self.cout, self.ksize ** 3, cin_p - self.cin)], 2)
+        return PackedConv(w.reshape(self.cout, -1).contiguous(), bn=bn, bias=self.bias, tap_major=True, taps=self.ksize ** 3)
+
+
+def _gn_rows(x, gn, relu=True):
+    call("coocc_groupnorm_rows", ptr(x), x.shape[0], x.shape[1], x.shape[1], gn.num_groups, ptr(gn.weight.detach()),
+         ptr(gn.bias.detach()), float(gn.eps), int(relu))
+    return x
+
+
+class _PostActBlock(nn.Sequential):
+    """post_act_block(conv_type='spconv'): SparseConv3d(k3, s2, p1, no bias) + BN1d + ReLU (keys 0.weight, 1.*)."""
+
+    def __init__(self, cin, cout, norm_cfg):
+        super().__init__(_SpConv(cin, cout, 3), _bn1d(norm_cfg, cout), nn.ReLU(inplace=True))
+
+
+def _bn1d(norm_cfg, c):
+    cfg = dict(norm_cfg or dict(type="BN1d"))
+    cfg.pop("type", None)
+    cfg.pop("requires_grad", None)
+    return nn.BatchNorm1d(c, **cfg)
+
+
+class SparseBasicBlock(nn.Module):
+    """sparse_lidar_enc.py:40-61: SubM3 + BN + ReLU + SubM3 + BN, + identity, ReLU (keys net.{0,1,3,4}.*)."""
+
+    def __init__(self, planes, norm_cfg):
+        super().__init__()
+        self.net = nn.Sequential(_SpConv(planes, planes, 3), _bn1d(norm_cfg, planes), nn.ReLU(inplace=True),
+                                 _SpConv(planes, planes, 3), _bn1d(norm_cfg, planes))
+
+
+class _SparseEncoderBase(nn.Module):
+    def __init__(self, input_channel, norm_cfg, base_channel, out_channel, sparse_shape_xyz, widths, first_down):
+        super().__init__()
+        self.sparse_shape_xyz = list(sparse_shape_xyz)
+        self.input_channel, self.out_channel = input_channel, out_channel
+        self.conv_input = nn.Sequential(_SpConv(input_channel, base_channel, 3, bias=True), nn.GroupNorm(16, base_channel),
+                                        nn.ReLU(inplace=True))
+        stages, cin = [], base_channel
+        for i, (c, down) in enumerate(zip(widths, first_down)):
+            mods = ([_PostActBlock(cin, c, norm_cfg)] if down else []) + [SparseBasicBlock(c, norm_cfg), SparseBasicBlock(c, norm_cfg)]
+            stages.append(nn.Sequential(*mods))
+            cin = c
+        self.conv1, self.conv2, self.conv3 = stages
+        self.conv_out = nn.Sequential(_SpConv(cin, out_channel, 3, bias=True), nn.GroupNorm(16, out_channel), nn.ReLU(inplace=True))
+        self._packs = PackCache()
+
+    def _packed(self):
+        srcs = list(self.parameters()) + list(self.buffers())
+
+        def build():
+            d = dict(inp=self.conv_input[0].packed(), out=self.conv_out[0].packed(), stages=[])
+            for st in (self.conv1, self.conv2, self.conv3):
+                ps = []
+                for m in st:
+                    if isinstance(m, _PostActBlock):
+                        ps.append(("down", m[0].packed(bn=m[1])))
+                    else:
+                        ps.append(("block", m.net[0].packed(bn=m.net[1]), m.net[3].packed(bn=m.net[4])))
+                d["stages"].append(ps)
+            return d
+        return self._packs.get(srcs, build)
+
+    def forward(self, voxel_features, coors, batch_size=1):
+        """voxel_features [M,Cin], coors [M,3] (z,y,x) or [M,4] (b,z,y,x) -> dict(x=[1,C,W,H,D] dense volume (channels-last
+        memory), pts_feats=[SparseRows])."""
+        if not voxel_features.is_cuda:
+            raise _lib.CooccError("the sparse LiDAR encoder runs on the GPU only (no CPU fallback)")
+        if coors.shape[1] == 4:
+            assert int(batch_size) == 1, "batch size 1 (hard-coded upstream, sparse_lidar_enc.py:109)"
+            coors = coors[:, 1:]
+        coors = coors.int().contiguous()
+        p = self._packed()
+        dev = voxel_features.device
+        M, Cin = voxel_features.shape
+        cin_p = _pad4(Cin)
+        x = voxel_features.float().contiguous()
+        if cin_p != Cin:
+            x = torch.cat([x, x.new_zeros(M, cin_p - Cin)], 1).contiguous()
+        cur = SparseRows(None, coors, self.sparse_shape_xyz[::-1])
+        f = _gn_rows(sparse_conv(x, cin_p, p["inp"], cur.subm_table("in"), relu=False), self.conv_input[1])
+        for si, ps in enumerate(p["stages"]):
+            for bi, item in enumerate(ps):
+                if item[0] == "down":
+                    coors_o, shape_o, table = cur.downsample(3, 2, 1)
+                    f = sparse_conv(f, f.shape[1], item[1], table, relu=True)
+                    cur = SparseRows(None, coors_o, shape_o)
+                else:
+                    tb = cur.subm_table("res%d" % si)
+                    h = sparse_conv(f, f.shape[1], item[1], tb, relu=True)
+                    f = sparse_conv(h, h.shape[1], item[2], tb, relu=True, res=f)
+        f = _gn_rows(sparse_conv(f, f.shape[1], p["out"], cur.subm_table("out"), relu=False), self.conv_out[1])
+        cur.feats = f
+        # dense().permute(0,1,4,3,2): [1, C, W, H, D] = (x, y, z); channels-last rows (x*H + y)*D + z
+        D, H, W = cur.shape
+        rows = torch.empty(f.shape[0], device=dev, dtype=_I32)
+        lin = ((cur.coors[:, 0].long() * H + cur.coors[:, 1]) * W + cur.coors[:, 2]).int().contiguous()
+        tmp = torch.empty_like(cur.coors)
+        call("coocc_sparse_lin_to_coors", ptr(lin), f.shape[0], D, H, W, ptr(tmp), ptr(rows))
+        dense = torch.zeros(W * H * D, f.shape[1], device=dev, dtype=_F32)
+        dense[rows.long()] = f
+        vol = Rows(dense, 1, W, H, D, f.shape[1])
+        return {'x': vol.as_ncdhw(), 'pts_feats': [cur]}
+
+
+@MIDDLE_ENCODERS.register_module()
+class SparseLiDAREnc8x(_SparseEncoderBase):
+    def __init__(self, input_channel, norm_cfg, base_channel, out_channel, sparse_shape_xyz, **kwargs):
+        b = base_channel
+        super().__init__(input_channel, norm_cfg, b, out_channel, sparse_shape_xyz, (2 * b, 4 * b, 8 * b), (True, True, True))
+
+
+@MIDDLE_ENCODERS.register_module()
+class SparseLiDAREnc4x(_SparseEncoderBase):
+    def __init__(self, input_channel, norm_cfg, base_channel, out_channel, sparse_shape_xyz, **kwargs):
+        b = base_channel
+        super().__init__(input_channel, norm_cfg, b, out_channel, sparse_shape_xyz, (b, 2 * b, 4 * b), (False, True, True))

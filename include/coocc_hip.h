@@ -376,6 +376,32 @@ int coocc_eval_semantic(const float* pred, int64_t stride_c, int64_t stride_x, i
                         const uint8_t* visible, int H, int W, int D, int empty_idx, int accumulate,
                         int64_t* hist, void* stream);
 
+/* ---------------------------------------------------------------- LiDAR producer */
+/* Hard voxelisation (mmdet3d/ops/voxel/src/voxelization_cpu.cpp:44-104 = the deterministic CUDA path of
+ * voxelization_cuda.cu): points:[n,F] (xyz first); range_host:[6] xyzxyz min/max; voxel_size_host:[3].
+ * voxels:[max_voxels,max_points,F] (zero padded), coors:[max_voxels,3] (z,y,x), num_points:[max_voxels], count:[1]
+ * (device) = number of voxels produced.  Voxels are numbered in order of first appearance, each keeps its first
+ * max_points points; voxels first seen after max_voxels are dropped. */
+size_t coocc_voxelize_ws(int n);
+int coocc_voxelize_hard(const float* points, int n, int F, const float* range_host, const float* voxel_size_host,
+                        int max_points, int max_voxels, float* voxels, int32_t* coors, int32_t* num_points,
+                        int32_t* count, void* ws, size_t ws_bytes, void* stream);
+/* HardSimpleVFE (mmdet3d/models/voxel_encoders/voxel_encoder.py:43-45): mean of the first nf features -> [M,out_stride] */
+int coocc_vfe_mean(const float* voxels, const int32_t* num_points, int M, int max_points, int F, int nf, float* out,
+                   int out_stride, void* stream);
+/* Rule books of the sparse encoder (P/coocc/voxel_encoder/sparse_lidar_enc.py; spconv SubMConv3d / SparseConv3d
+ * semantics restated).  coors:[M,3] (z,y,x); spatial shape (D,H,W).  A rule book is the [taps][Mo] row table that
+ * coocc_conv_fwd consumes through coocc_conv_desc.gather (tap t = (kd*k + kh)*k + kw, spconv's KRSC weight order). */
+int coocc_sparse_index_map(const int32_t* coors, int M, int D, int H, int W, int32_t* map /*[D*H*W], -1 = inactive*/,
+                           void* stream);
+int coocc_sparse_conv_table(const int32_t* out_coors, int Mo, int Di, int Hi, int Wi, int ksize, int stride, int pad,
+                            const int32_t* in_map, int32_t* table /*[k^3][Mo]*/, void* stream);
+int coocc_sparse_down_flags(const int32_t* coors, int M, int ksize, int stride, int pad, int Do, int Ho, int Wo,
+                            uint8_t* flags /*[Do*Ho*Wo]*/, void* stream);
+/* linear ids (z*H + y)*W + x -> coors:[n,3] and (optionally) the channels-last rows (x*H + y)*D + z of the dense volume */
+int coocc_sparse_lin_to_coors(const int32_t* lin, int n, int D, int H, int W, int32_t* coors, int32_t* dense_rows,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

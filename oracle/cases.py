@@ -61,6 +61,21 @@ def eval_inputs(c, same_size=False):
     return pred, torch.from_numpy(gt), torch.from_numpy(vis)
 
 
+LIDAR_CASE = dict(n_points=6000, F=5, voxel_size=(0.5, 0.5, 0.5), point_cloud_range=(-8., -8., -2., 8., 8., 2.),
+                  max_points=5, max_voxels=1500, seed=71)
+
+
+def lidar_points(c, n=None):
+    """Seeded LiDAR-like sweep: points clustered on a few surfaces, some outside the range, duplicates kept in order."""
+    g = np.random.default_rng(c["seed"])
+    n = n or c["n_points"]
+    lo, hi = np.array(c["point_cloud_range"][:3]), np.array(c["point_cloud_range"][3:])
+    pts = g.uniform(lo - 1.0, hi + 1.0, (n, 3))
+    pts[: n // 2, 2] = g.normal(-1.2, 0.15, n // 2)                 # a ground sheet: many points per voxel
+    feat = g.uniform(0, 1, (n, c["F"] - 3))
+    return np.concatenate([pts, feat], 1).astype(np.float32)
+
+
 def fuser_inputs(c):
     img, pts = synth.voxel_inputs(c["grid"], C=c["C"], seed=c["seed"], p_img=c["p_img"], p_pts=c["p_pts"])
     if "img_x_below" in c:

@@ -250,6 +250,29 @@ def gen_eval(R):
     save("eval", **out)
 
 
+def gen_voxelize():
+    """mmdet3d/core/voxel/voxel_generator.py points_to_voxel (the numpy twin the reference's test_voxelize.py compares the
+    op with) run unmodified with numba.jit stubbed to the identity; the oracle must reproduce it exactly."""
+    import importlib.util
+    from oracle import ref_lidar
+    nb = types.ModuleType("numba")
+    nb.jit = lambda *a, **k: (lambda f: f)
+    sys.modules.setdefault("numba", nb)
+    path = os.path.join(refshim.REF, "mmdetection3d", "mmdet3d", "core", "voxel", "voxel_generator.py")
+    spec = importlib.util.spec_from_file_location("ref_voxel_generator", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    c = cases.LIDAR_CASE
+    pts = cases.lidar_points(c)
+    vox, coors, num = mod.points_to_voxel(pts, list(c["voxel_size"]), list(c["point_cloud_range"]), c["max_points"], True,
+                                          c["max_voxels"])
+    o_vox, o_coors, o_num = ref_lidar.hard_voxelize(pts, c["voxel_size"], c["point_cloud_range"], c["max_points"], c["max_voxels"])
+    assert np.array_equal(vox, o_vox) and np.array_equal(coors, o_coors) and np.array_equal(num, o_num)
+    print("voxelize          ref == oracle: %d points -> %d voxels (cap %d), %d full voxels" % (
+        pts.shape[0], vox.shape[0], c["max_voxels"], int((num == c["max_points"]).sum())))
+    save("voxelize", coors=coors, num=num, voxels=vox)
+
+
 def main():
     torch.set_num_threads(1)
     R = refshim.install()
@@ -260,6 +283,7 @@ def main():
     gen_render(R)
     gen_rays(R)
     gen_eval(R)
+    gen_voxelize()
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print("golden fixtures: %.2f MB in %s" % (tot / 1e6, GOLD))
 

@@ -1,0 +1,88 @@
+"""LiDAR-side producer (hard voxelisation, HardSimpleVFE, sparse encoder) vs the golden output of the
+reference's numpy voxel generator and vs the oracle's dense restatement of the spconv layers."""
+import numpy as np
+import pytest
+import torch
+
+import co_occ_amd.synth as synth
+from co_occ_amd import lidar as L
+from oracle import cases, ref_lidar
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def test_voxelization_vs_golden_bit_exact(dev, golden):
+    c, g = cases.LIDAR_CASE, golden("voxelize")
+    pts = cases.lidar_points(c)
+    vox_layer = L.Voxelization(c["voxel_size"], c["point_cloud_range"], c["max_points"], (c["max_voxels"], c["max_voxels"])).eval()
+    vox, coors, num = vox_layer(torch.from_numpy(pts).to(dev))
+    assert np.array_equal(coors.cpu().numpy(), g["coors"])            # order of first appearance, (z,y,x)
+    assert np.array_equal(num.cpu().numpy(), g["num"])
+    assert np.array_equal(vox.cpu().numpy(), g["voxels"])             # first max_points points, in point order, zero padded
+    m = L.HardSimpleVFE(num_features=5)(vox, num, coors)
+    want = ref_lidar.vfe_mean(g["voxels"], g["num"], 5)
+    assert_close(m.cpu(), want, tol=1e-6, what="vfe mean")
+
+
+@pytest.mark.parametrize("n,max_voxels", [(0, 50), (1, 50), (777, 10 ** 6), (20000, 300)])
+def test_voxelization_edge_sizes_vs_oracle(dev, n, max_voxels):
+    """Empty sweep, single point, no truncation, heavy max_voxels truncation."""
+    c = cases.LIDAR_CASE
+    pts = cases.lidar_points(dict(c, seed=c["seed"] + n), n=max(n, 1))[:n]
+    layer = L.Voxelization(c["voxel_size"], c["point_cloud_range"], 3, (max_voxels, max_voxels)).eval()
+    vox, coors, num = layer(torch.from_numpy(pts).to(dev).view(-1, c["F"]))
+    o_vox, o_coors, o_num = ref_lidar.hard_voxelize(pts.reshape(-1, c["F"]), c["voxel_size"], c["point_cloud_range"], 3, max_voxels)
+    assert np.array_equal(coors.cpu().numpy(), o_coors) and np.array_equal(num.cpu().numpy(), o_num)
+    assert np.array_equal(vox.cpu().numpy(), o_vox)
+
+
+def _seeded_encoder(cls, shape_xyz, seed, dev):
+    enc = cls(4, dict(type="BN1d"), 16, 128, list(shape_xyz)).eval()
+    enc.load_state_dict(synth.random_state_dict(enc.state_dict(), seed=seed))
+    return enc.to(dev), {k: v.clone() for k, v in enc.state_dict().items()}
+
+
+@pytest.mark.parametrize("variant", ["8x", "4x"])
+def test_sparse_encoder_vs_dense_oracle(dev, variant):
+    """SparseLiDAREnc{8x,4x}: rule-book gather GEMMs vs masked dense convolutions (spconv semantics restated; unpinned)."""
+    g = np.random.default_rng(3)
+    shape_xyz = (32, 24, 16)
+    W, H, D = shape_xyz
+    M = 900
+    lin = g.choice(W * H * D, M, replace=False)
+    coors = np.stack([lin // (W * H), (lin // W) % H, lin % W], 1).astype(np.int32)        # (z, y, x), arbitrary order
+    feats = g.standard_normal((M, 4)).astype(np.float32)
+    cls = L.SparseLiDAREnc8x if variant == "8x" else L.SparseLiDAREnc4x
+    enc, sd = _seeded_encoder(cls, shape_xyz, 13, dev)
+    with torch.no_grad():
+        out = enc(torch.from_numpy(feats).to(dev), torch.from_numpy(coors).to(dev), 1)
+    want, mask = ref_lidar.sparse_encoder_forward({k: v.cpu() for k, v in sd.items()}, feats, coors, (D, H, W), variant)
+    f = 8 if variant == "8x" else 4
+    assert tuple(out["x"].shape) == tuple(want.shape) == (1, 128, W // f, H // f, D // f)
+    assert_close(out["x"].cpu(), want, what="dense lidar volume")
+    sp = out["pts_feats"][0]
+    assert sp.coors.shape[0] == int(mask.sum())                         # same active set
+    # batch-indexed coors (b, z, y, x) are accepted like upstream
+    coors4 = np.concatenate([np.zeros((M, 1), np.int32), coors], 1)
+    with torch.no_grad():
+        out4 = enc(torch.from_numpy(feats).to(dev), torch.from_numpy(coors4).to(dev), 1)
+    assert torch.equal(out4["x"], out["x"])
+
+
+def test_lidar_producer_end_to_end(dev):
+    """points -> Voxelization -> HardSimpleVFE -> SparseLiDAREnc8x -> [1,128,X/8,Y/8,Z/8] volume, vs the oracle chain."""
+    c = dict(cases.LIDAR_CASE, voxel_size=(0.25, 0.25, 0.25), max_voxels=20000, max_points=10)
+    pts = cases.lidar_points(c, n=4000)[:, :4]
+    shape_xyz = tuple(int(round((c["point_cloud_range"][3 + i] - c["point_cloud_range"][i]) / c["voxel_size"][i])) for i in range(3))
+    vox_layer = L.Voxelization(c["voxel_size"], c["point_cloud_range"], c["max_points"], (c["max_voxels"],) * 2).eval()
+    enc, sd = _seeded_encoder(L.SparseLiDAREnc8x, shape_xyz, 17, dev)
+    with torch.no_grad():
+        vox, coors, num = vox_layer(torch.from_numpy(pts).to(dev))
+        feats = L.HardSimpleVFE(num_features=5)(vox, num, coors)
+        out = enc(feats, coors, 1)
+    o_vox, o_coors, o_num = ref_lidar.hard_voxelize(pts, c["voxel_size"], c["point_cloud_range"], c["max_points"], c["max_voxels"])
+    o_feats = ref_lidar.vfe_mean(o_vox, o_num, 5)
+    want, _ = ref_lidar.sparse_encoder_forward({k: v.cpu() for k, v in sd.items()}, o_feats, o_coors, shape_xyz[::-1], "8x")
+    assert_close(out["x"].cpu(), want, what="pts_voxel_feats")
+    assert float(out["x"].abs().max()) > 0

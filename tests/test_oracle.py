@@ -173,3 +173,16 @@ def test_eval_oracle_vs_golden(golden):
         assert np.array_equal(sc, g[tag + "_sc"]) and np.array_equal(ssc, g[tag + "_ssc"])
         assert np.array_equal(occ, g[tag + "_occ"])
         assert ssc.sum() == int((gt != 255).sum()) and sc.sum() == ssc.sum()
+
+
+def test_voxelize_oracle_vs_golden(golden):
+    """voxelization_cpu.cpp:44-104 restated == the reference's numpy points_to_voxel (golden), incl. the max_voxels and
+    max_points truncations; HardSimpleVFE mean."""
+    from oracle import ref_lidar
+    c, g = cases.LIDAR_CASE, golden("voxelize")
+    pts = cases.lidar_points(c)
+    vox, coors, num = ref_lidar.hard_voxelize(pts, c["voxel_size"], c["point_cloud_range"], c["max_points"], c["max_voxels"])
+    assert np.array_equal(vox, g["voxels"]) and np.array_equal(coors, g["coors"]) and np.array_equal(num, g["num"])
+    assert vox.shape[0] == c["max_voxels"] and int(num.max()) == c["max_points"]
+    m = ref_lidar.vfe_mean(vox, num, 4)
+    assert m.shape == (vox.shape[0], 4) and torch.allclose(m[0], torch.from_numpy(vox[0, :num[0], :4]).mean(0))
