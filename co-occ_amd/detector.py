@@ -30,9 +30,15 @@ class COOCC_Ray(nn.Module):
                  color_encoder=None, semantic_encoder=None, density_neck=None, color_neck=None,
                  semantic_neck=None, loss_norm=False, use_rendering=False, loss_voxel_ce_weight=1.0,
                  loss_voxel_sem_scal_weight=1.0, loss_voxel_geo_scal_weight=1.0, loss_voxel_lovasz_weight=1.0,
-                 test_rendering=False, img_view_transformer=None, pts_bbox_head=None, **kwargs):
+                 test_rendering=False, img_view_transformer=None, pts_bbox_head=None, pts_voxel_layer=None,
+                 pts_voxel_encoder=None, pts_middle_encoder=None, **kwargs):
         super().__init__()
-        self.ignored_cfg_keys = sorted(kwargs)      # img_backbone, img_neck, pts_* encoders, train/test_cfg ...
+        self.ignored_cfg_keys = sorted(kwargs)      # img_backbone, img_neck, train/test_cfg ...
+        # LiDAR-side producer (coocc_ray.py:215-234; bevdepth.py builds these three from the config)
+        from . import lidar
+        self.pts_voxel_layer = lidar.Voxelization(**pts_voxel_layer) if pts_voxel_layer else None
+        self.pts_voxel_encoder = lidar.VOXEL_ENCODERS.build(pts_voxel_encoder) if pts_voxel_encoder else None
+        self.pts_middle_encoder = lidar.MIDDLE_ENCODERS.build(pts_middle_encoder) if pts_middle_encoder else None
         self.empty_idx, self.scale = empty_idx, scale
         self.voxel_size, self.n_voxels, self.aabb = voxel_size, n_voxels, aabb
         self.near_far_range, self.N_samples, self.N_rand = near_far_range, N_samples, N_rand
@@ -46,6 +52,19 @@ class COOCC_Ray(nn.Module):
         if use_rendering:                                      # coocc_ray.py:111-113
             self.sigma_head = MLP(input_dim=128, output_dim=1, net_depth=1, skip_layer=None)
             self.rgb_head = MLP(input_dim=128, output_dim=3, net_depth=3, skip_layer=None)
+
+    def extract_pts_feat(self, pts):
+        """coocc_ray.py:215-234 (batch size 1): points [N,F] (or a one-element list) -> (pts_voxel_feats [1,C,X,Y,Z],
+        [sparse features])."""
+        if self.pts_middle_encoder is None:
+            raise NotImplementedError("COOCC_Ray was built without pts_voxel_layer / pts_voxel_encoder / pts_middle_encoder")
+        if isinstance(pts, (list, tuple)):
+            assert len(pts) == 1, "batch size 1 (hard-coded upstream)"
+            pts = pts[0]
+        voxels, coors, num_points = self.pts_voxel_layer(pts)
+        feats = self.pts_voxel_encoder(voxels, num_points, coors)
+        enc = self.pts_middle_encoder(feats, coors, 1)
+        return enc['x'], enc['pts_feats']
 
     def fuse(self, img_voxel_feats, pts_voxel_feats, search=None):
         """coocc_ray.py:252-256."""

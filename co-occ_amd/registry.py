@@ -81,6 +81,8 @@ def register_into_mmdet():
         return False
     pairs = [(DETECTORS, mb.DETECTORS), (BACKBONES, m3b.BACKBONES), (NECKS, m3b.NECKS),
              (HEADS, m3b.HEADS), (FUSION_LAYERS, m3b.FUSION_LAYERS)]
+    from . import lidar
+    pairs += [(lidar.VOXEL_ENCODERS, m3b.VOXEL_ENCODERS), (lidar.MIDDLE_ENCODERS, m3b.MIDDLE_ENCODERS)]
     for ours, theirs in pairs:
         for k, cls in ours.module_dict.items():
             theirs.register_module(name=k, force=True, module=cls)

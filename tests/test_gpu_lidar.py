@@ -86,3 +86,22 @@ def test_lidar_producer_end_to_end(dev):
     want, _ = ref_lidar.sparse_encoder_forward({k: v.cpu() for k, v in sd.items()}, o_feats, o_coors, shape_xyz[::-1], "8x")
     assert_close(out["x"].cpu(), want, what="pts_voxel_feats")
     assert float(out["x"].abs().max()) > 0
+
+
+def test_detector_extract_pts_feat_from_reference_config_slice(dev):
+    """COOCC_Ray built with the pts_* entries of coocc_multi_r50_256x704.py:121-135 (smaller sparse shape)."""
+    import co_occ_amd as pkg
+    cfg = synth.model_cfg(C=128)
+    cfg.update(pts_voxel_layer=dict(max_num_points=10, point_cloud_range=[-8., -8., -2., 8., 8., 2.], voxel_size=[0.125] * 3,
+                                    max_voxels=(90000, 120000)),
+               pts_voxel_encoder=dict(type='HardSimpleVFE', num_features=5),
+               pts_middle_encoder=dict(type='SparseLiDAREnc8x', input_channel=4, base_channel=16, out_channel=128,
+                                       norm_cfg=dict(type='SyncBN', requires_grad=True), sparse_shape_xyz=[128, 128, 32]))
+    model = pkg.build_detector(cfg).to(dev).eval()
+    pts = torch.from_numpy(cases.lidar_points(cases.LIDAR_CASE, n=5000)[:, :4]).to(dev)
+    with torch.no_grad():
+        vol, sp = model.extract_pts_feat([pts])
+    assert tuple(vol.shape) == (1, 128, 16, 16, 4) and sp[0].coors.shape[0] > 0
+    keys = set(model.state_dict().keys())
+    assert {"pts_middle_encoder.conv_input.0.weight", "pts_middle_encoder.conv1.0.0.weight", "pts_middle_encoder.conv3.2.net.4.running_var",
+            "pts_middle_encoder.conv_out.1.bias"} <= keys

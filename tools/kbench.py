@@ -232,6 +232,27 @@ def bench_trunk():
             print("   %-32s %3d launches %8.2f ms%s" % (k, r["launches"], r["ms"], "  %.0f TFLOP/s" % (r["work"] / r["ms"] / 1e9) if r["work"] else ""))
 
 
+def bench_lidar():
+    """LiDAR producer at nuScenes scale: ~280 k points (10 sweeps) -> 0.125 m voxels on [800,800,64] -> 8x sparse encoder."""
+    from co_occ_amd import lidar as L
+    g = torch.Generator().manual_seed(8)
+    n = 280000
+    r = torch.rand(n, generator=g) ** 0.5 * 50
+    th = torch.rand(n, generator=g) * 6.2832
+    pts = torch.stack([r * torch.cos(th), r * torch.sin(th), torch.randn(n, generator=g) * 0.8 - 1.5, torch.rand(n, generator=g)], 1).to(dev)
+    vox = L.Voxelization([0.125] * 3, [-50, -50, -5, 50, 50, 3], 10, (90000, 120000)).eval()
+    vfe = L.HardSimpleVFE(5)
+    enc = L.SparseLiDAREnc8x(4, dict(type="BN1d"), 16, 128, [800, 800, 64]).to(dev).eval()
+    def run():
+        v, c, k = vox(pts)
+        return enc(vfe(v, k, c), c, 1), v.shape[0]
+    (out, m) = run()
+    t_v = timeit(lambda: vox(pts), n=5)
+    t_all = timeit(lambda: run(), n=5)
+    print("lidar  %d points -> %d voxels: voxelise %.3f ms, voxelise + VFE + SparseLiDAREnc8x %.3f ms -> %s, %d active at 1/8" % (
+        n, m, t_v, t_all, tuple(out["x"].shape), out["pts_feats"][0].coors.shape[0]))
+
+
 def bench_eval():
     from co_occ_amd import evaluation as ev
     g = torch.Generator().manual_seed(5)
