@@ -249,6 +249,15 @@ def bench_lidar():
     (out, m) = run()
     t_v = timeit(lambda: vox(pts), n=5)
     t_all = timeit(lambda: run(), n=5)
+    from co_occ_amd import _lib
+    _lib.TIMER.enabled = 2
+    _lib.TIMER.reset()
+    run()
+    torch.cuda.synchronize()
+    rows = _lib.TIMER.summary()
+    _lib.TIMER.enabled = False
+    for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:8]:
+        print("   %-32s %3d launches %8.3f ms" % (k, v["launches"], v["ms"]))
     print("lidar  %d points -> %d voxels: voxelise %.3f ms, voxelise + VFE + SparseLiDAREnc8x %.3f ms -> %s, %d active at 1/8" % (
         n, m, t_v, t_all, tuple(out["x"].shape), out["pts_feats"][0].coors.shape[0]))
 
