@@ -252,8 +252,13 @@ def main():
             ms = sum(v["ms"] for v in rk)
             by = sum(v["work"] for v in rk)
             ach = by / (ms * 1e-3) / 1e9
+            rtraffic = None
+            try:
+                rtraffic = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))["k_render_nearest+k_upsample_maps"][args.config]["bytes_per_launch"]
+            except Exception:
+                pass
             extra["roofline_render"] = dict(bound="hbm", kernel="k_render_nearest+k_upsample_maps", achieved=round(ach, 1),
-                                            peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                                            peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=rtraffic,
                                             avg_ms_per_step=round(ms / max(1, rk[0]["launches"]), 4))
 
     line = dict(metric="samples/sec (6-cam frame + sweep -> occ+render), 200x200x16 grid", value=round(world * args.steps / dt, 4),
