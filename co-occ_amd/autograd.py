@@ -628,3 +628,54 @@ def fine_branch_train(head, out_voxel_rows, geom, coarse_lin, img_feats=None, tr
     gn = head.fine_mlp[1]
     h = GroupNormRowsFn.apply(h, gn.weight, gn.bias, gn.num_groups, gn.eps, True)
     return linear_rows(h, head.fine_mlp[3].weight, head.fine_mlp[3].bias, relu=False), fine_xyz
+
+
+# ----------------------------------------------------------------------------- BatchNorm with batch statistics
+class BatchNormRowsFn(torch.autograd.Function):
+    """Training-mode BatchNorm3d / SyncBN (single process) on rows [M, C] (+ residual, ReLU): batch mean / biased variance,
+    running statistics updated in place like torch (momentum, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, bn, relu):
+        x = x.float().contiguous()
+        M, C = x.shape
+        dev = x.device
+        mean = torch.empty(C, device=dev, dtype=_F32)
+        var = torch.empty(C, device=dev, dtype=_F32)
+        ws = workspace(dev)
+        call("coocc_bn_stats", ptr(x), C, M, C, ptr(mean), ptr(var), ptr(ws), ws.numel() * 4)
+        y = torch.empty_like(x)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        call("coocc_bn_apply", ptr(x), M, C, ptr(mean), ptr(var), ptr(g), ptr(b), float(bn.eps),
+             ptr(res.float().contiguous()) if res is not None else None, int(relu), ptr(y))
+        if bn.track_running_stats and bn.running_mean is not None:
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            with torch.no_grad():
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var * (M / max(M - 1, 1)), alpha=mom)
+                bn.num_batches_tracked += 1
+        ctx.save_for_backward(x, y, mean, var, g)
+        ctx.cfg = (float(bn.eps), int(relu), res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, var, g = ctx.saved_tensors
+        eps, relu, has_res = ctx.cfg
+        M, C = x.shape
+        dev = x.device
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dgamma = torch.empty(C, device=dev, dtype=_F32)
+        dbeta = torch.empty(C, device=dev, dtype=_F32)
+        ws = workspace(dev)
+        call("coocc_bn_backward", ptr(x), ptr(y), ptr(dy.float().contiguous()), M, C, ptr(mean), ptr(var), ptr(g), eps, relu,
+             ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel() * 4)
+        return dx, dgamma, dbeta, dres, None, None
+
+
+def conv3d_bn_train_rows(x2d, weight, geom, bn, stride=1, pad=None, relu=True, res2d=None, bias=None):
+    """Training-mode Conv3d -> BatchNorm (batch statistics) (+res) -> ReLU on rows: the conv runs without epilogue,
+    BatchNormRowsFn normalises.  Use conv3d_rows(bn=...) for frozen statistics."""
+    y, g = conv3d_rows(x2d, weight, geom, bias=bias, bn=None, stride=stride, pad=pad, relu=False)
+    return BatchNormRowsFn.apply(y, bn.weight, bn.bias, res2d, bn, relu), g

@@ -723,3 +723,123 @@ extern "C" int coocc_groupnorm_nhwc_bwd(const float* x, const float* y, const fl
   COOCC_LAUNCH_CHECK("k_groupnorm_nhwc_bwd");
   return COOCC_OK;
 }
+
+// ------------------------------------------------------------------ BatchNorm with batch statistics (training mode)
+// Rows [M, C] (channels-last voxels): per-channel mean / biased variance over the M rows, deterministic two-pass column
+// reductions (256-row partials, then one pass over the partials in fp64).
+__global__ __launch_bounds__(256) void k_bn_part(const float* __restrict__ x, int stride, int M, int C, double* __restrict__ part) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int m0 = blockIdx.x * 256, m1 = min(M, m0 + 256);
+  double s = 0, q = 0;
+  for (int m = m0; m < m1; ++m) { const float v = x[(size_t)m * stride + c]; s += v; q += (double)v * v; }
+  part[((size_t)blockIdx.x * C + c) * 2] = s;
+  part[((size_t)blockIdx.x * C + c) * 2 + 1] = q;
+}
+
+__global__ __launch_bounds__(256) void k_bn_final(const double* __restrict__ part, int nparts, int M, int C, float* __restrict__ mean,
+                                                   float* __restrict__ var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, q = 0;
+  for (int p = 0; p < nparts; ++p) { s += part[((size_t)p * C + c) * 2]; q += part[((size_t)p * C + c) * 2 + 1]; }
+  const double mu = s / M, v = q / M - mu * mu;
+  mean[c] = (float)mu;
+  var[c] = (float)(v > 0 ? v : 0);
+}
+
+extern "C" int coocc_bn_stats(const float* x, int stride, int M, int C, float* mean, float* var, void* ws, size_t ws_bytes,
+                              void* stream) {
+  COOCC_CHECK_ARG(x && mean && var && M > 0 && C > 0 && stride >= C, "bn_stats: bad args");
+  const int nparts = (M + 255) / 256;
+  COOCC_CHECK_ARG(ws && ws_bytes >= sizeof(double) * 2 * (size_t)nparts * C, "bn_stats: workspace too small");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(k_bn_part, dim3(nparts, cdiv(C, 256)), dim3(256), 0, s, x, stride, M, C, (double*)ws);
+  hipLaunchKernelGGL(k_bn_final, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)ws, nparts, M, C, mean, var);
+  COOCC_LAUNCH_CHECK("bn_stats");
+  return COOCC_OK;
+}
+
+// y = relu((x - mean) * rstd * gamma + beta (+ res))
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, int M, int C, const float* __restrict__ mean,
+                                                   const float* __restrict__ var, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float eps, const float* __restrict__ res,
+                                                   int relu, float* __restrict__ y) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)M * C) return;
+  const int c = (int)(i % C);
+  float v = (x[i] - mean[c]) * (1.f / sqrtf(var[c] + eps)) * gamma[c] + beta[c];
+  if (res) v += res[i];
+  y[i] = relu ? fmaxf(v, 0.f) : v;
+}
+
+extern "C" int coocc_bn_apply(const float* x, int M, int C, const float* mean, const float* var, const float* gamma,
+                              const float* beta, float eps, const float* res, int relu, float* y, void* stream) {
+  COOCC_CHECK_ARG(x && mean && var && gamma && beta && y && M > 0 && C > 0, "bn_apply: bad args");
+  hipLaunchKernelGGL(k_bn_apply, dim3(cdiv((long long)M * C, 256)), dim3(256), 0, as_stream(stream), x, M, C, mean, var, gamma, beta, eps,
+                     res, relu, y);
+  COOCC_LAUNCH_CHECK("k_bn_apply");
+  return COOCC_OK;
+}
+
+// backward: dpre = dy * [y > 0];  dres = dpre;  dgamma = sum dpre * xhat;  dbeta = sum dpre;
+//           dx = gamma * rstd * (dpre - dbeta / M - xhat * dgamma / M)
+__global__ __launch_bounds__(256) void k_bn_bwd_part(const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ dy, int M, int C, const float* __restrict__ mean,
+                                                      const float* __restrict__ var, float eps, int relu, double* __restrict__ part) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int m0 = blockIdx.x * 256, m1 = min(M, m0 + 256);
+  const float mu = mean[c], rstd = 1.f / sqrtf(var[c] + eps);
+  double a = 0, b = 0;
+  for (int m = m0; m < m1; ++m) {
+    const size_t i = (size_t)m * C + c;
+    float g = dy[i];
+    if (relu && !(y[i] > 0.f)) g = 0.f;
+    a += (double)g * ((x[i] - mu) * rstd);
+    b += g;
+  }
+  part[((size_t)blockIdx.x * C + c) * 2] = a;
+  part[((size_t)blockIdx.x * C + c) * 2 + 1] = b;
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_final(const double* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a = 0, b = 0;
+  for (int p = 0; p < nparts; ++p) { a += part[((size_t)p * C + c) * 2]; b += part[((size_t)p * C + c) * 2 + 1]; }
+  dgamma[c] = (float)a;
+  dbeta[c] = (float)b;
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_dx(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                    int M, int C, const float* __restrict__ mean, const float* __restrict__ var,
+                                                    const float* __restrict__ gamma, float eps, int relu,
+                                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                    float* __restrict__ dx, float* __restrict__ dres) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)M * C) return;
+  const int c = (int)(i % C);
+  const float rstd = 1.f / sqrtf(var[c] + eps);
+  float g = dy[i];
+  if (relu && !(y[i] > 0.f)) g = 0.f;
+  if (dres) dres[i] = g;
+  const float xh = (x[i] - mean[c]) * rstd;
+  dx[i] = gamma[c] * rstd * (g - dbeta[c] / (float)M - xh * dgamma[c] / (float)M);
+}
+
+extern "C" int coocc_bn_backward(const float* x, const float* y, const float* dy, int M, int C, const float* mean, const float* var,
+                                 const float* gamma, float eps, int relu, float* dx, float* dres, float* dgamma, float* dbeta,
+                                 void* ws, size_t ws_bytes, void* stream) {
+  COOCC_CHECK_ARG(x && y && dy && mean && var && gamma && dx && dgamma && dbeta && M > 0 && C > 0, "bn_backward: bad args");
+  const int nparts = (M + 255) / 256;
+  COOCC_CHECK_ARG(ws && ws_bytes >= sizeof(double) * 2 * (size_t)nparts * C, "bn_backward: workspace too small");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(k_bn_bwd_part, dim3(nparts, cdiv(C, 256)), dim3(256), 0, s, x, y, dy, M, C, mean, var, eps, relu, (double*)ws);
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)ws, nparts, C, dgamma, dbeta);
+  hipLaunchKernelGGL(k_bn_bwd_dx, dim3(cdiv((long long)M * C, 256)), dim3(256), 0, s, x, y, dy, M, C, mean, var, gamma, eps, relu, dgamma,
+                     dbeta, dx, dres);
+  COOCC_LAUNCH_CHECK("bn_backward");
+  return COOCC_OK;
+}

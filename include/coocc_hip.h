@@ -242,6 +242,17 @@ int coocc_groupnorm_nhwc_bwd(const float* x, const float* y, const float* dy, in
                              const float* gamma, float eps, int relu, float* dx, float* dgamma, float* dbeta,
                              void* stream);
 
+/* BatchNorm3d / SyncBN in training mode on channels-last rows [M,C] (the reference trains with batch statistics):
+ * per-channel mean and biased variance (deterministic two-pass, fp64 partials; ws >= 16*ceil(M/256)*C bytes),
+ * y = relu((x - mean) * rsqrt(var + eps) * gamma + beta (+ res)), and the backward (dx, dres = dy*[y>0], dgamma, dbeta). */
+int coocc_bn_stats(const float* x, int stride, int M, int C, float* mean, float* var, void* ws, size_t ws_bytes,
+                   void* stream);
+int coocc_bn_apply(const float* x, int M, int C, const float* mean, const float* var, const float* gamma,
+                   const float* beta, float eps, const float* res, int relu, float* y, void* stream);
+int coocc_bn_backward(const float* x, const float* y, const float* dy, int M, int C, const float* mean, const float* var,
+                      const float* gamma, float eps, int relu, float* dx, float* dres, float* dgamma, float* dbeta,
+                      void* ws, size_t ws_bytes, void* stream);
+
 /* FPN3D top-down step (fpn3d.py:88-92): fine += trilinear(coarse -> fine size),
  * align_corners=False.  Rows NDHWC with C channels. */
 int coocc_upsample_add_trilinear(const float* coarse, float* fine, int B, int C, int Xc, int Yc,

@@ -479,3 +479,34 @@ def test_full_head_backward_vs_oracle_autograd(dev):
         assert_close(p.grad.cpu().view_as(rg) / sc, rg / sc, what=name)
         n += 1
     assert n >= 8 + 6 + 6        # conv weights/biases, three Linear layers, three GroupNorms
+
+
+def test_conv_batchnorm_training_mode_vs_torch(dev):
+    """Conv3d -> BatchNorm3d with BATCH statistics -> (+res) -> ReLU, forward, running-stat update and all gradients."""
+    g = torch.Generator().manual_seed(31)
+    B, Cin, Cout, (X, Y, Z) = 2, 16, 24, (7, 6, 5)
+    x = torch.randn(B, Cin, X, Y, Z, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (Cin * 27) ** 0.5
+    res = torch.randn(B, Cout, X, Y, Z, generator=g)
+    gout = torch.randn(B, Cout, X, Y, Z, generator=g)
+    bn_r = torch.nn.BatchNorm3d(Cout, momentum=0.1).train()
+    bn_r.weight.data.copy_(torch.rand(Cout, generator=g) + 0.5)
+    bn_r.bias.data.copy_(torch.randn(Cout, generator=g) * 0.1)
+    bn_d = torch.nn.BatchNorm3d(Cout, momentum=0.1).train()
+    bn_d.load_state_dict(bn_r.state_dict())
+    xr, wr, rr = x.clone().requires_grad_(), w.clone().requires_grad_(), res.clone().requires_grad_()
+    yr = F.relu(bn_r(F.conv3d(xr, wr, padding=1)) + rr)
+    yr.backward(gout)
+    bn_d = bn_d.to(dev)
+    xd, wd, rd = _rows(x).to(dev).requires_grad_(), w.to(dev).requires_grad_(), _rows(res).to(dev).requires_grad_()
+    y, geo = ag.conv3d_bn_train_rows(xd, wd, (B, X, Y, Z), bn_d, relu=True, res2d=rd)
+    assert_close(_vol(y.detach().cpu(), B, X, Y, Z), yr.detach(), what="bn-train forward")
+    assert_close(bn_d.running_mean.cpu(), bn_r.running_mean, tol=1e-6, what="running_mean")
+    assert_close(bn_d.running_var.cpu(), bn_r.running_var, tol=1e-6, what="running_var")
+    assert int(bn_d.num_batches_tracked) == 1
+    y.backward(_rows(gout).to(dev))
+    assert_close(_vol(xd.grad.cpu(), B, X, Y, Z), xr.grad, what="dx")
+    assert_close(wd.grad.cpu(), wr.grad, what="dw")
+    assert_close(_vol(rd.grad.cpu(), B, X, Y, Z), rr.grad, what="dres")
+    assert_close(bn_d.weight.grad.cpu(), bn_r.weight.grad, what="dgamma")
+    assert_close(bn_d.bias.grad.cpu(), bn_r.bias.grad, what="dbeta")
