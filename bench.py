@@ -120,12 +120,16 @@ def main():
     ap.add_argument("--prefetch", type=int, default=1,
                     help="issue the index search of sample i+1 (helper host thread + stream) under the dense stage of sample i")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs set aside for the FPS chains (hipExtStreamCreateWithCUMask)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL on GPUs)")
+    ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (single-GPU check of the N > 1 path, gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event timing table to stderr")
     args = ap.parse_args()
 
-    rank, world, local = cdist.init()
+    rank, world, local = cdist.init(backend=args.backend)
+    if args.same_device:
+        local = 0           # control-flow check of the multi-rank path on a single GPU (use with --backend gloo)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
