@@ -25,6 +25,7 @@ CONV_V2 = int(__import__("os").environ.get("COOCC_CONV_V2", "1"))       # mirror
 # weight bytes; the small deep layers are weight-bandwidth-bound and gain nothing)
 WINO = int(__import__("os").environ.get("COOCC_WINO", "1"))
 WINO_MIN_ROWS = int(__import__("os").environ.get("COOCC_WINO_MIN_ROWS", "8192"))
+ZTRIM = __import__("os").environ.get("COOCC_ZTRIM", "1") != "0"   # drop z taps that only see padding (Z = 1, 2 grids)
 WINO_TILE = int(__import__("os").environ.get("COOCC_WINO_TILE", "4"))   # F(4x4,3x3) where X, Y >= 8, else F(2x2,3x3)
 
 
@@ -138,6 +139,9 @@ class PackedConv:
         self.taps, self.ksize, self.stride, self.pad = taps, ksize, stride, pad
         # raw weights kept on the host for the lazily built Winograd packs
         self._w_raw = w if (ksize == 3 and stride == 1 and pad == 1 and not tap_major and taps == 27) else None
+        # cubic 3x3x3 weights also kept for the z-trimmed packs (conv_rows: taps that only ever see z padding)
+        self._w_cube = w.view(self.Cout, self.Cin, 3, 3, 3) if (ksize == 3 and not tap_major and taps == 27) else None
+        self._ztrim = {}
         self._wino = {}
         self.wino_tile = None        # per-layer override of WINO_TILE (2 | 3 | 4)
         lib = _lib.load()
@@ -154,6 +158,19 @@ class PackedConv:
             self.scale = None
             self.bias = bias.detach().float().to(dev).contiguous() if bias is not None else None
 
+
+    def ztrim_pack(self, lo, hi):
+        """Pack of the z taps lo..hi only (3 x 3 x (hi-lo+1) kernel): the other z taps read nothing but padding
+        for every output voxel of the grid this is called for, so dropping them is exact."""
+        if (lo, hi) not in self._ztrim:
+            w = self._w_cube[:, :, :, :, lo:hi + 1].contiguous().view(self.Cout, self.Cin, -1)
+            lib = _lib.load()
+            n = lib.coocc_conv_pack_weights(ctypes.c_void_p(w.data_ptr()), self.Cout, self.Cin, w.shape[2], 0, None)
+            packed = torch.empty(n, dtype=_F32)
+            lib.coocc_conv_pack_weights(ctypes.c_void_p(w.data_ptr()), self.Cout, self.Cin, w.shape[2], 0,
+                                        ctypes.c_void_p(packed.data_ptr()))
+            self._ztrim[(lo, hi)] = packed.to(self.w.device)
+        return self._ztrim[(lo, hi)]
 
     def wino_pack(self, tile):
         """(tile+2)^2 packs (one per transform point p = (tile+2)*xi + eta) of U[p][dz] = (G g G^T)[xi][eta][dz],
@@ -293,7 +310,16 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
     d.ksize, d.stride, d.pad = pc.ksize, pc.stride, pc.pad
     d.relu, d.res_mode, d.splitk = int(relu), (res_mode or (1 if res is not None else 0)), splitk
     d.tile_hint = TILE_HINT
-    with TIMER.region(conv_kernel_name(M, pc.Cout, False, 0, pc.taps * -(-pc.Cin // 32)), 2.0 * M * pc.Cin * pc.Cout * pc.taps):
+    taps = pc.taps
+    if ZTRIM and pc._w_cube is not None:
+        # z taps that are in range for at least one output z; on thin grids (Z = 1, 2) the rest only multiply padding
+        ok = [kz for kz in range(3) if any(0 <= zo * pc.stride - pc.pad + kz < x.Z for zo in range(Zo))]
+        lo, hi = ok[0], ok[-1]
+        if hi - lo + 1 < 3:
+            d.w = ptr(pc.ztrim_pack(lo, hi))
+            d.kx, d.ky, d.kz, d.px, d.py, d.pz = 3, 3, hi - lo + 1, pc.pad, pc.pad, pc.pad - lo
+            d.taps = taps = 9 * (hi - lo + 1)
+    with TIMER.region(conv_kernel_name(M, pc.Cout, False, 0, taps * -(-pc.Cin // 32)), 2.0 * M * pc.Cin * pc.Cout * taps):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     return out
 

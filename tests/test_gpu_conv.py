@@ -38,6 +38,8 @@ CASES = [
     (96, 4, (10, 6, 2), 1, 1, False, False, 0),      # Cout = 4
     (64, 128, (25, 25, 2), 1, 2, False, False, 0),   # 1x1x1 stride-2 shortcut
     (36, 40, (6, 5, 3), 3, 1, True, False, 0),       # Cin not a multiple of 32
+    (96, 160, (13, 13, 1), 3, 1, True, True, 0),     # Z = 1: only the centre z tap is ever in range (3x3x1 pack)
+    (64, 96, (9, 11, 2), 3, 2, True, False, 0),      # Z = 2 -> 1: z taps 1..2 (3x3x2 pack, pz = 0)
 ]
 
 
@@ -60,6 +62,21 @@ def test_conv3d_bn_relu_residual(dev, Cin, Cout, grid, k, stride, relu, use_res,
     out = core.conv_rows(rows_of(x, dev), pc, relu=relu, res=rows_of(res, dev) if use_res else None, splitk=splitk)
     assert (out.X, out.Y, out.Z) == tuple(ref.shape[2:])
     assert_close(out.as_ncdhw().cpu(), ref.detach(), what="conv")
+
+
+@pytest.mark.parametrize("grid,stride", [((13, 13, 1), 1), ((9, 11, 2), 2), ((12, 9, 1), 2)])
+def test_conv_ztrim_matches_full_taps(dev, grid, stride, monkeypatch):
+    """Dropping the z taps that only read padding gives the result of the full 27-tap kernel."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, *grid, generator=g)
+    w = torch.randn(96, 64, 3, 3, 3, generator=g) * 0.04
+    pc = core.PackedConv(w.to(dev), bn=bn_like(96, g).to(dev), ksize=3, stride=stride, pad=1)
+    outs = []
+    for z in (True, False):
+        monkeypatch.setattr(core, "ZTRIM", z)
+        outs.append(core.conv_rows(rows_of(x, dev), pc, relu=False).t.cpu())
+    assert len(pc._ztrim) == 1
+    assert_close(outs[0], outs[1], what="ztrim vs full")
 
 
 @pytest.mark.parametrize("hint", [128, 160])
