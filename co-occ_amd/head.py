@@ -8,12 +8,14 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import call, host_f32, host_i32, ptr
+from ._lib import TIMER, call, host_f32, host_i32, ptr
 from .backbone import build_bn
 from .core import PackCache, PackedConv, Rows, conv_rows, linear_rows, to_rows
 from .registry import HEADS
 
 _I32, _F32, _I64 = torch.int32, torch.float32, torch.int64
+# fine branch: the three Linear layers and two GroupNorms in one launch (coocc_fine_mlp); 0 = layer-by-layer path
+FUSED_FINE_MLP = __import__("os").environ.get("COOCC_FUSED_FINE_MLP", "1") != "0"
 
 
 def _conv3d(conv_cfg, cin, cout, k, pad):
@@ -146,7 +148,11 @@ class OccHead(nn.Module):
         nf = n * r ** 3
         fine_xyz = torch.empty(3, nf, device=dev, dtype=_I64)
         cvox = 128 if self.sample_from_voxel else 0
-        cat = torch.empty(nf, cvox + (64 if use_img else 0), device=dev, dtype=_F32)
+        # one launch for Linear+GN+ReLU -> cat -> Linear+GN+ReLU -> Linear when both samples feed the MLPs
+        fused = (FUSED_FINE_MLP and use_img and self.sample_from_voxel and ovf.C == 128 and g.shape[1] == 128
+                 and self.out_channel <= 32 and self.img_mlp[1].num_groups == 16 and self.fine_mlp[1].num_groups == 16
+                 and all(q.data_ptr() % 16 == 0 for m in (self.img_mlp, self.fine_mlp) for q in m.parameters()))
+        cat = torch.empty(nf, cvox if fused else cvox + (64 if use_img else 0), device=dev, dtype=_F32)
         vox_feat = cat if self.sample_from_voxel else torch.empty(nf, ovf.C, device=dev, dtype=_F32)
         # fine coordinates are always produced by this kernel (they are an output of the head)
         call("coocc_fine_sample_voxel", ptr(ovf.t), ovf.C, ovf.X, ovf.Y, ovf.Z, ptr(lin), n, r,
@@ -155,6 +161,16 @@ class OccHead(nn.Module):
             samp = torch.empty(nf, g.shape[1], device=dev, dtype=_F32)
             call("coocc_fine_sample_img", ptr(g), N_i, g.shape[1], Hf, Wf, ptr(params), ptr(fine_xyz), nf, ptr(samp),
                  samp.shape[1], 1 if r == 2 else 0)
+            if fused:
+                li, gi, l0, g0, l3 = self.img_mlp[0], self.img_mlp[1], self.fine_mlp[0], self.fine_mlp[1], self.fine_mlp[3]
+                logits = torch.empty(nf, self.out_channel, device=dev, dtype=_F32)
+                d = lambda t: ptr(t.detach())
+                with TIMER.region("k_fine_mlp", 2.0 * nf * 64 * (128 + 192 + self.out_channel)):
+                    call("coocc_fine_mlp", ptr(samp), samp.shape[1], ptr(cat), cat.shape[1], nf,
+                         d(li.weight), d(li.bias), d(gi.weight), d(gi.bias), float(gi.eps),
+                         d(l0.weight), d(l0.bias), d(g0.weight), d(g0.bias), float(g0.eps),
+                         d(l3.weight), d(l3.bias), self.out_channel, ptr(logits))
+                return logits, fine_xyz
             linear_rows(samp, p["img"], out=cat, out_coff=cvox)
             gn = self.img_mlp[1]
             sub = cat[:, cvox:]

@@ -289,6 +289,16 @@ int coocc_fine_sample_img(const float* img_nhwc, int ncam, int Ci, int Hf, int W
 int coocc_projection_params(const float* rots, const float* trans, const float* intrins, const float* post_rots,
                             const float* post_trans, const float* bda, int ncam, const float* hdr_host,
                             float* params, void* stream);
+/* The fine-branch MLP chain of OccHead in one launch (occ_head.py:70-83 modules, 224-233 use):
+ *   y1 = ReLU(GN16(samp . w_img^T + b_img));  h = ReLU(GN16(cat[vox, y1] . w_f0^T + b_f0));  out = h . w_f3^T + b_f3
+ * samp:[nfine, >=128] image samples, vox:[nfine, >=128] voxel samples (row strides in floats, multiples of 4),
+ * w_img:[64,128], w_f0:[64,192], w_f3:[ncls,64] (nn.Linear layout), GroupNorm(16, 64) affine arrays [64],
+ * out:[nfine, ncls], ncls <= 32.  Same bits as coocc_conv_fwd (taps = 1) + coocc_groupnorm_rows applied in turn. */
+int coocc_fine_mlp(const float* samp, int samp_stride, const float* vox, int vox_stride, int64_t nfine,
+                   const float* w_img, const float* b_img, const float* gn_img_w, const float* gn_img_b,
+                   float eps_img, const float* w_f0, const float* b_f0, const float* gn_f0_w,
+                   const float* gn_f0_b, float eps_f0, const float* w_f3, const float* b_f3, int ncls,
+                   float* out, void* stream);
 /* nn.GroupNorm on 2-D rows [n,C] (+ReLU), in place (occ_head.py:70-83) */
 int coocc_groupnorm_rows(float* x, int64_t n, int C, int stride, int groups, const float* gamma,
                          const float* beta, float eps, int relu, void* stream);

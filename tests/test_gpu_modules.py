@@ -427,3 +427,51 @@ def test_occhead_cascade_ratio_4_vs_oracle(dev):
     assert np.array_equal(res["output_coords_fine"][0].cpu().numpy(), want["fine_coord"].numpy())
     assert res["output_coords_fine"][0].shape[1] % 64 == 0
     assert_close(res["output_voxels_fine"][0].cpu(), want["fine_output"], what="fine (ratio 4)")
+
+
+@pytest.mark.parametrize("nf,ncls", [(1, 17), (63, 17), (1000, 17), (4133, 5), (256, 32)])
+def test_fine_mlp_kernel_vs_torch(dev, nf, ncls):
+    """coocc_fine_mlp (register-chained transposed MFMA GEMMs + in-lane GroupNorm) vs the torch fp32 modules
+    (occ_head.py:70-83), ragged point counts, strided inputs."""
+    import torch.nn.functional as F
+    from co_occ_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(nf * 31 + ncls)
+    samp = torch.randn(nf, 136, generator=g)[:, :128]          # row stride 136
+    vox = torch.randn(nf, 128, generator=g)
+    mk = lambda *s: torch.randn(*s, generator=g)
+    wi, bi, gwi, gbi = mk(64, 128) * 0.1, mk(64) * 0.1, mk(64) * 0.3 + 1, mk(64) * 0.1
+    w0, b0, gw0, gb0 = mk(64, 192) * 0.1, mk(64) * 0.1, mk(64) * 0.3 + 1, mk(64) * 0.1
+    w3, b3 = mk(ncls, 64) * 0.1, mk(ncls) * 0.1
+    y1 = F.relu(F.group_norm(F.linear(samp, wi, bi), 16, gwi, gbi, 1e-5))
+    h = F.relu(F.group_norm(F.linear(torch.cat([vox, y1], 1), w0, b0), 16, gw0, gb0, 1e-5))
+    want = F.linear(h, w3, b3)
+    d = lambda t: t.to(dev).contiguous()
+    samp_d = torch.zeros(nf, 136).copy_(torch.cat([samp, torch.full((nf, 8), 1e9)], 1)).to(dev)   # poison the row padding
+    ts = [d(t) for t in (vox, wi, bi, gwi, gbi, w0, b0, gw0, gb0, w3, b3)]
+    out = torch.full((nf, ncls), float("nan"), device=dev)
+    call("coocc_fine_mlp", ptr(samp_d), 136, ptr(ts[0]), 128, nf,
+         ptr(ts[1]), ptr(ts[2]), ptr(ts[3]), ptr(ts[4]), 1e-5, ptr(ts[5]), ptr(ts[6]), ptr(ts[7]), ptr(ts[8]), 1e-5,
+         ptr(ts[9]), ptr(ts[10]), ncls, ptr(out))
+    assert_close(out.cpu(), want, what="fine_mlp")
+
+
+def test_fine_mlp_fused_equals_layerwise(dev, monkeypatch):
+    """The fused launch and the layer-by-layer path (k_conv GEMMs + k_groupnorm_rows) accumulate in the same order."""
+    from co_occ_amd import head as H
+    c = cases.DECODER_CASE
+    x, rig, img_feats = cases.decoder_inputs(c)
+    cfg = synth.model_cfg(C=c["C"], block_inplanes=c["block_inplanes"], out_channels=c["fpn_out"],
+                          cascade_ratio=c["cascade_ratio"], final_occ_size=c["final_occ_size"],
+                          point_cloud_range=c["point_cloud_range"])
+    enc, _ = load_seeded(pkg.build_backbone(cfg["semantic_encoder"]), c["seed"], dev)
+    neck, _ = load_seeded(pkg.build_neck(cfg["semantic_neck"]), c["seed"], dev)
+    head, _ = load_seeded(pkg.build_head(cfg["pts_bbox_head"]), c["seed"], dev)
+    tr = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synth.rig_transform(rig))
+    outs = []
+    with torch.no_grad():
+        sem = neck(enc(x.to(dev)))
+        for fused in (True, False):
+            monkeypatch.setattr(H, "FUSED_FINE_MLP", fused)
+            outs.append(head(voxel_feats=sem, img_feats=[img_feats[0].to(dev)], transform=tr)["output_voxels_fine"][0].clone())
+    assert outs[0].shape == outs[1].shape and outs[0].shape[0] > 0
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * max(1.0, float(outs[1].abs().max()))
