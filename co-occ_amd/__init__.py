@@ -17,7 +17,7 @@ from .head import OccHead
 from .view_transformer import ViewTransformerLiftSplatShootVoxel
 from .render import MLP, raw2outputs, render_block, sample_along_camera_ray, volume_sampling
 from .detector import COOCC_Ray
-from . import evaluation
+from . import apis, evaluation
 from . import lidar
 from .lidar import HardSimpleVFE, SparseLiDAREnc4x, SparseLiDAREnc8x, Voxelization
 from .evaluation import SemanticEvaluator, cm_to_ious, evaluation_semantic

@@ -144,7 +144,7 @@ def sparse_conv(feats, Cin, pc, table, relu=True, res=None, out=None, out_rows=N
     d.B = d.Xi = d.Yi = d.Zi = d.Xo = d.Yo = d.Zo = 1
     d.ksize, d.stride, d.pad = 1, 1, 0
     d.relu, d.res_mode, d.splitk, d.tile_hint = int(relu), (1 if res is not None else 0), 1, TILE_HINT
-    with _lib.TIMER.region("k_conv<sparse table>", 2.0 * Mo * Cin * pc.Cout * taps):
+    with _lib.TIMER.region("k_conv<sparse table %d->%d>" % (Cin, pc.Cout), 2.0 * Mo * Cin * pc.Cout * taps):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     return out
 

@@ -396,6 +396,12 @@ int coocc_eval_semantic(const float* pred, int64_t stride_c, int64_t stride_x, i
                         int64_t stride_z, int C, int h, int w, int d, const uint8_t* gt,
                         const uint8_t* visible, int H, int W, int D, int empty_idx, int accumulate,
                         int64_t* hist, void* stream);
+/* Prediction labels of the dump formats: F.interpolate(pred, size=[H,W,D], trilinear, align_corners=False) +
+ * argmax(dim=1) (P/coocc/apis/test.py:67-68,198-201), narrowed to u8 as save_output_nuscenes does
+ * (P/coocc/apis/utils.py:65).  pred addressed by element strides as in coocc_eval_semantic; labels:[H,W,D] u8. */
+int coocc_predict_labels(const float* pred, int64_t stride_c, int64_t stride_x, int64_t stride_y,
+                         int64_t stride_z, int C, int h, int w, int d, int H, int W, int D, uint8_t* labels,
+                         void* stream);
 
 /* ---------------------------------------------------------------- LiDAR producer */
 /* Hard voxelisation (mmdet3d/ops/voxel/src/voxelization_cpu.cpp:44-104 = the deterministic CUDA path of

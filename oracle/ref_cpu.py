@@ -511,3 +511,11 @@ def evaluation_semantic(pred, gt, eval_type, visible_mask=None, empty_idx=0):
         mask = noise_mask & (visible_mask[0].numpy() != 0)
         hist_occ = fast_hist(p[mask], g[mask], max_label=17)
     return fast_hist(p[noise_mask], g[noise_mask], max_label=17), hist_occ, up
+
+
+def predict_labels(pred, size):
+    """P/coocc/apis/test.py:67-68 (and :198-201 for pred_f / pred_c): F.interpolate(trilinear, align_corners=False) to the
+    ground-truth size, argmax over classes; save_output_nuscenes narrows to uint8 (P/coocc/apis/utils.py:65).
+    Returns (labels u8 [1,H,W,D], resampled logits) -- the logits let tests bound argmax flips by the top-2 margin."""
+    up = F.interpolate(pred, size=list(size), mode='trilinear', align_corners=False).contiguous()
+    return torch.argmax(up, dim=1).numpy().astype(np.uint8), up

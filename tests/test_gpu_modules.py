@@ -1,6 +1,7 @@
 """Module mirrors on the GPU vs the golden vectors (produced from the real reference) and the
 oracle: BiFuser_N, CustomResNet3D/FPN3D/OccHead, get_geometry/voxel_pooling/bev_pool, the render
 block, the library renderer, losses, and the whole hot path."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -475,3 +476,36 @@ def test_fine_mlp_fused_equals_layerwise(dev, monkeypatch):
             outs.append(head(voxel_feats=sem, img_feats=[img_feats[0].to(dev)], transform=tr)["output_voxels_fine"][0].clone())
     assert outs[0].shape == outs[1].shape and outs[0].shape[0] > 0
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * max(1.0, float(outs[1].abs().max()))
+
+
+def test_predict_labels_and_nuscenes_dump(dev, tmp_path):
+    """Prediction dump (output formats): device-side resample + argmax -> uint8 labels equal the
+    oracle's except inside the float tolerance of an argmax tie; the pickle has the upstream keys and types."""
+    import pickle
+    from co_occ_amd import apis
+    c = dict(cases.EVAL_CASE, coarse=(50, 50, 4), gt=(100, 100, 8), seed=77)
+    pred, gt, _ = cases.eval_inputs(c)
+    for size, src in ((gt.shape[1:], pred), (None, pred)):
+        want, up = ref_cpu.predict_labels(src, size if size is not None else src.shape[2:])
+        got = apis.predict_labels(src.to(dev), size)
+        assert got.dtype == torch.uint8 and tuple(got.shape) == want.shape
+        diff = got.cpu().numpy() != want
+        top2 = torch.topk(up[0], 2, dim=0).values
+        margin = (top2[0] - top2[1]).numpy()
+        assert not (diff & (margin[None] > 1e-5)).any(), "label differs away from an argmax tie"
+        assert diff.sum() <= (margin < 1e-5).sum()
+        if size is None:
+            assert not diff.any()       # no resampling -> no rounding -> identical
+    # channels-last logits (OccHead's layout) give the same labels
+    cl = pred.to(dev).permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)
+    assert torch.equal(apis.predict_labels(cl, gt.shape[1:]), apis.predict_labels(pred.to(dev), gt.shape[1:]))
+    rig = synth.camera_rig(6, (64, 176), seed=1)
+    img_inputs = (None, rig["rots"], rig["trans"])
+    labels = apis.predict_labels(pred.to(dev), gt.shape[1:])
+    f = apis.save_output_nuscenes(img_inputs, labels, str(tmp_path), "scene", "sample0", None, 123, None)
+    d = pickle.load(open(f, "rb"))
+    assert f.endswith("sample0.pkl") and set(d) == {"pred_voxels", "cam2lidar", "img_canvas"}
+    assert d["pred_voxels"].dtype == np.uint8 and d["pred_voxels"].shape == tuple(gt.shape[1:])
+    assert d["cam2lidar"].shape == (6, 4, 4) and np.allclose(d["cam2lidar"][:, :3, 3], rig["trans"][0].numpy())
+    f2 = apis.save_output_nuscenes(img_inputs, labels, str(tmp_path), "scene", "sample0", None, 123, "scene-0001")
+    assert f2.endswith(os.path.join("scene-0001", "123.pkl"))
