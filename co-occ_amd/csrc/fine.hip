@@ -463,15 +463,28 @@ __global__ __launch_bounds__(256) void k_fill(float* __restrict__ p, size_t n, f
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
+// 256 fine points per block: their logits are read as one contiguous span into LDS, then every class plane gets one
+// store per lane whose addresses follow the fine coordinates (consecutive points = neighbouring z), instead of one
+// lane per (point, class) scattering a wave's stores over 17 planes.
 __global__ __launch_bounds__(256) void k_scatter_fine(const float* __restrict__ logits, long long nf, int ncls, int stride,
                                                        const int64_t* __restrict__ fine_xyz, float* __restrict__ grid,
                                                        int Xf, int Yf, int Zf) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nf * ncls) return;
-  long long f = i / ncls;
-  int c = (int)(i - f * ncls);
-  long long x = fine_xyz[f], y = fine_xyz[nf + f], z = fine_xyz[2 * nf + f];
-  grid[(((size_t)c * Xf + x) * Yf + y) * Zf + z] = logits[f * stride + c];
+  extern __shared__ float s_log[];   // [256][ncls | 1]: odd row pitch -> conflict-free column reads
+  const int pitch = ncls | 1;
+  const long long f0 = (long long)blockIdx.x * 256;
+  const int rows = (int)(nf - f0 < 256 ? nf - f0 : 256);
+  if (stride == ncls) {
+    for (int i = threadIdx.x; i < rows * ncls; i += 256) s_log[(i / ncls) * pitch + i % ncls] = logits[f0 * ncls + i];
+  } else {
+    for (int i = threadIdx.x; i < rows * ncls; i += 256) s_log[(i / ncls) * pitch + i % ncls] = logits[(f0 + i / ncls) * stride + i % ncls];
+  }
+  __syncthreads();
+  const long long f = f0 + threadIdx.x;
+  if (f >= nf) return;
+  const long long x = fine_xyz[f], y = fine_xyz[nf + f], z = fine_xyz[2 * nf + f];
+  const size_t plane = (size_t)Xf * Yf * Zf;
+  float* g = grid + ((size_t)x * Yf + y) * Zf + z;
+  for (int c = 0; c < ncls; ++c) g[c * plane] = s_log[threadIdx.x * pitch + c];
 }
 
 extern "C" int coocc_scatter_fine(const float* fine_logits, int64_t nfine, int ncls, int stride, const int64_t* fine_xyz,
@@ -481,7 +494,8 @@ extern "C" int coocc_scatter_fine(const float* fine_logits, int64_t nfine, int n
   hipLaunchKernelGGL(k_fill, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), grid, total, empty_val);
   if (nfine > 0) {
     COOCC_CHECK_ARG(fine_logits && fine_xyz && stride >= ncls, "scatter_fine: null pointer");
-    hipLaunchKernelGGL(k_scatter_fine, dim3(cdiv(nfine * ncls, 256)), dim3(256), 0, as_stream(stream), fine_logits,
+    COOCC_CHECK_ARG(ncls <= 128, "scatter_fine: at most 128 classes");
+    hipLaunchKernelGGL(k_scatter_fine, dim3(cdiv(nfine, 256)), dim3(256), 256 * (ncls | 1) * sizeof(float), as_stream(stream), fine_logits,
                        (long long)nfine, ncls, stride, fine_xyz, grid, Xf, Yf, Zf);
   }
   COOCC_LAUNCH_CHECK("scatter_fine");

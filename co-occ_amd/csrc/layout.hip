@@ -31,18 +31,18 @@ __global__ __launch_bounds__(256) void k_ncdhw_to_ndhwc(const float* __restrict_
   const int b = blockIdx.y;
   const int v0 = blockIdx.x * TV;
   const int t = threadIdx.x;
-  for (int c0 = 0; c0 < C; c0 += TC) {
-    const int cn = min(TC, C - c0);
-    for (int c = t >> 6; c < cn; c += 4) {
-      int v = v0 + (t & 63);
-      tile[t & 63][c] = v < V ? src[((size_t)b * C + c0 + c) * V + v] : 0.f;
-    }
-    __syncthreads();
-    for (int i = t; i < TV * cn; i += 256) {
-      int v = i / cn, c = i - v * cn;
-      if (v0 + v < V) dst[((size_t)b * V + v0 + v) * dst_stride + dst_coff + c0 + c] = tile[v][c];
-    }
-    __syncthreads();
+  // one 128-channel slab per blockIdx.z: small volumes with many channels (camera feature maps: 6 x 512 x 704)
+  // still spread over the whole chip
+  const int c0 = blockIdx.z * TC;
+  const int cn = min(TC, C - c0);
+  for (int c = t >> 6; c < cn; c += 4) {
+    int v = v0 + (t & 63);
+    tile[t & 63][c] = v < V ? src[((size_t)b * C + c0 + c) * V + v] : 0.f;
+  }
+  __syncthreads();
+  for (int i = t; i < TV * cn; i += 256) {
+    int v = i / cn, c = i - v * cn;
+    if (v0 + v < V) dst[((size_t)b * V + v0 + v) * dst_stride + dst_coff + c0 + c] = tile[v][c];
   }
 }
 
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_ndhwc_to_ncdhw(const float* __restrict_
 extern "C" int coocc_ncdhw_to_ndhwc(const float* src, float* dst, int B, int C, int V, int dst_stride,
                                     int dst_coff, void* stream) {
   COOCC_CHECK_ARG(src && dst && B > 0 && C > 0 && V > 0 && dst_stride >= dst_coff + C, "ncdhw_to_ndhwc: bad args");
-  dim3 grid(cdiv(V, TV), B);
+  dim3 grid(cdiv(V, TV), B, cdiv(C, TC));
   hipLaunchKernelGGL(k_ncdhw_to_ndhwc, grid, dim3(256), 0, as_stream(stream), src, dst, C, V, dst_stride, dst_coff);
   COOCC_LAUNCH_CHECK("k_ncdhw_to_ndhwc");
   return COOCC_OK;

@@ -296,6 +296,23 @@ def bench_fpsdbg():
     lib.coocc_fps_voxels_set_debug(ctypes.c_void_p(0))
 
 
+def bench_finemlp():
+    """coocc_fine_mlp alone at the r50 worst case (every coarse voxel foreground: 640 000 fine points)."""
+    from co_occ_amd._lib import call, ptr
+    nf, ncls = 640000, 17
+    g = torch.Generator().manual_seed(3)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)
+    samp, vox = mk(nf, 128), mk(nf, 128)
+    ws = [mk(64, 128) * 0.1, mk(64), mk(64), mk(64), mk(64, 192) * 0.1, mk(64), mk(64), mk(64), mk(ncls, 64) * 0.1, mk(ncls)]
+    out = torch.empty(nf, ncls, device=dev)
+    def run():
+        call("coocc_fine_mlp", ptr(samp), 128, ptr(vox), 128, nf, ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), ptr(ws[3]), 1e-5,
+             ptr(ws[4]), ptr(ws[5]), ptr(ws[6]), ptr(ws[7]), 1e-5, ptr(ws[8]), ptr(ws[9]), ncls, ptr(out))
+    t = timeit(run, n=20)
+    fl = 2.0 * nf * 64 * (128 + 192 + 32)
+    print("fine_mlp  %d points: %.3f ms  %.1f TFLOP/s executed (%.0f GB/s of samples)" % (nf, t, fl / t / 1e9, nf * 1024 / t / 1e6))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["fps", "knn", "conv"]
     with torch.no_grad():
