@@ -107,8 +107,23 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
   const int it1 = min(it0 + p.iters_per_split, p.total_iters);
 
   f32x4 ra[PA], rb[PB];
+  // TABLE: the source rows of an iteration are fetched one iteration before its feature rows are requested, so
+  // the dependent pair (row-table entry -> feature row) costs one memory latency per iteration instead of two
+  int nidx[PA];
+  auto iload = [&](int it) {
+    const int t = it % p.taps;
+#pragma unroll
+    for (int a = 0; a < PA; ++a) nidx[a] = rbase[a] >= 0 ? p.gather[(size_t)t * p.M + rbase[a]] : -1;
+  };
+  if (TABLE && it0 < it1) iload(it0);
   auto gload = [&](int it) {
     const int kc = it / p.taps, t = it - kc * p.taps;
+    int src[PA];
+    if (TABLE) {
+#pragma unroll
+      for (int a = 0; a < PA; ++a) src[a] = nidx[a];
+      if (it + 1 < it1) iload(it + 1);
+    }
 #pragma unroll
     for (int b = 0; b < PB; ++b)
       rb[b] = *(const f32x4*)(wbase + wfrag_index((size_t)it, p.Npad >> 7, n0 + lrow + 32 * b, piece * 4));
@@ -123,10 +138,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
     for (int a = 0; a < PA; ++a) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (TABLE) {
-        if (rbase[a] >= 0 && cok) {
-          int src = p.gather[(size_t)t * p.M + rbase[a]];
-          if (src >= 0) v = *(const f32x4*)(p.in + (size_t)src * p.in_stride + cc);
-        }
+        if (src[a] >= 0 && cok) v = *(const f32x4*)(p.in + (size_t)src[a] * p.in_stride + cc);
       } else {
         int ix = rix[a] + kd, iy = riy[a] + kh, iz = riz[a] + kw;
         bool ok = rbase[a] >= 0 && cok && (unsigned)ix < (unsigned)p.Xi && (unsigned)iy < (unsigned)p.Yi &&

@@ -257,7 +257,7 @@ def bench_lidar():
     rows = _lib.TIMER.summary()
     _lib.TIMER.enabled = False
     for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:14]:
-        print("   %-32s %3d launches %8.3f ms" % (k, v["launches"], v["ms"]))
+        print("   %-32s %3d launches %8.3f ms  %6.1f TFLOP/s (table entries counted dense)" % (k, v["launches"], v["ms"], v["work"] / max(v["ms"], 1e-9) / 1e9))
     print("lidar  %d points -> %d voxels: voxelise %.3f ms, voxelise + VFE + SparseLiDAREnc8x %.3f ms -> %s, %d active at 1/8" % (
         n, m, t_v, t_all, tuple(out["x"].shape), out["pts_feats"][0].coors.shape[0]))
 
