@@ -72,6 +72,7 @@ SIGNATURES = {
     "coocc_raw2outputs": (I, [P, P, I, I, I, F, F, P, P, P, P]),
     "coocc_render_losses": (I, [P, P, P, P, L, I, P, P]),
     "coocc_conv_pack_weights_dev": (L, [P, I, I, I, I, P, P]),
+    "coocc_wino_pack_weights_dev": (L, [P, I, I, I, I, P, P]),
     "coocc_conv_tap_table": (I, [I, I, I, I, I, I, I, I, I, I, I, P, P]),
     "coocc_conv_epilogue_bwd": (I, [P, I, P, I, P, I, I, I, P, I, P, I, I, P, I, P, L, P]),
     "coocc_conv_wgrad": (I, [P, I, I, P, I, P, I, I, I, I, P, I, P, L, P]),

@@ -16,6 +16,9 @@ from .core import TILE_HINT, out_dim, workspace
 
 _F32 = torch.float32
 _tables = {}
+# 3x3x3 stride-1 convolutions of the training path (forward and dgrad) through the Winograd kernels when the layer is
+# large enough (core.WINO_MIN_ROWS); wgrad stays a direct GEMM.  COOCC_TRAIN_WINO=0: direct convolutions everywhere.
+TRAIN_WINO = __import__("os").environ.get("COOCC_TRAIN_WINO", "1") != "0"
 
 
 def _pad4(n):
@@ -46,6 +49,48 @@ def pack_weights_dev(w, Cout, Cin, taps, mode):
     if n < 0:
         _lib.check(int(n))
     return packed
+
+
+class _DevWino:
+    """What core.conv_rows_wino needs of a PackedConv, with the Winograd packs transformed on the device from the live
+    parameter (training re-packs every step): forward packs, or (``dgrad``) the packs of dx = conv(dy, W')."""
+
+    def __init__(self, w5, dgrad, scale=None, bias=None):
+        Cout, Cin = w5.shape[:2]
+        self.Cin, self.Cout = (Cout, Cin) if dgrad else (Cin, Cout)
+        self.scale, self.bias = scale, bias
+        self._w_raw, self.wino_tile = True, None
+        self._w5, self._dgrad, self._packs = w5, int(bool(dgrad)), {}
+
+    def wino_pack(self, tile):
+        if tile not in self._packs:
+            lib = _lib.load()
+            Cout, Cin = self._w5.shape[:2]
+            n = lib.coocc_wino_pack_weights_dev(None, Cout, Cin, tile, self._dgrad, None, None)
+            if n < 0:
+                _lib.check(int(n))
+            packed = torch.empty((tile + 2) ** 2, n // (tile + 2) ** 2, dtype=_F32, device=self._w5.device)
+            n = lib.coocc_wino_pack_weights_dev(ptr(self._w5), Cout, Cin, tile, self._dgrad, ptr(packed), _lib.stream())
+            if n < 0:
+                _lib.check(int(n))
+            self._packs[tile] = packed
+        return self._packs[tile]
+
+
+def _wino_train(x2d, geom, w5, dgrad, out2d, scale, shift, res2d, relu):
+    """Winograd path of a 3x3x3 stride-1 pad-1 convolution in training (forward or dgrad); False if not eligible."""
+    from . import core
+    if not TRAIN_WINO:
+        return False
+    B, X, Y, Z = geom
+    pk = _DevWino(w5, dgrad, scale, shift)
+    xr = core.Rows(x2d, B, X, Y, Z, pk.Cin)
+    plan = core.wino_plan(xr, pk, out2d.shape[0], 1 if res2d is not None else 0)
+    if plan is None:
+        return False
+    core.conv_rows_wino(xr, pk, core.Rows(out2d, B, X, Y, Z, pk.Cout), relu,
+                        core.Rows(res2d, B, X, Y, Z, pk.Cout) if res2d is not None else None, plan)
+    return True
 
 
 def _conv_launch(x2d, in_C, w_packed, out2d, Cout, taps, geom_in, geom_out, ksize, stride, pad, scale, shift, res2d, relu,
@@ -84,12 +129,15 @@ class ConvRowsFn(torch.autograd.Function):
         Xo, Yo, Zo = (out_dim(n, ksize, stride, pad) for n in (Xi, Yi, Zi))
         geom_out = (B, Xo, Yo, Zo)
         out = torch.empty(B * Xo * Yo * Zo, Cout, device=x2d.device, dtype=_F32)
-        wp = pack_weights_dev(weight.reshape(Cout, Cin, taps), Cout, Cin, taps, 0)
         eff_shift = shift
         if bias is not None:    # y = scale * (conv + b) + shift
             eff_shift = (bias.detach() * scale if scale is not None else bias.detach()) + (shift if shift is not None else 0)
             eff_shift = eff_shift.float().contiguous()
-        _conv_launch(x2d, Cin, wp, out, Cout, taps, geom, geom_out, ksize, stride, pad, scale, eff_shift, res2d, relu)
+        w_ = weight.detach().float().contiguous()
+        if not (ksize == 3 and stride == 1 and pad == 1 and
+                _wino_train(x2d, geom, w_.view(Cout, Cin, 3, 3, 3), False, out, scale, eff_shift, res2d, relu)):
+            wp = pack_weights_dev(w_.reshape(Cout, Cin, taps), Cout, Cin, taps, 0)
+            _conv_launch(x2d, Cin, wp, out, Cout, taps, geom, geom_out, ksize, stride, pad, scale, eff_shift, res2d, relu)
         ctx.save_for_backward(x2d, weight, out, scale if scale is not None else torch.empty(0, device=x2d.device))
         ctx.cfg = (geom, geom_out, ksize, stride, pad, relu, bias is not None, res2d is not None, scale is not None)
         return out
@@ -119,7 +167,11 @@ class ConvRowsFn(torch.autograd.Function):
         if need_x:
             dx = torch.empty(Mi, Cin, device=dev, dtype=_F32)
             w3 = weight.reshape(Cout, Cin, taps)
-            if stride == 1:
+            if (stride == 1 and ksize == 3 and pad == 1 and Cp == Cout and
+                    _wino_train(dacc, geom, weight.detach().float().contiguous().view(Cout, Cin, 3, 3, 3), True, dx, None, None,
+                                None, False)):
+                pass
+            elif stride == 1:
                 wp = pack_weights_dev(w3, Cout, Cin, taps, 2)
                 _conv_launch(dacc, Cp, wp, dx, Cin, taps, geom_out, geom, ksize, 1, ksize - 1 - pad, None, None, None, False,
                              tag="conv_dgrad")

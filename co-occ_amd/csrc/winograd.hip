@@ -216,3 +216,65 @@ extern "C" int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int
   COOCC_LAUNCH_CHECK("k_wino_out");
   return COOCC_OK;
 }
+
+// ------------------------------------------------------------------ device-side weight transform (training)
+// U[p = xi*(m+2) + eta][dz] = sum_{a,b} G[xi][a] G[eta][b] g[a][b][dz], written straight into the fragment-major packs
+// the grouped GEMM reads (one pack per transform point, conv_layout.h).  Training re-packs every step, so the host
+// fp64 einsum of the inference path (core.PackedConv.wino_pack) is replaced by this kernel (fp64 accumulation kept).
+// dgrad != 0: packs of the transposed convolution dx = conv(dy, W'), W'[c][n][a][b][dz] = w[n][c][2-a][2-b][2-dz].
+#include "conv_layout.h"
+
+__constant__ double c_G4[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+__constant__ double c_G5[5][3] = {{1, 0, 0}, {-2. / 9, 2. / 9, -2. / 9}, {1. / 9, 2. / 9, 4. / 9}, {-8. / 9, -4. / 9, -2. / 9}, {0, 0, 1}};
+__constant__ double c_G6[6][3] = {{1, 0, 0}, {1. / 3, 1. / 3, 1. / 3}, {-1. / 3, 1. / 3, -1. / 3}, {-16. / 15, -8. / 15, -4. / 15},
+                                  {1. / 15, -2. / 15, 4. / 15}, {0, 0, 1}};
+
+template <int N>
+__global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ w, int Cout, int Cin, int dgrad, int Npad,
+                                                       size_t pack_floats, float* __restrict__ packed) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)Cout * Cin * 3) return;
+  const int dz = (int)(i % 3);
+  const int c = (int)((i / 3) % Cin), n = (int)(i / (3LL * Cin));
+  const double (*G)[3] = N == 4 ? c_G4 : (N == 5 ? c_G5 : c_G6);
+  const float* g = w + ((size_t)n * Cin + c) * 27;
+  double t[N][3];     // t[xi][b] = sum_a G[xi][a] g[a][b]
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    double col[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) col[a] = dgrad ? (double)g[((2 - a) * 3 + (2 - b)) * 3 + (2 - dz)] : (double)g[(a * 3 + b) * 3 + dz];
+#pragma unroll
+    for (int xi = 0; xi < N; ++xi) t[xi][b] = G[xi][0] * col[0] + G[xi][1] * col[1] + G[xi][2] * col[2];
+  }
+  // GEMM roles: forward K = Cin (c), N = Cout (n); dgrad K = Cout (n), N = Cin (c)
+  const int kk = dgrad ? n : c, nn = dgrad ? c : n;
+  const size_t idx = wfrag_index((size_t)(kk / KC) * 3 + dz, Npad >> 7, nn, kk % KC);
+#pragma unroll
+  for (int xi = 0; xi < N; ++xi)
+#pragma unroll
+    for (int eta = 0; eta < N; ++eta)
+      packed[(size_t)(xi * N + eta) * pack_floats + idx] =
+          (float)(G[eta][0] * t[xi][0] + G[eta][1] * t[xi][1] + G[eta][2] * t[xi][2]);
+}
+
+extern "C" int64_t coocc_wino_pack_weights_dev(const float* w, int Cout, int Cin, int tile, int dgrad, float* packed,
+                                               void* stream) {
+  if (Cout <= 0 || Cin <= 0 || tile < 2 || tile > 4) return coocc_set_error(COOCC_EINVAL, "wino_pack_weights_dev: bad args");
+  const int N = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+  const int kch = (K + KC - 1) / KC, Npad = (N + NPAD_TO - 1) / NPAD_TO * NPAD_TO;
+  const size_t pack_floats = (size_t)3 * kch * Npad * KC;
+  const int pts = (tile + 2) * (tile + 2);
+  const int64_t total = (int64_t)pts * (int64_t)pack_floats;
+  if (!packed) return total;
+  if (!w) return coocc_set_error(COOCC_EINVAL, "wino_pack_weights_dev: null weights");
+  hipStream_t s = as_stream(stream);
+  if (hipMemsetAsync(packed, 0, sizeof(float) * (size_t)total, s) != hipSuccess)
+    return coocc_set_error(COOCC_EHIP, "wino_pack_weights_dev: memset failed");
+  const dim3 grid(cdiv((long long)Cout * Cin * 3, 256));
+  if (tile == 2) hipLaunchKernelGGL(k_wino_weights<4>, grid, dim3(256), 0, s, w, Cout, Cin, dgrad, Npad, pack_floats, packed);
+  else if (tile == 3) hipLaunchKernelGGL(k_wino_weights<5>, grid, dim3(256), 0, s, w, Cout, Cin, dgrad, Npad, pack_floats, packed);
+  else hipLaunchKernelGGL(k_wino_weights<6>, grid, dim3(256), 0, s, w, Cout, Cin, dgrad, Npad, pack_floats, packed);
+  if (hipGetLastError() != hipSuccess) return coocc_set_error(COOCC_EHIP, "wino_pack_weights_dev: launch failed");
+  return total;
+}

@@ -158,6 +158,11 @@ int coocc_wino_input(const float* in, int in_stride, int B, int X, int Y, int Z,
 int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, int tile, float* out,
                       int out_stride, const float* scale, const float* bias, const float* res, int res_stride,
                       int relu, void* stream);
+/* Winograd weight packs made on the device (training re-packs every step): w:[Cout,Cin,3,3,3] -> (tile+2)^2 packs
+ * U[p] = G g G^T in the layout coocc_conv_fwd reads with wgroup_rows (taps = 3, the z taps).  dgrad != 0: packs of the
+ * transposed convolution (W'[c][n] = w[n][c] with all three tap axes flipped; GEMM N = Cin, K = Cout).
+ * packed == NULL: returns the number of floats needed.  Returns that count, or a negative COOCC_E* code. */
+int64_t coocc_wino_pack_weights_dev(const float* w, int Cout, int Cin, int tile, int dgrad, float* packed, void* stream);
 
 /* ---------------------------------------------------------------- backward of the conv family
  * Frozen-statistics BN (scale/shift constants), as the forward.  torch.autograd computes these through

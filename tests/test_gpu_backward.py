@@ -32,8 +32,33 @@ CONV_CASES = [
 ]
 
 
+WINO_CASES = [
+    (8, 12, (6, 5, 4), 3, 1, True, False, True, True),          # F(2x2): X, Y < 8
+    (132, 136, (9, 8, 4), 3, 1, True, True, True, True),        # F(4x4), ragged tiles, both channel counts cross 128
+    (32, 48, (13, 12, 3), 3, 1, False, False, False, False),    # F(4x4), no epilogue at all
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "c%d-%d_%dx%d" % (c[0], c[1], c[2][0], c[2][1]))
+def test_conv_backward_winograd_training_path(dev, case, monkeypatch):
+    """Forward and dgrad of the training path through the Winograd kernels with device-made weight packs
+    (coocc_wino_pack_weights_dev; production switches at core.WINO_MIN_ROWS output rows), wgrad direct."""
+    from co_occ_amd import core
+    monkeypatch.setattr(core, "WINO_MIN_ROWS", 0)
+    monkeypatch.setattr(core, "WINO", 1)
+    seen = []
+    real = core.conv_rows_wino
+    monkeypatch.setattr(core, "conv_rows_wino", lambda *a, **k: (seen.append(a[5][0]), real(*a, **k))[1])
+    _run_conv_case(dev, case)
+    assert len(seen) == 2 and seen[0] == (4 if min(case[2][:2]) >= 8 else 2), seen      # forward + dgrad
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "c%d-%d_k%d_s%d" % (c[0], c[1], c[3], c[4]))
 def test_conv_backward_vs_torch_autograd(dev, case):
+    _run_conv_case(dev, case)
+
+
+def _run_conv_case(dev, case):
     Cin, Cout, (X, Y, Z), k, stride, use_bn, use_bias, use_res, relu = case
     g = torch.Generator().manual_seed(Cin * 131 + Cout)
     B = 2
