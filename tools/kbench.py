@@ -78,12 +78,15 @@ def bench_conv():
     for name, ci, co, g, k, st in shapes:
         x = core.Rows(torch.randn(g[0] * g[1] * g[2], ci, device=dev), 1, g[0], g[1], g[2], ci)
         pc = core.PackedConv(torch.randn(co, ci, k, k, k, device=dev) * 0.02, ksize=k, stride=st, pad=k // 2)
+        if name.startswith("con_enc"):
+            pc.wino_tile = 2          # as BiFuser_N packs them (fuser.py): F(2x2) keeps the fine logits inside 1e-4
         t = timeit(lambda: core.conv_rows(x, pc, relu=True), n=3, warm=1)
         M = (core.out_dim(g[0], k, st, k // 2) * core.out_dim(g[1], k, st, k // 2) * core.out_dim(g[2], k, st, k // 2))
         fl = 2.0 * M * ci * co * k ** 3
-        print("%-14s %4d->%4d %-11s k%d s%d  %8.3f ms  %6.1f TFLOP/s  [%s]" % (
-            name, ci, co, "x".join(map(str, g)), k, st, t, fl / t / 1e9, core.conv_kernel_name(M, co, False)))
-
+        plan = core.wino_plan(x, pc, M, 0) if (k == 3 and st == 1) else None
+        path = "winograd F(%dx%d): transforms + grouped k_conv2" % (plan[0], plan[0]) if plan else "direct " + core.conv_kernel_name(M, co, False, 0, k ** 3 * -(-ci // 32))
+        print("%-14s %4d->%4d %-11s k%d s%d  %8.3f ms  %6.1f TFLOP/s direct-equivalent  [%s]" % (
+            name, ci, co, "x".join(map(str, g)), k, st, t, fl / t / 1e9, path))
 
 
 
