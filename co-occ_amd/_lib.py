@@ -73,6 +73,9 @@ SIGNATURES = {
     "coocc_render_losses": (I, [P, P, P, P, L, I, P, P]),
     "coocc_conv_pack_weights_dev": (L, [P, I, I, I, I, P, P]),
     "coocc_wino_pack_weights_dev": (L, [P, I, I, I, I, P, P]),
+    "coocc_wino_gradout": (I, [P, I, I, I, I, I, I, I, P, L, P]),
+    "coocc_wino_ztap_table": (I, [L, I, P, P]),
+    "coocc_wino_wgrad": (I, [P, P, L, I, I, I, I, P, P, I, P, L, P]),
     "coocc_conv_tap_table": (I, [I, I, I, I, I, I, I, I, I, I, I, P, P]),
     "coocc_conv_epilogue_bwd": (I, [P, I, P, I, P, I, I, I, P, I, P, I, I, P, I, P, L, P]),
     "coocc_conv_wgrad": (I, [P, I, I, P, I, P, I, I, I, I, P, I, P, L, P]),

@@ -19,6 +19,8 @@ _tables = {}
 # 3x3x3 stride-1 convolutions of the training path (forward and dgrad) through the Winograd kernels when the layer is
 # large enough (core.WINO_MIN_ROWS); wgrad stays a direct GEMM.  COOCC_TRAIN_WINO=0: direct convolutions everywhere.
 TRAIN_WINO = __import__("os").environ.get("COOCC_TRAIN_WINO", "1") != "0"
+# weight gradients of those layers in the Winograd domain too (COOCC_TRAIN_WINO_WGRAD=0: direct k_wgrad)
+TRAIN_WINO_WGRAD = TRAIN_WINO and __import__("os").environ.get("COOCC_TRAIN_WINO_WGRAD", "1") != "0"
 
 
 def _pad4(n):
@@ -90,6 +92,42 @@ def _wino_train(x2d, geom, w5, dgrad, out2d, scale, shift, res2d, relu):
         return False
     core.conv_rows_wino(xr, pk, core.Rows(out2d, B, X, Y, Z, pk.Cout), relu,
                         core.Rows(res2d, B, X, Y, Z, pk.Cout) if res2d is not None else None, plan)
+    return True
+
+
+_ztables = {}
+
+
+def _wino_wgrad(x2d, dacc, geom, Cin, Cout, dw):
+    """Weight gradient of a 3x3x3 stride-1 pad-1 layer in the Winograd domain; False if the layer is not eligible."""
+    from . import core
+    if not TRAIN_WINO_WGRAD:
+        return False
+    B, X, Y, Z = geom
+    dev = x2d.device
+    xr = core.Rows(x2d, B, X, Y, Z, Cin)
+    pk = _DevWino(torch.empty(Cout, Cin, 0, device=dev), False)      # geometry only: no packs are made
+    plan = core.wino_plan(xr, pk, x2d.shape[0], 0)
+    if plan is None:
+        return False
+    tile, pts, Tx, Ty, rows, G, _ = plan
+    ws = workspace(dev)
+    if ws.numel() < pts * 3 * Cin * Cout or pts * G * max(Cin, Cout) * 4 >= 0xFFFFFF00:
+        return False
+    V = core._wino_buffer(dev, "V", pts * G * Cin)
+    dM = core._wino_buffer(dev, "M", pts * G * Cout)
+    if G > rows:        # rows past the valid ones (stale from other layers) must not contribute
+        V[:pts * G * Cin].view(pts, G, Cin)[:, rows:].zero_()
+        dM[:pts * G * Cout].view(pts, G, Cout)[:, rows:].zero_()
+    call("coocc_wino_input", ptr(x2d), x2d.shape[1], B, X, Y, Z, Cin, tile, ptr(V), G)
+    call("coocc_wino_gradout", ptr(dacc), dacc.shape[1], B, X, Y, Z, Cout, tile, ptr(dM), G)
+    key = (dev.index, pts * G, Z)
+    if key not in _ztables:
+        t = torch.empty(3, pts * G, dtype=torch.int32, device=dev)
+        call("coocc_wino_ztap_table", pts * G, Z, ptr(t))
+        _ztables[key] = t
+    with _lib.TIMER.region("k_wgrad wino%d" % tile, 2.0 * pts * rows * 3 * Cin * Cout):
+        call("coocc_wino_wgrad", ptr(V), ptr(dM), G, Z, Cin, Cout, tile, ptr(_ztables[key]), ptr(dw), 0, ptr(ws), ws.numel())
     return True
 
 
@@ -182,10 +220,11 @@ class ConvRowsFn(torch.autograd.Function):
                              table=tb, tag="conv_dgrad")
         if need_w:
             dw = torch.empty(Cout, Cin, taps, device=dev, dtype=_F32)
-            tb = tap_table(dev, B, Xi, Yi, Zi, ksize, stride, pad, False) if (taps > 1 or stride > 1) else None
-            with _lib.TIMER.region("k_wgrad", 2.0 * Mo * Cin * Cout * taps):
-                call("coocc_conv_wgrad", ptr(x2d), Mi, Cin, ptr(dacc), Cp, ptr(tb), Mo, Cin, Cout, taps, ptr(dw), 0, ptr(ws),
-                     ws.numel())
+            if not (ksize == 3 and stride == 1 and pad == 1 and Cp == Cout and _wino_wgrad(x2d, dacc, geom, Cin, Cout, dw)):
+                tb = tap_table(dev, B, Xi, Yi, Zi, ksize, stride, pad, False) if (taps > 1 or stride > 1) else None
+                with _lib.TIMER.region("k_wgrad", 2.0 * Mo * Cin * Cout * taps):
+                    call("coocc_conv_wgrad", ptr(x2d), Mi, Cin, ptr(dacc), Cp, ptr(tb), Mo, Cin, Cout, taps, ptr(dw), 0, ptr(ws),
+                         ws.numel())
             dw = dw.view_as(weight)
         return dx, dw, dbias, dres, None, None, None, None, None, None, None
 

@@ -26,6 +26,10 @@ template <> struct Wino<4> {   // F(2,3)
   template <typename T> static __device__ __forceinline__ void at(const T* m, T* y) {
     y[0] = m[0] + m[1] + m[2]; y[1] = m[1] - m[2] - m[3];
   }
+  // adjoint of at(): t = A y (the gradient of the output transform, used by the Winograd-domain wgrad)
+  template <typename T> static __device__ __forceinline__ void a(const T* y, T* t) {
+    t[0] = y[0]; t[1] = y[0] + y[1]; t[2] = y[0] - y[1]; t[3] = -y[1];
+  }
 };
 template <> struct Wino<5> {   // F(3,3) on the points (0, -1, 2, 1/2, inf): rms error 1.7e-6 of the output scale, between
   static constexpr int M = 3;  // F(2,3) (0.75e-6) and F(4,3) (3.5e-6); 8.33*Cin multiplies per output
@@ -40,6 +44,10 @@ template <> struct Wino<5> {   // F(3,3) on the points (0, -1, 2, 1/2, inf): rms
     y[0] = m[0] + m[1] + m[2] + m[3];
     y[1] = 2.f * m[2] - m[1] + 0.5f * m[3];
     y[2] = m[1] + 4.f * m[2] + 0.25f * m[3] + m[4];
+  }
+  template <typename T> static __device__ __forceinline__ void a(const T* y, T* t) {
+    t[0] = y[0]; t[1] = y[0] - y[1] + y[2]; t[2] = y[0] + 2.f * y[1] + 4.f * y[2];
+    t[3] = y[0] + 0.5f * y[1] + 0.25f * y[2]; t[4] = y[2];
   }
 };
 template <> struct Wino<6> {   // F(4,3) on the points (0, 1, -1, 1/2, -2, inf): ~2.2x lower fp32 error than the
@@ -59,6 +67,13 @@ template <> struct Wino<6> {   // F(4,3) on the points (0, 1, -1, 1/2, -2, inf):
     y[1] = d12 + 0.5f * m[3] - 2.f * m[4];
     y[2] = s12 + 0.25f * m[3] + 4.f * m[4];
     y[3] = d12 + 0.125f * m[3] - 8.f * m[4] + m[5];
+  }
+  template <typename T> static __device__ __forceinline__ void a(const T* y, T* t) {
+    const T s02 = y[0] + y[2], s13 = y[1] + y[3];
+    t[0] = y[0]; t[1] = s02 + s13; t[2] = s02 - s13;
+    t[3] = y[0] + 0.5f * y[1] + 0.25f * y[2] + 0.125f * y[3];
+    t[4] = y[0] - 2.f * y[1] + 4.f * y[2] - 8.f * y[3];
+    t[5] = y[3];
   }
 };
 
@@ -214,6 +229,71 @@ extern "C" int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int
     hipLaunchKernelGGL(k_wino_out<6>, grid, dim3(256), 0, as_stream(stream), Mb, (size_t)group_rows * C, B, X, Y, Z, C, Tx, Ty,
                        out, out_stride, scale, bias, res, res_stride, relu);
   COOCC_LAUNCH_CHECK("k_wino_out");
+  return COOCC_OK;
+}
+
+// ------------------------------------------------------------------ gradient of the output transform (training)
+// dM[p = xi*(m+2) + eta] = sum_{i,j} A^T[i][xi] dY[i][j] A^T[j][eta] for every (tile, z) row: the second operand of the
+// Winograd-domain weight gradient dU[p][dz] = sum_rows V[p][row + dz - 1]^T dM[p][row].  Same row layout as V / M;
+// outputs outside the volume (ragged last tiles) contribute zeros.
+template <int N>
+__global__ __launch_bounds__(256) void k_wino_gradout(const float* __restrict__ dy, int dy_stride, int B, int X, int Y, int Z,
+                                                       int C, int Tx, int Ty, size_t gstride, float* __restrict__ dM) {
+  constexpr int MO = Wino<N>::M;
+  const int c4 = C >> 2;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long rows = (long long)B * Tx * Ty * Z;
+  if (i >= rows * c4) return;
+  const int c = (int)(i % c4) * 4;
+  const long long row = i / c4;
+  long long r = row;
+  const int z = (int)(r % Z); r /= Z;
+  const int ty = (int)(r % Ty); r /= Ty;
+  const int tx = (int)(r % Tx); const int b = (int)(r / Tx);
+  f32x4 t[N][MO];   // t[xi][j]: x-transformed, column j of the output patch
+#pragma unroll
+  for (int j = 0; j < MO; ++j) {
+    f32x4 d[MO], q[N];
+    const int y = MO * ty + j;
+#pragma unroll
+    for (int a = 0; a < MO; ++a) {
+      const int x = MO * tx + a;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (x < X && y < Y) v = *(const f32x4*)(dy + ((((size_t)b * X + x) * Y + y) * Z + z) * dy_stride + c);
+      d[a] = v;
+    }
+    Wino<N>::a(d, q);
+#pragma unroll
+    for (int xi = 0; xi < N; ++xi) t[xi][j] = q[xi];
+  }
+  float* o = dM + (size_t)row * C + c;
+#pragma unroll
+  for (int xi = 0; xi < N; ++xi) {
+    f32x4 q[N];
+    Wino<N>::a(t[xi], q);
+#pragma unroll
+    for (int e = 0; e < N; ++e) *(f32x4*)(o + (size_t)(xi * N + e) * gstride) = q[e];
+  }
+}
+
+extern "C" int coocc_wino_gradout(const float* dy, int dy_stride, int B, int X, int Y, int Z, int C, int tile, float* dM,
+                                  int64_t group_rows, void* stream) {
+  COOCC_CHECK_ARG(dy && dM && B > 0 && X > 0 && Y > 0 && Z > 0 && C > 0 && C % 4 == 0 && dy_stride % 4 == 0, "wino_gradout: bad args");
+  COOCC_CHECK_ARG(tile >= 2 && tile <= 4, "wino_gradout: tile must be 2, 3 or 4");
+  const int Tx = (X + tile - 1) / tile, Ty = (Y + tile - 1) / tile;
+  const long long rows = (long long)B * Tx * Ty * Z;
+  COOCC_CHECK_ARG(group_rows >= rows, "wino_gradout: group_rows too small");
+  const dim3 grid(cdiv(rows * (C / 4), 256));
+  if (tile == 2)
+    hipLaunchKernelGGL(k_wino_gradout<4>, grid, dim3(256), 0, as_stream(stream), dy, dy_stride, B, X, Y, Z, C, Tx, Ty,
+                       (size_t)group_rows * C, dM);
+  else if (tile == 3)
+    hipLaunchKernelGGL(k_wino_gradout<5>, grid, dim3(256), 0, as_stream(stream), dy, dy_stride, B, X, Y, Z, C, Tx, Ty,
+                       (size_t)group_rows * C, dM);
+  else
+    hipLaunchKernelGGL(k_wino_gradout<6>, grid, dim3(256), 0, as_stream(stream), dy, dy_stride, B, X, Y, Z, C, Tx, Ty,
+                       (size_t)group_rows * C, dM);
+  COOCC_LAUNCH_CHECK("k_wino_gradout");
   return COOCC_OK;
 }
 

@@ -163,6 +163,18 @@ int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int X, int Y, 
  * transposed convolution (W'[c][n] = w[n][c] with all three tap axes flipped; GEMM N = Cin, K = Cout).
  * packed == NULL: returns the number of floats needed.  Returns that count, or a negative COOCC_E* code. */
 int64_t coocc_wino_pack_weights_dev(const float* w, int Cout, int Cin, int tile, int dgrad, float* packed, void* stream);
+/* Winograd-domain weight gradient of a 3x3x3 stride-1 pad-1 convolution (training; 4x / 2.25x fewer multiplies than
+ * coocc_conv_wgrad).  coocc_wino_gradout: dM[p] = A dY A^T per (tile, z) row, same layout as coocc_wino_input's V
+ * ([(tile+2)^2][group_rows][C]; rows past the valid ones must be zero in dM or V).  coocc_wino_ztap_table: the z-tap
+ * row table [3][rows_total] (row + dz - 1, or -1 outside 0..Z-1), rows_total = (tile+2)^2 * group_rows.
+ * coocc_wino_wgrad: dU[p][dz] = sum_rows V[p][row+dz-1]^T dM[p][row], dw[Cout,Cin,3,3,3] (=|+=) G^T dU G;
+ * ws: >= (tile+2)^2 * 3 * Cin * Cout floats (more = more M slices in flight). */
+int coocc_wino_gradout(const float* dy, int dy_stride, int B, int X, int Y, int Z, int C, int tile, float* dM,
+                       int64_t group_rows, void* stream);
+int coocc_wino_ztap_table(int64_t rows_total, int Z, int32_t* table, void* stream);
+int coocc_wino_wgrad(const float* V, const float* dM, int64_t group_rows, int Z, int Cin, int Cout, int tile,
+                     const int32_t* ztap_table, float* dw, int accumulate, float* ws, int64_t ws_floats,
+                     void* stream);
 
 /* ---------------------------------------------------------------- backward of the conv family
  * Frozen-statistics BN (scale/shift constants), as the forward.  torch.autograd computes these through

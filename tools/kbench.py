@@ -229,10 +229,8 @@ def bench_trunk():
     rows = _lib.TIMER.summary()
     _lib.TIMER.enabled = False
     print("trunk train step (fwd+bwd, r50 100x100x8): %.1f ms" % t)
-    for k in ("conv_fwd", "conv_dgrad", "k_wgrad", "coocc_conv_epilogue_bwd", "coocc_upsample_trilinear_bwd", "coocc_upsample_add_trilinear"):
-        if k in rows:
-            r = rows[k]
-            print("   %-32s %3d launches %8.2f ms%s" % (k, r["launches"], r["ms"], "  %.0f TFLOP/s" % (r["work"] / r["ms"] / 1e9) if r["work"] else ""))
+    for k, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:16]:
+        print("   %-44s %3d launches %8.2f ms%s" % (k, r["launches"], r["ms"], "  %.0f TFLOP/s" % (r["work"] / r["ms"] / 1e9) if r["work"] else ""))
 
 
 def bench_lidar():
