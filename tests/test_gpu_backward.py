@@ -287,10 +287,15 @@ def test_render_block_train_reaches_features_and_heads(dev):
         assert_close(p.grad.cpu() / sc, r / sc, what="d head params")
 
 
-def test_decoder_trunk_backward_vs_oracle_autograd(dev):
+@pytest.mark.parametrize("conv_path", ["direct", "winograd"])
+def test_decoder_trunk_backward_vs_oracle_autograd(dev, monkeypatch, conv_path):
     """con_enc -> CustomResNet3D(18) -> FPN3D: every conv weight gradient and the input gradient of the
-    differentiable trunk vs torch autograd through the oracle's restatement (frozen BN statistics)."""
+    differentiable trunk vs torch autograd through the oracle's restatement (frozen BN statistics).
+    conv_path=winograd forces forward, dgrad and wgrad of every 3x3x3 stride-1 layer through the Winograd kernels
+    (production does so from core.WINO_MIN_ROWS output rows up)."""
     from oracle import ref_cpu
+    from co_occ_amd import core
+    monkeypatch.setattr(core, "WINO_MIN_ROWS", 0 if conv_path == "winograd" else 1 << 30)
     import co_occ_amd.synth as synth
     C, planes, fpn_out, grid = 8, [16, 32, 64, 128], 32, (12, 10, 4)
     bn = dict(type="BN3d")           # eps 1e-5, the value the oracle restates
