@@ -39,6 +39,33 @@ def tap_table(dev, B, Xi, Yi, Zi, ksize, stride, pad, dgrad):
     return _tables[key]
 
 
+_classes = {}
+
+
+def dgrad_classes(dev, B, Xi, Yi, Zi, ksize, stride, pad):
+    """Strided dgrad by residue class: input voxels with the same (x, y, z) mod stride are reached through the same
+    subset of taps (stride 2, k = 3: 1, 2, 4 or 8 of the 27), so each class is its own small row-table GEMM instead
+    of 27 taps of which 7/8 of the table entries are empty.  -> list of (rows int32 [Mc], taps int64 [Tc], table
+    int32 [Tc, Mc]) over the non-empty classes, cached per geometry."""
+    key = (dev.index, B, Xi, Yi, Zi, ksize, stride, pad)
+    if key not in _classes:
+        tb = tap_table(dev, B, Xi, Yi, Zi, ksize, stride, pad, True)          # [taps, Mi]: output row or -1
+        m = torch.arange(B * Xi * Yi * Zi, device=dev)
+        cls = (((m // (Yi * Zi)) % Xi % stride) * stride + (m // Zi) % Yi % stride) * stride + m % Zi % stride
+        out = []
+        for c in range(stride ** 3):
+            rows = torch.nonzero(cls == c).flatten()
+            if rows.numel() == 0:
+                continue
+            sub = tb[:, rows]
+            taps = torch.nonzero((sub >= 0).any(1)).flatten()
+            if taps.numel() == 0:
+                continue
+            out.append((rows.int().contiguous(), taps, sub[taps].contiguous()))
+        _classes[key] = out
+    return _classes[key]
+
+
 def pack_weights_dev(w, Cout, Cin, taps, mode):
     """Device-side fragment-major packing (modes: 0 fwd, 1 fwd tap-major, 2 dgrad flipped, 3 dgrad)."""
     lib = _lib.load()
@@ -132,16 +159,16 @@ def _wino_wgrad(x2d, dacc, geom, Cin, Cout, dw):
 
 
 def _conv_launch(x2d, in_C, w_packed, out2d, Cout, taps, geom_in, geom_out, ksize, stride, pad, scale, shift, res2d, relu,
-                 table=None, tag="conv_fwd"):
+                 table=None, tag="conv_fwd", out_rows=None):
     d = ConvDesc()
     ws = workspace(x2d.device)
     d.in_, d.w, d.out = ptr(x2d), ptr(w_packed), ptr(out2d)
     d.scale, d.bias = ptr(scale), ptr(shift)
     d.res = ptr(res2d)
     d.gather = ptr(table, torch.int32) if table is not None else None
-    d.out_rows = None
+    d.out_rows = ptr(out_rows, torch.int32) if out_rows is not None else None
     d.ws, d.ws_floats = ptr(ws), ws.numel()
-    d.M, d.Cin, d.Cout, d.taps = out2d.shape[0], in_C, Cout, taps
+    d.M, d.Cin, d.Cout, d.taps = (out_rows.shape[0] if out_rows is not None else out2d.shape[0]), in_C, Cout, taps
     d.in_stride, d.out_stride = x2d.shape[1], out2d.shape[1]
     d.res_stride = res2d.shape[1] if res2d is not None else 0
     B, Xi, Yi, Zi = geom_in
@@ -214,10 +241,11 @@ class ConvRowsFn(torch.autograd.Function):
                 _conv_launch(dacc, Cp, wp, dx, Cin, taps, geom_out, geom, ksize, 1, ksize - 1 - pad, None, None, None, False,
                              tag="conv_dgrad")
             else:
-                wp = pack_weights_dev(w3, Cout, Cin, taps, 3)
-                tb = tap_table(dev, B, Xi, Yi, Zi, ksize, stride, pad, True)
-                _conv_launch(dacc, Cp, wp, dx, Cin, taps, geom_out, geom, ksize, stride, pad, None, None, None, False,
-                             table=tb, tag="conv_dgrad")
+                dx.zero_()          # voxels no output reads (and classes without taps) get a zero gradient
+                for rows_c, taps_c, table_c in dgrad_classes(dev, B, Xi, Yi, Zi, ksize, stride, pad):
+                    wp = pack_weights_dev(w3.detach().index_select(2, taps_c), Cout, Cin, taps_c.numel(), 3)
+                    _conv_launch(dacc, Cp, wp, dx, Cin, taps_c.numel(), geom_out, geom, ksize, stride, pad, None, None, None,
+                                 False, table=table_c, tag="conv_dgrad", out_rows=rows_c)
         if need_w:
             dw = torch.empty(Cout, Cin, taps, device=dev, dtype=_F32)
             if not (ksize == 3 and stride == 1 and pad == 1 and Cp == Cout and _wino_wgrad(x2d, dacc, geom, Cin, Cout, dw)):
