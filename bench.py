@@ -113,7 +113,7 @@ def cpu_baseline(sd, s, cfgname, seconds_cap):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="r50", choices=sorted(synth.CONFIGS))
     ap.add_argument("--streams", type=int, default=1, help="samples in flight (software pipelining over HIP streams)")
