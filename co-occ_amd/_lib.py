@@ -105,6 +105,8 @@ SIGNATURES = {
     "coocc_bn_stats": (I, [P, I, I, I, P, P, P, Z, P]),
     "coocc_bn_apply": (I, [P, I, I, P, P, P, P, F, P, I, P, P]),
     "coocc_bn_backward": (I, [P, P, P, I, I, P, P, P, F, I, P, P, P, P, P, Z, P]),
+    "coocc_bn_backward_sums": (I, [P, P, P, I, I, P, P, F, I, P, P, P, Z, P]),
+    "coocc_bn_backward_dx": (I, [P, P, P, I, I, P, P, P, F, I, P, P, ctypes.c_double, P, P, P]),
     "coocc_predict_labels": (I, [P, L, L, L, L, I, I, I, I, I, I, I, P, P]),
     "coocc_eval_semantic": (I, [P, L, L, L, L, I, I, I, I, P, P, I, I, I, I, I, P, P]),
 }

@@ -750,12 +750,25 @@ def fine_branch_train(head, out_voxel_rows, geom, coarse_lin, img_feats=None, tr
 
 
 # ----------------------------------------------------------------------------- BatchNorm with batch statistics
+def _sync_group(bn, sync):
+    """The process group a training-mode BN synchronises over, or None.  sync=None: follow the module type
+    (nn.SyncBatchNorm, what norm_cfg type='SyncBN' builds upstream) whenever torch.distributed is initialised."""
+    import torch.distributed as dist
+    if sync is None:
+        sync = isinstance(bn, torch.nn.SyncBatchNorm)
+    if not sync or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None
+    return getattr(bn, "process_group", None) or dist.group.WORLD
+
+
 class BatchNormRowsFn(torch.autograd.Function):
-    """Training-mode BatchNorm3d / SyncBN (single process) on rows [M, C] (+ residual, ReLU): batch mean / biased variance,
-    running statistics updated in place like torch (momentum, unbiased variance)."""
+    """Training-mode BatchNorm3d / SyncBN on rows [M, C] (+ residual, ReLU): batch mean / biased variance, running
+    statistics updated in place like torch (momentum, unbiased variance).  With a process group the statistics are
+    those of all ranks' rows (one all-reduce of 2C+1 floats in the forward, one of 2C in the backward, as
+    torch.nn.SyncBatchNorm does); the returned dgamma / dbeta are this rank's share, which DDP then reduces."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, bn, relu):
+    def forward(ctx, x, gamma, beta, res, bn, relu, group=None):
         x = x.float().contiguous()
         M, C = x.shape
         dev = x.device
@@ -763,6 +776,16 @@ class BatchNormRowsFn(torch.autograd.Function):
         var = torch.empty(C, device=dev, dtype=_F32)
         ws = workspace(dev)
         call("coocc_bn_stats", ptr(x), C, M, C, ptr(mean), ptr(var), ptr(ws), ws.numel() * 4)
+        count = float(M)
+        if group is not None:
+            import torch.distributed as dist
+            m64 = mean.double()
+            pack = torch.cat([m64 * M, (var.double() + m64 * m64) * M, torch.tensor([float(M)], device=dev, dtype=torch.float64)])
+            dist.all_reduce(pack, group=group)
+            count = float(pack[-1].item())
+            gm = pack[:C] / count
+            mean = gm.float()
+            var = (pack[C:2 * C] / count - gm * gm).clamp_(min=0).float()
         y = torch.empty_like(x)
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         call("coocc_bn_apply", ptr(x), M, C, ptr(mean), ptr(var), ptr(g), ptr(b), float(bn.eps),
@@ -771,30 +794,37 @@ class BatchNormRowsFn(torch.autograd.Function):
             mom = bn.momentum if bn.momentum is not None else 0.1
             with torch.no_grad():
                 bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(var * (M / max(M - 1, 1)), alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var * (count / max(count - 1, 1)), alpha=mom)
                 bn.num_batches_tracked += 1
         ctx.save_for_backward(x, y, mean, var, g)
-        ctx.cfg = (float(bn.eps), int(relu), res is not None)
+        ctx.cfg = (float(bn.eps), int(relu), res is not None, group, count)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, mean, var, g = ctx.saved_tensors
-        eps, relu, has_res = ctx.cfg
+        eps, relu, has_res, group, count = ctx.cfg
         M, C = x.shape
         dev = x.device
+        dy = dy.float().contiguous()
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        dgamma = torch.empty(C, device=dev, dtype=_F32)
-        dbeta = torch.empty(C, device=dev, dtype=_F32)
+        sums = torch.empty(2, C, device=dev, dtype=_F32)        # [dgamma | dbeta] of this rank's rows
         ws = workspace(dev)
-        call("coocc_bn_backward", ptr(x), ptr(y), ptr(dy.float().contiguous()), M, C, ptr(mean), ptr(var), ptr(g), eps, relu,
-             ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel() * 4)
-        return dx, dgamma, dbeta, dres, None, None
+        call("coocc_bn_backward_sums", ptr(x), ptr(y), ptr(dy), M, C, ptr(mean), ptr(var), eps, relu, ptr(sums[0]), ptr(sums[1]),
+             ptr(ws), ws.numel() * 4)
+        tot = sums
+        if group is not None:
+            import torch.distributed as dist
+            tot = sums.clone()
+            dist.all_reduce(tot, group=group)
+        call("coocc_bn_backward_dx", ptr(x), ptr(y), ptr(dy), M, C, ptr(mean), ptr(var), ptr(g), eps, relu, ptr(tot[0]), ptr(tot[1]),
+             float(count), ptr(dx), ptr(dres))
+        return dx, sums[0], sums[1], dres, None, None, None
 
 
-def conv3d_bn_train_rows(x2d, weight, geom, bn, stride=1, pad=None, relu=True, res2d=None, bias=None):
+def conv3d_bn_train_rows(x2d, weight, geom, bn, stride=1, pad=None, relu=True, res2d=None, bias=None, sync=None):
     """Training-mode Conv3d -> BatchNorm (batch statistics) (+res) -> ReLU on rows: the conv runs without epilogue,
     BatchNormRowsFn normalises.  Use conv3d_rows(bn=...) for frozen statistics."""
     y, g = conv3d_rows(x2d, weight, geom, bias=bias, bn=None, stride=stride, pad=pad, relu=False)
-    return BatchNormRowsFn.apply(y, bn.weight, bn.bias, res2d, bn, relu), g
+    return BatchNormRowsFn.apply(y, bn.weight, bn.bias, res2d, bn, relu, _sync_group(bn, sync)), g

@@ -817,7 +817,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx(const float* __restrict__ x, 
                                                     int M, int C, const float* __restrict__ mean, const float* __restrict__ var,
                                                     const float* __restrict__ gamma, float eps, int relu,
                                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                    float* __restrict__ dx, float* __restrict__ dres) {
+                                                    float count, float* __restrict__ dx, float* __restrict__ dres) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)M * C) return;
   const int c = (int)(i % C);
@@ -826,20 +826,41 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx(const float* __restrict__ x, 
   if (relu && !(y[i] > 0.f)) g = 0.f;
   if (dres) dres[i] = g;
   const float xh = (x[i] - mean[c]) * rstd;
-  dx[i] = gamma[c] * rstd * (g - dbeta[c] / (float)M - xh * dgamma[c] / (float)M);
+  dx[i] = gamma[c] * rstd * (g - dbeta[c] / count - xh * dgamma[c] / count);
+}
+
+// The backward in two halves, so that SyncBN can all-reduce the two per-channel sums between them:
+// sums: dgamma = sum dy' * xhat, dbeta = sum dy' over THIS rank's rows (dy' = dy * [y > 0] with ReLU);
+// dx  : from sums and a row count that may be those of the whole (cross-rank) batch.
+extern "C" int coocc_bn_backward_sums(const float* x, const float* y, const float* dy, int M, int C, const float* mean,
+                                      const float* var, float eps, int relu, float* dgamma, float* dbeta, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  COOCC_CHECK_ARG(x && y && dy && mean && var && dgamma && dbeta && M > 0 && C > 0, "bn_backward_sums: bad args");
+  const int nparts = (M + 255) / 256;
+  COOCC_CHECK_ARG(ws && ws_bytes >= sizeof(double) * 2 * (size_t)nparts * C, "bn_backward_sums: workspace too small");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(k_bn_bwd_part, dim3(nparts, cdiv(C, 256)), dim3(256), 0, s, x, y, dy, M, C, mean, var, eps, relu, (double*)ws);
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)ws, nparts, C, dgamma, dbeta);
+  COOCC_LAUNCH_CHECK("bn_backward_sums");
+  return COOCC_OK;
+}
+
+extern "C" int coocc_bn_backward_dx(const float* x, const float* y, const float* dy, int M, int C, const float* mean,
+                                    const float* var, const float* gamma, float eps, int relu, const float* sum_dgamma,
+                                    const float* sum_dbeta, double count, float* dx, float* dres, void* stream) {
+  COOCC_CHECK_ARG(x && y && dy && mean && var && gamma && sum_dgamma && sum_dbeta && dx && M > 0 && C > 0 && count >= 1.0,
+                  "bn_backward_dx: bad args");
+  hipLaunchKernelGGL(k_bn_bwd_dx, dim3(cdiv((long long)M * C, 256)), dim3(256), 0, as_stream(stream), x, y, dy, M, C, mean, var,
+                     gamma, eps, relu, sum_dgamma, sum_dbeta, (float)count, dx, dres);
+  COOCC_LAUNCH_CHECK("bn_backward_dx");
+  return COOCC_OK;
 }
 
 extern "C" int coocc_bn_backward(const float* x, const float* y, const float* dy, int M, int C, const float* mean, const float* var,
                                  const float* gamma, float eps, int relu, float* dx, float* dres, float* dgamma, float* dbeta,
                                  void* ws, size_t ws_bytes, void* stream) {
-  COOCC_CHECK_ARG(x && y && dy && mean && var && gamma && dx && dgamma && dbeta && M > 0 && C > 0, "bn_backward: bad args");
-  const int nparts = (M + 255) / 256;
-  COOCC_CHECK_ARG(ws && ws_bytes >= sizeof(double) * 2 * (size_t)nparts * C, "bn_backward: workspace too small");
-  hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(k_bn_bwd_part, dim3(nparts, cdiv(C, 256)), dim3(256), 0, s, x, y, dy, M, C, mean, var, eps, relu, (double*)ws);
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)ws, nparts, C, dgamma, dbeta);
-  hipLaunchKernelGGL(k_bn_bwd_dx, dim3(cdiv((long long)M * C, 256)), dim3(256), 0, s, x, y, dy, M, C, mean, var, gamma, eps, relu, dgamma,
-                     dbeta, dx, dres);
-  COOCC_LAUNCH_CHECK("bn_backward");
-  return COOCC_OK;
+  COOCC_CHECK_ARG(gamma && dx, "bn_backward: bad args");
+  int rc = coocc_bn_backward_sums(x, y, dy, M, C, mean, var, eps, relu, dgamma, dbeta, ws, ws_bytes, stream);
+  if (rc != COOCC_OK) return rc;
+  return coocc_bn_backward_dx(x, y, dy, M, C, mean, var, gamma, eps, relu, dgamma, dbeta, (double)M, dx, dres, stream);
 }

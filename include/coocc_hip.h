@@ -269,6 +269,15 @@ int coocc_bn_apply(const float* x, int M, int C, const float* mean, const float*
 int coocc_bn_backward(const float* x, const float* y, const float* dy, int M, int C, const float* mean, const float* var,
                       const float* gamma, float eps, int relu, float* dx, float* dres, float* dgamma, float* dbeta,
                       void* ws, size_t ws_bytes, void* stream);
+/* The same backward in two halves for SyncBN (torch.nn.SyncBatchNorm semantics): `sums` gives this rank's
+ * dgamma = sum dy'*xhat and dbeta = sum dy'; the caller all-reduces them; `dx` uses the reduced sums and the
+ * cross-rank row count.  mean / var are then the cross-rank batch statistics. */
+int coocc_bn_backward_sums(const float* x, const float* y, const float* dy, int M, int C, const float* mean,
+                           const float* var, float eps, int relu, float* dgamma, float* dbeta, void* ws,
+                           size_t ws_bytes, void* stream);
+int coocc_bn_backward_dx(const float* x, const float* y, const float* dy, int M, int C, const float* mean,
+                         const float* var, const float* gamma, float eps, int relu, const float* sum_dgamma,
+                         const float* sum_dbeta, double count, float* dx, float* dres, void* stream);
 
 /* FPN3D top-down step (fpn3d.py:88-92): fine += trilinear(coarse -> fine size),
  * align_corners=False.  Rows NDHWC with C channels. */

@@ -540,3 +540,13 @@ def test_conv_batchnorm_training_mode_vs_torch(dev):
     assert_close(_vol(rd.grad.cpu(), B, X, Y, Z), rr.grad, what="dres")
     assert_close(bn_d.weight.grad.cpu(), bn_r.weight.grad, what="dgamma")
     assert_close(bn_d.bias.grad.cpu(), bn_r.bias.grad, what="dbeta")
+
+
+def test_syncbn_two_ranks_one_gpu():
+    """SyncBN (norm_cfg type='SyncBN' upstream): batch statistics and the two backward sums all-reduced across ranks.
+    Two processes share the one GPU of the test box; gloo carries the collectives."""
+    import socket
+    import torch.multiprocessing as mp
+    import syncbn_worker
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(syncbn_worker.run, args=(2, port), nprocs=2, join=True)
