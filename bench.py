@@ -226,7 +226,7 @@ def main():
             if not k.startswith("k_conv"):
                 continue
             sym = k.split(" wino")[0] + (",wg> wino" if " wino" in k else "")
-            sym = sym.replace(">,wg>", ",wg>")
+            sym = sym.replace(">,wg>", ",wg>").replace("k_conv2p,wg>", "k_conv2p")
             c_ = convs.setdefault(sym, dict(launches=0, ms=0.0, work=0.0, equiv=0.0))
             c_["launches"] += v["launches"]; c_["ms"] += v["ms"]; c_["work"] += v["work"]
             c_["equiv"] += v["work"] * {"wino2": 2.25, "wino4": 4.0}.get(k.split()[-1], 1.0)

@@ -25,6 +25,7 @@ CONV_V2 = int(__import__("os").environ.get("COOCC_CONV_V2", "1"))       # mirror
 # weight bytes; the small deep layers are weight-bandwidth-bound and gain nothing)
 WINO = int(__import__("os").environ.get("COOCC_WINO", "1"))
 WINO_MIN_ROWS = int(__import__("os").environ.get("COOCC_WINO_MIN_ROWS", "8192"))
+CONV_PERSIST = __import__("os").environ.get("COOCC_CONV_PERSIST", "1") != "0"   # persistent short-K grouped GEMM (k_conv2p)
 ZTRIM = __import__("os").environ.get("COOCC_ZTRIM", "1") != "0"   # drop z taps that only see padding (Z = 1, 2 grids)
 WINO_TILE = int(__import__("os").environ.get("COOCC_WINO_TILE", "4"))   # F(4x4,3x3) where X, Y >= 8, else F(2x2,3x3)
 
@@ -263,7 +264,11 @@ def conv_rows_wino(x, pc, out, relu, res, plan):
     d.kx, d.ky, d.kz, d.px, d.py, d.pz = 1, 1, 3, 0, 0, 1
     d.wgroup_rows = G
     d.relu, d.res_mode, d.splitk, d.tile_hint = 0, 0, 1, (hint or TILE_HINT)
-    with TIMER.region(conv_kernel_name(pts * G, pc.Cout, False, hint, 3 * -(-pc.Cin // 32)) + " wino%d" % tile, 2.0 * pts * rows * pc.Cin * pc.Cout * 3):
+    kname = conv_kernel_name(pts * G, pc.Cout, False, hint, 3 * -(-pc.Cin // 32))
+    if (CONV_PERSIST and CONV_V2 and kname == "k_conv2<128>" and 3 * -(-pc.Cin // 32) <= 24
+            and (pts * G // 128) * -(-pc.Cout // 128) > 768):
+        kname = "k_conv2p"          # mirror of the dispatch in coocc_conv_fwd: persistent workgroups, >= 2 tiles each
+    with TIMER.region(kname + " wino%d" % tile, 2.0 * pts * rows * pc.Cin * pc.Cout * 3):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     with TIMER.region("k_wino_out", 4.0 * pts * rows * pc.Cout + 4.0 * x.V * pc.Cout):
         call("coocc_wino_output", ptr(Mb), G, x.B, x.X, x.Y, x.Z, pc.Cout, tile, out.data(), out.stride, ptr(pc.scale),

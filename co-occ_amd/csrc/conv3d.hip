@@ -429,6 +429,173 @@ __global__ __launch_bounds__(256, MINW) void k_conv2(ConvK p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_conv2p: persistent form of k_conv2<128, PF = 1, WG> for the Winograd-domain grouped GEMMs with short K (<= 24
+// K-chunks per tile; 12 launches per sample, the dominant kernel of the decoder).  With 12-24 chunks per tile the
+// per-tile prologue (first loads -> LDS -> barrier -> first fragments) and the workgroup launch weigh as much as a
+// few chunks.  Here a workgroup walks tiles id, id + gridDim.x, ...: on the LAST chunk of a tile the prefetch slot that
+// k_conv2 fills with dummy zeros takes chunk 0 of the NEXT tile, so that chunk's LDS store, barrier and first fragment
+// reads happen under the last MFMA group of the current tile exactly like any other chunk; only the epilogue stores
+// and the accumulator reset sit between two tiles.  Specialised to the geometry of those launches (rows = (tile, z),
+// taps = the 3 z neighbours: kx = ky = 1, Xi = Yi = 1, stride 1), which keeps the per-tile state to 8 VGPRs.
+__global__ __launch_bounds__(256, 3) void k_conv2p(ConvK p) {
+  constexpr int BM = 128, TM = BM / 32, PA = BM / 32;
+  __shared__ float As[2][BM * LDS_ST];
+  const int tid = threadIdx.x;
+  const int piece = tid & 7, lrow = tid >> 3;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, h = lane >> 5;
+  const int nslots = p.mtiles_per_xcd > 0 ? 8 * p.mtiles_per_xcd * p.ntiles : p.mtiles * p.ntiles;
+  auto decode = [&](int id, int& mtile, int& nt_) -> bool {
+    if (p.mtiles_per_xcd > 0) {
+      const int xcd = id & 7, slot = id >> 3;
+      const int mt_local = slot / p.ntiles;
+      nt_ = slot - mt_local * p.ntiles;
+      mtile = xcd * p.mtiles_per_xcd + mt_local;
+      return mt_local < p.mtiles_per_xcd && mtile < p.mtiles;
+    }
+    mtile = id / p.ntiles;
+    nt_ = id - mtile * p.ntiles;
+    return true;
+  };
+
+  // state of the tile being LOADED: z of tap 0 per row (parked far outside for rows past M) and its input row
+  int cz[PA], rrow[PA];
+  __amdgpu_buffer_rsrc_t rs_w, rs_in;
+  int m0 = 0, n0 = 0, nt = 0;
+  int lc = 0, lkc = 0, lkw = 0;
+  auto setup = [&](int mtile, int nt_) {
+    m0 = mtile * BM; n0 = nt_ * 128; nt = nt_;
+    const float* wbase = p.w + (size_t)(m0 / p.wgroup_rows) * p.wgroup_floats;
+    rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, p.w_bytes, 0x00020000);
+    const int row0 = max(m0 - p.pz, 0);
+#pragma unroll
+    for (int a = 0; a < PA; ++a) {
+      const int m = m0 + lrow + 32 * a;
+      cz[a] = m < p.M ? m % p.Zi - p.pz : -4096;
+      rrow[a] = m - p.pz - row0;
+    }
+    const size_t base_off = (size_t)row0 * p.in_stride * 4;
+    const size_t remain = p.in_bytes > base_off ? p.in_bytes - base_off : 0;
+    rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.in + base_off), 0,
+                                              (unsigned)(remain < 0xFFFFFF00ull ? remain : 0xFFFFFF00ull), 0x00020000);
+    lc = 0; lkc = 0; lkw = 0;
+  };
+  const unsigned voffB = (unsigned)(lane * 16);
+  const int ngroups = p.Npad >> 7;
+
+  f32x4 rq[PA], bq[4], bcur[4];
+  auto issue_loads = [&](bool live) {
+    const unsigned soff = (unsigned)(((((size_t)lc * ngroups + nt) * 4 + wn) * 1024) * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = buf_load4(rs_w, live ? voffB + q * 1024u : 0xFFFFFFF0u, soff);
+    const int cc = lkc * KC + piece * 4;
+    const bool cok = live & (cc < p.Cin);
+#pragma unroll
+    for (int a = 0; a < PA; ++a) {
+      const bool ok = cok & ((unsigned)(cz[a] + lkw) < (unsigned)p.Zi);
+      unsigned voff = ok ? (unsigned)((rrow[a] + lkw) * p.in_stride + cc) * 4u : 0xFFFFFFF0u;
+      rq[a] = buf_load4(rs_in, voff, 0);
+    }
+    lc += 1; lkw += 1;                           // z taps innermost, then the next channel chunk
+    const int w2 = lkw == p.kz;
+    lkw = w2 ? 0 : lkw; lkc += w2;
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int a = 0; a < PA; ++a) *(f32x4*)&As[buf][(lrow + 32 * a) * LDS_ST + piece * 4] = rq[a];
+  };
+  f32x16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  f32x4 fa[2][TM];
+  auto lfrag = [&](int buf, int q, int slot_) {
+    const float* Ab = &As[buf][li * LDS_ST + h * 4 + q * 8];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[slot_][i] = *(const f32x4*)(Ab + i * 32 * LDS_ST);
+  };
+  auto mma = [&](int slot_, int q) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot_][i][s], bcur[q][s], acc[i], 0, 0, 0);
+  };
+  int cur = 0;
+  auto chunk_tail = [&]() {          // everything of a chunk after its prefetch has been issued
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, 0);
+    lfrag(cur, 2, 0);
+    mma(1, 1);
+    lfrag(cur, 3, 1);
+    mma(0, 2);
+    lstore(cur ^ 1);
+    __syncthreads();
+    lfrag(cur ^ 1, 0, 0);
+    mma(1, 3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bcur[q] = bq[q];
+    cur ^= 1;
+  };
+
+  int id = blockIdx.x, mtile, ntl;
+  while (id < nslots && !decode(id, mtile, ntl)) id += gridDim.x;
+  if (id >= nslots) return;
+  setup(mtile, ntl);
+  int m0c = m0, n0c = n0;            // tile being COMPUTED
+  issue_loads(true);
+  lstore(0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bcur[q] = bq[q];
+  __syncthreads();
+  lfrag(0, 0, 0);
+  const int iters = p.total_iters;
+  for (;;) {
+    int nid = id + gridDim.x, nmt = 0, nnt = 0;
+    while (nid < nslots && !decode(nid, nmt, nnt)) nid += gridDim.x;
+    const bool has_next = nid < nslots;
+    for (int it = 0; it + 1 < iters; ++it) {
+      lfrag(cur, 1, 1);
+      issue_loads(true);
+      chunk_tail();
+    }
+    // last chunk of this tile: the prefetch slot takes chunk 0 of the next tile (or dummy zeros at the very end)
+    lfrag(cur, 1, 1);
+    if (has_next) setup(nmt, nnt);
+    issue_loads(has_next);
+    chunk_tail();
+
+    // Winograd-domain products: no scale / bias / residual / ReLU here (they are applied by the output transform)
+    // buffer stores based at the tile's first row: rows past M fall outside num_records and are dropped by the
+    // hardware; one running 32-bit offset per lane (row steps +1,+1,+1,+5 in D-register order) instead of 64 addresses
+    {
+      const int rows_left = min(p.M - m0c, BM);
+      const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.out + (size_t)m0c * p.out_stride), 0, (unsigned)rows_left * (unsigned)p.out_stride * 4u, 0x00020000);
+      const int col = n0c + wn * 32 + li;
+      const unsigned s1 = (unsigned)p.out_stride * 4u, s5 = 5u * s1;
+      unsigned voff = (unsigned)(4 * h * p.out_stride + col) * 4u;
+      if (col < p.Cout) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][r]), rs_o, (int)voff, 0, 0);
+            voff += (r & 3) == 3 ? s5 : s1;
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    }
+    if (!has_next) break;
+    id = nid; m0c = m0; n0c = n0;
+  }
+}
+
 // split-K second pass: sum the partial slabs in a fixed order, then the epilogue
 __global__ __launch_bounds__(256) void k_conv_reduce(ConvK p) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -559,12 +726,22 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
     k.ntiles = (k.Cout + 127) / 128;
     k.mtiles_per_xcd = k.mtiles >= 64 ? (k.mtiles + 7) / 8 : 0;
     dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
+    // persistent short-K variant: 3 workgroups per CU resident, every workgroup the same number of tiles
+    static const int persist_env = getenv("COOCC_CONV_PERSIST") ? atoi(getenv("COOCC_CONV_PERSIST")) : 1;
+    const unsigned nslots = grid.x;
+    const unsigned per_wg = (nslots + 767) / 768;
+    const unsigned pg = ((nslots + per_wg - 1) / per_wg + 7) / 8 * 8;
+    const dim3 pgrid(persist_env == 2 ? nslots : (pg < nslots ? pg : nslots), 1);   // 2: debugging (one tile per workgroup, every size)
+    // k_conv2p's contract: grouped launch, rows = (tile, z) with the z taps only, bare products out
+    const bool persist = persist_env && splitk == 1 && (per_wg >= 2 || persist_env == 2) && k.wgroup_rows > 0 && k.kx == 1 && k.ky == 1 && k.Xi == 1 &&
+                         k.Yi == 1 && k.stride == 1 && !k.scale && !k.bias && !k.res && !k.relu && !k.out_rows && k.res_mode == 0;
     static const int pf160 = getenv("COOCC_CONV_PF160") ? atoi(getenv("COOCC_CONV_PF160")) : 2;
     static const int pf128 = getenv("COOCC_CONV_PF128") ? atoi(getenv("COOCC_CONV_PF128")) : 3;
     if (k.wgroup_rows > 0) {
       if (cfg == 4) hipLaunchKernelGGL((k_conv2<160, 2, true>), grid, dim3(256), 0, s, k);
       // short K (3*Cin/32 <= 24 chunks per tile): the per-tile prologue/epilogue weighs as much as the loop, so
       // trade prefetch depth for occupancy -- PF = 1 fits 168 VGPRs = 3 workgroups per CU (0.179 -> 0.158 ms)
+      else if (short_k && persist) hipLaunchKernelGGL(k_conv2p, pgrid, dim3(256), 0, s, k);
       else if (short_k) hipLaunchKernelGGL((k_conv2<128, 1, true, 3>), grid, dim3(256), 0, s, k);
       else hipLaunchKernelGGL((k_conv2<128, 3, true>), grid, dim3(256), 0, s, k);
     }

@@ -232,6 +232,33 @@ def test_conv3d_winograd_path(dev, monkeypatch, Cin, Cout, grid, B, relu, use_re
     assert_close(out.as_ncdhw().cpu(), direct.as_ncdhw().cpu(), what="winograd vs direct")
 
 
+@pytest.mark.parametrize("Cin,Cout,grid,tile", [(64, 160, (96, 90, 8), 2), (128, 128, (100, 100, 8), 4), (32, 128, (90, 93, 5), 4)])
+def test_conv3d_winograd_persistent_kernel(dev, monkeypatch, Cin, Cout, grid, tile):
+    """Full-size Winograd layers: short K and more than 768 GEMM tiles, i.e. the launches that take the persistent
+    k_conv2p kernel (every workgroup walks several tiles; chunk 0 of the next tile rides in the last prefetch slot).
+    Checked against our direct path (itself checked against torch at the smaller sizes above) and, for one case,
+    against torch's fp32 conv."""
+    g = torch.Generator().manual_seed(Cin + Cout)
+    X, Y, Z = grid
+    x = torch.randn(1, Cin, X, Y, Z, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (2.0 / (Cin * 27)) ** 0.5
+    bn = bn_like(Cout, g)
+    ref = F.relu(bn(F.conv3d(x, w, padding=1))).detach() if Cin == 32 else None
+    pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=3, stride=1, pad=1)
+    monkeypatch.setattr(core, "WINO_TILE", tile)
+    monkeypatch.setattr(core, "WINO", 1)
+    xr = rows_of(x, dev)
+    plan = core.wino_plan(xr, pc, X * Y * Z, 0)
+    assert plan is not None and plan[0] == tile
+    assert (plan[1] * plan[5] // 128) * -(-Cout // 128) > 768 and 3 * -(-Cin // 32) <= 24     # the k_conv2p dispatch rule
+    out = core.conv_rows(xr, pc, relu=True)
+    monkeypatch.setattr(core, "WINO", 0)
+    direct = core.conv_rows(xr, pc, relu=True)
+    assert_close(out.as_ncdhw().cpu(), direct.as_ncdhw().cpu(), what="persistent winograd GEMM vs direct")
+    if ref is not None:
+        assert_close(out.as_ncdhw().cpu(), ref, what="persistent winograd GEMM vs torch")
+
+
 def test_conv_anisotropic_taps_and_weight_groups(dev):
     """coocc_conv_desc kx/ky/kz + wgroup_rows: a (1,1,3) conv along z with a different weight set per row group."""
     import ctypes
