@@ -682,6 +682,7 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
     if (d->tile_hint == 160 || (d->tile_hint == 0 && util(160) > util(128) * 1.02)) cfg = 4;
   }
   const bool short_k = k.total_iters <= 24;
+  static const int persist_env = getenv("COOCC_CONV_PERSIST") ? atoi(getenv("COOCC_CONV_PERSIST")) : 1;
   if (short_k && cfg == 4 && d->tile_hint != 160 && !(d->wgroup_rows > 0 && d->wgroup_rows % 128 != 0)) cfg = 0;   // 128-row tiles, 3 per CU
   // mid-size layers (512 <= M < 8192) also run the pipelined kernel with 128-row tiles + split-K;
   // below that the 64-row tile wastes fewer padded rows (M = 169 at the deepest stage)
@@ -727,7 +728,6 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
     k.mtiles_per_xcd = k.mtiles >= 64 ? (k.mtiles + 7) / 8 : 0;
     dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
     // persistent short-K variant: 3 workgroups per CU resident, every workgroup the same number of tiles
-    static const int persist_env = getenv("COOCC_CONV_PERSIST") ? atoi(getenv("COOCC_CONV_PERSIST")) : 1;
     const unsigned nslots = grid.x;
     const unsigned per_wg = (nslots + 767) / 768;
     const unsigned pg = ((nslots + per_wg - 1) / per_wg + 7) / 8 * 8;
