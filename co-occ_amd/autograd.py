@@ -39,6 +39,19 @@ def tap_table(dev, B, Xi, Yi, Zi, ksize, stride, pad, dgrad):
     return _tables[key]
 
 
+_live = {}
+
+
+def live_taps(dev, B, Xi, Yi, Zi, ksize, stride, pad):
+    """(indices of the taps that read at least one real voxel, their rows of the forward table), cached per geometry."""
+    key = (dev.index, B, Xi, Yi, Zi, ksize, stride, pad)
+    if key not in _live:
+        tb = tap_table(dev, B, Xi, Yi, Zi, ksize, stride, pad, False)
+        idx = torch.nonzero((tb >= 0).any(1)).flatten()
+        _live[key] = (idx, tb[idx].contiguous())
+    return _live[key]
+
+
 _classes = {}
 
 
@@ -158,8 +171,14 @@ def _wino_wgrad(x2d, dacc, geom, Cin, Cout, dw):
     return True
 
 
+def _zrange(Zin, Zout, stride, pad):
+    """First / last z tap of a 3-tap axis that reads a real voxel for at least one output (thin grids: Z = 1, 2)."""
+    ok = [kz for kz in range(3) if any(0 <= zo * stride - pad + kz < Zin for zo in range(Zout))]
+    return ok[0], ok[-1]
+
+
 def _conv_launch(x2d, in_C, w_packed, out2d, Cout, taps, geom_in, geom_out, ksize, stride, pad, scale, shift, res2d, relu,
-                 table=None, tag="conv_fwd", out_rows=None):
+                 table=None, tag="conv_fwd", out_rows=None, kdims=None):
     d = ConvDesc()
     ws = workspace(x2d.device)
     d.in_, d.w, d.out = ptr(x2d), ptr(w_packed), ptr(out2d)
@@ -175,6 +194,8 @@ def _conv_launch(x2d, in_C, w_packed, out2d, Cout, taps, geom_in, geom_out, ksiz
     _, Xo, Yo, Zo = geom_out
     d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = B, Xi, Yi, Zi, Xo, Yo, Zo
     d.ksize, d.stride, d.pad = ksize, stride, pad
+    if kdims is not None:
+        d.kx, d.ky, d.kz, d.px, d.py, d.pz = kdims
     d.relu, d.res_mode, d.splitk = int(relu), (1 if res2d is not None else 0), 0
     d.tile_hint = TILE_HINT
     with _lib.TIMER.region(tag, 2.0 * d.M * in_C * Cout * taps):
@@ -201,8 +222,14 @@ class ConvRowsFn(torch.autograd.Function):
         w_ = weight.detach().float().contiguous()
         if not (ksize == 3 and stride == 1 and pad == 1 and
                 _wino_train(x2d, geom, w_.view(Cout, Cin, 3, 3, 3), False, out, scale, eff_shift, res2d, relu)):
-            wp = pack_weights_dev(w_.reshape(Cout, Cin, taps), Cout, Cin, taps, 0)
-            _conv_launch(x2d, Cin, wp, out, Cout, taps, geom, geom_out, ksize, stride, pad, scale, eff_shift, res2d, relu)
+            kd, wsub, nt = None, w_.reshape(Cout, Cin, taps), taps
+            if ksize == 3:
+                lo, hi = _zrange(Zi, Zo, stride, pad)
+                if hi - lo < 2:         # z taps that only read padding are dropped (exact)
+                    wsub = w_.view(Cout, Cin, 3, 3, 3)[..., lo:hi + 1].contiguous().view(Cout, Cin, -1)
+                    nt, kd = wsub.shape[2], (3, 3, hi - lo + 1, pad, pad, pad - lo)
+            wp = pack_weights_dev(wsub, Cout, Cin, nt, 0)
+            _conv_launch(x2d, Cin, wp, out, Cout, nt, geom, geom_out, ksize, stride, pad, scale, eff_shift, res2d, relu, kdims=kd)
         ctx.save_for_backward(x2d, weight, out, scale if scale is not None else torch.empty(0, device=x2d.device))
         ctx.cfg = (geom, geom_out, ksize, stride, pad, relu, bias is not None, res2d is not None, scale is not None)
         return out
@@ -237,9 +264,15 @@ class ConvRowsFn(torch.autograd.Function):
                                 None, False)):
                 pass
             elif stride == 1:
-                wp = pack_weights_dev(w3, Cout, Cin, taps, 2)
-                _conv_launch(dacc, Cp, wp, dx, Cin, taps, geom_out, geom, ksize, 1, ksize - 1 - pad, None, None, None, False,
-                             tag="conv_dgrad")
+                kd, wsub, nt, pd = None, w3, taps, ksize - 1 - pad
+                if ksize == 3:
+                    lo, hi = _zrange(geom_out[3], Zi, 1, pd)        # z taps of the flipped kernel that see real dy voxels
+                    if hi - lo < 2:
+                        wsub = weight.detach().float().view(Cout, Cin, 3, 3, 3)[..., 2 - hi:2 - lo + 1].contiguous().view(Cout, Cin, -1)
+                        nt, kd = wsub.shape[2], (3, 3, hi - lo + 1, pd, pd, pd - lo)
+                wp = pack_weights_dev(wsub, Cout, Cin, nt, 2)
+                _conv_launch(dacc, Cp, wp, dx, Cin, nt, geom_out, geom, ksize, 1, pd, None, None, None, False,
+                             tag="conv_dgrad", kdims=kd)
             else:
                 dx.zero_()          # voxels no output reads (and classes without taps) get a zero gradient
                 for rows_c, taps_c, table_c in dgrad_classes(dev, B, Xi, Yi, Zi, ksize, stride, pad):
@@ -250,9 +283,20 @@ class ConvRowsFn(torch.autograd.Function):
             dw = torch.empty(Cout, Cin, taps, device=dev, dtype=_F32)
             if not (ksize == 3 and stride == 1 and pad == 1 and Cp == Cout and _wino_wgrad(x2d, dacc, geom, Cin, Cout, dw)):
                 tb = tap_table(dev, B, Xi, Yi, Zi, ksize, stride, pad, False) if (taps > 1 or stride > 1) else None
-                with _lib.TIMER.region("k_wgrad", 2.0 * Mo * Cin * Cout * taps):
-                    call("coocc_conv_wgrad", ptr(x2d), Mi, Cin, ptr(dacc), Cp, ptr(tb), Mo, Cin, Cout, taps, ptr(dw), 0, ptr(ws),
-                         ws.numel())
+                live = live_taps(dev, B, Xi, Yi, Zi, ksize, stride, pad) if tb is not None else None
+                if live is not None and live[0].numel() < taps:
+                    # thin grids (Z = 1, 2): taps that only ever read padding have a zero gradient -- skip their GEMMs
+                    idx, tb_live = live
+                    dw_live = torch.empty(Cout, Cin, idx.numel(), device=dev, dtype=_F32)
+                    with _lib.TIMER.region("k_wgrad", 2.0 * Mo * Cin * Cout * idx.numel()):
+                        call("coocc_conv_wgrad", ptr(x2d), Mi, Cin, ptr(dacc), Cp, ptr(tb_live), Mo, Cin, Cout, idx.numel(),
+                             ptr(dw_live), 0, ptr(ws), ws.numel())
+                    dw.zero_()
+                    dw.index_copy_(2, idx, dw_live)
+                else:
+                    with _lib.TIMER.region("k_wgrad", 2.0 * Mo * Cin * Cout * taps):
+                        call("coocc_conv_wgrad", ptr(x2d), Mi, Cin, ptr(dacc), Cp, ptr(tb), Mo, Cin, Cout, taps, ptr(dw), 0, ptr(ws),
+                             ws.numel())
             dw = dw.view_as(weight)
         return dx, dw, dbias, dres, None, None, None, None, None, None, None
 

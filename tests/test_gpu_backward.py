@@ -29,6 +29,9 @@ CONV_CASES = [
     (64, 17, (4, 4, 2), 1, 1, False, True, False, False),      # class logits: Cout % 4 != 0
     (132, 136, (9, 8, 4), 3, 1, True, True, True, True),       # crosses the 128-wide tiles
     (32, 160, (10, 9, 3), 3, 2, False, False, False, True),
+    (16, 24, (7, 6, 1), 3, 1, True, False, True, True),        # Z = 1: only the centre z tap is live (fwd, dgrad, wgrad)
+    (16, 24, (7, 6, 2), 3, 2, True, False, False, True),       # Z = 2 -> 1: z taps 1..2 live
+    (20, 12, (5, 6, 2), 3, 1, False, True, False, False),      # Z = 2, stride 1: all taps live
 ]
 
 
@@ -53,7 +56,7 @@ def test_conv_backward_winograd_training_path(dev, case, monkeypatch):
     assert len(seen) == 2 and seen[0] == (4 if min(case[2][:2]) >= 8 else 2), seen      # forward + dgrad
 
 
-@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "c%d-%d_k%d_s%d" % (c[0], c[1], c[3], c[4]))
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "c%d-%d_k%d_s%d_z%d" % (c[0], c[1], c[3], c[4], c[2][2]))
 def test_conv_backward_vs_torch_autograd(dev, case):
     _run_conv_case(dev, case)
 
