@@ -53,6 +53,7 @@ SIGNATURES = {
     "coocc_argmax_flags": (I, [P, I, I, I, I, P, P]),
     "coocc_fine_sample_voxel": (I, [P, I, I, I, I, P, I, I, P, P, P, I, P]),
     "coocc_fine_sample_img": (I, [P, I, I, I, I, P, P, L, P, I, I, P]),
+    "coocc_fine_mlp_pre": (I, [P, I, P, I, L, P, P, P, F, P, P, P, P, F, P, P, I, P, P]),
     "coocc_fine_mlp": (I, [P, I, P, I, L, P, P, P, P, F, P, P, P, P, F, P, P, I, P, P]),
     "coocc_groupnorm_rows": (I, [P, L, I, I, I, P, P, F, I, P]),
     "coocc_groupnorm_nhwc": (I, [P, I, I, I, I, P, P, F, I, P]),

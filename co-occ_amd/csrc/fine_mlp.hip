@@ -87,6 +87,7 @@ __device__ __forceinline__ void bias_gn_relu(f32x16& v, const float* __restrict_
   __builtin_amdgcn_sched_barrier(0);
 }
 
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void k_fine_mlp(FineMlp p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int li = lane & 31, h = lane >> 5;
@@ -111,23 +112,49 @@ __global__ __launch_bounds__(256, 2) void k_fine_mlp(FineMlp p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
-  // ---- img_mlp: Linear(128 -> 64) + GN + ReLU
-  seg_mem(acc, rwi, (unsigned)(li * 128 + 4 * h) * 4u, (unsigned)((32 + li) * 128 + 4 * h) * 4u, rs,
-          (unsigned)(li * p.samp_stride + 4 * h) * 4u, (unsigned)((32 + li) * p.samp_stride + 4 * h) * 4u, 16);
+  // D-layout load of a 64-channel row block: register 4g+s of tile j <-> channel 32j + 8g + 4h + s of the lane's point
+  auto load_rows64 = [&](f32x16 (&dst)[2][2], __amdgpu_buffer_rsrc_t r, int stride) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      bias_gn_relu(acc[i][t], p.b_img, p.g_img, p.be_img, p.eps_img, 32 * i + 4 * h);
-      y[i][t] = acc[i][t];
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
-    }
-
-  // ---- fine_mlp[0]: Linear(192 -> 64) over cat[voxel sample (128), y1 (64)] + GN + ReLU
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = bl4(r, (unsigned)((32 * t + li) * stride + 32 * j + 8 * g + 4 * h) * 4u);
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_) dst[j][t][4 * g + s_] = v[s_];
+        }
+  };
   const unsigned w0a = (unsigned)(li * 192 + 4 * h) * 4u, w0b = (unsigned)((32 + li) * 192 + 4 * h) * 4u;
-  seg_mem(acc, rw0, w0a, w0b, rv, (unsigned)(li * p.vox_stride + 4 * h) * 4u,
-          (unsigned)((32 + li) * p.vox_stride + 4 * h) * 4u, 16);
+  if (PRE) {
+    // both Linear layers that precede a resampling were applied BEFORE it (they commute with the interpolation):
+    // samp = bilinear sample of W_img . img features, vox = trilinear sample of W_f0[:, :128] . voxel features
+    load_rows64(acc, rs, p.samp_stride);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bias_gn_relu(acc[i][t], p.b_img, p.g_img, p.be_img, p.eps_img, 32 * i + 4 * h);
+        y[i][t] = acc[i][t];
+      }
+    load_rows64(acc, rv, p.vox_stride);          // the accumulators of fine_mlp[0] start from the voxel term
+  } else {
+    // ---- img_mlp: Linear(128 -> 64) + GN + ReLU
+    seg_mem(acc, rwi, (unsigned)(li * 128 + 4 * h) * 4u, (unsigned)((32 + li) * 128 + 4 * h) * 4u, rs,
+            (unsigned)(li * p.samp_stride + 4 * h) * 4u, (unsigned)((32 + li) * p.samp_stride + 4 * h) * 4u, 16);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bias_gn_relu(acc[i][t], p.b_img, p.g_img, p.be_img, p.eps_img, 32 * i + 4 * h);
+        y[i][t] = acc[i][t];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+      }
+    // ---- fine_mlp[0]: Linear(192 -> 64) over cat[voxel sample (128), y1 (64)] + GN + ReLU
+    seg_mem(acc, rw0, w0a, w0b, rv, (unsigned)(li * p.vox_stride + 4 * h) * 4u,
+            (unsigned)((32 + li) * p.vox_stride + 4 * h) * 4u, 16);
+  }
   {
     f32x4 an0 = bl4(rw0, w0a + 128u * 4u), an1 = bl4(rw0, w0b + 128u * 4u);
 #pragma unroll
@@ -212,7 +239,31 @@ extern "C" int coocc_fine_mlp(const float* samp, int samp_stride, const float* v
   p.w_f3 = w_f3; p.b_f3 = b_f3;
   p.nf = nfine; p.samp_stride = samp_stride; p.vox_stride = vox_stride; p.ncls = ncls;
   p.eps_img = eps_img; p.eps_f0 = eps_f0;
-  hipLaunchKernelGGL(k_fine_mlp, dim3(cdiv(nfine, 256)), dim3(256), 0, as_stream(stream), p);
+  hipLaunchKernelGGL(k_fine_mlp<false>, dim3(cdiv(nfine, 256)), dim3(256), 0, as_stream(stream), p);
   COOCC_LAUNCH_CHECK("k_fine_mlp");
+  return COOCC_OK;
+}
+
+extern "C" int coocc_fine_mlp_pre(const float* samp64, int samp_stride, const float* vox64, int vox_stride, int64_t nfine,
+                                  const float* b_img, const float* gn_img_w, const float* gn_img_b, float eps_img,
+                                  const float* w_f0, const float* b_f0, const float* gn_f0_w, const float* gn_f0_b,
+                                  float eps_f0, const float* w_f3, const float* b_f3, int ncls, float* out, void* stream) {
+  COOCC_CHECK_ARG(samp64 && vox64 && out && b_img && gn_img_w && gn_img_b && w_f0 && b_f0 && gn_f0_w && gn_f0_b && w_f3 && b_f3,
+                  "fine_mlp_pre: null pointer");
+  COOCC_CHECK_ARG(nfine >= 0 && ncls >= 1 && ncls <= 32 && samp_stride >= 64 && vox_stride >= 64 && samp_stride % 4 == 0 &&
+                      vox_stride % 4 == 0 && samp_stride <= (1 << 20) && vox_stride <= (1 << 20), "fine_mlp_pre: bad args");
+  COOCC_CHECK_ARG(((uintptr_t)samp64 | (uintptr_t)vox64 | (uintptr_t)w_f0 | (uintptr_t)w_f3 | (uintptr_t)b_img | (uintptr_t)b_f0 |
+                   (uintptr_t)gn_img_w | (uintptr_t)gn_img_b | (uintptr_t)gn_f0_w | (uintptr_t)gn_f0_b) % 16 == 0,
+                  "fine_mlp_pre: arrays must be 16-byte aligned");
+  if (nfine == 0) return COOCC_OK;
+  FineMlp p;
+  p.samp = samp64; p.vox = vox64; p.out = out;
+  p.w_img = nullptr; p.b_img = b_img; p.g_img = gn_img_w; p.be_img = gn_img_b;
+  p.w_f0 = w_f0; p.b_f0 = b_f0; p.g_f0 = gn_f0_w; p.be_f0 = gn_f0_b;
+  p.w_f3 = w_f3; p.b_f3 = b_f3;
+  p.nf = nfine; p.samp_stride = samp_stride; p.vox_stride = vox_stride; p.ncls = ncls;
+  p.eps_img = eps_img; p.eps_f0 = eps_f0;
+  hipLaunchKernelGGL(k_fine_mlp<true>, dim3(cdiv(nfine, 256)), dim3(256), 0, as_stream(stream), p);
+  COOCC_LAUNCH_CHECK("k_fine_mlp<pre>");
   return COOCC_OK;
 }

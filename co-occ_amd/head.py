@@ -16,6 +16,9 @@ from .registry import HEADS
 _I32, _F32, _I64 = torch.int32, torch.float32, torch.int64
 # fine branch: the three Linear layers and two GroupNorms in one launch (coocc_fine_mlp); 0 = layer-by-layer path
 FUSED_FINE_MLP = __import__("os").environ.get("COOCC_FUSED_FINE_MLP", "1") != "0"
+# ... and the two Linear layers that precede a resampling applied before it, on the (much smaller) source grids
+# (coocc_fine_mlp_pre); 0 = sample the 128-channel sources as the reference does
+FINE_LINEAR_FIRST = __import__("os").environ.get("COOCC_FINE_LINEAR_FIRST", "1") != "0"
 
 
 def _conv3d(conv_cfg, cin, cout, k, pad):
@@ -90,6 +93,9 @@ class OccHead(nn.Module):
             if hasattr(self, "img_mlp"):
                 d["img0"] = PackedConv(self.img_mlp_0[0].weight.flatten(1), bias=self.img_mlp_0[0].bias)
                 d["img"] = PackedConv(self.img_mlp[0].weight, bias=self.img_mlp[0].bias)
+                if self.sample_from_voxel and self.fine_mlp[0].weight.shape[1] == 192:
+                    d["img_nb"] = PackedConv(self.img_mlp[0].weight)                                  # bias added after sampling
+                    d["f0_vox_nb"] = PackedConv(self.fine_mlp[0].weight[:, :128].contiguous())
             return d
         return self._packs.get(srcs, build)
 
@@ -152,6 +158,24 @@ class OccHead(nn.Module):
         fused = (FUSED_FINE_MLP and use_img and self.sample_from_voxel and ovf.C == 128 and g.shape[1] == 128
                  and self.out_channel <= 32 and self.img_mlp[1].num_groups == 16 and self.fine_mlp[1].num_groups == 16
                  and all(q.data_ptr() % 16 == 0 for m in (self.img_mlp, self.fine_mlp) for q in m.parameters()))
+        if fused and FINE_LINEAR_FIRST and "img_nb" in p:
+            # Linear(128->64) of img_mlp on the 6 x Hf x Wf feature map and the voxel half of fine_mlp[0] on the V coarse
+            # voxels instead of on the 8 V fine points: a Linear commutes with the interpolation that follows it
+            P = linear_rows(g, p["img_nb"])
+            Q = linear_rows(ovf.t, p["f0_vox_nb"], in_coff=ovf.coff, in_C=128)
+            vq = torch.empty(nf, 64, device=dev, dtype=_F32)
+            call("coocc_fine_sample_voxel", ptr(Q), 64, ovf.X, ovf.Y, ovf.Z, ptr(lin), n, r,
+                 host_i32(self.final_occ_size), ptr(fine_xyz), ptr(vq), 64)
+            samp = torch.empty(nf, 64, device=dev, dtype=_F32)
+            call("coocc_fine_sample_img", ptr(P), N_i, 64, Hf, Wf, ptr(params), ptr(fine_xyz), nf, ptr(samp), 64, 1 if r == 2 else 0)
+            li, gi, l0, g0, l3 = self.img_mlp[0], self.img_mlp[1], self.fine_mlp[0], self.fine_mlp[1], self.fine_mlp[3]
+            logits = torch.empty(nf, self.out_channel, device=dev, dtype=_F32)
+            d = lambda t: ptr(t.detach())
+            with TIMER.region("k_fine_mlp<pre>", 2.0 * nf * 64 * (64 + self.out_channel)):
+                call("coocc_fine_mlp_pre", ptr(samp), 64, ptr(vq), 64, nf, d(li.bias), d(gi.weight), d(gi.bias), float(gi.eps),
+                     d(l0.weight), d(l0.bias), d(g0.weight), d(g0.bias), float(g0.eps), d(l3.weight), d(l3.bias),
+                     self.out_channel, ptr(logits))
+            return logits, fine_xyz
         cat = torch.empty(nf, cvox if fused else cvox + (64 if use_img else 0), device=dev, dtype=_F32)
         vox_feat = cat if self.sample_from_voxel else torch.empty(nf, ovf.C, device=dev, dtype=_F32)
         # fine coordinates are always produced by this kernel (they are an output of the head)

@@ -325,6 +325,16 @@ int coocc_fine_mlp(const float* samp, int samp_stride, const float* vox, int vox
                    float eps_img, const float* w_f0, const float* b_f0, const float* gn_f0_w,
                    const float* gn_f0_b, float eps_f0, const float* w_f3, const float* b_f3, int ncls,
                    float* out, void* stream);
+/* Same chain with the two Linear layers that precede a resampling applied BEFORE it (a Linear commutes with the bi- /
+ * trilinear interpolation; biases stay after it): samp64:[nfine, >=64] = coocc_fine_sample_img of (img features . w_img^T),
+ * vox64:[nfine, >=64] = coocc_fine_sample_voxel of (voxel features . w_f0[:, :128]^T).  Then
+ *   y1 = ReLU(GN16(samp64 + b_img));  h = ReLU(GN16(vox64 + y1 . w_f0[:, 128:192]^T + b_f0));  out = h . w_f3^T + b_f3.
+ * w_f0 is still the whole [64,192] matrix (only its last 64 columns are read).  Half the sampling traffic and a quarter of
+ * the per-point multiplies of coocc_fine_mlp; results differ from it by fp32 rounding only. */
+int coocc_fine_mlp_pre(const float* samp64, int samp_stride, const float* vox64, int vox_stride, int64_t nfine,
+                       const float* b_img, const float* gn_img_w, const float* gn_img_b, float eps_img,
+                       const float* w_f0, const float* b_f0, const float* gn_f0_w, const float* gn_f0_b,
+                       float eps_f0, const float* w_f3, const float* b_f3, int ncls, float* out, void* stream);
 /* nn.GroupNorm on 2-D rows [n,C] (+ReLU), in place (occ_head.py:70-83) */
 int coocc_groupnorm_rows(float* x, int64_t n, int C, int stride, int groups, const float* gamma,
                          const float* beta, float eps, int relu, void* stream);

@@ -471,11 +471,15 @@ def test_fine_mlp_fused_equals_layerwise(dev, monkeypatch):
     outs = []
     with torch.no_grad():
         sem = neck(enc(x.to(dev)))
-        for fused in (True, False):
+        for fused, first in ((True, False), (False, False), (True, True)):
             monkeypatch.setattr(H, "FUSED_FINE_MLP", fused)
+            monkeypatch.setattr(H, "FINE_LINEAR_FIRST", first)
             outs.append(head(voxel_feats=sem, img_feats=[img_feats[0].to(dev)], transform=tr)["output_voxels_fine"][0].clone())
-    assert outs[0].shape == outs[1].shape and outs[0].shape[0] > 0
-    assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * max(1.0, float(outs[1].abs().max()))
+    assert outs[0].shape == outs[1].shape == outs[2].shape and outs[0].shape[0] > 0
+    sc = max(1.0, float(outs[1].abs().max()))
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * sc
+    # production form: Linear layers applied before the resampling (coocc_fine_mlp_pre) -- equal up to fp32 rounding
+    assert float((outs[2] - outs[1]).abs().max()) <= 2e-5 * sc
 
 
 def test_predict_labels_and_nuscenes_dump(dev, tmp_path):
@@ -509,3 +513,26 @@ def test_predict_labels_and_nuscenes_dump(dev, tmp_path):
     assert d["cam2lidar"].shape == (6, 4, 4) and np.allclose(d["cam2lidar"][:, :3, 3], rig["trans"][0].numpy())
     f2 = apis.save_output_nuscenes(img_inputs, labels, str(tmp_path), "scene", "sample0", None, 123, "scene-0001")
     assert f2.endswith(os.path.join("scene-0001", "123.pkl"))
+
+
+@pytest.mark.parametrize("nf,ncls", [(1, 17), (63, 17), (1000, 17), (4133, 5)])
+def test_fine_mlp_pre_kernel_vs_torch(dev, nf, ncls):
+    """coocc_fine_mlp_pre: GroupNorm of (pre-linearised image sample + bias), accumulators started from the
+    pre-linearised voxel sample, register-chained Linear(64->64) and Linear(64->ncls); vs torch fp32."""
+    import torch.nn.functional as F
+    from co_occ_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(nf * 17 + ncls)
+    mk = lambda *s: torch.randn(*s, generator=g)
+    samp, vox = mk(nf, 72)[:, :64], mk(nf, 64)                    # image sample with row stride 72
+    bi, gwi, gbi = mk(64) * 0.1, mk(64) * 0.3 + 1, mk(64) * 0.1
+    w0, b0, gw0, gb0 = mk(64, 192) * 0.1, mk(64) * 0.1, mk(64) * 0.3 + 1, mk(64) * 0.1
+    w3, b3 = mk(ncls, 64) * 0.1, mk(ncls) * 0.1
+    y1 = F.relu(F.group_norm(samp + bi, 16, gwi, gbi, 1e-5))
+    h = F.relu(F.group_norm(vox + F.linear(y1, w0[:, 128:]) + b0, 16, gw0, gb0, 1e-5))
+    want = F.linear(h, w3, b3)
+    samp_d = torch.cat([samp, torch.full((nf, 8), 1e9)], 1).contiguous().to(dev)
+    ts = [t.contiguous().to(dev) for t in (vox, bi, gwi, gbi, w0, b0, gw0, gb0, w3, b3)]
+    out = torch.full((nf, ncls), float("nan"), device=dev)
+    call("coocc_fine_mlp_pre", ptr(samp_d), 72, ptr(ts[0]), 64, nf, ptr(ts[1]), ptr(ts[2]), ptr(ts[3]), 1e-5,
+         ptr(ts[4]), ptr(ts[5]), ptr(ts[6]), ptr(ts[7]), 1e-5, ptr(ts[8]), ptr(ts[9]), ncls, ptr(out))
+    assert_close(out.cpu(), want, what="fine_mlp_pre")
