@@ -30,8 +30,12 @@ ZTRIM = __import__("os").environ.get("COOCC_ZTRIM", "1") != "0"   # drop z taps 
 WINO_TILE = int(__import__("os").environ.get("COOCC_WINO_TILE", "4"))   # F(4x4,3x3) where X, Y >= 8, else F(2x2,3x3)
 
 
-def conv_kernel_name(M, Cout, table, hint=0, iters=1 << 30):
-    """Mirror of the tile-configuration rule in csrc/conv3d.hip (coocc_conv_fwd).  iters = taps * ceil(Cin/32)."""
+def conv_kernel_name(M, Cout, table, hint=0, iters=1 << 30, one_by_one=False):
+    """Mirror of the tile-configuration rule in csrc/conv3d.hip (coocc_conv_fwd).  iters = taps * ceil(Cin/32);
+    one_by_one: a 1x1x1 stride-1 layer (takes the persistent kernel when it has more than 768 tiles)."""
+    if (one_by_one and CONV_PERSIST and CONV_V2 and not table and Cout > 64 and M >= 8192 and iters <= 24
+            and -(-M // 128) * -(-Cout // 128) > 768):
+        return "k_conv2p<1x1>"
     hint = hint or TILE_HINT
     if Cout <= 32:
         t = "128,32,32,32"
@@ -324,7 +328,8 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
             d.w = ptr(pc.ztrim_pack(lo, hi))
             d.kx, d.ky, d.kz, d.px, d.py, d.pz = 3, 3, hi - lo + 1, pc.pad, pc.pad, pc.pad - lo
             d.taps = taps = 9 * (hi - lo + 1)
-    with TIMER.region(conv_kernel_name(M, pc.Cout, False, 0, taps * -(-pc.Cin // 32)), 2.0 * M * pc.Cin * pc.Cout * taps):
+    with TIMER.region(conv_kernel_name(M, pc.Cout, False, 0, taps * -(-pc.Cin // 32), pc.ksize == 1 and pc.stride == 1 and pc.pad == 0),
+                      2.0 * M * pc.Cin * pc.Cout * taps):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     return out
 
@@ -353,7 +358,7 @@ def linear_rows(x2d, pc, relu=False, out=None, out_coff=0, in_coff=0, in_C=None)
     d.ksize, d.stride, d.pad = 1, 1, 0
     d.relu, d.res_mode, d.splitk = int(relu), 0, 0
     d.tile_hint = TILE_HINT
-    with TIMER.region(conv_kernel_name(n, pc.Cout, False, 0, -(-Cin // 32)), 2.0 * n * Cin * pc.Cout):
+    with TIMER.region(conv_kernel_name(n, pc.Cout, False, 0, -(-Cin // 32), True), 2.0 * n * Cin * pc.Cout):
         _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
     return out
 

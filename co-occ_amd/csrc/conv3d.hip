@@ -436,8 +436,11 @@ __global__ __launch_bounds__(256, MINW) void k_conv2(ConvK p) {
 // few chunks.  Here a workgroup walks tiles id, id + gridDim.x, ...: on the LAST chunk of a tile the prefetch slot that
 // k_conv2 fills with dummy zeros takes chunk 0 of the NEXT tile, so that chunk's LDS store, barrier and first fragment
 // reads happen under the last MFMA group of the current tile exactly like any other chunk; only the epilogue stores
-// and the accumulator reset sit between two tiles.  Specialised to the geometry of those launches (rows = (tile, z),
-// taps = the 3 z neighbours: kx = ky = 1, Xi = Yi = 1, stride 1), which keeps the per-tile state to 8 VGPRs.
+// and the accumulator reset sit between two tiles.  Specialised to row-linear geometries, which keeps the per-tile state
+// to 8 VGPRs: (WG) the grouped launches (rows = (tile, z), taps = the 3 z neighbours: kx = ky = 1, Xi = Yi = 1,
+// stride 1, bare products out), and (EPI) 1x1x1 stride-1 layers (input row = output row) with the usual epilogue --
+// the per-voxel render heads and the lateral / prediction 1x1 convs, whose K is only 4-8 chunks.
+template <bool WG, bool EPI>
 __global__ __launch_bounds__(256, 3) void k_conv2p(ConvK p) {
   constexpr int BM = 128, TM = BM / 32, PA = BM / 32;
   __shared__ float As[2][BM * LDS_ST];
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(256, 3) void k_conv2p(ConvK p) {
   int lc = 0, lkc = 0, lkw = 0;
   auto setup = [&](int mtile, int nt_) {
     m0 = mtile * BM; n0 = nt_ * 128; nt = nt_;
-    const float* wbase = p.w + (size_t)(m0 / p.wgroup_rows) * p.wgroup_floats;
+    const float* wbase = WG ? p.w + (size_t)(m0 / p.wgroup_rows) * p.wgroup_floats : p.w;
     rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, p.w_bytes, 0x00020000);
     const int row0 = max(m0 - p.pz, 0);
 #pragma unroll
@@ -582,7 +585,9 @@ __global__ __launch_bounds__(256, 3) void k_conv2p(ConvK p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][r]), rs_o, (int)voff, 0, 0);
+            float v = acc[i][r];
+            if (EPI) v = epilogue(p, v, col, (size_t)(m0c + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_o, (int)voff, 0, 0);
             voff += (r & 3) == 3 ? s5 : s1;
           }
       }
@@ -735,16 +740,20 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
     // k_conv2p's contract: grouped launch, rows = (tile, z) with the z taps only, bare products out
     const bool persist = persist_env && splitk == 1 && (per_wg >= 2 || persist_env == 2) && k.wgroup_rows > 0 && k.kx == 1 && k.ky == 1 && k.Xi == 1 &&
                          k.Yi == 1 && k.stride == 1 && !k.scale && !k.bias && !k.res && !k.relu && !k.out_rows && k.res_mode == 0;
+    // ... and the 1x1x1 stride-1 layers (input row = output row; res_mode 3 = split-K slices is excluded by splitk == 1)
+    const bool persist1 = persist_env && splitk == 1 && (per_wg >= 2 || persist_env == 2) && k.wgroup_rows == 0 && k.taps == 1 &&
+                          k.kx == 1 && k.ky == 1 && k.kz == 1 && k.px == 0 && k.py == 0 && k.pz == 0 && k.stride == 1 && !k.out_rows;
     static const int pf160 = getenv("COOCC_CONV_PF160") ? atoi(getenv("COOCC_CONV_PF160")) : 2;
     static const int pf128 = getenv("COOCC_CONV_PF128") ? atoi(getenv("COOCC_CONV_PF128")) : 3;
     if (k.wgroup_rows > 0) {
       if (cfg == 4) hipLaunchKernelGGL((k_conv2<160, 2, true>), grid, dim3(256), 0, s, k);
       // short K (3*Cin/32 <= 24 chunks per tile): the per-tile prologue/epilogue weighs as much as the loop, so
       // trade prefetch depth for occupancy -- PF = 1 fits 168 VGPRs = 3 workgroups per CU (0.179 -> 0.158 ms)
-      else if (short_k && persist) hipLaunchKernelGGL(k_conv2p, pgrid, dim3(256), 0, s, k);
+      else if (short_k && persist) hipLaunchKernelGGL((k_conv2p<true, false>), pgrid, dim3(256), 0, s, k);
       else if (short_k) hipLaunchKernelGGL((k_conv2<128, 1, true, 3>), grid, dim3(256), 0, s, k);
       else hipLaunchKernelGGL((k_conv2<128, 3, true>), grid, dim3(256), 0, s, k);
     }
+    else if (cfg != 4 && short_k && persist1) hipLaunchKernelGGL((k_conv2p<false, true>), pgrid, dim3(256), 0, s, k);
     else if (cfg != 4 && short_k && splitk == 1) hipLaunchKernelGGL((k_conv2<128, 1, false, 3>), grid, dim3(256), 0, s, k);
     else if (cfg == 4 && pf160 == 2) hipLaunchKernelGGL((k_conv2<160, 2>), grid, dim3(256), 0, s, k);
     else if (cfg == 4) hipLaunchKernelGGL((k_conv2<160, 1>), grid, dim3(256), 0, s, k);
