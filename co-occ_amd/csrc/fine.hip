@@ -85,7 +85,13 @@ __global__ __launch_bounds__(256, 4) void k_fine_sample_voxel_r2(const float* __
                                                                float fx1, float fy1, float fz1,
                                                                int64_t* __restrict__ fine_xyz, float* __restrict__ feat,
                                                                int out_stride) {
-  const int i = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  // C <= 64: two channels per lane fill only half a wave, so each half-wave takes its own coarse voxel (no cross-lane
+  // operation below: every lane derives the voxel's stencil itself)
+  const int wv = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const bool halfw = C <= 64;
+  const int i = halfw ? wv * 2 + (int)((threadIdx.x & 63) >> 5) : wv;
+  const int lane = halfw ? (threadIdx.x & 31) : (threadIdx.x & 63);
+  const int cstep = halfw ? 64 : 128;
   if (i >= n) return;
   const long long nf = (long long)n * 8;
   int l = coarse_lin[i];
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256, 4) void k_fine_sample_voxel_r2(const float* __
   // tap weight of window position x for a child with base index b0 and fraction t
   auto tapw = [](int b0, float t, int x) { return (x == b0 ? 1.f - t : 0.f) + (x == b0 + 1 ? t : 0.f); };
   const int wx0 = min(i0[0][0], i0[0][1]), wy0 = min(i0[1][0], i0[1][1]), wz0 = min(i0[2][0], i0[2][1]);
-  for (int c = lane * 2; c < C; c += 128) {
+  for (int c = lane * 2; c < C; c += cstep) {
     f32x2 acc[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) acc[o] = f32x2{0.f, 0.f};
@@ -157,7 +163,7 @@ extern "C" int coocc_fine_sample_voxel(const float* vol, int C, int X, int Y, in
   // the 3-wide window of the grouped kernel needs floor(p) of the two children of an axis to differ by <= 1:
   // true for final == ratio * coarse (p = q*S/(2S-1) - 1/2)
   if (ratio == 2 && final_size_host[0] == 2 * X && final_size_host[1] == 2 * Y && final_size_host[2] == 2 * Z) {
-    hipLaunchKernelGGL(k_fine_sample_voxel_r2, dim3(cdiv((long long)n * 64, 256)), dim3(256), 0, as_stream(stream), vol, C, X,
+    hipLaunchKernelGGL(k_fine_sample_voxel_r2, dim3(cdiv((long long)(C <= 64 ? (n + 1) / 2 : n) * 64, 256)), dim3(256), 0, as_stream(stream), vol, C, X,
                        Y, Z, coarse_lin, n, (float)(final_size_host[0] - 1), (float)(final_size_host[1] - 1),
                        (float)(final_size_host[2] - 1), fine_xyz, feat, out_stride);
     COOCC_LAUNCH_CHECK("k_fine_sample_voxel_r2");
