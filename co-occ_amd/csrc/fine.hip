@@ -309,10 +309,12 @@ __global__ __launch_bounds__(256) void k_fine_sample_img_g8(const float* __restr
   float ax = 0.f, ay = 0.f;
   if (lane < 8 * ncam) {
     const int o = lane / ncam, cam = lane - o * ncam;
-    const long long f = (long long)o * n + i;
-    float p0 = (float)fine_xyz[f] * prm[9] + prm[12];
-    float p1 = (float)fine_xyz[nf + f] * prm[10] + prm[13];
-    float p2 = (float)fine_xyz[2 * nf + f] * prm[11] + prm[14];
+    // child o = (a*2 + b)*2 + c of coarse voxel i sits at (child 0) + (a, b, c): three wave-uniform reads instead of
+    // 3 x 48 scattered 8-byte ones (f = o*n + i)
+    const long long fx = fine_xyz[i] + (o >> 2), fy = fine_xyz[nf + i] + ((o >> 1) & 1), fz = fine_xyz[2 * nf + i] + (o & 1);
+    float p0 = (float)fx * prm[9] + prm[12];
+    float p1 = (float)fy * prm[10] + prm[13];
+    float p2 = (float)fz * prm[11] + prm[14];
     float bx = prm[0] * p0 + prm[1] * p1 + prm[2] * p2;
     float by = prm[3] * p0 + prm[4] * p1 + prm[5] * p2;
     float bz = prm[6] * p0 + prm[7] * p1 + prm[8] * p2;

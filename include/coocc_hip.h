@@ -305,7 +305,8 @@ int coocc_fine_sample_voxel(const float* vol, int C, int X, int Y, int Z, const 
  * [ncam,Hf,Wf,Ci]; params (device): [0:9] inv(bda), [9:12] voxel_size, [12:15] range_lo,
  * [15] W_img-1, [16] H_img-1, then per camera 27 floats: inv(rots)[9], trans[3], intrins[9],
  * post_rots[:2,:2][4], post_trans[:2][2].  group8 != 0: fine_xyz is the offset-major list of
- * coocc_fine_sample_voxel with ratio 2 (f = o*n + i, 8 children per coarse voxel): one wave per coarse voxel. */
+ * coocc_fine_sample_voxel with ratio 2 (f = o*n + i, child o = (a*2+b)*2+c at (child 0) + (a,b,c), 8 children per
+ * coarse voxel): one wave per coarse voxel, child coordinates derived from child 0. */
 int coocc_fine_sample_img(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf,
                           const float* params, const int64_t* fine_xyz, int64_t nfine, float* feat,
                           int out_stride, int group8, void* stream);
