@@ -142,11 +142,14 @@ class BiFuser_N(nn.Module):
 
         def build():
             d = build_packs()
-            # con_enc opens the decoder: its rounding error is amplified by every later layer (measured on the
-            # 50x50x8 end-to-end case: F(4x4) here lifts the fine-logit error from 7e-5 to 1.1e-4, anywhere
-            # later it does not move it), so these two layers keep the F(2x2) transform
-            for k in ("c0", "c3"):
-                d[k].wino_tile = 2
+            # con_enc opens the decoder: its rounding error is amplified by every later layer.  Measured on the 50x50x8
+            # end-to-end case (voxel_feats / fine-logit error vs the reference, bound 1e-4), tiles of (con_enc.0, con_enc.3):
+            #   (2,2) 2.0e-6 / 7.2e-5    (2,4) 6.8e-6 / 9.0e-5    (4,2) 6.0e-6 / 1.7e-4    (4,4) 7.8e-6 / 1.4e-4
+            # F(4x4) anywhere later does not move the fine logits, so only these two layers keep F(2x2); (2,4) would save
+            # another 0.3 ms per sample but leaves a 10 % margin only.  COOCC_CONENC_TILES overrides (experiments).
+            import os
+            t0, t3 = [int(v) for v in os.environ.get("COOCC_CONENC_TILES", "2,2").split(",")]
+            d["c0"].wino_tile, d["c3"].wino_tile = t0, t3
             return d
 
         def build_packs():

@@ -4,6 +4,8 @@ seeded random weights the decoder's activations reach |x| ~ 1e2, where one fp32 
 (measured), so the bound is applied relative to the tensor's scale:
     max|a - b| <= tol * max(1, max|b|),   tol = 1e-4.
 Integer / index outputs are always compared bit-exactly."""
+import os
+
 import numpy as np
 import torch
 
@@ -26,5 +28,7 @@ def rel_err(a, b):
 
 def assert_close(a, b, tol=TOL, what=""):
     e = rel_err(a, b)
+    if os.environ.get("COOCC_PRINT_ERR"):
+        print("[err] %-28s %.3e" % (what, e))
     assert e <= tol, "%s scale-relative error %.3e > %.1e" % (what, e, tol)
     return e
