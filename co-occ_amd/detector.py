@@ -138,5 +138,6 @@ class COOCC_Ray(nn.Module):
 
     def forward(self, return_loss=False, **kwargs):
         if return_loss:
-            raise NotImplementedError("training (losses + backward) is SURVEY.md 8f 'next', not built yet")
+            raise NotImplementedError("forward_train is not assembled: the differentiable pieces (trunk, head, fine branch, render block, "
+                                      "render losses) are in co_occ_amd.autograd; the semantic losses are out of scope (SURVEY.md 8)")
         return self.forward_test(**kwargs)
