@@ -60,6 +60,38 @@ def all_gather_maps(rgbs, depths):
     return unpack_maps(out)
 
 
+class PendingMaps:
+    """An all-gather of rendered maps in flight (all_gather_maps_async): ``wait()`` -> (rgbs [world,N,H,W,3],
+    depths [world,N,H,W])."""
+
+    def __init__(self, work, out, parts, packed):
+        self.work, self.out, self.parts, self.packed = work, out, parts, packed
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()             # the CURRENT stream waits for the collective; no host block with RCCL
+            self.work = None
+        if self.parts is not None:
+            self.out = torch.stack(self.parts)
+            self.parts = None
+        return unpack_maps(self.out)
+
+
+def all_gather_maps_async(rgbs, depths):
+    """all_gather_maps without making the issuing stream wait: RCCL runs the collective on its own stream once the
+    maps are ready, and the next sample's dense stage is enqueued behind the render kernels, not behind the
+    collective ('overlappable with the next sample').  Call ``.wait()`` on the result before reading."""
+    packed = pack_maps(rgbs, depths)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return PendingMaps(None, packed.unsqueeze(0), None, packed)
+    world = dist.get_world_size()
+    if dist.get_backend() == "gloo":
+        parts = [torch.empty_like(packed) for _ in range(world)]
+        return PendingMaps(dist.all_gather(parts, packed, async_op=True), None, parts, packed)
+    out = torch.empty((world,) + tuple(packed.shape), device=packed.device, dtype=packed.dtype)
+    return PendingMaps(dist.all_gather_into_tensor(out, packed, async_op=True), out, None, packed)
+
+
 def gather_ray_shards(local_maps, n_rows_total):
     """Config 5 (ray-sharded render of ONE scene): each rank rendered a contiguous chunk of the
     flattened (camera,row) space; rows are padded to the largest chunk for the collective and

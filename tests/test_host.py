@@ -115,6 +115,12 @@ for r in range(2):
     g = torch.Generator().manual_seed(100 + r)
     er, ed = torch.rand(3, 4, 6, 3, generator=g), torch.rand(3, 4, 6, generator=g)
     assert torch.equal(R[r], er) and torch.equal(D[r], ed)
+# asynchronous form used by bench.py: two gathers issued back to back, each completed before the next is issued
+pend = cd.all_gather_maps_async(rgbs, depths)
+R2, D2 = pend.wait()
+pend = cd.all_gather_maps_async(rgbs * 2, depths * 2)
+R3, D3 = pend.wait()
+assert torch.equal(R2, R) and torch.equal(D2, D) and torch.equal(R3, R * 2) and torch.equal(D3, D * 2)
 # ray-sharded render of one scene: 7 rows over 2 ranks
 full = torch.arange(7 * 5 * 4, dtype=torch.float32).view(7, 5, 4)
 lo, hi = cd.shard_range(7, rank, world)
