@@ -71,7 +71,7 @@ SIGNATURES = {
     "coocc_upsample_maps": (I, [P, I, I, I, I, P, P, P]),
     "coocc_volume_sampling": (I, [P, I, I, I, I, P, I, P, P, P, P]),
     "coocc_raw2outputs": (I, [P, P, I, I, I, F, F, P, P, P, P]),
-    "coocc_render_losses": (I, [P, P, P, P, L, I, P, P]),
+    "coocc_render_losses": (I, [P, P, P, P, L, I, P, P, Z, P]),
     "coocc_conv_pack_weights_dev": (L, [P, I, I, I, I, P, P]),
     "coocc_wino_pack_weights_dev": (L, [P, I, I, I, I, P, P]),
     "coocc_wino_gradout": (I, [P, I, I, I, I, I, I, I, P, L, P]),

@@ -486,7 +486,8 @@ class RenderLossesFn(torch.autograd.Function):
         out = torch.empty(3, device=rgbs.device, dtype=_F32)
         r, d = rgbs.contiguous(), depths.contiguous()
         rg, dg = rgb_gt.float().contiguous(), depth_gt.float().contiguous()
-        call("coocc_render_losses", ptr(r), ptr(d), ptr(rg), ptr(dg), d.numel(), int(D), ptr(out))
+        ws = workspace(r.device)
+        call("coocc_render_losses", ptr(r), ptr(d), ptr(rg), ptr(dg), d.numel(), int(D), ptr(out), ptr(ws), ws.numel() * 4)
         ctx.save_for_backward(r, d, rg, dg, out)
         ctx.D = int(D)
         return out[:2].clone()

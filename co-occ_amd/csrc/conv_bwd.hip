@@ -8,6 +8,7 @@
 //             re-packed weights: stride 1 = taps flipped (mode 2); stride 2 = a row table o(i,t) (mode 3)
 //   wgrad     dW[n][c][t] = sum_o in[src(o,t)][c] dacc[o][n]       -> k_wgrad below (K = M on the MFMA)
 #include "conv_layout.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -100,6 +101,20 @@ __global__ __launch_bounds__(256) void k_epilogue_bwd(const float* __restrict__ 
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)M * c4) return;
   const int m = (int)(i / c4), c = (int)(i % c4) * 4;
+  if (((C | dout_stride | out_stride | dacc_stride | dres_stride) & 3) == 0) {   // whole rows of dwordx4 (the usual case)
+    f32x4 g = *(const f32x4*)(dout + (size_t)m * dout_stride + c);
+    if (relu) {
+      const f32x4 o = *(const f32x4*)(out + (size_t)m * out_stride + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+    }
+    if (dres) {
+      f32x4* d = (f32x4*)(dres + (size_t)m * dres_stride + c);
+      *d = dres_accumulate ? *d + g : g;
+    }
+    if (dacc) *(f32x4*)(dacc + (size_t)m * dacc_stride + c) = scale ? g * *(const f32x4*)(scale + c) : g;
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     if (c + e >= C) break;
@@ -285,7 +300,8 @@ extern "C" int coocc_conv_wgrad(const float* in, int in_rows, int in_stride, con
   const int ctiles = (Cin + 127) / 128, ntiles = (Cout + 127) / 128;
   const long long tiles = (long long)ctiles * ntiles * taps;
   const int64_t per = (int64_t)taps * Cin * Cout;
-  long long nslices = (1024 + tiles - 1) / tiles;                       // ~4 workgroups per CU
+  static const int wg_target = getenv("COOCC_WGRAD_WGS") ? atoi(getenv("COOCC_WGRAD_WGS")) : 512;
+  long long nslices = (wg_target + tiles - 1) / tiles;                  // ~2 workgroups per CU (the layers left on this kernel are the small ones)
   nslices = std::min<long long>(nslices, (M + 255) / 256);              // >= 256 voxels per slice
   nslices = std::min<long long>(nslices, ws_floats / per);
   COOCC_CHECK_ARG(nslices >= 1, "conv_wgrad: workspace smaller than one weight slab");

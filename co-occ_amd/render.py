@@ -165,8 +165,10 @@ def render_block_sharded(sigma_head, rgb_head, voxel_feats, gemo, scale=16, rank
 def render_losses(rgbs, depths, rgb_gt, depth_gt, D):
     """coocc_ray.py:423-433 -> dict(loss_depth_render, loss_rgb) (forward values)."""
     out = torch.empty(3, device=rgbs.device, dtype=_F32)
+    from .core import workspace
+    ws = workspace(rgbs.device)
     call("coocc_render_losses", ptr(rgbs.contiguous()), ptr(depths.contiguous()), ptr(rgb_gt.float().contiguous()),
-         ptr(depth_gt.float().contiguous()), depths.numel(), int(D), ptr(out))
+         ptr(depth_gt.float().contiguous()), depths.numel(), int(D), ptr(out), ptr(ws), ws.numel() * 4)
     return dict(loss_depth_render=out[0], loss_rgb=out[1])
 
 

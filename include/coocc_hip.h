@@ -419,9 +419,11 @@ int coocc_volume_sampling(const float* vol, int C, int d0, int d1, int d2, const
 int coocc_raw2outputs(const float* raw, const float* z, int R, int S, int white_bkgd, float zmin,
                       float zmax, float* rgb, float* depth, float* weights, void* stream);
 /* render losses (coocc_ray.py:423-433): out[0]=loss_depth_render, out[1]=loss_rgb, out[2]=number of
- * foreground pixels (kept for the backward).  rgbs/rgb_gt:[npix,3]; depths/depth_gt:[npix]. */
+ * foreground pixels (kept for the backward).  rgbs/rgb_gt:[npix,3]; depths/depth_gt:[npix]; ws: >= 24 KB of device
+ * scratch (fp64 partials of the deterministic two-pass reduction). */
 int coocc_render_losses(const float* rgbs, const float* depths, const float* rgb_gt,
-                        const float* depth_gt, int64_t npix, int D, float* out, void* stream);
+                        const float* depth_gt, int64_t npix, int D, float* out, void* ws, size_t ws_bytes,
+                        void* stream);
 
 /* On-device evaluation: COOCC_Ray.evaluation_semantic coocc_ray.py:659-684 + fast_hist
  * :726-730 without the device->host copy.  pred: class logits on an h x w x d grid addressed by element strides

@@ -233,6 +233,52 @@ def bench_trunk():
         print("   %-44s %3d launches %8.2f ms%s" % (k, r["launches"], r["ms"], "  %.0f TFLOP/s" % (r["work"] / r["ms"] / 1e9) if r["work"] else ""))
 
 
+def bench_trainfull():
+    """Whole differentiable path at the r50 workload, forward + backward (frozen-statistics BN): con_enc -> ResNet3D-18 ->
+    FPN3D -> OccHead coarse + fine (training-time top-k = 20000 coarse voxels, occ_head.py:187-196) + render block with
+    its two losses.  The semantic losses (CE / lovasz / scal) are out of scope: squared-mean surrogates close the graph."""
+    from co_occ_amd import autograd as ag
+    from co_occ_amd import _lib
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    B = importlib.util.module_from_spec(spec); spec.loader.exec_module(B)
+    model, _ = B.build_model("r50", dev)
+    s = B.make_inputs("r50", 1234, dev, model)
+    X, Y, Z = 100, 100, 8
+    C = model.occ_fuser.in_channels
+    x = torch.randn(X * Y * Z, 4 * C, device=dev).requires_grad_()
+    g = torch.Generator().manual_seed(1)
+    coarse = torch.randperm(X * Y * Z, generator=g)[:20000].sort().values.int().to(dev)
+    N, D, fH, fW = s["gemo"].shape[1:5]
+    rgb_gt = torch.rand(N * fH * 16 * fW * 16, 3, device=dev)
+    depth_gt = torch.rand(N * fH * 16 * fW * 16, device=dev) * 50
+    fuser, head = model.occ_fuser, model.pts_bbox_head
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        x.grad = None
+        ce = fuser.con_enc
+        vf, geom = ag.conv3d_rows(x, ce[0].weight, (1, X, Y, Z), bias=ce[0].bias, bn=ce[1], relu=True)
+        vf, geom = ag.conv3d_rows(vf, ce[3].weight, geom, bias=ce[3].bias, bn=ce[4], relu=True)
+        levels = ag.trunk_forward_train(None, model.semantic_encoder, model.semantic_neck, vf, geom)
+        out_rows, logits = ag.occhead_coarse_train(head, levels)
+        fine, _ = ag.fine_branch_train(head, out_rows, (1, X, Y, Z), coarse, s["img_feats"], s["transform"])
+        rgbs, depths = ag.render_block_train(model.sigma_head, model.rgb_head, vf, (X, Y, Z), s["gemo"])
+        L = ag.render_losses(rgbs.reshape(-1, 3), depths.reshape(-1), rgb_gt, depth_gt, D)
+        loss = logits.square().mean() + fine.square().mean() + L["loss_rgb"] + L["loss_depth_render"]
+        loss.backward()
+    t = timeit(step, n=3, warm=1)
+    _lib.TIMER.enabled = 2
+    _lib.TIMER.reset()
+    step()
+    torch.cuda.synchronize()
+    rows = _lib.TIMER.summary()
+    _lib.TIMER.enabled = False
+    print("full-model train step (fwd+bwd, r50: trunk + coarse head + fine branch (20000 coarse voxels) + render + losses): %.1f ms" % t)
+    for k, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:12]:
+        print("   %-44s %3d launches %8.2f ms%s" % (k, r["launches"], r["ms"], "  %.0f TFLOP/s" % (r["work"] / r["ms"] / 1e9) if r["work"] else ""))
+
+
 def bench_lidar():
     """LiDAR producer at nuScenes scale: ~280 k points (10 sweeps) -> 0.125 m voxels on [800,800,64] -> 8x sparse encoder."""
     from co_occ_amd import lidar as L
@@ -318,5 +364,5 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["fps", "knn", "conv"]
     with torch.no_grad():
         for w in which:
-            with torch.set_grad_enabled(w in ("bwd", "trunk")):
+            with torch.set_grad_enabled(w in ("bwd", "trunk", "trainfull")):
                 globals()["bench_" + w]()
