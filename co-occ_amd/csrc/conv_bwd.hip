@@ -395,9 +395,11 @@ extern "C" int coocc_wino_wgrad(const float* V, const float* dM, int64_t group_r
   const int ctiles = (Cin + 127) / 128, ntiles = (Cout + 127) / 128;
   const long long tiles = (long long)ctiles * ntiles * 3;
   const int64_t per = (int64_t)3 * Cin * Cout;
-  // S slices per transform point: ~4 workgroups per CU in total, >= 256 rows per slice, slice length a multiple of 16
+  // S slices per transform point: at least one workgroup per CU in total (longer slices beat more of them: 72 -> 77
+  // TFLOP/s), >= 256 rows per slice, slice length a multiple of 16
   int S = 1;
-  while (S < 64 && tiles * pts * S < 1024 && group_rows % (2 * S * 16) == 0 && group_rows / (2 * S) >= 256 &&
+  static const int wg_target = getenv("COOCC_WINO_WGRAD_WGS") ? atoi(getenv("COOCC_WINO_WGRAD_WGS")) : 256;
+  while (S < 64 && tiles * pts * S < wg_target && group_rows % (2 * S * 16) == 0 && group_rows / (2 * S) >= 256 &&
          (int64_t)pts * 2 * S * per <= ws_floats) S *= 2;
   COOCC_CHECK_ARG((int64_t)pts * S * per <= ws_floats, "wino_wgrad: workspace smaller than (tile+2)^2 weight slabs");
   const int mslice = (int)(group_rows / S);
