@@ -381,7 +381,7 @@ def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_co
     d.ws, d.ws_floats = ptr(ws), ws.numel()
     d.M, d.Cin, d.Cout, d.taps = M, C, pc.Cout, K
     d.in_stride, d.out_stride, d.res_stride = src.shape[1], dst.shape[1], dst.shape[1]
-    d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = 1, 1, 1, 1, 1, 1, 1
+    d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = 1, src.shape[0], 1, 1, 1, 1, 1     # Xi = number of source rows
     d.ksize, d.stride, d.pad = 1, 1, 0
     d.relu, d.res_mode, d.splitk = int(relu), 2, 1
     d.tile_hint = TILE_HINT

@@ -252,10 +252,14 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // layers (few M tiles, up to 113 MB of weights each) need the HBM latency of 2-3 chunks covered.
 // WG = true: the weight-grouped launch of the Winograd path (one weight pack per transform point); a separate
 // instantiation so that profilers list it under its own name.
-template <int BM, int PF = 1, bool WG = false, int MINW = 2>
+template <int BM, int PF = 1, bool WG = false, int MINW = 2, bool TB = false>
 __global__ __launch_bounds__(256, MINW) void k_conv2(ConvK p) {
   constexpr int TM = BM / 32, PA = BM / 32;
   __shared__ float As[2][BM * LDS_ST];
+  // TB (row-table mode: sparse convolutions, strided dgrad classes, the GSFusion gather GEMMs): the tile's slice of the
+  // [taps][M] table sits in LDS, so the dependent pair (table entry -> feature row) never adds a second global latency
+  // and the lookups do not share the in-order vmcnt queue with the prefetched rows
+  __shared__ int Ti[TB ? 27 * BM : 1];
 
   const int id = blockIdx.x;
   int mtile, nt, slot = id >> 3;
@@ -284,7 +288,14 @@ __global__ __launch_bounds__(256, MINW) void k_conv2(ConvK p) {
   // per-thread A rows: voxel coordinates of tap (0,0,0) and its row index; rows past M are parked
   // outside the grid so every tap fails the bounds test
   int cx[PA], cy[PA], cz[PA], rrow[PA];
-  size_t base_off;
+  size_t base_off = 0;
+  if (TB) {
+    for (int i = tid; i < p.taps * BM; i += 256) {
+      const int t = i / BM, m = m0 + (i - t * BM);
+      Ti[i] = m < p.M ? p.gather[(size_t)t * p.M + m] : -1;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int a = 0; a < PA; ++a) {
     int m = m0 + lrow + 32 * a;
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv2(ConvK p) {
   // tile touches lies in a short window above the row of (m0, tap 0).  The buffer descriptor is based there
   // (64-bit pointer) and the per-lane offsets stay 32-bit for inputs of any size (the Winograd V buffer of a
   // 200x200x16x512 volume is 5.2 GB).
-  {
+  if (!TB) {
     int oz = m0 % p.Zo; int r = m0 / p.Zo;
     int oy = r % p.Yo; r /= p.Yo;
     int ox = r % p.Xo; int b = r / p.Xo;
@@ -333,6 +344,16 @@ __global__ __launch_bounds__(256, MINW) void k_conv2(ConvK p) {
     const int drow = (lkd * p.Yi + lkh) * p.Zi + lkw;
     const int cc = lkc * KC + piece * 4;
     const bool cok = live & (cc < p.Cin);
+    if (TB) {
+      // lkw is the tap index here (kz = taps, ky = kx = 1 are set by the host for this mode)
+#pragma unroll
+      for (int a = 0; a < PA; ++a) {
+        const int idx = Ti[lkw * BM + lrow + 32 * a];
+        const bool ok = cok & (idx >= 0);
+        unsigned voff = ok ? (unsigned)(idx * p.in_stride + cc) * 4u : 0xFFFFFFF0u;
+        rq[slot_][a] = buf_load4(rs_in, voff, 0);
+      }
+    } else {
 #pragma unroll
     for (int a = 0; a < PA; ++a) {
       // bitwise, not short-circuit: keeps the body free of control flow
@@ -340,6 +361,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv2(ConvK p) {
                       ((unsigned)(cz[a] + lkw) < (unsigned)p.Zi);
       unsigned voff = ok ? (unsigned)((rrow[a] + drow) * p.in_stride + cc) * 4u : 0xFFFFFFF0u;
       rq[slot_][a] = buf_load4(rs_in, voff, 0);
+    }
     }
     // advance the cursor (scalar, branch-free so the loop body stays one basic block)
     lc += 1; lkw += 1;                         // taps innermost, then the next channel chunk
@@ -724,6 +746,28 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   // rows a tile can touch above its first one (bound: stride-2 outputs advance the input rows up to 8x faster)
   const unsigned long long window_rows = 8ull * 160 + (unsigned long long)k.kx * d->Yi * d->Zi + (unsigned long long)k.ky * d->Zi + k.kz + 8;
   const bool window_ok = window_rows * d->in_stride * 4ull < 0xFFFFFF00ull && (long long)d->B * d->Xi * d->Yi * d->Zi < (1ll << 31);
+  // row-table mode on the pipelined kernel (128-row tiles, table slice in LDS).  The caller states the number of input
+  // rows in B*Xi*Yi*Zi (1 = unknown -> phase-structured kernel); 32-bit row offsets need the input below 4 GB
+  const unsigned long long tb_rows = (unsigned long long)d->B * d->Xi * d->Yi * d->Zi;
+  static const int v2table = getenv("COOCC_CONV_V2_TABLE") ? atoi(getenv("COOCC_CONV_V2_TABLE")) : 1;
+  if (v2mode && v2table && table && cfg == 0 && d->wgroup_rows == 0 && k.taps <= 27 && tb_rows > 1 &&
+      tb_rows * d->in_stride * 4ull < 0xFFFFFF00ull && w_bytes < 0xFFFFFF00ull) {
+    k.in_bytes = (size_t)(tb_rows * d->in_stride * 4ull);
+    k.w_bytes = (unsigned)w_bytes;
+    k.kx = k.ky = 1; k.kz = k.taps; k.px = k.py = k.pz = 0;      // the kernel's cursor walks taps innermost
+    k.mtiles = (k.M + 127) / 128;
+    k.ntiles = (k.Cout + 127) / 128;
+    k.mtiles_per_xcd = k.mtiles >= 64 ? (k.mtiles + 7) / 8 : 0;
+    dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
+    if (short_k && splitk == 1) hipLaunchKernelGGL((k_conv2<128, 1, false, 3, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((k_conv2<128, 3, false, 2, true>), grid, dim3(256), 0, s, k);
+    COOCC_LAUNCH_CHECK("k_conv2<table>");
+    if (splitk > 1) {
+      hipLaunchKernelGGL(k_conv_reduce, dim3(cdiv((long long)k.M * k.Cout, 256)), dim3(256), 0, s, k);
+      COOCC_LAUNCH_CHECK("k_conv_reduce");
+    }
+    return COOCC_OK;
+  }
   if (v2mode && !table && (cfg == 0 || cfg == 4 || (cfg == 1 && v2small)) && window_ok && w_bytes < 0xFFFFFF00ull) {
     k.in_bytes = (size_t)in_bytes;
     k.w_bytes = (unsigned)w_bytes;

@@ -141,7 +141,8 @@ def sparse_conv(feats, Cin, pc, table, relu=True, res=None, out=None, out_rows=N
     d.M, d.Cin, d.Cout, d.taps = Mo, Cin, pc.Cout, taps
     d.in_stride, d.out_stride = feats.shape[1], out.shape[1]
     d.res_stride = res.shape[1] if res is not None else 0
-    d.B = d.Xi = d.Yi = d.Zi = d.Xo = d.Yo = d.Zo = 1
+    d.B = d.Yi = d.Zi = d.Xo = d.Yo = d.Zo = 1
+    d.Xi = feats.shape[0]          # number of input rows (lets coocc_conv_fwd pick the pipelined row-table kernel)
     d.ksize, d.stride, d.pad = 1, 1, 0
     d.relu, d.res_mode, d.splitk, d.tile_hint = int(relu), (1 if res is not None else 0), 1, TILE_HINT
     with _lib.TIMER.region("k_conv<sparse table %d->%d>" % (Cin, pc.Cout), 2.0 * Mo * Cin * pc.Cout * taps):
