@@ -316,3 +316,23 @@ def test_conv_large_volume_beyond_4gb_offsets(dev, monkeypatch):
         crop = x[:, :, x0:cx + 2, y0:cy + 2, z0:cz + 2]
         ref = F.conv3d(crop, w, padding=1)[0, :, cx - x0, cy - y0, cz - z0]
         assert_close(direct[0, :, cx, cy, cz].cpu(), ref, what="direct vs torch at %s" % ((cx, cy, cz),))
+
+
+@pytest.mark.parametrize("use_res", [False, True])
+def test_pointwise_conv_persistent_kernel_ragged(dev, use_res):
+    """1x1x1 stride-1 layers with more than 768 tiles take k_conv2p<false, true> (persistent, full epilogue): ragged row
+    count (last tile partly outside M), ragged Cout (last N tile partly outside), BN scale/shift, residual, ReLU."""
+    g = torch.Generator().manual_seed(9)
+    X, Y, Z, Cin, Cout = 103, 97, 10, 64, 160          # M = 99910 = 780 * 128 + 70
+    x = torch.randn(1, Cin, X, Y, Z, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, 1, generator=g) * 0.1
+    bn = bn_like(Cout, g)
+    res = torch.randn(1, Cout, X, Y, Z, generator=g) if use_res else None
+    ref = bn(F.conv3d(x, w))
+    if use_res:
+        ref = ref + res
+    ref = F.relu(ref).detach()
+    pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=1, stride=1, pad=0)
+    assert core.conv_kernel_name(X * Y * Z, Cout, False, 0, 2, True) == "k_conv2p<1x1>"
+    out = core.conv_rows(rows_of(x, dev), pc, relu=True, res=rows_of(res, dev) if use_res else None)
+    assert_close(out.as_ncdhw().cpu(), ref, what="persistent 1x1 conv")
