@@ -350,6 +350,46 @@ def gather_rows(src, idx):
     return GatherRowsFn.apply(src, idx)
 
 
+class ScatterRowsFn(torch.autograd.Function):
+    """out = zeros [nrows, C]; out[idx[r]] = vals[r] (idx unique, negative entries skipped); backward gathers."""
+
+    @staticmethod
+    def forward(ctx, vals, idx, nrows):
+        assert vals.dim() == 2 and vals.shape[1] % 4 == 0 and idx.dtype == torch.int32
+        C = vals.shape[1]
+        out = torch.zeros(nrows, C, device=vals.device, dtype=_F32)
+        call("coocc_scatter_add_rows", ptr(vals.float().contiguous()), C, ptr(idx.contiguous()), idx.numel(), C, ptr(out), C)
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        C = dout.shape[1]
+        dv = torch.empty(idx.numel(), C, device=dout.device, dtype=_F32)
+        call("coocc_gather_rows", ptr(dout.float().contiguous()), C, ptr(idx.contiguous()), idx.numel(), C, ptr(dv), C)
+        return dv, None, None
+
+
+def fuser_fuse_train(fuser, img_rows, pts_rows, sr):
+    """Differentiable G1 (bifuser_n.py:138-169) on rows: the neighbour tables of a ``BiFuser_N.search`` result are
+    indices (not differentiated, as upstream); gradients reach both feature volumes and ``knn_enc``.
+    img_rows / pts_rows: [V, C] channels-last rows of the two inputs -> [V, 4C] = (img | pts | fused_img | fused_pts).
+    The gate product and the concat are torch elementwise / copy ops; gather, Linear and scatter are the HIP kernels."""
+    V, C = img_rows.shape
+    W, b = fuser.knn_enc[0].weight, fuser.knn_enc[0].bias
+
+    def direction(src, rows, out_idx, gate_src):
+        if rows is None or rows.shape[1] == 0:
+            return torch.zeros(V, C, device=src.device, dtype=_F32)
+        g = torch.cat([gather_rows(src, rows[k].contiguous()) for k in range(rows.shape[0])], 1)
+        y = linear_rows(g, W, b, relu=True) * gather_rows(gate_src, out_idx)
+        return ScatterRowsFn.apply(y, out_idx, V)
+    fused_img = direction(img_rows, sr.rows, sr.lin_pts, pts_rows)
+    fused_pts = direction(pts_rows, sr.rows_p, sr.lin_img, img_rows)
+    return torch.cat([img_rows, pts_rows, fused_img, fused_pts], 1)
+
+
 # ----------------------------------------------------------------------------- P2 pooling
 class LiftSplatFn(torch.autograd.Function):
     """Fused lift (x) splat (view_transformer.lift_splat) with gradients for depth_prob and the context features."""

@@ -103,6 +103,47 @@ class COOCC_Ray(nn.Module):
             res.update(rgbs=rgbs, depths=depths, render_maps=maps)
         return res
 
+    def forward_train_hot_path(self, img_voxel_feats, pts_voxel_feats, gemo=None, img_feats=None, transform=None,
+                               coarse_lin=None, render=True, generator=None):
+        """Differentiable counterpart of ``forward_hot_path`` (frozen-statistics BN, as in ``co_occ_amd.autograd``):
+        K1-K5 run as in inference (indices are not differentiated, as upstream), everything after them is an autograd
+        Function over the HIP kernels.  Returns rows / tensors with ``grad_fn``:
+        ``voxel_rows`` [V,C] (con_enc output), ``levels`` [(rows, geom)], ``out_voxel_rows`` [V,128], ``logit_rows``
+        [V,ncls], ``fine_logits`` [8n,ncls] + ``fine_xyz`` [3,8n], ``rgbs`` / ``depths`` of the render block.
+        ``coarse_lin``: int32 rows of the coarse voxels whose children the fine branch evaluates; default: the
+        foreground voxels (argmax != empty), randomly thinned to ``fine_topk // ratio^3`` of them (the reference draws
+        its training-time top-k among fine points, occ_head.py:204-205; here whole coarse voxels are drawn).
+        The semantic losses (CE / lovasz / scal) are out of scope: apply them to the returned logits."""
+        from . import autograd as ag
+        B, C, X, Y, Z = img_voxel_feats.shape
+        assert B == 1, "batch size 1 per GPU (coocc_ray.py:365)"
+        V = X * Y * Z
+        with torch.no_grad():
+            sr = self.occ_fuser.search(img_voxel_feats.detach(), pts_voxel_feats.detach())
+        rows = lambda t: t.float().permute(0, 2, 3, 4, 1).reshape(V, C)
+        cat4 = ag.fuser_fuse_train(self.occ_fuser, rows(img_voxel_feats).contiguous(), rows(pts_voxel_feats).contiguous(), sr)
+        ce = self.occ_fuser.con_enc
+        vf, geom = ag.conv3d_rows(cat4, ce[0].weight, (1, X, Y, Z), bias=ce[0].bias, bn=ce[1], relu=True)
+        vf, geom = ag.conv3d_rows(vf, ce[3].weight, geom, bias=ce[3].bias, bn=ce[4], relu=True)
+        levels = ag.trunk_forward_train(None, self.semantic_encoder, self.semantic_neck, vf, geom)
+        head = self.pts_bbox_head
+        out_rows, logit_rows = ag.occhead_coarse_train(head, levels)
+        res = dict(voxel_rows=vf, levels=levels, out_voxel_rows=out_rows, logit_rows=logit_rows)
+        if head.cascade_ratio != 1 and (head.sample_from_img or head.sample_from_voxel):
+            if coarse_lin is None:
+                fg = torch.nonzero(logit_rows.detach().argmax(1) != head.empty_idx).flatten()
+                cap = max(1, int(head.fine_topk) // head.cascade_ratio ** 3)
+                if fg.numel() > cap:
+                    sel = torch.randperm(fg.numel(), generator=generator, device=fg.device if generator is None else generator.device)[:cap]
+                    fg = fg[sel.to(fg.device)].sort().values
+                coarse_lin = fg.int()
+            if coarse_lin.numel():
+                res["fine_logits"], res["fine_xyz"] = ag.fine_branch_train(head, out_rows, (1, X, Y, Z), coarse_lin.contiguous(),
+                                                                           img_feats, transform)
+        if render and self.use_rendering:
+            res["rgbs"], res["depths"] = ag.render_block_train(self.sigma_head, self.rgb_head, vf, (X, Y, Z), gemo)
+        return res
+
     def render_losses(self, rgbs, depths, rgb_gt, depth_gt, D):
         """coocc_ray.py:423-433."""
         return render_losses(rgbs, depths, rgb_gt, depth_gt, D)

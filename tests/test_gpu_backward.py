@@ -553,3 +553,81 @@ def test_syncbn_two_ranks_one_gpu():
     import syncbn_worker
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(syncbn_worker.run, args=(2, port), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("case", ["fuser_k2", "fuser_small_k1", "fuser_k2_far"])
+def test_fuser_g1_backward_vs_oracle_autograd(dev, case):
+    """G1 of BiFuser_N as a differentiable composition (gather -> knn_enc -> gate -> scatter, autograd.fuser_fuse_train)
+    over the neighbour tables of the inference search: forward equals the inference concat rows; the gradients of both
+    feature volumes and of knn_enc equal torch autograd through the oracle's restatement of bifuser_n.py:127-171
+    (incl. the -1 -> last-row quirk and the small-Q branch)."""
+    from oracle import cases, ref_cpu
+    import co_occ_amd.synth as synth
+    c = cases.FUSER_CASES[case]
+    img, pts = cases.fuser_inputs(c)
+    C = c["C"]
+    f = pkg.BiFuser_N(C, C, c["knum"])
+    sd = synth.random_state_dict(f.state_dict(), seed=c["seed"])
+    f.load_state_dict(sd)
+    g = torch.Generator().manual_seed(3)
+    # oracle with autograd
+    ir, pr = img.clone().requires_grad_(), pts.clone().requires_grad_()
+    sdr = {k: (v.clone().float().requires_grad_() if k.startswith("knn_enc") else v.clone()) for k, v in sd.items()}
+    allf = ref_cpu.bifuser_fuse(sdr, ir, pr, c["knum"])["all_feats"]                     # [1,X,Y,Z,4C]
+    G = torch.randn(allf.shape, generator=g)
+    (allf * G).sum().backward()
+    # ours
+    f = f.to(dev).eval()
+    with torch.no_grad():
+        sr = f.search(img.to(dev), pts.to(dev))
+        want_rows = f.finish(sr)[0].t.clone()
+    torch.cuda.synchronize()
+    V = img.shape[2] * img.shape[3] * img.shape[4]
+    rows = lambda t: t.permute(0, 2, 3, 4, 1).reshape(V, -1).contiguous()
+    xi, xp = rows(img).to(dev).requires_grad_(), rows(pts).to(dev).requires_grad_()
+    out = ag.fuser_fuse_train(f, xi, xp, sr)
+    assert_close(out.detach().cpu(), want_rows.cpu(), tol=1e-6, what="fuse forward vs inference rows")
+    assert_close(out.detach().cpu().view(allf.shape), allf.detach(), what="fuse forward vs oracle")
+    (out * G.view(V, -1).to(dev)).sum().backward()
+    assert_close(xi.grad.cpu(), rows(ir.grad), what="d img feats")
+    assert_close(xp.grad.cpu(), rows(pr.grad), what="d pts feats")
+    assert_close(f.knn_enc[0].weight.grad.cpu(), sdr["knn_enc.0.weight"].grad, what="d knn_enc.weight")
+    assert_close(f.knn_enc[0].bias.grad.cpu(), sdr["knn_enc.0.bias"].grad, what="d knn_enc.bias")
+
+
+def test_detector_forward_train_hot_path_matches_inference_and_backpropagates(dev):
+    """COOCC_Ray.forward_train_hot_path: same numbers as the inference forward (fused volume, coarse logits, fine logits
+    of the same coarse voxels, rendered maps) and a backward pass that reaches the two input volumes, the image features
+    and every parameter of fuser / encoder / neck / head / render heads."""
+    import co_occ_amd.synth as synth
+    grid, C = (50, 50, 8), 32
+    cfg = synth.model_cfg(C=C, knum=2, final_occ_size=(100, 100, 16), point_cloud_range=(-25, -25, -5.0, 25, 25, 3.0),
+                          input_size=(64, 176))
+    model = pkg.build_detector(cfg)
+    model.load_state_dict(synth.random_state_dict(model.state_dict(), seed=21))
+    model = model.to(dev).eval()
+    img, pts = synth.voxel_inputs(grid, C=C, seed=31)
+    rig = synth.camera_rig(6, (64, 176), seed=31)
+    r = {k: v.to(dev) for k, v in rig.items() if torch.is_tensor(v)}
+    gemo = model.img_view_transformer.get_geometry(r["rots"], r["trans"], r["intrins"], r["post_rots"], r["post_trans"], r["bda"])
+    img_feats = [synth.image_feats(6, (4, 11), 512, seed=31).to(dev).requires_grad_()]
+    tr = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synth.rig_transform(rig))
+    # the render block's bounds are those of a 100x100x8 volume (coocc_ray.py:577): render only checked for finiteness here
+    with torch.no_grad():
+        want = model.forward_hot_path(img.to(dev), pts.to(dev), gemo, [img_feats[0].detach()], tr, render=False)
+    xi, xp = img.to(dev).requires_grad_(), pts.to(dev).requires_grad_()
+    lin_all = torch.nonzero(want["pred_c"][0].argmax(0).flatten() != model.pts_bbox_head.empty_idx).flatten().int()
+    out = model.forward_train_hot_path(xi, xp, gemo, img_feats, tr, coarse_lin=lin_all, render=False)
+    V = grid[0] * grid[1] * grid[2]
+    assert_close(out["voxel_rows"].detach().cpu(), want["voxel_feats"].permute(0, 2, 3, 4, 1).reshape(V, -1).cpu(), what="voxel_feats")
+    assert_close(out["logit_rows"].detach().cpu(), want["pred_c"].permute(0, 2, 3, 4, 1).reshape(V, -1).cpu(), what="coarse logits")
+    assert torch.equal(out["fine_xyz"].cpu(), want["output_coords_fine"][0].cpu())
+    assert_close(out["fine_logits"].detach().cpu(), want["output_voxels_fine"][0].cpu(), tol=2e-4, what="fine logits")
+    loss = out["logit_rows"].square().mean() + out["fine_logits"].square().mean()
+    loss.backward()
+    for name, t in (("img volume", xi), ("pts volume", xp), ("img feats", img_feats[0])):
+        assert t.grad is not None and torch.isfinite(t.grad).all() and float(t.grad.abs().max()) > 0, name
+    skip = ("sigma_head", "rgb_head", "img_view_transformer")
+    missing = [n for n, p in model.named_parameters()
+               if p.requires_grad and not n.startswith(skip) and p.dim() > 1 and (p.grad is None or not torch.isfinite(p.grad).all())]
+    assert not missing, missing[:5]
