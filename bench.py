@@ -258,7 +258,9 @@ def main():
                 pass
             # direct-convolution-equivalent rate of the same launches: F(m x m,3x3) needs 9 m^2/(m+2)^2 x fewer multiplies
             equiv = v["equiv"] / v["work"]
-            roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+            symbol = {"k_conv2<160,wg> wino": "k_conv2<160, 2, true, 2, false>", "k_conv2p wino": "k_conv2p<true, false>",
+                      "k_conv2<128,wg> wino": "k_conv2<128, 1, true, 3, false>"}.get(dom, dom)     # name in the rocprofv3 trace
+            roof = dict(bound="mfma", kernel=dom, symbol=symbol, achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=traffic, launches=v["launches"],
                         avg_launch_ms=round(v["ms"] / v["launches"], 4),
                         share_of_timed_kernels=round(v["ms"] / tot, 3),
