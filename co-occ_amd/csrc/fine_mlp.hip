@@ -223,6 +223,7 @@ extern "C" int coocc_fine_mlp(const float* samp, int samp_stride, const float* v
                               float eps_img, const float* w_f0, const float* b_f0, const float* gn_f0_w,
                               const float* gn_f0_b, float eps_f0, const float* w_f3, const float* b_f3, int ncls,
                               float* out, void* stream) {
+  if (nfine == 0) return COOCC_OK;          // nothing selected: empty tensors carry null pointers
   COOCC_CHECK_ARG(samp && vox && out && w_img && b_img && gn_img_w && gn_img_b && w_f0 && b_f0 && gn_f0_w && gn_f0_b &&
                       w_f3 && b_f3, "fine_mlp: null pointer");
   COOCC_CHECK_ARG(nfine >= 0 && ncls >= 1 && ncls <= 32 && samp_stride >= 128 && vox_stride >= 128 &&
@@ -248,6 +249,7 @@ extern "C" int coocc_fine_mlp_pre(const float* samp64, int samp_stride, const fl
                                   const float* b_img, const float* gn_img_w, const float* gn_img_b, float eps_img,
                                   const float* w_f0, const float* b_f0, const float* gn_f0_w, const float* gn_f0_b,
                                   float eps_f0, const float* w_f3, const float* b_f3, int ncls, float* out, void* stream) {
+  if (nfine == 0) return COOCC_OK;
   COOCC_CHECK_ARG(samp64 && vox64 && out && b_img && gn_img_w && gn_img_b && w_f0 && b_f0 && gn_f0_w && gn_f0_b && w_f3 && b_f3,
                   "fine_mlp_pre: null pointer");
   COOCC_CHECK_ARG(nfine >= 0 && ncls >= 1 && ncls <= 32 && samp_stride >= 64 && vox_stride >= 64 && samp_stride % 4 == 0 &&

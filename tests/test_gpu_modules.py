@@ -536,3 +536,17 @@ def test_fine_mlp_pre_kernel_vs_torch(dev, nf, ncls):
     call("coocc_fine_mlp_pre", ptr(samp_d), 72, ptr(ts[0]), 64, nf, ptr(ts[1]), ptr(ts[2]), ptr(ts[3]), 1e-5,
          ptr(ts[4]), ptr(ts[5]), ptr(ts[6]), ptr(ts[7]), 1e-5, ptr(ts[8]), ptr(ts[9]), ncls, ptr(out))
     assert_close(out.cpu(), want, what="fine_mlp_pre")
+
+
+def test_fine_mlp_entry_points_accept_zero_points(dev):
+    """nfine = 0 (no foreground voxel selected): both fused entry points return without launching."""
+    from co_occ_amd._lib import call, ptr
+    z = torch.zeros(64, 192, device=dev)
+    v = torch.zeros(64, device=dev)
+    e = torch.empty(0, 128, device=dev)
+    out = torch.empty(0, 17, device=dev)
+    call("coocc_fine_mlp", ptr(e), 128, ptr(e), 128, 0, ptr(z[:, :128].contiguous()), ptr(v), ptr(v), ptr(v), 1e-5, ptr(z), ptr(v),
+         ptr(v), ptr(v), 1e-5, ptr(z[:17, :64].contiguous()), ptr(v[:17].contiguous()), 17, ptr(out))
+    call("coocc_fine_mlp_pre", ptr(e), 64, ptr(e), 64, 0, ptr(v), ptr(v), ptr(v), 1e-5, ptr(z), ptr(v), ptr(v), ptr(v), 1e-5,
+         ptr(z[:17, :64].contiguous()), ptr(v[:17].contiguous()), 17, ptr(out))
+    torch.cuda.synchronize()
