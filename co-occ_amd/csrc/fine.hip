@@ -338,6 +338,18 @@ __global__ __launch_bounds__(256) void k_fine_sample_img_g8(const float* __restr
     x0 = (int)flx; y0 = (int)fly;
     ax = px - flx; ay = py - fly;
   }
+  // per (child, camera) lane: the four tap offsets (pixels, clamped into the map) and weights (0 outside the map), so the
+  // channel loop below only broadcasts them (readlane) and issues load + fma per tap
+  int toff[4]; float tw[4];
+#pragma unroll
+  for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+    for (int xx = 0; xx < 2; ++xx) {
+      const int x = x0 + xx, y = y0 + yy;
+      const bool in = (unsigned)x < (unsigned)Wf && (unsigned)y < (unsigned)Hf;
+      toff[yy * 2 + xx] = in ? y * Wf + x : 0;
+      tw[yy * 2 + xx] = in ? (xx ? ax : 1.f - ax) * (yy ? ay : 1.f - ay) : 0.f;
+    }
   const unsigned long long seen = __ballot(m != 0);
   for (int c = lane; c < Ci; c += 64) {
     float acc[8];
@@ -347,21 +359,14 @@ __global__ __launch_bounds__(256) void k_fine_sample_img_g8(const float* __restr
       for (int cam = 0; cam < ncam; ++cam) {
         const int k = o * ncam + cam;
         if (!((seen >> k) & 1ull)) continue;                       // wave-uniform
-        const int xk = __builtin_amdgcn_readlane(x0, k), yk = __builtin_amdgcn_readlane(y0, k);
-        const float axk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ax), k));
-        const float ayk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ay), k));
-        const float* base = img + (size_t)cam * Hf * Wf * Ci;
+        const float* base = img + (size_t)cam * Hf * Wf * Ci + c;
         float a = acc[o];
 #pragma unroll
-        for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-          for (int xx = 0; xx < 2; ++xx) {
-            const int x = xk + xx, y = yk + yy;
-            if ((unsigned)x < (unsigned)Wf && (unsigned)y < (unsigned)Hf) {
-              const float w = (xx ? axk : 1.f - axk) * (yy ? ayk : 1.f - ayk);
-              a = a + base[((size_t)y * Wf + x) * Ci + c] * w;
-            }
-          }
+        for (int t = 0; t < 4; ++t) {
+          const int off = __builtin_amdgcn_readlane(toff[t], k);
+          const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tw[t]), k));
+          if (w != 0.f) a = a + base[(size_t)off * Ci] * w;          // wave-uniform; keeps the reference's skipped taps skipped
+        }
         acc[o] = a;
       }
     }
