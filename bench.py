@@ -71,11 +71,19 @@ def step(model, s, world, search=None):
         # completed first (at most one in flight), so it overlaps the whole next dense stage instead of delaying it
         if _pending:
             _pending.pop().wait()
-        _pending.append(cdist.all_gather_maps_async(out["rgbs"], out["depths"]))
+        if _async_ok[0]:
+            try:
+                _pending.append(cdist.all_gather_maps_async(out["rgbs"], out["depths"]))
+                return out
+            except Exception as e:        # a backend without asynchronous all-gather: blocking form from here on
+                _async_ok[0] = False
+                print("bench: asynchronous all-gather unavailable (%s); using the blocking form" % e, file=sys.stderr)
+        out["all_rgbs"], out["all_depths"] = cdist.all_gather_maps(out["rgbs"], out["depths"])
     return out
 
 
 _pending = []
+_async_ok = [True]
 
 
 def drain_gathers():
