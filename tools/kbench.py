@@ -279,6 +279,27 @@ def bench_trainfull():
         print("   %-44s %3d launches %8.2f ms%s" % (k, r["launches"], r["ms"], "  %.0f TFLOP/s" % (r["work"] / r["ms"] / 1e9) if r["work"] else ""))
 
 
+def bench_r3():
+    """R3, the library renderer (P/utils/render_ray.py; dead code upstream) at the config's ray budget: N_rand = 4096 rays x
+    N_samples = 64 (coocc_multi_r50_256x704.py:82-84), trilinear volume_sampling of the 128-channel 100x100x8 volume, heads per
+    sample, raw2outputs.  Algorithmic bytes: N_rays*N_samples*(12 + 8*C*4) worst case for the gather."""
+    from co_occ_amd import render as R
+    g = torch.Generator().manual_seed(2)
+    C, NR, NS = 128, 4096, 64
+    feats = torch.randn(1, C, 8, 100, 100, generator=g).to(dev)          # [1,C,D,W,H]
+    o = torch.tensor([0.0, 0.0, -1.0]).expand(NR, 3)
+    d = torch.randn(NR, 3, generator=g); d = d / d.norm(dim=1, keepdim=True)
+    pts, z = R.sample_along_camera_ray(o.to(dev), d.to(dev), (0.2, 60.0), NS, det=True)
+    aabb = (torch.tensor([-50.0, -50.0, -5.0]), torch.tensor([50.0, 50.0, 3.0]))
+    t1 = timeit(lambda: R.volume_sampling(pts, feats, aabb), n=10)
+    f, m = R.volume_sampling(pts, feats, aabb)
+    raw = torch.randn(NR, NS, 4, generator=g).to(dev)
+    t2 = timeit(lambda: R.raw2outputs(raw, z), n=10)
+    by = NR * NS * (12.0 + 8 * C * 4) + NR * NS * C * 4
+    print("R3  %d rays x %d samples: volume_sampling %.3f ms (%.0f GB/s of the worst-case gather + output bytes, %.0f%% of points in the box)"
+          "  raw2outputs %.3f ms" % (NR, NS, t1, by / t1 / 1e6, 100.0 * float(m.float().mean()), t2))
+
+
 def bench_lidar():
     """LiDAR producer at nuScenes scale: ~280 k points (10 sweeps) -> 0.125 m voxels on [800,800,64] -> 8x sparse encoder."""
     from co_occ_amd import lidar as L
