@@ -23,9 +23,11 @@ def _rng(seed, key=""):
     return np.random.default_rng([int(seed) & 0x7FFFFFFF, zlib.crc32(key.encode())])
 
 
-def random_state_dict(reference_sd, seed=0):
+def random_state_dict(reference_sd, seed=0, gain=1.0):
     """Fill a state_dict-shaped mapping with seeded values: kaiming-scaled weights, non-trivial
-    eval-mode norm statistics (mean~N(0,.1), var~U(.5,1.5), gamma~U(.5,1.5), beta~N(0,.1))."""
+    eval-mode norm statistics (mean~N(0,.1), var~U(.5,1.5), gamma~U(.5,1.5), beta~N(0,.1)).
+    ``gain`` multiplies every conv / linear weight (gain < 1 keeps the decoder's logits O(1-10), where the
+    north_star's ABSOLUTE 1e-4 bound is meaningful; the kaiming default lets them grow to ~1e2)."""
     out = {}
     for k, v in reference_sd.items():
         shape = tuple(v.shape)
@@ -48,7 +50,7 @@ def random_state_dict(reference_sd, seed=0):
             a = g.normal(0, 1.0, shape)
         else:
             fan_in = int(np.prod(shape[1:]))
-            a = g.normal(0, math.sqrt(2.0 / fan_in), shape)
+            a = g.normal(0, gain * math.sqrt(2.0 / fan_in), shape)
         out[k] = torch.from_numpy(np.asarray(a, dtype=np.float32)).to(v.dtype)
     return out
 

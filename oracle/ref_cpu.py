@@ -43,6 +43,20 @@ def _sub(sd, prefix):
     return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
+def to_dtype(obj, dtype):
+    """Cast every floating tensor in a (nested) dict / list / tuple to ``dtype`` -- the fp64 ANCHOR mode of the oracle:
+    every function below computes in the dtype of its inputs, so ``to_dtype(sd, torch.float64)`` + fp64 inputs evaluate
+    the same restatement in double precision (used by the parity tests to judge fp32 errors of ill-conditioned outputs:
+    ``err(HIP, fp64) <= c * err(oracle fp32, fp64)``)."""
+    if torch.is_tensor(obj):
+        return obj.to(dtype) if obj.is_floating_point() else obj
+    if isinstance(obj, dict):
+        return {k: to_dtype(v, dtype) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(to_dtype(v, dtype) for v in obj)
+    return obj
+
+
 # --------------------------------------------------------------------------- K1..K5
 def voxel_nonzero(feats):
     """K1: ``torch.nonzero(feats.sum(1))`` (P/coocc/fuser/bifuser_n.py:130-131).
@@ -118,9 +132,9 @@ def bifuser_fuse(sd, img_voxel_feats, pts_voxel_feats, knum):
         g = torch.cat([at(pts_cl, inds_img[near_pts[i]]) for i in range(knum)], 1)   # sic (:158)
     fused_pts_rows = knn_enc(g) * sel_img
 
-    fused_img = torch.zeros(B, X, Y, Z, C)
+    fused_img = torch.zeros(B, X, Y, Z, C, dtype=img_voxel_feats.dtype)
     fused_img[inds_pts[:, 0], inds_pts[:, 1], inds_pts[:, 2], inds_pts[:, 3]] = fused_img_rows
-    fused_pts = torch.zeros(B, X, Y, Z, C)
+    fused_pts = torch.zeros(B, X, Y, Z, C, dtype=img_voxel_feats.dtype)
     fused_pts[inds_img[:, 0], inds_img[:, 1], inds_img[:, 2], inds_img[:, 3]] = fused_pts_rows
     allf = torch.cat([img_cl, pts_cl, fused_img, fused_pts], -1)
     return dict(all_feats=allf, inds_img=inds_img, inds_pts=inds_pts, near_img=near_img, near_pts=near_pts)
@@ -186,7 +200,7 @@ def occhead_coarse(sd, voxel_feats, soft_weights=True):
     if soft_weights:
         w = torch.softmax(_seq_1x1(sd, occs[0], "voxel_soft_weights"), dim=1)
     else:
-        w = torch.ones(occs[0].shape[0], n, 1, 1, 1) / n
+        w = torch.ones(occs[0].shape[0], n, 1, 1, 1, dtype=occs[0].dtype) / n
     size = occs[0].shape[2:]
     out = 0
     for f, wi in zip(occs, torch.unbind(w, dim=1)):
@@ -208,7 +222,7 @@ def project_points_on_img(points, rots, trans, intrins, post_rots, post_trans, b
                           W_img, H_img, W_occ, H_occ, D_occ):
     """P/utils/coordinate_transform.py:25-65, nuScenes branch. points [1,N,3] ->
     uv [n_cam,N,1,2] in [-1,1], mask [1,N,n_cam]... returned as in the reference."""
-    voxel_size = (pts_range[3:] - pts_range[:3]) / torch.tensor([W_occ - 1, H_occ - 1, D_occ - 1])
+    voxel_size = (pts_range[3:] - pts_range[:3]) / torch.tensor([W_occ - 1, H_occ - 1, D_occ - 1]).to(pts_range.dtype)
     points = points * voxel_size[None, None] + pts_range[:3][None, None]
     points = (bda_mat.inverse() @ points.unsqueeze(-1)).squeeze(-1)
     points = points.view(-1, 1, 3) - trans.view(1, -1, 3)
@@ -239,8 +253,9 @@ def occhead_forward(sd, voxel_feats, img_feats, transform, cascade_ratio=2, fina
     _, W, H, D = mask.shape
     coarse_coord = torch.nonzero(mask[0]).t()                  # [3,N] ascending (x,y,z) == masked meshgrid
     fine = coarse_to_fine_coordinates(coarse_coord, cascade_ratio)
-    new_coord = fine[None].permute(0, 2, 1).float().contiguous()
-    g = fine.float()
+    dt = ovf.dtype
+    new_coord = fine[None].permute(0, 2, 1).to(dt).contiguous()
+    g = fine.to(dt)
     g = torch.stack([(g[i] / (final_occ_size[i] - 1) - 0.5) * 2 for i in range(3)], 0)
     grid = g[None, None, None].permute(0, 4, 1, 2, 3)          # [1,N,1,1,3]
     vox = F.grid_sample(ovf[0:1].permute(0, 1, 4, 3, 2), grid, mode="bilinear", padding_mode="zeros",
@@ -251,7 +266,7 @@ def occhead_forward(sd, voxel_feats, img_feats, transform, cascade_ratio=2, fina
     f = F.conv2d(f.reshape(-1, C_i, W_i, H_i), sd["img_mlp_0.0.weight"], sd["img_mlp_0.0.bias"])
     f = F.relu(F.group_norm(f, 16, sd["img_mlp_0.1.weight"], sd["img_mlp_0.1.bias"]))
     f = f.reshape(B_i, N_i, -1, W_i, H_i)
-    pr = torch.tensor(np.array(point_cloud_range)).float()
+    pr = torch.tensor(np.array(point_cloud_range)).float().to(dt)
     uv, m = project_points_on_img(new_coord, transform[0][0:1], transform[1][0:1], transform[2][0:1],
                                   transform[3][0:1], transform[4][0:1], transform[5][0:1], pr,
                                   W_img=transform[-1][1][0:1], H_img=transform[-1][0][0:1],
@@ -270,7 +285,7 @@ def occhead_forward(sd, voxel_feats, img_feats, transform, cascade_ratio=2, fina
 
 def scatter_fine(fine_pred, fine_coord, out_size, empty_idx=0):
     """``simple_test`` fine scatter (P/coocc/detectors/coocc_ray.py:546-550)."""
-    pred = torch.full((1, fine_pred.shape[1]) + tuple(out_size), float(empty_idx))
+    pred = torch.full((1, fine_pred.shape[1]) + tuple(out_size), float(empty_idx), dtype=fine_pred.dtype)
     pred[:, :, fine_coord[0], fine_coord[1], fine_coord[2]] = fine_pred.permute(1, 0)[None]
     return pred
 
@@ -359,7 +374,7 @@ def render_camera(sigma_sd, rgb_sd, voxel_feats, geom, literal=True):
     """R2, one camera: coocc_ray.py:575-616 (test) == :368-411 (train).
     voxel_feats [C,X,Y,Z], geom [D,H,W,3] ego metres -> rgb_map [H,W,3], depth_map [H,W]
     (pre-upsample).  ``literal=False`` evaluates the heads once per voxel (F5)."""
-    dx, bx, nx = gen_dx_bx(*RENDER_BOUNDS)
+    dx, bx, nx = (t.to(geom.dtype) for t in gen_dx_bx(*RENDER_BOUNDS))
     g = (geom - (bx - dx / 2.)) / dx
     inside = (g[..., 0] >= 0) & (g[..., 0] < nx[0]) & (g[..., 1] >= 0) & (g[..., 1] < nx[1]) \
         & (g[..., 2] >= 0) & (g[..., 2] < nx[2])
@@ -379,14 +394,14 @@ def render_camera(sigma_sd, rgb_sd, voxel_feats, geom, literal=True):
         rgb, sigma = rgb_t[lin], sig_t[lin].squeeze(-1)
     rgb = torch.sigmoid(rgb * mask.unsqueeze(-1))   # rgb[~mask] = 0 ; sigmoid
     sigma = F.relu(sigma)
-    p = pts.float()
+    p = pts.to(geom.dtype)
     dists = torch.norm(p[:, :, 1:, :] - p[:, :, :-1, :], dim=-1)
     dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e10)], -1)
     alpha = 1. - torch.exp(-F.relu(sigma * dists))
-    trans = torch.cumprod(torch.cat([torch.ones(H, W, 1), 1. - alpha + 1e-10], -1), -1)[:, :, :-1]
+    trans = torch.cumprod(torch.cat([torch.ones(H, W, 1, dtype=alpha.dtype), 1. - alpha + 1e-10], -1), -1)[:, :, :-1]
     weights = alpha * trans
     rgb_map = torch.sum(weights.unsqueeze(-1) * rgb, dim=-2)
-    z_vals = torch.linspace(0, D, D).reshape(1, 1, D)
+    z_vals = torch.linspace(0, D, D).reshape(1, 1, D).to(alpha.dtype)
     depth_map = torch.sum(weights * z_vals, dim=-1)
     return rgb_map, depth_map
 
@@ -475,14 +490,22 @@ def get_weights(sigma, z_vals):
 
 # --------------------------------------------------------------------------- whole path
 def hot_path_forward(sd, img_voxel_feats, pts_voxel_feats, gemo, img_feats, transform, knum=2,
-                     cascade_ratio=2, final_occ_size=(200, 200, 16), literal_render=True):
+                     cascade_ratio=2, final_occ_size=(200, 200, 16), literal_render=True, dtype=None,
+                     point_cloud_range=(-50, -50, -5.0, 50, 50, 3.0), render=True):
     """``COOCC_Ray.simple_test`` between the encoders and the metrics (coocc_ray.py:523-627)
-    with ``test_rendering=True``: fuser -> encoder -> neck -> head -> render."""
+    with ``test_rendering=True``: fuser -> encoder -> neck -> head -> render.
+    ``dtype=torch.float64`` evaluates the same restatement in double precision (the anchor of the fp32 parity tests)."""
+    if dtype is not None:
+        sd, img_voxel_feats, pts_voxel_feats, gemo, img_feats, transform = to_dtype(
+            (dict(sd), img_voxel_feats, pts_voxel_feats, gemo, img_feats, tuple(transform)), dtype)
     vf = bifuser_forward(_sub(sd, "occ_fuser."), img_voxel_feats, pts_voxel_feats, knum)
     mid = resnet3d_forward(_sub(sd, "semantic_encoder."), vf)
     sem = fpn3d_forward(_sub(sd, "semantic_neck."), mid)
-    head = occhead_forward(_sub(sd, "pts_bbox_head."), sem, img_feats, transform, cascade_ratio, final_occ_size)
-    rgbs, depths = render_block(_sub(sd, "sigma_head."), _sub(sd, "rgb_head."), vf, gemo, literal_render)
+    head = occhead_forward(_sub(sd, "pts_bbox_head."), sem, img_feats, transform, cascade_ratio, final_occ_size,
+                           point_cloud_range)
+    rgbs = depths = None
+    if render:
+        rgbs, depths = render_block(_sub(sd, "sigma_head."), _sub(sd, "rgb_head."), vf, gemo, literal_render)
     return dict(voxel_feats=vf, output_voxels=head["output_voxels"], fine_output=head["fine_output"],
                 fine_coord=head["fine_coord"], rgbs=rgbs, depths=depths)
 

@@ -274,11 +274,15 @@ def test_hot_path_end_to_end_vs_oracle(dev):
     h = ref_cpu.occhead_forward(sub("pts_bbox_head."), sem, img_feats, tr, 2, (100, 100, 16), (-25, -25, -5.0, 25, 25, 3.0))
     assert_close(out["pred_c"].cpu(), h["output_voxels"], what="pred_c")
     # argmax decisions can flip on near-ties; require the occupied sets to agree almost everywhere
-    a = set(map(tuple, out["output_coords_fine"][0].cpu().t().tolist()))
-    b = set(map(tuple, h["fine_coord"].t().tolist()))
-    assert len(a ^ b) <= 0.002 * len(b) + 8
-    if a == b:
-        assert_close(out["output_voxels_fine"][0].cpu(), h["fine_output"], what="fine")
+    ia = {tuple(c): i for i, c in enumerate(out["output_coords_fine"][0].cpu().t().tolist())}
+    ib = {tuple(c): i for i, c in enumerate(h["fine_coord"].t().tolist())}
+    assert len(set(ia) ^ set(ib)) <= 0.002 * len(ib) + 8
+    common = sorted(set(ia) & set(ib))          # compared on the intersection of the two coordinate sets
+    fa = out["output_voxels_fine"][0].cpu()[torch.tensor([ia[c] for c in common])]
+    fb = h["fine_output"][torch.tensor([ib[c] for c in common])]
+    # fine logits are ill-conditioned (two 4-channel GroupNorms): the fp64-anchored sweep in test_gpu_parity_full.py is
+    # the real judge; here only a loose sanity bound against the fp32 oracle
+    assert_close(fa, fb, tol=2e-3, what="fine")
 
 
 def _flip_budget(up, tol=1e-4):
