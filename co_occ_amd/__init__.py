@@ -16,7 +16,9 @@ from .neck import FPN3D
 from .head import OccHead
 from .view_transformer import ViewTransformerLiftSplatShootVoxel
 from .render import MLP, raw2outputs, render_block, sample_along_camera_ray, volume_sampling
-from .detector import COOCC_Ray
+from .detector import COOCC_Ray, COOCC_Ray_L
+from .view_transformer import get_frustum
+from . import losses
 from . import apis, evaluation
 from . import lidar
 from .lidar import HardSimpleVFE, SparseLiDAREnc4x, SparseLiDAREnc8x, Voxelization

@@ -543,13 +543,14 @@ class RenderLossesFn(torch.autograd.Function):
 
 def render_block_train(sigma_head, rgb_head, feats2d, grid, gemo, scale=16):
     """Differentiable render block: feats2d [X*Y*Z, C] rows -> (rgbs, depths).  The per-voxel heads run through
-    ConvRowsFn (Linear+ReLU layers), so gradients reach the voxel features and both MLPs."""
+    ConvRowsFn (Linear+ReLU layers), so gradients reach the voxel features and both MLPs.  ``rgb_head=None``: the
+    depth-only branch (coocc_ray.py:436-484) -- the colour columns of the table are zero and ``rgbs`` is meaningless."""
     def mlp(m, x):
         for l in m.hidden_layers:
             x = linear_rows(x, l.weight, l.bias, relu=True)
         return linear_rows(x, m.output_layer.weight, m.output_layer.bias, relu=False)
     sig = mlp(sigma_head, feats2d)                       # [V,1]
-    rgb = mlp(rgb_head, feats2d)                         # [V,3]
+    rgb = mlp(rgb_head, feats2d) if rgb_head is not None else torch.zeros(sig.shape[0], 3, device=sig.device)   # [V,3]
     table = torch.cat([sig, rgb], 1)                     # plumbing: 16 B per voxel
     N, D, H, W = gemo.shape[-5:-1]
     maps = RenderNearestFn.apply(table, gemo.reshape(N, D, H, W, 3).float().contiguous(), tuple(grid))
@@ -589,37 +590,71 @@ def upsample_add(coarse2d, fine2d, gc, gf):
 
 
 # ----------------------------------------------------------------------------- decoder trunk (C0 + C1 + C2)
+def rows_from_ncdhw(x):
+    """[B,C,X,Y,Z] -> ([B*X*Y*Z, C] contiguous rows, (B,X,Y,Z)); differentiable (torch permute / copy)."""
+    B, C, X, Y, Z = x.shape
+    return x.float().permute(0, 2, 3, 4, 1).reshape(B * X * Y * Z, C).contiguous(), (B, X, Y, Z)
+
+
+def ncdhw_from_rows(rows, geom):
+    B, X, Y, Z = geom
+    return rows.view(B, X, Y, Z, rows.shape[1]).permute(0, 4, 1, 2, 3)
+
+
+def conv_bn_rows(x2d, weight, geom, bn=None, bias=None, stride=1, pad=None, relu=True, res2d=None):
+    """Conv3d -> BatchNorm (+res) -> ReLU on rows with the norm layer's OWN mode: a BN in training mode normalises with
+    batch (or SyncBN all-reduced) statistics and updates its running stats, as nn.BatchNorm3d / nn.SyncBatchNorm do under
+    model.train() upstream; a BN in eval mode is folded into the GEMM epilogue (frozen statistics)."""
+    if bn is not None and bn.training:
+        return conv3d_bn_train_rows(x2d, weight, geom, bn, stride=stride, pad=pad, relu=relu, res2d=res2d, bias=bias)
+    return conv3d_rows(x2d, weight, geom, bias=bias, bn=bn, stride=stride, pad=pad, relu=relu, res2d=res2d)
+
+
 def _cm(x, geom, m, relu=True):
     """mmcv-style ConvModule (conv, bn) on rows."""
-    return conv3d_rows(x, m.conv.weight, geom, bias=m.conv.bias, bn=m.bn, relu=relu)
+    return conv_bn_rows(x, m.conv.weight, geom, bias=m.conv.bias, bn=m.bn, relu=relu)
 
 
-def trunk_forward_train(con_enc, backbone, neck, x2d, geom):
-    """Differentiable con_enc -> CustomResNet3D -> FPN3D on rows (bifuser_n.py:23-30, resnet3d.py:196-205,
-    fpn3d.py:70-108) with frozen-statistics BN.  x2d: [B*X*Y*Z, 4C] fused rows.  Returns [(rows, geom)] per level.
-    The modules are the inference modules: parameters (and state_dict keys) are shared."""
-    if con_enc is not None:     # Sequential(Conv3d, BN, ReLU, Conv3d, BN, ReLU)
-        x2d, geom = conv3d_rows(x2d, con_enc[0].weight, geom, bias=con_enc[0].bias, bn=con_enc[1], relu=True)
-        x2d, geom = conv3d_rows(x2d, con_enc[3].weight, geom, bias=con_enc[3].bias, bn=con_enc[4], relu=True)
-    x, g = conv3d_rows(x2d, backbone.input_proj[0].weight, geom, bn=backbone.input_proj[1], relu=True)
+def con_enc_train(con_enc, x2d, geom):
+    """bifuser_n.py:23-30: Sequential(Conv3d, BN, ReLU, Conv3d, BN, ReLU) on rows."""
+    x2d, geom = conv_bn_rows(x2d, con_enc[0].weight, geom, bias=con_enc[0].bias, bn=con_enc[1], relu=True)
+    return conv_bn_rows(x2d, con_enc[3].weight, geom, bias=con_enc[3].bias, bn=con_enc[4], relu=True)
+
+
+def backbone_forward_train(backbone, x2d, geom):
+    """CustomResNet3D (resnet3d.py:196-205) on rows -> [(rows, geom)] per out index."""
+    x, g = conv_bn_rows(x2d, backbone.input_proj[0].weight, geom, bn=backbone.input_proj[1], relu=True)
     feats = []
     for i, layer in enumerate(backbone.layers):
         for blk in layer:
-            out, go = conv3d_rows(x, blk.conv1.weight, g, bn=blk.bn1, stride=blk.stride, relu=True)
+            out, go = conv_bn_rows(x, blk.conv1.weight, g, bn=blk.bn1, stride=blk.stride, relu=True)
             if blk.downsample is not None:
-                res, _ = conv3d_rows(x, blk.downsample[0].weight, g, bn=blk.downsample[1], stride=blk.stride, pad=0, relu=False)
+                res, _ = conv_bn_rows(x, blk.downsample[0].weight, g, bn=blk.downsample[1], stride=blk.stride, pad=0, relu=False)
             else:
                 res = x
-            x, g = conv3d_rows(out, blk.conv2.weight, go, bn=blk.bn2, relu=True, res2d=res)
+            x, g = conv_bn_rows(out, blk.conv2.weight, go, bn=blk.bn2, relu=True, res2d=res)
         if i in backbone.out_indices:
             feats.append((x, g))
-    if neck is None:
-        return feats
+    return feats
+
+
+def neck_forward_train(neck, feats):
+    """FPN3D (fpn3d.py:70-108) on [(rows, geom)]."""
     lat = [_cm(x, g, neck.lateral_convs[i][0]) for i, (x, g) in enumerate(feats)]
     for i in range(len(lat) - 1, 0, -1):
         (c, gc), (f, gf) = lat[i], lat[i - 1]
         lat[i - 1] = (upsample_add(c, f, gc, gf), gf)
     return [_cm(x, g, neck.fpn_convs[i][0]) for i, (x, g) in enumerate(lat)]
+
+
+def trunk_forward_train(con_enc, backbone, neck, x2d, geom):
+    """Differentiable con_enc -> CustomResNet3D -> FPN3D on rows (bifuser_n.py:23-30, resnet3d.py:196-205,
+    fpn3d.py:70-108); every BN follows its own training flag (conv_bn_rows).  x2d: [B*X*Y*Z, 4C] fused rows.  Returns
+    [(rows, geom)] per level.  The modules are the inference modules: parameters (and state_dict keys) are shared."""
+    if con_enc is not None:
+        x2d, geom = con_enc_train(con_enc, x2d, geom)
+    feats = backbone_forward_train(backbone, x2d, geom)
+    return feats if neck is None else neck_forward_train(neck, feats)
 
 
 # ----------------------------------------------------------------------------- OccHead coarse mix (C3)
@@ -679,18 +714,18 @@ def occhead_coarse_train(head, feats):
     occs = []
     for i, (x, g) in enumerate(feats):
         m = head.occ_convs[i]
-        o, go = conv3d_rows(x, m[0].weight, g, bias=m[0].bias, bn=m[1], relu=True)
+        o, go = conv_bn_rows(x, m[0].weight, g, bias=m[0].bias, bn=m[1], relu=True)
         occs.append((o, go))
     wlogit = None
     g0 = occs[0][1]
     if head.soft_weights:
         sw = head.voxel_soft_weights
-        h, _ = conv3d_rows(occs[0][0], sw[0].weight, g0, bias=sw[0].bias, bn=sw[1], relu=True)
-        wlogit, _ = conv3d_rows(h, sw[3].weight, g0, bias=sw[3].bias, relu=False)
+        h, _ = conv_bn_rows(occs[0][0], sw[0].weight, g0, bias=sw[0].bias, bn=sw[1], relu=True)
+        wlogit, _ = conv_bn_rows(h, sw[3].weight, g0, bias=sw[3].bias, relu=False)
     out = OccHeadMixFn.apply(wlogit, tuple(g for _, g in occs), *[o for o, _ in occs])
     pc = head.occ_pred_conv
-    h, _ = conv3d_rows(out, pc[0].weight, g0, bias=pc[0].bias, bn=pc[1], relu=True)
-    occ, _ = conv3d_rows(h, pc[3].weight, g0, bias=pc[3].bias, relu=False)
+    h, _ = conv_bn_rows(out, pc[0].weight, g0, bias=pc[0].bias, bn=pc[1], relu=True)
+    occ, _ = conv_bn_rows(h, pc[3].weight, g0, bias=pc[3].bias, relu=False)
     return out, occ
 
 
@@ -876,11 +911,11 @@ class BatchNormRowsFn(torch.autograd.Function):
         call("coocc_bn_apply", ptr(x), M, C, ptr(mean), ptr(var), ptr(g), ptr(b), float(bn.eps),
              ptr(res.float().contiguous()) if res is not None else None, int(relu), ptr(y))
         if bn.track_running_stats and bn.running_mean is not None:
-            mom = bn.momentum if bn.momentum is not None else 0.1
             with torch.no_grad():
+                bn.num_batches_tracked += 1          # torch increments first; momentum=None = cumulative moving average
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
                 bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
                 bn.running_var.mul_(1 - mom).add_(var * (count / max(count - 1, 1)), alpha=mom)
-                bn.num_batches_tracked += 1
         ctx.save_for_backward(x, y, mean, var, g)
         ctx.cfg = (float(bn.eps), int(relu), res is not None, group, count)
         return y

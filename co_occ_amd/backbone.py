@@ -11,6 +11,15 @@ from .registry import BACKBONES
 _NORMS = {"BN": nn.BatchNorm3d, "BN3d": nn.BatchNorm3d, "SyncBN": nn.SyncBatchNorm}
 
 
+def _eval_only(module):
+    """The ``forward_rows`` fast paths fold the BN running statistics and return tensors without ``grad_fn``: they are
+    inference paths.  Under ``model.train()`` the reference normalises with batch statistics and is differentiable --
+    use ``forward`` (which dispatches to co_occ_amd.autograd) or call ``.eval()`` first."""
+    if module.training:
+        raise RuntimeError("%s.forward_rows is the eval-mode (folded-BN, no autograd) path but the module is in training "
+                           "mode; call .eval(), or use forward() / co_occ_amd.autograd for training" % type(module).__name__)
+
+
 def build_bn(norm_cfg, num_features):
     """BN-family only: the hot-path configs use SyncBN/BN3d (coocc_multi_r50_256x704.py:141-160);
     GroupNorm volumes are not implemented in the HIP path."""
@@ -97,6 +106,7 @@ class CustomResNet3D(nn.Module):
         return self._packs.get(srcs, build)
 
     def forward_rows(self, x):
+        _eval_only(self)
         p = self._packed()
         x = conv_rows(to_rows(x), p["proj"], relu=True)
         res = []
@@ -108,5 +118,11 @@ class CustomResNet3D(nn.Module):
         return res
 
     def forward(self, x):
-        """[B,C,X,Y,Z] -> list of [B,C_i,X_i,Y_i,Z_i] (resnet3d.py:196-205)."""
+        """[B,C,X,Y,Z] -> list of [B,C_i,X_i,Y_i,Z_i] (resnet3d.py:196-205).  In training mode every BatchNorm uses batch
+        (SyncBN: all-rank) statistics and the outputs carry ``grad_fn`` (co_occ_amd.autograd), as upstream under
+        ``model.train()``; in eval mode BN is folded into the GEMM epilogue."""
+        if self.training:
+            from . import autograd as ag
+            rows, geom = ag.rows_from_ncdhw(x)
+            return [ag.ncdhw_from_rows(r, g) for r, g in ag.backbone_forward_train(self, rows, geom)]
         return [r.as_ncdhw() for r in self.forward_rows(x)]

@@ -155,10 +155,12 @@ __global__ __launch_bounds__(256) void k_upsample_maps(const float* __restrict__
       }
     }
     *(f32x4*)(depths + i * 4) = f32x4{o[12], o[13], o[14], o[15]};
+    if (rgbs == nullptr) return;             // depth-only render branch (coocc_ray.py:436-484): no colour maps
     stage[wave][lane * 3 + 0] = f32x4{o[0], o[1], o[2], o[3]};
     stage[wave][lane * 3 + 1] = f32x4{o[4], o[5], o[6], o[7]};
     stage[wave][lane * 3 + 2] = f32x4{o[8], o[9], o[10], o[11]};
   }
+  if (rgbs == nullptr) return;
   // wave-private staging: the lanes of one wave execute in lock step, the LDS round trip only needs the waitcnt
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void k_upsample_maps(const float* __restrict__
 
 extern "C" int coocc_upsample_maps(const float* maps, int N, int H, int W, int scale, float* rgbs, float* depths,
                                    void* stream) {
-  COOCC_CHECK_ARG(maps && rgbs && depths && N > 0 && H > 0 && W > 0 && scale >= 1, "upsample_maps: bad args");
+  COOCC_CHECK_ARG(maps && depths && N > 0 && H > 0 && W > 0 && scale >= 1, "upsample_maps: bad args");
   COOCC_CHECK_ARG((W * scale) % 4 == 0, "upsample_maps: output width must be a multiple of 4");
   size_t total = (size_t)N * H * scale * (W * scale / 4);
   hipLaunchKernelGGL(k_upsample_maps, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), maps, N, H, W, scale,

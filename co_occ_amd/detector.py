@@ -1,16 +1,23 @@
-"""``COOCC_Ray`` -- the hot path of P/coocc/detectors/coocc_ray.py between "the encoders have
-produced per-modality voxel features" and "losses / metrics" (SURVEY.md section 1):
+"""``COOCC_Ray`` / ``COOCC_Ray_L`` -- the detector surface of P/coocc/detectors/coocc_ray.py (and coocc_ray_lidar.py)
+with the reference's call signatures, so that an unchanged ``tools/test.py`` / ``tools/train.py`` run reaches the HIP
+path through ``forward(return_loss=...)`` (M/models/detectors/base.py:46-58):
 
-    occ_fuser (BiFuser_N) -> semantic_encoder (CustomResNet3D) -> semantic_neck (FPN3D)
-    -> pts_bbox_head (OccHead) -> inline volume-render block (sigma_head / rgb_head)
+    extract_feat:  [image encoder -> DepthNet]* -> fused lift (x) splat -> | occ_fuser (BiFuser_N)
+                   [LiDAR points] -> voxelise -> VFE -> sparse encoder  -> |
+    -> semantic_encoder (CustomResNet3D) -> semantic_neck (FPN3D) -> pts_bbox_head (OccHead)
+    -> inline volume-render block (sigma_head / rgb_head) -> metrics / losses
 
-Child modules are built from the same config dicts through the registries
-(coocc_ray.py:80-83, bevdepth.py:21-34) and keep the reference attribute names, so a
-reference checkpoint's ``occ_fuser.* / semantic_encoder.* / semantic_neck.* / pts_bbox_head.* /
-sigma_head.* / rgb_head.*`` entries load with ``load_state_dict(strict=False)``.  The image and
-LiDAR encoders upstream of the path are out of scope: their config entries are accepted and
-ignored, and the path is fed their outputs.
+Child modules are built from the same config dicts through the registries (coocc_ray.py:80-83, bevdepth.py:21-34) and
+keep the reference attribute names, so a reference checkpoint's ``occ_fuser.* / semantic_encoder.* / semantic_neck.* /
+pts_bbox_head.* / sigma_head.* / rgb_head.*`` entries load unchanged.
+
+[*] The 2D image encoder (``img_backbone`` / ``img_neck``: mmdet ResNet + SECONDFPN) and DepthNet (DCN, ASPP) are
+UPSTREAM of the hot path (out of scope) and are NOT re-implemented: they are built through the real
+mmdet / mmdet3d registries when those packages are importable, may be injected as ``nn.Module`` instances, and
+otherwise construction fails (``external_encoders=True`` defers the failure to the first call that needs them, for
+callers that feed ``precomputed=`` features or attach the encoders afterwards).
 """
+import numpy as np
 import torch
 from torch import nn
 
@@ -18,10 +25,33 @@ from . import registry
 from .core import to_rows
 from .registry import DETECTORS
 from .render import MLP, render_block, render_losses
+from .view_transformer import get_frustum
+
+
+def _build_upstream(kind, cfg, external):
+    """``img_backbone`` / ``img_neck`` / ``pts_backbone`` / ``pts_neck``: modules upstream of the hot path.  Resolution
+    order: an injected nn.Module -> our registries (a type we do implement) -> the real mmdet3d builder -> error."""
+    if cfg is None or isinstance(cfg, nn.Module):
+        return cfg
+    ours = {"backbone": registry.BACKBONES, "neck": registry.NECKS}[kind]
+    if cfg.get("type") in ours:
+        return ours.build(cfg)
+    try:
+        from mmdet3d.models import builder as m3b
+    except Exception as e:
+        if external:
+            return None
+        raise ImportError("COOCC_Ray: config entry %s=%r is upstream of the MI355X hot path and is built through mmdet3d's "
+                          "registries, which are not importable here (%s).  Install mmdet/mmdet3d, pass the module "
+                          "instance instead of the config, or build with external_encoders=True and feed "
+                          "precomputed= features." % (kind, cfg.get("type"), e))
+    return getattr(m3b, "build_" + kind)(cfg)
 
 
 @DETECTORS.register_module()
 class COOCC_Ray(nn.Module):
+    WITH_RGB_HEAD = True          # COOCC_Ray_L has the sigma head only (coocc_ray_lidar.py:111-112)
+
     def __init__(self, voxel_size=None, n_voxels=None, loss_cfg=None, aabb=None, near_far_range=None,
                  N_samples=40, N_rand=4096, depth_supervise=False, use_nerf_mask=True, nerf_sample_view=3,
                  nerf_mode='volume', squeeze_scale=4, rgb_supervise=True, nerf_density=False,
@@ -31,19 +61,34 @@ class COOCC_Ray(nn.Module):
                  semantic_neck=None, loss_norm=False, use_rendering=False, loss_voxel_ce_weight=1.0,
                  loss_voxel_sem_scal_weight=1.0, loss_voxel_geo_scal_weight=1.0, loss_voxel_lovasz_weight=1.0,
                  test_rendering=False, img_view_transformer=None, pts_bbox_head=None, pts_voxel_layer=None,
-                 pts_voxel_encoder=None, pts_middle_encoder=None, **kwargs):
+                 pts_voxel_encoder=None, pts_middle_encoder=None, img_backbone=None, img_neck=None,
+                 pts_backbone=None, pts_neck=None, external_encoders=False, **kwargs):
         super().__init__()
-        self.ignored_cfg_keys = sorted(kwargs)      # img_backbone, img_neck, train/test_cfg ...
+        self.ignored_cfg_keys = sorted(kwargs)      # train_cfg / test_cfg / pretrained / img_bev_encoder_* ...
+        self.external_encoders = external_encoders
         # LiDAR-side producer (coocc_ray.py:215-234; bevdepth.py builds these three from the config)
         from . import lidar
         self.pts_voxel_layer = lidar.Voxelization(**pts_voxel_layer) if pts_voxel_layer else None
         self.pts_voxel_encoder = lidar.VOXEL_ENCODERS.build(pts_voxel_encoder) if pts_voxel_encoder else None
-        self.pts_middle_encoder = lidar.MIDDLE_ENCODERS.build(pts_middle_encoder) if pts_middle_encoder else None
+        self.pts_middle_encoder = None
+        if pts_middle_encoder:
+            if pts_middle_encoder.get("type") in lidar.MIDDLE_ENCODERS:
+                self.pts_middle_encoder = lidar.MIDDLE_ENCODERS.build(pts_middle_encoder)
+            elif not external_encoders:
+                raise NotImplementedError("COOCC_Ray: pts_middle_encoder type %r is not on the MI355X path (SparseLiDAREnc8x / "
+                                          "SparseLiDAREnc4x are); pass external_encoders=True to attach it yourself"
+                                          % pts_middle_encoder.get("type"))
+        self.img_backbone = _build_upstream("backbone", img_backbone, external_encoders)
+        self.img_neck = _build_upstream("neck", img_neck, external_encoders)
+        self.pts_backbone = _build_upstream("backbone", pts_backbone, external_encoders)
+        self.pts_neck = _build_upstream("neck", pts_neck, external_encoders)
         self.empty_idx, self.scale = empty_idx, scale
         self.voxel_size, self.n_voxels, self.aabb = voxel_size, n_voxels, aabb
         self.near_far_range, self.N_samples, self.N_rand = near_far_range, N_samples, N_rand
         self.white_bkgd, self.loss_norm = white_bkgd, loss_norm
+        self.loss_cfg, self.disable_loss_depth = loss_cfg, disable_loss_depth
         self.use_rendering, self.test_rendering = use_rendering, test_rendering
+        self.metrics_on_device = False              # True: SC/SSC histograms stay int64 device tensors (no sync)
         self.img_view_transformer = registry.build_neck(img_view_transformer) if img_view_transformer else None
         self.pts_bbox_head = registry.build_head(pts_bbox_head) if pts_bbox_head else None
         self.occ_fuser = registry.build_fusion_layer(occ_fuser) if occ_fuser is not None else None
@@ -51,7 +96,36 @@ class COOCC_Ray(nn.Module):
         self.semantic_neck = registry.build_neck(semantic_neck)
         if use_rendering:                                      # coocc_ray.py:111-113
             self.sigma_head = MLP(input_dim=128, output_dim=1, net_depth=1, skip_layer=None)
-            self.rgb_head = MLP(input_dim=128, output_dim=3, net_depth=3, skip_layer=None)
+            if self.WITH_RGB_HEAD:
+                self.rgb_head = MLP(input_dim=128, output_dim=3, net_depth=3, skip_layer=None)
+
+    # ------------------------------------------------------------------ encoders (coocc_ray.py:120-256)
+    @property
+    def with_img_neck(self):
+        return self.img_neck is not None
+
+    def image_encoder(self, img):
+        """coocc_ray.py:120-135: the 2D backbone (+ neck) over the B*N views -- upstream torch modules."""
+        if self.img_backbone is None:
+            raise NotImplementedError("COOCC_Ray.image_encoder: no img_backbone attached (built with external_encoders=True); "
+                                      "assign model.img_backbone / model.img_neck or pass precomputed= features")
+        B, N, C, imH, imW = img.shape
+        x = self.img_backbone(img.view(B * N, C, imH, imW))
+        if self.with_img_neck:
+            x = self.img_neck(x)
+        if type(x) in [list, tuple]:
+            x = x[0]
+        x = x.view(B, N, *x.shape[1:])
+        return {'x': x, 'img_feats': [x.clone()]}
+
+    def extract_img_feat(self, img, img_metas):
+        """coocc_ray.py:163-197 -> (img_voxel_feats [B,C,X,Y,Z], depth [B*N,D,fH,fW], img_feats, geom)."""
+        enc = self.image_encoder(img[0])
+        rots, trans, intrins, post_rots, post_trans, bda = img[1:7]
+        vt = self.img_view_transformer
+        mlp_input = vt.get_mlp_input(rots, trans, intrins, post_rots, post_trans, bda)
+        x, depth, geom, _ = vt([enc['x'], rots, trans, intrins, post_rots, post_trans, bda, mlp_input])
+        return x, depth, enc['img_feats'], geom
 
     def extract_pts_feat(self, pts):
         """coocc_ray.py:215-234 (batch size 1): points [N,F] (or a one-element list) -> (pts_voxel_feats [1,C,X,Y,Z],
@@ -64,7 +138,21 @@ class COOCC_Ray(nn.Module):
         voxels, coors, num_points = self.pts_voxel_layer(pts)
         feats = self.pts_voxel_encoder(voxels, num_points, coors)
         enc = self.pts_middle_encoder(feats, coors, 1)
+        if self.pts_backbone is not None:                    # coocc_ray.py:223-226 (no coocc_nusc fusion config sets them)
+            enc['x'] = self.pts_backbone(enc['x'])
+        if self.pts_neck is not None:
+            enc['x'] = self.pts_neck(enc['x'])
         return enc['x'], enc['pts_feats']
+
+    def extract_feat(self, points, img, img_metas, search=None):
+        """coocc_ray.py:237-266 -> (voxel_feats, img_feats, pts_feats, depth, geom, img_voxel_feats)."""
+        img_voxel_feats = pts_voxel_feats = pts_feats = depth = img_feats = geom = None
+        if img is not None:
+            img_voxel_feats, depth, img_feats, geom = self.extract_img_feat(img, img_metas)
+        if points is not None:
+            pts_voxel_feats, pts_feats = self.extract_pts_feat(points)
+        voxel_feats = self.fuse(img_voxel_feats, pts_voxel_feats, search)
+        return voxel_feats, img_feats, pts_feats, depth, geom, img_voxel_feats
 
     def fuse(self, img_voxel_feats, pts_voxel_feats, search=None):
         """coocc_ray.py:252-256."""
@@ -86,6 +174,11 @@ class COOCC_Ray(nn.Module):
         img_feats: [[1,N,512,fH,fW]]; transform: img_inputs[1:] (rots, trans, intrins, post_rots,
         post_trans, bda, ..., (H_img, W_img))."""
         voxel_feats = self.fuse(img_voxel_feats, pts_voxel_feats, search)
+        return self.decode(voxel_feats, gemo, img_feats, transform, render, dense_fine)
+
+    def decode(self, voxel_feats, gemo=None, img_feats=None, transform=None, render=None, dense_fine=True,
+               depth_only=False, fine_size=None):
+        """Everything after ``extract_feat`` and before the metrics (coocc_ray.py:525-627)."""
         mid = self.semantic_encoder.forward_rows(voxel_feats)
         sem = self.semantic_neck.forward_rows(mid)
         output = self.pts_bbox_head(voxel_feats=sem, img_feats=img_feats, transform=transform)
@@ -94,79 +187,106 @@ class COOCC_Ray(nn.Module):
         if output['output_voxels_fine'] is not None and dense_fine:
             cf = self.pts_bbox_head.cascade_ratio
             pc = res['pred_c']
-            size = [pc.shape[2] * cf, pc.shape[3] * cf, pc.shape[4] * cf]     # == gt_occ size (coocc_ray.py:549)
+            size = fine_size or [pc.shape[2] * cf, pc.shape[3] * cf, pc.shape[4] * cf]     # == gt_occ size (coocc_ray.py:549)
             res['pred_f'] = self.pts_bbox_head.scatter_fine(output['output_voxels_fine'][0],
-                                                            output['output_coords_fine'][0], size)
+                                                            output['output_coords_fine'][0], list(size))
         do_render = (self.use_rendering and self.test_rendering) if render is None else render
         if do_render:
-            rgbs, depths, maps = render_block(self.sigma_head, self.rgb_head, to_rows(voxel_feats), gemo, 16)
+            rgbs, depths, maps = render_block(self.sigma_head, getattr(self, "rgb_head", None), to_rows(voxel_feats), gemo, 16,
+                                              depth_only=depth_only or not hasattr(self, "rgb_head"))
             res.update(rgbs=rgbs, depths=depths, render_maps=maps)
         return res
 
     def forward_train_hot_path(self, img_voxel_feats, pts_voxel_feats, gemo=None, img_feats=None, transform=None,
-                               coarse_lin=None, render=True, generator=None):
-        """Differentiable counterpart of ``forward_hot_path`` (frozen-statistics BN, as in ``co_occ_amd.autograd``):
-        K1-K5 run as in inference (indices are not differentiated, as upstream), everything after them is an autograd
-        Function over the HIP kernels.  Returns rows / tensors with ``grad_fn``:
-        ``voxel_rows`` [V,C] (con_enc output), ``levels`` [(rows, geom)], ``out_voxel_rows`` [V,128], ``logit_rows``
-        [V,ncls], ``fine_logits`` [8n,ncls] + ``fine_xyz`` [3,8n], ``rgbs`` / ``depths`` of the render block.
-        ``coarse_lin``: int32 rows of the coarse voxels whose children the fine branch evaluates; default: the
-        foreground voxels (argmax != empty), randomly thinned to ``fine_topk // ratio^3`` of them (the reference draws
-        its training-time top-k among fine points, occ_head.py:204-205; here whole coarse voxels are drawn).
-        The semantic losses (CE / lovasz / scal) are out of scope: apply them to the returned logits."""
+                               coarse_lin=None, render=True, generator=None, depth_only=False):
+        """Differentiable counterpart of ``forward_hot_path``: K1-K5 run as in inference (indices are not differentiated, as
+        upstream), everything after them is an autograd Function over the HIP kernels; every BatchNorm follows its own
+        ``training`` flag (batch / SyncBN statistics under model.train(), folded running statistics in eval mode).
+        Returns rows / tensors with ``grad_fn``: ``voxel_rows`` [V,C] (con_enc output), ``levels`` [(rows, geom)],
+        ``out_voxel_rows`` [V,128], ``logit_rows`` [V,ncls], ``fine_logits`` [8n,ncls] + ``fine_xyz`` [3,8n], ``rgbs`` /
+        ``depths`` of the render block.  ``coarse_lin``: int32 rows of the coarse voxels whose children the fine branch
+        evaluates; default: the foreground voxels (argmax != empty), randomly thinned to ``fine_topk // ratio^3`` of them
+        (the reference draws its training-time top-k among fine points, occ_head.py:204-205; here whole coarse voxels are
+        drawn)."""
         from . import autograd as ag
-        B, C, X, Y, Z = img_voxel_feats.shape
+        one = img_voxel_feats if img_voxel_feats is not None else pts_voxel_feats
+        B, C, X, Y, Z = one.shape
         assert B == 1, "batch size 1 per GPU (coocc_ray.py:365)"
         V = X * Y * Z
-        with torch.no_grad():
-            sr = self.occ_fuser.search(img_voxel_feats.detach(), pts_voxel_feats.detach())
-        rows = lambda t: t.float().permute(0, 2, 3, 4, 1).reshape(V, C)
-        cat4 = ag.fuser_fuse_train(self.occ_fuser, rows(img_voxel_feats).contiguous(), rows(pts_voxel_feats).contiguous(), sr)
-        ce = self.occ_fuser.con_enc
-        vf, geom = ag.conv3d_rows(cat4, ce[0].weight, (1, X, Y, Z), bias=ce[0].bias, bn=ce[1], relu=True)
-        vf, geom = ag.conv3d_rows(vf, ce[3].weight, geom, bias=ce[3].bias, bn=ce[4], relu=True)
+        rows = lambda t: t.float().permute(0, 2, 3, 4, 1).reshape(V, t.shape[1])
+        if self.occ_fuser is not None:
+            with torch.no_grad():
+                sr = self.occ_fuser.search(img_voxel_feats.detach(), pts_voxel_feats.detach())
+            self.occ_fuser.finish_bookkeeping(sr)              # the img->pts direction ran on a side stream
+            cat4 = ag.fuser_fuse_train(self.occ_fuser, rows(img_voxel_feats).contiguous(), rows(pts_voxel_feats).contiguous(), sr)
+            vf, geom = ag.con_enc_train(self.occ_fuser.con_enc, cat4, (1, X, Y, Z))
+        else:                                                  # coocc_ray.py:255-256: single-modality models
+            assert (img_voxel_feats is None) or (pts_voxel_feats is None)
+            vf, geom = rows(one).contiguous(), (1, X, Y, Z)
         levels = ag.trunk_forward_train(None, self.semantic_encoder, self.semantic_neck, vf, geom)
         head = self.pts_bbox_head
         out_rows, logit_rows = ag.occhead_coarse_train(head, levels)
         res = dict(voxel_rows=vf, levels=levels, out_voxel_rows=out_rows, logit_rows=logit_rows)
         if head.cascade_ratio != 1 and (head.sample_from_img or head.sample_from_voxel):
             if coarse_lin is None:
-                fg = torch.nonzero(logit_rows.detach().argmax(1) != head.empty_idx).flatten()
-                cap = max(1, int(head.fine_topk) // head.cascade_ratio ** 3)
-                if fg.numel() > cap:
-                    sel = torch.randperm(fg.numel(), generator=generator, device=fg.device if generator is None else generator.device)[:cap]
-                    fg = fg[sel.to(fg.device)].sort().values
-                coarse_lin = fg.int()
+                coarse_lin = head.draw_fine_voxels(logit_rows.detach(), generator)
             if coarse_lin.numel():
                 res["fine_logits"], res["fine_xyz"] = ag.fine_branch_train(head, out_rows, (1, X, Y, Z), coarse_lin.contiguous(),
                                                                            img_feats, transform)
         if render and self.use_rendering:
-            res["rgbs"], res["depths"] = ag.render_block_train(self.sigma_head, self.rgb_head, vf, (X, Y, Z), gemo)
+            rgb_head = None if (depth_only or not hasattr(self, "rgb_head")) else self.rgb_head
+            res["rgbs"], res["depths"] = ag.render_block_train(self.sigma_head, rgb_head, vf, (X, Y, Z), gemo)
         return res
 
     def render_losses(self, rgbs, depths, rgb_gt, depth_gt, D):
         """coocc_ray.py:423-433."""
         return render_losses(rgbs, depths, rgb_gt, depth_gt, D)
 
+    def _metrics(self, out, gt_occ, visible_mask):
+        """coocc_ray.py:539-554: SC / SSC (/ visible-only SSC) confusion matrices of pred_c and pred_f -- one kernel per
+        prediction; by default one device->host read of the 4 + 2*17*17 counters so the dict holds numpy arrays like
+        upstream (``collect_results_cpu`` pickles them); ``metrics_on_device`` keeps int64 device tensors instead."""
+        from .evaluation import semantic_histograms, split_histograms
+        C = out["pred_c"].shape[1]
+        hc = semantic_histograms(out["pred_c"], gt_occ, visible_mask, self.empty_idx)
+        hf = semantic_histograms(out["pred_f"], gt_occ, visible_mask, self.empty_idx) if out.get("pred_f") is not None else None
+        if not self.metrics_on_device:
+            both = torch.stack([hc, hf]) if hf is not None else hc[None]
+            both = both.cpu().numpy()
+            hc, hf = both[0], (both[1] if hf is not None else None)
+            split = lambda h: (h[:4].reshape(2, 2), h[4:4 + C * C].reshape(C, C), h[4 + C * C:].reshape(C, C))
+        else:
+            split = lambda h: split_histograms(h, C)
+        sc, ssc, occ = split(hc)
+        res = dict(SC_metric=sc, SSC_metric=ssc)
+        if visible_mask is not None:
+            res["SSC_occ_metric"] = occ
+        if hf is not None:
+            sc, ssc, occ = split(hf)
+            res.update(SC_metric=sc, SSC_metric_fine=ssc)                    # coocc_ray.py:553-554 overwrites SC_metric
+            if visible_mask is not None:
+                res["SSC_occ_metric_fine"] = occ
+        return res
+
     def simple_test(self, img_metas=None, img=None, gt_depths=None, points=None, rescale=False, points_occ=None,
                     gt_occ=None, visible_mask=None, precomputed=None):
-        """Reference signature (coocc_ray.py:520).  The encoders are out of scope, so the
-        per-modality voxel features must be supplied via ``precomputed=dict(img_voxel_feats=...,
-        pts_voxel_feats=..., gemo=..., img_feats=...)``; ``img[1:]`` is the transform."""
-        if precomputed is None:
-            raise NotImplementedError("COOCC_Ray: image/LiDAR encoders are outside the MI355X hot path; pass precomputed=")
-        transform = img[1:] if img is not None else precomputed.get("transform")
-        out = self.forward_hot_path(precomputed["img_voxel_feats"], precomputed["pts_voxel_feats"],
-                                    precomputed.get("gemo"), precomputed.get("img_feats"), transform)
+        """Reference signature and result dict (coocc_ray.py:520-656).  ``img`` = img_inputs (imgs, rots, trans, intrins,
+        post_rots, post_trans, bda, ...); ``points`` = [points [N,5]].  ``precomputed=dict(img_voxel_feats=,
+        pts_voxel_feats=, gemo=, img_feats=)`` (an extension) bypasses the upstream encoders."""
+        if points_occ is not None:
+            raise NotImplementedError("lidarseg evaluation (forward_lidarseg) is not on the hot path")
+        if precomputed is not None:
+            voxel_feats = self.fuse(precomputed.get("img_voxel_feats"), precomputed.get("pts_voxel_feats"), precomputed.get("search"))
+            img_feats, gemo = precomputed.get("img_feats"), precomputed.get("gemo")
+            transform = img[1:] if img is not None else precomputed.get("transform")
+        else:
+            voxel_feats, img_feats, _, _, gemo, _ = self.extract_feat(points, img=img, img_metas=img_metas)
+            transform = img[1:] if img is not None else None
+        fine_size = list(gt_occ.shape[1:]) if gt_occ is not None else None
+        out = self.decode(voxel_feats, gemo, img_feats, transform, fine_size=fine_size)
         out.update(output_voxels=out["pred_c"], target_voxels=gt_occ)
-        if gt_occ is not None:   # coocc_ray.py:540-554, one kernel per prediction, histograms stay on the device
-            from .evaluation import semantic_histograms, split_histograms
-            C = out["pred_c"].shape[1]
-            sc, ssc, occ = split_histograms(semantic_histograms(out["pred_c"], gt_occ, visible_mask, self.empty_idx), C)
-            out.update(SC_metric=sc, SSC_metric=ssc, SSC_occ_metric=occ if visible_mask is not None else None)
-            if out.get("pred_f") is not None:
-                sc, ssc, occ = split_histograms(semantic_histograms(out["pred_f"], gt_occ, visible_mask, self.empty_idx), C)
-                out.update(SC_metric=sc, SSC_metric_fine=ssc, SSC_occ_metric_fine=occ if visible_mask is not None else None)
+        if gt_occ is not None:
+            out.update(self._metrics(out, gt_occ, visible_mask))
         return out
 
     def evaluation_semantic(self, pred, gt, eval_type, visible_mask=None):
@@ -174,11 +294,100 @@ class COOCC_Ray(nn.Module):
         from .evaluation import evaluation_semantic
         return evaluation_semantic(pred, gt, eval_type, visible_mask, self.empty_idx)
 
+    # ------------------------------------------------------------------ training (coocc_ray.py:313-518)
+    def forward_train(self, points=None, img_metas=None, img_inputs=None, gt_occ=None, points_occ=None, visible_mask=None,
+                      gt_depths=None, precomputed=None, generator=None, **kwargs):
+        """Reference signature; returns the reference's loss dict: ``loss_depth`` (DepthNet BCE, upstream torch),
+        the OccHead losses ``loss_voxel_{ce,sem_scal,geo_scal,lovasz}_{c_0,fine}`` (co_occ_amd.losses), ``loss_norm``
+        rescaling, and the render regulariser ``loss_depth_render`` / ``loss_rgb`` (camera branch :358-434) or
+        ``loss_depth_render`` alone through ``get_frustum`` (LiDAR-only branch :436-496).  Everything between the
+        encoders and the losses is an autograd Function over the HIP kernels (``forward_train_hot_path``)."""
+        if points_occ is not None:
+            raise NotImplementedError("lidarseg supervision (forward_lidarseg) is not on the hot path")
+        depth = None
+        if precomputed is not None:
+            img_voxel_feats, pts_voxel_feats = precomputed.get("img_voxel_feats"), precomputed.get("pts_voxel_feats")
+            img_feats, gemo, depth = precomputed.get("img_feats"), precomputed.get("gemo"), precomputed.get("depth")
+        else:
+            img_voxel_feats = pts_voxel_feats = img_feats = gemo = None
+            if img_inputs is not None:
+                img_voxel_feats, depth, img_feats, gemo = self.extract_img_feat(img_inputs, img_metas)
+            if points is not None:
+                pts_voxel_feats, _ = self.extract_pts_feat(points)
+        transform = img_inputs[1:] if img_inputs is not None else None
+        losses = dict()
+        if not self.disable_loss_depth and depth is not None:
+            losses['loss_depth'] = self.img_view_transformer.get_depth_loss(img_inputs[7], depth)
+        depth_only = img_feats is None
+        if self.use_rendering and depth_only:                  # :436-437
+            g = gt_depths
+            gemo = get_frustum(g[0], g[1], g[2], g[3], g[4], g[5], g[-1], 16)
+        res = self.forward_train_hot_path(img_voxel_feats, pts_voxel_feats, gemo, img_feats, transform,
+                                          render=self.use_rendering, generator=generator, depth_only=depth_only)
+        head = self.pts_bbox_head
+        B, _, X, Y, Z = (img_voxel_feats if img_voxel_feats is not None else pts_voxel_feats).shape
+        logits = res["logit_rows"].view(B, X, Y, Z, -1).permute(0, 4, 1, 2, 3)
+        fine = [res["fine_logits"]] if "fine_logits" in res else None
+        coords = [res["fine_xyz"]] if "fine_xyz" in res else None
+        losses.update(head.loss(output_voxels=[logits], output_voxels_fine=fine, output_coords_fine=coords,
+                                target_voxels=gt_occ, visible_mask=visible_mask))
+        if self.loss_norm:                                     # :351-354
+            for k in list(losses):
+                if k.startswith('loss'):
+                    losses[k] = losses[k] / (losses[k].detach() + 1e-9)
+        if self.use_rendering:
+            D = gemo.shape[2]
+            if not depth_only:                                 # :423-433
+                rl = self.render_losses_train(res["rgbs"], res["depths"], img_inputs[0][0].permute(0, 2, 3, 1), img_inputs[7][0], D)
+                losses.update(rl)
+            else:                                              # :486-496 (gt_depths[6] there, gt_depths[-2] in coocc_ray_lidar.py)
+                dg = gt_depths[self.DEPTH_GT_INDEX][0]
+                rl = self.render_losses_train(None, res["depths"], None, dg, D)
+                losses["loss_depth_render"] = rl["loss_depth_render"]
+        return losses
+
+    DEPTH_GT_INDEX = 6
+
+    @staticmethod
+    def render_losses_train(rgbs, depths, rgb_gt, depth_gt, D):
+        from . import autograd as ag
+        if rgbs is None:                                       # depth-only: the colour term does not exist
+            rgbs = torch.zeros(*depths.shape, 3, device=depths.device)
+            rgb_gt = rgbs
+        return ag.render_losses(rgbs, depths, rgb_gt.float().contiguous(), depth_gt.float().contiguous(), D)
+
     def forward_test(self, img_metas=None, img_inputs=None, **kwargs):
         return self.simple_test(img_metas, img_inputs, **kwargs)
 
-    def forward(self, return_loss=False, **kwargs):
+    def forward(self, return_loss=True, **kwargs):
+        """M/models/detectors/base.py:46-58."""
         if return_loss:
-            raise NotImplementedError("forward_train is not assembled: the differentiable pieces (trunk, head, fine branch, render block, "
-                                      "render losses) are in co_occ_amd.autograd; the semantic losses are out of scope (SURVEY.md 8)")
+            return self.forward_train(**kwargs)
         return self.forward_test(**kwargs)
+
+
+@DETECTORS.register_module()
+class COOCC_Ray_L(COOCC_Ray):
+    """LiDAR-only variant (P/coocc/detectors/coocc_ray_lidar.py): same decoder and depth-only render regulariser (no
+    rgb head, :111-112; depth ground truth at gt_depths[-2], :507).  Its ``pts_backbone`` / ``pts_neck`` (SECOND3D /
+    SECOND3DFPN over a SparseEncoderHD volume, projects/configs/coocc_nusc/coocc_lidar.py) are upstream of the hot path and
+    resolved like the image encoder of COOCC_Ray (mmdet3d registries, injected modules, or ``external_encoders``)."""
+    WITH_RGB_HEAD = False
+    DEPTH_GT_INDEX = -2
+
+    def extract_pts_feat(self, pts):
+        """coocc_ray_lidar.py:236-256: the dense LiDAR trunk returns [B,C,Z,Y,X]; the detector permutes to [B,C,X,Y,Z]."""
+        if self.pts_middle_encoder is None or (self.pts_backbone is None and self.pts_neck is None):
+            raise NotImplementedError("COOCC_Ray_L: the LiDAR trunk (pts_middle_encoder / pts_backbone / pts_neck) is upstream of "
+                                      "the hot path and was not attached; feed precomputed=dict(pts_voxel_feats=...)")
+        if isinstance(pts, (list, tuple)):
+            assert len(pts) == 1, "batch size 1 (hard-coded upstream)"
+            pts = pts[0]
+        voxels, coors, num_points = self.pts_voxel_layer(pts)
+        feats = self.pts_voxel_encoder(voxels, num_points, coors)
+        x = self.pts_middle_encoder(feats, coors, 1)
+        if self.pts_backbone is not None:
+            x = self.pts_backbone(x)
+        if self.pts_neck is not None:
+            x = self.pts_neck(x)
+        return x.permute(0, 1, 4, 3, 2), [x]

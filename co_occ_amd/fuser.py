@@ -249,6 +249,17 @@ class BiFuser_N(nn.Module):
             self.last_near = (sr.near_img, sr.near_pts)
         return sr.cat4, (sr.lin_img, sr.lin_pts)
 
+    def finish_bookkeeping(self, sr):
+        """Make a SearchResult issued on another stream safe to consume on the current one (training path)."""
+        cur = torch.cuda.current_stream(sr.cat4.t.device)
+        cur.wait_event(sr.done_main)
+        if sr.done_side is not None:
+            cur.wait_event(sr.done_side)
+        for t in sr.tensors():
+            t.record_stream(cur)
+        if sr.rows is not None:
+            self.last_near = (sr.near_img, sr.near_pts)
+
     def fuse(self, img_voxel_feats, pts_voxel_feats, search=None):
         """K1..G1: returns the [B*V, 4C] concat rows (img | pts | fused_img | fused_pts)."""
         return self.finish(search if search is not None else self.search(img_voxel_feats, pts_voxel_feats))
@@ -258,6 +269,15 @@ class BiFuser_N(nn.Module):
         inputs computed ahead of time (cross-sample pipelining)."""
         if not img_voxel_feats.is_cuda:
             raise _lib.CooccError("BiFuser_N runs on the GPU only (no CPU fallback)")
+        if self.training:                    # batch-statistics BN + autograd, as upstream under model.train()
+            from . import autograd as ag
+            assert img_voxel_feats.shape[0] == 1, "BiFuser_N training path: batch size 1 per GPU (samples_per_gpu=1 upstream)"
+            with torch.no_grad():
+                sr = search if search is not None else self.search(img_voxel_feats.detach(), pts_voxel_feats.detach())
+            (ri, geom), (rp, _) = ag.rows_from_ncdhw(img_voxel_feats), ag.rows_from_ncdhw(pts_voxel_feats)
+            self.finish_bookkeeping(sr)
+            x, g = ag.con_enc_train(self.con_enc, ag.fuser_fuse_train(self, ri, rp, sr), geom)
+            return ag.ncdhw_from_rows(x, g)
         packs = self._packed()
         cat4, _ = self.fuse(img_voxel_feats, pts_voxel_feats, search)
         x = conv_rows(cat4, packs["c0"], relu=True)

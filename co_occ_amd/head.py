@@ -52,7 +52,15 @@ class OccHead(nn.Module):
         self.padding_mode, self.data_type = padding_mode, data_type
         self.empty_idx, self.soft_weights = empty_idx, soft_weights
         self.num_img_level, self.num_point_sampling_feat = num_img_level, num_level
+        lw = loss_weight_cfg or {}                              # occ_head.py:84-99
         self.loss_weight_cfg = loss_weight_cfg
+        self.loss_voxel_ce_weight = lw.get('loss_voxel_ce_weight', 1.0)
+        self.loss_voxel_sem_scal_weight = lw.get('loss_voxel_sem_scal_weight', 1.0)
+        self.loss_voxel_geo_scal_weight = lw.get('loss_voxel_geo_scal_weight', 1.0)
+        self.loss_voxel_lovasz_weight = lw.get('loss_voxel_lovasz_weight', 1.0)
+        from .losses import nusc_class_weights
+        self.class_weights = nusc_class_weights() if balance_cls_weight else torch.ones(17) / 17     # :134-144
+        self.visible_loss = visible_loss
 
         if cascade_ratio != 1 and (sample_from_voxel or sample_from_img):
             fine_in = 128 if sample_from_voxel else 0
@@ -223,13 +231,41 @@ class OccHead(nn.Module):
         return params
 
     # ---------------------------------------------------------------- forward
+    def draw_fine_voxels(self, logit_rows, generator=None):
+        """Coarse voxels whose ``ratio^3`` children the fine branch evaluates: foreground = argmax != empty; in training
+        at most ``fine_topk`` of them, drawn at random (coordinate_transform.py:17-21 permutes the COARSE columns and keeps
+        the first topk).  logit_rows [V,ncls] -> int32 rows."""
+        fg = torch.nonzero(logit_rows.argmax(1) != self.empty_idx).flatten()
+        if self.training and fg.numel() >= int(self.fine_topk):
+            dev = fg.device if generator is None else generator.device
+            sel = torch.randperm(fg.numel(), generator=generator, device=dev)[:int(self.fine_topk)]
+            fg = fg[sel.to(fg.device)]
+        return fg.int()
+
+    def _forward_train(self, voxel_feats, img_feats, transform, generator=None):
+        """Training branch of occ_head.py:173-245: batch-statistics BN, autograd through every HIP kernel."""
+        from . import autograd as ag
+        levels = [ag.rows_from_ncdhw(f) for f in voxel_feats]
+        geom = levels[0][1]
+        assert geom[0] == 1, "OccHead training path: batch size 1 per GPU (samples_per_gpu=1 upstream)"
+        out_rows, logit_rows = ag.occhead_coarse_train(self, levels)
+        res = {'output_voxels': [ag.ncdhw_from_rows(logit_rows, geom)], 'output_voxels_fine': None, 'output_coords_fine': None,
+               'output_points': None}
+        self.last_out_voxel_rows = out_rows
+        if self.cascade_ratio != 1 and (self.sample_from_img or self.sample_from_voxel):
+            lin = self.draw_fine_voxels(logit_rows.detach(), generator)
+            assert lin.numel() > 0, 'no foreground in coarse voxel'
+            fine, xyz = ag.fine_branch_train(self, out_rows, geom, lin.contiguous(), img_feats, transform)
+            res['output_voxels_fine'], res['output_coords_fine'] = [fine], [xyz]
+        return res
+
     def forward(self, voxel_feats, img_feats=None, img_metas=None, pts_feats=None, target_points=None,
-                transform=None, **kwargs):
+                transform=None, points=None, **kwargs):
         assert type(voxel_feats) is list and len(voxel_feats) == self.num_level
-        if self.training:
-            raise NotImplementedError("OccHead training branch (random top-k + losses) is out of scope (SURVEY 8f)")
         if target_points:
             raise NotImplementedError("forward_lidarseg is not on the hot path")
+        if self.training:
+            return self._forward_train(voxel_feats, img_feats, transform, kwargs.get("generator"))
         ovf, occ = self.forward_coarse_rows(voxel_feats)
         res = {'output_voxels': [occ.as_ncdhw()], 'output_voxels_fine': None, 'output_coords_fine': None,
                'output_points': None}
@@ -247,5 +283,42 @@ class OccHead(nn.Module):
              out_size[0], out_size[1], out_size[2], float(self.empty_idx))
         return grid
 
-    def loss(self, *a, **k):
-        raise NotImplementedError("OccHead.loss is out of scope for the forward hot path (SURVEY.md 8a)")
+    # ---------------------------------------------------------------- losses (occ_head.py:265-337)
+    def _loss_terms(self, logits, target, tag, class_weights):
+        from . import losses as L
+        return {
+            'loss_voxel_ce_%s' % tag: self.loss_voxel_ce_weight * L.ce_ssc_loss(logits, target, class_weights, ignore_index=255),
+            'loss_voxel_sem_scal_%s' % tag: self.loss_voxel_sem_scal_weight * L.sem_scal_loss(logits, target, ignore_index=255),
+            'loss_voxel_geo_scal_%s' % tag: self.loss_voxel_geo_scal_weight * L.geo_scal_loss(logits, target, ignore_index=255,
+                                                                                             non_empty_idx=self.empty_idx),
+            'loss_voxel_lovasz_%s' % tag: self.loss_voxel_lovasz_weight * L.lovasz_softmax(torch.softmax(logits, dim=1), target,
+                                                                                           ignore=255)}
+
+    def loss_voxel(self, output_voxels, target_voxels, tag):
+        """occ_head.py:265-293: labels majority-pooled to the logits' grid, then the four terms (class-weighted CE)."""
+        from .losses import pool_labels
+        B, C, H, W, D = output_voxels.shape
+        target = pool_labels(target_voxels, H, W, D, self.empty_idx)
+        return self._loss_terms(output_voxels, target, tag, self.class_weights.to(output_voxels))
+
+    def loss_point(self, fine_coord, fine_output, target_voxels, tag):
+        """occ_head.py:295-310: fine logits [N,ncls] against the labels at their coordinates (unweighted CE)."""
+        gt = target_voxels[:, fine_coord[0, :], fine_coord[1, :], fine_coord[2, :]].long()[0]
+        return self._loss_terms(fine_output, gt, tag, None)
+
+    def loss(self, output_voxels=None, output_coords_fine=None, output_voxels_fine=None, target_voxels=None,
+             target_points=None, img_metas=None, visible_mask=None, **kwargs):
+        """occ_head.py:312-337."""
+        if target_points:
+            raise NotImplementedError("forward_lidarseg is not on the hot path")
+        loss_dict = {}
+        for index, ov in enumerate(output_voxels):
+            loss_dict.update(self.loss_voxel(ov, target_voxels, tag='c_%d' % index))
+        if self.cascade_ratio != 1 and (self.sample_from_voxel or self.sample_from_img) and output_voxels_fine:
+            acc = {}
+            for fine_coord, fine_output in zip(output_coords_fine, output_voxels_fine):
+                for k, v in self.loss_point(fine_coord, fine_output, target_voxels, tag='fine').items():
+                    acc[k] = acc[k] + v if k in acc else v
+            for k, v in acc.items():
+                loss_dict[k] = v / len(output_coords_fine)
+        return loss_dict

@@ -234,6 +234,11 @@ class _SparseEncoderBase(nn.Module):
         memory), pts_feats=[SparseRows])."""
         if not voxel_features.is_cuda:
             raise _lib.CooccError("the sparse LiDAR encoder runs on the GPU only (no CPU fallback)")
+        if self.training:
+            # BN1d is folded from its running statistics and the rule-book GEMMs carry no autograd: this is the
+            # inference path.  The reference trains this encoder (batch statistics); refuse rather than return eval numbers.
+            raise RuntimeError("%s: only the eval-mode path is implemented (folded BN1d, no autograd); call .eval() -- "
+                               "training the LiDAR encoder is outside the hot path (SURVEY.md 8f rank 3)" % type(self).__name__)
         if coors.shape[1] == 4:
             assert int(batch_size) == 1, "batch size 1 (hard-coded upstream, sparse_lidar_enc.py:109)"
             coors = coors[:, 1:]

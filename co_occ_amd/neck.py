@@ -6,7 +6,7 @@ trilinear-upsample-add kernel per level (fpn3d.py:88-92).
 from torch import nn
 
 from ._lib import call, ptr
-from .backbone import build_bn
+from .backbone import _eval_only, build_bn
 from .core import PackCache, PackedConv, conv_rows, to_rows
 from .registry import NECKS
 
@@ -50,6 +50,7 @@ class FPN3D(nn.Module):
 
     def forward_rows(self, inputs):
         assert len(inputs) == len(self.in_channels)
+        _eval_only(self)
         p = self._packed()
         lat = [conv_rows(to_rows(x), p["lat"][i], relu=True) for i, x in enumerate(inputs)]
         for i in range(self.num_out - 1, 0, -1):
@@ -58,5 +59,9 @@ class FPN3D(nn.Module):
         return [conv_rows(x, p["out"][i], relu=True) for i, x in enumerate(lat)]
 
     def forward(self, inputs):
-        """list of [B,C_i,...] -> list of [B,out,...] (fpn3d.py:70-108)."""
+        """list of [B,C_i,...] -> list of [B,out,...] (fpn3d.py:70-108); training mode: batch-statistics BN + autograd."""
+        if self.training:
+            from . import autograd as ag
+            feats = [ag.rows_from_ncdhw(x) for x in inputs]
+            return [ag.ncdhw_from_rows(r, g) for r, g in ag.neck_forward_train(self, feats)]
         return [r.as_ncdhw() for r in self.forward_rows(inputs)]

@@ -68,19 +68,27 @@ def build_head(cfg, **kw):
     return HEADS.build(cfg)
 
 
-def build_detector(cfg, train_cfg=None, test_cfg=None):
-    return DETECTORS.build(cfg)
+def build_detector(cfg, train_cfg=None, test_cfg=None, **overrides):
+    """``overrides`` are merged into the config (e.g. ``external_encoders=True``, ``img_backbone=<module>``)."""
+    return DETECTORS.build(dict(cfg, **overrides))
 
 
-def register_into_mmdet():
-    """Register our classes under the reference names into real mmdet/mmdet3d registries."""
+def register_into_mmdet(detectors=False):
+    """Register our classes under the reference names into the real mmdet / mmdet3d registries (``force=True``).
+
+    Default: the hot-path MODULES only (BiFuser_N, CustomResNet3D, FPN3D, OccHead, ViewTransformerLiftSplatShootVoxel and
+    the LiDAR producer) -- the reference's own ``COOCC_Ray`` then builds them from its unchanged configs and keeps its
+    encoders, losses and metrics.  ``detectors=True`` additionally replaces ``COOCC_Ray`` / ``COOCC_Ray_L`` with ours (HIP
+    render block, on-device metrics; its image encoder is built back through these same registries).  Returns False when
+    mmdet / mmdet3d are not importable."""
     try:
         from mmdet.models import builder as mb
         from mmdet3d.models import builder as m3b
     except Exception:
         return False
-    pairs = [(DETECTORS, mb.DETECTORS), (BACKBONES, m3b.BACKBONES), (NECKS, m3b.NECKS),
-             (HEADS, m3b.HEADS), (FUSION_LAYERS, m3b.FUSION_LAYERS)]
+    pairs = [(BACKBONES, m3b.BACKBONES), (NECKS, m3b.NECKS), (HEADS, m3b.HEADS), (FUSION_LAYERS, m3b.FUSION_LAYERS)]
+    if detectors:
+        pairs.append((DETECTORS, mb.DETECTORS))
     from . import lidar
     pairs += [(lidar.VOXEL_ENCODERS, m3b.VOXEL_ENCODERS), (lidar.MIDDLE_ENCODERS, m3b.MIDDLE_ENCODERS)]
     for ours, theirs in pairs:

@@ -1,7 +1,8 @@
-"""``ViewTransformerLiftSplatShootVoxel`` -- the geometry + pooling half of
-P/coocc/image2bev/ViewTransformerLSSVoxel.py / ViewTransformerLSSBEVDepth.py (P1, P2).
-DepthNet / lift (the image branch upstream of the path) are out of scope:
-``forward`` takes the already-lifted volume.
+"""``ViewTransformerLiftSplatShootVoxel`` -- P/coocc/image2bev/ViewTransformerLSSVoxel.py /
+ViewTransformerLSSBEVDepth.py: geometry (P1), voxel pooling (P2), and ``forward`` with the reference signature where
+Lift (x) Splat is ONE fused HIP pass (the [B,N,D,H,W,C] volume is never materialised).
+DepthNet (DCN + ASPP, the image branch upstream of the path) is not re-implemented: ``depth_net`` is the
+reference's own class when the plugin is importable, or an injected nn.Module.
 """
 import torch
 from torch import nn
@@ -21,13 +22,62 @@ def gen_dx_bx(xbound, ybound, zbound):
     return dx, bx, nx
 
 
+def camera_mats(rots, trans, intrins, post_rots, post_trans, bda):
+    """[B*N, COOCC_CAM_FLOATS] constants of the frustum -> ego chain (get_geometry / get_frustum): inv(post_rots),
+    post_trans, rots @ inv(intrins[:3,:3]), trans, bda[:3,:3], the KITTI shift intrins[:3,3] (3x4 / 4x4 intrinsics,
+    else 0) and the translation of a 4x4 bda (else 0).  Six tiny host-side torch matrices per sample."""
+    B, N, _ = trans.shape
+    z3 = torch.zeros(B * N, 3, device=trans.device, dtype=_F32)
+    shift = z3
+    if intrins.shape[3] == 4:                       # KITTI (ViewTransformerLSSBEVDepth.py:136-139)
+        shift = intrins[:, :, :3, 3].reshape(B * N, 3)
+        intrins = intrins[:, :, :3, :3]
+    bda_t = z3
+    if bda.shape[-1] == 4:                          # :145-148
+        bda_t = bda[:, :3, 3].view(B, 1, 3).expand(B, N, 3).reshape(B * N, 3)
+        bda = bda[:, :3, :3]
+    return torch.cat([torch.inverse(post_rots).reshape(B * N, 9), post_trans.reshape(B * N, 3),
+                      rots.matmul(torch.inverse(intrins)).reshape(B * N, 9), trans.reshape(B * N, 3),
+                      bda.reshape(B, 1, 9).expand(B, N, 9).reshape(B * N, 9), shift, bda_t], 1).float().contiguous()
+
+
+def frustum_axes(input_size, downsample, dbound, device):
+    """The three axes of create_frustum (ViewTransformerLSSBEVDepth.py:104-115) for an ``input_size // downsample`` map."""
+    ogfH, ogfW = int(input_size[0]), int(input_size[1])
+    fH, fW = ogfH // downsample, ogfW // downsample
+    ds = torch.arange(*dbound, dtype=torch.float)
+    xs = torch.linspace(0, ogfW - 1, fW, dtype=torch.float)
+    ys = torch.linspace(0, ogfH - 1, fH, dtype=torch.float)
+    return xs.to(device), ys.to(device), ds.to(device)
+
+
+def geometry_from_mats(mats, xs, ys, ds, B, N):
+    D, fH, fW = ds.numel(), ys.numel(), xs.numel()
+    geom = torch.empty(B, N, D, fH, fW, 3, device=mats.device, dtype=_F32)
+    call("coocc_get_geometry", ptr(mats), ptr(xs), ptr(ys), ptr(ds), B * N, D, fH, fW, ptr(geom))
+    return geom
+
+
+def get_frustum(rots, trans, intrins, post_rots, post_trans, bda, input_size, scale):
+    """Module-level ``get_frustum`` of the detector (P/coocc/detectors/coocc_ray.py:732-776): ego-frame sample points
+    [B,N,D,H//scale,W//scale,3] of the 112 depth bins (2.0 .. 58.0 step 0.5, hard-coded upstream) for the LiDAR-only
+    depth-render branch (:436-484).  input_size = (H, W) tensors / numbers; KITTI 3x4 intrinsics and 4x4 bda handled."""
+    H = input_size[0].item() if torch.is_tensor(input_size[0]) else input_size[0]
+    W = input_size[1].item() if torch.is_tensor(input_size[1]) else input_size[1]
+    xs, ys, ds = frustum_axes((H, W), scale, (2.0, 58.0, 0.5), trans.device)
+    mats = camera_mats(rots, trans, intrins, post_rots, post_trans, bda)
+    return geometry_from_mats(mats, xs, ys, ds, trans.shape[0], trans.shape[1])
+
+
 @NECKS.register_module()
 class ViewTransformerLiftSplatShootVoxel(nn.Module):
     def __init__(self, loss_depth_weight=1.0, scale=16, point_cloud_range=None, loss_depth_type='bce',
                  grid_config=None, data_config=None, numC_input=512, numC_Trans=64, downsample=16,
                  accelerate=False, use_bev_pool=True, vp_megvii=False, vp_stero=False, cam_channels=27,
-                 loss_depth_reg_weight=0.0, use_voxel_net=False, **kwargs):
+                 loss_depth_reg_weight=0.0, use_voxel_net=False, depth_net=None, **kwargs):
         super().__init__()
+        if use_voxel_net:
+            raise NotImplementedError("DepthAggregation (use_voxel_net) is not used by the coocc_nusc configs")
         if grid_config is None:
             grid_config = {'xbound': [-51.2, 51.2, 0.8], 'ybound': [-51.2, 51.2, 0.8],
                            'zbound': [-10.0, 10.0, 20.0], 'dbound': [1.0, 60.0, 1.0]}
@@ -46,6 +96,20 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         self.point_cloud_range = point_cloud_range
         self.frustum = self.create_frustum()
         self.D = self.frustum.shape[0]
+        self.cam_channels = cam_channels
+        self.depth_net = depth_net if isinstance(depth_net, nn.Module) else self._reference_depth_net()
+
+    def _reference_depth_net(self):
+        """DepthNet(numC_input, numC_input, numC_Trans, D, cam_channels) of ViewTransformerLSSBEVDepth.py:616-617 -- the
+        reference's class (it needs mmcv's DCN), or None when the plugin / mmcv are not importable (forward then raises)."""
+        try:
+            from projects.mmdet3d_plugin.coocc.image2bev.ViewTransformerLSSBEVDepth import DepthNet
+            return DepthNet(self.numC_input, self.numC_input, self.numC_Trans, self.D, cam_channels=self.cam_channels)
+        except Exception:
+            return None
+
+    def get_depth_dist(self, x):
+        return x.softmax(dim=1)
 
     def create_frustum(self):
         """ViewTransformerLSSBEVDepth.py:104-115 (kept as the reference's [D,fH,fW,3] Parameter)."""
@@ -58,27 +122,41 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         return nn.Parameter(torch.stack((xs, ys, ds), -1), requires_grad=False)
 
     def _camera_mats(self, rots, trans, intrins, post_rots, post_trans, bda):
-        """Per-camera constants of the geometry chain (33 floats each) + the frustum axes."""
-        B, N, _ = trans.shape
-        if intrins.shape[3] == 4 or bda.shape[-1] == 4:
-            raise NotImplementedError("KITTI 3x4 intrinsics / 4x4 bda are not on the nuScenes path")
+        """Per-camera constants of the geometry chain (COOCC_CAM_FLOATS each) + the frustum axes."""
         fr = self.frustum.to(trans.device)
         xs, ys, ds = fr[0, 0, :, 0].contiguous(), fr[0, :, 0, 1].contiguous(), fr[:, 0, 0, 2].contiguous()
-        mats = torch.cat([torch.inverse(post_rots).reshape(B * N, 9), post_trans.reshape(B * N, 3),
-                          rots.matmul(torch.inverse(intrins)).reshape(B * N, 9), trans.reshape(B * N, 3),
-                          bda.view(B, 1, 9).expand(B, N, 9).reshape(B * N, 9)], 1).float().contiguous()
-        return mats, xs, ys, ds
+        return camera_mats(rots, trans, intrins, post_rots, post_trans, bda), xs, ys, ds
 
     def get_geometry(self, rots, trans, intrins, post_rots, post_trans, bda):
         """ViewTransformerLSSBEVDepth.py:117-150 -> [B,N,D,fH,fW,3].  The 3x3 inverses and the
         rots @ inv(intrins) product are host-side torch (6 tiny matrices); the per-point chain
         runs in one HIP kernel."""
-        B, N, _ = trans.shape
         mats, xs, ys, ds = self._camera_mats(rots, trans, intrins, post_rots, post_trans, bda)
-        D, fH, fW = ds.numel(), ys.numel(), xs.numel()
-        geom = torch.empty(B, N, D, fH, fW, 3, device=trans.device, dtype=_F32)
-        call("coocc_get_geometry", ptr(mats), ptr(xs), ptr(ys), ptr(ds), B * N, D, fH, fW, ptr(geom))
-        return geom
+        return geometry_from_mats(mats, xs, ys, ds, trans.shape[0], trans.shape[1])
+
+    def get_frustum(self, rots, trans, intrins, post_rots, post_trans, bda, scale):
+        """ViewTransformerLSSBEVDepth.py:152-195: the same chain on a frustum of ``input_size // scale`` pixels."""
+        xs, ys, ds = frustum_axes(self.data_config['input_size'], scale, self.grid_config['dbound'], trans.device)
+        mats = camera_mats(rots, trans, intrins, post_rots, post_trans, bda)
+        return geometry_from_mats(mats, xs, ys, ds, trans.shape[0], trans.shape[1])
+
+    def get_mlp_input(self, rot, tran, intrin, post_rot, post_tran, bda=None):
+        """ViewTransformerLSSBEVDepth.py:636-691: the camera-parameter vector DepthNet's SE branches consume
+        (27 numbers per camera for 3x3 intrinsics and bda; KITTI 3x4 intrinsics add 3, a 4x4 bda adds 3)."""
+        B, N = rot.shape[:2]
+        if bda is None:
+            bda = torch.eye(3).to(rot).view(1, 3, 3).repeat(B, 1, 1)
+        bda = bda.view(B, 1, *bda.shape[-2:]).repeat(1, N, 1, 1)
+        pick = lambda m, ij: [m[:, :, i, j] for i, j in ij]
+        kitti = intrin.shape[-1] == 4
+        cols = pick(intrin, [(0, 0), (1, 1), (0, 2), (1, 2)] + ([(0, 3), (1, 3), (2, 3)] if kitti else []))
+        cols += pick(post_rot, [(0, 0), (0, 1)]) + [post_tran[:, :, 0]] + pick(post_rot, [(1, 0), (1, 1)]) + [post_tran[:, :, 1]]
+        cols += pick(bda, [(0, 0), (0, 1), (1, 0), (1, 1), (2, 2)])
+        mlp_input = torch.stack(cols, dim=-1)
+        if kitti and bda.shape[-1] == 4:
+            mlp_input = torch.cat((mlp_input, bda[:, :, :3, -1]), dim=2)
+        sensor2ego = torch.cat([rot, tran.reshape(B, N, 3, 1)], dim=-1).reshape(B, N, -1)
+        return torch.cat([mlp_input, sensor2ego], dim=-1)
 
     def voxel_pooling(self, geom_feats, x):
         """ViewTransformerLSSVoxel.py:100-123: geom [B,N,D,H,W,3], x [B,N,D,H,W,C] -> [B,C,X,Y,Z]
@@ -127,8 +205,53 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         return out.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
 
     def forward(self, input):
-        """(volume [B,N,D,H,W,C], rots, trans, intrins, post_rots, post_trans, bda, ...) ->
-        (bev_feat, geom): the Splat half of ViewTransformerLSSVoxel.py:125-145."""
-        volume, rots, trans, intrins, post_rots, post_trans, bda = input[:7]
+        """ViewTransformerLSSVoxel.py:125-145, reference signature:
+        (x [B,N,C,H,W], rots, trans, intrins, post_rots, post_trans, bda, mlp_input) ->
+        (bev_feat [B,C,X,Y,Z], depth_prob [B*N,D,H,W], geom [B,N,D,H,W,3], sum_d volume [B*N,H,W,C]).
+        DepthNet is upstream torch; Lift (x) Splat is one fused HIP pass with the geometry computed in the key kernel
+        (inference) or through ``autograd.lift_splat`` (when gradients are needed).
+        A 6-D first element is taken as an already-lifted volume [B,N,D,H,W,C] -> (bev_feat, geom) (the Splat half alone)."""
+        x, rots, trans, intrins, post_rots, post_trans, bda = input[:7]
+        if x.dim() == 6:
+            geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans, bda)
+            return self.voxel_pooling(geom, x), geom
+        if self.depth_net is None:
+            raise NotImplementedError("ViewTransformerLiftSplatShootVoxel.forward: DepthNet is upstream of the hot path and "
+                                      "could not be built here (needs the reference plugin + mmcv DCN); pass depth_net=<module>")
+        B, N, C, H, W = x.shape
+        y = self.depth_net(x.view(B * N, C, H, W), input[7])
+        depth_prob = self.get_depth_dist(y[:, :self.D, ...])
+        img_feat = y[:, self.D:self.D + self.numC_Trans, ...]
         geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans, bda)
-        return self.voxel_pooling(geom, volume), geom
+        if torch.is_grad_enabled() and (depth_prob.requires_grad or img_feat.requires_grad):
+            from . import autograd as ag
+            bev_feat = ag.lift_splat(self, depth_prob, img_feat, geom)
+        else:
+            bev_feat = self.lift_splat(depth_prob, img_feat, cams=(rots, trans, intrins, post_rots, post_trans, bda))
+        vol_sum = (img_feat * depth_prob.sum(1, keepdim=True)).permute(0, 2, 3, 1)      # == volume.sum over D (:145)
+        return bev_feat, depth_prob, geom, vol_sum
+
+    # ------------------------------------------------------------------ DepthNet supervision (upstream torch, eager)
+    def get_downsampled_gt_depth(self, gt_depths):
+        """ViewTransformerLSSVoxel.py:30-56: [B,N,H,W] metric depth -> (bin values [B*N,h,w], one-hot [B*N*h*w, D]) with the
+        nearest non-zero depth of every downsample x downsample patch."""
+        B, N, H, W = gt_depths.shape
+        ds = self.downsample
+        g = gt_depths.view(B * N, H // ds, ds, W // ds, ds).permute(0, 1, 3, 2, 4).reshape(-1, ds * ds)
+        g = torch.where(g == 0.0, torch.full_like(g, 1e5), g).min(dim=-1).values.view(B * N, H // ds, W // ds)
+        db = self.grid_config['dbound']
+        g = (g - (db[0] - db[2] / 2)) / db[2]
+        vals = g.clone()
+        g = torch.where((g < self.D + 1) & (g >= 0.0), g, torch.zeros_like(g))
+        onehot = torch.nn.functional.one_hot(g.long(), num_classes=self.D + 1).view(-1, self.D + 1)[:, 1:]
+        return vals, onehot.float()
+
+    def get_depth_loss(self, depth_labels, depth_preds):
+        """ViewTransformerLSSVoxel.py:58-98, 'bce' type (what the coocc_nusc configs set)."""
+        if self.loss_depth_type != 'bce':
+            raise NotImplementedError("loss_depth_type %r: only 'bce' is used by the coocc_nusc configs" % self.loss_depth_type)
+        _, labels = self.get_downsampled_gt_depth(depth_labels)
+        preds = depth_preds.permute(0, 2, 3, 1).contiguous().view(-1, self.D)
+        fg = labels.max(dim=1).values > 0.0
+        loss = torch.nn.functional.binary_cross_entropy(preds[fg].float(), labels[fg], reduction='none').sum() / max(1.0, float(fg.sum()))
+        return self.loss_depth_weight * loss

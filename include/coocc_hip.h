@@ -350,8 +350,11 @@ int coocc_scatter_fine(const float* fine_logits, int64_t nfine, int ncls, int st
 
 /* ---------------------------------------------------------------- P1, P2 */
 /* get_geometry (P/coocc/image2bev/ViewTransformerLSSBEVDepth.py:117-150).
- * mats:[B*N][33] = inv(post_rots)(9), post_trans(3), rots@inv(intrins)(9), trans(3), bda(9);
+ * and the detector's module-level get_frustum (P/coocc/detectors/coocc_ray.py:732-776; same chain, scale instead of
+ * downsample).  mats:[B*N][COOCC_CAM_FLOATS] = inv(post_rots)(9), post_trans(3), rots@inv(intrins[:3,:3])(9), trans(3),
+ * bda[:3,:3](9), intrins[:3,3] of a KITTI 3x4/4x4 intrinsic else 0 (3), bda[:3,3] of a 4x4 bda else 0 (3);
  * xs:[fW], ys:[fH], ds:[D] frustum axes of create_frustum (:104-115).  geom:[B*N,D,fH,fW,3]. */
+#define COOCC_CAM_FLOATS 39
 int coocc_get_geometry(const float* mats, const float* xs, const float* ys, const float* ds, int BN,
                        int D, int fH, int fW, float* geom, void* stream);
 
