@@ -21,8 +21,11 @@ def nusc_class_weights():
 
 
 def _bce_to_one(x):
-    """F.binary_cross_entropy(x, ones) = -log(x) with torch's clamp of the log at -100."""
-    return -torch.log(x).clamp(min=-100.0)
+    """F.binary_cross_entropy(x, ones) = -log(x) with torch's clamp of the log at -100.  Written with a substituted
+    argument so that x == 0 gives the value 100 and a ZERO gradient (0 * inf would be NaN; torch's own backward clamps the
+    denominator at 1e-12 instead -- a degenerate case, e.g. a present class that receives no probability mass at all)."""
+    ok = x > 1e-43
+    return torch.where(ok, -torch.log(torch.where(ok, x, torch.ones_like(x))), torch.full_like(x, 100.0))
 
 
 def _flat(pred, target):

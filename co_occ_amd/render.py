@@ -70,18 +70,25 @@ class MLP(nn.Module):
 
 
 def voxel_table(sigma_head, rgb_head, vf):
-    """R1 per voxel: [V,4] = (sigma_head(f), rgb_head(f)) raw outputs (pointwise heads, F5)."""
+    """R1 per voxel: [V,4] = (sigma_head(f), rgb_head(f)) raw outputs (pointwise heads, F5); ``rgb_head=None`` (depth-only
+    branch) leaves the colour columns zero."""
     V = vf.t.shape[0]
-    table = torch.empty(V, 4, device=vf.t.device, dtype=_F32)
+    dev = vf.t.device
+    table = torch.empty(V, 4, device=dev, dtype=_F32) if rgb_head is not None else torch.zeros(V, 4, device=dev, dtype=_F32)
     x = vf.t if (vf.coff == 0 and vf.stride == vf.C) else vf.t[:, vf.coff:vf.coff + vf.C].contiguous()
     sigma_head.forward_rows(x, out=table, out_coff=0)
-    rgb_head.forward_rows(x, out=table, out_coff=1)
+    if rgb_head is not None:
+        rgb_head.forward_rows(x, out=table, out_coff=1)
     return table
 
 
-def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16):
+def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16, depth_only=False):
     """coocc_ray.py:570-627: voxel_feats Rows/[1,C,X,Y,Z], gemo [1,N,D,H,W,3] ->
-    rgbs [N,16H,16W,3], depths [N,16H,16W] (+ the pre-upsample maps [N,H,W,4])."""
+    rgbs [N,16H,16W,3], depths [N,16H,16W] (+ the pre-upsample maps [N,H,W,4]).
+    ``depth_only`` (or ``rgb_head=None``): the LiDAR-only branch (:436-484, geometry from ``get_frustum``) -- only the sigma
+    head is evaluated and only the depth maps are written; ``rgbs`` is None."""
+    if depth_only or rgb_head is None:
+        return _render_depth_only(sigma_head, voxel_feats, gemo, scale)
     from .core import to_rows
     vf = to_rows(voxel_feats)
     B, N, D, H, W, _ = gemo.shape
@@ -123,6 +130,22 @@ def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16):
             for t in (maps, rgbs, depths):
                 t.record_stream(side)
     return rgbs, depths, maps
+
+
+def _render_depth_only(sigma_head, voxel_feats, gemo, scale):
+    from .core import to_rows
+    vf = to_rows(voxel_feats)
+    B, N, D, H, W, _ = gemo.shape
+    assert B == 1 and vf.B == 1
+    table = voxel_table(sigma_head, None, vf)
+    g = gemo.reshape(N, D, H, W, 3).float().contiguous()
+    dev = g.device
+    zvals = torch.linspace(0, D, D, device=dev)
+    maps = torch.empty(N, H, W, 4, device=dev, dtype=_F32)
+    depths = torch.empty(N, H * scale, W * scale, device=dev, dtype=_F32)
+    call("coocc_render_nearest", ptr(table), vf.X, vf.Y, vf.Z, ptr(g), ptr(zvals), N, D, H, W, host_f32(RENDER_BOUNDS), 1, ptr(maps))
+    call("coocc_upsample_maps", ptr(maps), N, H, W, scale, None, ptr(depths))
+    return None, depths, maps
 
 
 def render_block_sharded(sigma_head, rgb_head, voxel_feats, gemo, scale=16, rank=None, world=None):

@@ -16,6 +16,9 @@ CONFIGS = {
     "r50": dict(grid=(100, 100, 8), ncam=6, fmap=(16, 44), knum=2, C=128),          # coocc_multi_r50_256x704
     "r101": dict(grid=(100, 100, 8), ncam=6, fmap=(56, 100), knum=2, C=128),        # coocc_multi_r101_896x1600
     "stress200": dict(grid=(200, 200, 16), ncam=6, fmap=(16, 44), knum=2, C=128),   # north_star stress grid
+    # configs[4]: coocc_multi_r101_openoccupancy.py -- 512x512x40 occupancy grid, fused grid 128x128x10 (0.8 m), cascade 4
+    "openocc": dict(grid=(128, 128, 10), ncam=6, fmap=(56, 100), knum=2, C=128, cascade_ratio=4, final_occ_size=(512, 512, 40),
+                    point_cloud_range=(-51.2, -51.2, -5.0, 51.2, 51.2, 3.0), input_size=(896, 1600)),
 }
 
 
@@ -113,6 +116,17 @@ def lifted_volume(ncam, D, fmap, C, seed=1234):
     ctx = g.standard_normal((ncam, C, fH, fW), dtype=np.float32)
     vol = depth[:, None] * ctx[:, :, None]                       # [N,C,D,H,W]
     return torch.from_numpy(np.ascontiguousarray(vol.transpose(0, 2, 3, 4, 1))[None].astype(np.float32))
+
+
+def model_cfg_openocc(rendering=True):
+    """The hot-path slice of projects/configs/coocc_nusc/coocc_multi_r101_openoccupancy.py (configs[4])."""
+    c = CONFIGS["openocc"]
+    cfg = model_cfg(C=c["C"], knum=c["knum"], cascade_ratio=c["cascade_ratio"], final_occ_size=c["final_occ_size"],
+                    point_cloud_range=c["point_cloud_range"], input_size=c["input_size"], rendering=rendering)
+    cfg["scale"] = 4
+    cfg["img_view_transformer"].update(scale=4, grid_config=dict(xbound=[-51.2, 51.2, 0.8], ybound=[-51.2, 51.2, 0.8],
+                                                                 zbound=[-5.0, 3.0, 0.8], dbound=[2.0, 58.0, 0.5]))
+    return cfg
 
 
 def model_cfg(C=128, knum=2, block_inplanes=(128, 256, 512, 1024), out_channels=256, num_cls=17,

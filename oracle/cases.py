@@ -110,3 +110,62 @@ def ray_inputs(c):
     d = torch.from_numpy(d / np.linalg.norm(d, axis=1, keepdims=True))
     raw = torch.from_numpy(np.abs(g.normal(0, 0.5, (c["n_rays"], c["n_samples"], 4))).astype(np.float32))
     return vol, o, d, raw
+
+
+FRUSTUM_CASE = dict(ncam=3, input_size=(64, 176), scale=16, seed=81)
+
+
+def frustum_inputs(c, kitti=False):
+    """Camera matrices for get_frustum; ``kitti``: [B,N,4,4] intrinsics with a non-zero 4th column (the KITTI shift) and a
+    4x4 bda with rotation + translation (coocc_ray.py:757-771)."""
+    rig = synth.camera_rig(c["ncam"], c["input_size"], seed=c["seed"])
+    g = np.random.default_rng(c["seed"])
+    post_rots = rig["post_rots"] * torch.from_numpy(g.uniform(0.4, 0.6, (1, c["ncam"], 1, 1)).astype(np.float32))
+    post_trans = torch.from_numpy(g.uniform(-3, 3, (1, c["ncam"], 3)).astype(np.float32)) * torch.tensor([1., 1., 0.])
+    intr, bda = rig["intrins"], rig["bda"]
+    if kitti:
+        K = torch.zeros(1, c["ncam"], 4, 4)
+        K[:, :, :3, :3] = intr
+        K[:, :, 3, 3] = 1
+        K[:, :, :3, 3] = torch.from_numpy(g.uniform(-0.5, 0.5, (1, c["ncam"], 3)).astype(np.float32))
+        a = 0.1
+        b = torch.eye(4)[None].clone()
+        b[0, :3, :3] = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.05]], dtype=torch.float32)
+        b[0, :3, 3] = torch.tensor([0.5, -0.25, 0.1])
+        intr, bda = K, b
+    H, W = c["input_size"]
+    return (rig["rots"], rig["trans"], intr, post_rots, post_trans, bda, (torch.tensor([H]), torch.tensor([W])))
+
+
+TRAIN_RENDER_CASE = dict(grid=(100, 100, 8), C=128, ncam=2, input_size=(64, 176), seed=91)
+
+
+def train_render_inputs(c):
+    """voxel features, rig, images [1,N,3,H,W] in [0,1], sparse metric depth maps [1,N,H,W] (70 % empty pixels)."""
+    g = np.random.default_rng(c["seed"])
+    X, Y, Z = c["grid"]
+    vf = torch.from_numpy(g.standard_normal((1, c["C"], X, Y, Z), dtype=np.float32))
+    rig = synth.camera_rig(c["ncam"], c["input_size"], seed=c["seed"])
+    H, W = c["input_size"]
+    imgs = torch.from_numpy(g.random((1, c["ncam"], 3, H, W), dtype=np.float32))
+    depth = g.uniform(0.5, 70.0, (1, c["ncam"], H, W)).astype(np.float32) * (g.random((1, c["ncam"], H, W)) < 0.3)
+    return vf, rig, imgs, torch.from_numpy(depth.astype(np.float32))
+
+
+LOSS_CASE = dict(coarse=(10, 12, 4), ratio=2, ncls=17, n_fine=900, seed=95)
+
+
+def loss_inputs(c):
+    """coarse logits [1,ncls,h,w,d], label volume [1,2h,2w,2d] (0 = empty 60 %, classes 1..16, 255 noise 4 %), fine logits
+    [n,ncls] at random fine coordinates [3,n]."""
+    g = np.random.default_rng(c["seed"])
+    h, w, d = c["coarse"]
+    r = c["ratio"]
+    logits = torch.from_numpy(g.standard_normal((1, c["ncls"], h, w, d), dtype=np.float32) * 2)
+    gt = g.integers(1, c["ncls"], (1, h * r, w * r, d * r)).astype(np.int64)
+    gt[g.random(gt.shape) < 0.6] = 0
+    gt[g.random(gt.shape) < 0.04] = 255
+    gt[0, :2, :3] = 0                                           # some all-empty coarse cells
+    coord = np.stack([g.integers(0, h * r, c["n_fine"]), g.integers(0, w * r, c["n_fine"]), g.integers(0, d * r, c["n_fine"])])
+    fine = torch.from_numpy(g.standard_normal((c["n_fine"], c["ncls"]), dtype=np.float32) * 2)
+    return logits, torch.from_numpy(gt), fine, torch.from_numpy(coord)

@@ -273,6 +273,112 @@ def gen_voxelize():
     save("voxelize", coors=coors, num=num, voxels=vox)
 
 
+def gen_frustum(R):
+    """Module-level get_frustum (coocc_ray.py:732-776) run unmodified, nuScenes (3x3) and KITTI-style (4x4 intrinsics with a
+    shift column, 4x4 bda) matrices; the oracle must reproduce it."""
+    cr = R["coocc_ray"]
+    c = cases.FRUSTUM_CASE
+    out = {}
+    for tag, kitti in (("nus", False), ("kitti", True)):
+        a = cases.frustum_inputs(c, kitti)
+        with torch.no_grad():
+            ref = cr.get_frustum(*a[:6], a[6], c["scale"])
+        o = ref_cpu.get_frustum(*a[:6], (c["input_size"][0], c["input_size"][1]), c["scale"])
+        assert maxdiff(ref, o) < 1e-4, tag
+        out[tag] = ref
+    print("get_frustum       |ref-oracle| nus %.1e kitti %.1e  shape %s" % (
+        maxdiff(out["nus"], ref_cpu.get_frustum(*cases.frustum_inputs(c)[:6], c["input_size"], c["scale"])),
+        maxdiff(out["kitti"], ref_cpu.get_frustum(*cases.frustum_inputs(c, True)[:6], c["input_size"], c["scale"])),
+        tuple(out["nus"].shape)))
+    save("frustum", **out)
+
+
+def gen_train_render(R):
+    """L1: the render regulariser of the UNMODIFIED ``COOCC_Ray.forward_train`` -- camera branch (coocc_ray.py:358-434:
+    loss_depth_render + loss_rgb) and LiDAR-only depth branch (:436-496, geometry from the module-level get_frustum) -- driven
+    with a stub ``self`` (encoders / occupancy losses stubbed out, the render code itself untouched)."""
+    c = cases.TRAIN_RENDER_CASE
+    vf, rig, imgs, depth = cases.train_render_inputs(c)
+    cr = R["coocc_ray"]
+    sig = R["nerf_mlp"].MLP(input_dim=128, output_dim=1, net_depth=1, skip_layer=None).eval()
+    rgb = R["nerf_mlp"].MLP(input_dim=128, output_dim=3, net_depth=3, skip_layer=None).eval()
+    ssd, rsd = synth.random_state_dict(sig.state_dict(), c["seed"]), synth.random_state_dict(rgb.state_dict(), c["seed"] + 1)
+    sig.load_state_dict(ssd)
+    rgb.load_state_dict(rsd)
+    H, W = c["input_size"]
+    mats = (rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
+    fr = ref_cpu.create_frustum(c["input_size"], 16, [2.0, 58.0, 0.5])
+    gemo = ref_cpu.get_geometry(fr, *mats)
+
+    def stub(img_feats):
+        return types.SimpleNamespace(
+            extract_feat=lambda points, img, img_metas: (vf, img_feats, None, None, gemo, None),
+            semantic_encoder=lambda x: x, semantic_neck=lambda x: x, record_time=False, disable_loss_depth=True,
+            forward_pts_train=lambda *a, **k: {}, loss_norm=False, use_rendering=True, sigma_head=sig, rgb_head=rgb)
+    img_inputs = [imgs, *mats, depth]
+    with torch.no_grad():
+        cam = cr.COOCC_Ray.forward_train(stub([torch.zeros(1)]), img_inputs=img_inputs)
+        gt_depths = (*mats, depth, (torch.tensor([H]), torch.tensor([W])))
+        lid = cr.COOCC_Ray.forward_train(stub(None), img_inputs=None, gt_depths=gt_depths)
+    o_cam = ref_cpu.train_render_losses(ssd, rsd, vf, gemo, imgs[0], depth[0])
+    o_lid = ref_cpu.train_render_losses(ssd, None, vf, ref_cpu.get_frustum(*mats, c["input_size"], 16), None, depth[0])
+    ds = [abs(float(cam[k]) - float(o_cam[k])) for k in ("loss_depth_render", "loss_rgb")] + \
+         [abs(float(lid["loss_depth_render"]) - float(o_lid["loss_depth_render"]))]
+    print("train render L1   ref: depth %.6f rgb %.6f | lidar-only depth %.6f   |ref-oracle| %s" % (
+        float(cam["loss_depth_render"]), float(cam["loss_rgb"]), float(lid["loss_depth_render"]), " ".join("%.1e" % d for d in ds)))
+    assert max(ds) < 1e-6 and set(lid) == {"loss_depth_render"}
+    save("train_render", loss_depth_render=cam["loss_depth_render"], loss_rgb=cam["loss_rgb"],
+         lidar_loss_depth_render=lid["loss_depth_render"])
+
+
+def gen_losses(R):
+    """OccHead.loss (occ_head.py:265-337) run unmodified on top of the real semkitti.py / lovasz_softmax.py: the four
+    coarse terms (majority-pooled labels, class-weighted CE) and the four fine terms; plus the pooled label volume."""
+    c = cases.LOSS_CASE
+    logits, gt, fine, coord = cases.loss_inputs(c)
+    oh = R["occ_head"]
+    head = oh.OccHead(in_channels=[32] * 2, out_channel=c["ncls"], num_level=2, soft_weights=True,
+                      norm_cfg=dict(type='BN3d', requires_grad=True), cascade_ratio=c["ratio"], sample_from_voxel=True,
+                      sample_from_img=True, final_occ_size=[v * c["ratio"] for v in c["coarse"]], empty_idx=0)
+    captured = {}
+    real_ce = oh.CE_ssc_loss
+
+    def ce_spy(pred, target, *a, **k):
+        captured.setdefault("targets", []).append(target.clone())
+        return real_ce(pred, target, *a, **k)
+    oh.CE_ssc_loss = ce_spy
+    try:
+        with torch.no_grad():
+            out = head.loss(output_voxels=[logits], output_coords_fine=[coord], output_voxels_fine=[fine],
+                            target_voxels=gt.clone())
+    finally:
+        oh.CE_ssc_loss = real_ce
+    print("occupancy losses  " + "  ".join("%s %.5f" % (k.replace("loss_voxel_", ""), float(v)) for k, v in out.items()))
+    save("losses", pooled_target=captured["targets"][0], class_weights=head.class_weights,
+         **{k: v for k, v in out.items()})
+
+
+def gen_state_dict_maps(R):
+    """Key -> shape map of the hot-path modules of the reference detector built from the REAL config files (r50 and
+    OpenOccupancy): checkpoint compatibility is pinned against these, not against a hand-written key list.  The image
+    encoder / DepthNet / LiDAR encoder entries (upstream of the path; mmdet / mmcv DCN / spconv are absent here) are left
+    out of the build, everything else is the unmodified ``COOCC_Ray.__init__``."""
+    cr = R["coocc_ray"]
+    out = {}
+    for tag, name in (("r50", "coocc_multi_r50_256x704"), ("openocc", "coocc_multi_r101_openoccupancy")):
+        cfg = dict(refshim.load_config(name)["model"])
+        cfg.pop("type")
+        for k in ("img_view_transformer", "img_backbone", "img_neck", "pts_voxel_layer", "pts_voxel_encoder", "pts_middle_encoder"):
+            cfg.pop(k, None)
+        m = cr.COOCC_Ray(**cfg)
+        sd = m.state_dict()
+        keys = sorted(sd)
+        out[tag + "_keys"] = np.array(keys)
+        out[tag + "_shapes"] = np.array([",".join(str(d) for d in sd[k].shape) for k in keys])
+        print("state_dict map    %-8s %d entries, %.1f M parameters" % (tag, len(keys), sum(v.numel() for v in sd.values()) / 1e6))
+    save("state_dict_maps", **out)
+
+
 def main():
     torch.set_num_threads(1)
     R = refshim.install()
@@ -284,6 +390,10 @@ def main():
     gen_rays(R)
     gen_eval(R)
     gen_voxelize()
+    gen_frustum(R)
+    gen_train_render(R)
+    gen_losses(R)
+    gen_state_dict_maps(R)
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print("golden fixtures: %.2f MB in %s" % (tot / 1e6, GOLD))
 

@@ -308,15 +308,25 @@ def get_geometry(frustum, rots, trans, intrins, post_rots, post_trans, bda):
     p = frustum - post_trans.view(B, N, 1, 1, 1, 3)
     p = torch.inverse(post_rots).view(B, N, 1, 1, 1, 3, 3).matmul(p.unsqueeze(-1))
     p = torch.cat((p[..., :2, :] * p[..., 2:3, :], p[..., 2:3, :]), 5)
+    if intrins.shape[3] == 4:                                # KITTI 3x4 / 4x4 intrinsics (:136-139)
+        p = p - intrins[:, :, :3, 3].view(B, N, 1, 1, 1, 3, 1)
+        intrins = intrins[:, :, :3, :3]
     combine = rots.matmul(torch.inverse(intrins))
     p = combine.view(B, N, 1, 1, 1, 3, 3).matmul(p).squeeze(-1)
     p = p + trans.view(B, N, 1, 1, 1, 3)
     if bda.shape[-1] == 4:
-        p = torch.cat((p, torch.ones(*p.shape[:-1], 1)), dim=-1)
+        p = torch.cat((p, torch.ones(*p.shape[:-1], 1, dtype=p.dtype)), dim=-1)
         p = bda.view(B, 1, 1, 1, 1, 4, 4).matmul(p.unsqueeze(-1)).squeeze(-1)[..., :3]
     else:
         p = bda.view(B, 1, 1, 1, 1, 3, 3).matmul(p.unsqueeze(-1)).squeeze(-1)
     return p
+
+
+def get_frustum(rots, trans, intrins, post_rots, post_trans, bda, input_size, scale):
+    """Module-level ``get_frustum`` of the detector (P/coocc/detectors/coocc_ray.py:732-776): the get_geometry chain on a
+    frustum of input_size // scale pixels with the depth bins 2.0 .. 58.0 step 0.5 hard-coded."""
+    H, W = int(input_size[0]), int(input_size[1])
+    return get_geometry(create_frustum((H, W), scale, [2.0, 58.0, 0.5]), rots, trans, intrins, post_rots, post_trans, bda)
 
 
 def gen_dx_bx(xbound, ybound, zbound):
@@ -371,7 +381,8 @@ RENDER_BOUNDS = ([-50., 50., 1.], [-50., 50., 1.], [-5., 3., 1.0])   # hard-code
 
 
 def render_camera(sigma_sd, rgb_sd, voxel_feats, geom, literal=True):
-    """R2, one camera: coocc_ray.py:575-616 (test) == :368-411 (train).
+    """R2, one camera: coocc_ray.py:575-616 (test) == :368-411 (train); ``rgb_sd=None`` is the depth-only branch
+    (:441-478, no colour head: rgb_map is returned as zeros).
     voxel_feats [C,X,Y,Z], geom [D,H,W,3] ego metres -> rgb_map [H,W,3], depth_map [H,W]
     (pre-upsample).  ``literal=False`` evaluates the heads once per voxel (F5)."""
     dx, bx, nx = (t.to(geom.dtype) for t in gen_dx_bx(*RENDER_BOUNDS))
@@ -384,12 +395,13 @@ def render_camera(sigma_sd, rgb_sd, voxel_feats, geom, literal=True):
     mask = inside.permute(1, 2, 0)
     if literal:
         feat = voxel_feats[:, pts[..., 0], pts[..., 1], pts[..., 2]].permute(1, 2, 3, 0)
-        rgb = mlp_forward(rgb_sd, feat, 3)
+        rgb = mlp_forward(rgb_sd, feat, 3) if rgb_sd is not None else torch.zeros(*feat.shape[:-1], 3, dtype=feat.dtype)
         sigma = mlp_forward(sigma_sd, feat, 1).squeeze(-1)
     else:
         C = voxel_feats.shape[0]
         tab = voxel_feats.reshape(C, -1).t()
-        rgb_t, sig_t = mlp_forward(rgb_sd, tab, 3), mlp_forward(sigma_sd, tab, 1)
+        sig_t = mlp_forward(sigma_sd, tab, 1)
+        rgb_t = mlp_forward(rgb_sd, tab, 3) if rgb_sd is not None else torch.zeros(tab.shape[0], 3, dtype=tab.dtype)
         lin = (pts[..., 0] * voxel_feats.shape[2] + pts[..., 1]) * voxel_feats.shape[3] + pts[..., 2]
         rgb, sigma = rgb_t[lin], sig_t[lin].squeeze(-1)
     rgb = torch.sigmoid(rgb * mask.unsqueeze(-1))   # rgb[~mask] = 0 ; sigmoid
@@ -433,6 +445,18 @@ def render_losses(rgbs, depths, rgb_gt, depth_gt, D):
     dg = ((depth_gt - (d_bound[0] - d_bound[2] / 2.)) / d_bound[2]).clip(0, D)
     fg = dg > 0
     return dict(loss_depth_render=F.mse_loss(depths[fg] / D, dg[fg] / D), loss_rgb=F.mse_loss(rgbs, rgb_gt))
+
+
+def train_render_losses(sigma_sd, rgb_sd, voxel_feats, gemo, imgs, depth_gt):
+    """Render regulariser of ``forward_train``: camera branch (coocc_ray.py:358-434; imgs [N,3,H,W], depth_gt [N,H,W]) or, with
+    ``rgb_sd=None`` / ``imgs=None``, the LiDAR-only depth branch (:436-496) whose ``gemo`` comes from ``get_frustum``."""
+    D = gemo.shape[2]
+    rgbs, depths = render_block(sigma_sd, rgb_sd, voxel_feats, gemo, literal=True)
+    if rgb_sd is None or imgs is None:
+        dg = ((depth_gt - 1.75) / 0.5).clip(0, D)
+        fg = dg > 0
+        return dict(loss_depth_render=F.mse_loss(depths[fg] / D, dg[fg] / D))
+    return render_losses(rgbs, depths, imgs.permute(0, 2, 3, 1), depth_gt, D)
 
 
 def volume_sampling(sample_pts, features, aabb):

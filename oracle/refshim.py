@@ -172,6 +172,16 @@ def _load(name, path):
 _installed = {}
 
 
+def load_config(name):
+    """Execute a reference config file (projects/configs/coocc_nusc/<name>.py; plain Python, the ``_base_`` runtime files
+    are not needed for the ``model`` dict) and return its namespace."""
+    path = os.path.join(REF, "projects", "configs", "coocc_nusc", name + ".py")
+    ns = {}
+    with open(path) as f:
+        exec(compile(f.read(), path, "exec"), ns)
+    return ns
+
+
 def install():
     """Install the stubs and load the reference hot-path modules.  Idempotent."""
     if _installed:
@@ -229,8 +239,8 @@ def install():
     _mod("projects.mmdet3d_plugin.utils.projection", Projector=None)
     rr = _load("projects.mmdet3d_plugin.utils.render_ray", os.path.join(PLUGIN, "utils", "render_ray.py"))
     _mod("projects.mmdet3d_plugin.utils.gaussian", generate_guassian_depth_target=None)
-    semk = _mod("projects.mmdet3d_plugin.utils.semkitti", geo_scal_loss=None, sem_scal_loss=None,
-                CE_ssc_loss=None, semantic_kitti_class_frequencies=np.ones(20))
+    # the real (pure-torch) loss files: OccHead.loss runs unmodified on top of them
+    semk = _load("projects.mmdet3d_plugin.utils.semkitti", os.path.join(PLUGIN, "utils", "semkitti.py"))
     utils.__dict__.update(
         coarse_to_fine_coordinates=ct.coarse_to_fine_coordinates,
         project_points_on_img=ct.project_points_on_img, per_class_iu=None, fast_hist_crop=None,
@@ -245,7 +255,7 @@ def install():
     _pkg("projects.mmdet3d_plugin.coocc")
     for sub in ("fuser", "backbones", "necks", "dense_heads", "image2bev", "detectors"):
         _pkg("projects.mmdet3d_plugin.coocc." + sub, os.path.join(cooc, sub))
-    _mod("projects.mmdet3d_plugin.coocc.dense_heads.lovasz_softmax", lovasz_softmax=None)
+    lov = _load("projects.mmdet3d_plugin.coocc.dense_heads.lovasz_softmax", os.path.join(cooc, "dense_heads", "lovasz_softmax.py"))
 
     class BEVDepth(nn.Module):
         """Stand-in for P/coocc/detectors/bevdepth.py:16-34: only the child building."""
@@ -269,7 +279,7 @@ def install():
         lss_voxel=_load(P + "image2bev.ViewTransformerLSSVoxel",
                         os.path.join(cooc, "image2bev", "ViewTransformerLSSVoxel.py")),
         coocc_ray=_load(P + "detectors.coocc_ray", os.path.join(cooc, "detectors", "coocc_ray.py")),
-        nerf_mlp=nm, render_ray=rr, coordinate_transform=ct,
+        nerf_mlp=nm, render_ray=rr, coordinate_transform=ct, semkitti=semk, lovasz=lov,
     )
     _installed.update(out)
     return out

@@ -30,14 +30,14 @@ def test_registry_builds_reference_config_names():
     with pytest.raises(KeyError):
         pkg.build_backbone(dict(type="NoSuchBackbone"))
     # encoder configs upstream of the path are accepted and ignored (coocc_multi_r50_256x704.py:96-135)
-    m2 = pkg.build_detector(dict(cfg, img_backbone=dict(type='ResNet', depth=50),
+    m2 = pkg.build_detector(external_encoders=True, cfg=dict(cfg, img_backbone=dict(type='ResNet', depth=50), train_cfg=None,
                                  pts_voxel_layer=dict(max_num_points=10, point_cloud_range=[-50, -50, -5, 50, 50, 3],
                                                       voxel_size=[0.125] * 3, max_voxels=(90000, 120000)),
                                  pts_voxel_encoder=dict(type='HardSimpleVFE', num_features=5),
                                  pts_middle_encoder=dict(type='SparseLiDAREnc8x', input_channel=4, base_channel=16, out_channel=128,
                                                          norm_cfg=dict(type='SyncBN', requires_grad=True),
                                                          sparse_shape_xyz=[800, 800, 64])))
-    assert "img_backbone" in m2.ignored_cfg_keys            # encoders upstream of the path stay out of scope
+    assert "train_cfg" in m2.ignored_cfg_keys and m2.img_backbone is None   # encoders upstream of the path: deferred
     assert type(m2.pts_middle_encoder).__name__ == "SparseLiDAREnc8x" and m2.pts_voxel_layer.max_num_points == 10
 
 
