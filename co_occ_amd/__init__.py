@@ -19,6 +19,7 @@ from .render import MLP, raw2outputs, render_block, sample_along_camera_ray, vol
 from .detector import COOCC_Ray, COOCC_Ray_L
 from .view_transformer import get_frustum
 from . import losses
+from .core import invalidate_packs
 from . import apis, evaluation
 from . import lidar
 from .lidar import HardSimpleVFE, SparseLiDAREnc4x, SparseLiDAREnc8x, Voxelization

@@ -195,14 +195,39 @@ def check(rc):
         raise CooccError("libcoocc_hip: %s (code %d)" % (load().coocc_last_error().decode(), rc))
 
 
+def _device_of(args):
+    for a in args:
+        t = getattr(a, "_keep", None)
+        if t is not None:
+            return t.device
+    return None
+
+
 def call(name, *args):
-    """Call an int-returning entry point on the current torch HIP stream."""
+    """Call an int-returning entry point on the torch HIP stream OF THE ARGUMENTS' DEVICE (the first device pointer
+    decides; a module living on cuda:1 while cuda:0 is current launches on cuda:1's current stream under a device guard)."""
+    dev = _device_of(args)
+    if dev is not None and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            with TIMER.region(name):
+                check(getattr(load(), name)(*args, stream(dev)))
+        return
     with TIMER.region(name):
-        check(getattr(load(), name)(*args, stream()))
+        check(getattr(load(), name)(*args, stream(dev)))
 
 
-def stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+def conv_fwd(desc, device):
+    """coocc_conv_fwd on ``device``'s current stream (device guard when it is not the current device)."""
+    fn = load().coocc_conv_fwd
+    if device.index != torch.cuda.current_device():
+        with torch.cuda.device(device):
+            check(fn(ctypes.byref(desc), stream(device)))
+    else:
+        check(fn(ctypes.byref(desc), stream(device)))
+
+
+def stream(device=None):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 class DevPtr(ctypes.c_void_p):

@@ -87,7 +87,7 @@ def pack_weights_dev(w, Cout, Cin, taps, mode):
     if n < 0:
         _lib.check(int(n))
     packed = torch.empty(n, dtype=_F32, device=w.device)
-    n = lib.coocc_conv_pack_weights_dev(ptr(w), Cout, Cin, taps, mode, ptr(packed), _lib.stream())
+    n = lib.coocc_conv_pack_weights_dev(ptr(w), Cout, Cin, taps, mode, ptr(packed), _lib.stream(w.device))
     if n < 0:
         _lib.check(int(n))
     return packed
@@ -112,7 +112,7 @@ class _DevWino:
             if n < 0:
                 _lib.check(int(n))
             packed = torch.empty((tile + 2) ** 2, n // (tile + 2) ** 2, dtype=_F32, device=self._w5.device)
-            n = lib.coocc_wino_pack_weights_dev(ptr(self._w5), Cout, Cin, tile, self._dgrad, ptr(packed), _lib.stream())
+            n = lib.coocc_wino_pack_weights_dev(ptr(self._w5), Cout, Cin, tile, self._dgrad, ptr(packed), _lib.stream(self._w5.device))
             if n < 0:
                 _lib.check(int(n))
             self._packs[tile] = packed
@@ -199,7 +199,7 @@ def _conv_launch(x2d, in_C, w_packed, out2d, Cout, taps, geom_in, geom_out, ksiz
     d.relu, d.res_mode, d.splitk = int(relu), (1 if res2d is not None else 0), 0
     d.tile_hint = TILE_HINT
     with _lib.TIMER.region(tag, 2.0 * d.M * in_C * Cout * taps):
-        _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+        _lib.conv_fwd(d, x2d.device)
 
 
 class ConvRowsFn(torch.autograd.Function):

@@ -84,7 +84,7 @@ class CustomResNet3D(nn.Module):
             elif isinstance(m, (nn.BatchNorm3d, nn.SyncBatchNorm)):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
-        self._packs = PackCache()
+        self._packs = PackCache(self)
 
     def _make_layer(self, planes, blocks, stride, norm_cfg):
         downsample = None

@@ -273,7 +273,7 @@ def conv_rows_wino(x, pc, out, relu, res, plan):
             and (pts * G // 128) * -(-pc.Cout // 128) > 768):
         kname = "k_conv2p"          # mirror of the dispatch in coocc_conv_fwd: persistent workgroups, >= 2 tiles each
     with TIMER.region(kname + " wino%d" % tile, 2.0 * pts * rows * pc.Cin * pc.Cout * 3):
-        _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+        _lib.conv_fwd(d, V.device)
     with TIMER.region("k_wino_out", 4.0 * pts * rows * pc.Cout + 4.0 * x.V * pc.Cout):
         call("coocc_wino_output", ptr(Mb), G, x.B, x.X, x.Y, x.Z, pc.Cout, tile, out.data(), out.stride, ptr(pc.scale),
              ptr(pc.bias), res.data() if res is not None else None, res.stride if res is not None else 0, int(relu))
@@ -330,7 +330,7 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
             d.taps = taps = 9 * (hi - lo + 1)
     with TIMER.region(conv_kernel_name(M, pc.Cout, False, 0, taps * -(-pc.Cin // 32), pc.ksize == 1 and pc.stride == 1 and pc.pad == 0),
                       2.0 * M * pc.Cin * pc.Cout * taps):
-        _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+        _lib.conv_fwd(d, pc.w.device)
     return out
 
 
@@ -359,7 +359,7 @@ def linear_rows(x2d, pc, relu=False, out=None, out_coff=0, in_coff=0, in_C=None)
     d.relu, d.res_mode, d.splitk = int(relu), 0, 0
     d.tile_hint = TILE_HINT
     with TIMER.region(conv_kernel_name(n, pc.Cout, False, 0, -(-Cin // 32), True), 2.0 * n * Cin * pc.Cout):
-        _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+        _lib.conv_fwd(d, x2d.device)
     return out
 
 
@@ -386,15 +386,23 @@ def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_co
     d.relu, d.res_mode, d.splitk = int(relu), 2, 1
     d.tile_hint = TILE_HINT
     with TIMER.region(conv_kernel_name(M, pc.Cout, True), 2.0 * M * C * pc.Cout * K):
-        _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+        _lib.conv_fwd(d, src.device)
 
 
 class PackCache:
-    """Re-pack lazily when any source parameter/buffer changed (torch `_version` counters)."""
+    """Re-pack lazily when any source parameter/buffer changed (torch `_version` counters).  Writes that bypass the
+    version counter (``p.data.copy_()``, EMA / weight-surgery hooks) are not seen: ``PackCache(owner)`` registers a
+    ``load_state_dict`` post-hook on the owning module that drops the packs, and ``invalidate()`` (or
+    ``co_occ_amd.invalidate_packs(model)``) does so explicitly after any other in-place surgery."""
 
-    def __init__(self):
+    def __init__(self, owner=None):
         self._key = None
         self._val = None
+        if owner is not None and hasattr(owner, "register_load_state_dict_post_hook"):
+            owner.register_load_state_dict_post_hook(lambda module, incompatible_keys: self.invalidate())
+
+    def invalidate(self):
+        self._key = self._val = None
 
     def get(self, tensors, build):
         key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors if t is not None)
@@ -402,3 +410,15 @@ class PackCache:
             self._val = build()
             self._key = key
         return self._val
+
+
+def invalidate_packs(module):
+    """Drop every cached weight pack / folded-BN constant under ``module`` (call after writing parameters through
+    ``.data`` or any other path that does not bump the tensors' version counters)."""
+    n = 0
+    for m in module.modules():
+        pc = getattr(m, "_packs", None)
+        if isinstance(pc, PackCache):
+            pc.invalidate()
+            n += 1
+    return n

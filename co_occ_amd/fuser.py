@@ -133,7 +133,7 @@ class BiFuser_N(nn.Module):
             nn.Conv3d(in_channels * 2, out_channels, 3, padding=1, bias=False),
             nn.BatchNorm3d(out_channels), nn.ReLU(True))
         self.knn_enc = nn.Sequential(nn.Linear(in_channels * knum, out_channels), nn.ReLU())
-        self._packs = PackCache()
+        self._packs = PackCache(self)
         self.last_counts = None
 
     # ---------------------------------------------------------------- packing

@@ -80,7 +80,7 @@ class OccHead(nn.Module):
         if soft_weights:
             self.voxel_soft_weights = nn.Sequential(_conv3d(conv_cfg, mid, mid // 2, 1, 0), build_bn(norm_cfg, mid // 2),
                                                     nn.ReLU(inplace=True), _conv3d(conv_cfg, mid // 2, num_level, 1, 0))
-        self._packs = PackCache()
+        self._packs = PackCache(self)
 
     # ---------------------------------------------------------------- packing
     def _packed(self):

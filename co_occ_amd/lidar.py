@@ -146,7 +146,7 @@ def sparse_conv(feats, Cin, pc, table, relu=True, res=None, out=None, out_rows=N
     d.ksize, d.stride, d.pad = 1, 1, 0
     d.relu, d.res_mode, d.splitk, d.tile_hint = int(relu), (1 if res is not None else 0), 1, TILE_HINT
     with _lib.TIMER.region("k_conv<sparse table %d->%d>" % (Cin, pc.Cout), 2.0 * Mo * Cin * pc.Cout * taps):
-        _lib.check(_lib.load().coocc_conv_fwd(ctypes.byref(d), _lib.stream()))
+        _lib.conv_fwd(d, pc.w.device)
     return out
 
 
@@ -211,7 +211,7 @@ class _SparseEncoderBase(nn.Module):
             cin = c
         self.conv1, self.conv2, self.conv3 = stages
         self.conv_out = nn.Sequential(_SpConv(cin, out_channel, 3, bias=True), nn.GroupNorm(16, out_channel), nn.ReLU(inplace=True))
-        self._packs = PackCache()
+        self._packs = PackCache(self)
 
     def _packed(self):
         srcs = list(self.parameters()) + list(self.buffers())

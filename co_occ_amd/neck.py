@@ -37,7 +37,7 @@ class FPN3D(nn.Module):
         for i in range(self.num_out):
             self.lateral_convs.append(nn.Sequential(ConvModule(in_channels[i], out_channels, 1, 0, norm_cfg)))
             self.fpn_convs.append(nn.Sequential(ConvModule(out_channels, out_channels, 3, 1, norm_cfg)))
-        self._packs = PackCache()
+        self._packs = PackCache(self)
 
     def _packed(self):
         srcs = list(self.parameters()) + list(self.buffers())

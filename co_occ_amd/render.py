@@ -50,7 +50,7 @@ class MLP(nn.Module):
         for m in list(self.hidden_layers) + [self.output_layer]:
             nn.init.xavier_uniform_(m.weight)
             nn.init.zeros_(m.bias)
-        self._packs = PackCache()
+        self._packs = PackCache(self)
 
     def _packed(self):
         def build():
