@@ -33,38 +33,58 @@ from co_occ_amd import core  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, fp32-input MFMA (spec)
 HBM_PEAK_GBS = 8000.0          # HBM3E spec
+TRAFFIC_FILE = "r1_traffic.json"
 
 
 def make_inputs(cfgname, seed, dev, model):
+    """One synthetic sample, resident in HBM: the lifted image-branch outputs (softmax depth [N,D,fH,fW] + context features
+    [N,C,fH,fW], what DepthNet hands to Lift-Splat), the LiDAR-sweep voxel volume, the 2D features the fine branch samples,
+    the camera matrices.  ``img`` (the pooled camera volume) is kept too for --no-pool runs and the parity tests."""
     c = synth.CONFIGS[cfgname]
     img, pts = synth.voxel_inputs(c["grid"], C=c["C"], seed=seed, p_img=c.get("p_img", 0.65), p_pts=c.get("p_pts", 0.12))
     fH, fW = c["fmap"]
     rig = synth.camera_rig(c["ncam"], (fH * 16, fW * 16), seed=seed)
     r = {k: v.to(dev) for k, v in rig.items() if torch.is_tensor(v)}
     vt = model.img_view_transformer
-    gemo = vt.get_geometry(r["rots"], r["trans"], r["intrins"], r["post_rots"], r["post_trans"], r["bda"])
+    cams = tuple(r[k] for k in ("rots", "trans", "intrins", "post_rots", "post_trans", "bda"))
+    gemo = vt.get_geometry(*cams)
+    depth, ctx = synth.lift_inputs(c["ncam"], vt.D, c["fmap"], c["C"], seed=seed)
     img_feats = [synth.image_feats(c["ncam"], c["fmap"], 512, seed=seed).to(dev)]
     transform = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synth.rig_transform(rig))
-    return dict(img=img.to(dev), pts=pts.to(dev), gemo=gemo, img_feats=img_feats, transform=transform,
-                cpu=dict(img=img, pts=pts, rig=rig, img_feats=[img_feats[0].cpu()]))
+    return dict(img=img.to(dev), pts=pts.to(dev), gemo=gemo, img_feats=img_feats, transform=transform, cams=cams,
+                depth=depth.to(dev), ctx=ctx.to(dev),
+                cpu=dict(img=img, pts=pts, rig=rig, img_feats=[img_feats[0].cpu()], lift=(depth, ctx)))
 
 
 def build_model(cfgname, dev):
     c = synth.CONFIGS[cfgname]
     fH, fW = c["fmap"]
     X, Y, Z = c["grid"]
-    cfg = synth.model_cfg(C=c["C"], knum=c["knum"], final_occ_size=(2 * X, 2 * Y, 2 * Z), input_size=(fH * 16, fW * 16))
+    if cfgname == "openocc":
+        cfg = synth.model_cfg_openocc()
+    else:
+        cfg = synth.model_cfg(C=c["C"], knum=c["knum"], final_occ_size=(2 * X, 2 * Y, 2 * Z), input_size=(fH * 16, fW * 16))
+        cfg["img_view_transformer"]["grid_config"].update(synth.pool_bounds(cfgname))
+    c["bounds"] = synth.pool_bounds(cfgname)
     model = pkg.build_detector(cfg)
     sd = synth.random_state_dict(model.state_dict(), seed=0)
     model.load_state_dict(sd)
     return model.to(dev).eval(), sd
 
 
-def step(model, s, world, search=None):
+def pool(model, s):
+    """P2 inside the step: fused Lift (x) Splat of the sample's depth distribution and context features, geometry from
+    the camera matrices in-kernel (ViewTransformerLSSVoxel.py:135-145) -> the camera voxel volume [1,C,X,Y,Z]."""
+    return model.img_view_transformer.lift_splat(s["depth"], s["ctx"], cams=s["cams"])
+
+
+def step(model, s, world, search=None, img=None):
     # the reference hard-codes the render bounds to a 100x100x8 volume (coocc_ray.py:577): smaller test grids
     # (config1) cannot be rendered there either
-    X, Y, Z = s["img"].shape[2:]
-    out = model.forward_hot_path(s["img"], s["pts"], s["gemo"], s["img_feats"], s["transform"],
+    if img is None:
+        img = pool(model, s) if WITH_POOL[0] else s["img"]
+    X, Y, Z = img.shape[2:]
+    out = model.forward_hot_path(img, s["pts"], s["gemo"], s["img_feats"], s["transform"],
                                  render=(X >= 100 and Y >= 100 and Z >= 8), search=search)
     if world > 1:
         # one RCCL all-gather of the packed maps per step, issued asynchronously: the previous step's gather is
@@ -84,6 +104,7 @@ def step(model, s, world, search=None):
 
 _pending = []
 _async_ok = [True]
+WITH_POOL = [True]
 
 
 def drain_gathers():
@@ -110,9 +131,10 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(sd, s, cfgname, seconds_cap):
-    """The oracle's literal CPU restatement of the same step (gather-then-MLP render, materialised
-    concat, sort-based pooling is not part of the step) on this host's cores, one sample."""
+def cpu_baseline(sd, s, cfgname, with_pool, runs=3):
+    """The oracle's literal CPU restatement of the same step (materialised lift + sort-based pooling when the step starts
+    from the lifted inputs, materialised concat, gather-then-MLP render) on this host's cores: 1 warm-up run + the median of
+    ``runs`` timed runs, with per-stage seconds."""
     from oracle import ref_cpu
     c = synth.CONFIGS[cfgname]
     X, Y, Z = c["grid"]
@@ -121,15 +143,73 @@ def cpu_baseline(sd, s, cfgname, seconds_cap):
     fr = ref_cpu.create_frustum((c["fmap"][0] * 16, c["fmap"][1] * 16), 16, [2.0, 58.0, 0.5])
     gemo = ref_cpu.get_geometry(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
     sdc = {k: v.cpu() for k, v in sd.items()}
+    sub = lambda p: {k[len(p):]: v for k, v in sdc.items() if k.startswith(p)}
     torch.set_num_threads(usable_cores())
-    t0 = time.perf_counter()
+    tr = synth.rig_transform(rig)
+    cr = c.get("cascade_ratio", 2)
+    occ = tuple(c.get("final_occ_size", (2 * X, 2 * Y, 2 * Z)))
+    pcr = tuple(c.get("point_cloud_range", (-50, -50, -5.0, 50, 50, 3.0)))
+    render = X >= 100 and Y >= 100 and Z >= 8
+
+    def once():
+        st = {}
+        t = time.perf_counter()
+        img = cpu["img"]
+        if with_pool:
+            depth, ctx = cpu["lift"]
+            vol = (depth[:, None] * ctx[:, :, None]).permute(0, 2, 3, 4, 1)[None].contiguous()      # Lift (LSSVoxel.py:135-143)
+            dx, bx, nx = ref_cpu.gen_dx_bx(*[c["bounds"][k] for k in ("xbound", "ybound", "zbound")])
+            img = ref_cpu.voxel_pooling(gemo, vol, dx, bx, nx).contiguous()
+        st["lift+pool"] = time.perf_counter() - t; t = time.perf_counter()
+        vf = ref_cpu.bifuser_forward(sub("occ_fuser."), img, cpu["pts"], c["knum"])
+        st["fuser"] = time.perf_counter() - t; t = time.perf_counter()
+        sem = ref_cpu.fpn3d_forward(sub("semantic_neck."), ref_cpu.resnet3d_forward(sub("semantic_encoder."), vf))
+        st["encoder+neck"] = time.perf_counter() - t; t = time.perf_counter()
+        ref_cpu.occhead_forward(sub("pts_bbox_head."), sem, cpu["img_feats"], tr, cr, occ, pcr)
+        st["head"] = time.perf_counter() - t; t = time.perf_counter()
+        if render:
+            ref_cpu.render_block(sub("sigma_head."), sub("rgb_head."), vf, gemo, True)
+        st["render"] = time.perf_counter() - t
+        st["total"] = sum(st.values())
+        return st
     with torch.no_grad():
-        ref_cpu.hot_path_forward(sdc, cpu["img"], cpu["pts"], gemo, cpu["img_feats"], synth.rig_transform(rig), knum=c["knum"],
-                                 cascade_ratio=2, final_occ_size=(2 * X, 2 * Y, 2 * Z), literal_render=True)
-    dt = time.perf_counter() - t0
-    return dict(value=1.0 / dt, unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                sample="1 sample of the %s workload (rank-0 inputs, seed 1234), single run, %.1f s" % (cfgname, dt),
-                seconds=dt)
+        once()                                             # warm-up (allocator, oneDNN primitive caches)
+        runs_ = sorted((once() for _ in range(runs)), key=lambda d: d["total"])
+    med = runs_[len(runs_) // 2]
+    return dict(value=round(1.0 / med["total"], 5), unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample="1 sample of the %s workload (rank-0 inputs, seed 1234): 1 warm-up + median of %d runs, %.2f s each" % (
+                    cfgname, runs, med["total"]),
+                seconds=round(med["total"], 3), stage_seconds={k: round(v, 3) for k, v in med.items() if k != "total"},
+                all_runs_seconds=[round(r["total"], 3) for r in runs_])
+
+
+def render_r101_roofline(model, dev, iters=20):
+    """The HBM-bound render pair at configs[2]'s size (6 x 56 x 100 rays x 112 samples -> 6 x 896 x 1600 maps, 184.1 MB
+    algorithmic), timed with HIP events AFTER the timed region on random fused features: north_star's ">= 40 % of the HBM
+    roofline on the render kernel" is defined at this size (at r50 the pair moves 24 MB in ~25 us and is launch-bound)."""
+    from co_occ_amd.render import render_block
+    from co_occ_amd.view_transformer import get_frustum
+    rig = synth.camera_rig(6, (896, 1600), seed=7)
+    mats = [rig[k].to(dev) for k in ("rots", "trans", "intrins", "post_rots", "post_trans", "bda")]
+    gemo = get_frustum(*mats, (896, 1600), 16)
+    vf = torch.randn(1, 128, 100, 100, 8, device=dev)
+    keep = (core.TIMER.enabled, core.TIMER.only)
+    with torch.no_grad():
+        for _ in range(3):
+            render_block(model.sigma_head, model.rgb_head, vf, gemo, 16)
+        torch.cuda.synchronize()
+        core.TIMER.enabled, core.TIMER.only = 1, ("k_render_nearest",)
+        core.TIMER.reset()
+        for _ in range(iters):
+            render_block(model.sigma_head, model.rgb_head, vf, gemo, 16)
+        torch.cuda.synchronize()
+    v = core.TIMER.summary()["k_render_nearest+k_upsample_maps"]
+    core.TIMER.enabled, core.TIMER.only = keep
+    core.TIMER.reset()
+    ach = v["work"] / (v["ms"] * 1e-3) / 1e9
+    return dict(bound="hbm", kernel="k_render_nearest+k_upsample_maps", workload="coocc_multi_r101_896x1600 render pair",
+                achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                algorithmic_bytes=int(v["work"] / v["launches"]), avg_ms=round(v["ms"] / v["launches"], 4), launches=v["launches"])
 
 
 def main():
@@ -144,17 +224,38 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs set aside for the FPS chains (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL on GPUs)")
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (single-GPU check of the N > 1 path, gloo)")
+    ap.add_argument("--no-pool", action="store_true",
+                    help="start the step from an already-pooled camera volume (round-1 definition) instead of the lifted "
+                         "depth/context pair (SURVEY.md 8d: 'lifted features + sweep volume -> logits')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event timing table to stderr")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU
+        import socket
+        import subprocess
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     rank, world, local = cdist.init(backend=args.backend)
     if args.same_device:
         local = 0           # control-flow check of the multi-rank path on a single GPU (use with --backend gloo)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:  # never fall back to fewer ranks than asked for: the scaling curve would be silently wrong
+        raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s) (WORLD_SIZE=%s); launch with "
+                         "torch.distributed.run --nproc-per-node %d or without a launcher" % (
+                             args.gpus, world, os.environ.get("WORLD_SIZE"), args.gpus))
+    import torch.distributed as tdist
+    seen_world = tdist.get_world_size() if (tdist.is_available() and tdist.is_initialized()) else 1
+    backend_name = tdist.get_backend() if seen_world > 1 else None
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    WITH_POOL[0] = not args.no_pool
     model, sd = build_model(args.config, dev)
     samples = [make_inputs(args.config, 1234 + 17 * rank + i, dev, model) for i in range(2)]
     if args.reserve_cus > 0:
@@ -167,14 +268,16 @@ def main():
 
     import threading
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(1) if (args.prefetch and len(streams) == 1) else None
+    tpool = ThreadPoolExecutor(1) if (args.prefetch and len(streams) == 1) else None
     # high priority: a lone 1024-thread FPS workgroup must win a CU slot against the queue of convolution workgroups
     search_stream = torch.cuda.Stream(device=dev, priority=-1)
 
     def do_search(s):
+        """Pooling (P2) + index search (K1-K5) of one sample on the high-priority prefetch stream."""
         torch.cuda.set_device(dev)
         with torch.cuda.stream(search_stream), torch.no_grad():
-            return model.search(s["img"], s["pts"])
+            img = pool(model, s) if WITH_POOL[0] else s["img"]
+            return img, model.search(img, s["pts"])
 
     def run(nsteps, timed):
         """`nsteps` samples round-robin over len(streams) host threads, one HIP stream each: the
@@ -195,13 +298,15 @@ def main():
             # index search of sample i+1 (no collective, one device->host read) runs on a helper thread and its own
             # stream under the dense stage of sample i; dense stages never overlap each other.
             with torch.no_grad():
-                fut = pool.submit(do_search, samples[0]) if (pool and nsteps) else None
+                fut = tpool.submit(do_search, samples[0]) if (tpool and nsteps) else None
                 for i in range(nsteps):
-                    sr = fut.result() if fut is not None else None
-                    if pool and i + 1 < nsteps:
-                        fut = pool.submit(do_search, samples[(i + 1) % len(samples)])
+                    img, sr = fut.result() if fut is not None else (None, None)
+                    if tpool and i + 1 < nsteps:
+                        fut = tpool.submit(do_search, samples[(i + 1) % len(samples)])
                     with torch.cuda.stream(streams[i % len(streams)]):
-                        step(model, samples[i % len(samples)], world, search=sr)
+                        if img is not None:
+                            img.record_stream(streams[i % len(streams)])
+                        step(model, samples[i % len(samples)], world, search=sr, img=img)
             with torch.cuda.stream(streams[0]):
                 drain_gathers()          # the last step's all-gather belongs to the timed region
             for st in streams:
@@ -220,7 +325,7 @@ def main():
     torch.cuda.synchronize()
     run(args.warmup, False)
     core.TIMER.enabled = 0 if args.no_kernel_timing else (2 if args.kernel_table else 1)
-    core.TIMER.only = ("k_conv", "k_render_nearest")      # what the roofline objects below need
+    core.TIMER.only = ("k_conv", "k_render_nearest", "k_lift_splat")      # what the roofline objects below need
     core.TIMER.reset()
     cdist.barrier()
     torch.cuda.synchronize()
@@ -260,7 +365,7 @@ def main():
             ach = v["work"] / (v["ms"] * 1e-3) / 1e12      # flops the matrix cores execute (Winograd-domain for "wino")
             traffic = None
             try:   # HBM bytes per launch from the committed PMC passes (cannot be collected inside this process)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+                tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
                 traffic = tj[dom]["bytes_per_launch"] if args.config == "r50" else None
             except Exception:
                 pass
@@ -269,7 +374,10 @@ def main():
             symbol = {"k_conv2<160,wg> wino": "k_conv2<160, 2, true, 2, false>", "k_conv2p wino": "k_conv2p<true, false>",
                       "k_conv2<128,wg> wino": "k_conv2<128, 1, true, 3, false>"}.get(dom, dom)     # name in the rocprofv3 trace
             roof = dict(bound="mfma", kernel=dom, symbol=symbol, achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=traffic, launches=v["launches"],
+                        frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=traffic,
+                        traffic_source=("profiles/%s (rocprofv3 --pmc passes of this command, replayed: HBM counters cannot be "
+                                        "collected in-process)" % TRAFFIC_FILE) if traffic is not None else None,
+                        launches=v["launches"],
                         avg_launch_ms=round(v["ms"] / v["launches"], 4),
                         share_of_timed_kernels=round(v["ms"] / tot, 3),
                         flops="executed on the MFMA pipe (direct-conv-equivalent x%.2f = %.1f TFLOP/s)" % (equiv, ach * equiv))
@@ -277,6 +385,14 @@ def main():
             extra["roofline_all_convs"] = dict(bound="mfma", kernel="every k_conv* launch", achieved=round(allc, 2),
                                                peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(allc / MFMA_F32_PEAK_TFLOPS, 4),
                                                ms_per_step=round(sum(v2["ms"] for v2 in convs.values()) / args.steps, 3))
+        if "k_lift_splat" in ksum:
+            v = ksum["k_lift_splat"]
+            ach = v["work"] / (v["ms"] * 1e-3) / 1e9
+            extra["roofline_pool"] = dict(bound="hbm", kernel="coocc_lift_splat_cams (keys + binning + per-voxel sums)",
+                                          achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                                          traffic=None, algorithmic_bytes=int(v["work"] / v["launches"]),
+                                          avg_ms_per_step=round(v["ms"] / v["launches"], 4),
+                                          note="fused Lift (x) Splat, in the timed step (on the prefetch stream)")
         rk = [ksum[k] for k in ("k_render_nearest+k_upsample_maps",) if k in ksum]
         if rk:
             ms = sum(v["ms"] for v in rk)
@@ -284,27 +400,32 @@ def main():
             ach = by / (ms * 1e-3) / 1e9
             rtraffic = None
             try:
-                rtraffic = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))["k_render_nearest+k_upsample_maps"][args.config]["bytes_per_launch"]
+                rtraffic = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))["k_render_nearest+k_upsample_maps"][args.config]["bytes_per_launch"]
             except Exception:
                 pass
             extra["roofline_render"] = dict(bound="hbm", kernel="k_render_nearest+k_upsample_maps", achieved=round(ach, 1),
                                             peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=rtraffic,
                                             avg_ms_per_step=round(ms / max(1, rk[0]["launches"]), 4))
 
+    if rank == 0 and args.config == "r50" and not args.no_kernel_timing:
+        extra["roofline_render_r101"] = render_r101_roofline(model, dev)
     line = dict(metric="samples/sec (6-cam frame + sweep -> occ+render), 200x200x16 grid", value=round(world * args.steps / dt, 4),
-                unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                unit="samples/s", n_gpus=world, world_size_seen_by_backend=seen_world, backend=backend_name, steps=args.steps,
+                warmup=args.warmup,
                 ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
                 dtype="f32", data="synthetic",
                 config=dict(workload="coocc_multi_r50_256x704 hot path" if args.config == "r50" else args.config,
                             fused_grid="x".join(map(str, c["grid"])) + "x%d" % c["C"],
-                            occupancy_grid="x".join(str(2 * v) for v in c["grid"]), cams=c["ncam"],
+                            occupancy_grid="x".join(str(v) for v in c.get("final_occ_size", [2 * g for g in c["grid"]])), cams=c["ncam"],
                             render_maps="%dx%dx%d" % (c["ncam"], c["fmap"][0] * 16, c["fmap"][1] * 16), knum=c["knum"],
                             parallelism="dp%d (1 scene per GPU, RCCL all-gather of maps)" % world,
-                            samples_in_flight=len(streams), prefetched_search=bool(pool), weights="random"),
+                            samples_in_flight=len(streams), prefetched_search=bool(tpool), weights="random",
+                            step_starts_from=("lifted depth/context pair (fused lift-splat pooling inside the step)" if WITH_POOL[0]
+                                              else "pooled camera volume")),
                 roofline=roof)
     line.update(extra)
     if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(sd, samples[0], args.config, 30.0)
+        line["cpu_baseline"] = cpu_baseline(sd, samples[0], args.config, WITH_POOL[0])
     if rank == 0:
         print(json.dumps(line))
 

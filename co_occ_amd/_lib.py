@@ -43,6 +43,9 @@ SIGNATURES = {
     "coocc_fps_voxels": (I, [P, I, I, I, I, I, P, P, Z, P]),
     "coocc_ball_query": (I, [I, I, I, F, F, I, P, P, P, P]),
     "coocc_knn_topk": (I, [I, I, I, P, P, P, P, P]),
+    "coocc_voxel_index_map": (I, [P, I, I, P, P]),
+    "coocc_ball_query_voxels": (I, [I, F, F, I, I, I, I, P, P, P, P, P]),
+    "coocc_knn_topk_voxels": (I, [I, I, I, I, I, I, P, P, P, P, I, P, P, P, P, P]),
     "coocc_knn_assign": (I, [I, I, I, I, F, P, P, P, P, P, P]),
     "coocc_knn_threshold": (I, [I, F, P, P, P, P]),
     "coocc_index_rows_i32": (I, [P, I, P, I, P, P]),

@@ -545,6 +545,187 @@ extern "C" int coocc_knn_topk(int nq, int nk, int K, const float* q, const float
   return COOCC_OK;
 }
 
+// ------------------------------------------------------------------ K3 / K4 on a voxel grid
+// In the fuser both point sets are the non-empty voxels of ONE dense grid and the lists are ascending linear voxel ids,
+// so "index order" == lexicographic (x,y,z) order and a dense map voxel -> list ordinal (or -1) answers membership in O(1).
+// The brute-force kernels above evaluate 2048 x 52 k distances per direction (0.3-1.0 ms each, all CUs); here
+//   * the ball query walks only the (2R+1)^2 x Z window of a centre in linear order (<= 1352 voxels at R = 5, Z = 8), and
+//   * top-K walks a table of offsets sorted by (d^2, dx, dy, dz) -- exactly the canonical order (d^2, key index) -- and
+//     stops after the K-th occupied in-grid voxel, usually inside the first 64 offsets.
+// Both are bit-identical to the brute-force kernels (tests/test_gpu_knn.py); representatives whose K-th neighbour lies
+// beyond the table radius are finished by the brute-force kernel (k_knn_topk_unresolved).
+__global__ __launch_bounds__(256) void k_index_map_scatter(const int32_t* __restrict__ lin, int n, int32_t* __restrict__ map) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) map[lin[i]] = i;
+}
+
+extern "C" int coocc_voxel_index_map(const int32_t* lin, int n, int nvox, int32_t* map, void* stream) {
+  COOCC_CHECK_ARG(map && nvox > 0 && n >= 0 && (lin || n == 0), "voxel_index_map: bad args");
+  COOCC_HIP(hipMemsetAsync(map, 0xFF, (size_t)nvox * 4, as_stream(stream)));      // -1 everywhere
+  if (n) {
+    hipLaunchKernelGGL(k_index_map_scatter, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), lin, n, map);
+    COOCC_LAUNCH_CHECK("k_index_map_scatter");
+  }
+  return COOCC_OK;
+}
+
+// centres: list ordinals into the QUERY list (its voxels are lin_q[ord]); map_q: voxel -> query ordinal.
+__global__ __launch_bounds__(256) void k_ball_query_vox(int m, float min_r2, float max_r2, int R, int nsample, int X, int Y, int Z,
+                                                         const int32_t* __restrict__ centre_ord, const int32_t* __restrict__ lin_q,
+                                                         const int32_t* __restrict__ map_q, int32_t* __restrict__ idx_all) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= m) return;
+  int32_t* idx = idx_all + (size_t)c * nsample;
+  const int v0 = lin_q[centre_ord[c]];
+  const int cz = v0 % Z, cy = (v0 / Z) % Y, cx = v0 / (Z * Y);
+  const int x0 = max(cx - R, 0), x1 = min(cx + R, X - 1);
+  const int y0 = max(cy - R, 0), y1 = min(cy + R, Y - 1);
+  const int z0 = max(cz - R, 0), z1 = min(cz + R, Z - 1);
+  const int wy = y1 - y0 + 1, wz = z1 - z0 + 1;
+  const int total = (x1 - x0 + 1) * wy * wz;
+  int cnt = 0, first = 0;
+  for (int base = 0; base < total && cnt < nsample; base += 64) {
+    const int t = base + lane;
+    bool hit = false;
+    int ord = -1;
+    if (t < total) {
+      const int iz = z0 + t % wz, r = t / wz;
+      const int iy = y0 + r % wy, ix = x0 + r / wy;
+      ord = map_q[(ix * Y + iy) * Z + iz];
+      const float d2 = sqdist3((float)ix, (float)iy, (float)iz, (float)cx, (float)cy, (float)cz);
+      hit = ord >= 0 && ((d2 == 0.f) || (d2 >= min_r2 && d2 < max_r2));
+    }
+    const u64 bal = __ballot(hit);
+    if (bal) {
+      if (cnt == 0) first = __shfl(ord, (int)__ffsll((long long)bal) - 1);
+      const int slot = cnt + __popcll(bal & ((1ull << lane) - 1ull));
+      if (hit && slot < nsample) idx[slot] = ord;
+      cnt += __popcll(bal);
+    }
+  }
+  if (cnt > nsample) cnt = nsample;
+  for (int l = cnt + lane; l < nsample; l += 64) idx[l] = first;  // first == 0 when no hit
+}
+
+extern "C" int coocc_ball_query_voxels(int m, float min_radius, float max_radius, int nsample, int X, int Y, int Z,
+                                       const int32_t* centre_ord, const int32_t* lin_q, const int32_t* map_q, int32_t* idx,
+                                       void* stream) {
+  COOCC_CHECK_ARG(m > 0 && nsample > 0 && X > 0 && Y > 0 && Z > 0 && centre_ord && lin_q && map_q && idx, "ball_query_voxels: bad args");
+  COOCC_CHECK_ARG(max_radius >= 0.f && max_radius < 4096.f, "ball_query_voxels: bad radius");
+  const float max_r2 = max_radius * max_radius;
+  int R = (int)ceilf(max_radius);
+  while (R > 0 && (float)(R * R) >= max_r2) --R;          // largest R with R^2 < max_r2 (hits need d^2 < max_r2, or d^2 == 0)
+  hipLaunchKernelGGL(k_ball_query_vox, dim3(cdiv(m, 4)), dim3(256), 0, as_stream(stream), m, min_radius * min_radius, max_r2, R,
+                     nsample, X, Y, Z, centre_ord, lin_q, map_q, idx);
+  COOCC_LAUNCH_CHECK("k_ball_query_vox");
+  return COOCC_OK;
+}
+
+// offsets: [noff] packed (dx + 128) | (dy + 128) << 8 | (dz + 128) << 16, sorted by (d^2, dx, dy, dz); every offset with
+// d^2 <= table_d2 and |dz| < Z is present.  Representatives that find fewer than K keys inside the table get idx[.][0] = -2.
+template <int K>
+__global__ __launch_bounds__(256) void k_knn_topk_vox(int nq, int X, int Y, int Z, const int32_t* __restrict__ rep_ord,
+                                                       const int32_t* __restrict__ lin_q, const int32_t* __restrict__ map_k,
+                                                       const uint32_t* __restrict__ offsets, int noff, float* __restrict__ val,
+                                                       int32_t* __restrict__ idx) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nq) return;
+  const int v0 = lin_q[rep_ord[r]];
+  const int cz = v0 % Z, cy = (v0 / Z) % Y, cx = v0 / (Z * Y);
+  int found = 0;
+  for (int base = 0; base < noff && found < K; base += 64) {
+    const int t = base + lane;
+    int ord = -1;
+    float d2 = 0.f;
+    if (t < noff) {
+      const uint32_t o = offsets[t];
+      const int dx = (int)(o & 255u) - 128, dy = (int)((o >> 8) & 255u) - 128, dz = (int)((o >> 16) & 255u) - 128;
+      const int ix = cx + dx, iy = cy + dy, iz = cz + dz;
+      if ((unsigned)ix < (unsigned)X && (unsigned)iy < (unsigned)Y && (unsigned)iz < (unsigned)Z) {
+        ord = map_k[(ix * Y + iy) * Z + iz];
+        d2 = sqdist3((float)cx, (float)cy, (float)cz, (float)ix, (float)iy, (float)iz);
+      }
+    }
+    const u64 bal = __ballot(ord >= 0);
+    const int p = found + __popcll(bal & ((1ull << lane) - 1ull));
+    if (ord >= 0 && p < K) {
+      val[(size_t)r * K + p] = (float)__dsqrt_rn((double)d2);
+      idx[(size_t)r * K + p] = ord;
+    }
+    found += __popcll(bal);
+  }
+  if (found < K && lane == 0) idx[(size_t)r * K] = -2;       // finished by k_knn_topk_unresolved
+}
+
+// brute force (k_knn_topk) for the representatives the offset table could not resolve
+template <int K>
+__global__ __launch_bounds__(256) void k_knn_topk_unresolved(int nq, int nk, const float* __restrict__ q,
+                                                              const float* __restrict__ key, float* __restrict__ val,
+                                                              int32_t* __restrict__ idx) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nq || idx[(size_t)r * K] != -2) return;
+  const float qx = q[r * 3 + 0], qy = q[r * 3 + 1], qz = q[r * 3 + 2];
+  u64 best[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) best[j] = ~0ull;
+  for (int k = lane; k < nk; k += 64) {
+    float d2 = sqdist3(qx, qy, qz, key[k * 3 + 0], key[k * 3 + 1], key[k * 3 + 2]);
+    u64 kk = ((u64)__float_as_uint(d2) << 32) | (unsigned)k;
+    if (kk < best[K - 1]) {
+      best[K - 1] = kk;
+#pragma unroll
+      for (int j = K - 1; j > 0; --j) {
+        if (best[j] < best[j - 1]) { u64 t = best[j]; best[j] = best[j - 1]; best[j - 1] = t; }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < K; ++o) {
+    u64 mn = wave_min_u64(best[0]);
+    if (best[0] == mn) {
+#pragma unroll
+      for (int j = 0; j < K - 1; ++j) best[j] = best[j + 1];
+      best[K - 1] = ~0ull;
+    }
+    if (lane == 0) {
+      val[(size_t)r * K + o] = (float)__dsqrt_rn((double)__uint_as_float((unsigned)(mn >> 32)));
+      idx[(size_t)r * K + o] = (int32_t)(unsigned)mn;
+    }
+  }
+}
+
+template <int K>
+static void launch_topk_vox(int nq, int nk, int X, int Y, int Z, const int32_t* rep_ord, const int32_t* lin_q, const int32_t* map_k,
+                            const uint32_t* offsets, int noff, const float* q, const float* key, float* val, int32_t* idx,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(k_knn_topk_vox<K>, dim3(cdiv(nq, 4)), dim3(256), 0, s, nq, X, Y, Z, rep_ord, lin_q, map_k, offsets, noff, val, idx);
+  hipLaunchKernelGGL(k_knn_topk_unresolved<K>, dim3(cdiv(nq, 4)), dim3(256), 0, s, nq, nk, q, key, val, idx);
+}
+
+extern "C" int coocc_knn_topk_voxels(int nq, int nk, int K, int X, int Y, int Z, const int32_t* rep_ord, const int32_t* lin_q,
+                                     const int32_t* map_k, const uint32_t* offsets, int noff, const float* q, const float* key,
+                                     float* val, int32_t* idx, void* stream) {
+  COOCC_CHECK_ARG(nq > 0 && nk > 0 && X > 0 && Y > 0 && Z > 0 && rep_ord && lin_q && map_k && offsets && noff > 0 && q && key &&
+                      val && idx, "knn_topk_voxels: bad args");
+  COOCC_CHECK_ARG(K >= 1 && K <= 8 && K <= nk, "knn_topk_voxels: need 1 <= K <= min(8, nk)");
+  hipStream_t s = as_stream(stream);
+  switch (K) {
+    case 1: launch_topk_vox<1>(nq, nk, X, Y, Z, rep_ord, lin_q, map_k, offsets, noff, q, key, val, idx, s); break;
+    case 2: launch_topk_vox<2>(nq, nk, X, Y, Z, rep_ord, lin_q, map_k, offsets, noff, q, key, val, idx, s); break;
+    case 3: launch_topk_vox<3>(nq, nk, X, Y, Z, rep_ord, lin_q, map_k, offsets, noff, q, key, val, idx, s); break;
+    case 4: launch_topk_vox<4>(nq, nk, X, Y, Z, rep_ord, lin_q, map_k, offsets, noff, q, key, val, idx, s); break;
+    case 5: launch_topk_vox<5>(nq, nk, X, Y, Z, rep_ord, lin_q, map_k, offsets, noff, q, key, val, idx, s); break;
+    case 6: launch_topk_vox<6>(nq, nk, X, Y, Z, rep_ord, lin_q, map_k, offsets, noff, q, key, val, idx, s); break;
+    case 7: launch_topk_vox<7>(nq, nk, X, Y, Z, rep_ord, lin_q, map_k, offsets, noff, q, key, val, idx, s); break;
+    default: launch_topk_vox<8>(nq, nk, X, Y, Z, rep_ord, lin_q, map_k, offsets, noff, q, key, val, idx, s); break;
+  }
+  COOCC_LAUNCH_CHECK("k_knn_topk_vox");
+  return COOCC_OK;
+}
+
 // ------------------------------------------------------------------ K5: assignment
 // bifuser_n.py:104-125: query_NN_key_idx[k][group[c,:]] = nn[c,k] for valid centres, later
 // centres overriding earlier ones.  atomicMax on the centre ordinal makes "last writer wins"

@@ -65,10 +65,36 @@ def _fps_voxels_on_current(q_lin, grid, fps_num):
     return out
 
 
+GRID_SEARCH = __import__("os").environ.get("COOCC_GRID_SEARCH", "1") != "0"   # 0: brute-force top-K / ball query
+_offset_tables = {}
+
+
+def offset_table(Z, device, radius=16):
+    """Offsets (dx,dy,dz) with d^2 <= radius^2 and |dz| < Z, sorted by (d^2, dx, dy, dz) -- the canonical neighbour order
+    (d^2, key index) of a dense grid whose key list is ascending in the linear voxel id -- packed for
+    coocc_knn_topk_voxels.  radius 16 > the assignment threshold 13.3 (bifuser_n.py:104), so every neighbour that can matter
+    is inside the table; the kernel falls back to brute force for a representative with fewer than K keys in range."""
+    key = (int(Z), device.index, radius)
+    if key not in _offset_tables:
+        import numpy as np
+        r = np.arange(-radius, radius + 1)
+        zr = np.arange(-min(radius, Z - 1), min(radius, Z - 1) + 1)
+        dx, dy, dz = np.meshgrid(r, r, zr, indexing="ij")
+        dx, dy, dz = dx.ravel(), dy.ravel(), dz.ravel()
+        d2 = dx * dx + dy * dy + dz * dz
+        keep = d2 <= radius * radius
+        dx, dy, dz, d2 = dx[keep], dy[keep], dz[keep], d2[keep]
+        order = np.lexsort((dz, dy, dx, d2))
+        packed = ((dx[order] + 128) | ((dy[order] + 128) << 8) | ((dz[order] + 128) << 16)).astype(np.int64)
+        _offset_tables[key] = torch.from_numpy(packed.astype(np.uint32).view(np.int32)).to(device)
+    return _offset_tables[key]
+
+
 def _fps_nn_xyz(query_xyz, key_xyz, fps_num, radius, max_cluster_samples, dist_thresh, num, q_lin=None, grid=None,
-                which=0, home=None):
+                which=0, home=None, k_lin=None):
     """Index search on float xyz rows.  Returns int32 [num, Q] of key ordinals (-1 = none).
-    q_lin/grid: the queries as distinct voxels of one grid -> pruned FPS kernel."""
+    q_lin/grid: the queries as distinct voxels of one grid -> pruned FPS kernel; with k_lin as well (both sets on the same
+    grid) top-K and the ball query run their grid forms (index maps instead of 2048 x N distance sweeps)."""
     dev = query_xyz.device
     Q, Nk = query_xyz.shape[0], key_xyz.shape[0]
     if Q <= fps_num:
@@ -92,11 +118,23 @@ def _fps_nn_xyz(query_xyz, key_xyz, fps_num, radius, max_cluster_samples, dist_t
     repr_xyz = query_xyz[repr_idx[0].long()].contiguous()
     val = torch.empty(fps_num, num, device=dev, dtype=_F32)
     nn_ = torch.empty(fps_num, num, device=dev, dtype=_I32)
-    call("coocc_knn_topk", fps_num, Nk, num, ptr(repr_xyz), ptr(key_xyz), ptr(val), ptr(nn_))
     group = torch.empty(fps_num, max_cluster_samples, device=dev, dtype=_I32)
-    # the reference recomputes this identical ball query once per k (bifuser_n.py:109)
-    call("coocc_ball_query", 1, Q, fps_num, 0.0, float(radius), max_cluster_samples, ptr(repr_xyz), ptr(query_xyz),
-         ptr(group))
+    if GRID_SEARCH and q_lin is not None and k_lin is not None and grid is not None:
+        X, Y, Z = grid
+        maps = torch.empty(2, X * Y * Z, device=dev, dtype=_I32)
+        call("coocc_voxel_index_map", ptr(q_lin), Q, X * Y * Z, ptr(maps[0]))
+        call("coocc_voxel_index_map", ptr(k_lin), Nk, X * Y * Z, ptr(maps[1]))
+        off = offset_table(Z, dev)
+        rep = repr_idx[0].contiguous()
+        call("coocc_knn_topk_voxels", fps_num, Nk, num, X, Y, Z, ptr(rep), ptr(q_lin), ptr(maps[1]), ptr(off), off.numel(),
+             ptr(repr_xyz), ptr(key_xyz), ptr(val), ptr(nn_))
+        call("coocc_ball_query_voxels", fps_num, 0.0, float(radius), max_cluster_samples, X, Y, Z, ptr(rep), ptr(q_lin),
+             ptr(maps[0]), ptr(group))
+    else:
+        call("coocc_knn_topk", fps_num, Nk, num, ptr(repr_xyz), ptr(key_xyz), ptr(val), ptr(nn_))
+        # the reference recomputes this identical ball query once per k (bifuser_n.py:109)
+        call("coocc_ball_query", 1, Q, fps_num, 0.0, float(radius), max_cluster_samples, ptr(repr_xyz), ptr(query_xyz),
+             ptr(group))
     winner = torch.empty(num, Q, device=dev, dtype=_I32)
     out = torch.empty(num, Q, device=dev, dtype=_I32)
     call("coocc_knn_assign", fps_num, num, max_cluster_samples, Q, float(dist_thresh), ptr(val), ptr(nn_), ptr(group),
@@ -212,7 +250,8 @@ class BiFuser_N(nn.Module):
             with torch.cuda.stream(side):
                 # img queries <- nearest pts keys (:150-162); for knum > 1 the reference indexes
                 # inds_img with the pts ordinals (:158) -- kept
-                sr.near_pts = _fps_nn_xyz(xyz_img, xyz_pts, q_lin=lin_img if vox else None, grid=vox, which=1, home=cur, **kw)
+                sr.near_pts = _fps_nn_xyz(xyz_img, xyz_pts, q_lin=lin_img if vox else None, k_lin=lin_pts if vox else None, grid=vox,
+                                          which=1, home=cur, **kw)
                 sr.rows_p = torch.empty(K, Ni, device=dev, dtype=_I32)
                 base, nbase = (lin_pts, Np) if K == 1 else (lin_img, Ni)
                 for k in range(K):
@@ -220,7 +259,8 @@ class BiFuser_N(nn.Module):
                 sr.done_side = torch.cuda.Event()
                 sr.done_side.record()
             # pts queries <- nearest img keys (bifuser_n.py:137-148)
-            sr.near_img = _fps_nn_xyz(xyz_pts, xyz_img, q_lin=lin_pts if vox else None, grid=vox, which=0, home=cur, **kw)
+            sr.near_img = _fps_nn_xyz(xyz_pts, xyz_img, q_lin=lin_pts if vox else None, k_lin=lin_img if vox else None, grid=vox,
+                                      which=0, home=cur, **kw)
             sr.rows = torch.empty(K, Np, device=dev, dtype=_I32)
             for k in range(K):
                 call("coocc_index_rows_i32", ptr(lin_img), Ni, ptr(sr.near_img[k]), Np, ptr(sr.rows[k]))

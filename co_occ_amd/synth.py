@@ -22,6 +22,18 @@ CONFIGS = {
 }
 
 
+def pool_bounds(cfgname):
+    """xbound / ybound / zbound of the view transformer for a CONFIGS entry (1 m voxels centred on the ego vehicle unless
+    the entry names its own point_cloud_range, as the OpenOccupancy config does)."""
+    c = CONFIGS[cfgname]
+    X, Y, Z = c["grid"]
+    if "point_cloud_range" in c:
+        lo, hi = c["point_cloud_range"][:3], c["point_cloud_range"][3:]
+        return dict(xbound=[lo[0], hi[0], (hi[0] - lo[0]) / X], ybound=[lo[1], hi[1], (hi[1] - lo[1]) / Y],
+                    zbound=[lo[2], hi[2], (hi[2] - lo[2]) / Z])
+    return dict(xbound=[-X / 2.0, X / 2.0, 1.0], ybound=[-Y / 2.0, Y / 2.0, 1.0], zbound=[-5.0, -5.0 + Z, 1.0])
+
+
 def _rng(seed, key=""):
     return np.random.default_rng([int(seed) & 0x7FFFFFFF, zlib.crc32(key.encode())])
 
@@ -104,6 +116,18 @@ def rig_transform(rig):
 def image_feats(ncam, fmap, channels=512, seed=1234):
     g = _rng(seed, "imgfeat")
     return torch.from_numpy(g.standard_normal((1, ncam, channels) + tuple(fmap), dtype=np.float32))
+
+
+def lift_inputs(ncam, D, fmap, C, seed=1234):
+    """What DepthNet hands to Lift-Splat (LSSVoxel.py:131-133): softmax depth distribution [N,D,fH,fW] and context features
+    [N,C,fH,fW] (the same arrays ``lifted_volume`` multiplies out)."""
+    g = _rng(seed, "lift")
+    fH, fW = fmap
+    logit = g.normal(0, 2.0, (ncam, D, fH, fW)).astype(np.float32)
+    e = np.exp(logit - logit.max(1, keepdims=True))
+    depth = e / e.sum(1, keepdims=True)
+    ctx = g.standard_normal((ncam, C, fH, fW), dtype=np.float32)
+    return torch.from_numpy(depth.astype(np.float32)), torch.from_numpy(ctx)
 
 
 def lifted_volume(ncam, D, fmap, C, seed=1234):

@@ -192,16 +192,19 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         out = torch.empty(B * X * Y * Z, C, device=dev, dtype=_F32)
         ws = _pool_workspace(dev, npts, B * X * Y * Z)
         dp = depth_prob.float().contiguous()
-        if cams is None:
-            assert geom_feats.numel() == npts * 3
-            g = geom_feats.reshape(-1, 3).float().contiguous()
-            call("coocc_lift_splat", ptr(dp), ptr(feat), ptr(g), BN, D, H, W, C, npts // B, lo, B, X, Y, Z, ptr(out), C,
-                 ptr(ws), ws.numel())
-        else:
-            mats, xs, ys, ds = self._camera_mats(*cams)
-            assert (ds.numel(), ys.numel(), xs.numel()) == (D, H, W)
-            call("coocc_lift_splat_cams", ptr(dp), ptr(feat), ptr(mats), ptr(xs), ptr(ys), ptr(ds), BN, D, H, W, C,
-                 npts // B, lo, B, X, Y, Z, ptr(out), C, ptr(ws), ws.numel())
+        from ._lib import TIMER
+        # algorithmic HBM bytes of the fused form: depth + context rows read, pooled rows written
+        with TIMER.region("k_lift_splat", 4.0 * npts + 4.0 * BN * H * W * C + 4.0 * B * X * Y * Z * C):
+            if cams is None:
+                assert geom_feats.numel() == npts * 3
+                g = geom_feats.reshape(-1, 3).float().contiguous()
+                call("coocc_lift_splat", ptr(dp), ptr(feat), ptr(g), BN, D, H, W, C, npts // B, lo, B, X, Y, Z, ptr(out), C,
+                     ptr(ws), ws.numel())
+            else:
+                mats, xs, ys, ds = self._camera_mats(*cams)
+                assert (ds.numel(), ys.numel(), xs.numel()) == (D, H, W)
+                call("coocc_lift_splat_cams", ptr(dp), ptr(feat), ptr(mats), ptr(xs), ptr(ys), ptr(ds), BN, D, H, W, C,
+                     npts // B, lo, B, X, Y, Z, ptr(out), C, ptr(ws), ws.numel())
         return out.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
 
     def forward(self, input):

@@ -91,6 +91,24 @@ int coocc_fps_voxels(const int32_t* lin, int n, int X, int Y, int Z, int m, int3
 int coocc_ball_query(int b, int n, int m, float min_radius, float max_radius, int nsample,
                      const float* new_xyz, const float* xyz, int32_t* idx, void* stream);
 
+/* ---- K3 / K4 when both point sets are the non-empty voxels of ONE dense X x Y x Z grid (the fuser's case: the lists
+ * are ascending linear voxel ids v = (x*Y + y)*Z + z, so "index order" == lexicographic voxel order).  Bit-identical to
+ * coocc_ball_query / coocc_knn_topk on the same points, 20-100x less work (no 2048 x N distance sweep). */
+/* map[v] = ordinal of voxel v in lin[0..n) or -1.  map:[nvox] i32. */
+int coocc_voxel_index_map(const int32_t* lin, int n, int nvox, int32_t* map, void* stream);
+/* ball_query (bifuser_n.py:109) for m centres given as ordinals into the query list lin_q; map_q = its index map.
+ * idx:[m,nsample] query ordinals, first-hit padded, zeros when a centre has no hit (ball_query_cuda.cu:11-54). */
+int coocc_ball_query_voxels(int m, float min_radius, float max_radius, int nsample, int X, int Y, int Z,
+                            const int32_t* centre_ord, const int32_t* lin_q, const int32_t* map_q, int32_t* idx,
+                            void* stream);
+/* top-K (bifuser_n.py:101-103) for nq representatives given as ordinals into lin_q against the keys of map_k.
+ * offsets:[noff] u32 = (dx+128) | (dy+128)<<8 | (dz+128)<<16 sorted by (d^2, dx, dy, dz) and complete up to some radius
+ * (co_occ_amd.fuser.offset_table); representatives not resolved inside the table are finished by brute force over
+ * q:[nq,3] (the representatives' xyz) / key:[nk,3].  val:[nq,K], idx:[nq,K] as coocc_knn_topk. */
+int coocc_knn_topk_voxels(int nq, int nk, int K, int X, int Y, int Z, const int32_t* rep_ord, const int32_t* lin_q,
+                          const int32_t* map_k, const uint32_t* offsets, int noff, const float* q, const float* key,
+                          float* val, int32_t* idx, void* stream);
+
 /* norm + topk(largest=False) of bifuser_n.py:101-103 without the [nq,nk,3] temporary;
  * ties ordered by (d^2, key index).  q:[nq,3], key:[nk,3]; val:[nq,K] f32 (= sqrt d^2),
  * idx:[nq,K] i32.  1 <= K <= 8, K <= nk. */

@@ -175,3 +175,48 @@ def test_compaction_property_full_size(dev):
     assert n == int(flags.sum().item())
     l = lin[:n].long()
     assert bool((l[1:] > l[:-1]).all()) and bool(flags[l].all())
+
+
+@pytest.mark.parametrize("grid,pq,pk,K,m", [((40, 40, 4), 0.45, 0.7, 4, 2048), ((100, 100, 8), 0.12, 0.65, 2, 2048),
+                                            ((100, 100, 8), 0.65, 0.12, 2, 2048), ((64, 40, 4), 0.65, 0.003, 3, 512),
+                                            ((33, 21, 5), 0.5, 0.5, 8, 300), ((50, 50, 1), 0.3, 0.02, 2, 256),
+                                            ((128, 128, 10), 0.1, 0.6, 2, 2048)])
+def test_grid_topk_and_ball_query_equal_brute_force(dev, grid, pq, pk, K, m):
+    """K3 / K4 on a voxel grid (index maps + sorted offset table / window walk) == the brute-force kernels == the oracle,
+    bit for bit: dense and sparse key sets (the 0.3 % case leaves most representatives to the brute-force fallback),
+    K up to 8, thin grids, the OpenOccupancy grid."""
+    from co_occ_amd.fuser import offset_table
+    X, Y, Z = grid
+    g = torch.Generator().manual_seed(X * 13 + Z + K)
+    lin_q = torch.nonzero(torch.rand(X * Y * Z, generator=g) < pq)[:, 0].int()
+    lin_k = torch.nonzero(torch.rand(X * Y * Z, generator=g) < pk)[:, 0].int()
+    Q, Nk = lin_q.numel(), lin_k.numel()
+    assert Nk >= K
+    m = min(m, Q)
+    xyz = lambda l: torch.stack([l // (Y * Z), (l // Z) % Y, l % Z], 1).float().contiguous()
+    q, k = xyz(lin_q).to(dev), xyz(lin_k).to(dev)
+    rep = torch.randperm(Q, generator=g)[:m].int().to(dev)
+    rq = q[rep.long()].contiguous()
+    lq, lk = lin_q.to(dev), lin_k.to(dev)
+    maps = torch.empty(2, X * Y * Z, device=dev, dtype=I32)
+    call("coocc_voxel_index_map", ptr(lq), Q, X * Y * Z, ptr(maps[0]))
+    call("coocc_voxel_index_map", ptr(lk), Nk, X * Y * Z, ptr(maps[1]))
+    inv = torch.full((X * Y * Z,), -1, dtype=I32)
+    inv[lin_k.long()] = torch.arange(Nk, dtype=I32)
+    assert torch.equal(maps[1].cpu(), inv)
+    # top-K
+    val_b, idx_b = torch.empty(m, K, device=dev, dtype=F32), torch.empty(m, K, device=dev, dtype=I32)
+    call("coocc_knn_topk", m, Nk, K, ptr(rq), ptr(k), ptr(val_b), ptr(idx_b))
+    off = offset_table(Z, dev)
+    val_g, idx_g = torch.empty(m, K, device=dev, dtype=F32), torch.empty(m, K, device=dev, dtype=I32)
+    call("coocc_knn_topk_voxels", m, Nk, K, X, Y, Z, ptr(rep), ptr(lq), ptr(maps[1]), ptr(off), off.numel(), ptr(rq), ptr(k),
+         ptr(val_g), ptr(idx_g))
+    assert torch.equal(idx_g, idx_b) and torch.equal(val_g, val_b)
+    o_val, o_idx = native.knn_topk(rq.cpu().numpy(), k.cpu().numpy(), K)
+    assert np.array_equal(idx_g.cpu().numpy(), o_idx) and np.array_equal(val_g.cpu().numpy(), o_val)
+    # ball query (radius 6, 200 samples: the fuser's call; and a small cap that truncates)
+    for radius, ns in ((6.0, 200), (3.0, 7)):
+        grp_b = pkg.ball_query(0, radius, ns, q[None].contiguous(), rq[None].contiguous())[0]
+        grp_g = torch.empty(m, ns, device=dev, dtype=I32)
+        call("coocc_ball_query_voxels", m, 0.0, radius, ns, X, Y, Z, ptr(rep), ptr(lq), ptr(maps[0]), ptr(grp_g))
+        assert torch.equal(grp_g, grp_b)
