@@ -75,7 +75,9 @@ def build_model(cfgname, dev):
 def pool(model, s):
     """P2 inside the step: fused Lift (x) Splat of the sample's depth distribution and context features, geometry from
     the camera matrices in-kernel (ViewTransformerLSSVoxel.py:135-145) -> the camera voxel volume [1,C,X,Y,Z]."""
-    return model.img_view_transformer.lift_splat(s["depth"], s["ctx"], cams=s["cams"])
+    X, Y, Z = synth.CONFIGS[CFGNAME[0]]["grid"]
+    slot0 = model.occ_fuser.concat_buffer(1, X, Y, Z, s["depth"].device)      # pooled rows land in the fuser's concat buffer
+    return model.img_view_transformer.lift_splat(s["depth"], s["ctx"], cams=s["cams"], out=slot0)
 
 
 def step(model, s, world, search=None, img=None):
@@ -105,6 +107,7 @@ def step(model, s, world, search=None, img=None):
 _pending = []
 _async_ok = [True]
 WITH_POOL = [True]
+CFGNAME = ["r50"]
 
 
 def drain_gathers():
@@ -256,6 +259,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     WITH_POOL[0] = not args.no_pool
+    CFGNAME[0] = args.config
     model, sd = build_model(args.config, dev)
     samples = [make_inputs(args.config, 1234 + 17 * rank + i, dev, model) for i in range(2)]
     if args.reserve_cus > 0:

@@ -36,6 +36,7 @@ SIGNATURES = {
     "coocc_ncdhw_to_ndhwc": (I, [P, P, I, I, I, I, I, P]),
     "coocc_ndhwc_to_ncdhw": (I, [P, P, I, I, I, I, I, P]),
     "coocc_fuser_prepare": (I, [P, P, P, P, P, I, I, I, P]),
+    "coocc_fuser_prepare_rows": (I, [P, I, I, P, I, I, P, P, P, I, I, I, P]),
     "coocc_compact_flags": (I, [P, I, P, P, P, Z, P]),
     "coocc_lin_to_coords": (I, [P, I, I, I, I, P, P, P]),
     "coocc_furthest_point_sampling": (I, [I, I, I, P, P, P, P]),
@@ -61,6 +62,7 @@ SIGNATURES = {
     "coocc_groupnorm_rows": (I, [P, L, I, I, I, P, P, F, I, P]),
     "coocc_groupnorm_nhwc": (I, [P, I, I, I, I, P, P, F, I, P]),
     "coocc_scatter_fine": (I, [P, L, I, I, P, P, I, I, I, F, P]),
+    "coocc_camera_mats": (I, [P, P, P, P, P, P, I, I, I, I, P, P]),
     "coocc_get_geometry": (I, [P, P, P, P, I, I, I, I, P, P]),
     "coocc_bev_pool_forward": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
     "coocc_bev_pool_backward": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),

@@ -136,6 +136,67 @@ extern "C" int coocc_fuser_prepare(const float* img, const float* pts, float* ca
   return COOCC_OK;
 }
 
+// Same prologue when a producer already hands over channels-last rows (the fused lift-splat writes [V, stride] rows; the
+// sparse LiDAR encoder scatters rows): *_rows != 0 -> src is [B*V, *_stride] rows instead of NCDHW.  A row source that IS
+// the destination slot (lift-splat wrote straight into cat4[:, 0:C]) is only read for its flag, not copied.
+__global__ __launch_bounds__(256) void k_fuser_prepare_rows(const float* __restrict__ img, int img_rows, int img_stride,
+                                                             const float* __restrict__ pts, int pts_rows, int pts_stride,
+                                                             float* __restrict__ cat4, uint8_t* __restrict__ flag_img,
+                                                             uint8_t* __restrict__ flag_pts, int C, int V) {
+  __shared__ float tile[TV][TC + 1];
+  const int b = blockIdx.y;
+  const int v0 = blockIdx.x * TV;
+  const int t = threadIdx.x;
+  const int stride = 4 * C;
+  for (int mod = 0; mod < 2; ++mod) {
+    const float* src = mod ? pts : img;
+    const int rows = mod ? pts_rows : img_rows, sstride = mod ? pts_stride : img_stride;
+    uint8_t* flags = mod ? flag_pts : flag_img;
+    const bool in_place = rows && src == cat4 + mod * C && sstride == stride;
+    float rsum = 0.f;  // channel sum of voxel t (threads 0..63), ascending c, fp32
+    for (int c0 = 0; c0 < C; c0 += TC) {
+      const int cn = min(TC, C - c0);
+      if (rows) {
+        for (int i = t; i < TV * cn; i += 256) {
+          int v = i / cn, c = i - v * cn;
+          tile[v][c] = v0 + v < V ? src[((size_t)b * V + v0 + v) * sstride + c0 + c] : 0.f;
+        }
+      } else {
+        for (int c = t >> 6; c < cn; c += 4) {
+          int v = v0 + (t & 63);
+          tile[t & 63][c] = v < V ? src[((size_t)b * C + c0 + c) * V + v] : 0.f;
+        }
+      }
+      __syncthreads();
+      if (t < TV)
+        for (int c = 0; c < cn; ++c) rsum += tile[t][c];
+      if (!in_place)
+        for (int i = t; i < TV * cn; i += 256) {
+          int v = i / cn, c = i - v * cn;
+          if (v0 + v < V) cat4[((size_t)b * V + v0 + v) * stride + mod * C + c0 + c] = tile[v][c];
+        }
+      __syncthreads();
+    }
+    if (t < TV && v0 + t < V) flags[(size_t)b * V + v0 + t] = rsum != 0.f ? 1 : 0;
+  }
+  for (int i = t; i < TV * 2 * C; i += 256) {
+    int v = i / (2 * C), c = i - v * 2 * C;
+    if (v0 + v < V) cat4[((size_t)b * V + v0 + v) * stride + 2 * C + c] = 0.f;
+  }
+}
+
+extern "C" int coocc_fuser_prepare_rows(const float* img, int img_rows, int img_stride, const float* pts, int pts_rows,
+                                        int pts_stride, float* cat4, uint8_t* flag_img, uint8_t* flag_pts, int B, int C, int V,
+                                        void* stream) {
+  COOCC_CHECK_ARG(img && pts && cat4 && flag_img && flag_pts && B > 0 && C > 0 && V > 0, "fuser_prepare_rows: bad args");
+  COOCC_CHECK_ARG((!img_rows || img_stride >= C) && (!pts_rows || pts_stride >= C), "fuser_prepare_rows: row stride < C");
+  dim3 grid(cdiv(V, TV), B);
+  hipLaunchKernelGGL(k_fuser_prepare_rows, grid, dim3(256), 0, as_stream(stream), img, img_rows, img_stride, pts, pts_rows,
+                     pts_stride, cat4, flag_img, flag_pts, C, V);
+  COOCC_LAUNCH_CHECK("k_fuser_prepare_rows");
+  return COOCC_OK;
+}
+
 // ------------------------------------------------------------------ compaction
 #define CB 1024  // flags per block
 

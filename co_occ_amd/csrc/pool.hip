@@ -2,12 +2,16 @@
 //
 // The reference pools with argsort(ranks) + an interval-sum kernel (bev_pool.py:83-97,
 // bev_pool_cuda.cu:20-42); argsort is unstable there, so the fp32 summation order inside a
-// voxel is unspecified.  Here the (voxel, point id) pairs go through a STABLE LSD radix sort
-// on the voxel key only (rocPRIM device primitive), so every voxel sums its rows in ascending
-// point id -- deterministic and equal to the oracle's order.  The [EXT] entry points that take
-// already-sorted intervals are provided as well.
+// voxel is unspecified.  Here every voxel sums its rows in ASCENDING POINT ID -- deterministic
+// and equal to the oracle's (stable) order -- without any sort of the point set:
+//   keys + per-voxel histogram (integer atomics) -> exclusive scan -> CSR fill through an atomic
+//   cursor (order inside a voxel arbitrary) -> the sum kernel orders each voxel's few ids itself
+//   (wave-level rank for <= 64 points: 4.5 points per voxel on average at r50, 23 at r101; an LDS
+//   bitonic sort by a whole workgroup for the few hundred voxels next to the cameras).
+// Round 1 ran rocPRIM's stable radix sort over all (key, id) pairs: three passes over 473 k -
+// 3.8 M pairs were 80 % of the kernel time.  The [EXT] entry points that take already-sorted
+// intervals are provided as well.
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include "common.h"
 
@@ -38,6 +42,58 @@ __device__ __forceinline__ void geometry_point(const float* __restrict__ mats, c
   gx = m[24] * ex + m[25] * ey + m[26] * ez + m[36];
   gy = m[27] * ex + m[28] * ey + m[29] * ez + m[37];
   gz = m[30] * ex + m[31] * ey + m[32] * ez + m[38];
+}
+
+// The 39 per-camera constants from the raw calibration tensors in ONE tiny launch (3x3 inverses by the adjugate in fp64,
+// rounded to fp32).  The host-side torch form needs two torch.inverse calls, which synchronise with the host to read their
+// status word -- 0.24 ms per sample in front of a 0.05 ms pooling kernel, and a stall of the enqueue-ahead pipeline.
+__device__ __forceinline__ void inv3x3(const float* a, float* o) {
+  const double a00 = a[0], a01 = a[1], a02 = a[2], a10 = a[3], a11 = a[4], a12 = a[5], a20 = a[6], a21 = a[7], a22 = a[8];
+  const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+  const double det = a00 * c00 + a01 * c01 + a02 * c02, r = 1.0 / det;
+  o[0] = (float)(c00 * r); o[1] = (float)((a02 * a21 - a01 * a22) * r); o[2] = (float)((a01 * a12 - a02 * a11) * r);
+  o[3] = (float)(c01 * r); o[4] = (float)((a00 * a22 - a02 * a20) * r); o[5] = (float)((a02 * a10 - a00 * a12) * r);
+  o[6] = (float)(c02 * r); o[7] = (float)((a01 * a20 - a00 * a21) * r); o[8] = (float)((a00 * a11 - a01 * a10) * r);
+}
+
+__global__ void k_camera_mats(const float* __restrict__ rots, const float* __restrict__ trans, const float* __restrict__ intrins,
+                              const float* __restrict__ post_rots, const float* __restrict__ post_trans,
+                              const float* __restrict__ bda, int B, int N, int kdim, int bdim, float* __restrict__ mats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * N) return;
+  float* m = mats + (size_t)i * COOCC_CAM_FLOATS;
+  inv3x3(post_rots + (size_t)i * 9, m);
+  for (int j = 0; j < 3; ++j) m[9 + j] = post_trans[(size_t)i * 3 + j];
+  float K[9], Ki[9];
+  const float* kin = intrins + (size_t)i * kdim * kdim;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) K[r * 3 + c] = kin[r * kdim + c];
+  inv3x3(K, Ki);
+  const float* R = rots + (size_t)i * 9;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+#pragma clang fp contract(off)
+      m[12 + r * 3 + c] = (R[r * 3 + 0] * Ki[0 * 3 + c] + R[r * 3 + 1] * Ki[1 * 3 + c]) + R[r * 3 + 2] * Ki[2 * 3 + c];
+    }
+  for (int j = 0; j < 3; ++j) m[21 + j] = trans[(size_t)i * 3 + j];
+  const float* bd = bda + (size_t)(i / N) * bdim * bdim;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) m[24 + r * 3 + c] = bd[r * bdim + c];
+  for (int j = 0; j < 3; ++j) {
+    m[33 + j] = kdim == 4 ? kin[j * 4 + 3] : 0.f;
+    m[36 + j] = bdim == 4 ? bd[j * 4 + 3] : 0.f;
+  }
+}
+
+extern "C" int coocc_camera_mats(const float* rots, const float* trans, const float* intrins, const float* post_rots,
+                                 const float* post_trans, const float* bda, int B, int N, int intrin_dim, int bda_dim,
+                                 float* mats, void* stream) {
+  COOCC_CHECK_ARG(rots && trans && intrins && post_rots && post_trans && bda && mats && B > 0 && N > 0, "camera_mats: bad args");
+  COOCC_CHECK_ARG((intrin_dim == 3 || intrin_dim == 4) && (bda_dim == 3 || bda_dim == 4), "camera_mats: 3x3 or 4x4 matrices");
+  hipLaunchKernelGGL(k_camera_mats, dim3(cdiv(B * N, 64)), dim3(64), 0, as_stream(stream), rots, trans, intrins, post_rots,
+                     post_trans, bda, B, N, intrin_dim, bda_dim, mats);
+  COOCC_LAUNCH_CHECK("k_camera_mats");
+  return COOCC_OK;
 }
 
 __global__ __launch_bounds__(256) void k_get_geometry(const float* __restrict__ mats, const float* __restrict__ xs,
@@ -134,13 +190,11 @@ __device__ __forceinline__ uint32_t voxel_key(float x, float y, float z, int b, 
 
 __global__ __launch_bounds__(256) void k_quantize_geom(const float* __restrict__ geom, int npts, int pts_per_batch,
                                                         float lox, float loy, float loz, float dx, float dy, float dz,
-                                                        int X, int Y, int Z, int nvox, uint32_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ ids) {
+                                                        int X, int Y, int Z, int nvox, uint32_t* __restrict__ keys) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npts) return;
   keys[i] = voxel_key(geom[(size_t)i * 3 + 0], geom[(size_t)i * 3 + 1], geom[(size_t)i * 3 + 2], i / pts_per_batch, lox,
                       loy, loz, dx, dy, dz, X, Y, Z, nvox);
-  ids[i] = (uint32_t)i;
 }
 
 // geometry computed in-kernel from the camera matrices (no [npts,3] geom tensor)
@@ -148,42 +202,77 @@ __global__ __launch_bounds__(256) void k_quantize_cams(const float* __restrict__
                                                         const float* __restrict__ ys, const float* __restrict__ ds, int D,
                                                         int fH, int fW, int npts, int pts_per_batch, float lox, float loy,
                                                         float loz, float dx, float dy, float dz, int X, int Y, int Z,
-                                                        int nvox, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+                                                        int nvox, uint32_t* __restrict__ keys) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npts) return;
   float gx, gy, gz;
   geometry_point(mats, xs, ys, ds, (size_t)i, D, fH, fW, gx, gy, gz);
   keys[i] = voxel_key(gx, gy, gz, i / pts_per_batch, lox, loy, loz, dx, dy, dz, X, Y, Z, nvox);
-  ids[i] = (uint32_t)i;
 }
 
 // keys from integer coords (bev_pool drop-in): coords [n,4] = (x,y,z,b) int64
 __global__ __launch_bounds__(256) void k_keys_from_coords(const int64_t* __restrict__ coords, int n, int B, int X, int Y,
-                                                           int Z, int nvox, uint32_t* __restrict__ keys,
-                                                           uint32_t* __restrict__ ids) {
+                                                           int Z, int nvox, uint32_t* __restrict__ keys) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   long long x = coords[(size_t)i * 4 + 0], y = coords[(size_t)i * 4 + 1], z = coords[(size_t)i * 4 + 2],
             b = coords[(size_t)i * 4 + 3];
   bool ok = x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z && b >= 0 && b < B;
   keys[i] = ok ? (uint32_t)(((b * X + x) * Y + y) * Z + z) : (uint32_t)nvox;
-  ids[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(256) void k_segment_bounds(const uint32_t* __restrict__ keys, int npts, int nvox,
-                                                         int32_t* __restrict__ seg_start, int32_t* __restrict__ seg_end) {
+// ------------------------------------------------------------------ CSR build: histogram -> scan -> fill
+__global__ __launch_bounds__(256) void k_key_hist(const uint32_t* __restrict__ keys, int npts, int nvox,
+                                                   int32_t* __restrict__ count) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npts) return;
-  uint32_t k = keys[i];
-  if (k < (uint32_t)nvox && (i == 0 || keys[i - 1] != k)) seg_start[k] = i;
-  if (k < (uint32_t)nvox && (i == npts - 1 || keys[i + 1] != k)) seg_end[k] = i + 1;
+  const uint32_t k = keys[i];
+  if (k < (uint32_t)nvox) atomicAdd(&count[k], 1);
 }
 
-// One wave per voxel row, 4 channels per lane.  Rows are summed in sorted (= ascending id) order with a
-// single accumulator, the association of the reference's interval kernel, but the loads run ahead: the
-// wave fetches 64 ids at once, broadcasts them through SGPRs (v_readlane) and keeps POOL_BATCH independent
-// row loads in flight before the dependent adds.  The longest voxel holds 484 (r50) / 2576 (r101) points,
-// so the serial chain, not bandwidth, bounds this kernel.
+// exclusive scan of count[0..nvox) by ONE workgroup (nvox <= a few 100 k): start[v], start[nvox] = total; voxels with more
+// than 64 points are appended to long_list (their order does not matter) and *nlong counts them.
+__global__ __launch_bounds__(1024) void k_count_scan(const int32_t* __restrict__ count, int nvox, int32_t* __restrict__ start,
+                                                      int32_t* __restrict__ long_list, int32_t* __restrict__ nlong) {
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x;
+  const int per = (nvox + 1023) / 1024;
+  const int lo = min(tid * per, nvox), hi = min(lo + per, nvox);
+  int sum = 0;
+  for (int v = lo; v < hi; ++v) sum += count[v];
+  int inc = sum;
+  for (int o = 1; o < 64; o <<= 1) {
+    int n = __shfl_up(inc, o);
+    if ((tid & 63) >= o) inc += n;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+  __syncthreads();
+  int off = inc - sum;
+  for (int w = 0; w < (tid >> 6); ++w) off += wsum[w];
+  for (int v = lo; v < hi; ++v) {
+    const int c = count[v];
+    start[v] = off;
+    off += c;
+    if (c > 64) long_list[atomicAdd(nlong, 1)] = v;
+  }
+  if (tid == 1023) start[nvox] = off;
+}
+
+__global__ __launch_bounds__(256) void k_csr_fill(const uint32_t* __restrict__ keys, int npts, int nvox,
+                                                   const int32_t* __restrict__ start, int32_t* __restrict__ cursor,
+                                                   uint32_t* __restrict__ ids) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npts) return;
+  const uint32_t k = keys[i];
+  if (k < (uint32_t)nvox) ids[start[k] + atomicAdd(&cursor[k], 1)] = (uint32_t)i;
+}
+
+// One wave per voxel row, VEC channels per lane.  Rows are summed in ascending point id with a single accumulator, the
+// association of the reference's interval kernel over a stably sorted input.  The segment arrives in arbitrary order (atomic
+// cursor): each lane takes one id, its rank is the number of smaller ids in the segment (n broadcast compares, n = 4.5 on
+// average) and one ds_permute puts the ids in order.  Then the wave fetches the sorted ids' rows POOL_BATCH at a time
+// (v_readlane broadcasts) so that the loads run ahead of the dependent adds.  Segments longer than 64 belong to
+// k_pool_sum_long.
 constexpr int POOL_BATCH = 16;
 
 template <int VEC> struct PoolVec;
@@ -198,89 +287,209 @@ __device__ __forceinline__ void pool_row(const float* __restrict__ x, const floa
                                          const uint32_t* __restrict__ ids, int s, int e, int lane, int C, int D, int HW,
                                          float* __restrict__ orow) {
   typedef typename PoolVec<VEC>::type vec;
+  const int nb = e - s;                      // 0 .. 64
+  uint32_t myid = lane < nb ? ids[s + lane] : 0xFFFFFFFFu;
+  if (nb > 1) {
+    int rank = 0;
+    for (int j = 0; j < nb; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)myid, j) < myid;   // ids are distinct
+    // idle lanes (id = 0xFFFFFFFF) all rank nb: they land on lane nb, which is not read
+    myid = (uint32_t)__builtin_amdgcn_ds_permute(rank << 2, (int)myid);
+  }
+  uint32_t myrow = myid;
+  float mydp = 1.f;
+  if (LIFT && lane < nb) {
+    myrow = (myid / (uint32_t)(D * HW)) * (uint32_t)HW + myid % (uint32_t)HW;
+    mydp = depth[myid];
+  }
   for (int c0 = 0; c0 < C; c0 += 64 * VEC) {
     const int c = c0 + lane * VEC;
     const bool lane_on = c < C;
     const float* xc = x + (lane_on ? c : 0);   // idle lanes re-read channel 0 instead of branching
     vec acc = (vec)(0.f);
-    for (int base = s; base < e; base += 64) {
-      const int nb = min(64, e - base);
-      const uint32_t myid = ids[base + min(lane, nb - 1)];
-      uint32_t myrow = myid;
-      float mydp = 1.f;
-      if (LIFT) {
-        myrow = (myid / (uint32_t)(D * HW)) * (uint32_t)HW + myid % (uint32_t)HW;
-        mydp = depth[myid];
-      }
-      for (int j0 = 0; j0 < nb; j0 += POOL_BATCH) {
-        vec r[POOL_BATCH];
+    for (int j0 = 0; j0 < nb; j0 += POOL_BATCH) {
+      vec r[POOL_BATCH];
 #pragma unroll
-        for (int j = 0; j < POOL_BATCH; ++j) {
+      for (int j = 0; j < POOL_BATCH; ++j) {
 #pragma clang fp contract(off)  // LIFT: the product is rounded before the add, as the materialised volume is
-          const int jj = min(j0 + j, nb - 1);
-          const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)myrow, jj);
-          vec v = *(const vec*)(xc + (size_t)row * C);
-          if (LIFT) v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mydp), jj)) * v;
-          r[j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < POOL_BATCH; ++j)
-          if (j0 + j < nb) acc = acc + r[j];
+        const int jj = min(j0 + j, nb - 1);
+        const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)myrow, jj);
+        vec v = *(const vec*)(xc + (size_t)row * C);
+        if (LIFT) v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mydp), jj)) * v;
+        r[j] = v;
       }
+#pragma unroll
+      for (int j = 0; j < POOL_BATCH; ++j)
+        if (j0 + j < nb) acc = acc + r[j];
     }
     if (lane_on) *(vec*)(orow + c) = acc;
   }
 }
 
+// Voxels with more than 64 points (229 of 57 k at r50, 4 k of 73 k at r101; up to 2614 points each): one WORKGROUP per
+// voxel.  The ids are bitonic-sorted in LDS by all 256 threads (padded to a power of two with 0xFFFFFFFF), decoded to
+// (row, depth) in place, then thread c sums channel c (c + 256, ...) over the sorted rows, 16 independent loads ahead of
+// the dependent adds.  Segments beyond POOL_LONG_CAP ids (never seen: 8192 points in one voxel) take a slow selection path, O(n^2 / 256).
+constexpr int POOL_LONG_CAP = 8192;
+
+template <bool LIFT>
+__global__ __launch_bounds__(256) void k_pool_sum_long(const float* __restrict__ x, const float* __restrict__ depth,
+                                                        uint32_t* __restrict__ ids, const int32_t* __restrict__ start,
+                                                        const int32_t* __restrict__ long_list,
+                                                        const int32_t* __restrict__ nlong_p, int C, int D, int HW,
+                                                        float* __restrict__ out, int out_stride) {
+  __shared__ uint32_t sid[POOL_LONG_CAP];
+  __shared__ float sdp[POOL_LONG_CAP];
+  const int tid = threadIdx.x;
+  const int nlong = *nlong_p;
+  for (int li = blockIdx.x; li < nlong; li += gridDim.x) {
+    const int v = long_list[li];
+    const int s = start[v], n = start[v + 1] - s;
+    uint32_t* seg = ids + s;
+    if (n <= POOL_LONG_CAP) {
+      int np2 = 128;
+      while (np2 < n) np2 <<= 1;
+      for (int i = tid; i < np2; i += 256) sid[i] = i < n ? seg[i] : 0xFFFFFFFFu;
+      __syncthreads();
+      for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int i = tid; i < np2; i += 256) {
+            const int l = i ^ j;
+            if (l > i) {
+              const uint32_t a = sid[i], b = sid[l];
+              const bool up = (i & k) == 0;
+              if ((a > b) == up) { sid[i] = b; sid[l] = a; }
+            }
+          }
+          __syncthreads();
+        }
+      for (int i = tid; i < n; i += 256) {
+        const uint32_t id = sid[i];
+        if (LIFT) {
+          sdp[i] = depth[id];
+          sid[i] = (id / (uint32_t)(D * HW)) * (uint32_t)HW + id % (uint32_t)HW;
+        }
+      }
+      __syncthreads();
+    }
+    float* orow = out + (size_t)v * out_stride;
+    if (n <= POOL_LONG_CAP) {
+      for (int c = tid; c < C; c += 256) {
+        float acc = 0.f;
+        for (int j0 = 0; j0 < n; j0 += POOL_BATCH) {
+          float r[POOL_BATCH];
+#pragma unroll
+          for (int j = 0; j < POOL_BATCH; ++j) {
+#pragma clang fp contract(off)
+            const int jj = min(j0 + j, n - 1);
+            float val = x[(size_t)sid[jj] * C + c];
+            if (LIFT) val = sdp[jj] * val;
+            r[j] = val;
+          }
+#pragma unroll
+          for (int j = 0; j < POOL_BATCH; ++j)
+            if (j0 + j < n) acc = acc + r[j];
+        }
+        orow[c] = acc;
+      }
+    } else {
+      // never seen in practice (> 8192 points in one voxel): the next id in ascending order is found by a block-wide min
+      // over the unsorted segment, one point at a time -- O(n^2 / 256), correct for any n
+      for (int c = tid; c < C; c += 256) orow[c] = 0.f;
+      uint32_t prev = 0;
+      bool first = true;
+      for (int t = 0; t < n; ++t) {
+        // next = smallest id greater than prev (ids distinct): block-wide min reduction through LDS
+        uint32_t best = 0xFFFFFFFFu;
+        for (int i = tid; i < n; i += 256) {
+          const uint32_t me = seg[i];
+          if ((first || me > prev) && me < best) best = me;
+        }
+        sid[tid] = best;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+          if (tid < o) sid[tid] = min(sid[tid], sid[tid + o]);
+          __syncthreads();
+        }
+        const uint32_t id = sid[0];
+        __syncthreads();
+        prev = id; first = false;
+        const uint32_t row = LIFT ? (id / (uint32_t)(D * HW)) * (uint32_t)HW + id % (uint32_t)HW : id;
+        const float dp = LIFT ? depth[id] : 1.f;
+        for (int c = tid; c < C; c += 256) {
+#pragma clang fp contract(off)
+          float val = x[(size_t)row * C + c];
+          if (LIFT) val = dp * val;
+          orow[c] = orow[c] + val;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void k_pool_sum(const float* __restrict__ x, const uint32_t* __restrict__ ids,
-                                                   const int32_t* __restrict__ seg_start,
-                                                   const int32_t* __restrict__ seg_end, int nvox, int C,
+                                                   const int32_t* __restrict__ start, int nvox, int C,
                                                    float* __restrict__ out, int out_stride) {
   const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   if (v >= nvox) return;
-  if (C <= 128) pool_row<false, 2>(x, nullptr, ids, seg_start[v], seg_end[v], lane, C, 0, 0, out + (size_t)v * out_stride);
-  else pool_row<false, 4>(x, nullptr, ids, seg_start[v], seg_end[v], lane, C, 0, 0, out + (size_t)v * out_stride);
+  const int s = start[v], e = start[v + 1];
+  if (e - s > 64) return;                                   // k_pool_sum_long
+  if (C <= 128) pool_row<false, 2>(x, nullptr, ids, s, e, lane, C, 0, 0, out + (size_t)v * out_stride);
+  else pool_row<false, 4>(x, nullptr, ids, s, e, lane, C, 0, 0, out + (size_t)v * out_stride);
+}
+
+__global__ __launch_bounds__(256) void k_lift_pool_sum(const float* __restrict__ depth, const float* __restrict__ feat,
+                                                        const uint32_t* __restrict__ ids, const int32_t* __restrict__ start,
+                                                        int nvox, int C, int D, int HW, float* __restrict__ out,
+                                                        int out_stride) {
+  const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  if (v >= nvox) return;
+  const int s = start[v], e = start[v + 1];
+  if (e - s > 64) return;                                   // k_pool_sum_long
+  if (C <= 128) pool_row<true, 2>(feat, depth, ids, s, e, lane, C, D, HW, out + (size_t)v * out_stride);
+  else pool_row<true, 4>(feat, depth, ids, s, e, lane, C, D, HW, out + (size_t)v * out_stride);
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static size_t sort_temp_bytes(int npts) {
-  size_t tmp = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (uint32_t*)nullptr, (size_t)npts, 0, 32, (hipStream_t)0);
-  return tmp;
-}
-
+// workspace: keys[npts] | ids[npts] | count[nvox] | cursor[nvox] | nlong[64] (one memset clears these three) | start[nvox+1]
+// | long_list[nvox]
 extern "C" size_t coocc_voxel_pool_ws(int npts, int nvox) {
   if (npts <= 0 || nvox <= 0) return 0;
-  return 4 * align256(sizeof(uint32_t) * (size_t)npts) + 2 * align256(sizeof(int32_t) * (size_t)nvox) +
-         align256(sort_temp_bytes(npts)) + 256;
+  return 2 * align256(sizeof(uint32_t) * (size_t)npts) + 4 * align256(sizeof(int32_t) * ((size_t)nvox + 1)) + 256 + 256;
 }
 
-static int pool_sorted(const float* x, int npts, int C, int nvox, float* out, int out_stride, uint32_t* k_in,
-                       uint32_t* k_out, uint32_t* i_in, uint32_t* i_out, int32_t* seg_s, int32_t* seg_e, void* tmp,
-                       size_t tmp_bytes, hipStream_t s) {
-  int bits = 1;
-  while ((1ll << bits) <= nvox) ++bits;  // keys go up to nvox inclusive
-  COOCC_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)npts, 0, bits, s));
-  COOCC_HIP(hipMemsetAsync(seg_s, 0, 2 * align256(sizeof(int32_t) * (size_t)nvox), s));
-  hipLaunchKernelGGL(k_segment_bounds, dim3(cdiv(npts, 256)), dim3(256), 0, s, k_out, npts, nvox, seg_s, seg_e);
-  hipLaunchKernelGGL(k_pool_sum, dim3(cdiv(nvox, 4)), dim3(256), 0, s, x, i_out, seg_s, seg_e, nvox, C, out, out_stride);
-  COOCC_LAUNCH_CHECK("voxel_pool");
-  return COOCC_OK;
-}
-
-struct PoolWs { uint32_t *k_in, *k_out, *i_in, *i_out; int32_t *seg_s, *seg_e; void* tmp; size_t tmp_bytes; };
+struct PoolWs { uint32_t *keys, *ids; int32_t *count, *cursor, *nlong, *start, *long_list; size_t zero_bytes; };
 
 static int carve(void* ws, size_t ws_bytes, int npts, int nvox, PoolWs* p) {
   size_t need = coocc_voxel_pool_ws(npts, nvox);
   if (!ws || ws_bytes < need) return coocc_set_error(COOCC_ENOMEM, "voxel_pool: workspace %zu < %zu bytes", ws_bytes, need);
   char* c = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  size_t a = align256(sizeof(uint32_t) * (size_t)npts), v = align256(sizeof(int32_t) * (size_t)nvox);
-  p->k_in = (uint32_t*)c; c += a; p->k_out = (uint32_t*)c; c += a;
-  p->i_in = (uint32_t*)c; c += a; p->i_out = (uint32_t*)c; c += a;
-  p->seg_s = (int32_t*)c; c += v; p->seg_e = (int32_t*)c; c += v;  // contiguous: one memset clears both
-  p->tmp = c; p->tmp_bytes = sort_temp_bytes(npts);
+  size_t a = align256(sizeof(uint32_t) * (size_t)npts), v = align256(sizeof(int32_t) * ((size_t)nvox + 1));
+  p->keys = (uint32_t*)c; c += a; p->ids = (uint32_t*)c; c += a;
+  p->count = (int32_t*)c; c += v; p->cursor = (int32_t*)c; c += v; p->nlong = (int32_t*)c; c += 256;
+  p->zero_bytes = 2 * v + 256;
+  p->start = (int32_t*)c; c += v; p->long_list = (int32_t*)c;
+  return COOCC_OK;
+}
+
+// keys[npts] (voxel row or nvox = dropped) -> CSR (start, ids) -> per-voxel sums in ascending point id.
+// LIFT: x = context rows [N*H*W, C], depth [npts], product formed inside the sum (fused lift (x) splat).
+template <bool LIFT>
+static int pool_csr(const float* x, const float* depth, int npts, int C, int D, int HW, int nvox, float* out, int out_stride,
+                    const PoolWs& p, hipStream_t s) {
+  COOCC_HIP(hipMemsetAsync(p.count, 0, p.zero_bytes, s));
+  hipLaunchKernelGGL(k_key_hist, dim3(cdiv(npts, 256)), dim3(256), 0, s, p.keys, npts, nvox, p.count);
+  hipLaunchKernelGGL(k_count_scan, dim3(1), dim3(1024), 0, s, p.count, nvox, p.start, p.long_list, p.nlong);
+  hipLaunchKernelGGL(k_csr_fill, dim3(cdiv(npts, 256)), dim3(256), 0, s, p.keys, npts, nvox, p.start, p.cursor, p.ids);
+  if (LIFT)
+    hipLaunchKernelGGL(k_lift_pool_sum, dim3(cdiv(nvox, 4)), dim3(256), 0, s, depth, x, p.ids, p.start, nvox, C, D, HW, out,
+                       out_stride);
+  else
+    hipLaunchKernelGGL(k_pool_sum, dim3(cdiv(nvox, 4)), dim3(256), 0, s, x, p.ids, p.start, nvox, C, out, out_stride);
+  hipLaunchKernelGGL(k_pool_sum_long<LIFT>, dim3(512), dim3(256), 0, s, x, depth, p.ids, p.start, p.long_list, p.nlong, C, D, HW,
+                     out, out_stride);
+  COOCC_LAUNCH_CHECK("voxel_pool");
   return COOCC_OK;
 }
 
@@ -298,9 +507,8 @@ extern "C" int coocc_voxel_pool(const float* x, const float* geom, int npts, int
   hipStream_t s = as_stream(stream);
   const float* l = lo_dx_host;
   hipLaunchKernelGGL(k_quantize_geom, dim3(cdiv(npts, 256)), dim3(256), 0, s, geom, npts, pts_per_batch, l[0], l[1], l[2],
-                     l[3], l[4], l[5], X, Y, Z, nvox, p.k_in, p.i_in);
-  return pool_sorted(x, npts, C, nvox, out, out_stride, p.k_in, p.k_out, p.i_in, p.i_out, p.seg_s, p.seg_e, p.tmp,
-                     p.tmp_bytes, s);
+                     l[3], l[4], l[5], X, Y, Z, nvox, p.keys);
+  return pool_csr<false>(x, nullptr, npts, C, 0, 0, nvox, out, out_stride, p, s);
 }
 
 // ------------------------------------------------------------------ fused lift (x) splat
@@ -309,17 +517,6 @@ extern "C" int coocc_voxel_pool(const float* x, const float* geom, int npts, int
 // point id = ((n*D + d)*H + h)*W + w indexes depth directly and selects the context row (n,h,w).
 // Products are rounded to fp32 before the add (no FMA), in ascending point id: bit-equal to pooling the
 // materialised volume with the stable order.
-__global__ __launch_bounds__(256) void k_lift_pool_sum(const float* __restrict__ depth, const float* __restrict__ feat,
-                                                        const uint32_t* __restrict__ ids,
-                                                        const int32_t* __restrict__ seg_start,
-                                                        const int32_t* __restrict__ seg_end, int nvox, int C, int D, int HW,
-                                                        float* __restrict__ out, int out_stride) {
-  const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  if (v >= nvox) return;
-  if (C <= 128) pool_row<true, 2>(feat, depth, ids, seg_start[v], seg_end[v], lane, C, D, HW, out + (size_t)v * out_stride);
-  else pool_row<true, 4>(feat, depth, ids, seg_start[v], seg_end[v], lane, C, D, HW, out + (size_t)v * out_stride);
-}
-
 static int lift_splat_impl(const float* depth, const float* feat_nhwc, const float* geom, const float* mats,
                            const float* xs, const float* ys, const float* ds, int N, int D, int H, int W, int C,
                            int pts_per_batch, const float* lo_dx_host, int B, int X, int Y, int Z, float* out,
@@ -339,19 +536,11 @@ static int lift_splat_impl(const float* depth, const float* feat_nhwc, const flo
   const float* l = lo_dx_host;
   if (geom)
     hipLaunchKernelGGL(k_quantize_geom, dim3(cdiv(npts, 256)), dim3(256), 0, s, geom, npts, pts_per_batch, l[0], l[1], l[2],
-                       l[3], l[4], l[5], X, Y, Z, nvox, p.k_in, p.i_in);
+                       l[3], l[4], l[5], X, Y, Z, nvox, p.keys);
   else
     hipLaunchKernelGGL(k_quantize_cams, dim3(cdiv(npts, 256)), dim3(256), 0, s, mats, xs, ys, ds, D, H, W, npts,
-                       pts_per_batch, l[0], l[1], l[2], l[3], l[4], l[5], X, Y, Z, nvox, p.k_in, p.i_in);
-  int bits = 1;
-  while ((1ll << bits) <= nvox) ++bits;
-  COOCC_HIP(rocprim::radix_sort_pairs(p.tmp, p.tmp_bytes, p.k_in, p.k_out, p.i_in, p.i_out, (size_t)npts, 0, bits, s));
-  COOCC_HIP(hipMemsetAsync(p.seg_s, 0, 2 * align256(sizeof(int32_t) * (size_t)nvox), s));
-  hipLaunchKernelGGL(k_segment_bounds, dim3(cdiv(npts, 256)), dim3(256), 0, s, p.k_out, npts, nvox, p.seg_s, p.seg_e);
-  hipLaunchKernelGGL(k_lift_pool_sum, dim3(cdiv(nvox, 4)), dim3(256), 0, s, depth, feat_nhwc, p.i_out, p.seg_s, p.seg_e,
-                     nvox, C, D, H * W, out, out_stride);
-  COOCC_LAUNCH_CHECK("lift_splat");
-  return COOCC_OK;
+                       pts_per_batch, l[0], l[1], l[2], l[3], l[4], l[5], X, Y, Z, nvox, p.keys);
+  return pool_csr<true>(feat_nhwc, depth, npts, C, D, H * W, nvox, out, out_stride, p, s);
 }
 
 extern "C" int coocc_lift_splat(const float* depth, const float* feat_nhwc, const float* geom, int N, int D, int H, int W,
@@ -382,7 +571,6 @@ extern "C" int coocc_bev_pool_coords(const float* x, const int64_t* coords, int 
   int rc = carve(ws, ws_bytes, n, nvox, &p);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(k_keys_from_coords, dim3(cdiv(n, 256)), dim3(256), 0, s, coords, n, B, X, Y, Z, nvox, p.k_in, p.i_in);
-  return pool_sorted(x, n, C, nvox, out, out_stride, p.k_in, p.k_out, p.i_in, p.i_out, p.seg_s, p.seg_e, p.tmp, p.tmp_bytes,
-                     s);
+  hipLaunchKernelGGL(k_keys_from_coords, dim3(cdiv(n, 256)), dim3(256), 0, s, coords, n, B, X, Y, Z, nvox, p.keys);
+  return pool_csr<false>(x, nullptr, n, C, 0, 0, nvox, out, out_stride, p, s);
 }

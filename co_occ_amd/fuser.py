@@ -142,6 +142,26 @@ def _fps_nn_xyz(query_xyz, key_xyz, fps_num, radius, max_cluster_samples, dist_t
     return out
 
 
+def _as_rows_view(x):
+    """Rows for inputs that already ARE channels-last rows in memory (a Rows object, or the permuted [B,C,X,Y,Z] view of
+    one, possibly a column slice of a wider buffer such as the [V,4C] concat rows); None for NCDHW / other layouts."""
+    if isinstance(x, Rows):
+        return x
+    if x.dim() != 5 or not x.is_cuda or x.dtype != _F32:
+        return None
+    B, C, X, Y, Z = x.shape
+    sb, sc, sx, sy, sz = x.stride()
+    S = sz
+    if sc != 1 or S < C or S % 4 or sy != Z * S or sx != Y * Z * S or (B > 1 and sb != X * Y * Z * S):
+        return None
+    off = x.storage_offset()
+    coff = off % S
+    if coff + C > S or (x.data_ptr() - 4 * coff) % 16:
+        return None
+    base = torch.as_strided(x, (B * X * Y * Z, S), (S, 1), off - coff)
+    return Rows(base, B, X, Y, Z, C, coff)
+
+
 class SearchResult:
     """Output of ``BiFuser_N.search``: the concat rows (img | pts halves written), the non-empty voxel lists and
     the neighbour row tables of both directions, with the events that mark them ready."""
@@ -206,6 +226,13 @@ class BiFuser_N(nn.Module):
         out = _fps_nn_xyz(q, k, fps_num, radius, max_cluster_samples, dist_thresh, num).long()
         return out[0] if num == 1 else out
 
+    def concat_buffer(self, B, X, Y, Z, device):
+        """A fresh [B*X*Y*Z, 4C] concat buffer and the Rows of its slot 0: a producer that writes the camera volume there
+        (``ViewTransformerLiftSplatShootVoxel.lift_splat(out=...)``) saves the prologue its copy."""
+        C = self.in_channels
+        cat4 = torch.empty(B * X * Y * Z, 4 * C, device=device, dtype=_F32)
+        return Rows(cat4, B, X, Y, Z, C, 0)
+
     # ---------------------------------------------------------------- forward
     def search(self, img_voxel_feats, pts_voxel_feats):
         """K1..K5 on the current stream: concat rows with the img | pts halves in place, non-empty voxel lists,
@@ -213,15 +240,32 @@ class BiFuser_N(nn.Module):
         the indices has been launched, so a caller may run this for sample i+1 on its own stream (and host
         thread: there is one device->host read of the two voxel counts) while sample i is in its dense stage
         -- the 2 x 2047 dependent FPS steps occupy one CU each and overlap everything."""
-        B, C, X, Y, Z = img_voxel_feats.shape
-        V, dev = X * Y * Z, img_voxel_feats.device
-        if not img_voxel_feats.is_cuda:
+        img_r, pts_r = _as_rows_view(img_voxel_feats), _as_rows_view(pts_voxel_feats)
+        one = img_r if img_r is not None else img_voxel_feats
+        if isinstance(one, Rows):
+            B, C, X, Y, Z = one.B, one.C, one.X, one.Y, one.Z
+            dev = one.t.device
+        else:
+            B, C, X, Y, Z = one.shape
+            dev = one.device
+        V = X * Y * Z
+        if dev.type != "cuda":
             raise _lib.CooccError("BiFuser_N runs on the GPU only (no CPU fallback)")
-        img = img_voxel_feats.float().contiguous()
-        pts = pts_voxel_feats.float().contiguous()
-        cat4 = torch.empty(B * V, 4 * C, device=dev, dtype=_F32)
         flags = torch.empty(2, B * V, device=dev, dtype=torch.uint8)
-        call("coocc_fuser_prepare", ptr(img), ptr(pts), ptr(cat4), ptr(flags[0]), ptr(flags[1]), B, C, V)
+        if img_r is None and pts_r is None:
+            img = img_voxel_feats.float().contiguous()
+            pts = pts_voxel_feats.float().contiguous()
+            cat4 = torch.empty(B * V, 4 * C, device=dev, dtype=_F32)
+            call("coocc_fuser_prepare", ptr(img), ptr(pts), ptr(cat4), ptr(flags[0]), ptr(flags[1]), B, C, V)
+        else:
+            # a producer handed over channels-last rows (fused lift-splat, sparse LiDAR encoder): no NCDHW round trip; rows
+            # that already sit in slot 0 of a [V,4C] concat buffer (lift_splat(out=BiFuser_N.concat_buffer(...))) stay there
+            in_place = img_r is not None and img_r.t.shape[1] == 4 * C and img_r.coff == 0 and img_r.t.is_contiguous()
+            cat4 = img_r.t if in_place else torch.empty(B * V, 4 * C, device=dev, dtype=_F32)
+            img = img_r if img_r is not None else img_voxel_feats.float().contiguous()
+            pts = pts_r if pts_r is not None else pts_voxel_feats.float().contiguous()
+            src = lambda r: (r.data(), 1, r.stride) if isinstance(r, Rows) else (ptr(r), 0, 0)
+            call("coocc_fuser_prepare_rows", *src(img), *src(pts), ptr(cat4), ptr(flags[0]), ptr(flags[1]), B, C, V)
         lin = torch.empty(2, B * V, device=dev, dtype=_I32)
         counts = torch.empty(2, device=dev, dtype=_I32)
         ws = torch.empty(2, B * V // 1024 + 2, device=dev, dtype=_I32)
@@ -307,7 +351,7 @@ class BiFuser_N(nn.Module):
     def forward(self, img_voxel_feats, pts_voxel_feats, search=None):
         """[B,C,X,Y,Z] x2 -> [B,out,X,Y,Z] (bifuser_n.py:127-174).  ``search``: a ``SearchResult`` of the same
         inputs computed ahead of time (cross-sample pipelining)."""
-        if not img_voxel_feats.is_cuda:
+        if not (img_voxel_feats.t if isinstance(img_voxel_feats, Rows) else img_voxel_feats).is_cuda:
             raise _lib.CooccError("BiFuser_N runs on the GPU only (no CPU fallback)")
         if self.training:                    # batch-statistics BN + autograd, as upstream under model.train()
             from . import autograd as ag

@@ -25,20 +25,17 @@ def gen_dx_bx(xbound, ybound, zbound):
 def camera_mats(rots, trans, intrins, post_rots, post_trans, bda):
     """[B*N, COOCC_CAM_FLOATS] constants of the frustum -> ego chain (get_geometry / get_frustum): inv(post_rots),
     post_trans, rots @ inv(intrins[:3,:3]), trans, bda[:3,:3], the KITTI shift intrins[:3,3] (3x4 / 4x4 intrinsics,
-    else 0) and the translation of a 4x4 bda (else 0).  Six tiny host-side torch matrices per sample."""
+    else 0) and the translation of a 4x4 bda (else 0).  One device kernel (coocc_camera_mats): torch.inverse would
+    synchronise with the host."""
     B, N, _ = trans.shape
-    z3 = torch.zeros(B * N, 3, device=trans.device, dtype=_F32)
-    shift = z3
-    if intrins.shape[3] == 4:                       # KITTI (ViewTransformerLSSBEVDepth.py:136-139)
-        shift = intrins[:, :, :3, 3].reshape(B * N, 3)
-        intrins = intrins[:, :, :3, :3]
-    bda_t = z3
-    if bda.shape[-1] == 4:                          # :145-148
-        bda_t = bda[:, :3, 3].view(B, 1, 3).expand(B, N, 3).reshape(B * N, 3)
-        bda = bda[:, :3, :3]
-    return torch.cat([torch.inverse(post_rots).reshape(B * N, 9), post_trans.reshape(B * N, 3),
-                      rots.matmul(torch.inverse(intrins)).reshape(B * N, 9), trans.reshape(B * N, 3),
-                      bda.reshape(B, 1, 9).expand(B, N, 9).reshape(B * N, 9), shift, bda_t], 1).float().contiguous()
+    f = lambda t: t.float().contiguous()
+    kd, bd = int(intrins.shape[-1]), int(bda.shape[-1])
+    if intrins.shape[-2] != kd:                      # 3x4 KITTI intrinsics: pad to 4x4 rows (only [:3,:] is read)
+        intrins = torch.cat([intrins, intrins.new_zeros(B, N, kd - intrins.shape[-2], kd)], -2)
+    mats = torch.empty(B * N, 39, device=trans.device, dtype=_F32)
+    call("coocc_camera_mats", ptr(f(rots)), ptr(f(trans)), ptr(f(intrins)), ptr(f(post_rots)), ptr(f(post_trans)), ptr(f(bda)),
+         B, N, kd, bd, ptr(mats))
+    return mats
 
 
 def frustum_axes(input_size, downsample, dbound, device):
@@ -174,11 +171,12 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
              ptr(out), C, ptr(ws), ws.numel())
         return out.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
 
-    def lift_splat(self, depth_prob, img_feat, geom_feats=None, cams=None):
+    def lift_splat(self, depth_prob, img_feat, geom_feats=None, cams=None, out=None):
         """Fused Lift + Splat (ViewTransformerLSSVoxel.py:135-145 without the [B,N,D,H,W,C] volume):
         depth_prob [B*N,D,H,W], img_feat [B*N,C,H,W] -> [B,C,X,Y,Z].  Geometry is either the tensor
         get_geometry returned ([B,N,D,H,W,3]) or, with cams=(rots, trans, intrins, post_rots, post_trans,
-        bda), computed inside the key kernel so it never exists in HBM."""
+        bda), computed inside the key kernel so it never exists in HBM.  ``out``: Rows to write into (e.g. slot 0 of the
+        fuser's concat buffer, ``BiFuser_N.concat_buffer``) instead of a fresh [V,C] tensor."""
         BN, C, H, W = img_feat.shape
         D = depth_prob.shape[1]
         assert tuple(depth_prob.shape) == (BN, D, H, W) and (geom_feats is None) != (cams is None)
@@ -189,7 +187,13 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         call("coocc_ncdhw_to_ndhwc", ptr(img_feat.float().contiguous()), ptr(feat), BN, C, H * W, C, 0)
         lo = host_f32((self.bx - self.dx / 2.).tolist() + self.dx.tolist())
         npts = BN * D * H * W
-        out = torch.empty(B * X * Y * Z, C, device=dev, dtype=_F32)
+        if out is None:
+            out_t, out_stride, out_ptr = torch.empty(B * X * Y * Z, C, device=dev, dtype=_F32), C, None
+        else:
+            assert (out.B, out.X, out.Y, out.Z, out.C) == (B, X, Y, Z, C) and out.t.is_contiguous()
+            out_t, out_stride, out_ptr = out.t, out.stride, out.data()
+        if out_ptr is None:
+            out_ptr = ptr(out_t)
         ws = _pool_workspace(dev, npts, B * X * Y * Z)
         dp = depth_prob.float().contiguous()
         from ._lib import TIMER
@@ -198,14 +202,16 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
             if cams is None:
                 assert geom_feats.numel() == npts * 3
                 g = geom_feats.reshape(-1, 3).float().contiguous()
-                call("coocc_lift_splat", ptr(dp), ptr(feat), ptr(g), BN, D, H, W, C, npts // B, lo, B, X, Y, Z, ptr(out), C,
+                call("coocc_lift_splat", ptr(dp), ptr(feat), ptr(g), BN, D, H, W, C, npts // B, lo, B, X, Y, Z, out_ptr, out_stride,
                      ptr(ws), ws.numel())
             else:
                 mats, xs, ys, ds = self._camera_mats(*cams)
                 assert (ds.numel(), ys.numel(), xs.numel()) == (D, H, W)
                 call("coocc_lift_splat_cams", ptr(dp), ptr(feat), ptr(mats), ptr(xs), ptr(ys), ptr(ds), BN, D, H, W, C,
-                     npts // B, lo, B, X, Y, Z, ptr(out), C, ptr(ws), ws.numel())
-        return out.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
+                     npts // B, lo, B, X, Y, Z, out_ptr, out_stride, ptr(ws), ws.numel())
+        if out is not None:
+            return out.as_ncdhw()
+        return out_t.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
 
     def forward(self, input):
         """ViewTransformerLSSVoxel.py:125-145, reference signature:

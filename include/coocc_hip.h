@@ -59,6 +59,12 @@ int coocc_ndhwc_to_ncdhw(const float* src, float* dst, int B, int C, int V, int 
  * (feats.sum(1) != 0, channels summed in ascending order in fp32). */
 int coocc_fuser_prepare(const float* img, const float* pts, float* cat4, uint8_t* flag_img,
                         uint8_t* flag_pts, int B, int C, int V, void* stream);
+/* The same prologue when a producer hands over channels-last rows [B*V, *_stride] (*_rows != 0) instead of NCDHW: the
+ * fused lift-splat and the sparse LiDAR encoder do.  A row source that IS its destination slot (img == cat4,
+ * img_stride == 4*C: lift-splat wrote straight into the concat buffer) is only read for its flag. */
+int coocc_fuser_prepare_rows(const float* img, int img_rows, int img_stride, const float* pts, int pts_rows,
+                             int pts_stride, float* cat4, uint8_t* flag_img, uint8_t* flag_pts, int B, int C, int V,
+                             void* stream);
 
 /* torch.nonzero on a flag volume (bifuser_n.py:130-131): ascending linear voxel ids
  * (== lexicographic (b,x,y,z)).  lin:[n<=total] i32, count: 1 i32.  ws: >= 4*(total/1024+2) bytes. */
@@ -373,6 +379,11 @@ int coocc_scatter_fine(const float* fine_logits, int64_t nfine, int ncls, int st
  * bda[:3,:3](9), intrins[:3,3] of a KITTI 3x4/4x4 intrinsic else 0 (3), bda[:3,3] of a 4x4 bda else 0 (3);
  * xs:[fW], ys:[fH], ds:[D] frustum axes of create_frustum (:104-115).  geom:[B*N,D,fH,fW,3]. */
 #define COOCC_CAM_FLOATS 39
+/* the constants above from the raw calibration tensors (rots/post_rots [B,N,3,3], trans/post_trans [B,N,3], intrins
+ * [B,N,k,k] k = intrin_dim 3|4, bda [B,b,b] b = bda_dim 3|4), 3x3 inverses in fp64: one launch, no host synchronisation. */
+int coocc_camera_mats(const float* rots, const float* trans, const float* intrins, const float* post_rots,
+                      const float* post_trans, const float* bda, int B, int N, int intrin_dim, int bda_dim,
+                      float* mats, void* stream);
 int coocc_get_geometry(const float* mats, const float* xs, const float* ys, const float* ds, int BN,
                        int D, int fH, int fW, float* geom, void* stream);
 

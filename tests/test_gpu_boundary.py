@@ -114,8 +114,10 @@ def _sample(dev, seed=5):
     rig = synth.camera_rig(6, (256, 704), seed=seed)
     imgs = torch.from_numpy(g.random((1, 6, 3, 256, 704), dtype=np.float32))
     depth = torch.from_numpy((g.uniform(0.5, 70.0, (1, 6, 256, 704)) * (g.random((1, 6, 256, 704)) < 0.05)).astype(np.float32))
-    n = 60000
-    pts = np.concatenate([g.uniform(-48, 48, (n, 2)), g.normal(-1.5, 1.2, (n, 1)).clip(-4.9, 2.9), g.random((n, 2))], 1).astype(np.float32)
+    # a sweep that stays SPARSER than the camera volume: with knum > 1 the reference indexes inds_img with pts ordinals
+    # (bifuser_n.py:158) and raises IndexError as soon as the LiDAR list is the longer one
+    n = 6000
+    pts = np.concatenate([g.uniform(-22, 22, (n, 2)), g.normal(-1.5, 1.0, (n, 1)).clip(-4.9, 2.9), g.random((n, 2))], 1).astype(np.float32)
     gt = g.integers(1, 17, (1, 200, 200, 16)).astype(np.uint8)
     gt[g.random(gt.shape) < 0.8] = 0
     gt[g.random(gt.shape) < 0.02] = 255

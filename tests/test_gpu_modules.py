@@ -554,3 +554,46 @@ def test_fine_mlp_entry_points_accept_zero_points(dev):
     call("coocc_fine_mlp_pre", ptr(e), 64, ptr(e), 64, 0, ptr(v), ptr(v), ptr(v), 1e-5, ptr(z), ptr(v), ptr(v), ptr(v), 1e-5,
          ptr(z[:17, :64].contiguous()), ptr(v[:17].contiguous()), 17, ptr(out))
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n,grid", [(20000, (2, 9, 7, 3)), (3000, (1, 40, 30, 4)), (20000, (2, 1, 1, 1)), (70, (1, 1, 1, 1)), (64, (1, 2, 1, 1))])
+def test_sort_free_pooling_orders_every_voxel_by_point_id(dev, n, grid):
+    """CSR pooling (histogram -> scan -> atomic fill -> in-voxel ordering): bit-equal to the oracle's stable order for short
+    voxels (wave rank sort), long voxels (> 64 points: workgroup bitonic sort) and the > 8192-point slow path."""
+    B, X, Y, Z = grid
+    rng = np.random.default_rng(n + X)
+    C = 12
+    feats = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32))
+    coords = torch.from_numpy(np.stack([rng.integers(0, X, n), rng.integers(0, Y, n), rng.integers(0, Z, n), rng.integers(0, B, n)], 1))
+    want = ref_cpu.bev_pool(feats, coords, B, Z, X, Y)
+    for _ in range(2):                                    # atomics fill in a different order every run: same bits
+        got = pkg.bev_pool(feats.to(dev), coords.to(dev), B, Z, X, Y)
+        assert torch.equal(got.cpu(), want)
+
+
+def test_lift_splat_into_the_fuser_concat_buffer(dev):
+    """P2 -> K1 without a layout round trip: lift_splat(out=BiFuser_N.concat_buffer(...)) writes the camera rows into slot 0
+    of the [V,4C] buffer, the rows prologue only computes its flag; everything downstream equals the NCDHW path bit for bit."""
+    c = cases.FUSER_CASES["fuser_k2"]
+    X, Y, Z = c["grid"]
+    C = c["C"]
+    _, pts = cases.fuser_inputs(c)
+    rig = synth.camera_rig(3, (64, 176), seed=4)
+    vt = pkg.ViewTransformerLiftSplatShootVoxel(grid_config=dict(xbound=[-20, 20, 1.0], ybound=[-20, 20, 1.0], zbound=[-2.0, 2.0, 1.0],
+                                                                 dbound=[2.0, 30.0, 0.5]),
+                                                data_config=dict(input_size=(64, 176)), downsample=16, numC_Trans=C).to(dev)
+    depth, ctx = synth.lift_inputs(3, vt.D, (4, 11), C, seed=4)
+    cams = tuple(rig[k].to(dev) for k in ("rots", "trans", "intrins", "post_rots", "post_trans", "bda"))
+    f, _ = load_seeded(pkg.BiFuser_N(C, C, c["knum"]), c["seed"], dev)
+    plain = vt.lift_splat(depth.to(dev), ctx.to(dev), cams=cams)
+    slot0 = f.concat_buffer(1, X, Y, Z, dev)
+    inplace = vt.lift_splat(depth.to(dev), ctx.to(dev), cams=cams, out=slot0)
+    assert torch.equal(inplace, plain) and inplace.data_ptr() == slot0.t.data_ptr()
+    with torch.no_grad():
+        a = f(plain.contiguous(), pts.to(dev))            # NCDHW copy -> coocc_fuser_prepare
+        na = f.last_near
+        b = f(inplace, pts.to(dev))                       # rows in place -> coocc_fuser_prepare_rows
+        nb = f.last_near
+        cview = f(plain, pts.to(dev))                     # channels-last view of a [V,C] buffer -> rows prologue with a copy
+    assert torch.equal(a, b) and torch.equal(a, cview)
+    assert torch.equal(na[0], nb[0]) and torch.equal(na[1], nb[1])
