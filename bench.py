@@ -80,7 +80,41 @@ def pool(model, s):
     return model.img_view_transformer.lift_splat(s["depth"], s["ctx"], cams=s["cams"], out=slot0)
 
 
-def step(model, s, world, search=None, img=None):
+class _Ticket:
+    """Collectives must be issued in the same order on every rank: sample order, whichever host thread owns the sample."""
+
+    def __init__(self):
+        self.cv = __import__("threading").Condition()
+        self.turn, self.dead = 0, False
+
+    def reset(self):
+        with self.cv:
+            self.turn, self.dead = 0, False
+
+    def abort(self):
+        with self.cv:
+            self.dead = True
+            self.cv.notify_all()
+
+    def __call__(self, i):
+        ticket = self
+
+        class _Turn:
+            def __enter__(self_):
+                with ticket.cv:
+                    ticket.cv.wait_for(lambda: ticket.turn == i or ticket.dead)
+
+            def __exit__(self_, *a):
+                with ticket.cv:
+                    ticket.turn += 1
+                    ticket.cv.notify_all()
+        return _Turn()
+
+
+TICKET = _Ticket()
+
+
+def step(model, s, world, search=None, img=None, ticket=None):
     # the reference hard-codes the render bounds to a 100x100x8 volume (coocc_ray.py:577): smaller test grids
     # (config1) cannot be rendered there either
     if img is None:
@@ -88,7 +122,16 @@ def step(model, s, world, search=None, img=None):
     X, Y, Z = img.shape[2:]
     out = model.forward_hot_path(img, s["pts"], s["gemo"], s["img_feats"], s["transform"],
                                  render=(X >= 100 and Y >= 100 and Z >= 8), search=search)
+    if world > 1 and ticket is not None:
+        with TICKET(ticket):
+            return _gather(out)
     if world > 1:
+        return _gather(out)
+    return out
+
+
+def _gather(out):
+    if True:
         # one RCCL all-gather of the packed maps per step, issued asynchronously: the previous step's gather is
         # completed first (at most one in flight), so it overlaps the whole next dense stage instead of delaying it
         if _pending:
@@ -221,7 +264,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="r50", choices=sorted(synth.CONFIGS))
-    ap.add_argument("--streams", type=int, default=1, help="samples in flight (software pipelining over HIP streams)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="dense stages in flight: S host threads / HIP streams, sample i on stream i mod S (S = 2 runs one "
+                         "sample's low-occupancy tail under the other's large GEMMs)")
     ap.add_argument("--prefetch", type=int, default=1,
                     help="issue the index search of sample i+1 (helper host thread + stream) under the dense stage of sample i")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs set aside for the FPS chains (hipExtStreamCreateWithCUMask)")
@@ -272,57 +317,74 @@ def main():
 
     import threading
     from concurrent.futures import ThreadPoolExecutor
-    tpool = ThreadPoolExecutor(1) if (args.prefetch and len(streams) == 1) else None
-    # high priority: a lone 1024-thread FPS workgroup must win a CU slot against the queue of convolution workgroups
-    search_stream = torch.cuda.Stream(device=dev, priority=-1)
+    S = len(streams)
+    # one prefetch worker + high-priority stream per dense stream: a lone 1024-thread FPS workgroup must win a CU slot
+    # against the queue of convolution workgroups
+    tpool = ThreadPoolExecutor(S) if args.prefetch else None
+    search_streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(S)]
 
-    def do_search(s):
-        """Pooling (P2) + index search (K1-K5) of one sample on the high-priority prefetch stream."""
+    def do_search(i):
+        """Pooling (P2) + index search (K1-K5) of sample i on a high-priority prefetch stream."""
+        s = samples[i % len(samples)]
         torch.cuda.set_device(dev)
-        with torch.cuda.stream(search_stream), torch.no_grad():
+        with torch.cuda.stream(search_streams[i % S]), torch.no_grad():
             img = pool(model, s) if WITH_POOL[0] else s["img"]
             return img, model.search(img, s["pts"])
 
     def run(nsteps, timed):
-        """`nsteps` samples round-robin over len(streams) host threads, one HIP stream each: the
-        path has two small device->host reads per sample (voxel counts), so samples are kept in
-        flight from independent host threads (torch drops the GIL while it waits)."""
+        """`nsteps` samples over S dense streams (one host thread each; S = 1: a single driver thread).  Sample i runs its
+        dense stage (fuser finish -> encoder -> neck -> head -> render) on stream i mod S; its pooling + index search were
+        issued S samples earlier on a prefetch stream by a helper thread, so they overlap the dense stages in flight.  With
+        S = 2 the low-occupancy tail of one sample (the 25x25x2 / 13x13x1 encoder stages, laterals, small heads: ~1.3 ms on
+        <= 20 % of the CUs) runs under the other sample's large GEMMs.  Collectives (N > 1) are issued in sample order on
+        every rank (ticket), whatever thread owns the sample."""
         errs = []
-        def worker(si):
+        futs = {}
+        lock = threading.Lock()
+
+        def submit(i):
+            if tpool is not None and i < nsteps:
+                with lock:
+                    futs[i] = tpool.submit(do_search, i)
+
+        for i in range(min(S, nsteps)):
+            submit(i)
+
+        def worker(w):
             try:
                 torch.cuda.set_device(dev)
-                with torch.cuda.stream(streams[si]), torch.no_grad():
-                    for i in range(si, nsteps, len(streams)):
-                        step(model, samples[i % len(samples)], world)
-                streams[si].synchronize()
+                with torch.no_grad():
+                    for i in range(w, nsteps, S):
+                        img, sr = (None, None)
+                        if tpool is not None:
+                            with lock:
+                                f = futs.pop(i)
+                            img, sr = f.result()
+                        submit(i + S)
+                        with torch.cuda.stream(streams[w]):
+                            if img is not None and torch.is_tensor(img):
+                                img.record_stream(streams[w])
+                            step(model, samples[i % len(samples)], world, search=sr, img=img, ticket=i)
+                streams[w].synchronize()
             except Exception as e:  # surface worker failures in the main thread
                 errs.append(e)
-        if len(streams) == 1 or world > 1:
-            # collectives must be issued in the same order on every rank: single driver thread.  With --prefetch the
-            # index search of sample i+1 (no collective, one device->host read) runs on a helper thread and its own
-            # stream under the dense stage of sample i; dense stages never overlap each other.
-            with torch.no_grad():
-                fut = tpool.submit(do_search, samples[0]) if (tpool and nsteps) else None
-                for i in range(nsteps):
-                    img, sr = fut.result() if fut is not None else (None, None)
-                    if tpool and i + 1 < nsteps:
-                        fut = tpool.submit(do_search, samples[(i + 1) % len(samples)])
-                    with torch.cuda.stream(streams[i % len(streams)]):
-                        if img is not None:
-                            img.record_stream(streams[i % len(streams)])
-                        step(model, samples[i % len(samples)], world, search=sr, img=img)
-            with torch.cuda.stream(streams[0]):
-                drain_gathers()          # the last step's all-gather belongs to the timed region
-            for st in streams:
-                st.synchronize()
-            return
-        ths = [threading.Thread(target=worker, args=(si,)) for si in range(len(streams))]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
+                TICKET.abort()
+
+        TICKET.reset()
+        if S == 1:
+            worker(0)
+        else:
+            ths = [threading.Thread(target=worker, args=(w,)) for w in range(S)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
         if errs:
             raise errs[0]
+        with torch.cuda.stream(streams[0]):
+            drain_gathers()          # the last step's all-gather belongs to the timed region
+        for st in streams:
+            st.synchronize()
 
     with torch.no_grad():
         step(model, samples[0], world)          # packs weights, sizes workspaces (untimed, extra to --warmup)

@@ -50,8 +50,8 @@ def random_state_dict(reference_sd, seed=0, gain=1.0):
         if k.endswith("num_batches_tracked"):
             out[k] = torch.zeros(shape, dtype=v.dtype)
             continue
-        if k.endswith("posi_encoder.scales"):
-            out[k] = v.clone()
+        if k.endswith("posi_encoder.scales") or k.rsplit(".", 1)[-1] in ("dx", "bx", "nx", "frustum"):
+            out[k] = v.clone()              # constants, not weights (the view transformer keeps its grid / frustum as Parameters)
             continue
         if k.endswith("running_mean"):
             a = g.normal(0, 0.1, shape)

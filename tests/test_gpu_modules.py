@@ -578,17 +578,18 @@ def test_lift_splat_into_the_fuser_concat_buffer(dev):
     X, Y, Z = c["grid"]
     C = c["C"]
     _, pts = cases.fuser_inputs(c)
-    rig = synth.camera_rig(3, (64, 176), seed=4)
+    rig = synth.camera_rig(6, (128, 352), seed=4)       # dense enough that both voxel lists exceed 2048 (knum = 2 needs it)
     vt = pkg.ViewTransformerLiftSplatShootVoxel(grid_config=dict(xbound=[-20, 20, 1.0], ybound=[-20, 20, 1.0], zbound=[-2.0, 2.0, 1.0],
-                                                                 dbound=[2.0, 30.0, 0.5]),
-                                                data_config=dict(input_size=(64, 176)), downsample=16, numC_Trans=C).to(dev)
-    depth, ctx = synth.lift_inputs(3, vt.D, (4, 11), C, seed=4)
+                                                                 dbound=[1.0, 25.0, 0.25]),
+                                                data_config=dict(input_size=(128, 352)), downsample=16, numC_Trans=C).to(dev)
+    depth, ctx = synth.lift_inputs(6, vt.D, (8, 22), C, seed=4)
     cams = tuple(rig[k].to(dev) for k in ("rots", "trans", "intrins", "post_rots", "post_trans", "bda"))
     f, _ = load_seeded(pkg.BiFuser_N(C, C, c["knum"]), c["seed"], dev)
     plain = vt.lift_splat(depth.to(dev), ctx.to(dev), cams=cams)
     slot0 = f.concat_buffer(1, X, Y, Z, dev)
     inplace = vt.lift_splat(depth.to(dev), ctx.to(dev), cams=cams, out=slot0)
     assert torch.equal(inplace, plain) and inplace.data_ptr() == slot0.t.data_ptr()
+    assert int((plain.abs().sum(1) != 0).sum()) > 2048
     with torch.no_grad():
         a = f(plain.contiguous(), pts.to(dev))            # NCDHW copy -> coocc_fuser_prepare
         na = f.last_near
