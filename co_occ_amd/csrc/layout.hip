@@ -4,6 +4,8 @@
 
 #include "common.h"
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // ------------------------------------------------------------------ error state
 static thread_local char g_err[512] = "";
 
@@ -157,9 +159,18 @@ __global__ __launch_bounds__(256) void k_fuser_prepare_rows(const float* __restr
     for (int c0 = 0; c0 < C; c0 += TC) {
       const int cn = min(TC, C - c0);
       if (rows) {
-        for (int i = t; i < TV * cn; i += 256) {
-          int v = i / cn, c = i - v * cn;
-          tile[v][c] = v0 + v < V ? src[((size_t)b * V + v0 + v) * sstride + c0 + c] : 0.f;
+        if (cn == TC) {            // full channel chunk: TC / 4 lanes x 16 B per voxel row, constant divisors
+          for (int i = t; i < TV * (TC / 4); i += 256) {
+            const int v = i / (TC / 4), c = (i % (TC / 4)) * 4;
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};
+            if (v0 + v < V) q = *(const f32x4*)(src + ((size_t)b * V + v0 + v) * sstride + c0 + c);
+            tile[v][c] = q[0]; tile[v][c + 1] = q[1]; tile[v][c + 2] = q[2]; tile[v][c + 3] = q[3];
+          }
+        } else {
+          for (int i = t; i < TV * cn; i += 256) {
+            int v = i / cn, c = i - v * cn;
+            tile[v][c] = v0 + v < V ? src[((size_t)b * V + v0 + v) * sstride + c0 + c] : 0.f;
+          }
         }
       } else {
         for (int c = t >> 6; c < cn; c += 4) {

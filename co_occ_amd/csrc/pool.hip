@@ -248,32 +248,55 @@ __global__ __launch_bounds__(256) void k_key_hist(const uint32_t* __restrict__ k
   if (valid) slot[i] = myslot;
 }
 
-// exclusive scan of count[0..nvox) by ONE workgroup (nvox <= a few 100 k): start[v], start[nvox] = total; voxels with more
-// than 64 points are appended to long_list (their order does not matter) and *nlong counts them.
-__global__ __launch_bounds__(1024) void k_count_scan(const int32_t* __restrict__ count, int nvox, int32_t* __restrict__ start,
-                                                      int32_t* __restrict__ long_list, int32_t* __restrict__ nlong) {
+// exclusive scan of count[0..nvox): 1024 voxels per workgroup -> local prefix + block total; one workgroup scans the
+// (<= 1024) block totals; a third pass adds the block offset, writes start[nvox] = total and appends the voxels with more
+// than POOL_MEDIUM points to long_list (their order does not matter).  A single-workgroup scan of 80 k counts took 140 us.
+constexpr int POOL_MEDIUM = 256;     // <= 64 points: wave rank sort in registers; <= 256: wave rank sort through LDS; else workgroup
+
+__global__ __launch_bounds__(1024) void k_scan_local(const int32_t* __restrict__ count, int nvox, int32_t* __restrict__ start,
+                                                      int32_t* __restrict__ tops) {
   __shared__ int wsum[16];
-  const int tid = threadIdx.x;
-  const int per = (nvox + 1023) / 1024;
-  const int lo = min(tid * per, nvox), hi = min(lo + per, nvox);
-  int sum = 0;
-  for (int v = lo; v < hi; ++v) sum += count[v];
-  int inc = sum;
+  const int tid = threadIdx.x, v = blockIdx.x * 1024 + tid;
+  const int c = v < nvox ? count[v] : 0;
+  int inc = c;
   for (int o = 1; o < 64; o <<= 1) {
     int n = __shfl_up(inc, o);
     if ((tid & 63) >= o) inc += n;
   }
   if ((tid & 63) == 63) wsum[tid >> 6] = inc;
   __syncthreads();
-  int off = inc - sum;
+  int off = inc - c;
   for (int w = 0; w < (tid >> 6); ++w) off += wsum[w];
-  for (int v = lo; v < hi; ++v) {
-    const int c = count[v];
-    start[v] = off;
-    off += c;
-    if (c > 64) long_list[atomicAdd(nlong, 1)] = v;
+  if (v < nvox) start[v] = off;
+  if (tid == 1023) tops[blockIdx.x] = off + c;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_tops(int32_t* __restrict__ tops, int nblk) {
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x;
+  const int c = tid < nblk ? tops[tid] : 0;
+  int inc = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    int n = __shfl_up(inc, o);
+    if ((tid & 63) >= o) inc += n;
   }
-  if (tid == 1023) start[nvox] = off;
+  if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+  __syncthreads();
+  int off = inc - c;
+  for (int w = 0; w < (tid >> 6); ++w) off += wsum[w];
+  if (tid < nblk) tops[tid] = off;
+  if (tid == nblk - 1) tops[nblk] = off + c;      // grand total
+}
+
+__global__ __launch_bounds__(1024) void k_scan_finish(const int32_t* __restrict__ count, int nvox, int nblk,
+                                                       const int32_t* __restrict__ tops, int32_t* __restrict__ start,
+                                                       int32_t* __restrict__ long_list, int32_t* __restrict__ nlong) {
+  const int v = blockIdx.x * 1024 + threadIdx.x;
+  if (v < nvox) {
+    start[v] += tops[blockIdx.x];
+    if (count[v] > POOL_MEDIUM) long_list[atomicAdd(nlong, 1)] = v;
+  }
+  if (v == 0) start[nvox] = tops[nblk];
 }
 
 __global__ __launch_bounds__(256) void k_csr_fill(const uint32_t* __restrict__ keys, int npts, int nvox,
@@ -287,207 +310,238 @@ __global__ __launch_bounds__(256) void k_csr_fill(const uint32_t* __restrict__ k
 
 // One wave per voxel row, VEC channels per lane.  Rows are summed in ascending point id with a single accumulator, the
 // association of the reference's interval kernel over a stably sorted input.  The segment arrives in arbitrary order (atomic
-// cursor): each lane takes one id, its rank is the number of smaller ids in the segment (n broadcast compares, n = 4.5 on
-// average) and one ds_permute puts the ids in order.  Then the wave fetches the sorted ids' rows POOL_BATCH at a time
-// (v_readlane broadcasts) so that the loads run ahead of the dependent adds.  Segments longer than 64 belong to
-// k_pool_sum_long.
+// slots).  n <= 64: each lane takes one id, its rank is the number of smaller ids in the segment (n broadcast compares,
+// n = 4.5 on average) and one ds_permute puts the ids in order.  64 < n <= 256: four ids per lane, ranks by n LDS broadcast
+// reads, the sorted ids go through the wave's 1 KB LDS slice.  Then the wave fetches the sorted ids' rows POOL_BATCH at a
+// time so that the loads run ahead of the dependent adds.  n > 256 (24 voxels of 57 k at r50, 554 of 73 k at r101, up to
+// 2614 points each, next to the cameras): a whole workgroup bitonic-sorts the ids in LDS and thread c sums channel c; these
+// workgroups are the FIRST blocks of the same launch, so the long tail runs under the short voxels instead of after them.
 constexpr int POOL_BATCH = 16;
+constexpr int POOL_LONG_CAP = 4096;   // ids a workgroup sorts in LDS; beyond: a slow selection path (never seen)
 
 template <int VEC> struct PoolVec;
 template <> struct PoolVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct PoolVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
 
-// A lone wave issues roughly one instruction per 5 cycles, so the per-point instruction count matters as
-// much as the load latency: the id -> (context row, depth) decode is done once per 64 ids in the vector
-// lanes and broadcast with v_readlane (3 per point); VEC = 2 keeps all 64 lanes busy at C <= 128.
+// sum of nb (<= 64) rows whose (row, depth) sit in the lanes' registers in ascending id order
+template <bool LIFT, int VEC>
+__device__ __forceinline__ void pool_accumulate(const float* __restrict__ xc, int C, uint32_t myrow, float mydp, int nb,
+                                                typename PoolVec<VEC>::type& acc) {
+  typedef typename PoolVec<VEC>::type vec;
+  for (int j0 = 0; j0 < nb; j0 += POOL_BATCH) {
+    vec r[POOL_BATCH];
+#pragma unroll
+    for (int j = 0; j < POOL_BATCH; ++j) {
+#pragma clang fp contract(off)  // LIFT: the product is rounded before the add, as the materialised volume is
+      const int jj = min(j0 + j, nb - 1);
+      const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)myrow, jj);
+      vec v = *(const vec*)(xc + (size_t)row * C);
+      if (LIFT) v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mydp), jj)) * v;
+      r[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < POOL_BATCH; ++j)
+      if (j0 + j < nb) acc = acc + r[j];
+  }
+}
+
 template <bool LIFT, int VEC>
 __device__ __forceinline__ void pool_row(const float* __restrict__ x, const float* __restrict__ depth,
                                          const uint32_t* __restrict__ ids, int s, int e, int lane, int C, int D, int HW,
-                                         float* __restrict__ orow) {
+                                         float* __restrict__ orow, uint32_t* __restrict__ lds /* 256 ids, wave-private */) {
   typedef typename PoolVec<VEC>::type vec;
-  const int nb = e - s;                      // 0 .. 64
-  uint32_t myid = lane < nb ? ids[s + lane] : 0xFFFFFFFFu;
-  if (nb > 1) {
-    int rank = 0;
-    for (int j = 0; j < nb; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)myid, j) < myid;   // ids are distinct
-    // idle lanes (id = 0xFFFFFFFF) all rank nb: they land on lane nb, which is not read
-    myid = (uint32_t)__builtin_amdgcn_ds_permute(rank << 2, (int)myid);
+  const int n = e - s;                      // 0 .. POOL_MEDIUM
+  if (n <= 64) {
+    uint32_t myid = lane < n ? ids[s + lane] : 0xFFFFFFFFu;
+    if (n > 1) {
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)myid, j) < myid;   // ids are distinct
+      // idle lanes (id = 0xFFFFFFFF) all rank n: they land on lane n, which is not read
+      myid = (uint32_t)__builtin_amdgcn_ds_permute(rank << 2, (int)myid);
+    }
+    uint32_t myrow = myid;
+    float mydp = 1.f;
+    if (LIFT && lane < n) {
+      myrow = (myid / (uint32_t)(D * HW)) * (uint32_t)HW + myid % (uint32_t)HW;
+      mydp = depth[myid];
+    }
+    for (int c0 = 0; c0 < C; c0 += 64 * VEC) {
+      const int c = c0 + lane * VEC;
+      const bool lane_on = c < C;
+      vec acc = (vec)(0.f);
+      pool_accumulate<LIFT, VEC>(x + (lane_on ? c : 0), C, myrow, mydp, n, acc);   // idle lanes re-read channel 0
+      if (lane_on) *(vec*)(orow + c) = acc;
+    }
+    return;
   }
-  uint32_t myrow = myid;
-  float mydp = 1.f;
-  if (LIFT && lane < nb) {
-    myrow = (myid / (uint32_t)(D * HW)) * (uint32_t)HW + myid % (uint32_t)HW;
-    mydp = depth[myid];
+  // medium voxel: ids -> LDS (unsorted) -> ranks -> LDS (sorted, after every lane has read what it needs)
+  uint32_t mine[POOL_MEDIUM / 64];
+  int rank[POOL_MEDIUM / 64];
+#pragma unroll
+  for (int q = 0; q < POOL_MEDIUM / 64; ++q) {
+    mine[q] = q * 64 + lane < n ? ids[s + q * 64 + lane] : 0xFFFFFFFFu;
+    lds[q * 64 + lane] = mine[q];
+    rank[q] = 0;
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int j = 0; j < n; ++j) {
+    const uint32_t o = lds[j];              // broadcast read
+#pragma unroll
+    for (int q = 0; q < POOL_MEDIUM / 64; ++q) rank[q] += o < mine[q];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < POOL_MEDIUM / 64; ++q)
+    if (q * 64 + lane < n) lds[rank[q]] = mine[q];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   for (int c0 = 0; c0 < C; c0 += 64 * VEC) {
     const int c = c0 + lane * VEC;
     const bool lane_on = c < C;
-    const float* xc = x + (lane_on ? c : 0);   // idle lanes re-read channel 0 instead of branching
     vec acc = (vec)(0.f);
-    for (int j0 = 0; j0 < nb; j0 += POOL_BATCH) {
-      vec r[POOL_BATCH];
-#pragma unroll
-      for (int j = 0; j < POOL_BATCH; ++j) {
-#pragma clang fp contract(off)  // LIFT: the product is rounded before the add, as the materialised volume is
-        const int jj = min(j0 + j, nb - 1);
-        const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)myrow, jj);
-        vec v = *(const vec*)(xc + (size_t)row * C);
-        if (LIFT) v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mydp), jj)) * v;
-        r[j] = v;
+    for (int base = 0; base < n; base += 64) {
+      const int nb = min(64, n - base);
+      const uint32_t myid = lds[base + min(lane, nb - 1)];
+      uint32_t myrow = myid;
+      float mydp = 1.f;
+      if (LIFT) {
+        myrow = (myid / (uint32_t)(D * HW)) * (uint32_t)HW + myid % (uint32_t)HW;
+        mydp = depth[myid];
       }
-#pragma unroll
-      for (int j = 0; j < POOL_BATCH; ++j)
-        if (j0 + j < nb) acc = acc + r[j];
+      pool_accumulate<LIFT, VEC>(x + (lane_on ? c : 0), C, myrow, mydp, nb, acc);
     }
     if (lane_on) *(vec*)(orow + c) = acc;
   }
 }
 
-// Voxels with more than 64 points (229 of 57 k at r50, 4 k of 73 k at r101; up to 2614 points each): one WORKGROUP per
-// voxel.  The ids are bitonic-sorted in LDS by all 256 threads (padded to a power of two with 0xFFFFFFFF), decoded to
-// (row, depth) in place, then thread c sums channel c (c + 256, ...) over the sorted rows, 16 independent loads ahead of
-// the dependent adds.  Segments beyond POOL_LONG_CAP ids (never seen: 8192 points in one voxel) take a slow selection path, O(n^2 / 256).
-constexpr int POOL_LONG_CAP = 8192;
-
+// n > POOL_MEDIUM: one workgroup per voxel
 template <bool LIFT>
-__global__ __launch_bounds__(256) void k_pool_sum_long(const float* __restrict__ x, const float* __restrict__ depth,
-                                                        uint32_t* __restrict__ ids, const int32_t* __restrict__ start,
-                                                        const int32_t* __restrict__ long_list,
-                                                        const int32_t* __restrict__ nlong_p, int C, int D, int HW,
-                                                        float* __restrict__ out, int out_stride) {
-  __shared__ uint32_t sid[POOL_LONG_CAP];
-  __shared__ float sdp[POOL_LONG_CAP];
+__device__ __forceinline__ void pool_long(const float* __restrict__ x, const float* __restrict__ depth, uint32_t* __restrict__ seg,
+                                          int n, int C, int D, int HW, float* __restrict__ orow, uint32_t* __restrict__ sid) {
   const int tid = threadIdx.x;
-  const int nlong = *nlong_p;
-  for (int li = blockIdx.x; li < nlong; li += gridDim.x) {
-    const int v = long_list[li];
-    const int s = start[v], n = start[v + 1] - s;
-    uint32_t* seg = ids + s;
-    if (n <= POOL_LONG_CAP) {
-      int np2 = 128;
-      while (np2 < n) np2 <<= 1;
-      for (int i = tid; i < np2; i += 256) sid[i] = i < n ? seg[i] : 0xFFFFFFFFu;
-      __syncthreads();
-      for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-          for (int i = tid; i < np2; i += 256) {
-            const int l = i ^ j;
-            if (l > i) {
-              const uint32_t a = sid[i], b = sid[l];
-              const bool up = (i & k) == 0;
-              if ((a > b) == up) { sid[i] = b; sid[l] = a; }
-            }
+  if (n <= POOL_LONG_CAP) {
+    int np2 = 512;
+    while (np2 < n) np2 <<= 1;
+    for (int i = tid; i < np2; i += 256) sid[i] = i < n ? seg[i] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < np2; i += 256) {
+          const int l = i ^ j;
+          if (l > i) {
+            const uint32_t a = sid[i], b = sid[l];
+            const bool up = (i & k) == 0;
+            if ((a > b) == up) { sid[i] = b; sid[l] = a; }
           }
-          __syncthreads();
         }
-      for (int i = tid; i < n; i += 256) {
-        const uint32_t id = sid[i];
-        if (LIFT) {
-          sdp[i] = depth[id];
-          sid[i] = (id / (uint32_t)(D * HW)) * (uint32_t)HW + id % (uint32_t)HW;
-        }
-      }
-      __syncthreads();
-    }
-    float* orow = out + (size_t)v * out_stride;
-    if (n <= POOL_LONG_CAP) {
-      for (int c = tid; c < C; c += 256) {
-        float acc = 0.f;
-        for (int j0 = 0; j0 < n; j0 += POOL_BATCH) {
-          float r[POOL_BATCH];
-#pragma unroll
-          for (int j = 0; j < POOL_BATCH; ++j) {
-#pragma clang fp contract(off)
-            const int jj = min(j0 + j, n - 1);
-            float val = x[(size_t)sid[jj] * C + c];
-            if (LIFT) val = sdp[jj] * val;
-            r[j] = val;
-          }
-#pragma unroll
-          for (int j = 0; j < POOL_BATCH; ++j)
-            if (j0 + j < n) acc = acc + r[j];
-        }
-        orow[c] = acc;
-      }
-    } else {
-      // never seen in practice (> 8192 points in one voxel): the next id in ascending order is found by a block-wide min
-      // over the unsorted segment, one point at a time -- O(n^2 / 256), correct for any n
-      for (int c = tid; c < C; c += 256) orow[c] = 0.f;
-      uint32_t prev = 0;
-      bool first = true;
-      for (int t = 0; t < n; ++t) {
-        // next = smallest id greater than prev (ids distinct): block-wide min reduction through LDS
-        uint32_t best = 0xFFFFFFFFu;
-        for (int i = tid; i < n; i += 256) {
-          const uint32_t me = seg[i];
-          if ((first || me > prev) && me < best) best = me;
-        }
-        sid[tid] = best;
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-          if (tid < o) sid[tid] = min(sid[tid], sid[tid + o]);
-          __syncthreads();
-        }
-        const uint32_t id = sid[0];
-        __syncthreads();
-        prev = id; first = false;
-        const uint32_t row = LIFT ? (id / (uint32_t)(D * HW)) * (uint32_t)HW + id % (uint32_t)HW : id;
-        const float dp = LIFT ? depth[id] : 1.f;
-        for (int c = tid; c < C; c += 256) {
+      }
+    for (int c = tid; c < C; c += 256) {
+      float acc = 0.f;
+      for (int j0 = 0; j0 < n; j0 += POOL_BATCH) {
+        float r[POOL_BATCH];
+#pragma unroll
+        for (int j = 0; j < POOL_BATCH; ++j) {
 #pragma clang fp contract(off)
+          const uint32_t id = sid[min(j0 + j, n - 1)];
+          const uint32_t row = LIFT ? (id / (uint32_t)(D * HW)) * (uint32_t)HW + id % (uint32_t)HW : id;
           float val = x[(size_t)row * C + c];
-          if (LIFT) val = dp * val;
-          orow[c] = orow[c] + val;
+          if (LIFT) val = depth[id] * val;
+          r[j] = val;
         }
+#pragma unroll
+        for (int j = 0; j < POOL_BATCH; ++j)
+          if (j0 + j < n) acc = acc + r[j];
       }
+      orow[c] = acc;
     }
     __syncthreads();
+    return;
   }
+  // never seen in practice (> 4096 points in one voxel): the next id in ascending order is found by a block-wide min over
+  // the unsorted segment, one point at a time -- O(n^2 / 256), correct for any n
+  for (int c = tid; c < C; c += 256) orow[c] = 0.f;
+  uint32_t prev = 0;
+  bool first = true;
+  for (int t = 0; t < n; ++t) {
+    uint32_t best = 0xFFFFFFFFu;
+    for (int i = tid; i < n; i += 256) {
+      const uint32_t me = seg[i];
+      if ((first || me > prev) && me < best) best = me;
+    }
+    sid[tid] = best;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) sid[tid] = min(sid[tid], sid[tid + o]);
+      __syncthreads();
+    }
+    const uint32_t id = sid[0];
+    __syncthreads();
+    prev = id; first = false;
+    const uint32_t row = LIFT ? (id / (uint32_t)(D * HW)) * (uint32_t)HW + id % (uint32_t)HW : id;
+    const float dp = LIFT ? depth[id] : 1.f;
+    for (int c = tid; c < C; c += 256) {
+#pragma clang fp contract(off)
+      float val = x[(size_t)row * C + c];
+      if (LIFT) val = dp * val;
+      orow[c] = orow[c] + val;
+    }
+  }
+  __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_pool_sum(const float* __restrict__ x, const uint32_t* __restrict__ ids,
-                                                   const int32_t* __restrict__ start, int nvox, int C,
-                                                   float* __restrict__ out, int out_stride) {
-  const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+// blocks [0, long_blocks): the long voxels (persistent over long_list); the rest: one wave per voxel
+template <bool LIFT>
+__global__ __launch_bounds__(256) void k_pool_sum_csr(const float* __restrict__ x, const float* __restrict__ depth,
+                                                       uint32_t* __restrict__ ids, const int32_t* __restrict__ start,
+                                                       const int32_t* __restrict__ long_list,
+                                                       const int32_t* __restrict__ nlong_p, int long_blocks, int nvox, int C,
+                                                       int D, int HW, float* __restrict__ out, int out_stride) {
+  __shared__ uint32_t sid[POOL_LONG_CAP];
+  if ((int)blockIdx.x < long_blocks) {
+    const int nlong = *nlong_p;
+    for (int li = blockIdx.x; li < nlong; li += long_blocks) {
+      const int v = long_list[li];
+      const int s = start[v];
+      pool_long<LIFT>(x, depth, ids + s, start[v + 1] - s, C, D, HW, out + (size_t)v * out_stride, sid);
+    }
+    return;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int v = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - long_blocks) * 4 + wave);
   if (v >= nvox) return;
   const int s = start[v], e = start[v + 1];
-  if (e - s > 64) return;                                   // k_pool_sum_long
-  if (C <= 128) pool_row<false, 2>(x, nullptr, ids, s, e, lane, C, 0, 0, out + (size_t)v * out_stride);
-  else pool_row<false, 4>(x, nullptr, ids, s, e, lane, C, 0, 0, out + (size_t)v * out_stride);
-}
-
-__global__ __launch_bounds__(256) void k_lift_pool_sum(const float* __restrict__ depth, const float* __restrict__ feat,
-                                                        const uint32_t* __restrict__ ids, const int32_t* __restrict__ start,
-                                                        int nvox, int C, int D, int HW, float* __restrict__ out,
-                                                        int out_stride) {
-  const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  if (v >= nvox) return;
-  const int s = start[v], e = start[v + 1];
-  if (e - s > 64) return;                                   // k_pool_sum_long
-  if (C <= 128) pool_row<true, 2>(feat, depth, ids, s, e, lane, C, D, HW, out + (size_t)v * out_stride);
-  else pool_row<true, 4>(feat, depth, ids, s, e, lane, C, D, HW, out + (size_t)v * out_stride);
+  if (e - s > POOL_MEDIUM) return;
+  uint32_t* lds = sid + wave * POOL_MEDIUM;
+  if (C <= 128) pool_row<LIFT, 2>(x, depth, ids, s, e, lane, C, D, HW, out + (size_t)v * out_stride, lds);
+  else pool_row<LIFT, 4>(x, depth, ids, s, e, lane, C, D, HW, out + (size_t)v * out_stride, lds);
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // workspace: keys[npts] | ids[npts] | slot[npts] | count[nvox+1] | nlong[64] (one memset clears these two) | start[nvox+1] |
-// long_list[nvox]
+// long_list[nvox] | tops[1025]
 extern "C" size_t coocc_voxel_pool_ws(int npts, int nvox) {
   if (npts <= 0 || nvox <= 0) return 0;
-  return 3 * align256(sizeof(uint32_t) * (size_t)npts) + 3 * align256(sizeof(int32_t) * ((size_t)nvox + 1)) + 256 + 256;
+  return 3 * align256(sizeof(uint32_t) * (size_t)npts) + 3 * align256(sizeof(int32_t) * ((size_t)nvox + 1)) + 256 + 8192 + 256;
 }
 
-struct PoolWs { uint32_t *keys, *ids; int32_t *slot, *count, *nlong, *start, *long_list; size_t zero_bytes; };
+struct PoolWs { uint32_t *keys, *ids; int32_t *slot, *count, *nlong, *start, *long_list, *tops; size_t zero_bytes; };
 
 static int carve(void* ws, size_t ws_bytes, int npts, int nvox, PoolWs* p) {
   size_t need = coocc_voxel_pool_ws(npts, nvox);
   if (!ws || ws_bytes < need) return coocc_set_error(COOCC_ENOMEM, "voxel_pool: workspace %zu < %zu bytes", ws_bytes, need);
+  if (nvox > 1024 * 1024) return coocc_set_error(COOCC_EINVAL, "voxel_pool: more than 2^20 voxels");
   char* c = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   size_t a = align256(sizeof(uint32_t) * (size_t)npts), v = align256(sizeof(int32_t) * ((size_t)nvox + 1));
   p->keys = (uint32_t*)c; c += a; p->ids = (uint32_t*)c; c += a; p->slot = (int32_t*)c; c += a;
   p->count = (int32_t*)c; c += v; p->nlong = (int32_t*)c; c += 256;
   p->zero_bytes = v + 256;
-  p->start = (int32_t*)c; c += v; p->long_list = (int32_t*)c;
+  p->start = (int32_t*)c; c += v; p->long_list = (int32_t*)c; c += v; p->tops = (int32_t*)c;
   return COOCC_OK;
 }
 
@@ -497,16 +551,15 @@ template <bool LIFT>
 static int pool_csr(const float* x, const float* depth, int npts, int C, int D, int HW, int nvox, float* out, int out_stride,
                     const PoolWs& p, hipStream_t s) {
   COOCC_HIP(hipMemsetAsync(p.count, 0, p.zero_bytes, s));
+  const int nblk = (nvox + 1023) / 1024;
   hipLaunchKernelGGL(k_key_hist, dim3(cdiv(npts, 256)), dim3(256), 0, s, p.keys, npts, nvox, p.count, p.slot);
-  hipLaunchKernelGGL(k_count_scan, dim3(1), dim3(1024), 0, s, p.count, nvox, p.start, p.long_list, p.nlong);
+  hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(1024), 0, s, p.count, nvox, p.start, p.tops);
+  hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, p.tops, nblk);
+  hipLaunchKernelGGL(k_scan_finish, dim3(nblk), dim3(1024), 0, s, p.count, nvox, nblk, p.tops, p.start, p.long_list, p.nlong);
   hipLaunchKernelGGL(k_csr_fill, dim3(cdiv(npts, 256)), dim3(256), 0, s, p.keys, npts, nvox, p.start, p.slot, p.ids);
-  if (LIFT)
-    hipLaunchKernelGGL(k_lift_pool_sum, dim3(cdiv(nvox, 4)), dim3(256), 0, s, depth, x, p.ids, p.start, nvox, C, D, HW, out,
-                       out_stride);
-  else
-    hipLaunchKernelGGL(k_pool_sum, dim3(cdiv(nvox, 4)), dim3(256), 0, s, x, p.ids, p.start, nvox, C, out, out_stride);
-  hipLaunchKernelGGL(k_pool_sum_long<LIFT>, dim3(512), dim3(256), 0, s, x, depth, p.ids, p.start, p.long_list, p.nlong, C, D, HW,
-                     out, out_stride);
+  const int long_blocks = 128;
+  hipLaunchKernelGGL(k_pool_sum_csr<LIFT>, dim3(long_blocks + cdiv(nvox, 4)), dim3(256), 0, s, x, depth, p.ids, p.start,
+                     p.long_list, p.nlong, long_blocks, nvox, C, D, HW, out, out_stride);
   COOCC_LAUNCH_CHECK("voxel_pool");
   return COOCC_OK;
 }
