@@ -7,10 +7,13 @@ bench cpu_baseline) -- the product never imports this.
   ``points_to_voxel`` run here (oracle/gen_golden.py, numba stubbed out).
 * ``vfe_mean``: mmdet3d/models/voxel_encoders/voxel_encoder.py:43-45.
 * ``sparse_encoder_forward``: P/coocc/voxel_encoder/sparse_lidar_enc.py:66-190 with spconv 2.3.6's SubMConv3d /
-  SparseConv3d written as masked dense convolutions.  **Parity unpinned**: spconv is an un-vendored dependency
-  (docs/requirements_ref.txt:166) and cannot be imported or built here, so this restates its published semantics
-  (SubM: outputs only at active inputs; SparseConv3d: an output is active iff its receptive field holds an active input;
-  weights [Cout, kd, kh, kw, Cin]; ``dense()`` zero-fills).
+  SparseConv3d written as masked dense convolutions.  spconv 2.3.6 is an un-vendored dependency
+  (docs/requirements_ref.txt:166) and cannot be imported or built here, so no golden from the real library exists
+  ("parity unpinned" for this half); its semantics (SubM: outputs only at active inputs; SparseConv3d: an output is
+  active iff its receptive field holds an active input; ``dense()`` zero-fills) are CROSS-CHECKED against the spconv v1
+  rule-book code that mmdetection3d vendors (M/ops/spconv/include/spconv/geometry.h, ops.py; ``spconv_v1_*`` below,
+  tests/test_oracle.py::test_sparse_conv_rules_match_vendored_spconv_v1_rulebook).  What stays an assumption is the 2.x
+  weight layout [Cout, kd, kh, kw, Cin] (v1 stores [kd, kh, kw, Cin, Cout]).
 """
 import numpy as np
 import torch
@@ -105,3 +108,66 @@ def sparse_encoder_forward(sd, feats, coors, shape_zyx, variant="8x", bn_eps=1e-
     x = F.conv3d(x, _w(sd, "conv_out.0.weight"), sd.get("conv_out.0.bias"), padding=1) * mask
     x = F.relu(_gn_active(x, mask, sd, "conv_out.1")) * mask
     return x.permute(0, 1, 4, 3, 2).contiguous(), mask
+
+
+# ----------------------------------------------------------------------------- spconv v1 rule books (cross-check)
+# spconv 2.3.6 (the reference's dependency) is absent, but mmdetection3d VENDORS spconv v1 (M/ops/spconv/), whose rule-book
+# generation defines the same SubMConv3d / SparseConv3d semantics.  Restated here from the vendored sources so that the
+# masked-dense formulation above can be checked against them (tests/test_oracle.py::test_sparse_conv_rules_*):
+#   * output size:   M/ops/spconv/ops.py:20-31        (in + 2p - d(k-1) - 1) // s + 1
+#   * valid outputs of one input position + kernel offset:  include/spconv/geometry.h:25-86 (getValidOutPos)
+#   * SparseConv3d:  geometry.h:144-192 (getIndicePairsConv) -- an output site is created by the FIRST input that reaches it
+#   * SubMConv3d:    geometry.h:247-297 (getIndicePairsSubM) -- outputs = inputs, pairs only where the output site is active
+def spconv_v1_out_shape(shape, k, s, p, d=1):
+    return [(n + 2 * p - d * (k - 1) - 1) // s + 1 for n in shape]
+
+
+def spconv_v1_valid_out_pos(pos, k, s, p, out_shape, d=1):
+    """geometry.h:25-86 for one input position (z, y, x): [(out_pos, kernel_offset)], offset = (kz*k + ky)*k + kx."""
+    res = []
+    rng = []
+    for i in range(3):
+        lo = (pos[i] - (k - 1) * d - 1 + s + p) // s
+        hi = (pos[i] + p) // s
+        rng.append(range(hi, lo - 1, -d) if hi >= lo else range(0))
+    for oz in rng[0]:
+        for oy in rng[1]:
+            for ox in rng[2]:
+                o = (oz, oy, ox)
+                if any(v < 0 or v > out_shape[i] - 1 for i, v in enumerate(o)):
+                    continue
+                off, m = 0, 1
+                for j in (2, 1, 0):
+                    off += m * ((pos[j] - o[j] * s + p) // d)
+                    m *= k
+                res.append((o, off))
+    return res
+
+
+def spconv_v1_conv(feats, coors, shape, weight_kkkio, k=3, s=1, p=1, subm=False):
+    """Rule-book sparse convolution with spconv-v1 semantics.  feats [N,Cin], coors [N,3] (z,y,x), weight [k,k,k,Cin,Cout]
+    indexed by the kernel offset -> (out_feats [M,Cout], out_coors [M,3], out_shape)."""
+    feats = torch.as_tensor(feats).float()
+    coors = [tuple(int(v) for v in c) for c in np.asarray(coors)]
+    out_shape = list(shape) if subm else spconv_v1_out_shape(shape, k, s, p)
+    W = torch.as_tensor(weight_kkkio).float().reshape(k ** 3, weight_kkkio.shape[3], weight_kkkio.shape[4])
+    if subm:
+        grid = {c: j for j, c in enumerate(coors)}
+        out_coors = list(coors)
+    else:
+        grid, out_coors = {}, []
+    pairs = []
+    for j, c in enumerate(coors):
+        for o, off in spconv_v1_valid_out_pos(c, k, 1 if subm else s, p, out_shape):
+            if subm:
+                if o in grid:
+                    pairs.append((off, j, grid[o]))
+            else:
+                if o not in grid:
+                    grid[o] = len(out_coors)
+                    out_coors.append(o)
+                pairs.append((off, j, grid[o]))
+    out = torch.zeros(len(out_coors), W.shape[2])
+    for off, j, oi in pairs:
+        out[oi] += feats[j] @ W[off]
+    return out, np.asarray(out_coors, dtype=np.int64).reshape(-1, 3), out_shape

@@ -186,3 +186,39 @@ def test_voxelize_oracle_vs_golden(golden):
     assert vox.shape[0] == c["max_voxels"] and int(num.max()) == c["max_points"]
     m = ref_lidar.vfe_mean(vox, num, 4)
     assert m.shape == (vox.shape[0], 4) and torch.allclose(m[0], torch.from_numpy(vox[0, :num[0], :4]).mean(0))
+
+
+@pytest.mark.parametrize("shape,n", [((6, 9, 8), 40), ((5, 12, 7), 90), ((4, 4, 4), 3)])
+def test_sparse_conv_rules_match_vendored_spconv_v1_rulebook(shape, n):
+    """The LiDAR encoder's sparse convolutions are restated as MASKED DENSE convolutions (oracle/ref_lidar.py) because spconv
+    2.3.6 is absent.  mmdetection3d vendors spconv v1 (M/ops/spconv): its rule-book generation (geometry.h:25-86, :144-192,
+    :247-297; output size ops.py:20-31), restated in ref_lidar.spconv_v1_*, must give the same active sets and values as the
+    masked-dense form -- SubMConv3d(k3) and SparseConv3d(k3, s2, p1), the two layer types of sparse_lidar_enc.py."""
+    import torch.nn.functional as F
+    from oracle import ref_lidar as RL
+    g = np.random.default_rng(sum(shape) + n)
+    D, H, W = shape
+    lin = g.choice(D * H * W, size=min(n, D * H * W), replace=False)
+    coors = np.stack([lin // (H * W), (lin // W) % H, lin % W], 1)
+    Cin, Cout = 4, 6
+    feats = torch.from_numpy(g.standard_normal((len(lin), Cin)).astype(np.float32))
+    w2 = torch.from_numpy(g.standard_normal((Cout, 3, 3, 3, Cin)).astype(np.float32))      # spconv 2.x layout [Cout,kd,kh,kw,Cin]
+    w1 = w2.permute(1, 2, 3, 4, 0).contiguous()                                             # v1 layout [kd,kh,kw,Cin,Cout]
+    vol, mask = RL._to_dense(feats, torch.from_numpy(coors), shape)
+    wt = w2.permute(0, 4, 1, 2, 3).contiguous()
+    # SubMConv3d: outputs exactly at the active inputs
+    out, oc, osz = RL.spconv_v1_conv(feats, coors, shape, w1, subm=True)
+    dense = F.conv3d(vol, wt, padding=1) * mask
+    assert list(osz) == list(shape) and np.array_equal(oc, coors)
+    got = dense[0][:, coors[:, 0], coors[:, 1], coors[:, 2]].t()
+    assert torch.allclose(got, out, atol=1e-5)
+    # SparseConv3d(k3, s2, p1): an output is active iff its receptive field holds an active input
+    out, oc, osz = RL.spconv_v1_conv(feats, coors, shape, w1, k=3, s=2, p=1)
+    newmask = F.max_pool3d(mask.float(), 3, 2, 1) > 0
+    dense = F.conv3d(vol, wt, stride=2, padding=1)
+    assert list(osz) == list(dense.shape[2:])
+    act = newmask[0, 0].nonzero().numpy()
+    assert {tuple(c) for c in oc.tolist()} == {tuple(c) for c in act.tolist()}
+    got = dense[0][:, oc[:, 0], oc[:, 1], oc[:, 2]].t()
+    assert torch.allclose(got, out, atol=1e-5)
+    assert float((dense * ~newmask).abs().max()) == 0.0          # nothing outside the active set
