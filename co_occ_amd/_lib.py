@@ -22,7 +22,7 @@ class ConvDesc(ctypes.Structure):
                [(n, c_int) for n in ("M", "Cin", "Cout", "taps", "in_stride", "out_stride", "res_stride",
                                      "B", "Xi", "Yi", "Zi", "Xo", "Yo", "Zo", "ksize", "stride", "pad",
                                      "relu", "res_mode", "splitk", "tile_hint", "kx", "ky", "kz", "px", "py", "pz",
-                                     "wgroup_rows")]
+                                     "wgroup_rows", "mfma_dtype")]
 
 
 P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_int64

@@ -28,6 +28,10 @@ WINO_MIN_ROWS = int(__import__("os").environ.get("COOCC_WINO_MIN_ROWS", "8192"))
 CONV_PERSIST = __import__("os").environ.get("COOCC_CONV_PERSIST", "1") != "0"   # persistent short-K grouped GEMM (k_conv2p)
 ZTRIM = __import__("os").environ.get("COOCC_ZTRIM", "1") != "0"   # drop z taps that only see padding (Z = 1, 2 grids)
 WINO_TILE = int(__import__("os").environ.get("COOCC_WINO_TILE", "4"))   # F(4x4,3x3) where X, Y >= 8, else F(2x2,3x3)
+# "f32": exact-fp32 MFMA (the parity path, default).  "bf16": the geometric convolutions of C0-C3 round their operands to
+# bf16 in LDS and run v_mfma_f32_32x32x16_bf16 (fp32 accumulate / BN epilogue / storage; direct form, no Winograd): the
+# reduced-precision path of the OpenOccupancy config (configs[4]).  Set per process or assign core.CONV_DTYPE.
+CONV_DTYPE = __import__("os").environ.get("COOCC_CONV_DTYPE", "f32")
 
 
 def conv_kernel_name(M, Cout, table, hint=0, iters=1 << 30, one_by_one=False):
@@ -301,7 +305,8 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
         out = Rows(torch.empty(M, pc.Cout, device=x.t.device, dtype=_F32), x.B, Xo, Yo, Zo, pc.Cout)
     assert x.C == pc.Cin, "channel mismatch: %d vs %d" % (x.C, pc.Cin)
     rm = res_mode or (1 if res is not None else 0)
-    plan = wino_plan(x, pc, M, rm)
+    bf16 = CONV_DTYPE == "bf16"
+    plan = None if bf16 else wino_plan(x, pc, M, rm)
     if plan is not None:
         return conv_rows_wino(x, pc, out, relu, res, plan)
     ws = workspace(x.t.device)
@@ -319,6 +324,7 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
     d.ksize, d.stride, d.pad = pc.ksize, pc.stride, pc.pad
     d.relu, d.res_mode, d.splitk = int(relu), (res_mode or (1 if res is not None else 0)), splitk
     d.tile_hint = TILE_HINT
+    d.mfma_dtype = 1 if bf16 else 0
     taps = pc.taps
     if ZTRIM and pc._w_cube is not None:
         # z taps that are in range for at least one output z; on thin grids (Z = 1, 2) the rest only multiply padding
@@ -328,8 +334,9 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
             d.w = ptr(pc.ztrim_pack(lo, hi))
             d.kx, d.ky, d.kz, d.px, d.py, d.pz = 3, 3, hi - lo + 1, pc.pad, pc.pad, pc.pad - lo
             d.taps = taps = 9 * (hi - lo + 1)
-    with TIMER.region(conv_kernel_name(M, pc.Cout, False, 0, taps * -(-pc.Cin // 32), pc.ksize == 1 and pc.stride == 1 and pc.pad == 0),
-                      2.0 * M * pc.Cin * pc.Cout * taps):
+    kname = "k_conv_bf16" if bf16 else conv_kernel_name(M, pc.Cout, False, 0, taps * -(-pc.Cin // 32),
+                                                         pc.ksize == 1 and pc.stride == 1 and pc.pad == 0)
+    with TIMER.region(kname, 2.0 * M * pc.Cin * pc.Cout * taps):
         _lib.conv_fwd(d, pc.w.device)
     return out
 

@@ -225,6 +225,162 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_conv_bf16: the same implicit GEMM on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32-MFMA rate): operands
+// are rounded to bf16 (RNE) when they are staged into LDS, accumulation and the epilogue (folded BN, residual, ReLU) stay
+// fp32, activations stay fp32 in HBM.  This is the reduced-precision path of configs[4] (OpenOccupancy, "fp16"): NOT
+// bit-comparable with the fp32 reference -- its parity test states its tolerance from an fp64 anchor.  Geometric taps
+// only (3x3x3 / 1x1x1, stride 1 / 2), the fp32 fragment-major weight pack is read as is.  K step = 64 (two 32-channel
+// chunks of the pack: same channel slice, consecutive taps), 128 x 128 tile, 2 x 2 waves of 64 x 64, LDS rows of 64 bf16
+// padded to 144 B so that ds_read_b128 (8 bf16 per lane = one MFMA operand) is conflict-free.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define BF_KC 64
+#define BF_ST 72   // LDS row stride in bf16 (144 B)
+
+__device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
+  bf16x4 r;
+  r[0] = (__bf16)v[0]; r[1] = (__bf16)v[1]; r[2] = (__bf16)v[2]; r[3] = (__bf16)v[3];
+  return r;
+}
+
+__global__ __launch_bounds__(256, 2) void k_conv_bf16(ConvK p) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2, PA = BM / 32, PB = BN / 32;
+  __shared__ __bf16 As[2][BM * BF_ST];
+  __shared__ __bf16 Bs[2][BN * BF_ST];
+
+  const int id = blockIdx.x;
+  int mtile, nt, slot = id >> 3;
+  if (p.mtiles_per_xcd > 0) {
+    const int xcd = id & 7;
+    const int mt_local = slot / p.ntiles;
+    nt = slot - mt_local * p.ntiles;
+    mtile = xcd * p.mtiles_per_xcd + mt_local;
+    if (mt_local >= p.mtiles_per_xcd || mtile >= p.mtiles) return;
+  } else {
+    mtile = id / p.ntiles;
+    nt = id - mtile * p.ntiles;
+  }
+  const int m0 = mtile * BM, n0 = nt * BN;
+  const int tid = threadIdx.x;
+  const int piece = tid & 7, lrow = tid >> 3;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, h = lane >> 5;
+
+  int rbase[PA], rix[PA], riy[PA], riz[PA];
+#pragma unroll
+  for (int a = 0; a < PA; ++a) {
+    int m = m0 + lrow + 32 * a;
+    bool ok = m < p.M;
+    int oz = m % p.Zo; int r = m / p.Zo;
+    int oy = r % p.Yo; r /= p.Yo;
+    int ox = r % p.Xo; int b = r / p.Xo;
+    rbase[a] = ok ? b : -1;
+    rix[a] = ox * p.stride - p.px;
+    riy[a] = oy * p.stride - p.py;
+    riz[a] = oz * p.stride - p.pz;
+  }
+  // iterations of the fp32 pack are 32-channel chunks ordered (channel chunk, tap); one K step here = two of them
+  const int it0 = blockIdx.y * p.iters_per_split;
+  const int it1 = min(it0 + p.iters_per_split, p.total_iters);
+
+  f32x4 ra[2][PA], rb[2][PB];
+  auto gload = [&](int it2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int it = it2 + half;
+      const bool live = it < it1;
+      const int kc = it / p.taps, t = it - kc * p.taps;
+#pragma unroll
+      for (int b = 0; b < PB; ++b) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (live) v = *(const f32x4*)(p.w + wfrag_index((size_t)it, p.Npad >> 7, n0 + lrow + 32 * b, piece * 4));
+        rb[half][b] = v;
+      }
+      const int cc = kc * KC + piece * 4;
+      const bool cok = live && cc < p.Cin;
+      const int kw = t % p.kz; int r = t / p.kz;
+      const int kh = r % p.ky, kd = r / p.ky;
+#pragma unroll
+      for (int a = 0; a < PA; ++a) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int ix = rix[a] + kd, iy = riy[a] + kh, iz = riz[a] + kw;
+        bool ok = rbase[a] >= 0 && cok && (unsigned)ix < (unsigned)p.Xi && (unsigned)iy < (unsigned)p.Yi &&
+                  (unsigned)iz < (unsigned)p.Zi;
+        if (ok) {
+          size_t row = (((size_t)rbase[a] * p.Xi + ix) * p.Yi + iy) * p.Zi + iz;
+          v = *(const f32x4*)(p.in + row * p.in_stride + cc);
+        }
+        ra[half][a] = v;
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int a = 0; a < PA; ++a) *(bf16x4*)&As[buf][(lrow + 32 * a) * BF_ST + half * 32 + piece * 4] = to_bf16x4(ra[half][a]);
+#pragma unroll
+      for (int b = 0; b < PB; ++b) *(bf16x4*)&Bs[buf][(lrow + 32 * b) * BF_ST + half * 32 + piece * 4] = to_bf16x4(rb[half][b]);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (it0 < it1) {
+    gload(it0);
+    lstore(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int it = it0; it < it1; it += 2) {
+    const bool more = it + 2 < it1;
+    if (more) gload(it + 2);
+    const __bf16* Ab = &As[cur][(wm * 64 + li) * BF_ST + h * 8];
+    const __bf16* Bb = &Bs[cur][(wn * 64 + li) * BF_ST + h * 8];
+#pragma unroll
+    for (int s = 0; s < BF_KC / 16; ++s) {
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(Ab + i * 32 * BF_ST + s * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8*)(Bb + j * 32 * BF_ST + s * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r];
+        if (p.splitk > 1) {
+          p.ws[((size_t)blockIdx.y * p.M + m) * p.Npad + n] = v;
+        } else if (n < p.Cout) {
+          p.out[(size_t)m * p.out_stride + n] = epilogue(p, v, n, (size_t)m);
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_conv2: software-pipelined variant for the large geometric layers (Cout >= 128, M >= 8192).
 // Ablation of the phase-structured k_conv on MI355X (profiles/r1_conv_ablation.txt): MFMAs alone
 // 142 TFLOP/s, + fragment reads 139, + LDS stores and barrier 125, + global loads 108.  A lone wave
@@ -739,6 +895,23 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
 
   hipStream_t s = as_stream(stream);
   const bool table = d->gather != nullptr;
+  if (d->mfma_dtype == 1) {
+    COOCC_CHECK_ARG(!table && d->wgroup_rows == 0 && !d->out_rows, "conv_fwd: the bf16-MFMA path covers geometric convolutions only");
+    // K steps of two pack chunks: keep the split boundaries even
+    if (k.iters_per_split & 1) { k.iters_per_split += 1; k.splitk = (k.total_iters + k.iters_per_split - 1) / k.iters_per_split; }
+    COOCC_CHECK_ARG(k.splitk == 1 || (d->ws && (long long)k.splitk * d->M * k.Npad <= d->ws_floats), "conv_fwd: split-K workspace too small");
+    k.mtiles = (k.M + 127) / 128;
+    k.ntiles = (k.Cout + 127) / 128;
+    k.mtiles_per_xcd = k.mtiles >= 64 ? (k.mtiles + 7) / 8 : 0;
+    dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
+    hipLaunchKernelGGL(k_conv_bf16, grid, dim3(256), 0, s, k);
+    COOCC_LAUNCH_CHECK("k_conv_bf16");
+    if (k.splitk > 1) {
+      hipLaunchKernelGGL(k_conv_reduce, dim3(cdiv((long long)k.M * k.Cout, 256)), dim3(256), 0, s, k);
+      COOCC_LAUNCH_CHECK("k_conv_reduce");
+    }
+    return COOCC_OK;
+  }
   // software-pipelined kernel for the large geometric layers (COOCC_CONV_V2=0 switches it off)
   static const int v2mode = getenv("COOCC_CONV_V2") ? atoi(getenv("COOCC_CONV_V2")) : 1;
   const unsigned long long in_bytes = (unsigned long long)d->B * d->Xi * d->Yi * d->Zi * d->in_stride * 4ull;

@@ -421,7 +421,8 @@ __device__ __forceinline__ void pool_row(const float* __restrict__ x, const floa
 // n > POOL_MEDIUM: one workgroup per voxel
 template <bool LIFT>
 __device__ __forceinline__ void pool_long(const float* __restrict__ x, const float* __restrict__ depth, uint32_t* __restrict__ seg,
-                                          int n, int C, int D, int HW, float* __restrict__ orow, uint32_t* __restrict__ sid) {
+                                          int n, int C, int D, int HW, float* __restrict__ orow, uint32_t* __restrict__ sid,
+                                          float* __restrict__ sdp) {
   const int tid = threadIdx.x;
   if (n <= POOL_LONG_CAP) {
     int np2 = 512;
@@ -440,6 +441,15 @@ __device__ __forceinline__ void pool_long(const float* __restrict__ x, const flo
         }
         __syncthreads();
       }
+    // decode once (two integer divisions per point), not once per point and channel thread
+    for (int i = tid; i < n; i += 256) {
+      const uint32_t id = sid[i];
+      if (LIFT) {
+        sdp[i] = depth[id];
+        sid[i] = (id / (uint32_t)(D * HW)) * (uint32_t)HW + id % (uint32_t)HW;
+      }
+    }
+    __syncthreads();
     for (int c = tid; c < C; c += 256) {
       float acc = 0.f;
       for (int j0 = 0; j0 < n; j0 += POOL_BATCH) {
@@ -447,10 +457,9 @@ __device__ __forceinline__ void pool_long(const float* __restrict__ x, const flo
 #pragma unroll
         for (int j = 0; j < POOL_BATCH; ++j) {
 #pragma clang fp contract(off)
-          const uint32_t id = sid[min(j0 + j, n - 1)];
-          const uint32_t row = LIFT ? (id / (uint32_t)(D * HW)) * (uint32_t)HW + id % (uint32_t)HW : id;
-          float val = x[(size_t)row * C + c];
-          if (LIFT) val = depth[id] * val;
+          const int jj = min(j0 + j, n - 1);
+          float val = x[(size_t)sid[jj] * C + c];
+          if (LIFT) val = sdp[jj] * val;
           r[j] = val;
         }
 #pragma unroll
@@ -502,12 +511,13 @@ __global__ __launch_bounds__(256) void k_pool_sum_csr(const float* __restrict__ 
                                                        const int32_t* __restrict__ nlong_p, int long_blocks, int nvox, int C,
                                                        int D, int HW, float* __restrict__ out, int out_stride) {
   __shared__ uint32_t sid[POOL_LONG_CAP];
+  __shared__ float sdp[LIFT ? POOL_LONG_CAP : 1];
   if ((int)blockIdx.x < long_blocks) {
     const int nlong = *nlong_p;
     for (int li = blockIdx.x; li < nlong; li += long_blocks) {
       const int v = long_list[li];
       const int s = start[v];
-      pool_long<LIFT>(x, depth, ids + s, start[v + 1] - s, C, D, HW, out + (size_t)v * out_stride, sid);
+      pool_long<LIFT>(x, depth, ids + s, start[v + 1] - s, C, D, HW, out + (size_t)v * out_stride, sid, sdp);
     }
     return;
   }

@@ -165,6 +165,9 @@ typedef struct coocc_conv_desc {
   int wgroup_rows;        /* > 0: output rows [g*wgroup_rows, (g+1)*wgroup_rows) use the g-th weight pack of `w`
                              (consecutive packs of taps*ceil(Cin/32)*roundup(Cout,128)*32 floats); must be a
                              multiple of 640.  Used by the Winograd path: one launch, 16 transform points. */
+  int mfma_dtype;         /* 0: fp32 operands (v_mfma_f32_32x32x2_f32, exact fp32 -- the parity path);
+                             1: operands rounded to bf16 in LDS (v_mfma_f32_32x32x16_bf16), fp32 accumulate / epilogue /
+                                storage: the reduced-precision path of the OpenOccupancy config; geometric taps only */
 } coocc_conv_desc;
 
 /* nn.Conv3d(k=3|1)+BN(eval)+ReLU(+residual) (bifuser_n.py:23-30, resnet3d.py:34-64,

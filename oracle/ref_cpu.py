@@ -29,6 +29,15 @@ import torch.nn.functional as F
 from . import native
 
 BN_EPS = 1e-5
+# None: exact arithmetic in the dtype of the inputs.  torch.bfloat16: every Conv3d of C0-C3 rounds BOTH operands to bf16
+# first (fp32 accumulate and epilogue): the emulation of the product's reduced-precision MFMA path (configs[4]).
+CONV_OPERAND_DTYPE = None
+
+
+def _conv3d(x, w, bias=None, **kw):
+    if CONV_OPERAND_DTYPE is not None:
+        x, w = x.to(CONV_OPERAND_DTYPE).to(x.dtype), w.to(CONV_OPERAND_DTYPE).to(w.dtype)
+    return F.conv3d(x, w, bias, **kw)
 
 
 # --------------------------------------------------------------------------- helpers
@@ -143,8 +152,8 @@ def bifuser_fuse(sd, img_voxel_feats, pts_voxel_feats, knum):
 def con_enc(sd, all_feats_cl):
     """C0: ``con_enc`` (bifuser_n.py:23-30,172-173). in [B,X,Y,Z,4C] -> [B,C,X,Y,Z]."""
     x = all_feats_cl.permute(0, 4, 1, 2, 3)
-    x = F.relu(_bn(F.conv3d(x, sd["con_enc.0.weight"], padding=1), sd, "con_enc.1"))
-    x = F.relu(_bn(F.conv3d(x, sd["con_enc.3.weight"], padding=1), sd, "con_enc.4"))
+    x = F.relu(_bn(_conv3d(x, sd["con_enc.0.weight"], padding=1), sd, "con_enc.1"))
+    x = F.relu(_bn(_conv3d(x, sd["con_enc.3.weight"], padding=1), sd, "con_enc.4"))
     return x
 
 
@@ -159,16 +168,16 @@ RESNET_LAYERS = {10: [1, 1, 1, 1], 18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
 def resnet3d_forward(sd, x, depth=18, block_strides=(1, 2, 2, 2), out_indices=(0, 1, 2, 3)):
     """C1: ``CustomResNet3D.forward`` (P/coocc/backbones/resnet3d.py:196-205) with
     ``BasicBlock`` (:34-64) and shortcut type B (:181-184)."""
-    x = F.relu(_bn(F.conv3d(x, sd["input_proj.0.weight"]), sd, "input_proj.1"))
+    x = F.relu(_bn(_conv3d(x, sd["input_proj.0.weight"]), sd, "input_proj.1"))
     res = []
     for s, nblocks in enumerate(RESNET_LAYERS[depth]):
         for b in range(nblocks):
             p = "layers.%d.%d." % (s, b)
             stride = block_strides[s] if b == 0 else 1
-            out = F.relu(_bn(F.conv3d(x, sd[p + "conv1.weight"], stride=stride, padding=1), sd, p + "bn1"))
-            out = _bn(F.conv3d(out, sd[p + "conv2.weight"], padding=1), sd, p + "bn2")
+            out = F.relu(_bn(_conv3d(x, sd[p + "conv1.weight"], stride=stride, padding=1), sd, p + "bn1"))
+            out = _bn(_conv3d(out, sd[p + "conv2.weight"], padding=1), sd, p + "bn2")
             if (p + "downsample.0.weight") in sd:
-                x = _bn(F.conv3d(x, sd[p + "downsample.0.weight"], stride=stride), sd, p + "downsample.1")
+                x = _bn(_conv3d(x, sd[p + "downsample.0.weight"], stride=stride), sd, p + "downsample.1")
             x = F.relu(out + x)
         if s in out_indices:
             res.append(x)
@@ -177,24 +186,24 @@ def resnet3d_forward(sd, x, depth=18, block_strides=(1, 2, 2, 2), out_indices=(0
 
 def fpn3d_forward(sd, inputs):
     """C2: ``FPN3D.forward`` (P/coocc/necks/fpn3d.py:70-108), BN-family norm."""
-    lat = [F.relu(_bn(F.conv3d(x, sd["lateral_convs.%d.0.conv.weight" % i]), sd, "lateral_convs.%d.0.bn" % i))
+    lat = [F.relu(_bn(_conv3d(x, sd["lateral_convs.%d.0.conv.weight" % i]), sd, "lateral_convs.%d.0.bn" % i))
            for i, x in enumerate(inputs)]
     for i in range(len(lat) - 1, 0, -1):
         lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="trilinear",
                                                 align_corners=False)
-    return [F.relu(_bn(F.conv3d(x, sd["fpn_convs.%d.0.conv.weight" % i], padding=1), sd, "fpn_convs.%d.0.bn" % i))
+    return [F.relu(_bn(_conv3d(x, sd["fpn_convs.%d.0.conv.weight" % i], padding=1), sd, "fpn_convs.%d.0.bn" % i))
             for i, x in enumerate(lat)]
 
 
 def _seq_1x1(sd, x, name):
     """conv1x1 -> BN -> ReLU -> conv1x1 (occ_pred_conv / voxel_soft_weights, occ_head.py:113-132)."""
-    x = F.relu(_bn(F.conv3d(x, sd[name + ".0.weight"], sd.get(name + ".0.bias")), sd, name + ".1"))
-    return F.conv3d(x, sd[name + ".3.weight"], sd.get(name + ".3.bias"))
+    x = F.relu(_bn(_conv3d(x, sd[name + ".0.weight"], sd.get(name + ".0.bias")), sd, name + ".1"))
+    return _conv3d(x, sd[name + ".3.weight"], sd.get(name + ".3.bias"))
 
 
 def occhead_coarse(sd, voxel_feats, soft_weights=True):
     """C3: ``OccHead.forward_coarse_voxel`` (P/coocc/dense_heads/occ_head.py:149-171)."""
-    occs = [F.relu(_bn(F.conv3d(x, sd["occ_convs.%d.0.weight" % i], sd.get("occ_convs.%d.0.bias" % i), padding=1),
+    occs = [F.relu(_bn(_conv3d(x, sd["occ_convs.%d.0.weight" % i], sd.get("occ_convs.%d.0.bias" % i), padding=1),
                        sd, "occ_convs.%d.1" % i)) for i, x in enumerate(voxel_feats)]
     n = len(occs)
     if soft_weights:

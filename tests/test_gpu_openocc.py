@@ -1,0 +1,122 @@
+"""configs[4]: the OpenOccupancy grid (coocc_multi_r101_openoccupancy.py: fused grid 128x128x10, occupancy 512x512x40,
+cascade 4) and the reduced-precision convolution path (bf16 MFMA operands, fp32 accumulate / epilogue / storage).
+
+* the bf16 kernel against torch's conv on bf16-ROUNDED operands (fp32 arithmetic): same rounding rule, so only the
+  accumulation order differs -> tight tolerance; this is what pins the kernel itself;
+* the whole C0-C3 decoder at the full 128x128x10 size in fp32 (default dispatch) against the oracle, and in bf16 against the
+  oracle run in the same operand precision (ref_cpu.CONV_OPERAND_DTYPE) -- with the distance of all of them from an fp64
+  evaluation reported, which is where the bf16 tolerance comes from."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import co_occ_amd as pkg
+import co_occ_amd.synth as synth
+from co_occ_amd import core
+from oracle import ref_cpu
+from test_gpu_conv import CASES, bn_like, rows_of
+from util import assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("Cin,Cout,grid,k,stride,relu,use_res,splitk", CASES + [(512, 256, (24, 20, 8), 3, 1, True, False, 0),
+                                                                             (128, 128, (50, 50, 8), 3, 1, True, True, 0)])
+def test_conv_bf16_mfma_equals_conv_on_bf16_rounded_operands(dev, monkeypatch, Cin, Cout, grid, k, stride, relu, use_res, splitk):
+    """k_conv_bf16: operands rounded to bf16 (RNE) in LDS, fp32 accumulation, fp32 BN / residual / ReLU epilogue."""
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout + 1)
+    X, Y, Z = grid
+    B = 2 if X < 20 else 1
+    x = torch.randn(B, Cin, X, Y, Z, generator=g)
+    w = torch.randn(Cout, Cin, k, k, k, generator=g) * (2.0 / (Cin * k ** 3)) ** 0.5
+    bn = bn_like(Cout, g)
+    pad = k // 2
+    ref = bn(F.conv3d(_bf(x), _bf(w), stride=stride, padding=pad))
+    exact = bn(F.conv3d(x, w, stride=stride, padding=pad))
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref, exact = ref + res, exact + res
+    if relu:
+        ref, exact = F.relu(ref), F.relu(exact)
+    pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=k, stride=stride, pad=pad)
+    monkeypatch.setattr(core, "CONV_DTYPE", "bf16")
+    out = core.conv_rows(rows_of(x, dev), pc, relu=relu, res=rows_of(res, dev) if use_res else None, splitk=splitk)
+    got = out.as_ncdhw().cpu()
+    assert_close(got, ref.detach(), tol=2e-5, what="bf16-MFMA conv vs bf16-rounded operands")
+    # and it IS a reduced-precision result: ~2^-9 relative per operand
+    e = rel_err(got, exact.detach())
+    assert 1e-5 < e < 2e-2, e
+
+
+def _trunk(dev, grid, seed):
+    cfg = synth.model_cfg_openocc()
+    model = pkg.build_detector(cfg)
+    sd = synth.random_state_dict(model.state_dict(), seed=seed)
+    model.load_state_dict(sd)
+    X, Y, Z = grid
+    g = synth._rng(seed, "cat4")
+    cat4 = torch.from_numpy(g.standard_normal((1, 512, X, Y, Z), dtype=np.float32))
+    cat4 *= torch.from_numpy((g.random((1, 1, X, Y, Z)) < 0.7).astype(np.float32))
+    return model.to(dev).eval(), sd, cat4
+
+
+def _hip_trunk(model, cat4, dev):
+    from co_occ_amd.core import conv_rows, to_rows
+    f = model.occ_fuser
+    p = f._packed()
+    with torch.no_grad():
+        x = conv_rows(to_rows(cat4.to(dev)), p["c0"], relu=True)
+        vf = conv_rows(x, p["c3"], relu=True)
+        sem = model.semantic_neck.forward_rows(model.semantic_encoder.forward_rows(vf))
+        ovf, occ = model.pts_bbox_head.forward_coarse_rows(sem)
+    return vf.as_ncdhw().cpu(), occ.as_ncdhw().cpu()
+
+
+def _oracle_trunk(sd, cat4, dtype=None):
+    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    x = cat4
+    if dtype is not None:
+        sd, x = ref_cpu.to_dtype(dict(sd), dtype), cat4.to(dtype)
+        sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    vf = ref_cpu.con_enc(sub("occ_fuser."), x.permute(0, 2, 3, 4, 1))
+    sem = ref_cpu.fpn3d_forward(sub("semantic_neck."), ref_cpu.resnet3d_forward(sub("semantic_encoder."), vf))
+    return vf, ref_cpu.occhead_coarse(sub("pts_bbox_head."), sem)["occ"]
+
+
+def test_openocc_decoder_fp32_and_bf16_at_full_size(dev, monkeypatch):
+    """C0-C3 on the OpenOccupancy fused grid (128 x 128 x 10 x 512 -> 17 classes; 3.56 TFLOP of convolutions).
+    fp32 (default dispatch: Winograd F(2x2)/F(4x4) + persistent GEMMs at this size): within 1e-4 of the oracle / the fp64 anchor.
+    bf16 operands: equal to the oracle evaluated with bf16-rounded conv operands up to re-rounding flips (2e-3 of the tensor
+    scale), and its distance from the fp64 anchor is reported next to the fp32 paths' -- that distance (~1e-2) IS the price of
+    the reduced precision, the parity claim is against the same-precision oracle."""
+    import os
+    grid = synth.CONFIGS["openocc"]["grid"]
+    model, sd, cat4 = _trunk(dev, grid, seed=9)
+    o32 = _oracle_trunk(sd, cat4)
+    o64 = _oracle_trunk(sd, cat4, torch.float64)
+    monkeypatch.setattr(ref_cpu, "CONV_OPERAND_DTYPE", torch.bfloat16)
+    obf = _oracle_trunk(sd, cat4)
+    monkeypatch.setattr(ref_cpu, "CONV_OPERAND_DTYPE", None)
+    h32 = _hip_trunk(model, cat4, dev)
+    monkeypatch.setattr(core, "CONV_DTYPE", "bf16")
+    hbf = _hip_trunk(model, cat4, dev)
+    lines = []
+    for name, i in (("voxel_feats", 0), ("coarse logits", 1)):
+        scale = max(1.0, float(o64[i].abs().max()))
+        e = lambda a, b: float((a.double() - b.double()).abs().max()) / scale
+        lines.append("openocc 128x128x10 %-13s |x| %.1f  hip32-fp64 %.2e  oracle32-fp64 %.2e  hip32-oracle32 %.2e | hipbf16-oraclebf16 %.2e  "
+                     "hipbf16-fp64 %.2e  oraclebf16-fp64 %.2e" % (name, scale, e(h32[i], o64[i]), e(o32[i], o64[i]), e(h32[i], o32[i]),
+                                                                  e(hbf[i], obf[i]), e(hbf[i], o64[i]), e(obf[i], o64[i])))
+        assert e(h32[i], o64[i]) <= 1e-4 and e(h32[i], o32[i]) <= 1e-4 + e(o32[i], o64[i]), lines[-1]
+        assert e(hbf[i], obf[i]) <= 2e-3, lines[-1]
+        assert e(hbf[i], o64[i]) <= 2.0 * e(obf[i], o64[i]) + 1e-4, lines[-1]
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "r2_openocc_parity.txt"), "a") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
