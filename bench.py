@@ -32,6 +32,7 @@ import co_occ_amd.synth as synth  # noqa: E402
 from co_occ_amd import core  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, fp32-input MFMA (spec)
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA (spec; 2:1-sparse figures are not used)
 HBM_PEAK_GBS = 8000.0          # HBM3E spec
 TRAFFIC_FILE = "r1_traffic.json"
 
@@ -272,6 +273,9 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs set aside for the FPS chains (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL on GPUs)")
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (single-GPU check of the N > 1 path, gloo)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32: exact-fp32 MFMA (the parity path).  bf16: C0-C3 run k_conv_bf16 (operands rounded to bf16, fp32 "
+                         "accumulate / epilogue / storage, direct form) -- the reduced-precision path of configs[4]")
     ap.add_argument("--no-pool", action="store_true",
                     help="start the step from an already-pooled camera volume (round-1 definition) instead of the lifted "
                          "depth/context pair (SURVEY.md 8d: 'lifted features + sweep volume -> logits')")
@@ -305,6 +309,7 @@ def main():
     torch.cuda.set_device(dev)
     WITH_POOL[0] = not args.no_pool
     CFGNAME[0] = args.config
+    core.CONV_DTYPE = args.dtype
     model, sd = build_model(args.config, dev)
     samples = [make_inputs(args.config, 1234 + 17 * rank + i, dev, model) for i in range(2)]
     if args.reserve_cus > 0:
@@ -439,18 +444,24 @@ def main():
             equiv = v["equiv"] / v["work"]
             symbol = {"k_conv2<160,wg> wino": "k_conv2<160, 2, true, 2, false>", "k_conv2p wino": "k_conv2p<true, false>",
                       "k_conv2<128,wg> wino": "k_conv2<128, 1, true, 3, false>"}.get(dom, dom)     # name in the rocprofv3 trace
-            roof = dict(bound="mfma", kernel=dom, symbol=symbol, achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=traffic,
+            peak = MFMA_BF16_PEAK_TFLOPS if dom.startswith("k_conv_bf16") else MFMA_F32_PEAK_TFLOPS
+            roof = dict(bound="mfma", kernel=dom, symbol=symbol, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                        frac=round(ach / peak, 4), traffic=traffic,
                         traffic_source=("profiles/%s (rocprofv3 --pmc passes of this command, replayed: HBM counters cannot be "
                                         "collected in-process)" % TRAFFIC_FILE) if traffic is not None else None,
                         launches=v["launches"],
                         avg_launch_ms=round(v["ms"] / v["launches"], 4),
                         share_of_timed_kernels=round(v["ms"] / tot, 3),
                         flops="executed on the MFMA pipe (direct-conv-equivalent x%.2f = %.1f TFLOP/s)" % (equiv, ach * equiv))
-            allc = sum(v2["work"] for v2 in convs.values()) / (sum(v2["ms"] for v2 in convs.values()) * 1e-3) / 1e12
-            extra["roofline_all_convs"] = dict(bound="mfma", kernel="every k_conv* launch", achieved=round(allc, 2),
-                                               peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(allc / MFMA_F32_PEAK_TFLOPS, 4),
-                                               ms_per_step=round(sum(v2["ms"] for v2 in convs.values()) / args.steps, 3))
+            for tag, sel, pk in (("roofline_all_convs", lambda k: not k.startswith("k_conv_bf16"), MFMA_F32_PEAK_TFLOPS),
+                                 ("roofline_bf16_convs", lambda k: k.startswith("k_conv_bf16"), MFMA_BF16_PEAK_TFLOPS)):
+                grp = [v2 for k2, v2 in convs.items() if sel(k2)]
+                if not grp:
+                    continue
+                allc = sum(v2["work"] for v2 in grp) / (sum(v2["ms"] for v2 in grp) * 1e-3) / 1e12
+                extra[tag] = dict(bound="mfma", kernel="every fp32-MFMA k_conv* launch" if pk == MFMA_F32_PEAK_TFLOPS else "every k_conv_bf16 launch",
+                                  achieved=round(allc, 2), peak=pk, unit="TFLOP/s", frac=round(allc / pk, 4),
+                                  ms_per_step=round(sum(v2["ms"] for v2 in grp) / args.steps, 3))
         if "k_lift_splat" in ksum:
             v = ksum["k_lift_splat"]
             ach = v["work"] / (v["ms"] * 1e-3) / 1e9
@@ -479,7 +490,7 @@ def main():
                 unit="samples/s", n_gpus=world, world_size_seen_by_backend=seen_world, backend=backend_name, steps=args.steps,
                 warmup=args.warmup,
                 ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
-                dtype="f32", data="synthetic",
+                dtype=args.dtype, data="synthetic",
                 config=dict(workload="coocc_multi_r50_256x704 hot path" if args.config == "r50" else args.config,
                             fused_grid="x".join(map(str, c["grid"])) + "x%d" % c["C"],
                             occupancy_grid="x".join(str(v) for v in c.get("final_occ_size", [2 * g for g in c["grid"]])), cams=c["ncam"],
@@ -490,7 +501,7 @@ def main():
                                               else "pooled camera volume")),
                 roofline=roof)
     line.update(extra)
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.config != "openocc":   # cascade 4: ~10 M fine points, hours on the CPU
         line["cpu_baseline"] = cpu_baseline(sd, samples[0], args.config, WITH_POOL[0])
     if rank == 0:
         print(json.dumps(line))
