@@ -450,12 +450,15 @@ __device__ __forceinline__ void pool_long(const float* __restrict__ x, const flo
       }
     }
     __syncthreads();
+    // the serial chain of the longest voxel (2614 points at r101) bounds the whole launch: 64 row loads in flight per batch
+    // (one memory latency per 64 points instead of per 16), then the 64 dependent adds
+    constexpr int LB = 64;
     for (int c = tid; c < C; c += 256) {
       float acc = 0.f;
-      for (int j0 = 0; j0 < n; j0 += POOL_BATCH) {
-        float r[POOL_BATCH];
+      for (int j0 = 0; j0 < n; j0 += LB) {
+        float r[LB];
 #pragma unroll
-        for (int j = 0; j < POOL_BATCH; ++j) {
+        for (int j = 0; j < LB; ++j) {
 #pragma clang fp contract(off)
           const int jj = min(j0 + j, n - 1);
           float val = x[(size_t)sid[jj] * C + c];
@@ -463,7 +466,7 @@ __device__ __forceinline__ void pool_long(const float* __restrict__ x, const flo
           r[j] = val;
         }
 #pragma unroll
-        for (int j = 0; j < POOL_BATCH; ++j)
+        for (int j = 0; j < LB; ++j)
           if (j0 + j < n) acc = acc + r[j];
       }
       orow[c] = acc;
