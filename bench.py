@@ -34,7 +34,7 @@ from co_occ_amd import core  # noqa: E402
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, fp32-input MFMA (spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA (spec; 2:1-sparse figures are not used)
 HBM_PEAK_GBS = 8000.0          # HBM3E spec
-TRAFFIC_FILE = "r1_traffic.json"
+TRAFFIC_FILE = "r2_traffic.json"
 
 
 def make_inputs(cfgname, seed, dev, model):
@@ -230,6 +230,86 @@ def cpu_baseline(sd, s, cfgname, with_pool, runs=3):
                 all_runs_seconds=[round(r["total"], 3) for r in runs_])
 
 
+def rooflines(ksum, nsteps, args, rank, table):
+    """roofline objects from a KernelTimer summary: dominant conv instantiation (largest summed HIP-event time), every
+    conv launch together (per MFMA dtype), the pooling call, the render pair."""
+    roof = None
+    extra = {}
+    if ksum:
+        tot = sum(v["ms"] for v in ksum.values())
+        if table and rank == 0:
+            for k, v in sorted(ksum.items(), key=lambda kv: -kv[1]["ms"]):
+                unit = v["work"] / (v["ms"] * 1e-3) if v["ms"] else 0
+                print("%-34s launches %5d  total %9.3f ms  avg %8.3f ms  %6.1f%%  work/s %.4g" % (
+                    k, v["launches"], v["ms"], v["ms"] / v["launches"], 100 * v["ms"] / tot, unit), file=sys.stderr)
+        # one entry per kernel symbol: the Winograd-domain launches of either tile size are the same instantiation
+        # (k_conv2<BM,PF,0,true>); keep their direct-convolution-equivalent flops alongside the executed ones
+        convs = {}
+        for k, v in ksum.items():
+            if not k.startswith("k_conv"):
+                continue
+            sym = k.split(" wino")[0] + (",wg> wino" if " wino" in k else "")
+            sym = sym.replace(">,wg>", ",wg>").replace("k_conv2p,wg>", "k_conv2p")
+            c_ = convs.setdefault(sym, dict(launches=0, ms=0.0, work=0.0, equiv=0.0))
+            c_["launches"] += v["launches"]; c_["ms"] += v["ms"]; c_["work"] += v["work"]
+            c_["equiv"] += v["work"] * {"wino2": 2.25, "wino4": 4.0}.get(k.split()[-1], 1.0)
+        dom = max(convs, key=lambda k: convs[k]["ms"]) if convs else None
+        if dom:
+            v = convs[dom]
+            ach = v["work"] / (v["ms"] * 1e-3) / 1e12      # flops the matrix cores execute (Winograd-domain for "wino")
+            traffic = None
+            try:   # HBM bytes per launch from the committed PMC passes (cannot be collected inside this process)
+                tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+                traffic = tj[dom]["bytes_per_launch"] if args.config == "r50" else None
+            except Exception:
+                pass
+            # direct-convolution-equivalent rate of the same launches: F(m x m,3x3) needs 9 m^2/(m+2)^2 x fewer multiplies
+            equiv = v["equiv"] / v["work"]
+            symbol = {"k_conv2<160,wg> wino": "k_conv2<160, 2, true, 2, false>", "k_conv2p wino": "k_conv2p<true, false>",
+                      "k_conv2<128,wg> wino": "k_conv2<128, 1, true, 3, false>"}.get(dom, dom)     # name in the rocprofv3 trace
+            peak = MFMA_BF16_PEAK_TFLOPS if dom.startswith("k_conv_bf16") else MFMA_F32_PEAK_TFLOPS
+            roof = dict(bound="mfma", kernel=dom, symbol=symbol, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                        frac=round(ach / peak, 4), traffic=traffic,
+                        traffic_source=("profiles/%s (rocprofv3 --pmc passes of this command, replayed: HBM counters cannot be "
+                                        "collected in-process)" % TRAFFIC_FILE) if traffic is not None else None,
+                        launches=v["launches"],
+                        avg_launch_ms=round(v["ms"] / v["launches"], 4),
+                        share_of_timed_kernels=round(v["ms"] / tot, 3),
+                        flops="executed on the MFMA pipe (direct-conv-equivalent x%.2f = %.1f TFLOP/s)" % (equiv, ach * equiv))
+            for tag, sel, pk in (("roofline_all_convs", lambda k: not k.startswith("k_conv_bf16"), MFMA_F32_PEAK_TFLOPS),
+                                 ("roofline_bf16_convs", lambda k: k.startswith("k_conv_bf16"), MFMA_BF16_PEAK_TFLOPS)):
+                grp = [v2 for k2, v2 in convs.items() if sel(k2)]
+                if not grp:
+                    continue
+                allc = sum(v2["work"] for v2 in grp) / (sum(v2["ms"] for v2 in grp) * 1e-3) / 1e12
+                extra[tag] = dict(bound="mfma", kernel="every fp32-MFMA k_conv* launch" if pk == MFMA_F32_PEAK_TFLOPS else "every k_conv_bf16 launch",
+                                  achieved=round(allc, 2), peak=pk, unit="TFLOP/s", frac=round(allc / pk, 4),
+                                  ms_per_step=round(sum(v2["ms"] for v2 in grp) / nsteps, 3))
+        if "k_lift_splat" in ksum:
+            v = ksum["k_lift_splat"]
+            ach = v["work"] / (v["ms"] * 1e-3) / 1e9
+            extra["roofline_pool"] = dict(bound="hbm", kernel="coocc_lift_splat_cams (keys + binning + per-voxel sums)",
+                                          achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                                          traffic=None, algorithmic_bytes=int(v["work"] / v["launches"]),
+                                          avg_ms_per_step=round(v["ms"] / v["launches"], 4),
+                                          note="fused Lift (x) Splat, in the timed step (on the prefetch stream)")
+        rk = [ksum[k] for k in ("k_render_nearest+k_upsample_maps",) if k in ksum]
+        if rk:
+            ms = sum(v["ms"] for v in rk)
+            by = sum(v["work"] for v in rk)
+            ach = by / (ms * 1e-3) / 1e9
+            rtraffic = None
+            try:
+                rtraffic = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))["k_render_nearest+k_upsample_maps"][args.config]["bytes_per_launch"]
+            except Exception:
+                pass
+            extra["roofline_render"] = dict(bound="hbm", kernel="k_render_nearest+k_upsample_maps", achieved=round(ach, 1),
+                                            peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=rtraffic,
+                                            avg_ms_per_step=round(ms / max(1, rk[0]["launches"]), 4))
+
+    return roof, extra
+
+
 def render_r101_roofline(model, dev, iters=20):
     """The HBM-bound render pair at configs[2]'s size (6 x 56 x 100 rays x 112 samples -> 6 x 896 x 1600 maps, 184.1 MB
     algorithmic), timed with HIP events AFTER the timed region on random fused features: north_star's ">= 40 % of the HBM
@@ -265,7 +345,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="r50", choices=sorted(synth.CONFIGS))
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="dense stages in flight: S host threads / HIP streams, sample i on stream i mod S (S = 2 runs one "
                          "sample's low-occupancy tail under the other's large GEMMs)")
     ap.add_argument("--prefetch", type=int, default=1,
@@ -409,81 +489,24 @@ def main():
     dt = cdist.max_over_ranks(dt, dev)
 
     c = synth.CONFIGS[args.config]
-    ksum = core.TIMER.summary()
-    roof = None
-    extra = {}
-    if ksum:
-        tot = sum(v["ms"] for v in ksum.values())
-        if args.kernel_table and rank == 0:
-            for k, v in sorted(ksum.items(), key=lambda kv: -kv[1]["ms"]):
-                unit = v["work"] / (v["ms"] * 1e-3) if v["ms"] else 0
-                print("%-34s launches %5d  total %9.3f ms  avg %8.3f ms  %6.1f%%  work/s %.4g" % (
-                    k, v["launches"], v["ms"], v["ms"] / v["launches"], 100 * v["ms"] / tot, unit), file=sys.stderr)
-        # one entry per kernel symbol: the Winograd-domain launches of either tile size are the same instantiation
-        # (k_conv2<BM,PF,0,true>); keep their direct-convolution-equivalent flops alongside the executed ones
-        convs = {}
-        for k, v in ksum.items():
-            if not k.startswith("k_conv"):
-                continue
-            sym = k.split(" wino")[0] + (",wg> wino" if " wino" in k else "")
-            sym = sym.replace(">,wg>", ",wg>").replace("k_conv2p,wg>", "k_conv2p")
-            c_ = convs.setdefault(sym, dict(launches=0, ms=0.0, work=0.0, equiv=0.0))
-            c_["launches"] += v["launches"]; c_["ms"] += v["ms"]; c_["work"] += v["work"]
-            c_["equiv"] += v["work"] * {"wino2": 2.25, "wino4": 4.0}.get(k.split()[-1], 1.0)
-        dom = max(convs, key=lambda k: convs[k]["ms"]) if convs else None
-        if dom:
-            v = convs[dom]
-            ach = v["work"] / (v["ms"] * 1e-3) / 1e12      # flops the matrix cores execute (Winograd-domain for "wino")
-            traffic = None
-            try:   # HBM bytes per launch from the committed PMC passes (cannot be collected inside this process)
-                tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
-                traffic = tj[dom]["bytes_per_launch"] if args.config == "r50" else None
-            except Exception:
-                pass
-            # direct-convolution-equivalent rate of the same launches: F(m x m,3x3) needs 9 m^2/(m+2)^2 x fewer multiplies
-            equiv = v["equiv"] / v["work"]
-            symbol = {"k_conv2<160,wg> wino": "k_conv2<160, 2, true, 2, false>", "k_conv2p wino": "k_conv2p<true, false>",
-                      "k_conv2<128,wg> wino": "k_conv2<128, 1, true, 3, false>"}.get(dom, dom)     # name in the rocprofv3 trace
-            peak = MFMA_BF16_PEAK_TFLOPS if dom.startswith("k_conv_bf16") else MFMA_F32_PEAK_TFLOPS
-            roof = dict(bound="mfma", kernel=dom, symbol=symbol, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
-                        frac=round(ach / peak, 4), traffic=traffic,
-                        traffic_source=("profiles/%s (rocprofv3 --pmc passes of this command, replayed: HBM counters cannot be "
-                                        "collected in-process)" % TRAFFIC_FILE) if traffic is not None else None,
-                        launches=v["launches"],
-                        avg_launch_ms=round(v["ms"] / v["launches"], 4),
-                        share_of_timed_kernels=round(v["ms"] / tot, 3),
-                        flops="executed on the MFMA pipe (direct-conv-equivalent x%.2f = %.1f TFLOP/s)" % (equiv, ach * equiv))
-            for tag, sel, pk in (("roofline_all_convs", lambda k: not k.startswith("k_conv_bf16"), MFMA_F32_PEAK_TFLOPS),
-                                 ("roofline_bf16_convs", lambda k: k.startswith("k_conv_bf16"), MFMA_BF16_PEAK_TFLOPS)):
-                grp = [v2 for k2, v2 in convs.items() if sel(k2)]
-                if not grp:
-                    continue
-                allc = sum(v2["work"] for v2 in grp) / (sum(v2["ms"] for v2 in grp) * 1e-3) / 1e12
-                extra[tag] = dict(bound="mfma", kernel="every fp32-MFMA k_conv* launch" if pk == MFMA_F32_PEAK_TFLOPS else "every k_conv_bf16 launch",
-                                  achieved=round(allc, 2), peak=pk, unit="TFLOP/s", frac=round(allc / pk, 4),
-                                  ms_per_step=round(sum(v2["ms"] for v2 in grp) / args.steps, 3))
-        if "k_lift_splat" in ksum:
-            v = ksum["k_lift_splat"]
-            ach = v["work"] / (v["ms"] * 1e-3) / 1e9
-            extra["roofline_pool"] = dict(bound="hbm", kernel="coocc_lift_splat_cams (keys + binning + per-voxel sums)",
-                                          achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                                          traffic=None, algorithmic_bytes=int(v["work"] / v["launches"]),
-                                          avg_ms_per_step=round(v["ms"] / v["launches"], 4),
-                                          note="fused Lift (x) Splat, in the timed step (on the prefetch stream)")
-        rk = [ksum[k] for k in ("k_render_nearest+k_upsample_maps",) if k in ksum]
-        if rk:
-            ms = sum(v["ms"] for v in rk)
-            by = sum(v["work"] for v in rk)
-            ach = by / (ms * 1e-3) / 1e9
-            rtraffic = None
-            try:
-                rtraffic = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))["k_render_nearest+k_upsample_maps"][args.config]["bytes_per_launch"]
-            except Exception:
-                pass
-            extra["roofline_render"] = dict(bound="hbm", kernel="k_render_nearest+k_upsample_maps", achieved=round(ach, 1),
-                                            peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=rtraffic,
-                                            avg_ms_per_step=round(ms / max(1, rk[0]["launches"]), 4))
-
+    roof, extra = rooflines(core.TIMER.summary(), args.steps, args, rank, args.kernel_table)
+    if S > 1 and not args.no_kernel_timing:
+        # Kernel durations inside the S-stream pipeline include the contention between the samples in flight (that is the
+        # point of it: one sample's low-occupancy tail runs under the other's GEMMs).  A short sequential pass -- one stream,
+        # no prefetch, nothing else on the GPU -- gives each kernel's own rate next to it.
+        n_iso = max(4, min(10, args.steps // 4))
+        core.TIMER.enabled, core.TIMER.only = 1, ("k_conv", "k_render_nearest", "k_lift_splat")
+        core.TIMER.reset()
+        with torch.no_grad(), torch.cuda.stream(streams[0]):
+            for i in range(n_iso):
+                step(model, samples[i % len(samples)], 1)
+        torch.cuda.synchronize()
+        core.TIMER.enabled = False
+        r_iso, e_iso = rooflines(core.TIMER.summary(), n_iso, args, rank, False)
+        core.TIMER.reset()
+        extra["roofline_isolated"] = dict(r_iso or {}, note="separate sequential pass after the timed region (1 stream, no prefetch)",
+                                          all_convs=e_iso.get("roofline_all_convs"), render=e_iso.get("roofline_render"),
+                                          pool=e_iso.get("roofline_pool"))
     if rank == 0 and args.config == "r50" and not args.no_kernel_timing:
         extra["roofline_render_r101"] = render_r101_roofline(model, dev)
     line = dict(metric="samples/sec (6-cam frame + sweep -> occ+render), 200x200x16 grid", value=round(world * args.steps / dt, 4),

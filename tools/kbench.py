@@ -62,7 +62,19 @@ def bench_knn():
         t1 = timeit(lambda: call("coocc_knn_topk", 2048, kx.shape[0], 2, ptr(rq), ptr(kx), ptr(val), ptr(idx)))
         grp = torch.empty(2048, 200, device=dev, dtype=torch.int32)
         t2 = timeit(lambda: call("coocc_ball_query", 1, qx.shape[0], 2048, 0.0, 6.0, 200, ptr(rq), ptr(qx), ptr(grp)))
-        print("%s: topk %.3f ms  ball_query %.3f ms" % (qn, t1, t2))
+        # the grid forms the fuser uses (index maps + sorted offset table / window walk), incl. building both maps
+        rep = fuser._fps_voxels(q, grid, 2048)[0].contiguous()
+        maps = torch.empty(2, X * Y * Z, device=dev, dtype=torch.int32)
+        off = fuser.offset_table(Z, dev)
+
+        def grid_forms():
+            call("coocc_voxel_index_map", ptr(q), q.numel(), X * Y * Z, ptr(maps[0]))
+            call("coocc_voxel_index_map", ptr(k), k.numel(), X * Y * Z, ptr(maps[1]))
+            call("coocc_knn_topk_voxels", 2048, kx.shape[0], 2, X, Y, Z, ptr(rep), ptr(q), ptr(maps[1]), ptr(off), off.numel(), ptr(rq),
+                 ptr(kx), ptr(val), ptr(idx))
+            call("coocc_ball_query_voxels", 2048, 0.0, 6.0, 200, X, Y, Z, ptr(rep), ptr(q), ptr(maps[0]), ptr(grp))
+        t3 = timeit(grid_forms)
+        print("%s: brute force topk %.3f ms  ball_query %.3f ms | grid forms (2 index maps + topk + ball query) %.3f ms" % (qn, t1, t2, t3))
 
 
 def bench_conv():
