@@ -94,6 +94,8 @@ SIGNATURES = {
     "coocc_render_losses_bwd": (I, [P, P, P, P, L, I, P, P, P, P, P]),
     "coocc_upsample_trilinear_bwd": (I, [P, P, I, I, I, I, I, I, I, I, I, P]),
     "coocc_wino_input": (I, [P, I, I, I, I, I, I, I, P, L, P]),
+    "coocc_wino_input_strided": (I, [P, I, I, I, I, I, I, I, P, I, L, P]),
+    "coocc_sparse_tap_sum": (I, [P, P, I, I, I, I, I, P, P, I, P]),
     "coocc_wino_output": (I, [P, L, I, I, I, I, I, I, P, I, P, P, P, I, I, P]),
     "coocc_projection_params": (I, [P, P, P, P, P, P, I, P, P, P]),
     "coocc_occhead_mix_bwd": (I, [P, P, I, P, P, P, P, I, I, P]),

@@ -250,16 +250,39 @@ def wino_eligible(x, pc, M, res_mode):
     return wino_plan(x, pc, M, res_mode) is not None
 
 
-def conv_rows_wino(x, pc, out, relu, res, plan):
+def scratch(device, kind, nfloats):
+    """Per-stream scratch buffer (uninitialised), grown on demand."""
+    key = (device.index, "s:" + kind, torch.cuda.current_stream(device).cuda_stream)
+    t = _wino_ws.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(nfloats, device=device, dtype=_F32)
+        _wino_ws[key] = t
+    return t
+
+
+def conv_rows_wino(x, pc, out, relu, res, plan, in_ranges=None):
     """3x3x3 stride-1 conv as Winograd F(m x m,3x3) over (x,y) + direct z taps: input transform, one grouped
-    GEMM launch (one weight pack per transform point), output transform with the epilogue."""
+    GEMM launch (one weight pack per transform point), output transform with the epilogue.
+    ``in_ranges``: [(channel offset, count), ...] inside x's rows whose concatenation is the layer's input (sum = pc.Cin);
+    default: the first pc.Cin channels of x."""
     dev = x.t.device
     tile, pts, Tx, Ty, rows, G, hint = plan
     V = _wino_buffer(dev, "V", pts * G * pc.Cin)
     Mb = _wino_buffer(dev, "M", pts * G * pc.Cout)
     wp = pc.wino_pack(tile)
     with TIMER.region("k_wino_in", 4.0 * x.V * pc.Cin + 4.0 * pts * rows * pc.Cin):
-        call("coocc_wino_input", x.data(), x.stride, x.B, x.X, x.Y, x.Z, pc.Cin, tile, ptr(V), G)
+        if in_ranges is None:
+            call("coocc_wino_input", x.data(), x.stride, x.B, x.X, x.Y, x.Z, pc.Cin, tile, ptr(V), G)
+        else:
+            assert sum(c for _, c in in_ranges) == pc.Cin
+            voff = 0
+            for coff, cr in in_ranges:
+                src = _lib.DevPtr(x.t.data_ptr() + 4 * (x.coff + coff))
+                src._keep = x.t
+                dst = _lib.DevPtr(V.data_ptr() + 4 * voff)
+                dst._keep = V
+                call("coocc_wino_input_strided", src, x.stride, x.B, x.X, x.Y, x.Z, cr, tile, dst, pc.Cin, G)
+                voff += cr
     d = ConvDesc()
     ws = workspace(dev)
     d.in_, d.w, d.out = ptr(V), ptr(wp), ptr(Mb)

@@ -79,7 +79,7 @@ template <> struct Wino<6> {   // F(4,3) on the points (0, 1, -1, 1/2, -2, inf):
 
 template <int N>
 __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ in, int in_stride, int B, int X, int Y, int Z,
-                                                  int C, int Tx, int Ty, size_t gstride, float* __restrict__ V) {
+                                                  int C, int Tx, int Ty, size_t gstride, int vstride, float* __restrict__ V) {
   constexpr int MO = Wino<N>::M;
   const int c4 = C >> 2;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ in, i
 #pragma unroll
     for (int a = 0; a < N; ++a) t[a][e] = q[a];
   }
-  float* o = V + (size_t)row * C + c;
+  float* o = V + (size_t)row * vstride + c;
 #pragma unroll
   for (int a = 0; a < N; ++a) {
     f32x4 q[N];
@@ -118,25 +118,36 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ in, i
   }
 }
 
-extern "C" int coocc_wino_input(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, float* V,
-                                int64_t group_rows, void* stream) {
+static int wino_input_impl(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, float* V, int vstride,
+                           int64_t group_rows, void* stream) {
   COOCC_CHECK_ARG(in && V && B > 0 && X > 0 && Y > 0 && Z > 0 && C > 0 && C % 4 == 0 && in_stride % 4 == 0, "wino_input: bad args");
   COOCC_CHECK_ARG(tile >= 2 && tile <= 4, "wino_input: tile must be 2, 3 or 4");
+  COOCC_CHECK_ARG(vstride >= C && vstride % 4 == 0 && ((uintptr_t)V & 15) == 0, "wino_input: V row stride / alignment");
   const int Tx = (X + tile - 1) / tile, Ty = (Y + tile - 1) / tile;
   const long long rows = (long long)B * Tx * Ty * Z;
   COOCC_CHECK_ARG(group_rows >= rows, "wino_input: group_rows smaller than B*ceil(X/tile)*ceil(Y/tile)*Z");
   const dim3 grid(cdiv(rows * (C / 4), 256));
+  const size_t gstride = (size_t)group_rows * vstride;
   if (tile == 2)
-    hipLaunchKernelGGL(k_wino_in<4>, grid, dim3(256), 0, as_stream(stream), in, in_stride, B, X, Y, Z, C, Tx, Ty,
-                       (size_t)group_rows * C, V);
+    hipLaunchKernelGGL(k_wino_in<4>, grid, dim3(256), 0, as_stream(stream), in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, V);
   else if (tile == 3)
-    hipLaunchKernelGGL(k_wino_in<5>, grid, dim3(256), 0, as_stream(stream), in, in_stride, B, X, Y, Z, C, Tx, Ty,
-                       (size_t)group_rows * C, V);
+    hipLaunchKernelGGL(k_wino_in<5>, grid, dim3(256), 0, as_stream(stream), in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, V);
   else
-    hipLaunchKernelGGL(k_wino_in<6>, grid, dim3(256), 0, as_stream(stream), in, in_stride, B, X, Y, Z, C, Tx, Ty,
-                       (size_t)group_rows * C, V);
+    hipLaunchKernelGGL(k_wino_in<6>, grid, dim3(256), 0, as_stream(stream), in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, V);
   COOCC_LAUNCH_CHECK("k_wino_in");
   return COOCC_OK;
+}
+
+extern "C" int coocc_wino_input(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, float* V,
+                                int64_t group_rows, void* stream) {
+  return wino_input_impl(in, in_stride, B, X, Y, Z, C, tile, V, C, group_rows, stream);
+}
+
+// the same transform writing C channels into rows of `vstride` floats (V already offset to the first of them): the input
+// channels of one GEMM may come from several channel ranges of the source rows (the dense half of con_enc.0, fuser.py)
+extern "C" int coocc_wino_input_strided(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, float* V,
+                                        int vstride, int64_t group_rows, void* stream) {
+  return wino_input_impl(in, in_stride, B, X, Y, Z, C, tile, V, vstride, group_rows, stream);
 }
 
 template <int N>

@@ -66,6 +66,10 @@ def _fps_voxels_on_current(q_lin, grid, fps_num):
 
 
 GRID_SEARCH = __import__("os").environ.get("COOCC_GRID_SEARCH", "1") != "0"   # 0: brute-force top-K / ball query
+# con_enc.0 split by input-channel support (csrc/sparse_taps.hip): the pts / fused_img slots are non-zero on the LiDAR voxels
+# only, so they are convolved in scatter form over those rows while img / fused_pts go through the Winograd GEMM.
+SPLIT_C0 = __import__("os").environ.get("COOCC_SPLIT_C0", "1") != "0"
+SPLIT_C0_MAX_DENSITY = 0.30      # above this share of LiDAR voxels the dense 4C-channel GEMM is the cheaper form
 _offset_tables = {}
 
 
@@ -208,10 +212,18 @@ class BiFuser_N(nn.Module):
             import os
             t0, t3 = [int(v) for v in os.environ.get("COOCC_CONENC_TILES", "2,4").split(",")]
             d["c0"].wino_tile, d["c3"].wino_tile = t0, t3
+            d["c0_dense"].wino_tile = t0
             return d
 
         def build_packs():
+            C, W0 = self.in_channels, self.con_enc[0].weight
+            Co = W0.shape[0]
+            dense_idx = list(range(0, C)) + list(range(3 * C, 4 * C))                       # img | fused_pts
+            # sparse half (pts | fused_img) as a Linear with one 27*Cout-wide output row per occupied voxel: column (t, n)
+            w_cols = W0[:, C:3 * C].reshape(Co, 2 * C, 27).permute(2, 0, 1).reshape(27 * Co, 2 * C).contiguous()
             return dict(
+                c0_dense=PackedConv(W0[:, dense_idx].contiguous(), bn=self.con_enc[1], ksize=3, pad=1),
+                c0_sparse=PackedConv(w_cols),
                 c0=PackedConv(self.con_enc[0].weight, bn=self.con_enc[1], ksize=3, pad=1),
                 c3=PackedConv(self.con_enc[3].weight, bn=self.con_enc[4], ksize=3, pad=1),
                 knn=PackedConv(self.knn_enc[0].weight, bias=self.knn_enc[0].bias, tap_major=True, taps=self.knum))
@@ -363,7 +375,46 @@ class BiFuser_N(nn.Module):
             x, g = ag.con_enc_train(self.con_enc, ag.fuser_fuse_train(self, ri, rp, sr), geom)
             return ag.ncdhw_from_rows(x, g)
         packs = self._packed()
-        cat4, _ = self.fuse(img_voxel_feats, pts_voxel_feats, search)
-        x = conv_rows(cat4, packs["c0"], relu=True)
+        cat4, (_, lin_pts) = self.fuse(img_voxel_feats, pts_voxel_feats, search)
+        x = self.con_enc0(cat4, lin_pts, packs)
         x = conv_rows(x, packs["c3"], relu=True)
         return x.as_ncdhw()
+
+    def con_enc0(self, cat4, lin_pts, packs):
+        """con_enc[0:3] (Conv3d 4C -> 2C + BN + ReLU) on the concat rows.  When the LiDAR voxels are a small share of the grid
+        the layer is split by input-channel support: img | fused_pts through the Winograd GEMM (half the K), pts | fused_img
+        (non-zero on ``lin_pts`` only) in scatter form -- one row-table GEMM over the occupied rows into per-tap
+        contributions, summed per output voxel in tap order and handed to the output transform as its residual."""
+        from . import core
+        C, V, dev = self.in_channels, cat4.V * cat4.B, cat4.t.device
+        Np = int(lin_pts.numel())
+        pd = packs["c0_dense"]
+        plan = core.wino_plan(cat4, pd, V, 1) if (SPLIT_C0 and core.CONV_DTYPE == "f32") else None
+        if plan is None or Np == 0 or Np > SPLIT_C0_MAX_DENSITY * V or cat4.B != 1:
+            return conv_rows(cat4, packs["c0"], relu=True)
+        ps = packs["c0_sparse"]
+        Co = pd.Cout
+        # P[u][t][n] = W_t[n, :] . cat4[u, C:3C] for the occupied rows u
+        P = core.scratch(dev, "c0P", Np * 27 * Co)
+        d = _lib.ConvDesc()
+        ws = core.workspace(dev)
+        src = _lib.DevPtr(cat4.t.data_ptr() + 4 * (cat4.coff + C))
+        src._keep = cat4.t
+        d.in_, d.w, d.out = src, ptr(ps.w), ptr(P)
+        d.scale = d.bias = d.res = d.out_rows = None
+        d.gather = ptr(lin_pts)
+        d.ws, d.ws_floats = ptr(ws), ws.numel()
+        d.M, d.Cin, d.Cout, d.taps = Np, 2 * C, 27 * Co, 1
+        d.in_stride, d.out_stride, d.res_stride = cat4.stride, 27 * Co, 0
+        d.B = d.Yi = d.Zi = d.Xo = d.Yo = d.Zo = 1
+        d.Xi = V                      # number of input rows (lets coocc_conv_fwd pick the pipelined row-table kernel)
+        d.ksize, d.stride, d.pad = 1, 1, 0
+        d.relu, d.res_mode, d.splitk, d.tile_hint = 0, 0, 1, core.TILE_HINT
+        with core.TIMER.region(core.conv_kernel_name(Np, 27 * Co, True) + " c0-sparse", 2.0 * Np * 2 * C * 27 * Co):
+            _lib.conv_fwd(d, dev)
+        vmap = torch.empty(V, device=dev, dtype=_I32)
+        call("coocc_voxel_index_map", ptr(lin_pts), Np, V, ptr(vmap))
+        S = core.Rows(torch.empty(V, Co, device=dev, dtype=_F32), cat4.B, cat4.X, cat4.Y, cat4.Z, Co)
+        call("coocc_sparse_tap_sum", ptr(P), ptr(vmap), cat4.B, cat4.X, cat4.Y, cat4.Z, Co, ptr(pd.scale), ptr(S.t), Co)
+        out = core.Rows(torch.empty(V, Co, device=dev, dtype=_F32), cat4.B, cat4.X, cat4.Y, cat4.Z, Co)
+        return core.conv_rows_wino(cat4, pd, out, True, S, plan, in_ranges=[(0, C), (3 * C, C)])

@@ -182,6 +182,15 @@ int coocc_conv_fwd(const coocc_conv_desc* d, void* stream);
  * >= B*Tx*Ty*Z.  12*Cin (m=2) / 6.75*Cin (m=4) multiplies per output instead of 27*Cin. */
 int coocc_wino_input(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, float* V,
                      int64_t group_rows, void* stream);
+/* coocc_wino_input writing its C channels into V rows of `vstride` floats (V already offset to the first of them): one
+ * GEMM's input channels gathered from several channel ranges of the source rows. */
+int coocc_wino_input_strided(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, float* V,
+                             int vstride, int64_t group_rows, void* stream);
+/* Scatter-form sparse half of a dense 3x3x3 convolution (csrc/sparse_taps.hip): P:[Np][27][Cout] = per occupied input voxel
+ * and tap the contribution W_t . in[u] (a row-table coocc_conv_fwd with N = 27*Cout), map: voxel -> row of P or -1
+ * (coocc_voxel_index_map); S[v][n] = scale[n] * sum_t P[map[v + t - 1]][t][n], taps in order (deterministic). */
+int coocc_sparse_tap_sum(const float* P, const int32_t* map, int B, int X, int Y, int Z, int Cout, const float* scale,
+                         float* S, int s_stride, void* stream);
 int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, int tile, float* out,
                       int out_stride, const float* scale, const float* bias, const float* res, int res_stride,
                       int relu, void* stream);

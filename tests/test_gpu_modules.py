@@ -598,3 +598,30 @@ def test_lift_splat_into_the_fuser_concat_buffer(dev):
         cview = f(plain, pts.to(dev))                     # channels-last view of a [V,C] buffer -> rows prologue with a copy
     assert torch.equal(a, b) and torch.equal(a, cview)
     assert torch.equal(na[0], nb[0]) and torch.equal(na[1], nb[1])
+
+
+@pytest.mark.parametrize("name", ["fuser_k2", "fuser_k2_far", "fuser_k3"])
+def test_con_enc0_split_by_channel_support_equals_dense_form(dev, golden, monkeypatch, name):
+    """con_enc.0 with the pts | fused_img channels convolved in scatter form over the LiDAR voxels (csrc/sparse_taps.hip) and
+    img | fused_pts through the Winograd GEMM: same result as the one dense 4C-channel convolution (fp32 reassociation only),
+    and within the parity bound of the reference's golden output."""
+    from co_occ_amd import fuser as fz
+    c, g = cases.FUSER_CASES[name], golden(name)
+    img, pts = cases.fuser_inputs(c)
+    f, sd = load_seeded(pkg.BiFuser_N(c["C"], c["C"], c["knum"]), c["seed"], dev)
+    monkeypatch.setattr(core, "WINO", 1)
+    monkeypatch.setattr(core, "WINO_MIN_ROWS", 0)
+    outs = {}
+    for split in (True, False):
+        monkeypatch.setattr(fz, "SPLIT_C0", split)
+        monkeypatch.setattr(fz, "SPLIT_C0_MAX_DENSITY", 1.0)      # the seeded cases are 40-65 % dense: force the split form
+        core.TIMER.enabled, core.TIMER.only = 1, None
+        core.TIMER.reset()
+        with torch.no_grad():
+            outs[split] = f(img.to(dev), pts.to(dev)).cpu()
+        torch.cuda.synchronize()
+        tags = set(core.TIMER.summary())
+        core.TIMER.enabled = False
+        assert any("c0-sparse" in t for t in tags) == split, tags
+    assert_close(outs[True], outs[False], tol=2e-5, what="split vs dense con_enc.0")
+    assert_close(outs[True], g["out"], what=name + " split con_enc.0 vs golden")
