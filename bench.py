@@ -345,9 +345,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="r50", choices=sorted(synth.CONFIGS))
-    ap.add_argument("--streams", type=int, default=2,
-                    help="dense stages in flight: S host threads / HIP streams, sample i on stream i mod S (S = 2 runs one "
-                         "sample's low-occupancy tail under the other's large GEMMs)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="dense stages in flight: S host threads / HIP streams, sample i on stream i mod S.  Default 1: measured "
+                         "A/B on one box (profiles/r2_streams_ab.txt) 110.6 / 111.4 samples/s at S = 1 vs 104.2 / 99.4 at S = 2")
     ap.add_argument("--prefetch", type=int, default=1,
                     help="issue the index search of sample i+1 (helper host thread + stream) under the dense stage of sample i")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs set aside for the FPS chains (hipExtStreamCreateWithCUMask)")
