@@ -6,8 +6,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_r2
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+timeout 300 python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1      # clocks / caches warm before the recorded runs
 timeout 400 python $R/bench.py --steps 50 --warmup 3 > $O/r2_bench_default.json 2> $O/r2_bench_default.err
-timeout 300 python $R/bench.py --steps 50 --warmup 3 --streams 1 --no-cpu-baseline > $O/r2_bench_streams1.json 2>/dev/null
+timeout 300 python $R/bench.py --steps 50 --warmup 3 --streams 2 --no-cpu-baseline > $O/r2_bench_streams2.json 2>/dev/null
+timeout 300 python $R/bench.py --steps 50 --warmup 3 --no-cpu-baseline --kernel-table > $O/r2_bench_kernel_table.json 2> $O/r2_bench_kernel_table.txt
 for S in 1 2; do
   rm -rf /tmp/p_stats$S
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats$S -o b -- python $R/bench.py --steps 10 --warmup 3 --streams $S --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
