@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 import co_occ_amd as pkg  # noqa: E402
 import co_occ_amd.dist as cdist  # noqa: E402
 import co_occ_amd.synth as synth  # noqa: E402
-from co_occ_amd import core  # noqa: E402
+from co_occ_amd import _lib, core  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, fp32-input MFMA (spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA (spec; 2:1-sparse figures are not used)
@@ -115,14 +115,65 @@ class _Ticket:
 TICKET = _Ticket()
 
 
+class _Gates:
+    """Events posted by sample i for sample i+1 to wait on (host side: until the event object exists)."""
+
+    def __init__(self):
+        self.cv = __import__("threading").Condition()
+        self.ev = {}
+        self.dead = False
+
+    def reset(self):
+        with self.cv:
+            self.ev, self.dead = {-1: None}, False
+
+    def post(self, i, ev):
+        with self.cv:
+            self.ev[i] = ev
+            self.ev.pop(i - 4, None)
+            self.cv.notify_all()
+
+    def wait_for(self, i):
+        with self.cv:
+            self.cv.wait_for(lambda: i in self.ev or self.dead, timeout=60)
+            return self.ev.get(i)
+
+    def abort(self):
+        with self.cv:
+            self.dead = True
+            self.cv.notify_all()
+
+
+GATES = _Gates()
+DIAG = {"search_host_s": [], "search_blocked_s": [], "wait_search_host_s": [], "dense_host_s": [], "dense_blocked_s": []}     # host-side issue times per sample (--diag)
+STAGGER = [0]
+
+
 def step(model, s, world, search=None, img=None, ticket=None):
     # the reference hard-codes the render bounds to a 100x100x8 volume (coocc_ray.py:577): smaller test grids
     # (config1) cannot be rendered there either
     if img is None:
         img = pool(model, s) if WITH_POOL[0] else s["img"]
     X, Y, Z = img.shape[2:]
-    out = model.forward_hot_path(img, s["pts"], s["gemo"], s["img_feats"], s["transform"],
-                                 render=(X >= 100 and Y >= 100 and Z >= 8), search=search)
+    do_render = X >= 100 and Y >= 100 and Z >= 8
+    if STAGGER[0] and ticket is not None:
+        # S > 1: sample i+1 may enter its dense stage only after sample i has passed the gate point (end of the fuser or of the
+        # encoder), so the two dense stages in flight keep a fixed phase offset instead of locking step by chance
+        cur = torch.cuda.current_stream()
+        prev = GATES.wait_for(ticket - 1)
+        if prev is not None:
+            cur.wait_event(prev)
+
+        def passed():
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            GATES.post(ticket, ev)
+        vf = model.fuse(img, s["pts"], search)
+        if STAGGER[0] == 1:
+            passed()
+        out = model.decode(vf, s["gemo"], s["img_feats"], s["transform"], do_render, after_encoder=passed if STAGGER[0] == 2 else None)
+    else:
+        out = model.forward_hot_path(img, s["pts"], s["gemo"], s["img_feats"], s["transform"], render=do_render, search=search)
     if world > 1 and ticket is not None:
         with TICKET(ticket):
             return _gather(out)
@@ -348,6 +399,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="dense stages in flight: S host threads / HIP streams, sample i on stream i mod S.  Default 1: measured "
                          "A/B on one box (profiles/r2_streams_ab.txt) 110.6 / 111.4 samples/s at S = 1 vs 104.2 / 99.4 at S = 2")
+    ap.add_argument("--stagger", type=int, default=0,
+                    help="with --streams > 1: 1 = sample i+1 enters its dense stage after sample i finished the fuser, 2 = after "
+                         "its encoder (fixed phase offset between the dense stages in flight); 0 = free running")
     ap.add_argument("--prefetch", type=int, default=1,
                     help="issue the index search of sample i+1 (helper host thread + stream) under the dense stage of sample i")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs set aside for the FPS chains (hipExtStreamCreateWithCUMask)")
@@ -359,6 +413,7 @@ def main():
     ap.add_argument("--no-pool", action="store_true",
                     help="start the step from an already-pooled camera volume (round-1 definition) instead of the lifted "
                          "depth/context pair (SURVEY.md 8d: 'lifted features + sweep volume -> logits')")
+    ap.add_argument("--diag", action="store_true", help="host-side issue times per sample to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event timing table to stderr")
@@ -390,6 +445,7 @@ def main():
     WITH_POOL[0] = not args.no_pool
     CFGNAME[0] = args.config
     core.CONV_DTYPE = args.dtype
+    STAGGER[0] = args.stagger if args.streams > 1 else 0
     model, sd = build_model(args.config, dev)
     samples = [make_inputs(args.config, 1234 + 17 * rank + i, dev, model) for i in range(2)]
     if args.reserve_cus > 0:
@@ -412,9 +468,13 @@ def main():
         """Pooling (P2) + index search (K1-K5) of sample i on a high-priority prefetch stream."""
         s = samples[i % len(samples)]
         torch.cuda.set_device(dev)
+        t0, b0 = time.perf_counter(), _lib.blocked_seconds()
         with torch.cuda.stream(search_streams[i % S]), torch.no_grad():
             img = pool(model, s) if WITH_POOL[0] else s["img"]
-            return img, model.search(img, s["pts"])
+            sr = model.search(img, s["pts"])
+        DIAG["search_host_s"].append(time.perf_counter() - t0)
+        DIAG["search_blocked_s"].append(_lib.blocked_seconds() - b0)
+        return img, sr
 
     def run(nsteps, timed):
         """`nsteps` samples over S dense streams (one host thread each; S = 1: a single driver thread).  Sample i runs its
@@ -441,21 +501,28 @@ def main():
                 with torch.no_grad():
                     for i in range(w, nsteps, S):
                         img, sr = (None, None)
+                        t0 = time.perf_counter()
                         if tpool is not None:
                             with lock:
                                 f = futs.pop(i)
                             img, sr = f.result()
+                        t1, b1 = time.perf_counter(), _lib.blocked_seconds()
                         submit(i + S)
                         with torch.cuda.stream(streams[w]):
                             if img is not None and torch.is_tensor(img):
                                 img.record_stream(streams[w])
                             step(model, samples[i % len(samples)], world, search=sr, img=img, ticket=i)
+                        DIAG["wait_search_host_s"].append(t1 - t0)
+                        DIAG["dense_host_s"].append(time.perf_counter() - t1)
+                        DIAG["dense_blocked_s"].append(_lib.blocked_seconds() - b1)
                 streams[w].synchronize()
             except Exception as e:  # surface worker failures in the main thread
                 errs.append(e)
                 TICKET.abort()
+                GATES.abort()
 
         TICKET.reset()
+        GATES.reset()
         if S == 1:
             worker(0)
         else:
@@ -481,10 +548,16 @@ def main():
     cdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    for v in DIAG.values():
+        del v[:]
     run(args.steps, True)
     cdist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if args.diag and rank == 0:
+        print("diag: " + json.dumps({k: dict(mean_ms=round(1e3 * sum(v) / max(len(v), 1), 3), max_ms=round(1e3 * max(v or [0]), 3))
+                                     for k, v in DIAG.items()}, sort_keys=True) + " wall_ms_per_step %.3f" % (1e3 * dt / args.steps),
+              file=sys.stderr)
     core.TIMER.enabled = False
     dt = cdist.max_over_ranks(dt, dev)
 

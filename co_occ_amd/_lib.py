@@ -5,6 +5,8 @@ module without a built library, or calling an op with CPU tensors, raises immedi
 """
 import ctypes
 import os
+import threading
+import time
 
 import torch
 
@@ -210,17 +212,28 @@ def _device_of(args):
     return None
 
 
+_fns = {}
+
+
 def call(name, *args):
     """Call an int-returning entry point on the torch HIP stream OF THE ARGUMENTS' DEVICE (the first device pointer
     decides; a module living on cuda:1 while cuda:0 is current launches on cuda:1's current stream under a device guard)."""
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
     dev = _device_of(args)
     if dev is not None and dev.index != torch.cuda.current_device():
         with torch.cuda.device(dev):
             with TIMER.region(name):
-                check(getattr(load(), name)(*args, stream(dev)))
+                check(fn(*args, stream(dev)))
+        return
+    if not TIMER.enabled:                  # the common case: ~250 of these per sample, keep the host path short
+        rc = fn(*args, stream(dev))
+        if rc:
+            check(rc)
         return
     with TIMER.region(name):
-        check(getattr(load(), name)(*args, stream(dev)))
+        check(fn(*args, stream(dev)))
 
 
 def conv_fwd(desc, device):
@@ -233,7 +246,14 @@ def conv_fwd(desc, device):
         check(fn(ctypes.byref(desc), stream(device)))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream(device=None):
+    """The current torch HIP stream of ``device`` (default: the current device) as a raw handle."""
+    if _raw_stream is not None:        # no Stream object per launch
+        idx = device.index if device is not None and device.index is not None else torch.cuda.current_device()
+        return c_void_p(_raw_stream(idx))
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
@@ -257,6 +277,23 @@ def ptr(t, dtype=None, strided=False):
     p = DevPtr(t.data_ptr())
     p._keep = t
     return p
+
+
+_blocked = threading.local()
+
+
+def host_read(t):
+    """Device->host read of a small tensor: the synchronisation points of the path (voxel counts of the index search, the
+    fine-branch count).  The time the calling thread spent blocked is accumulated per thread (``blocked_seconds``) so that
+    ``bench.py --diag`` can separate issue time from waiting."""
+    t0 = time.perf_counter()
+    v = t.tolist()
+    _blocked.s = getattr(_blocked, "s", 0.0) + time.perf_counter() - t0
+    return v
+
+
+def blocked_seconds():
+    return getattr(_blocked, "s", 0.0)
 
 
 def host_f32(vals):

@@ -797,7 +797,7 @@ class FineSampleImgFn(torch.autograd.Function):
         nf = fine_xyz.shape[1]
         samp = torch.empty(nf, Ci, device=img_rows.device, dtype=_F32)
         call("coocc_fine_sample_img", ptr(img_rows.contiguous()), ncam, Ci, Hf, Wf, ptr(params), ptr(fine_xyz), nf, ptr(samp), Ci,
-             1 if ratio == 2 else 0)
+             ratio if ratio in (2, 4) else 0)
         ctx.save_for_backward(params, fine_xyz)
         ctx.cfg = (ncam, Ci, Hf, Wf)
         return samp

@@ -98,12 +98,10 @@ class CustomResNet3D(nn.Module):
         return nn.Sequential(*layers)
 
     def _packed(self):
-        srcs = list(self.parameters()) + list(self.buffers())
-
         def build():
             return dict(proj=PackedConv(self.input_proj[0].weight, bn=self.input_proj[1], ksize=1),
                         blocks=[[b.packed() for b in layer] for layer in self.layers])
-        return self._packs.get(srcs, build)
+        return self._packs.get_modules((self,), build)
 
     def forward_rows(self, x):
         _eval_only(self)

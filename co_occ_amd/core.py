@@ -309,7 +309,7 @@ def conv_rows_wino(x, pc, out, relu, res, plan, in_ranges=None):
 
 def workspace(device, nfloats=64 << 20):
     """Split-K scratch (256 MB by default), one per device, reused by every launch on the stream."""
-    key = (device.index, nfloats, torch.cuda.current_stream(device).cuda_stream)   # one per stream: samples overlap
+    key = (device.index, nfloats, _lib.stream(device).value)   # one per stream: samples overlap
     if key not in _ws_cache:
         _ws_cache[key] = torch.empty(nfloats, device=device, dtype=_F32)
     return _ws_cache[key]
@@ -357,6 +357,9 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
             d.w = ptr(pc.ztrim_pack(lo, hi))
             d.kx, d.ky, d.kz, d.px, d.py, d.pz = 3, 3, hi - lo + 1, pc.pad, pc.pad, pc.pad - lo
             d.taps = taps = 9 * (hi - lo + 1)
+    if not TIMER.enabled:
+        _lib.conv_fwd(d, pc.w.device)
+        return out
     kname = "k_conv_bf16" if bf16 else conv_kernel_name(M, pc.Cout, False, 0, taps * -(-pc.Cin // 32),
                                                          pc.ksize == 1 and pc.stride == 1 and pc.pad == 0)
     with TIMER.region(kname, 2.0 * M * pc.Cin * pc.Cout * taps):
@@ -428,11 +431,38 @@ class PackCache:
     def __init__(self, owner=None):
         self._key = None
         self._val = None
+        self._slots = None
         if owner is not None and hasattr(owner, "register_load_state_dict_post_hook"):
             owner.register_load_state_dict_post_hook(lambda module, incompatible_keys: self.invalidate())
 
     def invalidate(self):
         self._key = self._val = None
+        self._slots = None
+
+    def get_modules(self, modules, build, buffers=True):
+        """``get`` over every parameter (and buffer) under ``modules`` without walking the module tree per call: the
+        (``_parameters`` / ``_buffers`` dict, name) slots are listed once and read by direct lookups afterwards, so replaced
+        Parameter objects, ``.to()`` moves and in-place writes are all seen; adding or removing SUBMODULES after the first
+        call is not (``invalidate()``).  The per-call tree walk was ~0.5 ms of host time per sample."""
+        slots = getattr(self, "_slots", None)
+        if slots is None:
+            slots = []
+            for mod in modules:
+                for m in mod.modules():
+                    slots += [(m._parameters, k) for k in m._parameters]
+                    if buffers:
+                        slots += [(m._buffers, k) for k in m._buffers]
+            self._slots = slots
+        key = []
+        for d, k in slots:
+            t = d.get(k)
+            if t is not None:
+                key.append(t.data_ptr())
+                key.append(t._version)
+        if key != self._key:
+            self._val = build()
+            self._key = key
+        return self._val
 
     def get(self, tensors, build):
         key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors if t is not None)

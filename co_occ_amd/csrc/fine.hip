@@ -153,6 +153,98 @@ __global__ __launch_bounds__(256, 4) void k_fine_sample_voxel_r2(const float* __
   }
 }
 
+// ratio R > 2 (OpenOccupancy: cascade_ratio 4, 64 children): same idea, one (half-)wave per coarse voxel.  With
+// final == R * coarse a child's base index along an axis is c-1 (a < R/2) or c (p = q*S/(R*S-1) - 1/2), so all R^3 stencils
+// still live in the 3x3x3 neighbourhood.  The R x-children are walked one after the other with R*R accumulators each; the
+// window rows are re-read from L1 (R x 18 row loads per coarse voxel instead of 8 R^3, and the volume is streamed from HBM
+// once instead of R^3 times).  Same tap weights, products and accumulation order as k_fine_sample_voxel (zero-weight window
+// positions add v * 0).
+template <int R>
+__global__ __launch_bounds__(256) void k_fine_sample_voxel_rn(const float* __restrict__ vol, int C, int X, int Y, int Z,
+                                                               const int32_t* __restrict__ coarse_lin, int n,
+                                                               float fx1, float fy1, float fz1,
+                                                               int64_t* __restrict__ fine_xyz, float* __restrict__ feat,
+                                                               int out_stride) {
+  constexpr int R3 = R * R * R;
+  const int wv = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const bool halfw = C <= 64;
+  const int i = halfw ? wv * 2 + (int)((threadIdx.x & 63) >> 5) : wv;
+  const int lane = halfw ? (threadIdx.x & 31) : (threadIdx.x & 63);
+  const int nl = halfw ? 32 : 64;
+  const int cstep = 2 * nl;
+  if (i >= n) return;
+  const long long nf = (long long)n * R3;
+  int l = coarse_lin[i];
+  const int cz = l % Z; l /= Z;
+  const int cy = l % Y; const int cx = l / Y;   // B == 1
+  int i0[3][R]; float t[3][R];
+  const int cc[3] = {cx, cy, cz}; const float f1[3] = {fx1, fy1, fz1}; const int S[3] = {X, Y, Z};
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      const int q = cc[ax] * R + a;
+      const float g = ((float)q / f1[ax] - 0.5f) * 2.f;
+      const float p = ((g + 1.f) * (float)S[ax] - 1.f) / 2.f;
+      const float fl = floorf(p);
+      i0[ax][a] = (int)fl; t[ax][a] = p - fl;
+    }
+  for (int o = lane; o < R3; o += nl) {
+    const int oa = o / (R * R), ob = (o / R) % R, oc = o % R;
+    const long long f = (long long)o * n + i;
+    fine_xyz[f] = cx * R + oa; fine_xyz[nf + f] = cy * R + ob; fine_xyz[2 * nf + f] = cz * R + oc;
+  }
+  auto tapw = [](int b0, float t, int x) { return (x == b0 ? 1.f - t : 0.f) + (x == b0 + 1 ? t : 0.f); };
+  int wy0 = i0[1][0], wz0 = i0[2][0];
+#pragma unroll
+  for (int a = 1; a < R; ++a) { wy0 = min(wy0, i0[1][a]); wz0 = min(wz0, i0[2][a]); }
+  for (int c = lane * 2; c < C; c += cstep) {
+#pragma unroll 1
+    for (int a = 0; a < R; ++a) {
+      // runtime-indexed copies of this x-child's base / fraction (R is small: select chain instead of scratch)
+      int bx = i0[0][0]; float txa = t[0][0];
+#pragma unroll
+      for (int k = 1; k < R; ++k) if (a == k) { bx = i0[0][k]; txa = t[0][k]; }
+      f32x2 acc[R * R];
+#pragma unroll
+      for (int o = 0; o < R * R; ++o) acc[o] = f32x2{0.f, 0.f};
+#pragma unroll 1
+      for (int kx = 0; kx < 2; ++kx) {
+        const int x = bx + kx;
+        if ((unsigned)x >= (unsigned)X) continue;
+        const float wxa = kx ? txa : 1.f - txa;
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+          const int y = wy0 + ky;
+          if ((unsigned)y >= (unsigned)Y) continue;
+          float wxy[R];
+#pragma unroll
+          for (int b = 0; b < R; ++b) wxy[b] = wxa * tapw(i0[1][b], t[1][b], y);
+          const float* rowp = vol + (((size_t)x * Y + y) * Z) * C + c;
+#pragma unroll
+          for (int kz = 0; kz < 3; ++kz) {
+            const int z = wz0 + kz;
+            if ((unsigned)z >= (unsigned)Z) continue;
+            const f32x2 v = *(const f32x2*)(rowp + (size_t)z * C);
+#pragma unroll
+            for (int d = 0; d < R; ++d) {
+              const float czd = tapw(i0[2][d], t[2][d], z);
+#pragma unroll
+              for (int b = 0; b < R; ++b) acc[b * R + d] = acc[b * R + d] + v * (wxy[b] * czd);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < R * R; ++o)
+        *(f32x2*)(feat + ((size_t)(a * R * R + o) * n + i) * out_stride + c) = acc[o];
+    }
+  }
+}
+
+static int g_fine_pointwise = 0;   // test hook: 1 = always the one-wave-per-fine-point kernels
+extern "C" void coocc_fine_set_pointwise(int on) { g_fine_pointwise = on; }
+
 extern "C" int coocc_fine_sample_voxel(const float* vol, int C, int X, int Y, int Z, const int32_t* coarse_lin, int n,
                                        int ratio, const int* final_size_host, int64_t* fine_xyz, float* feat,
                                        int out_stride, void* stream) {
@@ -162,11 +254,18 @@ extern "C" int coocc_fine_sample_voxel(const float* vol, int C, int X, int Y, in
   long long nf = (long long)n * ratio * ratio * ratio;
   // the 3-wide window of the grouped kernel needs floor(p) of the two children of an axis to differ by <= 1:
   // true for final == ratio * coarse (p = q*S/(2S-1) - 1/2)
-  if (ratio == 2 && final_size_host[0] == 2 * X && final_size_host[1] == 2 * Y && final_size_host[2] == 2 * Z) {
+  if (!g_fine_pointwise && ratio == 2 && final_size_host[0] == 2 * X && final_size_host[1] == 2 * Y && final_size_host[2] == 2 * Z) {
     hipLaunchKernelGGL(k_fine_sample_voxel_r2, dim3(cdiv((long long)(C <= 64 ? (n + 1) / 2 : n) * 64, 256)), dim3(256), 0, as_stream(stream), vol, C, X,
                        Y, Z, coarse_lin, n, (float)(final_size_host[0] - 1), (float)(final_size_host[1] - 1),
                        (float)(final_size_host[2] - 1), fine_xyz, feat, out_stride);
     COOCC_LAUNCH_CHECK("k_fine_sample_voxel_r2");
+    return COOCC_OK;
+  }
+  if (!g_fine_pointwise && ratio == 4 && final_size_host[0] == 4 * X && final_size_host[1] == 4 * Y && final_size_host[2] == 4 * Z) {
+    hipLaunchKernelGGL(k_fine_sample_voxel_rn<4>, dim3(cdiv((long long)(C <= 64 ? (n + 1) / 2 : n) * 64, 256)), dim3(256), 0,
+                       as_stream(stream), vol, C, X, Y, Z, coarse_lin, n, (float)(final_size_host[0] - 1),
+                       (float)(final_size_host[1] - 1), (float)(final_size_host[2] - 1), fine_xyz, feat, out_stride);
+    COOCC_LAUNCH_CHECK("k_fine_sample_voxel_rn");
     return COOCC_OK;
   }
   hipLaunchKernelGGL(k_fine_sample_voxel, dim3(cdiv(nf * 64, 256)), dim3(256), 0, as_stream(stream), vol, C, X, Y, Z,
@@ -294,98 +393,138 @@ extern "C" int coocc_projection_params(const float* rots, const float* trans, co
   return COOCC_OK;
 }
 
-// Grouped form for the offset-major fine list of the head (f = o*n + i, 8 children per coarse voxel): one wave per
-// coarse voxel.  Lane o*ncam + cam projects child o into camera cam (the 8*ncam projections run in parallel
-// instead of every lane repeating all of them); then lanes = channels and the (child, camera) pairs that see the
-// point are walked with wave-uniform readlanes.  Same expressions and accumulation order as k_fine_sample_img.
-__global__ __launch_bounds__(256) void k_fine_sample_img_g8(const float* __restrict__ img, int ncam, int Ci, int Hf, int Wf,
-                                                             const float* __restrict__ prm,
-                                                             const int64_t* __restrict__ fine_xyz, int n,
-                                                             float* __restrict__ feat, int out_stride) {
+// Grouped form for the offset-major fine list of the head (f = o*n + i, R^3 children per coarse voxel): one wave per
+// coarse voxel, 8 children per round (R^3 / 8 rounds).  Lane o8*ncam + cam projects child g*8 + o8 into camera cam (the
+// 8*ncam projections run in parallel instead of every lane repeating all of them); then lanes = channels and the (child,
+// camera) pairs that see the point are walked with wave-uniform readlanes.  Same expressions and accumulation order as
+// k_fine_sample_img.
+template <int R>
+__global__ __launch_bounds__(256) void k_fine_sample_img_grp(const float* __restrict__ img, int ncam, int Ci, int Hf, int Wf,
+                                                              const float* __restrict__ prm,
+                                                              const int64_t* __restrict__ fine_xyz, int n,
+                                                              float* __restrict__ feat, int out_stride) {
+  constexpr int R3 = R * R * R;
   const int i = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
-  const long long nf = (long long)n * 8;
-  int m = 0, x0 = 0, y0 = 0;
-  float ax = 0.f, ay = 0.f;
-  if (lane < 8 * ncam) {
-    const int o = lane / ncam, cam = lane - o * ncam;
-    // child o = (a*2 + b)*2 + c of coarse voxel i sits at (child 0) + (a, b, c): three wave-uniform reads instead of
-    // 3 x 48 scattered 8-byte ones (f = o*n + i)
-    const long long fx = fine_xyz[i] + (o >> 2), fy = fine_xyz[nf + i] + ((o >> 1) & 1), fz = fine_xyz[2 * nf + i] + (o & 1);
-    float p0 = (float)fx * prm[9] + prm[12];
-    float p1 = (float)fy * prm[10] + prm[13];
-    float p2 = (float)fz * prm[11] + prm[14];
-    float bx = prm[0] * p0 + prm[1] * p1 + prm[2] * p2;
-    float by = prm[3] * p0 + prm[4] * p1 + prm[5] * p2;
-    float bz = prm[6] * p0 + prm[7] * p1 + prm[8] * p2;
-    const float wimg1 = prm[15], himg1 = prm[16];
-    const float* q = prm + FINE_HDR + cam * FINE_CAM_STRIDE;
-    float tx = bx - q[9], ty = by - q[10], tz = bz - q[11];
-    float cx = q[0] * tx + q[1] * ty + q[2] * tz;
-    float cy = q[3] * tx + q[4] * ty + q[5] * tz;
-    float cz = q[6] * tx + q[7] * ty + q[8] * tz;
-    float ix = q[12] * cx + q[13] * cy + q[14] * cz;
-    float iy = q[15] * cx + q[16] * cy + q[17] * cz;
-    float d = q[18] * cx + q[19] * cy + q[20] * cz;
-    float u = ix / (d + 1e-5f), v = iy / (d + 1e-5f);
-    float u2 = q[21] * u + q[22] * v + q[25];
-    float v2 = q[23] * u + q[24] * v + q[26];
-    u2 = (u2 / wimg1 - 0.5f) * 2.f;
-    v2 = (v2 / himg1 - 0.5f) * 2.f;
-    m = (d > 1e-5f && u2 > -1.f && u2 < 1.f && v2 > -1.f && v2 < 1.f) ? 1 : 0;
-    float px = (u2 + 1.f) / 2.f * (float)(Wf - 1), py = (v2 + 1.f) / 2.f * (float)(Hf - 1);
-    float flx = floorf(px), fly = floorf(py);
-    x0 = (int)flx; y0 = (int)fly;
-    ax = px - flx; ay = py - fly;
-  }
-  // per (child, camera) lane: the four tap offsets (pixels, clamped into the map) and weights (0 outside the map), so the
-  // channel loop below only broadcasts them (readlane) and issues load + fma per tap
-  int toff[4]; float tw[4];
-#pragma unroll
-  for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-    for (int xx = 0; xx < 2; ++xx) {
-      const int x = x0 + xx, y = y0 + yy;
-      const bool in = (unsigned)x < (unsigned)Wf && (unsigned)y < (unsigned)Hf;
-      toff[yy * 2 + xx] = in ? y * Wf + x : 0;
-      tw[yy * 2 + xx] = in ? (xx ? ax : 1.f - ax) * (yy ? ay : 1.f - ay) : 0.f;
+  const long long nf = (long long)n * R3;
+  // child o = (a*R + b)*R + c of coarse voxel i sits at (child 0) + (a, b, c): three wave-uniform reads instead of
+  // 3 x 48 scattered 8-byte ones per round (f = o*n + i)
+  const long long x00 = fine_xyz[i], y00 = fine_xyz[nf + i], z00 = fine_xyz[2 * nf + i];
+#pragma unroll 1
+  for (int g = 0; g < R3 / 8; ++g) {
+    int m = 0, x0 = 0, y0 = 0;
+    float ax = 0.f, ay = 0.f;
+    if (lane < 8 * ncam) {
+      const int o8 = lane / ncam, cam = lane - o8 * ncam;
+      const int o = g * 8 + o8;
+      const long long fx = x00 + o / (R * R), fy = y00 + (o / R) % R, fz = z00 + o % R;
+      float p0 = (float)fx * prm[9] + prm[12];
+      float p1 = (float)fy * prm[10] + prm[13];
+      float p2 = (float)fz * prm[11] + prm[14];
+      float bx = prm[0] * p0 + prm[1] * p1 + prm[2] * p2;
+      float by = prm[3] * p0 + prm[4] * p1 + prm[5] * p2;
+      float bz = prm[6] * p0 + prm[7] * p1 + prm[8] * p2;
+      const float wimg1 = prm[15], himg1 = prm[16];
+      const float* q = prm + FINE_HDR + cam * FINE_CAM_STRIDE;
+      float tx = bx - q[9], ty = by - q[10], tz = bz - q[11];
+      float cx = q[0] * tx + q[1] * ty + q[2] * tz;
+      float cy = q[3] * tx + q[4] * ty + q[5] * tz;
+      float cz = q[6] * tx + q[7] * ty + q[8] * tz;
+      float ix = q[12] * cx + q[13] * cy + q[14] * cz;
+      float iy = q[15] * cx + q[16] * cy + q[17] * cz;
+      float d = q[18] * cx + q[19] * cy + q[20] * cz;
+      float u = ix / (d + 1e-5f), v = iy / (d + 1e-5f);
+      float u2 = q[21] * u + q[22] * v + q[25];
+      float v2 = q[23] * u + q[24] * v + q[26];
+      u2 = (u2 / wimg1 - 0.5f) * 2.f;
+      v2 = (v2 / himg1 - 0.5f) * 2.f;
+      m = (d > 1e-5f && u2 > -1.f && u2 < 1.f && v2 > -1.f && v2 < 1.f) ? 1 : 0;
+      float px = (u2 + 1.f) / 2.f * (float)(Wf - 1), py = (v2 + 1.f) / 2.f * (float)(Hf - 1);
+      float flx = floorf(px), fly = floorf(py);
+      x0 = (int)flx; y0 = (int)fly;
+      ax = px - flx; ay = py - fly;
     }
-  const unsigned long long seen = __ballot(m != 0);
-  for (int c = lane; c < Ci; c += 64) {
-    float acc[8];
+    // per (child, camera) lane: the four tap offsets (rows of the [ncam*Hf*Wf, Ci] map, clamped into it) and weights (0 outside
+    // the map or when the camera does not see the child), so the channel loop below only broadcasts them (readlane)
+    int toff[4]; float tw[4];
+    const int cbase = lane < 8 * ncam ? (lane % ncam) * Hf * Wf : 0;
+#pragma unroll
+    for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+      for (int xx = 0; xx < 2; ++xx) {
+        const int x = x0 + xx, y = y0 + yy;
+        const bool in = (unsigned)x < (unsigned)Wf && (unsigned)y < (unsigned)Hf;
+        toff[yy * 2 + xx] = cbase + (in ? y * Wf + x : 0);
+        tw[yy * 2 + xx] = (in && m) ? (xx ? ax : 1.f - ax) * (yy ? ay : 1.f - ay) : 0.f;
+      }
+    // Cameras that see each child, as wave-uniform bit fields.  Round r takes every child's r-th seeing camera (ascending:
+    // the accumulation order of k_fine_sample_img) and issues the 8 x 4 tap loads together -- walking the (child, camera)
+    // pairs one after the other put 30-40 dependent L2 round trips in a row (~20 k cycles per wave).  A child without an
+    // r-th camera rides along with weight 0 (x + 0 * v: finite features assumed, as everywhere in this branch).
+    const unsigned long long seen = __ballot(m != 0);
+    unsigned sub[8];
+    int rounds = 0;
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
-      acc[o] = 0.f;
-      for (int cam = 0; cam < ncam; ++cam) {
-        const int k = o * ncam + cam;
-        if (!((seen >> k) & 1ull)) continue;                       // wave-uniform
-        const float* base = img + (size_t)cam * Hf * Wf * Ci + c;
-        float a = acc[o];
+      sub[o] = (unsigned)(seen >> (o * ncam)) & ((1u << ncam) - 1u);
+      rounds = max(rounds, __popc(sub[o]));
+    }
+    // every lane stays in the channel loop (a lane past Ci works on a clamped column and skips the store): the readlanes
+    // below must not sit under a divergent branch -- registers of lanes that are inactive there are not preserved
+    for (int c0 = 0; c0 < Ci; c0 += 64) {
+      const int c = c0 + lane;
+      float acc[8];
+      unsigned left[8];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int off = __builtin_amdgcn_readlane(toff[t], k);
-          const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tw[t]), k));
-          if (w != 0.f) a = a + base[(size_t)off * Ci] * w;          // wave-uniform; keeps the reference's skipped taps skipped
+      for (int o = 0; o < 8; ++o) { acc[o] = 0.f; left[o] = sub[o]; }
+      const float* base = img + min(c, Ci - 1);
+#pragma unroll 1
+      for (int r = 0; r < rounds; ++r) {
+        float v[8][4], w[8][4];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          const bool has = left[o] != 0u;                                  // wave-uniform
+          const int k = has ? o * ncam + (__ffs((int)left[o]) - 1) : 0;
+          left[o] &= left[o] - 1u;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int off = __builtin_amdgcn_readlane(toff[t], k);
+            const float wt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tw[t]), k));
+            w[o][t] = has ? wt : 0.f;
+            v[o][t] = base[(size_t)off * Ci];
+          }
         }
-        acc[o] = a;
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[o] = acc[o] + v[o][t] * w[o][t];
+      }
+      if (c < Ci) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) feat[((size_t)(g * 8 + o) * n + i) * out_stride + c] = acc[o];
       }
     }
-#pragma unroll
-    for (int o = 0; o < 8; ++o) feat[((size_t)o * n + i) * out_stride + c] = acc[o];
   }
 }
 
 extern "C" int coocc_fine_sample_img(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf, const float* params,
-                                     const int64_t* fine_xyz, int64_t nfine, float* feat, int out_stride, int group8,
+                                     const int64_t* fine_xyz, int64_t nfine, float* feat, int out_stride, int group,
                                      void* stream) {
   COOCC_CHECK_ARG(img_nhwc && params && fine_xyz && feat && ncam > 0 && Ci > 0 && Ci % 2 == 0 && Ci <= 512,
                   "fine_sample_img: bad args (Ci even, <= 512)");
   if (nfine == 0) return COOCC_OK;
-  if (group8 && nfine % 8 == 0 && ncam <= 8 && nfine / 8 < (1ll << 31)) {
-    const int n = (int)(nfine / 8);
-    hipLaunchKernelGGL(k_fine_sample_img_g8, dim3(cdiv((long long)n * 64, 256)), dim3(256), 0, as_stream(stream), img_nhwc, ncam,
-                       Ci, Hf, Wf, params, fine_xyz, n, feat, out_stride);
-    COOCC_LAUNCH_CHECK("k_fine_sample_img_g8");
+  // group: 1 / 2 -> children of ratio 2, 4 -> ratio 4, anything else -> the list is taken point by point
+  const int R = (group == 1 || group == 2) ? 2 : group == 4 ? 4 : 0;
+  const int r3 = R * R * R;
+  if (R && !g_fine_pointwise && nfine % r3 == 0 && ncam <= 8 && nfine / r3 < (1ll << 31)) {
+    const int n = (int)(nfine / r3);
+    if (R == 2)
+      hipLaunchKernelGGL(k_fine_sample_img_grp<2>, dim3(cdiv((long long)n * 64, 256)), dim3(256), 0, as_stream(stream), img_nhwc,
+                         ncam, Ci, Hf, Wf, params, fine_xyz, n, feat, out_stride);
+    else
+      hipLaunchKernelGGL(k_fine_sample_img_grp<4>, dim3(cdiv((long long)n * 64, 256)), dim3(256), 0, as_stream(stream), img_nhwc,
+                         ncam, Ci, Hf, Wf, params, fine_xyz, n, feat, out_stride);
+    COOCC_LAUNCH_CHECK("k_fine_sample_img_grp");
     return COOCC_OK;
   }
   hipLaunchKernelGGL(k_fine_sample_img, dim3(cdiv(nfine * 64, 256)), dim3(256), 0, as_stream(stream), img_nhwc, ncam, Ci,

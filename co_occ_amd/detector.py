@@ -177,9 +177,12 @@ class COOCC_Ray(nn.Module):
         return self.decode(voxel_feats, gemo, img_feats, transform, render, dense_fine)
 
     def decode(self, voxel_feats, gemo=None, img_feats=None, transform=None, render=None, dense_fine=True,
-               depth_only=False, fine_size=None):
-        """Everything after ``extract_feat`` and before the metrics (coocc_ray.py:525-627)."""
+               depth_only=False, fine_size=None, after_encoder=None):
+        """Everything after ``extract_feat`` and before the metrics (coocc_ray.py:525-627).  ``after_encoder``: callback run
+        once the encoder's launches are enqueued (a serving loop with two samples in flight staggers them there)."""
         mid = self.semantic_encoder.forward_rows(voxel_feats)
+        if after_encoder is not None:
+            after_encoder()
         sem = self.semantic_neck.forward_rows(mid)
         output = self.pts_bbox_head(voxel_feats=sem, img_feats=img_feats, transform=transform)
         res = dict(voxel_feats=voxel_feats, pred_c=output['output_voxels'][0], pred_f=None,

@@ -200,8 +200,6 @@ class BiFuser_N(nn.Module):
 
     # ---------------------------------------------------------------- packing
     def _packed(self):
-        srcs = list(self.con_enc.parameters()) + list(self.con_enc.buffers()) + list(self.knn_enc.parameters())
-
         def build():
             d = build_packs()
             # con_enc opens the decoder: its rounding error is amplified by every later layer and goes straight into the
@@ -231,7 +229,7 @@ class BiFuser_N(nn.Module):
                 c0=PackedConv(self.con_enc[0].weight, bn=self.con_enc[1], ksize=3, pad=1),
                 c3=PackedConv(self.con_enc[3].weight, bn=self.con_enc[4], ksize=3, pad=1),
                 knn=PackedConv(self.knn_enc[0].weight, bias=self.knn_enc[0].bias, tap_major=True, taps=self.knum))
-        return self._packs.get(srcs, build)
+        return self._packs.get_modules((self.con_enc, self.knn_enc), build)
 
     # ---------------------------------------------------------------- K2-K5
     def fps_NN_fast(self, query, key, fps_num, radius, max_cluster_samples, dist_thresh, num):
@@ -288,7 +286,7 @@ class BiFuser_N(nn.Module):
         for i in range(2):
             call("coocc_compact_flags", ptr(flags[i]), B * V, ptr(lin[i]), ptr(counts[i:i + 1]), ptr(ws[i]),
                  ws[i].numel() * 4)
-        Ni, Np = (int(v) for v in counts.tolist())     # the one host sync of the stage (torch.nonzero does two)
+        Ni, Np = (int(v) for v in _lib.host_read(counts))     # the one host sync of the stage (torch.nonzero does two)
         self.last_counts = (Ni, Np)
         lin_img, lin_pts = lin[0, :Ni], lin[1, :Np]
         xyz = torch.empty(Ni + Np, 3, device=dev, dtype=_F32)

@@ -84,8 +84,6 @@ class OccHead(nn.Module):
 
     # ---------------------------------------------------------------- packing
     def _packed(self):
-        srcs = list(self.parameters()) + list(self.buffers())
-
         def seq2(m):
             return (PackedConv(m[0].weight, bn=m[1], bias=m[0].bias, ksize=1),
                     PackedConv(m[3].weight, bias=m[3].bias, ksize=1))
@@ -104,8 +102,10 @@ class OccHead(nn.Module):
                 if self.sample_from_voxel and self.fine_mlp[0].weight.shape[1] == 192:
                     d["img_nb"] = PackedConv(self.img_mlp[0].weight)                                  # bias added after sampling
                     d["f0_vox_nb"] = PackedConv(self.fine_mlp[0].weight[:, :128].contiguous())
+            if hasattr(self, "img_mlp") and hasattr(self, "fine_mlp"):     # the fused fine-branch kernel loads 16-byte vectors
+                d["mlp_aligned"] = all(q.data_ptr() % 16 == 0 for m in (self.img_mlp, self.fine_mlp) for q in m.parameters())
             return d
-        return self._packs.get(srcs, build)
+        return self._packs.get_modules((self,), build)
 
     # ---------------------------------------------------------------- C3
     def forward_coarse_rows(self, voxel_feats):
@@ -157,7 +157,7 @@ class OccHead(nn.Module):
             call("coocc_groupnorm_nhwc", ptr(g), N_i, Hf * Wf, g.shape[1], gn.num_groups, ptr(gn.weight.detach()),
                  ptr(gn.bias.detach()), float(gn.eps), 1)
             params = self._projection_params(transform, ovf, dev)
-        n = int(cnt.item())
+        n = int(_lib.host_read(cnt)[0])
         assert n > 0, 'no foreground in coarse voxel'
         nf = n * r ** 3
         fine_xyz = torch.empty(3, nf, device=dev, dtype=_I64)
@@ -165,7 +165,7 @@ class OccHead(nn.Module):
         # one launch for Linear+GN+ReLU -> cat -> Linear+GN+ReLU -> Linear when both samples feed the MLPs
         fused = (FUSED_FINE_MLP and use_img and self.sample_from_voxel and ovf.C == 128 and g.shape[1] == 128
                  and self.out_channel <= 32 and self.img_mlp[1].num_groups == 16 and self.fine_mlp[1].num_groups == 16
-                 and all(q.data_ptr() % 16 == 0 for m in (self.img_mlp, self.fine_mlp) for q in m.parameters()))
+                 and p.get("mlp_aligned", False))
         if fused and FINE_LINEAR_FIRST and "img_nb" in p:
             # Linear(128->64) of img_mlp on the 6 x Hf x Wf feature map and the voxel half of fine_mlp[0] on the V coarse
             # voxels instead of on the 8 V fine points: a Linear commutes with the interpolation that follows it
@@ -175,7 +175,7 @@ class OccHead(nn.Module):
             call("coocc_fine_sample_voxel", ptr(Q), 64, ovf.X, ovf.Y, ovf.Z, ptr(lin), n, r,
                  host_i32(self.final_occ_size), ptr(fine_xyz), ptr(vq), 64)
             samp = torch.empty(nf, 64, device=dev, dtype=_F32)
-            call("coocc_fine_sample_img", ptr(P), N_i, 64, Hf, Wf, ptr(params), ptr(fine_xyz), nf, ptr(samp), 64, 1 if r == 2 else 0)
+            call("coocc_fine_sample_img", ptr(P), N_i, 64, Hf, Wf, ptr(params), ptr(fine_xyz), nf, ptr(samp), 64, r if r in (2, 4) else 0)
             li, gi, l0, g0, l3 = self.img_mlp[0], self.img_mlp[1], self.fine_mlp[0], self.fine_mlp[1], self.fine_mlp[3]
             logits = torch.empty(nf, self.out_channel, device=dev, dtype=_F32)
             d = lambda t: ptr(t.detach())
@@ -192,7 +192,7 @@ class OccHead(nn.Module):
         if use_img:
             samp = torch.empty(nf, g.shape[1], device=dev, dtype=_F32)
             call("coocc_fine_sample_img", ptr(g), N_i, g.shape[1], Hf, Wf, ptr(params), ptr(fine_xyz), nf, ptr(samp),
-                 samp.shape[1], 1 if r == 2 else 0)
+                 samp.shape[1], r if r in (2, 4) else 0)
             if fused:
                 li, gi, l0, g0, l3 = self.img_mlp[0], self.img_mlp[1], self.fine_mlp[0], self.fine_mlp[1], self.fine_mlp[3]
                 logits = torch.empty(nf, self.out_channel, device=dev, dtype=_F32)

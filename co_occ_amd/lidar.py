@@ -214,8 +214,6 @@ class _SparseEncoderBase(nn.Module):
         self._packs = PackCache(self)
 
     def _packed(self):
-        srcs = list(self.parameters()) + list(self.buffers())
-
         def build():
             d = dict(inp=self.conv_input[0].packed(), out=self.conv_out[0].packed(), stages=[])
             for st in (self.conv1, self.conv2, self.conv3):
@@ -227,7 +225,7 @@ class _SparseEncoderBase(nn.Module):
                         ps.append(("block", m.net[0].packed(bn=m.net[1]), m.net[3].packed(bn=m.net[4])))
                 d["stages"].append(ps)
             return d
-        return self._packs.get(srcs, build)
+        return self._packs.get_modules((self,), build)
 
     def forward(self, voxel_features, coors, batch_size=1):
         """voxel_features [M,Cin], coors [M,3] (z,y,x) or [M,4] (b,z,y,x) -> dict(x=[1,C,W,H,D] dense volume (channels-last

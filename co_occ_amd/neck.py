@@ -40,13 +40,11 @@ class FPN3D(nn.Module):
         self._packs = PackCache(self)
 
     def _packed(self):
-        srcs = list(self.parameters()) + list(self.buffers())
-
         def build():
             return dict(
                 lat=[PackedConv(m[0].conv.weight, bn=m[0].bn, bias=m[0].conv.bias, ksize=1) for m in self.lateral_convs],
                 out=[PackedConv(m[0].conv.weight, bn=m[0].bn, bias=m[0].conv.bias, ksize=3, pad=1) for m in self.fpn_convs])
-        return self._packs.get(srcs, build)
+        return self._packs.get_modules((self,), build)
 
     def forward_rows(self, inputs):
         assert len(inputs) == len(self.in_channels)

@@ -55,7 +55,7 @@ class MLP(nn.Module):
     def _packed(self):
         def build():
             return [PackedConv(l.weight, bias=l.bias) for l in list(self.hidden_layers) + [self.output_layer]]
-        return self._packs.get(list(self.parameters()), build)
+        return self._packs.get_modules((self,), build)
 
     def forward_rows(self, x2d, out=None, out_coff=0):
         p = self._packed()

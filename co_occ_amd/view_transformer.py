@@ -155,19 +155,29 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         sensor2ego = torch.cat([rot, tran.reshape(B, N, 3, 1)], dim=-1).reshape(B, N, -1)
         return torch.cat([mlp_input, sensor2ego], dim=-1)
 
+    def _grid_host(self):
+        """(X, Y, Z) and [lo(3), dx(3)] of the pooling grid as host numbers.  nx / bx / dx are Parameters as upstream, so they
+        live on the device after ``.to()``: reading them per call would be three device->host synchronisations per sample;
+        the host copy is refreshed whenever one of them is written (``load_state_dict`` bumps ``_version``)."""
+        key = (self.nx._version, self.bx._version, self.dx._version, self.nx.data_ptr())
+        if getattr(self, "_grid_host_key", None) != key:
+            nx = tuple(int(v) for v in self.nx.tolist())
+            lo = (self.bx - self.dx / 2.).tolist() + self.dx.tolist()
+            self._grid_host_val, self._grid_host_key = (nx, lo), key
+        return self._grid_host_val
+
     def voxel_pooling(self, geom_feats, x):
         """ViewTransformerLSSVoxel.py:100-123: geom [B,N,D,H,W,3], x [B,N,D,H,W,C] -> [B,C,X,Y,Z]
         (a channels-last view).  Truncate-then-filter quantisation and the pooling run in the
         library without argsort / boolean-mask compaction."""
         B, N, D, H, W, C = x.shape
         Nprime = B * N * D * H * W
-        X, Y, Z = (int(v) for v in self.nx.tolist())
+        (X, Y, Z), lo = self._grid_host()
         xf = x.reshape(Nprime, C).float().contiguous()
         g = geom_feats.reshape(Nprime, 3).float().contiguous()
-        lo = (self.bx - self.dx / 2.).tolist()
         out = torch.empty(B * X * Y * Z, C, device=x.device, dtype=_F32)
         ws = _pool_workspace(x.device, Nprime, B * X * Y * Z)
-        call("coocc_voxel_pool", ptr(xf), ptr(g), Nprime, Nprime // B, C, host_f32(lo + self.dx.tolist()), B, X, Y, Z,
+        call("coocc_voxel_pool", ptr(xf), ptr(g), Nprime, Nprime // B, C, host_f32(lo), B, X, Y, Z,
              ptr(out), C, ptr(ws), ws.numel())
         return out.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
 
@@ -181,11 +191,11 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         D = depth_prob.shape[1]
         assert tuple(depth_prob.shape) == (BN, D, H, W) and (geom_feats is None) != (cams is None)
         B = geom_feats.shape[0] if cams is None else cams[1].shape[0]
-        X, Y, Z = (int(v) for v in self.nx.tolist())
+        (X, Y, Z), lo = self._grid_host()
+        lo = host_f32(lo)
         dev = img_feat.device
         feat = torch.empty(BN * H * W, C, device=dev, dtype=_F32)
         call("coocc_ncdhw_to_ndhwc", ptr(img_feat.float().contiguous()), ptr(feat), BN, C, H * W, C, 0)
-        lo = host_f32((self.bx - self.dx / 2.).tolist() + self.dx.tolist())
         npts = BN * D * H * W
         if out is None:
             out_t, out_stride, out_ptr = torch.empty(B * X * Y * Z, C, device=dev, dtype=_F32), C, None

@@ -340,12 +340,12 @@ int coocc_fine_sample_voxel(const float* vol, int C, int X, int Y, int Z, const 
  * summed over cameras (coordinate_transform.py:25-65, occ_head.py:217-234).  img_nhwc:
  * [ncam,Hf,Wf,Ci]; params (device): [0:9] inv(bda), [9:12] voxel_size, [12:15] range_lo,
  * [15] W_img-1, [16] H_img-1, then per camera 27 floats: inv(rots)[9], trans[3], intrins[9],
- * post_rots[:2,:2][4], post_trans[:2][2].  group8 != 0: fine_xyz is the offset-major list of
- * coocc_fine_sample_voxel with ratio 2 (f = o*n + i, child o = (a*2+b)*2+c at (child 0) + (a,b,c), 8 children per
- * coarse voxel): one wave per coarse voxel, child coordinates derived from child 0. */
+ * post_rots[:2,:2][4], post_trans[:2][2].  group = R in {2, 4} (1 is read as 2): fine_xyz is the offset-major list of
+ * coocc_fine_sample_voxel with ratio R (f = o*n + i, child o = (a*R+b)*R+c at (child 0) + (a,b,c), R^3 children per
+ * coarse voxel): one wave per coarse voxel, child coordinates derived from child 0.  Other values: point by point. */
 int coocc_fine_sample_img(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf,
                           const float* params, const int64_t* fine_xyz, int64_t nfine, float* feat,
-                          int out_stride, int group8, void* stream);
+                          int out_stride, int group, void* stream);
 /* Builds the `params` block of coocc_fine_sample_img on the device (3x3 inverses included, no host sync):
  * rots/intrins/post_rots:[ncam,3,3], trans/post_trans:[ncam,3], bda:[3,3] (device); hdr_host:[8] = voxel_size(3),
  * range_lo(3), W_img-1, H_img-1; params:[17 + 27*ncam] (device). */

@@ -9,7 +9,8 @@ import torch
 import co_occ_amd as pkg
 import co_occ_amd.synth as synth
 from co_occ_amd import core, render as R
-from co_occ_amd._lib import call, ptr
+from co_occ_amd import _lib
+from co_occ_amd._lib import call, ptr, host_f32, host_i32
 from oracle import cases, ref_cpu
 from util import assert_close
 
@@ -412,7 +413,7 @@ def test_ray_sharded_render_equals_whole_render(dev):
 
 def test_occhead_cascade_ratio_4_vs_oracle(dev):
     """OpenOccupancy-style head (config 5: coarse grid x4 -> fine grid, `coocc_multi_r101_openoccupancy.py`): 64 children
-    per occupied coarse voxel through the generic (one wave per fine point) sampling kernels."""
+    per occupied coarse voxel through the grouped (one wave per coarse voxel) sampling kernels."""
     c = cases.DECODER_CASE
     grid, ratio = (8, 8, 4), 4
     final = tuple(v * ratio for v in grid)
@@ -625,3 +626,48 @@ def test_con_enc0_split_by_channel_support_equals_dense_form(dev, golden, monkey
         assert any("c0-sparse" in t for t in tags) == split, tags
     assert_close(outs[True], outs[False], tol=2e-5, what="split vs dense con_enc.0")
     assert_close(outs[True], g["out"], what=name + " split con_enc.0 vs golden")
+
+
+@pytest.mark.parametrize("ratio,C", [(2, 64), (2, 128), (4, 64), (4, 128), (4, 16)])
+def test_grouped_fine_samplers_equal_point_by_point_kernels(dev, ratio, C):
+    """C4 samplers: the one-wave-per-coarse-voxel kernels (cascade ratio 2 and 4) against the one-wave-per-fine-point kernels of
+    the same library -- same bits (values and fine coordinates), every coarse voxel of a grid with all its borders selected."""
+    X, Y, Z = 9, 7, 5
+    g = torch.Generator().manual_seed(ratio * 100 + C)
+    vol = torch.randn(X * Y * Z, C, generator=g).to(dev)
+    lin = torch.randperm(X * Y * Z, generator=g)[: X * Y * Z - 11].to(torch.int32).to(dev)
+    n, r3 = lin.numel(), ratio ** 3
+    final = host_i32([X * ratio, Y * ratio, Z * ratio])
+
+    def vox():
+        xyz = torch.full((3, n * r3), -1, device=dev, dtype=torch.int64)
+        feat = torch.full((n * r3, C + 4), 7.0, device=dev)
+        call("coocc_fine_sample_voxel", ptr(vol), C, X, Y, Z, ptr(lin), n, ratio, final, ptr(xyz), ptr(feat), C + 4)
+        return xyz, feat
+    lib = _lib.load()
+    xyz_g, feat_g = vox()
+    lib.coocc_fine_set_pointwise(1)
+    try:
+        xyz_p, feat_p = vox()
+    finally:
+        lib.coocc_fine_set_pointwise(0)
+    assert torch.equal(xyz_g, xyz_p)
+    assert torch.equal(feat_g, feat_p)
+    assert torch.equal(feat_g[:, C:], torch.full_like(feat_g[:, C:], 7.0))
+
+    ncam, Hf, Wf = 6, 8, 22
+    rig = synth.camera_rig(ncam, (128, 352), seed=5)
+    img = torch.randn(ncam * Hf * Wf, C, generator=g).to(dev)
+    prm = torch.empty(17 + 27 * ncam, device=dev)
+    hdr = host_f32([100.0 / (X * ratio), 100.0 / (Y * ratio), 8.0 / (Z * ratio), -50.0, -50.0, -5.0, 351.0, 127.0])
+    d = lambda k: rig[k].float().contiguous().to(dev)
+    keep = [d(k) for k in ("rots", "trans", "intrins", "post_rots", "post_trans")] + [rig["bda"][0].float().contiguous().to(dev)]
+    call("coocc_projection_params", *[ptr(t) for t in keep], ncam, hdr, ptr(prm))
+    outs = []
+    for group in (ratio, 0):
+        samp = torch.full((n * r3, C + 2), 3.0, device=dev)
+        call("coocc_fine_sample_img", ptr(img), ncam, C, Hf, Wf, ptr(prm), ptr(xyz_g), n * r3, ptr(samp), C + 2, group)
+        outs.append(samp)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0][:, C:], torch.full_like(outs[0][:, C:], 3.0))
+    assert float(outs[0][:, :C].abs().sum()) > 0

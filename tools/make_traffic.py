@@ -54,7 +54,7 @@ def main():
         out["k_render_nearest+k_upsample_maps"] = {cfg: dict(bytes_per_launch=rays["bytes_per_launch"] + ups["bytes_per_launch"],
                                                              rays=rays, upsample=ups)}
     for sym in ("k_wino_in<6>", "k_wino_out<6>", "k_wino_in<4>", "k_wino_out<4>", "k_pool_sum_csr<true>", "k_key_hist", "k_fuser_prepare_rows",
-                "k_fine_mlp<true>", "k_fine_sample_img_g8", "k_fine_sample_voxel_r2"):
+                "k_fine_mlp<true>", "k_fine_sample_img_grp", "k_fine_sample_voxel_r2"):
         d = per_launch("void " + sym) or per_launch(sym)
         if d:
             out[sym] = d
