@@ -396,9 +396,11 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="r50", choices=sorted(synth.CONFIGS))
-    ap.add_argument("--streams", type=int, default=1,
-                    help="dense stages in flight: S host threads / HIP streams, sample i on stream i mod S.  Default 1: measured "
-                         "A/B on one box (profiles/r2_streams_ab.txt) 110.6 / 111.4 samples/s at S = 1 vs 104.2 / 99.4 at S = 2")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="dense stages in flight: S host threads / HIP streams, sample i on stream i mod S.  Default 2: one "
+                         "sample's low-occupancy tail (25x25x2 / 13x13x1 layers, heads, fine branch) runs under the other's GEMMs; "
+                         "profiles/r2_streams_ab.txt: 120.4-127.0 samples/s over 12 processes at S = 2 against 112.5-116.3 at S = 1 "
+                         "(since the host issue path was shortened; before, S = 2 fell into a host-bound mode in 3 of 10 runs)")
     ap.add_argument("--stagger", type=int, default=0,
                     help="with --streams > 1: 1 = sample i+1 enters its dense stage after sample i finished the fuser, 2 = after "
                          "its encoder (fixed phase offset between the dense stages in flight); 0 = free running")
@@ -476,7 +478,7 @@ def main():
         DIAG["search_blocked_s"].append(_lib.blocked_seconds() - b0)
         return img, sr
 
-    def run(nsteps, timed):
+    def run(nsteps, timed, S=S):
         """`nsteps` samples over S dense streams (one host thread each; S = 1: a single driver thread).  Sample i runs its
         dense stage (fuser finish -> encoder -> neck -> head -> render) on stream i mod S; its pooling + index search were
         issued S samples earlier on a prefetch stream by a helper thread, so they overlap the dense stages in flight.  With
@@ -565,19 +567,25 @@ def main():
     roof, extra = rooflines(core.TIMER.summary(), args.steps, args, rank, args.kernel_table)
     if S > 1 and not args.no_kernel_timing:
         # Kernel durations inside the S-stream pipeline include the contention between the samples in flight (that is the
-        # point of it: one sample's low-occupancy tail runs under the other's GEMMs).  A short sequential pass -- one stream,
-        # no prefetch, nothing else on the GPU -- gives each kernel's own rate next to it.
-        n_iso = max(4, min(10, args.steps // 4))
+        # point of it: one sample's low-occupancy tail runs under the other's GEMMs).  A short pass of the same pipeline with ONE
+        # sample in flight (the next sample's pooling + search still prefetched) gives each kernel's own rate next to it.
+        n_iso = max(8, min(20, args.steps // 2))
+        run(3, False, S=1)
         core.TIMER.enabled, core.TIMER.only = 1, ("k_conv", "k_render_nearest", "k_lift_splat")
         core.TIMER.reset()
-        with torch.no_grad(), torch.cuda.stream(streams[0]):
-            for i in range(n_iso):
-                step(model, samples[i % len(samples)], 1)
+        run(n_iso, False, S=1)
         torch.cuda.synchronize()
         core.TIMER.enabled = False
         r_iso, e_iso = rooflines(core.TIMER.summary(), n_iso, args, rank, False)
         core.TIMER.reset()
-        extra["roofline_isolated"] = dict(r_iso or {}, note="separate sequential pass after the timed region (1 stream, no prefetch)",
+        if roof and r_iso and r_iso.get("kernel") == roof.get("kernel"):
+            # the same kernel with nothing else on the GPU, inside the headline object: a launch that shares the CUs with the
+            # other sample in flight takes longer while the GPU as a whole does more work per unit time
+            roof.update(achieved_alone=r_iso["achieved"], frac_alone=r_iso["frac"], avg_launch_ms_alone=r_iso["avg_launch_ms"],
+                        note="achieved / frac: HIP-event durations inside the timed %d-sample pipeline (launches of two samples "
+                             "share the CUs); *_alone: the same launches with one sample in flight, measured after the timed "
+                             "region (roofline_isolated)" % S)
+        extra["roofline_isolated"] = dict(r_iso or {}, note="separate pass after the timed region: the same pipeline with one sample in flight (--streams 1)",
                                           all_convs=e_iso.get("roofline_all_convs"), render=e_iso.get("roofline_render"),
                                           pool=e_iso.get("roofline_pool"))
     if rank == 0 and args.config == "r50" and not args.no_kernel_timing:

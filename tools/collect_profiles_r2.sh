@@ -7,9 +7,9 @@ O=$R/gpurun_out/prof_r2
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 300 python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1      # clocks / caches warm before the recorded runs
-timeout 400 python $R/bench.py --steps 50 --warmup 3 > $O/r2_bench_default.json 2> $O/r2_bench_default.err
-timeout 300 python $R/bench.py --steps 50 --warmup 3 --streams 2 --no-cpu-baseline > $O/r2_bench_streams2.json 2>/dev/null
-timeout 300 python $R/bench.py --steps 50 --warmup 3 --no-cpu-baseline --kernel-table > $O/r2_bench_kernel_table.json 2> $O/r2_bench_kernel_table.txt
+timeout 400 python $R/bench.py > $O/r2_bench_default.json 2> $O/r2_bench_default.err                     # the driver's command (S = 2)
+timeout 300 python $R/bench.py --steps 50 --warmup 3 --streams 1 --no-cpu-baseline > $O/r2_bench_streams1.json 2>/dev/null
+timeout 300 python $R/bench.py --steps 50 --warmup 3 --streams 1 --no-cpu-baseline --kernel-table > $O/r2_bench_kernel_table.json 2> $O/r2_bench_kernel_table.txt
 for S in 1 2; do
   rm -rf /tmp/p_stats$S
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats$S -o b -- python $R/bench.py --steps 10 --warmup 3 --streams $S --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
@@ -43,6 +43,6 @@ timeout 300 python $R/bench.py --config openocc --steps 10 --warmup 2 > $O/r2_be
 timeout 300 python $R/bench.py --config openocc --dtype bf16 --steps 10 --warmup 2 > $O/r2_bench_openocc_bf16.json 2>/dev/null
 timeout 300 python $R/bench.py --config stress200 --steps 6 --warmup 1 --no-cpu-baseline > $O/r2_bench_stress200.json 2>/dev/null
 timeout 600 python $R/tools/kbench.py fps knn conv render pool > $O/r2_kbench.txt 2>&1
-python $R/tools/kstats.py $O/r2_bench_streams1_kernel_stats.csv 16 < /dev/null
+python $R/tools/kstats.py $O/r2_bench_streams2_kernel_stats.csv 16 < /dev/null
 cut -c1-900 $O/r2_bench_default.json
 head -14 $O/r2_bench_pmc_hbm.txt; head -8 $O/r2_bench_pmc_sq.txt
