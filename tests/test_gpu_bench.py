@@ -1,0 +1,57 @@
+"""bench.py's contract, end to end on one GPU: the one-JSON-line output with ``roofline`` / ``cpu_baseline``-less fast settings,
+and the N > 1 path (one process per rank under torch.distributed.run, two dense streams per rank, ticketed collectives) with both
+ranks on cuda:0 over gloo -- the control flow the driver's scaling run takes, minus RCCL."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_streams_line_has_the_contract_fields():
+    d = _run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["unit"] == "samples/s" and d["scaling"] == "weak"
+    assert d["config"]["samples_in_flight"] == 2 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0 < r["frac_alone"] < 1 and "roofline_isolated" in d and "roofline_render_r101" in d and "roofline_pool" in d
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 0.05 * d["value"]
+
+
+def test_two_ranks_two_streams_each_on_one_gpu():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", str(port), "bench.py", "--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "6",
+              "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timing"])
+    assert d["n_gpus"] == 2 and d["world_size_seen_by_backend"] == 2 and d["backend"] == "gloo"
+    assert d["config"]["samples_in_flight"] == 2
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 0.05 * d["value"]      # whole-job rate: both ranks' samples
+
+
+def test_world_size_mismatch_fails_loudly():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29512")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "process group has 1 rank" in (p.stderr + p.stdout)
