@@ -36,6 +36,7 @@ SIGNATURES = {
     "coocc_stream_create_cu_mask": (I, [P, I, P]),
     "coocc_stream_destroy": (I, [P]),
     "coocc_ncdhw_to_ndhwc": (I, [P, P, I, I, I, I, I, P]),
+    "coocc_rows_to_bf16": (I, [P, I, L, I, P, P]),
     "coocc_ndhwc_to_ncdhw": (I, [P, P, I, I, I, I, I, P]),
     "coocc_fuser_prepare": (I, [P, P, P, P, P, I, I, I, P]),
     "coocc_fuser_prepare_rows": (I, [P, I, I, P, I, I, P, P, P, I, I, I, P]),

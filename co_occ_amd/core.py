@@ -152,6 +152,8 @@ class PackedConv:
         self._w_cube = w.view(self.Cout, self.Cin, 3, 3, 3) if (ksize == 3 and not tap_major and taps == 27) else None
         self._ztrim = {}
         self._wino = {}
+        self._bf16 = {}
+        self._w_taps = w if not tap_major else None      # [Cout, Cin, taps] on the host: source of the bf16 packs
         self.wino_tile = None        # per-layer override of WINO_TILE (2 | 3 | 4)
         lib = _lib.load()
         n = lib.coocc_conv_pack_weights(ctypes.c_void_p(w.data_ptr()), self.Cout, self.Cin, taps, int(tap_major), None)
@@ -180,6 +182,23 @@ class PackedConv:
                                         ctypes.c_void_p(packed.data_ptr()))
             self._ztrim[(lo, hi)] = packed.to(self.w.device)
         return self._ztrim[(lo, hi)]
+
+    def bf16_pack(self, ztrim=None):
+        """bf16 pack of k_conv_bf16g: [(64-channel chunk, tap)][roundup(Cout,128)][64] (RNE), for all taps or, with
+        ``ztrim=(lo, hi)``, for the z taps lo..hi of a 3x3x3 kernel only.  None when the layer cannot take that kernel."""
+        if self._w_taps is None or self.Cin % 64:
+            return None
+        if ztrim not in self._bf16:
+            w = self._w_taps
+            if ztrim is not None:
+                w = self._w_cube[:, :, :, :, ztrim[0]:ztrim[1] + 1].reshape(self.Cout, self.Cin, -1)
+            taps = w.shape[2]
+            npad = -(-self.Cout // 128) * 128
+            wp = torch.zeros(npad, self.Cin, taps, dtype=_F32)
+            wp[:self.Cout] = w
+            pack = wp.view(npad, self.Cin // 64, 64, taps).permute(1, 3, 0, 2).contiguous().to(torch.bfloat16)
+            self._bf16[ztrim] = pack.to(self.w.device)
+        return self._bf16[ztrim]
 
     def wino_pack(self, tile):
         """(tile+2)^2 packs (one per transform point p = (tile+2)*xi + eta) of U[p][dz] = (G g G^T)[xi][eta][dz],
@@ -210,6 +229,19 @@ class PackedConv:
 
 _ws_cache = {}
 _wino_ws = {}
+_bf16_ws = {}
+# bf16 path: 1 = round the activations to bf16 in memory once per layer and run k_conv_bf16g (operands staged by
+# global_load_lds); 0 = k_conv_bf16 (fp32 operands rounded inside the K loop)
+BF16_PRECONVERT = __import__("os").environ.get("COOCC_BF16_PRECONVERT", "1") != "0"
+
+
+def _bf16_buffer(device, n):
+    key = (device.index, _lib.stream(device).value)
+    t = _bf16_ws.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(n, device=device, dtype=torch.bfloat16)
+        _bf16_ws[key] = t
+    return t
 
 
 def _wino_buffer(device, kind, nfloats):
@@ -349,18 +381,27 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
     d.tile_hint = TILE_HINT
     d.mfma_dtype = 1 if bf16 else 0
     taps = pc.taps
+    trim = None
     if ZTRIM and pc._w_cube is not None:
         # z taps that are in range for at least one output z; on thin grids (Z = 1, 2) the rest only multiply padding
         ok = [kz for kz in range(3) if any(0 <= zo * pc.stride - pc.pad + kz < x.Z for zo in range(Zo))]
         lo, hi = ok[0], ok[-1]
         if hi - lo + 1 < 3:
+            trim = (lo, hi)
             d.w = ptr(pc.ztrim_pack(lo, hi))
             d.kx, d.ky, d.kz, d.px, d.py, d.pz = 3, 3, hi - lo + 1, pc.pad, pc.pad, pc.pad - lo
             d.taps = taps = 9 * (hi - lo + 1)
+    if bf16 and BF16_PRECONVERT and pc.Cin % 64 == 0 and pc._w_taps is not None and taps > 1:    # 1x1x1: HBM-bound either way
+        # operands bf16 in memory (k_conv_bf16g): the activations are rounded once per layer into a scratch buffer, the
+        # weights once per pack
+        xb = _bf16_buffer(x.t.device, x.B * x.V * pc.Cin)
+        call("coocc_rows_to_bf16", x.data(), x.stride, x.B * x.V, pc.Cin, ptr(xb))
+        wb = pc.bf16_pack(trim)
+        d.in_, d.in_stride, d.w, d.mfma_dtype = ptr(xb), pc.Cin, ptr(wb), 2
     if not TIMER.enabled:
         _lib.conv_fwd(d, pc.w.device)
         return out
-    kname = "k_conv_bf16" if bf16 else conv_kernel_name(M, pc.Cout, False, 0, taps * -(-pc.Cin // 32),
+    kname = ("k_conv_bf16g" if d.mfma_dtype == 2 else "k_conv_bf16") if bf16 else conv_kernel_name(M, pc.Cout, False, 0, taps * -(-pc.Cin // 32),
                                                          pc.ksize == 1 and pc.stride == 1 and pc.pad == 0)
     with TIMER.region(kname, 2.0 * M * pc.Cin * pc.Cout * taps):
         _lib.conv_fwd(d, pc.w.device)

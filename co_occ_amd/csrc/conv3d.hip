@@ -36,6 +36,7 @@ struct ConvK {
   int mtiles, ntiles, mtiles_per_xcd;
   size_t in_bytes;              // total input bytes (k_conv2 bases its buffer descriptor at the tile's first row)
   unsigned w_bytes;             // bytes of one weight pack
+  const void* zrow;             // k_conv_bf16g: 16 zero bytes in global memory (source of padded / out-of-range rows)
 };
 
 __device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t rrow) {
@@ -378,6 +379,183 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16(ConvK p) {
         }
       }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_bf16g (mfma_dtype 2): the same arithmetic as k_conv_bf16 with both operands ALREADY bf16 in memory -- activations
+// as [rows][Cin] bf16 (coocc_rows_to_bf16: same RNE rounding, done once per layer instead of 27 times per element inside the
+// K loop), weights packed [iteration = (64-channel chunk, tap)][Npad][64] bf16 -- and staged by global_load_lds (16 B per
+// lane straight into LDS: no staging VGPRs, no conversion VALU work, no ds_write pass).  k_conv_bf16 moved 64 KB of fp32
+// operands per 128 x 128 x 64 step through registers: 128 B/clk per workgroup against ~64 B/clk a CU can pull from L2, which is
+// what held it at 0.13 of the bf16 peak; here a step moves 32 KB.  The LDS image of a tile is lane-linear (a wave's 64 lanes
+// fill 8 rows x 128 B), so the bank-conflict swizzle sits on the SOURCE side: 16-byte slot c of row r holds channel chunk
+// c ^ ((r >> 1) & 7), and the fragment reads apply the same XOR (16 consecutive rows x one chunk = 64 distinct banks).
+// Out-of-range taps / rows read 16 zero bytes from `zrow`.  One barrier per K step, loads of step i+1 in flight under the
+// MFMAs of step i.  128 x 128 tile, 2 x 2 waves of 64 x 64; Cin % 64 == 0.
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l,
+                                   16, 0, 0);
+}
+
+// Variants measured on MI355X at the OpenOccupancy shapes (tools/kbench.py convbf16, TFLOP/s of the whole layer incl. the
+// conversion pass): this form 620-690; K steps of 32 with four workgroups per CU 585-670; a 256 x 128 tile with three LDS stages,
+// counted vmcnt and raw barriers (one workgroup per CU; 4 waves of 128 x 64 or 8 waves of 64 x 64) 425-670.  PMC: MFMA pipe busy
+// 36 %, no LDS bank conflicts, little instruction wait: every variant sits at the same L2 -> LDS operand rate (~10 TB/s over the
+// chip), so the next step is fewer operand bytes per flop (taps served from an LDS-resident halo block), not scheduling.
+__global__ __launch_bounds__(256, 2) void k_conv_bf16g(ConvK p) {
+  constexpr int BK = 64;
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+  constexpr int CPR = BK / 8;            // 16-byte chunks per LDS row
+  constexpr int RPI = 64 / CPR;          // tile rows one wave instruction fills
+  constexpr int NI = BM / (4 * RPI);     // instructions per operand tile and thread
+  constexpr int HALVES = 64 / BK;        // K steps per pack iteration
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * BK];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * BK];
+
+  const int id = blockIdx.x;
+  int mtile, nt, slot_ = id >> 3;
+  if (p.mtiles_per_xcd > 0) {
+    const int xcd = id & 7;
+    const int mt_local = slot_ / p.ntiles;
+    nt = slot_ - mt_local * p.ntiles;
+    mtile = xcd * p.mtiles_per_xcd + mt_local;
+    if (mt_local >= p.mtiles_per_xcd || mtile >= p.mtiles) return;
+  } else {
+    mtile = id / p.ntiles;
+    nt = id - mtile * p.ntiles;
+  }
+  const int m0 = mtile * BM, n0 = nt * BN;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, h = lane >> 5;
+  const int srow = lane / CPR, slot = lane % CPR;
+  auto key = [](int r) { return BK == 64 ? (r >> 1) & 7 : (r >> 2) & 3; };
+
+  // staging: instruction j of wave w fills tile rows (j*4 + w)*RPI .. +RPI-1; this lane: row (j*4 + w)*RPI + srow, slot `slot`
+  int rix[NI], riy[NI], riz[NI];
+  long long abase[NI];        // byte offset of (row of tap (0,0,0), this lane's channel chunk)
+  unsigned boff[NI];          // byte offset of this lane's piece inside one iteration's weight tile
+  const long long rowbytes = (long long)p.in_stride * 2;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int r = (j * 4 + wave) * RPI + srow;
+    const int m = m0 + r;
+    int oz = m % p.Zo; int q = m / p.Zo;
+    int oy = q % p.Yo; q /= p.Yo;
+    int ox = q % p.Xo; int b = q / p.Xo;
+    rix[j] = m < p.M ? ox * p.stride - p.px : -(1 << 20);      // a row past M fails every bounds test below
+    riy[j] = oy * p.stride - p.py;
+    riz[j] = oz * p.stride - p.pz;
+    const unsigned qo = (unsigned)((slot ^ key(r)) * 16);
+    abase[j] = ((((long long)b * p.Xi + rix[j]) * p.Yi + riy[j]) * p.Zi + riz[j]) * rowbytes + qo;
+    boff[j] = (unsigned)r * 128u + qo;
+  }
+  const char* inb = (const char*)p.in;
+  const char* wb = (const char*)p.w + (size_t)n0 * 128;
+  const char* zrow = (const char*)p.zrow;
+  const int it0 = blockIdx.y * p.iters_per_split;
+  const int it1 = min(it0 + p.iters_per_split, p.total_iters);
+  const int nsteps = (it1 - it0) * HALVES;
+  // (channel chunk, tap, half) cursor of the NEXT step to issue, advanced incrementally (wave-uniform: no divisions in the loop)
+  int ckc = it0 / p.taps, ct = it0 - ckc * p.taps;
+  int ckw = ct % p.kz, ckh = (ct / p.kz) % p.ky, ckd = ct / (p.kz * p.ky), chalf = 0;
+  const long long wstep = (long long)p.Npad * 128;
+  const char* wcur = wb + (long long)it0 * wstep;
+
+  auto issue = [&](int buf) {
+    const long long tapoff = (((long long)ckd * p.Yi + ckh) * p.Zi + ckw) * rowbytes + (long long)ckc * 128 + chalf * (BK * 2);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const bool ok = (unsigned)(rix[j] + ckd) < (unsigned)p.Xi && (unsigned)(riy[j] + ckh) < (unsigned)p.Yi &&
+                      (unsigned)(riz[j] + ckw) < (unsigned)p.Zi;
+      const char* src = ok ? inb + (abase[j] + tapoff) : zrow;
+      glds16(src, &As[buf][(j * 4 + wave) * RPI * BK]);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) glds16(wcur + boff[j] + chalf * (BK * 2), &Bs[buf][(j * 4 + wave) * RPI * BK]);
+    if (++chalf == HALVES) {
+      chalf = 0;
+      wcur += wstep;
+      if (++ckw == p.kz) { ckw = 0; if (++ckh == p.ky) { ckh = 0; if (++ckd == p.kx) { ckd = 0; ++ckc; } } }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nsteps > 0) issue(0);
+  __syncthreads();
+  const int sw = key(li);
+  int cur = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    if (st + 1 < nsteps) issue(cur ^ 1);
+    const __bf16* Ab = &As[cur][(wm * 64 + li) * BK];
+    const __bf16* Bb = &Bs[cur][(wn * 64 + li) * BK];
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      const int ch = ((s * 2 + h) ^ sw) * 8;
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(Ab + i * 32 * BK + ch);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8*)(Bb + j * 32 * BK + ch);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();          // every wave done with `cur`; the loads of the next step have landed (the barrier drains vmcnt)
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r];
+        if (p.splitk > 1) {
+          p.ws[((size_t)blockIdx.y * p.M + m) * p.Npad + n] = v;
+        } else if (n < p.Cout) {
+          p.out[(size_t)m * p.out_stride + n] = epilogue(p, v, n, (size_t)m);
+        }
+      }
+    }
+}
+
+// fp32 rows (row stride in_stride floats, first C columns) -> dense bf16 rows [rows][C], RNE: the operand of k_conv_bf16g
+__global__ __launch_bounds__(256) void k_rows_to_bf16(const float* __restrict__ in, int in_stride, long long rows, int C,
+                                                       __bf16* __restrict__ out) {
+  const int c8 = C >> 3;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * c8) return;
+  const long long r = i / c8;
+  const int c = (int)(i - r * c8) * 8;
+  const f32x4 a = *(const f32x4*)(in + r * in_stride + c), b = *(const f32x4*)(in + r * in_stride + c + 4);
+  bf16x8 o;
+  o[0] = (__bf16)a[0]; o[1] = (__bf16)a[1]; o[2] = (__bf16)a[2]; o[3] = (__bf16)a[3];
+  o[4] = (__bf16)b[0]; o[5] = (__bf16)b[1]; o[6] = (__bf16)b[2]; o[7] = (__bf16)b[3];
+  *(bf16x8*)(out + r * C + c) = o;
+}
+
+extern "C" int coocc_rows_to_bf16(const float* in, int in_stride, int64_t rows, int C, void* out_bf16, void* stream) {
+  COOCC_CHECK_ARG(in && out_bf16 && rows >= 0 && C > 0 && C % 8 == 0 && in_stride % 4 == 0 && in_stride >= C, "rows_to_bf16: bad args");
+  COOCC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)out_bf16 & 15) == 0, "rows_to_bf16: pointers must be 16-byte aligned");
+  if (rows == 0) return COOCC_OK;
+  hipLaunchKernelGGL(k_rows_to_bf16, dim3(cdiv(rows * (C / 8), 256)), dim3(256), 0, as_stream(stream), in, in_stride, (long long)rows, C,
+                     (__bf16*)out_bf16);
+  COOCC_LAUNCH_CHECK("k_rows_to_bf16");
+  return COOCC_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -848,6 +1026,11 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   k.wgroup_floats = (size_t)k.taps * k.kchunks * k.Npad * KC;
   k.relu = d->relu; k.res_mode = d->res_mode;
   k.total_iters = k.taps * k.kchunks;
+  if (d->mfma_dtype == 2) {      // bf16 operands in memory: K steps of 64 channels
+    COOCC_CHECK_ARG(d->Cin % 64 == 0 && d->in_stride % 8 == 0, "conv_fwd: bf16 operands need Cin % 64 == 0 and in_stride % 8 == 0");
+    k.kchunks = d->Cin / 64;
+    k.total_iters = k.taps * k.kchunks;
+  }
 
   // tile configuration by problem shape
   int cfg;  // 0: 128x128 (64x64 waves), 1: 64x128 (32x64), 2: 128x64 (32x64), 3: 128x32 (32x32), 4: 160x128 (160x32)
@@ -895,6 +1078,29 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
 
   hipStream_t s = as_stream(stream);
   const bool table = d->gather != nullptr;
+  if (d->mfma_dtype == 2) {
+    COOCC_CHECK_ARG(!table && d->wgroup_rows == 0 && !d->out_rows, "conv_fwd: the bf16-MFMA path covers geometric convolutions only");
+    static void* zero_row[64] = {nullptr};
+    int dev = 0;
+    COOCC_HIP(hipGetDevice(&dev));
+    COOCC_CHECK_ARG(dev >= 0 && dev < 64, "conv_fwd: device index");
+    if (!zero_row[dev]) {
+      COOCC_HIP(hipMalloc(&zero_row[dev], 256));
+      COOCC_HIP(hipMemset(zero_row[dev], 0, 256));
+    }
+    k.zrow = zero_row[dev];
+    k.ntiles = (k.Cout + 127) / 128;
+    k.mtiles = (k.M + 127) / 128;
+    k.mtiles_per_xcd = k.mtiles >= 64 ? (k.mtiles + 7) / 8 : 0;
+    dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
+    hipLaunchKernelGGL(k_conv_bf16g, grid, dim3(256), 0, s, k);
+    COOCC_LAUNCH_CHECK("k_conv_bf16g");
+    if (k.splitk > 1) {
+      hipLaunchKernelGGL(k_conv_reduce, dim3(cdiv((long long)k.M * k.Cout, 256)), dim3(256), 0, s, k);
+      COOCC_LAUNCH_CHECK("k_conv_reduce");
+    }
+    return COOCC_OK;
+  }
   if (d->mfma_dtype == 1) {
     COOCC_CHECK_ARG(!table && d->wgroup_rows == 0 && !d->out_rows, "conv_fwd: the bf16-MFMA path covers geometric convolutions only");
     // K steps of two pack chunks: keep the split boundaries even

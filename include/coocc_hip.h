@@ -167,13 +167,20 @@ typedef struct coocc_conv_desc {
                              multiple of 640.  Used by the Winograd path: one launch, 16 transform points. */
   int mfma_dtype;         /* 0: fp32 operands (v_mfma_f32_32x32x2_f32, exact fp32 -- the parity path);
                              1: operands rounded to bf16 in LDS (v_mfma_f32_32x32x16_bf16), fp32 accumulate / epilogue /
-                                storage: the reduced-precision path of the OpenOccupancy config; geometric taps only */
+                                storage: the reduced-precision path of the OpenOccupancy config; geometric taps only;
+                             2: the same arithmetic with the operands already bf16 in memory: `in` = [rows][in_stride] bf16
+                                (coocc_rows_to_bf16), `w` = bf16 pack [(Cin/64 chunk, tap)][roundup(Cout,128)][64]; Cin % 64 == 0 */
 } coocc_conv_desc;
 
 /* nn.Conv3d(k=3|1)+BN(eval)+ReLU(+residual) (bifuser_n.py:23-30, resnet3d.py:34-64,
  * fpn3d.py:46-64, occ_head.py:102-132), nn.Linear (+ReLU) and the gather->knn_enc->gate
  * ->scatter of bifuser_n.py:138-169 as one fp32-MFMA implicit-GEMM kernel family. */
 int coocc_conv_fwd(const coocc_conv_desc* d, void* stream);
+
+/* fp32 rows (row stride in_stride floats, first C columns, C % 8 == 0) -> dense bf16 rows [rows][C], round to nearest even:
+ * the activation operand of coocc_conv_fwd with mfma_dtype 2 (the fp16 / autocast hooks of coocc_ray.py:136,142,265 and
+ * fpn3d.py:69 cast the same tensors once per layer). */
+int coocc_rows_to_bf16(const float* in, int in_stride, int64_t rows, int C, void* out_bf16, void* stream);
 
 /* Winograd F(m x m, 3x3), m = tile = 2 or 4, over (x,y) for 3x3x3 stride-1 pad-1 convs (z stays a direct 3-tap
  * conv): input transform, then ONE coocc_conv_fwd launch over (m+2)^2 x group_rows rows (kx=ky=1, kz=3, pz=1,

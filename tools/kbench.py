@@ -102,6 +102,35 @@ def bench_conv():
 
 
 
+def bench_convbf16():
+    """The reduced-precision convolution path at the OpenOccupancy decoder's shapes: k_conv_bf16g (operands bf16 in memory,
+    global_load_lds staging; includes the coocc_rows_to_bf16 pass) and k_conv_bf16 (fp32 operands rounded inside the K loop),
+    against the 2.5 PFLOP/s dense bf16-MFMA peak."""
+    shapes = [("con_enc.0", 512, 256, (128, 128, 10), 3, 1), ("con_enc.3", 256, 128, (128, 128, 10), 3, 1),
+              ("enc.l0.conv", 128, 128, (128, 128, 10), 3, 1), ("enc.l1.conv1", 128, 256, (128, 128, 10), 3, 2),
+              ("enc.l1.conv2", 256, 256, (64, 64, 5), 3, 1), ("enc.l2.conv2", 512, 512, (32, 32, 3), 3, 1),
+              ("enc.l3.conv2", 1024, 1024, (16, 16, 2), 3, 1), ("fpn.out0", 256, 256, (128, 128, 10), 3, 1),
+              ("lat0 1x1", 128, 256, (128, 128, 10), 1, 1)]
+    core.CONV_DTYPE = "bf16"
+    try:
+        for name, ci, co, g, k, st in shapes:
+            x = core.Rows(torch.randn(g[0] * g[1] * g[2], ci, device=dev), 1, g[0], g[1], g[2], ci)
+            pc = core.PackedConv(torch.randn(co, ci, k, k, k, device=dev) * 0.02, ksize=k, stride=st, pad=k // 2)
+            M = (core.out_dim(g[0], k, st, k // 2) * core.out_dim(g[1], k, st, k // 2) * core.out_dim(g[2], k, st, k // 2))
+            fl = 2.0 * M * ci * co * k ** 3
+            ts = {}
+            for pre in (True, False):
+                core.BF16_PRECONVERT = pre
+                ts[pre] = timeit(lambda: core.conv_rows(x, pc, relu=True), n=5, warm=2)
+            xb = torch.empty(x.V * ci, device=dev, dtype=torch.bfloat16)
+            tc = timeit(lambda: call("coocc_rows_to_bf16", x.data(), x.stride, x.V, ci, ptr(xb)), n=5, warm=1)
+            print("%-14s %4d->%4d %-11s k%d s%d  bf16g %7.3f ms (conversion pass %.3f) = %6.1f TFLOP/s = %.3f of peak | k_conv_bf16 %7.3f ms = %6.1f TFLOP/s" % (
+                name, ci, co, "x".join(map(str, g)), k, st, ts[True], tc, fl / ts[True] / 1e9, fl / ts[True] / 1e9 / 2500.0,
+                ts[False], fl / ts[False] / 1e9))
+    finally:
+        core.CONV_DTYPE, core.BF16_PRECONVERT = "f32", True
+
+
 def bench_render():
     """R2 at r50 / r101 sizes: ray kernel + x16 upsample vs their algorithmic HBM bytes."""
     from co_occ_amd import render as R
