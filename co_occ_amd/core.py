@@ -184,7 +184,7 @@ class PackedConv:
         return self._ztrim[(lo, hi)]
 
     def bf16_pack(self, ztrim=None):
-        """bf16 pack of k_conv_bf16g: [(64-channel chunk, tap)][roundup(Cout,128)][64] (RNE), for all taps or, with
+        """bf16 pack of k_conv_bf16w (fragment-major, RNE), for all taps or, with
         ``ztrim=(lo, hi)``, for the z taps lo..hi of a 3x3x3 kernel only.  None when the layer cannot take that kernel."""
         if self._w_taps is None or self.Cin % 64:
             return None
@@ -196,8 +196,9 @@ class PackedConv:
             npad = -(-self.Cout // 128) * 128
             wp = torch.zeros(npad, self.Cin, taps, dtype=_F32)
             wp[:self.Cout] = w
-            pack = wp.view(npad, self.Cin // 64, 64, taps).permute(1, 3, 0, 2).contiguous().to(torch.bfloat16)
-            self._bf16[ztrim] = pack.to(self.w.device)
+            # fragment-major: [(chunk, tap)][Npad/32][4 k-steps][2 lane halves][32 columns][8 k] (k = 16 s + 8 h + e)
+            pack = wp.view(npad // 32, 32, self.Cin // 64, 4, 2, 8, taps).permute(2, 6, 0, 3, 4, 1, 5)
+            self._bf16[ztrim] = pack.contiguous().to(torch.bfloat16).to(self.w.device)
         return self._bf16[ztrim]
 
     def wino_pack(self, tile):
@@ -230,7 +231,7 @@ class PackedConv:
 _ws_cache = {}
 _wino_ws = {}
 _bf16_ws = {}
-# bf16 path: 1 = round the activations to bf16 in memory once per layer and run k_conv_bf16g (operands staged by
+# bf16 path: 1 = round the activations to bf16 in memory once per layer and run k_conv_bf16w (operands staged by
 # global_load_lds); 0 = k_conv_bf16 (fp32 operands rounded inside the K loop)
 BF16_PRECONVERT = __import__("os").environ.get("COOCC_BF16_PRECONVERT", "1") != "0"
 
@@ -392,7 +393,7 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
             d.kx, d.ky, d.kz, d.px, d.py, d.pz = 3, 3, hi - lo + 1, pc.pad, pc.pad, pc.pad - lo
             d.taps = taps = 9 * (hi - lo + 1)
     if bf16 and BF16_PRECONVERT and pc.Cin % 64 == 0 and pc._w_taps is not None and taps > 1:    # 1x1x1: HBM-bound either way
-        # operands bf16 in memory (k_conv_bf16g): the activations are rounded once per layer into a scratch buffer, the
+        # operands bf16 in memory (k_conv_bf16w): the activations are rounded once per layer into a scratch buffer, the
         # weights once per pack
         xb = _bf16_buffer(x.t.device, x.B * x.V * pc.Cin)
         call("coocc_rows_to_bf16", x.data(), x.stride, x.B * x.V, pc.Cin, ptr(xb))
@@ -401,7 +402,7 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
     if not TIMER.enabled:
         _lib.conv_fwd(d, pc.w.device)
         return out
-    kname = ("k_conv_bf16g" if d.mfma_dtype == 2 else "k_conv_bf16") if bf16 else conv_kernel_name(M, pc.Cout, False, 0, taps * -(-pc.Cin // 32),
+    kname = ("k_conv_bf16w" if d.mfma_dtype == 2 else "k_conv_bf16") if bf16 else conv_kernel_name(M, pc.Cout, False, 0, taps * -(-pc.Cin // 32),
                                                          pc.ksize == 1 and pc.stride == 1 and pc.pad == 0)
     with TIMER.region(kname, 2.0 * M * pc.Cin * pc.Cout * taps):
         _lib.conv_fwd(d, pc.w.device)

@@ -14,6 +14,7 @@
 // MFMA 32x32x2 f32 operand maps (MI355X guide): A: lane l holds A[i=l&31][k=l>>5];
 // B: B[k=l>>5][j=l&31]; D: 16 regs, col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5).
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 #include "common.h"
@@ -36,7 +37,7 @@ struct ConvK {
   int mtiles, ntiles, mtiles_per_xcd;
   size_t in_bytes;              // total input bytes (k_conv2 bases its buffer descriptor at the tile's first row)
   unsigned w_bytes;             // bytes of one weight pack
-  const void* zrow;             // k_conv_bf16g: 16 zero bytes in global memory (source of padded / out-of-range rows)
+  const void* zrow;             // k_conv_bf16w: 16 zero bytes in global memory (source of padded / out-of-range rows)
 };
 
 __device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t rrow) {
@@ -382,35 +383,33 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16(ConvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_conv_bf16g (mfma_dtype 2): the same arithmetic as k_conv_bf16 with both operands ALREADY bf16 in memory -- activations
-// as [rows][Cin] bf16 (coocc_rows_to_bf16: same RNE rounding, done once per layer instead of 27 times per element inside the
-// K loop), weights packed [iteration = (64-channel chunk, tap)][Npad][64] bf16 -- and staged by global_load_lds (16 B per
-// lane straight into LDS: no staging VGPRs, no conversion VALU work, no ds_write pass).  k_conv_bf16 moved 64 KB of fp32
-// operands per 128 x 128 x 64 step through registers: 128 B/clk per workgroup against ~64 B/clk a CU can pull from L2, which is
-// what held it at 0.13 of the bf16 peak; here a step moves 32 KB.  The LDS image of a tile is lane-linear (a wave's 64 lanes
-// fill 8 rows x 128 B), so the bank-conflict swizzle sits on the SOURCE side: 16-byte slot c of row r holds channel chunk
-// c ^ ((r >> 1) & 7), and the fragment reads apply the same XOR (16 consecutive rows x one chunk = 64 distinct banks).
-// Out-of-range taps / rows read 16 zero bytes from `zrow`.  One barrier per K step, loads of step i+1 in flight under the
-// MFMAs of step i.  128 x 128 tile, 2 x 2 waves of 64 x 64; Cin % 64 == 0.
+// k_conv_bf16w (mfma_dtype 2): the same arithmetic as k_conv_bf16 with both operands ALREADY bf16 in memory -- activations as
+// [rows][Cin] bf16 (coocc_rows_to_bf16: same RNE rounding, done once per layer instead of 27 times per element inside the K
+// loop), weights packed once.  k_conv_bf16 moved 64 KB of fp32 operands per 128 x 128 x 64 step through registers (convert,
+// ds_write): 128 B/clk per workgroup against ~64 B/clk a CU can pull from L2, which held it at 0.13 of the bf16 peak.
+// * The activation tile is staged by global_load_lds (16 B per lane straight into LDS: no staging VGPRs, no conversion VALU
+//   work, no ds_write pass).  Its LDS image is lane-linear (a wave's 64 lanes fill 8 rows x 128 B), so the bank-conflict
+//   swizzle sits on the SOURCE side: 16-byte slot c of row r holds channel chunk c ^ ((r >> 1) & 7), and the fragment reads
+//   apply the same XOR (SQ_LDS_BANK_CONFLICT = 0).  Out-of-range taps / rows read 16 zero bytes from `zrow`.
+// * The WEIGHTS stay out of LDS.  A global_load_lds costs 100-185 issue cycles in a phase that also carries ds_reads and MFMAs
+//   (MI355X guide); with both tiles staged that way (first version, "k_conv_bf16g": 620-700 TFLOP/s) 8 of them per 16 MFMAs
+//   (512 cycles) bounded the K loop -- MFMA pipe busy 36 %, no bank conflicts, little instruction wait, and neither K steps of
+//   32 at four workgroups per CU nor a 256 x 128 tile with three LDS stages, counted vmcnt and raw barriers moved it.  Here
+//   the pack is fragment-major -- [(chunk, tap)][Npad/32][4 k-steps][64 lanes][8 bf16]: lane l of a wave holds B[k = 16 s +
+//   8 (l >> 5) + 0..7][n = 32 nt + (l & 31)], one ordinary 16-byte load per fragment, 1 KB coalesced per wave instruction -- and
+//   each wave loads its own 2 x 4 fragments one K step ahead into registers (as k_conv2 does for fp32): 4 global_load_lds + 8
+//   plain loads per step, 16 KB of LDS per stage.
+// * The (chunk, tap) cursor and the per-row base offsets are advanced incrementally (five integer divisions per K step cost
+//   13 %).  One barrier per K step; loads of step i+1 in flight under the MFMAs of step i.  128 x 128 tile, 2 x 2 waves of
+//   64 x 64; Cin % 64 == 0.
 __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l,
                                    16, 0, 0);
 }
 
-// Variants measured on MI355X at the OpenOccupancy shapes (tools/kbench.py convbf16, TFLOP/s of the whole layer incl. the
-// conversion pass): this form 620-690; K steps of 32 with four workgroups per CU 585-670; a 256 x 128 tile with three LDS stages,
-// counted vmcnt and raw barriers (one workgroup per CU; 4 waves of 128 x 64 or 8 waves of 64 x 64) 425-670.  PMC: MFMA pipe busy
-// 36 %, no LDS bank conflicts, little instruction wait: every variant sits at the same L2 -> LDS operand rate (~10 TB/s over the
-// chip), so the next step is fewer operand bytes per flop (taps served from an LDS-resident halo block), not scheduling.
-__global__ __launch_bounds__(256, 2) void k_conv_bf16g(ConvK p) {
-  constexpr int BK = 64;
-  constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
-  constexpr int CPR = BK / 8;            // 16-byte chunks per LDS row
-  constexpr int RPI = 64 / CPR;          // tile rows one wave instruction fills
-  constexpr int NI = BM / (4 * RPI);     // instructions per operand tile and thread
-  constexpr int HALVES = 64 / BK;        // K steps per pack iteration
+__global__ __launch_bounds__(256, 2) void k_conv_bf16w(ConvK p) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2, BK = 64;
   __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * BK];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * BK];
 
   const int id = blockIdx.x;
   int mtile, nt, slot_ = id >> 3;
@@ -429,56 +428,54 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16g(ConvK p) {
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, h = lane >> 5;
-  const int srow = lane / CPR, slot = lane % CPR;
-  auto key = [](int r) { return BK == 64 ? (r >> 1) & 7 : (r >> 2) & 3; };
+  const int srow = lane >> 3, slot = lane & 7;
 
-  // staging: instruction j of wave w fills tile rows (j*4 + w)*RPI .. +RPI-1; this lane: row (j*4 + w)*RPI + srow, slot `slot`
-  int rix[NI], riy[NI], riz[NI];
-  long long abase[NI];        // byte offset of (row of tap (0,0,0), this lane's channel chunk)
-  unsigned boff[NI];          // byte offset of this lane's piece inside one iteration's weight tile
+  int rix[4], riy[4], riz[4];
+  long long abase[4];
   const long long rowbytes = (long long)p.in_stride * 2;
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int r = (j * 4 + wave) * RPI + srow;
+  for (int j = 0; j < 4; ++j) {
+    const int r = (j * 4 + wave) * 8 + srow;
     const int m = m0 + r;
     int oz = m % p.Zo; int q = m / p.Zo;
     int oy = q % p.Yo; q /= p.Yo;
     int ox = q % p.Xo; int b = q / p.Xo;
-    rix[j] = m < p.M ? ox * p.stride - p.px : -(1 << 20);      // a row past M fails every bounds test below
+    rix[j] = m < p.M ? ox * p.stride - p.px : -(1 << 20);
     riy[j] = oy * p.stride - p.py;
     riz[j] = oz * p.stride - p.pz;
-    const unsigned qo = (unsigned)((slot ^ key(r)) * 16);
+    const unsigned qo = (unsigned)((slot ^ ((r >> 1) & 7)) * 16);
     abase[j] = ((((long long)b * p.Xi + rix[j]) * p.Yi + riy[j]) * p.Zi + riz[j]) * rowbytes + qo;
-    boff[j] = (unsigned)r * 128u + qo;
   }
   const char* inb = (const char*)p.in;
-  const char* wb = (const char*)p.w + (size_t)n0 * 128;
   const char* zrow = (const char*)p.zrow;
   const int it0 = blockIdx.y * p.iters_per_split;
   const int it1 = min(it0 + p.iters_per_split, p.total_iters);
-  const int nsteps = (it1 - it0) * HALVES;
-  // (channel chunk, tap, half) cursor of the NEXT step to issue, advanced incrementally (wave-uniform: no divisions in the loop)
+  const int nsteps = it1 - it0;
   int ckc = it0 / p.taps, ct = it0 - ckc * p.taps;
-  int ckw = ct % p.kz, ckh = (ct / p.kz) % p.ky, ckd = ct / (p.kz * p.ky), chalf = 0;
-  const long long wstep = (long long)p.Npad * 128;
-  const char* wcur = wb + (long long)it0 * wstep;
+  int ckw = ct % p.kz, ckh = (ct / p.kz) % p.ky, ckd = ct / (p.kz * p.ky);
+  // this wave's two 32-column fragments tiles of the pack: 4 KB per (iteration, tile)
+  const long long wstep = (long long)(p.Npad >> 5) * 4096;
+  const char* wcur = (const char*)p.w + (long long)it0 * wstep + (long long)((n0 >> 5) + wn * 2) * 4096 + lane * 16;
 
-  auto issue = [&](int buf) {
-    const long long tapoff = (((long long)ckd * p.Yi + ckh) * p.Zi + ckw) * rowbytes + (long long)ckc * 128 + chalf * (BK * 2);
+  auto issueA = [&](int buf) {
+    const long long tapoff = (((long long)ckd * p.Yi + ckh) * p.Zi + ckw) * rowbytes + (long long)ckc * 128;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const bool ok = (unsigned)(rix[j] + ckd) < (unsigned)p.Xi && (unsigned)(riy[j] + ckh) < (unsigned)p.Yi &&
                       (unsigned)(riz[j] + ckw) < (unsigned)p.Zi;
       const char* src = ok ? inb + (abase[j] + tapoff) : zrow;
-      glds16(src, &As[buf][(j * 4 + wave) * RPI * BK]);
+      glds16(src, &As[buf][(j * 4 + wave) * 8 * 64]);
     }
+    if (++ckw == p.kz) { ckw = 0; if (++ckh == p.ky) { ckh = 0; if (++ckd == p.kx) { ckd = 0; ++ckc; } } }
+  };
+  bf16x8 breg[2][4][TN];
+  auto loadB = [&](auto bufc) {
+    constexpr int B_ = decltype(bufc)::value;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) glds16(wcur + boff[j] + chalf * (BK * 2), &Bs[buf][(j * 4 + wave) * RPI * BK]);
-    if (++chalf == HALVES) {
-      chalf = 0;
-      wcur += wstep;
-      if (++ckw == p.kz) { ckw = 0; if (++ckh == p.ky) { ckh = 0; if (++ckd == p.kx) { ckd = 0; ++ckc; } } }
-    }
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) breg[B_][s][j] = *(const bf16x8*)(wcur + j * 4096 + s * 1024);
+    wcur += wstep;
   };
 
   f32x16 acc[TM][TN];
@@ -489,29 +486,36 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16g(ConvK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (nsteps > 0) issue(0);
-  __syncthreads();
-  const int sw = key(li);
-  int cur = 0;
-  for (int st = 0; st < nsteps; ++st) {
-    if (st + 1 < nsteps) issue(cur ^ 1);
-    const __bf16* Ab = &As[cur][(wm * 64 + li) * BK];
-    const __bf16* Bb = &Bs[cur][(wn * 64 + li) * BK];
+  const int sw = (li >> 1) & 7;
+  auto step = [&](auto curc, bool more) {
+    constexpr int C_ = decltype(curc)::value;
+    if (more) {
+      issueA(C_ ^ 1);
+      loadB(std::integral_constant<int, C_ ^ 1>{});
+    }
+    const __bf16* Ab = &As[C_][(wm * 64 + li) * 64];
 #pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
+    for (int s = 0; s < 4; ++s) {
       const int ch = ((s * 2 + h) ^ sw) * 8;
-      bf16x8 a[TM], b[TN];
+      bf16x8 a[TM];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(Ab + i * 32 * BK + ch);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8*)(Bb + j * 32 * BK + ch);
+      for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(Ab + i * 32 * 64 + ch);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], breg[C_][s][j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();          // every wave done with `cur`; the loads of the next step have landed (the barrier drains vmcnt)
-    cur ^= 1;
+    __syncthreads();          // every wave done with this stage; the next step's tile and fragments have landed
+  };
+
+  if (nsteps > 0) {
+    issueA(0);
+    loadB(std::integral_constant<int, 0>{});
+  }
+  __syncthreads();
+  for (int st = 0; st < nsteps; st += 2) {
+    step(std::integral_constant<int, 0>{}, st + 1 < nsteps);
+    if (st + 1 < nsteps) step(std::integral_constant<int, 1>{}, st + 2 < nsteps);
   }
 
 #pragma unroll
@@ -533,7 +537,177 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16g(ConvK p) {
     }
 }
 
-// fp32 rows (row stride in_stride floats, first C columns) -> dense bf16 rows [rows][C], RNE: the operand of k_conv_bf16g
+// k_conv_bf16z: k_conv_bf16w for stride-1 "same" convolutions (every 3x3x3 layer of C0-C3 but the three strided ones), with the
+// activation tile shared by the z taps.  Output rows are linear in (x, y, z), z fastest, so the rows tap (dx, dy, dz) needs for a
+// tile of 128 consecutive outputs are the tile's own rows shifted by ((dx-1) Y + (dy-1)) Z + (dz-1): ONE LDS image of 128 + KZ - 1
+// rows per (channel chunk, dx, dy) serves all KZ z taps -- the fragments of tap dz are read dz rows further down -- instead of
+// KZ images of 128 rows: 4-5 global_load_lds per KZ x 16 MFMAs instead of 4 per 16, and one barrier per KZ taps.  Linear
+// neighbours are not always spatial neighbours (a column's first voxel sits next to the previous column's last): a lane zeroes
+// its A fragment when its output voxel's tap falls outside the grid (v_cndmask under the MFMAs), which is also exactly the zero
+// padding.  The next group's image is issued at the first tap of the current group (three taps of MFMAs to land), the weight
+// fragments of the next tap are loaded into the other register set during the current one.
+template <int KZ>
+__global__ __launch_bounds__(256, 2) void k_conv_bf16z(ConvK p) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+  constexpr int AROWS = 136;                       // 128 + KZ - 1 rounded up to whole 8-row wave instructions
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][AROWS * 64];
+
+  const int id = blockIdx.x;
+  int mtile, nt, slot_ = id >> 3;
+  if (p.mtiles_per_xcd > 0) {
+    const int xcd = id & 7;
+    const int mt_local = slot_ / p.ntiles;
+    nt = slot_ - mt_local * p.ntiles;
+    mtile = xcd * p.mtiles_per_xcd + mt_local;
+    if (mt_local >= p.mtiles_per_xcd || mtile >= p.mtiles) return;
+  } else {
+    mtile = id / p.ntiles;
+    nt = id - mtile * p.ntiles;
+  }
+  const int m0 = mtile * BM, n0 = nt * BN;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, h = lane >> 5;
+  const int srow = lane >> 3, slot = lane & 7;
+
+  // staging: LDS row r holds input row  m0 + r - pz + ((dx - px) Yi + (dy - py)) Zi  (any row of the buffer, else zeros)
+  const long long rowbytes = (long long)p.in_stride * 2;
+  const long long total_rows = (long long)p.Xi * p.Yi * p.Zi * (p.M / ((long long)p.Xo * p.Yo * p.Zo));
+  long long arow[5];          // m0 + r - pz for this lane's rows (instruction 4: rows 128..135, issued by wave 0 only)
+  unsigned aq[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int r = j < 4 ? (j * 4 + wave) * 8 + srow : 128 + srow;
+    arow[j] = (long long)m0 + r - p.pz;
+    aq[j] = (unsigned)((slot ^ ((r >> 1) & 7)) * 16);
+  }
+  // the two output voxels this lane's A fragments belong to (fragment i: row wm*64 + i*32 + li)
+  int vx[TM], vy[TM], vz[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * 64 + i * 32 + li;
+    int oz = m % p.Zo; int q = m / p.Zo;
+    int oy = q % p.Yo; q /= p.Yo;
+    vx[i] = m < p.M ? q % p.Xo : -(1 << 20);
+    vy[i] = oy; vz[i] = oz;
+  }
+  const char* inb = (const char*)p.in;
+  const char* zrow = (const char*)p.zrow;
+  const int it0 = blockIdx.y * p.iters_per_split;
+  const int it1 = min(it0 + p.iters_per_split, p.total_iters);
+  const int ngroups = (it1 - it0) / KZ;                 // the launcher keeps split boundaries on whole (dx, dy) groups
+  // cursors: `g*` = the group whose image is issued next, `c*` = the group being computed
+  const int g0 = it0 / KZ;                              // group index = (chunk * kx + dx) * ky + dy
+  int gkc = g0 / (p.kx * p.ky), gd = (g0 / p.ky) % p.kx, gh = g0 % p.ky;
+  int cd = gd, ch_ = gh;
+  const long long wstep = (long long)(p.Npad >> 5) * 4096;
+  const char* wcur = (const char*)p.w + (long long)it0 * wstep + (long long)((n0 >> 5) + wn * 2) * 4096 + lane * 16;
+
+  auto issueA = [&](int buf) {
+    const long long off = ((long long)(gd - p.px) * p.Yi + (gh - p.py)) * p.Zi;
+    const long long coff = (long long)gkc * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long L = arow[j] + off;
+      const char* src = (L >= 0 && L < total_rows) ? inb + L * rowbytes + coff + aq[j] : zrow;
+      glds16(src, &As[buf][(j * 4 + wave) * 8 * 64]);
+    }
+    if (wave == 0) {
+      const long long L = arow[4] + off;
+      const char* src = (L >= 0 && L < total_rows) ? inb + L * rowbytes + coff + aq[4] : zrow;
+      glds16(src, &As[buf][128 * 64]);
+    }
+    if (++gh == p.ky) { gh = 0; if (++gd == p.kx) { gd = 0; ++gkc; } }
+  };
+  bf16x8 breg[2][4][TN];
+  auto loadB = [&](auto bufc) {
+    constexpr int B_ = decltype(bufc)::value;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) breg[B_][s][j] = *(const bf16x8*)(wcur + j * 4096 + s * 1024);
+    wcur += wstep;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bf16x8 zero8 = {};
+  // one tap: MFMAs of tap DZ of the group in stage AB_ with the weight set BB_; loads the next tap's weights into the other set
+  auto tap = [&](auto abufc, auto bbufc, auto dzc, bool more_taps, bool xy0, bool xy1) {
+    constexpr int AB_ = decltype(abufc)::value, BB_ = decltype(bbufc)::value, DZ = decltype(dzc)::value;
+    if (more_taps) loadB(std::integral_constant<int, BB_ ^ 1>{});
+    const bool ok0 = xy0 && (unsigned)(vz[0] + DZ - p.pz) < (unsigned)p.Zi;
+    const bool ok1 = xy1 && (unsigned)(vz[1] + DZ - p.pz) < (unsigned)p.Zi;
+    const int r0 = wm * 64 + li + DZ, r1 = r0 + 32;
+    const __bf16* A0 = &As[AB_][r0 * 64];
+    const __bf16* A1 = &As[AB_][r1 * 64];
+    const int k0 = (r0 >> 1) & 7, k1 = (r1 >> 1) & 7;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 a0 = *(const bf16x8*)(A0 + ((s * 2 + h) ^ k0) * 8);
+      bf16x8 a1 = *(const bf16x8*)(A1 + ((s * 2 + h) ^ k1) * 8);
+      a0 = ok0 ? a0 : zero8;
+      a1 = ok1 ? a1 : zero8;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, breg[BB_][s][j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[BB_][s][j], acc[1][j], 0, 0, 0);
+      }
+    }
+  };
+  // one (chunk, dx, dy) group in stage GP: KZ taps; weight-set parity of its first tap = (GP * KZ) & 1
+  auto group = [&](auto gpc, int g) {
+    constexpr int GP = decltype(gpc)::value;
+    if (g + 1 < ngroups) issueA(GP ^ 1);
+    const bool xy0 = (unsigned)(vx[0] + cd - p.px) < (unsigned)p.Xi && (unsigned)(vy[0] + ch_ - p.py) < (unsigned)p.Yi;
+    const bool xy1 = (unsigned)(vx[1] + cd - p.px) < (unsigned)p.Xi && (unsigned)(vy[1] + ch_ - p.py) < (unsigned)p.Yi;
+    const bool last = g + 1 >= ngroups;
+    tap(gpc, std::integral_constant<int, (GP * KZ) & 1>{}, std::integral_constant<int, 0>{}, KZ > 1 || !last, xy0, xy1);
+    if constexpr (KZ > 1)
+      tap(gpc, std::integral_constant<int, (GP * KZ + 1) & 1>{}, std::integral_constant<int, 1>{}, KZ > 2 || !last, xy0, xy1);
+    if constexpr (KZ > 2)
+      tap(gpc, std::integral_constant<int, (GP * KZ + 2) & 1>{}, std::integral_constant<int, 2>{}, !last, xy0, xy1);
+    if (++ch_ == p.ky) { ch_ = 0; if (++cd == p.kx) cd = 0; }
+    __syncthreads();          // every wave done with this stage; the next group's image has landed
+  };
+
+  if (ngroups > 0) {
+    issueA(0);
+    loadB(std::integral_constant<int, 0>{});
+  }
+  __syncthreads();
+  for (int g = 0; g < ngroups; g += 2) {
+    group(std::integral_constant<int, 0>{}, g);
+    if (g + 1 < ngroups) group(std::integral_constant<int, 1>{}, g + 1);
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r];
+        if (p.splitk > 1) {
+          p.ws[((size_t)blockIdx.y * p.M + m) * p.Npad + n] = v;
+        } else if (n < p.Cout) {
+          p.out[(size_t)m * p.out_stride + n] = epilogue(p, v, n, (size_t)m);
+        }
+      }
+    }
+}
+
+// fp32 rows (row stride in_stride floats, first C columns) -> dense bf16 rows [rows][C], RNE: the operand of k_conv_bf16w
 __global__ __launch_bounds__(256) void k_rows_to_bf16(const float* __restrict__ in, int in_stride, long long rows, int C,
                                                        __bf16* __restrict__ out) {
   const int c8 = C >> 3;
@@ -1093,8 +1267,23 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
     k.mtiles = (k.M + 127) / 128;
     k.mtiles_per_xcd = k.mtiles >= 64 ? (k.mtiles + 7) / 8 : 0;
     dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
-    hipLaunchKernelGGL(k_conv_bf16g, grid, dim3(256), 0, s, k);
-    COOCC_LAUNCH_CHECK("k_conv_bf16g");
+    // stride-1 "same" layers share the activation tile between their z taps (split boundaries on whole (dx, dy) groups)
+    static const int zshare_env = getenv("COOCC_BF16_ZSHARE") ? atoi(getenv("COOCC_BF16_ZSHARE")) : 1;
+    const bool same = k.stride == 1 && k.Xo == k.Xi && k.Yo == k.Yi && k.Zo == k.Zi && k.kz >= 1 && k.kz <= 3 && k.taps > 1;
+    if (zshare_env && same) {
+      if (k.iters_per_split % k.kz) {
+        k.iters_per_split += k.kz - k.iters_per_split % k.kz;
+        k.splitk = (k.total_iters + k.iters_per_split - 1) / k.iters_per_split;
+      }
+      dim3 gridz(grid.x, k.splitk);
+      if (k.kz == 3) hipLaunchKernelGGL(k_conv_bf16z<3>, gridz, dim3(256), 0, s, k);
+      else if (k.kz == 2) hipLaunchKernelGGL(k_conv_bf16z<2>, gridz, dim3(256), 0, s, k);
+      else hipLaunchKernelGGL(k_conv_bf16z<1>, gridz, dim3(256), 0, s, k);
+      COOCC_LAUNCH_CHECK("k_conv_bf16z");
+    } else {
+      hipLaunchKernelGGL(k_conv_bf16w, grid, dim3(256), 0, s, k);
+      COOCC_LAUNCH_CHECK("k_conv_bf16w");
+    }
     if (k.splitk > 1) {
       hipLaunchKernelGGL(k_conv_reduce, dim3(cdiv((long long)k.M * k.Cout, 256)), dim3(256), 0, s, k);
       COOCC_LAUNCH_CHECK("k_conv_reduce");

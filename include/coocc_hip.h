@@ -169,7 +169,8 @@ typedef struct coocc_conv_desc {
                              1: operands rounded to bf16 in LDS (v_mfma_f32_32x32x16_bf16), fp32 accumulate / epilogue /
                                 storage: the reduced-precision path of the OpenOccupancy config; geometric taps only;
                              2: the same arithmetic with the operands already bf16 in memory: `in` = [rows][in_stride] bf16
-                                (coocc_rows_to_bf16), `w` = bf16 pack [(Cin/64 chunk, tap)][roundup(Cout,128)][64]; Cin % 64 == 0 */
+                                (coocc_rows_to_bf16), `w` = bf16 pack [(Cin/64 chunk, tap)][roundup(Cout,128)/32][4][64 lanes][8] (fragment-major:
+                                lane l of k-step s holds k = 16 s + 8 (l >> 5) + 0..7 of column 32 nt + (l & 31)); Cin % 64 == 0 */
 } coocc_conv_desc;
 
 /* nn.Conv3d(k=3|1)+BN(eval)+ReLU(+residual) (bifuser_n.py:23-30, resnet3d.py:34-64,

@@ -30,7 +30,7 @@ def _bf(x):
 @pytest.mark.parametrize("preconvert", [True, False])
 def test_conv_bf16_mfma_equals_conv_on_bf16_rounded_operands(dev, monkeypatch, Cin, Cout, grid, k, stride, relu, use_res, splitk,
                                                              preconvert):
-    """k_conv_bf16g (operands rounded to bf16 once in memory, staged by global_load_lds; layers with Cin % 64 == 0) and
+    """k_conv_bf16w (operands rounded to bf16 once in memory, staged by global_load_lds; layers with Cin % 64 == 0) and
     k_conv_bf16 (operands rounded to bf16 in LDS): RNE rounding, fp32 accumulation, fp32 BN / residual / ReLU epilogue."""
     monkeypatch.setattr(core, "BF16_PRECONVERT", preconvert)
     g = torch.Generator().manual_seed(Cin * 1000 + Cout + 1)

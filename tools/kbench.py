@@ -103,7 +103,7 @@ def bench_conv():
 
 
 def bench_convbf16():
-    """The reduced-precision convolution path at the OpenOccupancy decoder's shapes: k_conv_bf16g (operands bf16 in memory,
+    """The reduced-precision convolution path at the OpenOccupancy decoder's shapes: k_conv_bf16w (operands bf16 in memory,
     global_load_lds staging; includes the coocc_rows_to_bf16 pass) and k_conv_bf16 (fp32 operands rounded inside the K loop),
     against the 2.5 PFLOP/s dense bf16-MFMA peak."""
     shapes = [("con_enc.0", 512, 256, (128, 128, 10), 3, 1), ("con_enc.3", 256, 128, (128, 128, 10), 3, 1),
@@ -124,7 +124,7 @@ def bench_convbf16():
                 ts[pre] = timeit(lambda: core.conv_rows(x, pc, relu=True), n=5, warm=2)
             xb = torch.empty(x.V * ci, device=dev, dtype=torch.bfloat16)
             tc = timeit(lambda: call("coocc_rows_to_bf16", x.data(), x.stride, x.V, ci, ptr(xb)), n=5, warm=1)
-            print("%-14s %4d->%4d %-11s k%d s%d  bf16g %7.3f ms (conversion pass %.3f) = %6.1f TFLOP/s = %.3f of peak | k_conv_bf16 %7.3f ms = %6.1f TFLOP/s" % (
+            print("%-14s %4d->%4d %-11s k%d s%d  bf16w %7.3f ms (conversion pass %.3f) = %6.1f TFLOP/s = %.3f of peak | k_conv_bf16 %7.3f ms = %6.1f TFLOP/s" % (
                 name, ci, co, "x".join(map(str, g)), k, st, ts[True], tc, fl / ts[True] / 1e9, fl / ts[True] / 1e9 / 2500.0,
                 ts[False], fl / ts[False] / 1e9))
     finally:
