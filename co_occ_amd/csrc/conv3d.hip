@@ -649,16 +649,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16z(ConvK p) {
     const __bf16* A0 = &As[AB_][r0 * 64];
     const __bf16* A1 = &As[AB_][r1 * 64];
     const int k0 = (r0 >> 1) & 7, k1 = (r1 >> 1) & 7;
+    // all eight fragments of the tap first: one LDS latency per tap instead of one per k-step
+    bf16x8 a0[4], a1[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      bf16x8 a0 = *(const bf16x8*)(A0 + ((s * 2 + h) ^ k0) * 8);
-      bf16x8 a1 = *(const bf16x8*)(A1 + ((s * 2 + h) ^ k1) * 8);
-      a0 = ok0 ? a0 : zero8;
-      a1 = ok1 ? a1 : zero8;
+      a0[s] = *(const bf16x8*)(A0 + ((s * 2 + h) ^ k0) * 8);
+      a1[s] = *(const bf16x8*)(A1 + ((s * 2 + h) ^ k1) * 8);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 f0 = ok0 ? a0[s] : zero8, f1 = ok1 ? a1[s] : zero8;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, breg[BB_][s][j], acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[BB_][s][j], acc[1][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, breg[BB_][s][j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, breg[BB_][s][j], acc[1][j], 0, 0, 0);
       }
     }
   };

@@ -43,6 +43,8 @@ timeout 300 python $R/bench.py --config openocc --steps 10 --warmup 2 > $O/r2_be
 timeout 300 python $R/bench.py --config openocc --dtype bf16 --steps 10 --warmup 2 > $O/r2_bench_openocc_bf16.json 2>/dev/null
 timeout 300 python $R/bench.py --config stress200 --steps 6 --warmup 1 --no-cpu-baseline > $O/r2_bench_stress200.json 2>/dev/null
 timeout 600 python $R/tools/kbench.py fps knn conv render pool > $O/r2_kbench.txt 2>&1
+timeout 300 python $R/tools/kbench.py convbf16 2>&1 | grep -v amdgpu.ids > $O/r2_kbench_bf16.txt
+timeout 300 bash $R/tools/pmc_bf16.sh > $O/r2_pmc_bf16.txt 2>&1
 python $R/tools/kstats.py $O/r2_bench_streams2_kernel_stats.csv 16 < /dev/null
 cut -c1-900 $O/r2_bench_default.json
 head -14 $O/r2_bench_pmc_hbm.txt; head -8 $O/r2_bench_pmc_sq.txt
