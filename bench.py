@@ -543,6 +543,10 @@ def main():
     with torch.no_grad():
         step(model, samples[0], world)          # packs weights, sizes workspaces (untimed, extra to --warmup)
     torch.cuda.synchronize()
+    # every dense / prefetch stream owns its scratch (split-K slabs, Winograd buffers, search workspaces): size them for both
+    # synthetic samples before anything is timed, whatever --warmup is (a first use inside the timed region is a multi-GB
+    # allocation + zero fill: seen once as 110 instead of 54 ms per step at stress200 with --warmup 1)
+    run(2 * S, False)
     run(args.warmup, False)
     core.TIMER.enabled = 0 if args.no_kernel_timing else (2 if args.kernel_table else 1)
     core.TIMER.only = ("k_conv", "k_render_nearest", "k_lift_splat")      # what the roofline objects below need

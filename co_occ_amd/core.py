@@ -234,6 +234,7 @@ _bf16_ws = {}
 # bf16 path: 1 = round the activations to bf16 in memory once per layer and run k_conv_bf16w (operands staged by
 # global_load_lds); 0 = k_conv_bf16 (fp32 operands rounded inside the K loop)
 BF16_PRECONVERT = __import__("os").environ.get("COOCC_BF16_PRECONVERT", "1") != "0"
+ZSHARE = __import__("os").environ.get("COOCC_BF16_ZSHARE", "1") != "0"       # read by the library too (k_conv_bf16z)
 
 
 def _bf16_buffer(device, n):
@@ -402,7 +403,10 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
     if not TIMER.enabled:
         _lib.conv_fwd(d, pc.w.device)
         return out
-    kname = ("k_conv_bf16w" if d.mfma_dtype == 2 else "k_conv_bf16") if bf16 else conv_kernel_name(M, pc.Cout, False, 0, taps * -(-pc.Cin // 32),
+    if d.mfma_dtype == 2:      # mirror of the dispatch in coocc_conv_fwd: stride-1 "same" layers share the tile between z taps
+        kname = "k_conv_bf16z" if (pc.stride == 1 and (Xo, Yo, Zo) == (x.X, x.Y, x.Z) and ZSHARE) else "k_conv_bf16w"
+    else:
+        kname = "k_conv_bf16" if bf16 else conv_kernel_name(M, pc.Cout, False, 0, taps * -(-pc.Cin // 32),
                                                          pc.ksize == 1 and pc.stride == 1 and pc.pad == 0)
     with TIMER.region(kname, 2.0 * M * pc.Cin * pc.Cout * taps):
         _lib.conv_fwd(d, pc.w.device)
