@@ -220,3 +220,47 @@ def test_grid_topk_and_ball_query_equal_brute_force(dev, grid, pq, pk, K, m):
         grp_g = torch.empty(m, ns, device=dev, dtype=I32)
         call("coocc_ball_query_voxels", m, 0.0, radius, ns, X, Y, Z, ptr(rep), ptr(lq), ptr(maps[0]), ptr(grp_g))
         assert torch.equal(grp_g, grp_b)
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 11, 9, 5), (2, 128, 20, 13, 4), (1, 128, 33, 31, 3), (1, 48, 7, 5, 3)])
+@pytest.mark.parametrize("img_form,pts_form", [("ncdhw", "ncdhw"), ("rows", "ncdhw"), ("inplace", "ncdhw"), ("rows", "rows"),
+                                               ("inplace", "wide")])
+def test_fuser_prepare_rows_every_source_form(dev, shape, img_form, pts_form):
+    """coocc_fuser_prepare_rows (vector fast path for C % 32 == 0, generic kernel otherwise) against the NCDHW prologue
+    coocc_fuser_prepare: same concat rows, same non-empty flags (incl. all-zero rows and rows whose entries cancel exactly),
+    for NCDHW sources, dense rows, rows that already sit in their slot, and rows inside a wider buffer; V is never a multiple
+    of the 256-voxel workgroup."""
+    B, C, X, Y, Z = shape
+    g = torch.Generator().manual_seed(C + X)
+    img = torch.randn(shape, generator=g) * (torch.rand(B, 1, X, Y, Z, generator=g) < 0.6)
+    pts = torch.relu(torch.randn(shape, generator=g)) * (torch.rand(B, 1, X, Y, Z, generator=g) < 0.2)
+    img[0, :, 1, 1, 1] = 0.
+    img[0, 0, 1, 1, 1], img[0, C - 1, 1, 1, 1] = 3.5, -3.5          # non-zero row with a zero sum: flag 0 as upstream's sum(1)
+    V = X * Y * Z
+    want = torch.empty(B * V, 4 * C, device=dev)
+    wflags = torch.empty(2, B * V, device=dev, dtype=torch.uint8)
+    call("coocc_fuser_prepare", ptr(img.to(dev)), ptr(pts.to(dev)), ptr(want), ptr(wflags[0]), ptr(wflags[1]), B, C, V)
+    rows_of = lambda t: t.permute(0, 2, 3, 4, 1).reshape(B * V, C).contiguous().to(dev)
+    cat4 = torch.full((B * V, 4 * C), 9.0, device=dev)
+    flags = torch.full((2, B * V), 7, device=dev, dtype=torch.uint8)
+    keep = []
+
+    def source(t, form, slot):
+        if form == "ncdhw":
+            s = t.to(dev).contiguous(); keep.append(s)
+            return ptr(s), 0, 0
+        if form == "rows":
+            s = rows_of(t); keep.append(s)
+            return ptr(s), 1, C
+        if form == "inplace":
+            cat4[:, slot * C:(slot + 1) * C] = rows_of(t)
+            return _lib.c_void_p(cat4.data_ptr() + 4 * slot * C), 1, 4 * C
+        wide = torch.full((B * V, C + 8), 5.0, device=dev)            # rows at column offset 4 of a wider buffer
+        wide[:, 4:4 + C] = rows_of(t); keep.append(wide)
+        return _lib.c_void_p(wide.data_ptr() + 16), 1, C + 8
+    a = source(img, img_form, 0)
+    b = source(pts, pts_form, 1)
+    call("coocc_fuser_prepare_rows", *a, *b, ptr(cat4), ptr(flags[0]), ptr(flags[1]), B, C, V)
+    assert torch.equal(cat4, want)
+    assert torch.equal(flags, wflags)
+    assert int(wflags[0, (1 * Y + 1) * Z + 1]) == 0
