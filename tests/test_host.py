@@ -144,3 +144,49 @@ def test_gloo_world_size_2_all_gather(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("OK %d" % rank) in o, o[-2000:]
+
+
+def test_bench_ticket_orders_collectives_across_threads():
+    """bench.py's N > 1 path with several dense streams: whichever host thread owns sample i, the gathers are issued in sample
+    order on every rank (the ticket), and an aborted run releases every waiter instead of hanging."""
+    import random
+    import threading
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    ticket = bench._Ticket()
+    for S in (2, 3):
+        ticket.reset()
+        order, n = [], 40
+
+        def worker(w):
+            rnd = random.Random(w)
+            for i in range(w, n, S):
+                time.sleep(rnd.random() * 0.003)          # threads reach their turn in arbitrary order
+                with ticket(i):
+                    order.append(i)
+        ths = [threading.Thread(target=worker, args=(w,)) for w in range(S)]
+        [t.start() for t in ths]
+        [t.join(timeout=30) for t in ths]
+        assert not any(t.is_alive() for t in ths)
+        assert order == list(range(n))
+    # a waiter whose turn never comes is released by abort()
+    ticket.reset()
+    done = []
+
+    def stuck():
+        with ticket(5):
+            done.append(1)
+    t = threading.Thread(target=stuck)
+    t.start()
+    time.sleep(0.05)
+    assert t.is_alive()
+    ticket.abort()
+    t.join(timeout=10)
+    assert not t.is_alive()
+    # the gates of --stagger: an event posted for sample i is what sample i + 1 finds
+    gates = bench._Gates()
+    gates.reset()
+    assert gates.wait_for(-1) is None
+    gates.post(0, "ev0")
+    assert gates.wait_for(0) == "ev0"
