@@ -390,6 +390,97 @@ def render_r101_roofline(model, dev, iters=20):
                 algorithmic_bytes=int(v["work"] / v["launches"]), avg_ms=round(v["ms"] / v["launches"], 4), launches=v["launches"])
 
 
+class Pipeline:
+    """The serving loop bench.py times: sample i runs its dense stage (fuser finish -> encoder -> neck -> head -> render) on
+    dense stream i mod S (one host thread per stream; S = 1: the calling thread); its pooling + index search were issued S
+    samples earlier on a high-priority prefetch stream by a helper thread, so they overlap the dense stages in flight.  With S = 2
+    the low-occupancy tail of one sample (the 25x25x2 / 13x13x1 encoder stages, laterals, small heads: ~1.3 ms on <= 20 % of
+    the CUs) runs under the other sample's large GEMMs.  Collectives (N > 1) are issued in sample order on every rank (ticket),
+    whatever thread owns the sample.  ``collect(i, out)`` (tests) is called on sample i's stream right after its launches."""
+
+    def __init__(self, model, samples, dev, streams, prefetch=True, world=1):
+        from concurrent.futures import ThreadPoolExecutor
+        self.model, self.samples, self.dev, self.streams, self.world = model, samples, dev, streams, world
+        S = len(streams)
+        # one prefetch worker + high-priority stream per dense stream: a lone 1024-thread FPS workgroup must win a CU slot
+        # against the queue of convolution workgroups
+        self.tpool = ThreadPoolExecutor(S) if prefetch else None
+        self.search_streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(S)]
+
+    def do_search(self, i):
+        """Pooling (P2) + index search (K1-K5) of sample i on a high-priority prefetch stream."""
+        s = self.samples[i % len(self.samples)]
+        torch.cuda.set_device(self.dev)
+        t0, b0 = time.perf_counter(), _lib.blocked_seconds()
+        with torch.cuda.stream(self.search_streams[i % len(self.search_streams)]), torch.no_grad():
+            img = pool(self.model, s) if WITH_POOL[0] else s["img"]
+            sr = self.model.search(img, s["pts"])
+        DIAG["search_host_s"].append(time.perf_counter() - t0)
+        DIAG["search_blocked_s"].append(_lib.blocked_seconds() - b0)
+        return img, sr
+
+    def run(self, nsteps, S=None, collect=None):
+        import threading
+        streams, tpool, samples, model, world, dev = self.streams, self.tpool, self.samples, self.model, self.world, self.dev
+        S = len(streams) if S is None else S
+        errs = []
+        futs = {}
+        lock = threading.Lock()
+
+        def submit(i):
+            if tpool is not None and i < nsteps:
+                with lock:
+                    futs[i] = tpool.submit(self.do_search, i)
+
+        for i in range(min(S, nsteps)):
+            submit(i)
+
+        def worker(w):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.no_grad():
+                    for i in range(w, nsteps, S):
+                        img, sr = (None, None)
+                        t0 = time.perf_counter()
+                        if tpool is not None:
+                            with lock:
+                                f = futs.pop(i)
+                            img, sr = f.result()
+                        t1, b1 = time.perf_counter(), _lib.blocked_seconds()
+                        submit(i + S)
+                        with torch.cuda.stream(streams[w]):
+                            if img is not None and torch.is_tensor(img):
+                                img.record_stream(streams[w])
+                            out = step(model, samples[i % len(samples)], world, search=sr, img=img, ticket=i)
+                            if collect is not None:
+                                collect(i, out)
+                        DIAG["wait_search_host_s"].append(t1 - t0)
+                        DIAG["dense_host_s"].append(time.perf_counter() - t1)
+                        DIAG["dense_blocked_s"].append(_lib.blocked_seconds() - b1)
+                streams[w].synchronize()
+            except Exception as e:  # surface worker failures in the main thread
+                errs.append(e)
+                TICKET.abort()
+                GATES.abort()
+
+        TICKET.reset()
+        GATES.reset()
+        if S == 1:
+            worker(0)
+        else:
+            ths = [threading.Thread(target=worker, args=(w,)) for w in range(S)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        if errs:
+            raise errs[0]
+        with torch.cuda.stream(streams[0]):
+            drain_gathers()          # the last step's all-gather belongs to the timed region
+        for st in streams:
+            st.synchronize()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -458,87 +549,9 @@ def main():
     else:
         streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
-    import threading
-    from concurrent.futures import ThreadPoolExecutor
     S = len(streams)
-    # one prefetch worker + high-priority stream per dense stream: a lone 1024-thread FPS workgroup must win a CU slot
-    # against the queue of convolution workgroups
-    tpool = ThreadPoolExecutor(S) if args.prefetch else None
-    search_streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(S)]
-
-    def do_search(i):
-        """Pooling (P2) + index search (K1-K5) of sample i on a high-priority prefetch stream."""
-        s = samples[i % len(samples)]
-        torch.cuda.set_device(dev)
-        t0, b0 = time.perf_counter(), _lib.blocked_seconds()
-        with torch.cuda.stream(search_streams[i % S]), torch.no_grad():
-            img = pool(model, s) if WITH_POOL[0] else s["img"]
-            sr = model.search(img, s["pts"])
-        DIAG["search_host_s"].append(time.perf_counter() - t0)
-        DIAG["search_blocked_s"].append(_lib.blocked_seconds() - b0)
-        return img, sr
-
-    def run(nsteps, timed, S=S):
-        """`nsteps` samples over S dense streams (one host thread each; S = 1: a single driver thread).  Sample i runs its
-        dense stage (fuser finish -> encoder -> neck -> head -> render) on stream i mod S; its pooling + index search were
-        issued S samples earlier on a prefetch stream by a helper thread, so they overlap the dense stages in flight.  With
-        S = 2 the low-occupancy tail of one sample (the 25x25x2 / 13x13x1 encoder stages, laterals, small heads: ~1.3 ms on
-        <= 20 % of the CUs) runs under the other sample's large GEMMs.  Collectives (N > 1) are issued in sample order on
-        every rank (ticket), whatever thread owns the sample."""
-        errs = []
-        futs = {}
-        lock = threading.Lock()
-
-        def submit(i):
-            if tpool is not None and i < nsteps:
-                with lock:
-                    futs[i] = tpool.submit(do_search, i)
-
-        for i in range(min(S, nsteps)):
-            submit(i)
-
-        def worker(w):
-            try:
-                torch.cuda.set_device(dev)
-                with torch.no_grad():
-                    for i in range(w, nsteps, S):
-                        img, sr = (None, None)
-                        t0 = time.perf_counter()
-                        if tpool is not None:
-                            with lock:
-                                f = futs.pop(i)
-                            img, sr = f.result()
-                        t1, b1 = time.perf_counter(), _lib.blocked_seconds()
-                        submit(i + S)
-                        with torch.cuda.stream(streams[w]):
-                            if img is not None and torch.is_tensor(img):
-                                img.record_stream(streams[w])
-                            step(model, samples[i % len(samples)], world, search=sr, img=img, ticket=i)
-                        DIAG["wait_search_host_s"].append(t1 - t0)
-                        DIAG["dense_host_s"].append(time.perf_counter() - t1)
-                        DIAG["dense_blocked_s"].append(_lib.blocked_seconds() - b1)
-                streams[w].synchronize()
-            except Exception as e:  # surface worker failures in the main thread
-                errs.append(e)
-                TICKET.abort()
-                GATES.abort()
-
-        TICKET.reset()
-        GATES.reset()
-        if S == 1:
-            worker(0)
-        else:
-            ths = [threading.Thread(target=worker, args=(w,)) for w in range(S)]
-            for t in ths:
-                t.start()
-            for t in ths:
-                t.join()
-        if errs:
-            raise errs[0]
-        with torch.cuda.stream(streams[0]):
-            drain_gathers()          # the last step's all-gather belongs to the timed region
-        for st in streams:
-            st.synchronize()
+    pipe = Pipeline(model, samples, dev, streams, prefetch=bool(args.prefetch), world=world)
+    run, tpool = (lambda n, timed, S=S: pipe.run(n, S)), pipe.tpool
 
     with torch.no_grad():
         step(model, samples[0], world)          # packs weights, sizes workspaces (untimed, extra to --warmup)
