@@ -14,6 +14,8 @@
 // intervals are provided as well.
 #include <cstring>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -570,7 +572,10 @@ static int pool_csr(const float* x, const float* depth, int npts, int C, int D, 
   hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, p.tops, nblk);
   hipLaunchKernelGGL(k_scan_finish, dim3(nblk), dim3(1024), 0, s, p.count, nvox, nblk, p.tops, p.start, p.long_list, p.nlong);
   hipLaunchKernelGGL(k_csr_fill, dim3(cdiv(npts, 256)), dim3(256), 0, s, p.keys, npts, nvox, p.start, p.slot, p.ids);
-  const int long_blocks = 128;
+  // workgroups that walk the list of long voxels (> POOL_MEDIUM points; 24 at r50, 554 at r101, up to 2614 points each): their
+  // per-voxel sort + ordered accumulation is the launch's critical path, so there are enough of them for one voxel each at r101
+  // (r101, whole pooling call: 128 workgroups 0.60 ms, 512 0.43, 1024 0.375; idle ones exit after one load)
+  static const int long_blocks = getenv("COOCC_POOL_LONG_BLOCKS") ? atoi(getenv("COOCC_POOL_LONG_BLOCKS")) : 1024;
   hipLaunchKernelGGL(k_pool_sum_csr<LIFT>, dim3(long_blocks + cdiv(nvox, 4)), dim3(256), 0, s, x, depth, p.ids, p.start,
                      p.long_list, p.nlong, long_blocks, nvox, C, D, HW, out, out_stride);
   COOCC_LAUNCH_CHECK("voxel_pool");
