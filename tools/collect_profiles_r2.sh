@@ -37,11 +37,8 @@ for k, c in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"])[:18]:
     busy = max(c["SQ_BUSY_CU_CYCLES"], 1.0); wave = max(c["SQ_WAVE_CYCLES"], 1.0)
     print("%-46s %6d %10.3f %10.3f %10.3f %12.0f" % (k, calls[k], c["SQ_VALU_MFMA_BUSY_CYCLES"] / busy, c["SQ_WAIT_INST_ANY"] / wave, c["SQ_WAIT_INST_LDS"] / wave, c["SQ_LDS_BANK_CONFLICT"]))
 PY
-# other configurations + the reduced-precision path
-timeout 300 python $R/bench.py --config r101 --steps 30 --no-cpu-baseline > $O/r2_bench_r101.json 2>/dev/null
-timeout 300 python $R/bench.py --config openocc --steps 10 --warmup 2 > $O/r2_bench_openocc_f32.json 2>/dev/null
-timeout 300 python $R/bench.py --config openocc --dtype bf16 --steps 10 --warmup 2 > $O/r2_bench_openocc_bf16.json 2>/dev/null
-timeout 300 python $R/bench.py --config stress200 --steps 6 --warmup 1 --no-cpu-baseline > $O/r2_bench_stress200.json 2>/dev/null
+# other configurations + the reduced-precision path: median of three runs each (shared boxes)
+bash $R/tools/record_configs.sh
 timeout 600 python $R/tools/kbench.py fps knn conv render pool > $O/r2_kbench.txt 2>&1
 timeout 300 python $R/tools/kbench.py convbf16 2>&1 | grep -v amdgpu.ids > $O/r2_kbench_bf16.txt
 timeout 300 bash $R/tools/pmc_bf16.sh > $O/r2_pmc_bf16.txt 2>&1
