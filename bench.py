@@ -145,6 +145,7 @@ class _Gates:
 
 
 GATES = _Gates()
+TRACE, TRACE_T0 = [None], [0.0]          # --diag: per-sample host issue window + completion event
 DIAG = {"search_host_s": [], "search_blocked_s": [], "wait_search_host_s": [], "dense_host_s": [], "dense_blocked_s": []}     # host-side issue times per sample (--diag)
 STAGGER = [0]
 
@@ -454,6 +455,10 @@ class Pipeline:
                             out = step(model, samples[i % len(samples)], world, search=sr, img=img, ticket=i)
                             if collect is not None:
                                 collect(i, out)
+                            if TRACE[0] is not None:
+                                ev = torch.cuda.Event(enable_timing=True)
+                                ev.record()
+                                TRACE[0].append((i, w, t0 - TRACE_T0[0], t1 - TRACE_T0[0], time.perf_counter() - TRACE_T0[0], ev))
                         DIAG["wait_search_host_s"].append(t1 - t0)
                         DIAG["dense_host_s"].append(time.perf_counter() - t1)
                         DIAG["dense_blocked_s"].append(_lib.blocked_seconds() - b1)
@@ -569,10 +574,19 @@ def main():
     t0 = time.perf_counter()
     for v in DIAG.values():
         del v[:]
+    if args.diag:
+        TRACE[0], TRACE_T0[0] = [], time.perf_counter()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     run(args.steps, True)
     cdist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if args.diag and rank == 0 and TRACE[0]:
+        for i, w, a, b, c, ev in sorted(TRACE[0]):
+            print("trace: sample %2d stream %d  host: search ready %.1f  issue %.1f -> %.1f ms   GPU done %.1f ms" % (
+                i, w, 1e3 * b, 1e3 * b, 1e3 * c, ev0.elapsed_time(ev)), file=sys.stderr)
+        TRACE[0] = None
     if args.diag and rank == 0:
         print("diag: " + json.dumps({k: dict(mean_ms=round(1e3 * sum(v) / max(len(v), 1), 3), max_ms=round(1e3 * max(v or [0]), 3))
                                      for k, v in DIAG.items()}, sort_keys=True) + " wall_ms_per_step %.3f" % (1e3 * dt / args.steps),
