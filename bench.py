@@ -492,11 +492,12 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="r50", choices=sorted(synth.CONFIGS))
-    ap.add_argument("--streams", type=int, default=2,
-                    help="dense stages in flight: S host threads / HIP streams, sample i on stream i mod S.  Default 2: one "
-                         "sample's low-occupancy tail (25x25x2 / 13x13x1 layers, heads, fine branch) runs under the other's GEMMs; "
-                         "profiles/r2_streams_ab.txt: 120.4-127.0 samples/s over 12 processes at S = 2 against 112.5-116.3 at S = 1 "
-                         "(since the host issue path was shortened; before, S = 2 fell into a host-bound mode in 3 of 10 runs)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="dense stages in flight: S host threads / HIP streams, sample i on stream i mod S.  With 2, one "
+                         "sample's low-occupancy tail (25x25x2 / 13x13x1 layers, heads, fine branch) runs under the other's GEMMs: "
+                         "120.4-127.0 samples/s over 12 processes against 112.5-116.3 at S = 1 on a quiet host, but no gain and "
+                         "more spread when neighbours saturate the host's CPUs (profiles/r2_streams_ab.txt).  Default 0: decide "
+                         "between 1 and 2 from two short untimed bursts of each before the warm-up")
     ap.add_argument("--stagger", type=int, default=0,
                     help="with --streams > 1: 1 = sample i+1 enters its dense stage after sample i finished the fuser, 2 = after "
                          "its encoder (fixed phase offset between the dense stages in flight); 0 = free running")
@@ -543,6 +544,9 @@ def main():
     WITH_POOL[0] = not args.no_pool
     CFGNAME[0] = args.config
     core.CONV_DTYPE = args.dtype
+    auto_streams = args.streams == 0
+    if auto_streams:
+        args.streams = 2
     STAGGER[0] = args.stagger if args.streams > 1 else 0
     model, sd = build_model(args.config, dev)
     samples = [make_inputs(args.config, 1234 + 17 * rank + i, dev, model) for i in range(2)]
@@ -565,6 +569,25 @@ def main():
     # synthetic samples before anything is timed, whatever --warmup is (a first use inside the timed region is a multi-GB
     # allocation + zero fill: seen once as 110 instead of 54 ms per step at stress200 with --warmup 1)
     run(2 * S, False)
+    probe = None
+    if auto_streams:
+        # One or two samples in flight?  Two win by ~8 % when the host keeps up (four Python threads share the GIL) and lose
+        # that margin when neighbours saturate the box's CPUs (profiles/r2_streams_ab.txt) -- so ask the box: two untimed
+        # bursts of each, the faster total decides.  The rule is the same on every rank (the decision is rank-local: collectives
+        # are issued in sample order whatever the stream count).
+        nprobe = max(8, min(16, args.steps))
+        tt = {1: 0.0, 2: 0.0}
+        for _ in range(2):
+            for Sp in (1, 2):
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                run(nprobe, False, S=Sp)
+                torch.cuda.synchronize()
+                tt[Sp] += time.perf_counter() - tp
+        S = 2 if tt[2] < tt[1] else 1
+        probe = dict(samples_per_burst=nprobe, bursts_each=2, samples_per_s={k: round(2 * nprobe / v, 2) for k, v in tt.items()},
+                     chosen=S)
+        run = (lambda n, timed, S=S: pipe.run(n, S))
     run(args.warmup, False)
     core.TIMER.enabled = 0 if args.no_kernel_timing else (2 if args.kernel_table else 1)
     core.TIMER.only = ("k_conv", "k_render_nearest", "k_lift_splat")      # what the roofline objects below need
@@ -631,11 +654,14 @@ def main():
                             occupancy_grid="x".join(str(v) for v in c.get("final_occ_size", [2 * g for g in c["grid"]])), cams=c["ncam"],
                             render_maps="%dx%dx%d" % (c["ncam"], c["fmap"][0] * 16, c["fmap"][1] * 16), knum=c["knum"],
                             parallelism="dp%d (1 scene per GPU, RCCL all-gather of maps)" % world,
-                            samples_in_flight=len(streams), prefetched_search=bool(tpool), weights="random",
+                            samples_in_flight=S, prefetched_search=bool(tpool), weights="random",
                             step_starts_from=("lifted depth/context pair (fused lift-splat pooling inside the step)" if WITH_POOL[0]
                                               else "pooled camera volume")),
                 roofline=roof)
     line.update(extra)
+    if probe is not None:
+        line["stream_probe"] = dict(probe, note="untimed bursts before the warm-up: samples in flight chosen by the faster total "
+                                                "(--streams 1 / 2 fixes it)")
     if world == 1 and not args.no_cpu_baseline and args.config != "openocc":   # cascade 4: ~10 M fine points, hours on the CPU
         line["cpu_baseline"] = cpu_baseline(sd, samples[0], args.config, WITH_POOL[0])
     if rank == 0:

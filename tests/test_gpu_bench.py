@@ -24,17 +24,34 @@ def _run(cmd, timeout=600):
     return json.loads(lines[0])
 
 
-def test_default_streams_line_has_the_contract_fields():
-    d = _run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"])
+def _check_contract(d, steps, warmup):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["unit"] == "samples/s" and d["scaling"] == "weak"
-    assert d["config"]["samples_in_flight"] == 2 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup and d["unit"] == "samples/s" and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32"
     r = d["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert 0 < r["frac_alone"] < 1 and "roofline_isolated" in d and "roofline_render_r101" in d and "roofline_pool" in d
+    assert "roofline_render_r101" in d and "roofline_pool" in d
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 0.05 * d["value"]
+
+
+def test_default_line_has_the_contract_fields_and_reports_its_stream_probe():
+    """The driver's command: the number of samples in flight is chosen from untimed bursts and reported."""
+    d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"])
+    _check_contract(d, 8, 2)
+    p = d["stream_probe"]
+    assert p["chosen"] == d["config"]["samples_in_flight"] and p["chosen"] in (1, 2)
+    assert set(p["samples_per_s"]) == {"1", "2"} and all(v > 0 for v in p["samples_per_s"].values())
+    faster = max(p["samples_per_s"], key=lambda k: p["samples_per_s"][k])
+    assert int(faster) == p["chosen"]
+
+
+def test_two_streams_line_carries_the_alone_figures():
+    d = _run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--streams", "2", "--no-cpu-baseline"])
+    _check_contract(d, 6, 2)
+    assert d["config"]["samples_in_flight"] == 2 and "stream_probe" not in d
+    assert 0 < d["roofline"]["frac_alone"] < 1 and "roofline_isolated" in d
 
 
 def test_two_ranks_two_streams_each_on_one_gpu():
@@ -44,7 +61,7 @@ def test_two_ranks_two_streams_each_on_one_gpu():
     s.close()
     d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
               "--master-port", str(port), "bench.py", "--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "6",
-              "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timing"])
+              "--warmup", "2", "--streams", "2", "--no-cpu-baseline", "--no-kernel-timing"])
     assert d["n_gpus"] == 2 and d["world_size_seen_by_backend"] == 2 and d["backend"] == "gloo"
     assert d["config"]["samples_in_flight"] == 2
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 0.05 * d["value"]      # whole-job rate: both ranks' samples
