@@ -5,6 +5,7 @@ samples/s (6-cam frame + sweep -> occupancy logits + rendered rgb/depth).
     python bench.py --gpus N --steps K --warmup W          (N>1: launched through torch.distributed.run)
 
 A step is one pass of the hot path over one synthetic sample already resident in HBM:
+fused lift (x) splat pooling of the sample's depth distribution and context features (P2) ->
 BiFuser_N (KNN + gather/encode/scatter + con_enc) -> CustomResNet3D -> FPN3D -> OccHead
 (coarse + cascade fine, scattered into the 200x200x16 grid) -> 6-camera volume render
 (+ for N>1 one RCCL all-gather of the rendered maps).  Workload = the reference config
@@ -12,8 +13,13 @@ coocc_multi_r50_256x704 (configs[1]): fused grid 100x100x8 x 128 ch, final occup
 200x200x16, 6 cams with 16x44 feature maps -> 6x256x704 maps, knum=2, random weights, fp32.
 Weak scaling: every rank processes its own samples (the reference's samples_per_gpu=1 DP).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: fp32-MFMA implicit-GEMM conv)
-and, at N=1, `cpu_baseline` (the oracle's CPU restatement timed on this host).
+The serving loop (class Pipeline): pooling + index search of the next sample(s) prefetched on high-priority streams by helper
+threads; one or two samples' dense stages in flight (chosen per box by an untimed probe unless --streams says so).  Its outputs
+are checked bit for bit against sequential calls in tests/test_gpu_bench.py.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: fp32-MFMA implicit-GEMM conv; with two samples in flight the
+in-pipeline figure and, as *_alone / roofline_isolated, the one-sample figure), `roofline_pool`, `roofline_render[_r101]` and,
+at N=1, `cpu_baseline` (the oracle's CPU restatement timed on this host).
 """
 import argparse
 import json
