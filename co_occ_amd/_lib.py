@@ -24,7 +24,7 @@ class ConvDesc(ctypes.Structure):
                [(n, c_int) for n in ("M", "Cin", "Cout", "taps", "in_stride", "out_stride", "res_stride",
                                      "B", "Xi", "Yi", "Zi", "Xo", "Yo", "Zo", "ksize", "stride", "pad",
                                      "relu", "res_mode", "splitk", "tile_hint", "kx", "ky", "kz", "px", "py", "pz",
-                                     "wgroup_rows", "mfma_dtype")]
+                                     "wgroup_rows", "mfma_dtype")] + [("alpha", ctypes.c_float)]
 
 
 P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_int64
@@ -37,6 +37,8 @@ SIGNATURES = {
     "coocc_stream_destroy": (I, [P]),
     "coocc_ncdhw_to_ndhwc": (I, [P, P, I, I, I, I, I, P]),
     "coocc_rows_to_bf16": (I, [P, I, L, I, P, P]),
+    "coocc_rows_to_h2": (I, [P, I, L, I, F, P, P]),
+    "coocc_wino_input_h2": (I, [P, I, I, I, I, I, I, I, P, I, L, F, P]),
     "coocc_ndhwc_to_ncdhw": (I, [P, P, I, I, I, I, I, P]),
     "coocc_fuser_prepare": (I, [P, P, P, P, P, I, I, I, P]),
     "coocc_fuser_prepare_rows": (I, [P, I, I, P, I, I, P, P, P, I, I, I, P]),

@@ -25,7 +25,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "coocc_hip.h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "coocc_hip.h")]
     jobs = []
     for s in sources():
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + ".o")

@@ -32,6 +32,13 @@ WINO_TILE = int(__import__("os").environ.get("COOCC_WINO_TILE", "4"))   # F(4x4,
 # bf16 in LDS and run v_mfma_f32_32x32x16_bf16 (fp32 accumulate / BN epilogue / storage; direct form, no Winograd): the
 # reduced-precision path of the OpenOccupancy config (configs[4]).  Set per process or assign core.CONV_DTYPE.
 CONV_DTYPE = __import__("os").environ.get("COOCC_CONV_DTYPE", "f32")
+# How the fp32 convolutions of CONV_DTYPE == "f32" are evaluated:  "h2" (default): operands split into two f16 halves
+# (hi + lo * 2^-11), three v_mfma_f32_32x32x16_f16 per step, fp32 accumulation (csrc/gemm_h2.hip) -- fp32-accurate (measured
+# error vs fp64 is half that of the fp32-MFMA chain) at up to 5.3x the fp32-MFMA rate; "f32": v_mfma_f32_32x32x2_f32 everywhere.
+CONV_ENGINE = __import__("os").environ.get("COOCC_CONV_ENGINE", "h2")
+# operand scale of the Winograd-domain V in the h2 engine (keeps B^T d B inside the f16 range: |activation| < 65504 / (amp * scale),
+# amp = 100 for F(4x4), 25 for F(3x3), 4 for F(2x2))
+H2_WINO_SCALE = {2: 0.5, 3: 0.25, 4: 0.125}
 
 
 def conv_kernel_name(M, Cout, table, hint=0, iters=1 << 30, one_by_one=False):
@@ -201,6 +208,57 @@ class PackedConv:
             self._bf16[ztrim] = pack.contiguous().to(torch.bfloat16).to(self.w.device)
         return self._bf16[ztrim]
 
+    @staticmethod
+    def _h2_layout(w64):
+        """[Npad, Cin, taps] fp64 -> H2 pack [(chunk, tap)][Npad/32][2 k16 steps][hi | lo][64 lanes][8 f16] (csrc/gemm_h2.hip):
+        lane l of step s holds k = 32 chunk + 16 s + 8 (l >> 5) + 0..7 of column 32 nt + (l & 31)."""
+        npad, cin, taps = w64.shape
+        hi = w64.to(torch.float16)
+        lo = ((w64 - hi.double()) * 2048.0).to(torch.float16)
+        planes = torch.stack([hi, lo], 0)                                     # [pl, n, c, t]
+        v = planes.view(2, npad // 32, 32, cin // 32, 2, 2, 8, taps)            # pl, nt, li, chunk, s, hf, e, t
+        return v.permute(3, 7, 1, 4, 0, 5, 2, 6).contiguous()                  # chunk, t, nt, s, pl, hf, li, e
+
+    def h2_pack(self, ztrim=None):
+        """H2 (split-f16) pack of the direct form: all taps or, with ``ztrim=(lo, hi)``, the z taps lo..hi of a 3x3x3 kernel.
+        None when the layer cannot take the h2 kernel (Cin % 32)."""
+        if self._w_taps is None or self.Cin % 32:
+            return None
+        key = ("h2", ztrim)
+        if key not in self._bf16:
+            w = self._w_taps
+            if ztrim is not None:
+                w = self._w_cube[:, :, :, :, ztrim[0]:ztrim[1] + 1].reshape(self.Cout, self.Cin, -1)
+            npad = -(-self.Cout // 128) * 128
+            wp = torch.zeros(npad, self.Cin, w.shape[2], dtype=torch.float64)
+            wp[:self.Cout] = w.double()
+            self._bf16[key] = self._h2_layout(wp).to(self.w.device)
+        return self._bf16[key]
+
+    def wino_h2_pack(self, tile):
+        """(tile+2)^2 H2 packs of U[p][dz] = (G g G^T)[xi][eta][dz] (taps = 3), split from the fp64 products."""
+        key = ("h2", tile)
+        if key not in self._wino:
+            G = self._wino_G(tile)
+            n2 = G.shape[0] ** 2
+            w = self._w_raw.double().view(self.Cout, self.Cin, 3, 3, 3)
+            U = torch.einsum("pa,qb,ncabz->pqncz", G, G, w).reshape(n2, self.Cout, self.Cin, 3)
+            npad = -(-self.Cout // 128) * 128
+            Up = torch.zeros(n2, npad, self.Cin, 3, dtype=torch.float64)
+            Up[:, :self.Cout] = U
+            self._wino[key] = torch.stack([self._h2_layout(Up[p]) for p in range(n2)], 0).to(self.w.device)
+        return self._wino[key]
+
+    @staticmethod
+    def _wino_G(tile):
+        if tile == 2:
+            return torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], dtype=torch.float64)
+        if tile == 3:
+            return torch.tensor([[1, 0, 0], [-2 / 9, 2 / 9, -2 / 9], [1 / 9, 2 / 9, 4 / 9], [-8 / 9, -4 / 9, -2 / 9], [0, 0, 1]],
+                                dtype=torch.float64)
+        return torch.tensor([[1, 0, 0], [1 / 3, 1 / 3, 1 / 3], [-1 / 3, 1 / 3, -1 / 3], [-16 / 15, -8 / 15, -4 / 15],
+                             [1 / 15, -2 / 15, 4 / 15], [0, 0, 1]], dtype=torch.float64)
+
     def wino_pack(self, tile):
         """(tile+2)^2 packs (one per transform point p = (tile+2)*xi + eta) of U[p][dz] = (G g G^T)[xi][eta][dz],
         taps = 3 (z).  G: F(2,3) / F(4,3) Toom-Cook matrices, products in fp64."""
@@ -274,6 +332,9 @@ def wino_plan(x, pc, M, res_mode):
     g640, g128 = _lcm(640, x.Z), _lcm(128, x.Z)
     G640, G128 = -(-rows // g640) * g640, -(-rows // g128) * g128
     G, hint = (G640, 0) if G640 <= 1.05 * G128 else (G128, 128)
+    if CONV_ENGINE == "h2" and pc.Cin % 32 == 0:
+        g256 = _lcm(256, x.Z)           # 256-row tiles of the persistent split-f16 GEMM (k_gemm_h2p)
+        G, hint = -(-rows // g256) * g256, 0
     pts = (tile + 2) ** 2
     if pts * G >= 1 << 31:
         return None     # row indices are 32-bit
@@ -303,19 +364,24 @@ def conv_rows_wino(x, pc, out, relu, res, plan, in_ranges=None):
     tile, pts, Tx, Ty, rows, G, hint = plan
     V = _wino_buffer(dev, "V", pts * G * pc.Cin)
     Mb = _wino_buffer(dev, "M", pts * G * pc.Cout)
-    wp = pc.wino_pack(tile)
+    h2 = CONV_ENGINE == "h2" and pc.Cin % 32 == 0 and all(c % 32 == 0 for _, c in (in_ranges or []))
+    wp = pc.wino_h2_pack(tile) if h2 else pc.wino_pack(tile)
+    vscale = H2_WINO_SCALE[tile]
     with TIMER.region("k_wino_in", 4.0 * x.V * pc.Cin + 4.0 * pts * rows * pc.Cin):
-        if in_ranges is None:
+        if in_ranges is None and not h2:
             call("coocc_wino_input", x.data(), x.stride, x.B, x.X, x.Y, x.Z, pc.Cin, tile, ptr(V), G)
         else:
-            assert sum(c for _, c in in_ranges) == pc.Cin
+            assert in_ranges is None or sum(c for _, c in in_ranges) == pc.Cin
             voff = 0
-            for coff, cr in in_ranges:
+            for coff, cr in (in_ranges or [(0, pc.Cin)]):
                 src = _lib.DevPtr(x.t.data_ptr() + 4 * (x.coff + coff))
                 src._keep = x.t
-                dst = _lib.DevPtr(V.data_ptr() + 4 * voff)
+                dst = _lib.DevPtr(V.data_ptr() + 4 * voff)        # H2 rows: 128 bytes per 32-channel chunk = 4 bytes per channel too
                 dst._keep = V
-                call("coocc_wino_input_strided", src, x.stride, x.B, x.X, x.Y, x.Z, cr, tile, dst, pc.Cin, G)
+                if h2:
+                    call("coocc_wino_input_h2", src, x.stride, x.B, x.X, x.Y, x.Z, cr, tile, dst, pc.Cin, G, vscale)
+                else:
+                    call("coocc_wino_input_strided", src, x.stride, x.B, x.X, x.Y, x.Z, cr, tile, dst, pc.Cin, G)
                 voff += cr
     d = ConvDesc()
     ws = workspace(dev)
@@ -333,6 +399,8 @@ def conv_rows_wino(x, pc, out, relu, res, plan, in_ranges=None):
     if (CONV_PERSIST and CONV_V2 and kname == "k_conv2<128>" and 3 * -(-pc.Cin // 32) <= 24
             and (pts * G // 128) * -(-pc.Cout // 128) > 768):
         kname = "k_conv2p"          # mirror of the dispatch in coocc_conv_fwd: persistent workgroups, >= 2 tiles each
+    if h2:
+        d.mfma_dtype, d.alpha, kname = 3, 1.0 / vscale, "k_gemm_h2z"
     with TIMER.region(kname + " wino%d" % tile, 2.0 * pts * rows * pc.Cin * pc.Cout * 3):
         _lib.conv_fwd(d, V.device)
     with TIMER.region("k_wino_out", 4.0 * pts * rows * pc.Cout + 4.0 * x.V * pc.Cout):

@@ -22,33 +22,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#include "conv_layout.h"
-
-struct ConvK {
-  const float* in; const float* w; float* out; const float* scale; const float* bias;
-  const float* res; const int32_t* gather; const int32_t* out_rows; float* ws;
-  int M, Cin, Cout, Npad, taps, kchunks;
-  int in_stride, out_stride, res_stride;
-  int Xi, Yi, Zi, Xo, Yo, Zo, stride;
-  int kx, ky, kz, px, py, pz;   // per-axis kernel extent / padding (taps = kx*ky*kz, tap index t = (dx*ky + dy)*kz + dz)
-  int wgroup_rows;              // > 0: output rows [g*wgroup_rows, (g+1)*wgroup_rows) use weight pack g (Winograd points)
-  size_t wgroup_floats;         // floats per weight pack
-  int relu, res_mode, iters_per_split, total_iters, splitk;
-  int mtiles, ntiles, mtiles_per_xcd;
-  size_t in_bytes;              // total input bytes (k_conv2 bases its buffer descriptor at the tile's first row)
-  unsigned w_bytes;             // bytes of one weight pack
-  const void* zrow;             // k_conv_bf16w: 16 zero bytes in global memory (source of padded / out-of-range rows)
-};
-
-__device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t rrow) {
-  if (p.res_mode == 3) v += p.res[rrow * p.res_stride + n];   // raw partial sum of an earlier K-slice pass
-  if (p.scale) v *= p.scale[n];
-  if (p.bias) v += p.bias[n];
-  if (p.res_mode == 1) v += p.res[rrow * p.res_stride + n];
-  if (p.relu) v = fmaxf(v, 0.f);
-  if (p.res_mode == 2) v *= p.res[rrow * p.res_stride + n];
-  return v;
-}
+#include "conv_k.h"
 
 template <int BM, int BN, int WM, int WN, bool TABLE>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
@@ -1165,6 +1139,20 @@ extern "C" int64_t coocc_conv_pack_weights(const float* w_host, int Cout, int Ci
   return total;
 }
 
+// 256 zero bytes per device: the source of padded / out-of-range rows for the global_load_lds staged kernels
+int coocc_zero_row(const void** out) {
+  static void* zero_row[64] = {nullptr};
+  int dev = 0;
+  COOCC_HIP(hipGetDevice(&dev));
+  COOCC_CHECK_ARG(dev >= 0 && dev < 64, "conv_fwd: device index");
+  if (!zero_row[dev]) {
+    COOCC_HIP(hipMalloc(&zero_row[dev], 256));
+    COOCC_HIP(hipMemset(zero_row[dev], 0, 256));
+  }
+  *out = zero_row[dev];
+  return COOCC_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(ConvK& k, bool table, hipStream_t s) {
   k.mtiles = (k.M + BM - 1) / BM;
@@ -1204,6 +1192,16 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   k.wgroup_floats = (size_t)k.taps * k.kchunks * k.Npad * KC;
   k.relu = d->relu; k.res_mode = d->res_mode;
   k.total_iters = k.taps * k.kchunks;
+  if (d->mfma_dtype == 3) {      // H2 operands (fp32 split into two f16 halves): gemm_h2.hip
+    hipStream_t s3 = as_stream(stream);
+    const int rc = coocc_launch_h2(k, d, s3);
+    if (rc != COOCC_OK) return rc;
+    if (k.splitk > 1) {
+      hipLaunchKernelGGL(k_conv_reduce, dim3(cdiv((long long)k.M * k.Cout, 256)), dim3(256), 0, s3, k);
+      COOCC_LAUNCH_CHECK("k_conv_reduce");
+    }
+    return COOCC_OK;
+  }
   if (d->mfma_dtype == 2) {      // bf16 operands in memory: K steps of 64 channels
     COOCC_CHECK_ARG(d->Cin % 64 == 0 && d->in_stride % 8 == 0, "conv_fwd: bf16 operands need Cin % 64 == 0 and in_stride % 8 == 0");
     k.kchunks = d->Cin / 64;
@@ -1258,15 +1256,8 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   const bool table = d->gather != nullptr;
   if (d->mfma_dtype == 2) {
     COOCC_CHECK_ARG(!table && d->wgroup_rows == 0 && !d->out_rows, "conv_fwd: the bf16-MFMA path covers geometric convolutions only");
-    static void* zero_row[64] = {nullptr};
-    int dev = 0;
-    COOCC_HIP(hipGetDevice(&dev));
-    COOCC_CHECK_ARG(dev >= 0 && dev < 64, "conv_fwd: device index");
-    if (!zero_row[dev]) {
-      COOCC_HIP(hipMalloc(&zero_row[dev], 256));
-      COOCC_HIP(hipMemset(zero_row[dev], 0, 256));
-    }
-    k.zrow = zero_row[dev];
+    const int zrc = coocc_zero_row(&k.zrow);
+    if (zrc != COOCC_OK) return zrc;
     k.ntiles = (k.Cout + 127) / 128;
     k.mtiles = (k.M + 127) / 128;
     k.mtiles_per_xcd = k.mtiles >= 64 ? (k.mtiles + 7) / 8 : 0;

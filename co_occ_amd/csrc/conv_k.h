@@ -1,0 +1,36 @@
+// Kernel-side launch record of the implicit-GEMM family (conv3d.hip, gemm_h2.hip) and the shared epilogue.
+#pragma once
+#include "common.h"
+#include "conv_layout.h"
+
+struct ConvK {
+  const float* in; const float* w; float* out; const float* scale; const float* bias;
+  const float* res; const int32_t* gather; const int32_t* out_rows; float* ws;
+  int M, Cin, Cout, Npad, taps, kchunks;
+  int in_stride, out_stride, res_stride;
+  int Xi, Yi, Zi, Xo, Yo, Zo, stride;
+  int kx, ky, kz, px, py, pz;   // per-axis kernel extent / padding (taps = kx*ky*kz, tap index t = (dx*ky + dy)*kz + dz)
+  int wgroup_rows;              // > 0: output rows [g*wgroup_rows, (g+1)*wgroup_rows) use weight pack g (Winograd points)
+  size_t wgroup_floats;         // floats per weight pack
+  int relu, res_mode, iters_per_split, total_iters, splitk;
+  int mtiles, ntiles, mtiles_per_xcd;
+  size_t in_bytes;              // total input bytes (k_conv2 bases its buffer descriptor at the tile's first row)
+  unsigned w_bytes;             // bytes of one weight pack
+  const void* zrow;             // k_conv_bf16w / k_gemm_h2z: 16 zero bytes in global memory (source of padded / out-of-range rows)
+  float alpha;                  // k_gemm_h2z: accumulators are multiplied by alpha before the epilogue (1 / operand scale)
+};
+
+__device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t rrow) {
+  if (p.res_mode == 3) v += p.res[rrow * p.res_stride + n];   // raw partial sum of an earlier K-slice pass
+  if (p.scale) v *= p.scale[n];
+  if (p.bias) v += p.bias[n];
+  if (p.res_mode == 1) v += p.res[rrow * p.res_stride + n];
+  if (p.relu) v = fmaxf(v, 0.f);
+  if (p.res_mode == 2) v *= p.res[rrow * p.res_stride + n];
+  return v;
+}
+
+
+// gemm_h2.hip: fp32-accurate GEMM on the f16 matrix cores (operands split hi + lo * 2^-11); called by coocc_conv_fwd for mfma_dtype 3
+int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s);
+int coocc_zero_row(const void** out);

@@ -1,0 +1,380 @@
+// fp32-accurate implicit GEMM on the f16 matrix cores (v_mfma_f32_32x32x16_f16, 16x the fp32-MFMA rate).
+//
+// Every fp32 operand is split into two halves,  a = hi + lo * 2^-11,  hi = f16(a),  lo = f16((a - hi) * 2^11)
+// (22 significand bits; lo is scaled so that it stays a normal f16 wherever hi is), and the product keeps the three
+// leading terms in two fp32 accumulator sets:
+//
+//     sum a b  ~=  sum ah bh  +  2^-11 * sum (ah bl + al bh)            (the dropped al bl term is 2^-22 relative)
+//
+// Three MFMAs per 32x32x16 step instead of eight 32x32x2 fp32 steps at 1/16 of the rate: 5.3x the fp32-MFMA peak.
+// Measured error (tools/proto/split_mfma.hip on MI355X, K = 768..13824, against fp64): rms 1.9e-7 .. 7.5e-7 of the output
+// scale, HALF the error of the exact-fp32 MFMA chain on the same data (3.5e-7 .. 1.5e-6): the matrix core sums the 16
+// products of a step in one go instead of through 16 dependent fp32 roundings, and the operand rounding (2^-22 per
+// product, random sign) is an order of magnitude below the accumulation error of a K >= 768 fp32 chain.
+//
+// Operand layout ("H2 rows"): a row of C channels (C % 32 == 0) is C/32 chunks of 128 bytes, each
+// [32 x f16 hi | 32 x f16 lo] -- the size of the fp32 row it replaces, and one 128-byte chunk is exactly one K = 32
+// stage of a row in LDS.  Producers write it directly (coocc_wino_input_h2: the Winograd input transform;
+// coocc_rows_to_h2: any fp32 rows).  Weights: coocc pack [(chunk, tap)][Npad/32][k16 step s][plane hi|lo][64 lanes][8 f16],
+// lane l holds B[k = 32 chunk + 16 s + 8 (l >> 5) + 0..7][n = 32 nt + (l & 31)]: one 16-byte load per fragment, 1 KB coalesced
+// per wave instruction, straight into registers (no LDS), made on the host by core.PackedConv.h2_pack.
+//
+// k_gemm_h2z<KZ>: stride-1 "same" geometry (the Winograd-domain grouped GEMM with its 3 z taps, and direct 3x3x3 / 3x3xKZ
+// layers).  128 x 128 tile, 4 waves, wave w owns columns 32 w .. 32 w + 31 of all 128 rows (B never shared between waves,
+// A read by every wave from LDS).  Output rows are linear in (x, y, z), so the rows tap (dx, dy, dz) needs are the tile's own
+// rows shifted by a constant: ONE LDS image of 128 + KZ - 1 rows per (chunk, dx, dy) serves all KZ z taps (k_conv_bf16z's
+// scheme).  The image is staged by global_load_lds (16 B per lane, no staging registers); it is lane-linear, so the
+// bank-conflict swizzle sits on the SOURCE address: 16-byte slot c of LDS row r holds slot c ^ ((r >> 1) & 7) of the chunk.
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+
+#include "conv_k.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+#define H2_LO_SCALE 2048.f
+
+__device__ __forceinline__ void glds16_(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l,
+                                   16, 0, 0);
+}
+
+__device__ __forceinline__ void split_h2(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)((v - (float)hi) * H2_LO_SCALE);
+}
+
+// XY = false: kx = ky = 1 (the Winograd-domain grouped GEMM: only the z taps), no (dx, dy) cursor and no x / y range checks.
+// Computed TRANSPOSED (weights as the first MFMA operand): a lane ends up with 4-channel runs of its own output rows, so the
+// epilogue is 16-byte stores (and 16-byte scale / bias / residual loads).
+// Fragments are SINGLE-buffered (32 registers): a k16 step runs  P0 = W_hi x A_hi, P1 = W_lo x A_hi, P2 = W_hi x A_lo  (4 MFMAs each);
+// A_lo of step u is read from LDS under P0/P1 of step u (its registers are free once P2 of step u-1 has issued), A_hi of step u+1
+// under P2 of step u; sched_barrier(0) between the phases keeps hipcc from hoisting the reads (more live fragment registers ->
+// spills -> scratch reloads that wait vmcnt(0), i.e. for the weight loads just issued).  Two workgroups per CU (<= 256 registers)
+// cover each other's barriers, prologues and epilogues.
+#define H2_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <int KZ, bool XY>
+__global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
+  constexpr int BM = 128, TM = 4;
+  constexpr int AROWS = 136;                       // 128 + KZ - 1 rounded up to whole 8-row wave instructions
+  constexpr unsigned STAGE = AROWS * 128, ZOFF = 2 * STAGE;     // two stages + one row of zeros (masked fragments read it)
+  __shared__ __attribute__((aligned(16))) char As[2 * AROWS * 128 + 128];
+
+  const int id = blockIdx.x;
+  int mtile, nt, slot_ = id >> 3;
+  if (p.mtiles_per_xcd > 0) {
+    const int xcd = id & 7;
+    const int mt_local = slot_ / p.ntiles;
+    nt = slot_ - mt_local * p.ntiles;
+    mtile = xcd * p.mtiles_per_xcd + mt_local;
+    if (mt_local >= p.mtiles_per_xcd || mtile >= p.mtiles) return;
+  } else {
+    mtile = id / p.ntiles;
+    nt = id - mtile * p.ntiles;
+  }
+  const int m0 = mtile * BM, n0 = nt * 128;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, h = lane >> 5;
+  const int srow = lane >> 3, slot = lane & 7;
+  if (tid < 8) *(f32x4*)&As[ZOFF + tid * 16] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // everything the K loop needs in registers (a field of `p` read inside the loop is a scalar load whose lgkmcnt(0) also waits
+  // for the LDS reads in flight)
+  const int kx = p.kx, ky = p.ky, px = p.px, py = p.py, Xi = p.Xi, Yi = p.Yi, Zi = p.Zi;
+  const unsigned rowbytes = (unsigned)p.in_stride * 4;
+  const int total_rows = Xi * Yi * Zi * (p.M / (p.Xo * p.Yo * p.Zo));
+  const char* inb = (const char*)p.in;
+  const char* zrow = (const char*)p.zrow;
+  // staging: LDS row r holds input row  m0 + r - pz + ((dx - px) Yi + (dy - py)) Zi  (any row of the buffer, else zeros);
+  // 32-bit byte offsets (the launcher checks that the input is smaller than 4 GB).  The swizzle term of a row does not depend
+  // on the instruction: ((r >> 1) & 7) with r = (4 j + wave) 8 + srow  is  (4 (wave & 1) + (srow >> 1)) & 7
+  const int arow0 = m0 + srow - p.pz;
+  const unsigned aq = (unsigned)((slot ^ ((4 * (wave & 1) + (srow >> 1)) & 7)) * 16);
+  // the output voxels this lane's A fragments belong to (fragment i: row i*32 + li); zbits: bit (i*3 + dz) = z tap dz in range
+  int vx[TM], vy[TM];
+  unsigned zbits = 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + i * 32 + li;
+    const int oz = m % p.Zo; int q = m / p.Zo;
+    if (XY) {
+      const int oy = q % p.Yo; q /= p.Yo;
+      vx[i] = q % p.Xo; vy[i] = oy;
+    }
+#pragma unroll
+    for (int dz = 0; dz < KZ; ++dz)
+      if (m < p.M && (unsigned)(oz + dz - p.pz) < (unsigned)Zi) zbits |= 1u << (i * 3 + dz);
+  }
+  const int it0 = blockIdx.y * p.iters_per_split;
+  const int it1 = min(it0 + p.iters_per_split, p.total_iters);
+  const int ngroups = (it1 - it0) / KZ;                 // the launcher keeps split boundaries on whole (dx, dy) groups
+  const int g0 = it0 / KZ;                              // group index = (chunk * kx + dx) * ky + dy
+  int gkc = XY ? g0 / (kx * ky) : g0, gd = XY ? (g0 / ky) % kx : 0, gh = XY ? g0 % ky : 0;
+  int cd = gd, ch_ = gh;
+  const long long wstep = (long long)(p.Npad >> 5) * 4096;
+  const char* wcur = (const char*)p.w + (p.wgroup_rows > 0 ? (size_t)(m0 / p.wgroup_rows) * p.wgroup_floats * 4 : (size_t)0) +
+                     (long long)it0 * wstep + (long long)((n0 >> 5) + wave) * 4096 + lane * 16;
+
+  auto issueA = [&](int buf) {
+    const int off = XY ? ((gd - px) * Yi + (gh - py)) * Zi : 0;
+    const unsigned coff = (unsigned)gkc * 128 + aq;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (j == 4 && wave != 0) break;
+      const int r8 = j < 4 ? (j * 4 + wave) * 8 : 128;
+      const int L = arow0 + r8 + off;
+      const char* src = (unsigned)L < (unsigned)total_rows ? inb + ((unsigned)L * rowbytes + coff) : zrow;
+      glds16_(src, &As[buf * STAGE + r8 * 128]);
+    }
+    if (XY) { if (++gh == ky) { gh = 0; if (++gd == kx) { gd = 0; ++gkc; } } }
+    else ++gkc;
+  };
+  f16x8 breg[2][2][2];        // [register set][k16 step][plane]
+  auto loadB = [&](auto bufc) {
+    constexpr int B_ = decltype(bufc)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) breg[B_][s][pl] = *(const f16x8*)(wcur + (s * 2 + pl) * 1024);
+    wcur += wstep;
+  };
+  // fragment of row i*32 + li + dz, 16-byte slot q = (2 s + h | 4 + 2 s + h): (li + dz) * 128 + ((q ^ (((li + dz) >> 1) & 7)) << 4)
+  unsigned fragoff[KZ][4];
+#pragma unroll
+  for (int dz = 0; dz < KZ; ++dz)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int sl = (q & 1) * 4 + 2 * (q >> 1) + h;            // q = 2 s + plane
+      fragoff[dz][q] = (li + dz) * 128 + ((sl ^ (((li + dz) >> 1) & 7)) << 4);
+    }
+  f16x8 fhi[TM], flo[TM];
+  // a lane whose output voxel's tap leaves the grid reads the zero row instead: one select on the LDS address, the loads stay
+  // unconditional (hipcc turns "ok ? fragment : 0" into a branch around the loads)
+  auto load_plane = [&](auto planec, auto stagec, auto dzc, auto sc, unsigned bits) {
+    constexpr int PL = decltype(planec)::value, ST = decltype(stagec)::value, DZ = decltype(dzc)::value, S_ = decltype(sc)::value;
+    asm volatile("" : "+v"(bits));      // keep the address selects here: hoisted out of the K loop they are dozens of live registers
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const bool ok = (bits >> (i * 3 + DZ)) & 1;
+      const unsigned a = ok ? fragoff[DZ][2 * S_ + PL] + (ST * STAGE + i * 4096) : ZOFF;
+      if (PL == 0) fhi[i] = *(const f16x8*)&As[a];
+      else flo[i] = *(const f16x8*)&As[a];
+    }
+  };
+
+  f32x16 hh[TM], xx[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hh[i][r] = 0.f; xx[i][r] = 0.f; }
+  auto p01 = [&](auto setc, auto sc) {
+    constexpr int B_ = decltype(setc)::value, S_ = decltype(sc)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) hh[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], fhi[i], hh[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][1], fhi[i], xx[i], 0, 0, 0);
+  };
+  auto p2 = [&](auto setc, auto sc) {
+    constexpr int B_ = decltype(setc)::value, S_ = decltype(sc)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], flo[i], xx[i], 0, 0, 0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+
+  // one tap (two k16 steps) of the group in stage ST with weight set BB; `nxt`: what the A_hi fragments fetched under the last P2
+  // belong to -- the next tap of this group (stage ST, tap DZ + 1), or, for the last tap, step 0 of the next group (other stage,
+  // after the barrier that retires this one)
+  auto tap = [&](auto stc, auto bbc, auto dzc, bool more_taps, unsigned okbits, unsigned okbits_next) {
+    constexpr int ST = decltype(stc)::value, BB = decltype(bbc)::value, DZ = decltype(dzc)::value;
+    using STC = std::integral_constant<int, ST>; using SNC = std::integral_constant<int, ST ^ 1>;
+    using DZC = std::integral_constant<int, DZ>; using DZN = std::integral_constant<int, (DZ + 1 < KZ ? DZ + 1 : 0)>;
+    using BBC = std::integral_constant<int, BB>;
+    if (more_taps) loadB(std::integral_constant<int, BB ^ 1>{});
+    load_plane(I1{}, STC{}, DZC{}, I0{}, okbits);
+    p01(BBC{}, I0{});
+    H2_FENCE();
+    load_plane(I0{}, STC{}, DZC{}, I1{}, okbits);
+    p2(BBC{}, I0{});
+    H2_FENCE();
+    load_plane(I1{}, STC{}, DZC{}, I1{}, okbits);
+    p01(BBC{}, I1{});
+    H2_FENCE();
+    if constexpr (DZ + 1 < KZ) {
+      load_plane(I0{}, STC{}, DZN{}, I0{}, okbits);
+    } else {
+      __syncthreads();          // every wave has read this stage for the last time; the next group's image has landed
+      load_plane(I0{}, SNC{}, I0{}, I0{}, okbits_next);
+    }
+    p2(BBC{}, I1{});
+    H2_FENCE();
+  };
+  auto xybits = [&]() {
+    unsigned b = zbits;
+    if (XY) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        if (!((unsigned)(vx[i] + cd - px) < (unsigned)Xi && (unsigned)(vy[i] + ch_ - py) < (unsigned)Yi)) b &= ~(7u << (i * 3));
+    }
+    return b;
+  };
+  // one (chunk, dx, dy) group in stage GP: KZ taps; weight-set parity of its first tap = (GP * KZ) & 1
+  unsigned okbits = xybits();
+  auto group = [&](auto gpc, int g) {
+    constexpr int GP = decltype(gpc)::value;
+    using GPC = std::integral_constant<int, GP>;
+    const bool last = g + 1 >= ngroups;
+    if (!last) issueA(GP ^ 1);
+    if (XY) { if (++ch_ == ky) { ch_ = 0; if (++cd == kx) cd = 0; } }
+    const unsigned nextbits = xybits();
+    tap(GPC{}, std::integral_constant<int, (GP * KZ) & 1>{}, I0{}, KZ > 1 || !last, okbits, nextbits);
+    if constexpr (KZ > 1)
+      tap(GPC{}, std::integral_constant<int, (GP * KZ + 1) & 1>{}, I1{}, KZ > 2 || !last, okbits, nextbits);
+    if constexpr (KZ > 2)
+      tap(GPC{}, std::integral_constant<int, (GP * KZ + 2) & 1>{}, std::integral_constant<int, 2>{}, !last, okbits, nextbits);
+    okbits = nextbits;
+  };
+
+  if (ngroups > 0) {
+    issueA(0);
+    loadB(I0{});
+  }
+  __syncthreads();
+  if (ngroups > 0) load_plane(I0{}, I0{}, I0{}, I0{}, okbits);
+  for (int g = 0; g < ngroups; g += 2) {
+    group(I0{}, g);
+    if (g + 1 < ngroups) group(I1{}, g + 1);
+  }
+
+  // epilogue: lane (li, h) holds, for output row m0 + i*32 + li, the channels n0 + 32 wave + 8 j + 4 h + 0..3 (j = 0..3)
+  const int nb = n0 + wave * 32 + 4 * h;
+  const float alpha = p.alpha, lo = p.alpha * (1.f / H2_LO_SCALE);
+  if (p.splitk > 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + i * 32 + li;
+      if (m >= p.M) continue;
+      float* o = p.ws + ((size_t)blockIdx.y * p.M + m) * p.Npad + nb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo;
+        *(f32x4*)(o + 8 * j) = v;
+      }
+    }
+  } else {
+    const bool vec = (p.Cout & 3) == 0 && (p.out_stride & 3) == 0 && (!p.res || (p.res_stride & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + i * 32 + li;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = nb + 8 * j;
+        if (n >= p.Cout) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo;
+        if (vec) {
+          if (p.res_mode == 3) v = v + *(const f32x4*)(p.res + (size_t)m * p.res_stride + n);
+          if (p.scale) v = v * *(const f32x4*)(p.scale + n);
+          if (p.bias) v = v + *(const f32x4*)(p.bias + n);
+          if (p.res_mode == 1) v = v + *(const f32x4*)(p.res + (size_t)m * p.res_stride + n);
+          if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          if (p.res_mode == 2) v = v * *(const f32x4*)(p.res + (size_t)m * p.res_stride + n);
+          *(f32x4*)(p.out + (size_t)m * p.out_stride + n) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.Cout) p.out[(size_t)m * p.out_stride + n + e] = epilogue(p, v[e], n + e, (size_t)m);
+        }
+      }
+    }
+  }
+}
+
+int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
+  COOCC_CHECK_ARG(!d->gather && !d->out_rows, "conv_fwd: the split-f16 path covers geometric taps only");
+  COOCC_CHECK_ARG(d->Cin % 32 == 0 && d->in_stride % 32 == 0, "conv_fwd: H2 operands need Cin % 32 == 0 and in_stride % 32 == 0");
+  COOCC_CHECK_ARG(k.stride == 1 && k.Xo == k.Xi && k.Yo == k.Yi && k.Zo == k.Zi && k.kz >= 1 && k.kz <= 3,
+                  "conv_fwd: the split-f16 kernel covers stride-1 'same' layers with 1..3 z taps");
+  COOCC_CHECK_ARG(d->wgroup_rows == 0 || d->wgroup_rows % 128 == 0, "conv_fwd: wgroup_rows must be a multiple of 128");
+  k.kchunks = d->Cin / 32;
+  k.total_iters = k.taps * k.kchunks;
+  k.wgroup_floats = (size_t)k.taps * k.kchunks * k.Npad * 32;       // 128 bytes per (chunk, tap, column)
+  k.alpha = d->alpha != 0.f ? d->alpha : 1.f;
+  int rc = coocc_zero_row(&k.zrow);
+  if (rc != COOCC_OK) return rc;
+  k.ntiles = (k.Cout + 127) / 128;
+  k.mtiles = (k.M + 127) / 128;
+  k.mtiles_per_xcd = k.mtiles >= 64 ? (k.mtiles + 7) / 8 : 0;
+  // split-K on whole (dx, dy) groups
+  int splitk = d->splitk;
+  const long long blocks = (long long)k.mtiles * k.ntiles;
+  const int ngroups = k.total_iters / k.kz;
+  if (splitk <= 0) {
+    splitk = 1;
+    if (blocks < 256 && ngroups >= 8 && d->ws) {
+      splitk = (int)(512 / blocks);
+      if (splitk > ngroups / 4) splitk = ngroups / 4;
+      if (splitk > 64) splitk = 64;
+      while (splitk > 1 && (long long)splitk * d->M * k.Npad > d->ws_floats) --splitk;
+      if (splitk < 1) splitk = 1;
+    }
+  }
+  int gps = (ngroups + splitk - 1) / splitk;
+  k.iters_per_split = gps * k.kz;
+  k.splitk = (k.total_iters + k.iters_per_split - 1) / k.iters_per_split;
+  COOCC_CHECK_ARG(k.splitk == 1 || (d->ws && (long long)k.splitk * d->M * k.Npad <= d->ws_floats), "conv_fwd: split-K workspace too small");
+  dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
+  COOCC_CHECK_ARG((unsigned long long)d->B * d->Xi * d->Yi * d->Zi * d->in_stride * 4ull < 0xFFFFFF00ull && (long long)d->M < (1ll << 30),
+                  "conv_fwd: the split-f16 kernel addresses its input with 32-bit byte offsets (< 4 GB)");
+  const bool xy = !(k.kx == 1 && k.ky == 1 && k.px == 0 && k.py == 0);
+  if (!xy) {
+    if (k.kz == 3) hipLaunchKernelGGL((k_gemm_h2z<3, false>), grid, dim3(256), 0, s, k);
+    else if (k.kz == 2) hipLaunchKernelGGL((k_gemm_h2z<2, false>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((k_gemm_h2z<1, false>), grid, dim3(256), 0, s, k);
+  } else {
+    if (k.kz == 3) hipLaunchKernelGGL((k_gemm_h2z<3, true>), grid, dim3(256), 0, s, k);
+    else if (k.kz == 2) hipLaunchKernelGGL((k_gemm_h2z<2, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((k_gemm_h2z<1, true>), grid, dim3(256), 0, s, k);
+  }
+  COOCC_LAUNCH_CHECK("k_gemm_h2z");
+  return COOCC_OK;
+}
+
+// fp32 rows (row stride in_stride floats, first C columns, C % 32 == 0) * scale -> H2 rows [rows][C/32][hi 32 | lo 32] (4 C bytes per row)
+__global__ __launch_bounds__(256) void k_rows_to_h2(const float* __restrict__ in, int in_stride, long long rows, int C, float scale,
+                                                     char* __restrict__ out) {
+  const int c8 = C >> 3;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * c8) return;
+  const long long r = i / c8;
+  const int c = (int)(i - r * c8) * 8;
+  const f32x4 a = *(const f32x4*)(in + r * in_stride + c), b = *(const f32x4*)(in + r * in_stride + c + 4);
+  f16x8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    _Float16 u, v;
+    split_h2(a[e] * scale, u, v); hi[e] = u; lo[e] = v;
+    split_h2(b[e] * scale, u, v); hi[4 + e] = u; lo[4 + e] = v;
+  }
+  char* o = out + r * (long long)C * 4 + (c >> 5) * 128 + (c & 31) * 2;
+  *(f16x8*)o = hi;
+  *(f16x8*)(o + 64) = lo;
+}
+
+extern "C" int coocc_rows_to_h2(const float* in, int in_stride, int64_t rows, int C, float scale, void* out_h2, void* stream) {
+  COOCC_CHECK_ARG(in && out_h2 && rows >= 0 && C > 0 && C % 32 == 0 && in_stride % 4 == 0 && in_stride >= C, "rows_to_h2: bad args");
+  COOCC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)out_h2 & 15) == 0, "rows_to_h2: pointers must be 16-byte aligned");
+  if (rows == 0) return COOCC_OK;
+  hipLaunchKernelGGL(k_rows_to_h2, dim3(cdiv(rows * (C / 8), 256)), dim3(256), 0, as_stream(stream), in, in_stride, (long long)rows, C,
+                     scale, (char*)out_h2);
+  COOCC_LAUNCH_CHECK("k_rows_to_h2");
+  return COOCC_OK;
+}

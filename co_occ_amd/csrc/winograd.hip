@@ -118,6 +118,84 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ in, i
   }
 }
 
+// The same transform writing V * scale as "H2 rows" (gemm_h2.hip): per row and 32-channel chunk 64 bytes of f16 hi followed by
+// 64 bytes of f16 lo = f16((v - hi) * 2^11).  A thread owns 4 channels: 8-byte stores.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int N>
+__global__ __launch_bounds__(256) void k_wino_in_h2(const float* __restrict__ in, int in_stride, int B, int X, int Y, int Z,
+                                                     int C, int Tx, int Ty, size_t gstride_bytes, int vstride, float scale,
+                                                     char* __restrict__ V) {
+  constexpr int MO = Wino<N>::M;
+  const int c4 = C >> 2;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long rows = (long long)B * Tx * Ty * Z;
+  if (i >= rows * c4) return;
+  const int c = (int)(i % c4) * 4;
+  const long long row = i / c4;
+  long long r = row;
+  const int z = (int)(r % Z); r /= Z;
+  const int ty = (int)(r % Ty); r /= Ty;
+  const int tx = (int)(r % Tx); const int b = (int)(r / Tx);
+  f32x4 t[N][N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    f32x4 d[N], q[N];
+    const int y = MO * ty - 1 + e;
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+      const int x = MO * tx - 1 + a;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y)
+        v = *(const f32x4*)(in + ((((size_t)b * X + x) * Y + y) * Z + z) * in_stride + c);
+      d[a] = v;
+    }
+    Wino<N>::bt(d, q);
+#pragma unroll
+    for (int a = 0; a < N; ++a) t[a][e] = q[a];
+  }
+  char* o = V + (size_t)row * vstride * 4 + (c >> 5) * 128 + (c & 31) * 2;
+#pragma unroll
+  for (int a = 0; a < N; ++a) {
+    f32x4 q[N];
+    Wino<N>::bt(t[a], q);
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      f16x4 hi, lo;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float v = q[e][u] * scale;
+        hi[u] = (_Float16)v;
+        lo[u] = (_Float16)((v - (float)hi[u]) * 2048.f);
+      }
+      char* oo = o + (size_t)(a * N + e) * gstride_bytes;
+      *(f16x4*)oo = hi;
+      *(f16x4*)(oo + 64) = lo;
+    }
+  }
+}
+
+extern "C" int coocc_wino_input_h2(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, void* V,
+                                   int vstride, int64_t group_rows, float scale, void* stream) {
+  COOCC_CHECK_ARG(in && V && B > 0 && X > 0 && Y > 0 && Z > 0 && C > 0 && C % 32 == 0 && in_stride % 4 == 0, "wino_input_h2: bad args");
+  COOCC_CHECK_ARG(tile >= 2 && tile <= 4, "wino_input_h2: tile must be 2, 3 or 4");
+  COOCC_CHECK_ARG(vstride >= C && vstride % 32 == 0 && ((uintptr_t)V & 127) == 0, "wino_input_h2: V row stride / alignment");
+  COOCC_CHECK_ARG(scale > 0.f, "wino_input_h2: scale must be positive");
+  const int Tx = (X + tile - 1) / tile, Ty = (Y + tile - 1) / tile;
+  const long long rows = (long long)B * Tx * Ty * Z;
+  COOCC_CHECK_ARG(group_rows >= rows, "wino_input_h2: group_rows smaller than B*ceil(X/tile)*ceil(Y/tile)*Z");
+  const dim3 grid(cdiv(rows * (C / 4), 256));
+  const size_t gstride = (size_t)group_rows * vstride * 4;
+  hipStream_t s = as_stream(stream);
+  if (tile == 2)
+    hipLaunchKernelGGL(k_wino_in_h2<4>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V);
+  else if (tile == 3)
+    hipLaunchKernelGGL(k_wino_in_h2<5>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V);
+  else
+    hipLaunchKernelGGL(k_wino_in_h2<6>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V);
+  COOCC_LAUNCH_CHECK("k_wino_in_h2");
+  return COOCC_OK;
+}
+
 static int wino_input_impl(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, float* V, int vstride,
                            int64_t group_rows, void* stream) {
   COOCC_CHECK_ARG(in && V && B > 0 && X > 0 && Y > 0 && Z > 0 && C > 0 && C % 4 == 0 && in_stride % 4 == 0, "wino_input: bad args");

@@ -170,7 +170,14 @@ typedef struct coocc_conv_desc {
                                 storage: the reduced-precision path of the OpenOccupancy config; geometric taps only;
                              2: the same arithmetic with the operands already bf16 in memory: `in` = [rows][in_stride] bf16
                                 (coocc_rows_to_bf16), `w` = bf16 pack [(Cin/64 chunk, tap)][roundup(Cout,128)/32][4][64 lanes][8] (fragment-major:
-                                lane l of k-step s holds k = 16 s + 8 (l >> 5) + 0..7 of column 32 nt + (l & 31)); Cin % 64 == 0 */
+                                lane l of k-step s holds k = 16 s + 8 (l >> 5) + 0..7 of column 32 nt + (l & 31)); Cin % 64 == 0;
+                             3: fp32-ACCURATE arithmetic on the f16 matrix cores (csrc/gemm_h2.hip): every operand split into two
+                                f16 halves (hi + lo * 2^-11, 22 significand bits), three v_mfma_f32_32x32x16_f16 per step, fp32
+                                accumulation -- measured error vs fp64 is half that of mfma_dtype 0.  `in` = H2 rows
+                                (coocc_rows_to_h2 / coocc_wino_input_h2), `w` = H2 pack [(Cin/32 chunk, tap)][roundup(Cout,128)/32]
+                                [2 k16 steps][hi | lo][64 lanes][8 f16]; Cin % 32 == 0; stride-1 "same" geometry, kz <= 3, geometric
+                                taps only; wgroup_rows a multiple of 128 */
+  float alpha;            /* mfma_dtype 3: the accumulators are multiplied by alpha (1 / operand scale) before the epilogue; 0 = 1 */
 } coocc_conv_desc;
 
 /* nn.Conv3d(k=3|1)+BN(eval)+ReLU(+residual) (bifuser_n.py:23-30, resnet3d.py:34-64,
@@ -183,6 +190,12 @@ int coocc_conv_fwd(const coocc_conv_desc* d, void* stream);
  * fpn3d.py:69 cast the same tensors once per layer). */
 int coocc_rows_to_bf16(const float* in, int in_stride, int64_t rows, int C, void* out_bf16, void* stream);
 
+/* fp32 rows * scale -> "H2 rows": per row C/32 chunks of [32 x f16 hi | 32 x f16 lo], hi = f16(v), lo = f16((v - hi) * 2^11)
+ * (4 C bytes per row, the size of the fp32 row): the activation operand of coocc_conv_fwd with mfma_dtype 3.  C % 32 == 0.
+ * Replaces nothing in the reference (its convolutions are cuDNN fp32, resnet3d.py:34-64): it is how the same fp32 sums are
+ * evaluated on the 16-bit matrix pipe. */
+int coocc_rows_to_h2(const float* in, int in_stride, int64_t rows, int C, float scale, void* out_h2, void* stream);
+
 /* Winograd F(m x m, 3x3), m = tile = 2 or 4, over (x,y) for 3x3x3 stride-1 pad-1 convs (z stays a direct 3-tap
  * conv): input transform, then ONE coocc_conv_fwd launch over (m+2)^2 x group_rows rows (kx=ky=1, kz=3, pz=1,
  * wgroup_rows=group_rows, weights = (m+2)^2 packs of G g G^T), then output transform + epilogue.  V / Mb:
@@ -194,6 +207,10 @@ int coocc_wino_input(const float* in, int in_stride, int B, int X, int Y, int Z,
  * GEMM's input channels gathered from several channel ranges of the source rows. */
 int coocc_wino_input_strided(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, float* V,
                              int vstride, int64_t group_rows, void* stream);
+/* coocc_wino_input_strided writing V * scale as H2 rows (mfma_dtype 3): C % 32 == 0, vstride (channels of a V row) % 32 == 0,
+ * V offset to a 32-channel chunk boundary (128 bytes per chunk). */
+int coocc_wino_input_h2(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, void* V,
+                        int vstride, int64_t group_rows, float scale, void* stream);
 /* Scatter-form sparse half of a dense 3x3x3 convolution (csrc/sparse_taps.hip): P:[Np][27][Cout] = per occupied input voxel
  * and tap the contribution W_t . in[u] (a row-table coocc_conv_fwd with N = 27*Cout), map: voxel -> row of P or -1
  * (coocc_voxel_index_map); S[v][n] = scale[n] * sum_t P[map[v + t - 1]][t][n], taps in order (deterministic). */
