@@ -24,7 +24,7 @@ class ConvDesc(ctypes.Structure):
                [(n, c_int) for n in ("M", "Cin", "Cout", "taps", "in_stride", "out_stride", "res_stride",
                                      "B", "Xi", "Yi", "Zi", "Xo", "Yo", "Zo", "ksize", "stride", "pad",
                                      "relu", "res_mode", "splitk", "tile_hint", "kx", "ky", "kz", "px", "py", "pz",
-                                     "wgroup_rows", "mfma_dtype")] + [("alpha", ctypes.c_float)]
+                                     "wgroup_rows", "mfma_dtype")] + [("alpha", ctypes.c_float), ("M_dev", c_void_p), ("gather_stride", c_int)]
 
 
 P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_int64
@@ -50,6 +50,11 @@ SIGNATURES = {
     "coocc_ball_query": (I, [I, I, I, F, F, I, P, P, P, P]),
     "coocc_knn_topk": (I, [I, I, I, P, P, P, P, P]),
     "coocc_voxel_index_map": (I, [P, I, I, P, P]),
+    "coocc_voxel_index_map_dev": (I, [P, I, P, I, P, P]),
+    "coocc_fine_sample_voxel_dev": (I, [P, I, I, I, I, P, I, P, I, P, P, P, I, P]),
+    "coocc_fine_sample_img_dev": (I, [P, I, I, I, I, P, P, L, P, P, I, I, P]),
+    "coocc_fine_mlp_pre_dev": (I, [P, I, P, I, L, P, I, P, P, P, F, P, P, P, P, F, P, P, I, P, P]),
+    "coocc_scatter_fine_dev": (I, [P, L, P, I, I, I, P, P, I, I, I, F, P]),
     "coocc_ball_query_voxels": (I, [I, F, F, I, I, I, I, P, P, P, P, P]),
     "coocc_knn_topk_voxels": (I, [I, I, I, I, I, I, P, P, P, P, I, P, P, P, P, P]),
     "coocc_knn_assign": (I, [I, I, I, I, F, P, P, P, P, P, P]),

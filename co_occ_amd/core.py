@@ -510,9 +510,11 @@ def linear_rows(x2d, pc, relu=False, out=None, out_coff=0, in_coff=0, in_C=None)
     return out
 
 
-def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_coff, C, relu=True):
+def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_coff, C, relu=True, count_dev=None):
     """GSFusion G1: dst[out_rows[m], dst_coff:+C] = relu(sum_k W_k . src[gather[k,m], src_coff:+C] + b)
-    * dst[out_rows[m], gate_coff:+C]   (bifuser_n.py:138-169).  src/dst: [rows, stride] tensors."""
+    * dst[out_rows[m], gate_coff:+C]   (bifuser_n.py:138-169).  src/dst: [rows, stride] tensors.
+    ``count_dev``: int32 device tensor holding the number of rows; ``gather`` [K, cap] / ``out_rows`` [cap] are then
+    capacity-sized buffers and nothing about the launch depends on the count (hipGraph replay)."""
     K, M = gather.shape
     if M == 0:
         return
@@ -532,6 +534,8 @@ def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_co
     d.ksize, d.stride, d.pad = 1, 1, 0
     d.relu, d.res_mode, d.splitk = int(relu), 2, 1
     d.tile_hint = TILE_HINT
+    if count_dev is not None:
+        d.M_dev, d.gather_stride = ptr(count_dev, torch.int32), M
     with TIMER.region(conv_kernel_name(M, pc.Cout, True), 2.0 * M * C * pc.Cout * K):
         _lib.conv_fwd(d, src.device)
 

@@ -51,6 +51,10 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
     nt = id - mtile * p.ntiles;
   }
   const int m0 = mtile * BM, n0 = nt * BN;
+  if (p.M_dev) {                       // row count on the device (grid sized for the capacity p.M): whole tiles past it leave
+    p.M = min(p.M, *p.M_dev);
+    if (m0 >= p.M) return;
+  }
   const int tid = threadIdx.x;
   const int piece = tid & 7, lrow = tid >> 3;
   const int wave = tid >> 6, lane = tid & 63;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
   auto iload = [&](int it) {
     const int t = it % p.taps;
 #pragma unroll
-    for (int a = 0; a < PA; ++a) nidx[a] = rbase[a] >= 0 ? p.gather[(size_t)t * p.M + rbase[a]] : -1;
+    for (int a = 0; a < PA; ++a) nidx[a] = rbase[a] >= 0 ? p.gather[(size_t)t * p.gstride + rbase[a]] : -1;
   };
   if (TABLE && it0 < it1) iload(it0);
   auto gload = [&](int it) {
@@ -760,6 +764,10 @@ __global__ __launch_bounds__(256, MINW) void k_conv2(ConvK p) {
     nt = id - mtile * p.ntiles;
   }
   const int m0 = mtile * BM, n0 = nt * 128;
+  if (TB && p.M_dev) {                 // row count on the device (grid sized for the capacity p.M): whole tiles past it leave
+    p.M = min(p.M, *p.M_dev);
+    if (m0 >= p.M) return;
+  }
 
   const int tid = threadIdx.x;
   const int piece = tid & 7, lrow = tid >> 3;
@@ -778,7 +786,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv2(ConvK p) {
   if (TB) {
     for (int i = tid; i < p.taps * BM; i += 256) {
       const int t = i / BM, m = m0 + (i - t * BM);
-      Ti[i] = m < p.M ? p.gather[(size_t)t * p.M + m] : -1;
+      Ti[i] = m < p.M ? p.gather[(size_t)t * p.gstride + m] : -1;
     }
     __syncthreads();
   }
@@ -1180,6 +1188,10 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   memset(&k, 0, sizeof(k));
   k.in = d->in; k.w = d->w; k.out = d->out; k.scale = d->scale; k.bias = d->bias; k.res = d->res;
   k.gather = d->gather; k.out_rows = d->out_rows; k.ws = d->ws;
+  k.M_dev = d->gather ? d->M_dev : nullptr;
+  k.gstride = d->gather_stride > 0 ? d->gather_stride : d->M;
+  COOCC_CHECK_ARG(!d->M_dev || (d->gather && d->splitk == 1), "conv_fwd: M_dev needs a row table (gather) and splitk = 1");
+  COOCC_CHECK_ARG(k.gstride >= d->M, "conv_fwd: gather_stride smaller than M");
   k.M = d->M; k.Cin = d->Cin; k.Cout = d->Cout; k.taps = d->taps;
   k.kchunks = (d->Cin + KC - 1) / KC;
   k.Npad = (d->Cout + NPAD_TO - 1) / NPAD_TO * NPAD_TO;

@@ -18,6 +18,8 @@ struct ConvK {
   unsigned w_bytes;             // bytes of one weight pack
   const void* zrow;             // k_conv_bf16w / k_gemm_h2z: 16 zero bytes in global memory (source of padded / out-of-range rows)
   float alpha;                  // k_gemm_h2z: accumulators are multiplied by alpha before the epilogue (1 / operand scale)
+  const int32_t* M_dev;         // row-table kernels: actual row count on the device (<= M, the grid's capacity), or NULL
+  int gstride;                  // row-table kernels: entries per tap of `gather` (>= M)
 };
 
 __device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t rrow) {

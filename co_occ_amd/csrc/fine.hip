@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void k_fine_sample_voxel(const float* __restri
                                                             const int32_t* __restrict__ coarse_lin, int n, int ratio,
                                                             float fx1, float fy1, float fz1,
                                                             int64_t* __restrict__ fine_xyz, float* __restrict__ feat,
-                                                            int out_stride) {
+                                                            int out_stride, const int32_t* __restrict__ n_dev) {
+  if (n_dev) n = min(n, *n_dev);
   const int r3 = ratio * ratio * ratio;
   const long long nf = (long long)n * r3;
   const long long f = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256, 4) void k_fine_sample_voxel_r2(const float* __
                                                                const int32_t* __restrict__ coarse_lin, int n,
                                                                float fx1, float fy1, float fz1,
                                                                int64_t* __restrict__ fine_xyz, float* __restrict__ feat,
-                                                               int out_stride) {
+                                                               int out_stride, const int32_t* __restrict__ n_dev) {
+  if (n_dev) n = min(n, *n_dev);
   // C <= 64: two channels per lane fill only half a wave, so each half-wave takes its own coarse voxel (no cross-lane
   // operation below: every lane derives the voxel's stencil itself)
   const int wv = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -164,7 +166,8 @@ __global__ __launch_bounds__(256) void k_fine_sample_voxel_rn(const float* __res
                                                                const int32_t* __restrict__ coarse_lin, int n,
                                                                float fx1, float fy1, float fz1,
                                                                int64_t* __restrict__ fine_xyz, float* __restrict__ feat,
-                                                               int out_stride) {
+                                                               int out_stride, const int32_t* __restrict__ n_dev) {
+  if (n_dev) n = min(n, *n_dev);
   constexpr int R3 = R * R * R;
   const int wv = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const bool halfw = C <= 64;
@@ -245,9 +248,21 @@ __global__ __launch_bounds__(256) void k_fine_sample_voxel_rn(const float* __res
 static int g_fine_pointwise = 0;   // test hook: 1 = always the one-wave-per-fine-point kernels
 extern "C" void coocc_fine_set_pointwise(int on) { g_fine_pointwise = on; }
 
+static int fine_sample_voxel_impl(const float* vol, int C, int X, int Y, int Z, const int32_t* coarse_lin, int n, const int32_t* n_dev,
+                                  int ratio, const int* final_size_host, int64_t* fine_xyz, float* feat, int out_stride, void* stream);
 extern "C" int coocc_fine_sample_voxel(const float* vol, int C, int X, int Y, int Z, const int32_t* coarse_lin, int n,
                                        int ratio, const int* final_size_host, int64_t* fine_xyz, float* feat,
                                        int out_stride, void* stream) {
+  return fine_sample_voxel_impl(vol, C, X, Y, Z, coarse_lin, n, nullptr, ratio, final_size_host, fine_xyz, feat, out_stride, stream);
+}
+extern "C" int coocc_fine_sample_voxel_dev(const float* vol, int C, int X, int Y, int Z, const int32_t* coarse_lin, int n_cap,
+                                           const int32_t* n_dev, int ratio, const int* final_size_host, int64_t* fine_xyz,
+                                           float* feat, int out_stride, void* stream) {
+  COOCC_CHECK_ARG(n_dev, "fine_sample_voxel_dev: null device count");
+  return fine_sample_voxel_impl(vol, C, X, Y, Z, coarse_lin, n_cap, n_dev, ratio, final_size_host, fine_xyz, feat, out_stride, stream);
+}
+static int fine_sample_voxel_impl(const float* vol, int C, int X, int Y, int Z, const int32_t* coarse_lin, int n, const int32_t* n_dev,
+                                  int ratio, const int* final_size_host, int64_t* fine_xyz, float* feat, int out_stride, void* stream) {
   COOCC_CHECK_ARG(vol && coarse_lin && final_size_host && fine_xyz && feat && C % 2 == 0 && ratio >= 1 && n >= 0,
                   "fine_sample_voxel: bad args");
   if (n == 0) return COOCC_OK;
@@ -257,20 +272,20 @@ extern "C" int coocc_fine_sample_voxel(const float* vol, int C, int X, int Y, in
   if (!g_fine_pointwise && ratio == 2 && final_size_host[0] == 2 * X && final_size_host[1] == 2 * Y && final_size_host[2] == 2 * Z) {
     hipLaunchKernelGGL(k_fine_sample_voxel_r2, dim3(cdiv((long long)(C <= 64 ? (n + 1) / 2 : n) * 64, 256)), dim3(256), 0, as_stream(stream), vol, C, X,
                        Y, Z, coarse_lin, n, (float)(final_size_host[0] - 1), (float)(final_size_host[1] - 1),
-                       (float)(final_size_host[2] - 1), fine_xyz, feat, out_stride);
+                       (float)(final_size_host[2] - 1), fine_xyz, feat, out_stride, n_dev);
     COOCC_LAUNCH_CHECK("k_fine_sample_voxel_r2");
     return COOCC_OK;
   }
   if (!g_fine_pointwise && ratio == 4 && final_size_host[0] == 4 * X && final_size_host[1] == 4 * Y && final_size_host[2] == 4 * Z) {
     hipLaunchKernelGGL(k_fine_sample_voxel_rn<4>, dim3(cdiv((long long)(C <= 64 ? (n + 1) / 2 : n) * 64, 256)), dim3(256), 0,
                        as_stream(stream), vol, C, X, Y, Z, coarse_lin, n, (float)(final_size_host[0] - 1),
-                       (float)(final_size_host[1] - 1), (float)(final_size_host[2] - 1), fine_xyz, feat, out_stride);
+                       (float)(final_size_host[1] - 1), (float)(final_size_host[2] - 1), fine_xyz, feat, out_stride, n_dev);
     COOCC_LAUNCH_CHECK("k_fine_sample_voxel_rn");
     return COOCC_OK;
   }
   hipLaunchKernelGGL(k_fine_sample_voxel, dim3(cdiv(nf * 64, 256)), dim3(256), 0, as_stream(stream), vol, C, X, Y, Z,
                      coarse_lin, n, ratio, (float)(final_size_host[0] - 1), (float)(final_size_host[1] - 1),
-                     (float)(final_size_host[2] - 1), fine_xyz, feat, out_stride);
+                     (float)(final_size_host[2] - 1), fine_xyz, feat, out_stride, n_dev);
   COOCC_LAUNCH_CHECK("k_fine_sample_voxel");
   return COOCC_OK;
 }
@@ -285,7 +300,9 @@ extern "C" int coocc_fine_sample_voxel(const float* vol, int C, int X, int Y, in
 __global__ __launch_bounds__(256) void k_fine_sample_img(const float* __restrict__ img, int ncam, int Ci, int Hf, int Wf,
                                                           const float* __restrict__ prm,
                                                           const int64_t* __restrict__ fine_xyz, long long nf,
-                                                          float* __restrict__ feat, int out_stride) {
+                                                          float* __restrict__ feat, int out_stride,
+                                                          const int32_t* __restrict__ n_dev, int n_mul) {
+  if (n_dev) nf = min(nf, (long long)*n_dev * n_mul);
   const long long f = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (f >= nf) return;
@@ -402,7 +419,9 @@ template <int R>
 __global__ __launch_bounds__(256) void k_fine_sample_img_grp(const float* __restrict__ img, int ncam, int Ci, int Hf, int Wf,
                                                               const float* __restrict__ prm,
                                                               const int64_t* __restrict__ fine_xyz, int n,
-                                                              float* __restrict__ feat, int out_stride) {
+                                                              float* __restrict__ feat, int out_stride,
+                                                              const int32_t* __restrict__ n_dev) {
+  if (n_dev) n = min(n, *n_dev);
   constexpr int R3 = R * R * R;
   const int i = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
@@ -507,9 +526,21 @@ __global__ __launch_bounds__(256) void k_fine_sample_img_grp(const float* __rest
   }
 }
 
+static int fine_sample_img_impl(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf, const float* params, const int64_t* fine_xyz,
+                                int64_t nfine, const int32_t* n_dev, float* feat, int out_stride, int group, void* stream);
 extern "C" int coocc_fine_sample_img(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf, const float* params,
                                      const int64_t* fine_xyz, int64_t nfine, float* feat, int out_stride, int group,
                                      void* stream) {
+  return fine_sample_img_impl(img_nhwc, ncam, Ci, Hf, Wf, params, fine_xyz, nfine, nullptr, feat, out_stride, group, stream);
+}
+extern "C" int coocc_fine_sample_img_dev(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf, const float* params,
+                                         const int64_t* fine_xyz, int64_t nfine_cap, const int32_t* n_dev, float* feat,
+                                         int out_stride, int group, void* stream) {
+  COOCC_CHECK_ARG(n_dev && (group == 1 || group == 2 || group == 4), "fine_sample_img_dev: needs the device count of COARSE voxels and group 2 | 4");
+  return fine_sample_img_impl(img_nhwc, ncam, Ci, Hf, Wf, params, fine_xyz, nfine_cap, n_dev, feat, out_stride, group, stream);
+}
+static int fine_sample_img_impl(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf, const float* params, const int64_t* fine_xyz,
+                                int64_t nfine, const int32_t* n_dev, float* feat, int out_stride, int group, void* stream) {
   COOCC_CHECK_ARG(img_nhwc && params && fine_xyz && feat && ncam > 0 && Ci > 0 && Ci % 2 == 0 && Ci <= 512,
                   "fine_sample_img: bad args (Ci even, <= 512)");
   if (nfine == 0) return COOCC_OK;
@@ -520,15 +551,15 @@ extern "C" int coocc_fine_sample_img(const float* img_nhwc, int ncam, int Ci, in
     const int n = (int)(nfine / r3);
     if (R == 2)
       hipLaunchKernelGGL(k_fine_sample_img_grp<2>, dim3(cdiv((long long)n * 64, 256)), dim3(256), 0, as_stream(stream), img_nhwc,
-                         ncam, Ci, Hf, Wf, params, fine_xyz, n, feat, out_stride);
+                         ncam, Ci, Hf, Wf, params, fine_xyz, n, feat, out_stride, n_dev);
     else
       hipLaunchKernelGGL(k_fine_sample_img_grp<4>, dim3(cdiv((long long)n * 64, 256)), dim3(256), 0, as_stream(stream), img_nhwc,
-                         ncam, Ci, Hf, Wf, params, fine_xyz, n, feat, out_stride);
+                         ncam, Ci, Hf, Wf, params, fine_xyz, n, feat, out_stride, n_dev);
     COOCC_LAUNCH_CHECK("k_fine_sample_img_grp");
     return COOCC_OK;
   }
   hipLaunchKernelGGL(k_fine_sample_img, dim3(cdiv(nfine * 64, 256)), dim3(256), 0, as_stream(stream), img_nhwc, ncam, Ci,
-                     Hf, Wf, params, fine_xyz, (long long)nfine, feat, out_stride);
+                     Hf, Wf, params, fine_xyz, (long long)nfine, feat, out_stride, n_dev, r3 ? r3 : 1);
   COOCC_LAUNCH_CHECK("k_fine_sample_img");
   return COOCC_OK;
 }
@@ -620,7 +651,9 @@ __global__ __launch_bounds__(256) void k_fill(float* __restrict__ p, size_t n, f
 // lane per (point, class) scattering a wave's stores over 17 planes.
 __global__ __launch_bounds__(256) void k_scatter_fine(const float* __restrict__ logits, long long nf, int ncls, int stride,
                                                        const int64_t* __restrict__ fine_xyz, float* __restrict__ grid,
-                                                       int Xf, int Yf, int Zf) {
+                                                       int Xf, int Yf, int Zf, const int32_t* __restrict__ n_dev, int n_mul) {
+  if (n_dev) nf = min(nf, (long long)*n_dev * n_mul);
+  if ((long long)blockIdx.x * 256 >= nf) return;
   extern __shared__ float s_log[];   // [256][ncls | 1]: odd row pitch -> conflict-free column reads
   const int pitch = ncls | 1;
   const long long f0 = (long long)blockIdx.x * 256;
@@ -639,8 +672,19 @@ __global__ __launch_bounds__(256) void k_scatter_fine(const float* __restrict__ 
   for (int c = 0; c < ncls; ++c) g[c * plane] = s_log[threadIdx.x * pitch + c];
 }
 
+static int scatter_fine_impl(const float* fine_logits, int64_t nfine, const int32_t* n_dev, int n_mul, int ncls, int stride,
+                             const int64_t* fine_xyz, float* grid, int Xf, int Yf, int Zf, float empty_val, void* stream);
 extern "C" int coocc_scatter_fine(const float* fine_logits, int64_t nfine, int ncls, int stride, const int64_t* fine_xyz,
                                   float* grid, int Xf, int Yf, int Zf, float empty_val, void* stream) {
+  return scatter_fine_impl(fine_logits, nfine, nullptr, 1, ncls, stride, fine_xyz, grid, Xf, Yf, Zf, empty_val, stream);
+}
+extern "C" int coocc_scatter_fine_dev(const float* fine_logits, int64_t nfine_cap, const int32_t* n_dev, int n_mul, int ncls, int stride,
+                                      const int64_t* fine_xyz, float* grid, int Xf, int Yf, int Zf, float empty_val, void* stream) {
+  COOCC_CHECK_ARG(n_dev && n_mul > 0, "scatter_fine_dev: null device count");
+  return scatter_fine_impl(fine_logits, nfine_cap, n_dev, n_mul, ncls, stride, fine_xyz, grid, Xf, Yf, Zf, empty_val, stream);
+}
+static int scatter_fine_impl(const float* fine_logits, int64_t nfine, const int32_t* n_dev, int n_mul, int ncls, int stride,
+                             const int64_t* fine_xyz, float* grid, int Xf, int Yf, int Zf, float empty_val, void* stream) {
   COOCC_CHECK_ARG(grid && ncls > 0 && Xf > 0 && Yf > 0 && Zf > 0, "scatter_fine: bad args");
   size_t total = (size_t)ncls * Xf * Yf * Zf;
   hipLaunchKernelGGL(k_fill, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), grid, total, empty_val);
@@ -648,7 +692,7 @@ extern "C" int coocc_scatter_fine(const float* fine_logits, int64_t nfine, int n
     COOCC_CHECK_ARG(fine_logits && fine_xyz && stride >= ncls, "scatter_fine: null pointer");
     COOCC_CHECK_ARG(ncls <= 128, "scatter_fine: at most 128 classes");
     hipLaunchKernelGGL(k_scatter_fine, dim3(cdiv(nfine, 256)), dim3(256), 256 * (ncls | 1) * sizeof(float), as_stream(stream), fine_logits,
-                       (long long)nfine, ncls, stride, fine_xyz, grid, Xf, Yf, Zf);
+                       (long long)nfine, ncls, stride, fine_xyz, grid, Xf, Yf, Zf, n_dev, n_mul);
   }
   COOCC_LAUNCH_CHECK("scatter_fine");
   return COOCC_OK;

@@ -25,6 +25,8 @@ struct FineMlp {
   const float* w_f0; const float* b_f0; const float* g_f0; const float* be_f0;
   const float* w_f3; const float* b_f3;
   long long nf;
+  const int32_t* n_dev;       // optional device-side count (coarse voxels); nf = min(nf, *n_dev * n_mul)
+  int n_mul;
   int samp_stride, vox_stride, ncls;
   float eps_img, eps_f0;
 };
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(256, 2) void k_fine_mlp(FineMlp p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int li = lane & 31, h = lane >> 5;
   const long long r0 = ((long long)blockIdx.x * 4 + wave) * 64;
+  if (p.n_dev) p.nf = min(p.nf, (long long)*p.n_dev * p.n_mul);
   if (r0 >= p.nf) return;
   const unsigned rows = (unsigned)(p.nf - r0 < 64 ? p.nf - r0 : 64);
   // the wave's 64 points: descriptors based at its first row, rows past the end read 0
@@ -239,16 +242,37 @@ extern "C" int coocc_fine_mlp(const float* samp, int samp_stride, const float* v
   p.w_f0 = w_f0; p.b_f0 = b_f0; p.g_f0 = gn_f0_w; p.be_f0 = gn_f0_b;
   p.w_f3 = w_f3; p.b_f3 = b_f3;
   p.nf = nfine; p.samp_stride = samp_stride; p.vox_stride = vox_stride; p.ncls = ncls;
+  p.n_dev = nullptr; p.n_mul = 1;
   p.eps_img = eps_img; p.eps_f0 = eps_f0;
   hipLaunchKernelGGL(k_fine_mlp<false>, dim3(cdiv(nfine, 256)), dim3(256), 0, as_stream(stream), p);
   COOCC_LAUNCH_CHECK("k_fine_mlp");
   return COOCC_OK;
 }
 
+static int fine_mlp_pre_impl(const float* samp64, int samp_stride, const float* vox64, int vox_stride, int64_t nfine,
+                             const int32_t* n_dev, int n_mul, const float* b_img, const float* gn_img_w, const float* gn_img_b,
+                             float eps_img, const float* w_f0, const float* b_f0, const float* gn_f0_w, const float* gn_f0_b,
+                             float eps_f0, const float* w_f3, const float* b_f3, int ncls, float* out, void* stream);
 extern "C" int coocc_fine_mlp_pre(const float* samp64, int samp_stride, const float* vox64, int vox_stride, int64_t nfine,
                                   const float* b_img, const float* gn_img_w, const float* gn_img_b, float eps_img,
                                   const float* w_f0, const float* b_f0, const float* gn_f0_w, const float* gn_f0_b,
                                   float eps_f0, const float* w_f3, const float* b_f3, int ncls, float* out, void* stream) {
+  return fine_mlp_pre_impl(samp64, samp_stride, vox64, vox_stride, nfine, nullptr, 1, b_img, gn_img_w, gn_img_b, eps_img, w_f0, b_f0,
+                           gn_f0_w, gn_f0_b, eps_f0, w_f3, b_f3, ncls, out, stream);
+}
+extern "C" int coocc_fine_mlp_pre_dev(const float* samp64, int samp_stride, const float* vox64, int vox_stride, int64_t nfine_cap,
+                                      const int32_t* n_dev, int n_mul, const float* b_img, const float* gn_img_w,
+                                      const float* gn_img_b, float eps_img, const float* w_f0, const float* b_f0,
+                                      const float* gn_f0_w, const float* gn_f0_b, float eps_f0, const float* w_f3, const float* b_f3,
+                                      int ncls, float* out, void* stream) {
+  COOCC_CHECK_ARG(n_dev && n_mul > 0, "fine_mlp_pre_dev: null device count");
+  return fine_mlp_pre_impl(samp64, samp_stride, vox64, vox_stride, nfine_cap, n_dev, n_mul, b_img, gn_img_w, gn_img_b, eps_img, w_f0,
+                           b_f0, gn_f0_w, gn_f0_b, eps_f0, w_f3, b_f3, ncls, out, stream);
+}
+static int fine_mlp_pre_impl(const float* samp64, int samp_stride, const float* vox64, int vox_stride, int64_t nfine,
+                             const int32_t* n_dev, int n_mul, const float* b_img, const float* gn_img_w, const float* gn_img_b,
+                             float eps_img, const float* w_f0, const float* b_f0, const float* gn_f0_w, const float* gn_f0_b,
+                             float eps_f0, const float* w_f3, const float* b_f3, int ncls, float* out, void* stream) {
   if (nfine == 0) return COOCC_OK;
   COOCC_CHECK_ARG(samp64 && vox64 && out && b_img && gn_img_w && gn_img_b && w_f0 && b_f0 && gn_f0_w && gn_f0_b && w_f3 && b_f3,
                   "fine_mlp_pre: null pointer");
@@ -264,6 +288,7 @@ extern "C" int coocc_fine_mlp_pre(const float* samp64, int samp_stride, const fl
   p.w_f0 = w_f0; p.b_f0 = b_f0; p.g_f0 = gn_f0_w; p.be_f0 = gn_f0_b;
   p.w_f3 = w_f3; p.b_f3 = b_f3;
   p.nf = nfine; p.samp_stride = samp_stride; p.vox_stride = vox_stride; p.ncls = ncls;
+  p.n_dev = n_dev; p.n_mul = n_mul;
   p.eps_img = eps_img; p.eps_f0 = eps_f0;
   hipLaunchKernelGGL(k_fine_mlp<true>, dim3(cdiv(nfine, 256)), dim3(256), 0, as_stream(stream), p);
   COOCC_LAUNCH_CHECK("k_fine_mlp<pre>");

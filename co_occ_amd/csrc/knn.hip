@@ -554,16 +554,27 @@ extern "C" int coocc_knn_topk(int nq, int nk, int K, const float* q, const float
 //     stops after the K-th occupied in-grid voxel, usually inside the first 64 offsets.
 // Both are bit-identical to the brute-force kernels (tests/test_gpu_knn.py); representatives whose K-th neighbour lies
 // beyond the table radius are finished by the brute-force kernel (k_knn_topk_unresolved).
-__global__ __launch_bounds__(256) void k_index_map_scatter(const int32_t* __restrict__ lin, int n, int32_t* __restrict__ map) {
+__global__ __launch_bounds__(256) void k_index_map_scatter(const int32_t* __restrict__ lin, int n, int32_t* __restrict__ map,
+                                                            const int32_t* __restrict__ n_dev) {
+  if (n_dev) n = min(n, *n_dev);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) map[lin[i]] = i;
+}
+
+// the list length read on the device (n_dev; at most n_cap entries): no host round trip, grid sized for n_cap
+extern "C" int coocc_voxel_index_map_dev(const int32_t* lin, int n_cap, const int32_t* n_dev, int nvox, int32_t* map, void* stream) {
+  COOCC_CHECK_ARG(map && nvox > 0 && n_cap > 0 && lin && n_dev, "voxel_index_map_dev: bad args");
+  COOCC_HIP(hipMemsetAsync(map, 0xFF, (size_t)nvox * 4, as_stream(stream)));
+  hipLaunchKernelGGL(k_index_map_scatter, dim3(cdiv(n_cap, 256)), dim3(256), 0, as_stream(stream), lin, n_cap, map, n_dev);
+  COOCC_LAUNCH_CHECK("k_index_map_scatter");
+  return COOCC_OK;
 }
 
 extern "C" int coocc_voxel_index_map(const int32_t* lin, int n, int nvox, int32_t* map, void* stream) {
   COOCC_CHECK_ARG(map && nvox > 0 && n >= 0 && (lin || n == 0), "voxel_index_map: bad args");
   COOCC_HIP(hipMemsetAsync(map, 0xFF, (size_t)nvox * 4, as_stream(stream)));      // -1 everywhere
   if (n) {
-    hipLaunchKernelGGL(k_index_map_scatter, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), lin, n, map);
+    hipLaunchKernelGGL(k_index_map_scatter, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), lin, n, map, (const int32_t*)nullptr);
     COOCC_LAUNCH_CHECK("k_index_map_scatter");
   }
   return COOCC_OK;

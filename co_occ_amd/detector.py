@@ -177,14 +177,16 @@ class COOCC_Ray(nn.Module):
         return self.decode(voxel_feats, gemo, img_feats, transform, render, dense_fine)
 
     def decode(self, voxel_feats, gemo=None, img_feats=None, transform=None, render=None, dense_fine=True,
-               depth_only=False, fine_size=None, after_encoder=None):
+               depth_only=False, fine_size=None, after_encoder=None, static=False):
         """Everything after ``extract_feat`` and before the metrics (coocc_ray.py:525-627).  ``after_encoder``: callback run
-        once the encoder's launches are enqueued (a serving loop with two samples in flight staggers them there)."""
+        once the encoder's launches are enqueued (a serving loop with two samples in flight staggers them there).
+        ``static``: no host read anywhere (the fine branch keeps its count on the device and returns capacity-sized
+        tensors + ``fine_count``): the form ``co_occ_amd.graph`` captures into a hipGraph."""
         mid = self.semantic_encoder.forward_rows(voxel_feats)
         if after_encoder is not None:
             after_encoder()
         sem = self.semantic_neck.forward_rows(mid)
-        output = self.pts_bbox_head(voxel_feats=sem, img_feats=img_feats, transform=transform)
+        output = self.pts_bbox_head(voxel_feats=sem, img_feats=img_feats, transform=transform, static=static)
         res = dict(voxel_feats=voxel_feats, pred_c=output['output_voxels'][0], pred_f=None,
                    output_voxels_fine=output['output_voxels_fine'], output_coords_fine=output['output_coords_fine'])
         if output['output_voxels_fine'] is not None and dense_fine:
@@ -192,7 +194,9 @@ class COOCC_Ray(nn.Module):
             pc = res['pred_c']
             size = fine_size or [pc.shape[2] * cf, pc.shape[3] * cf, pc.shape[4] * cf]     # == gt_occ size (coocc_ray.py:549)
             res['pred_f'] = self.pts_bbox_head.scatter_fine(output['output_voxels_fine'][0],
-                                                            output['output_coords_fine'][0], list(size))
+                                                            output['output_coords_fine'][0], list(size),
+                                                            count_dev=output.get('fine_count'))
+            res['fine_count'] = output.get('fine_count')
         do_render = (self.use_rendering and self.test_rendering) if render is None else render
         if do_render:
             rgbs, depths, maps = render_block(self.sigma_head, getattr(self, "rgb_head", None), to_rows(voxel_feats), gemo, 16,

@@ -166,6 +166,27 @@ def _as_rows_view(x):
     return Rows(base, B, X, Y, Z, C, coff)
 
 
+class SearchSlot:
+    """Static buffers of one sample in flight (serving loop over captured hipGraphs, ``co_occ_amd.graph``): everything the
+    dense stage reads from the search stage lives at fixed addresses with capacity-sized shapes -- the concat rows
+    [V,4C] (slot 0 = the pooled camera volume, written by ``lift_splat(out=slot.img_rows())``), the non-empty voxel lists
+    [2,V], their lengths [2] ON THE DEVICE, and the two neighbour row tables [K,V]."""
+
+    def __init__(self, C, knum, grid, device):
+        X, Y, Z = grid
+        V = X * Y * Z
+        self.grid, self.C, self.V = (X, Y, Z), C, V
+        self.cat4 = torch.empty(V, 4 * C, device=device, dtype=_F32)
+        self.lin = torch.zeros(2, V, device=device, dtype=_I32)
+        self.counts = torch.zeros(2, device=device, dtype=_I32)
+        self.rows = torch.zeros(knum, V, device=device, dtype=_I32)
+        self.rows_p = torch.zeros(knum, V, device=device, dtype=_I32)
+
+    def img_rows(self):
+        X, Y, Z = self.grid
+        return Rows(self.cat4, 1, X, Y, Z, self.C, 0)
+
+
 class SearchResult:
     """Output of ``BiFuser_N.search``: the concat rows (img | pts halves written), the non-empty voxel lists and
     the neighbour row tables of both directions, with the events that mark them ready."""
@@ -175,6 +196,8 @@ class SearchResult:
         self.rows = self.rows_p = self.near_img = self.near_pts = None
         self.done_main = self.done_side = None
         self.keep = ()
+        self.slot = None          # SearchSlot: the dense stage reads capacity-sized buffers + device-side counts
+        self.counts = (lin_img.numel(), lin_pts.numel())
 
     def tensors(self):
         out = [self.cat4.t, self.lin_img, self.lin_pts]
@@ -248,7 +271,7 @@ class BiFuser_N(nn.Module):
         return Rows(cat4, B, X, Y, Z, C, 0)
 
     # ---------------------------------------------------------------- forward
-    def search(self, img_voxel_feats, pts_voxel_feats):
+    def search(self, img_voxel_feats, pts_voxel_feats, slot=None):
         """K1..K5 on the current stream: concat rows with the img | pts halves in place, non-empty voxel lists,
         both index searches (the second on a side stream).  Returns a ``SearchResult``; nothing downstream of
         the indices has been launched, so a caller may run this for sample i+1 on its own stream (and host
@@ -275,13 +298,17 @@ class BiFuser_N(nn.Module):
             # a producer handed over channels-last rows (fused lift-splat, sparse LiDAR encoder): no NCDHW round trip; rows
             # that already sit in slot 0 of a [V,4C] concat buffer (lift_splat(out=BiFuser_N.concat_buffer(...))) stay there
             in_place = img_r is not None and img_r.t.shape[1] == 4 * C and img_r.coff == 0 and img_r.t.is_contiguous()
+            if slot is not None:
+                assert in_place and img_r.t.data_ptr() == slot.cat4.data_ptr() and B == 1, \
+                    "search(slot=...): the camera rows must already sit in slot 0 of the slot's concat buffer"
             cat4 = img_r.t if in_place else torch.empty(B * V, 4 * C, device=dev, dtype=_F32)
             img = img_r if img_r is not None else img_voxel_feats.float().contiguous()
             pts = pts_r if pts_r is not None else pts_voxel_feats.float().contiguous()
             src = lambda r: (r.data(), 1, r.stride) if isinstance(r, Rows) else (ptr(r), 0, 0)
             call("coocc_fuser_prepare_rows", *src(img), *src(pts), ptr(cat4), ptr(flags[0]), ptr(flags[1]), B, C, V)
-        lin = torch.empty(2, B * V, device=dev, dtype=_I32)
-        counts = torch.empty(2, device=dev, dtype=_I32)
+        assert slot is None or (img_r is not None or pts_r is not None), "search(slot=...) takes channels-last producers"
+        lin = slot.lin if slot is not None else torch.empty(2, B * V, device=dev, dtype=_I32)
+        counts = slot.counts if slot is not None else torch.empty(2, device=dev, dtype=_I32)
         ws = torch.empty(2, B * V // 1024 + 2, device=dev, dtype=_I32)
         for i in range(2):
             call("coocc_compact_flags", ptr(flags[i]), B * V, ptr(lin[i]), ptr(counts[i:i + 1]), ptr(ws[i]),
@@ -298,6 +325,7 @@ class BiFuser_N(nn.Module):
         K = self.knum
         kw = dict(fps_num=2048, radius=6, max_cluster_samples=200, dist_thresh=13.3, num=K)
         sr = SearchResult(Rows(cat4, B, X, Y, Z, 4 * C), lin_img, lin_pts)
+        sr.slot = slot
         cur = torch.cuda.current_stream(dev)
         if Np and Ni:
             vox = (X, Y, Z) if B == 1 else None
@@ -310,7 +338,7 @@ class BiFuser_N(nn.Module):
                 # inds_img with the pts ordinals (:158) -- kept
                 sr.near_pts = _fps_nn_xyz(xyz_img, xyz_pts, q_lin=lin_img if vox else None, k_lin=lin_pts if vox else None, grid=vox,
                                           which=1, home=cur, **kw)
-                sr.rows_p = torch.empty(K, Ni, device=dev, dtype=_I32)
+                sr.rows_p = slot.rows_p[:, :Ni] if slot is not None else torch.empty(K, Ni, device=dev, dtype=_I32)
                 base, nbase = (lin_pts, Np) if K == 1 else (lin_img, Ni)
                 for k in range(K):
                     call("coocc_index_rows_i32", ptr(base), nbase, ptr(sr.near_pts[k]), Ni, ptr(sr.rows_p[k]))
@@ -319,7 +347,7 @@ class BiFuser_N(nn.Module):
             # pts queries <- nearest img keys (bifuser_n.py:137-148)
             sr.near_img = _fps_nn_xyz(xyz_pts, xyz_img, q_lin=lin_pts if vox else None, k_lin=lin_img if vox else None, grid=vox,
                                       which=0, home=cur, **kw)
-            sr.rows = torch.empty(K, Np, device=dev, dtype=_I32)
+            sr.rows = slot.rows[:, :Np] if slot is not None else torch.empty(K, Np, device=dev, dtype=_I32)
             for k in range(K):
                 call("coocc_index_rows_i32", ptr(lin_img), Ni, ptr(sr.near_img[k]), Np, ptr(sr.rows[k]))
             sr.keep = (xyz, lin, img, pts)       # referenced by kernels still in flight on the side stream
@@ -346,6 +374,25 @@ class BiFuser_N(nn.Module):
             gather_conv_rows(cat4, C, packs["knn"], sr.rows_p, sr.lin_img, cat4, 3 * C, 0, C)
             self.last_near = (sr.near_img, sr.near_pts)
         return sr.cat4, (sr.lin_img, sr.lin_pts)
+
+    def finish_static(self, slot):
+        """``finish`` over a ``SearchSlot``: the same two gather GEMMs with the row counts read on the device and
+        capacity-sized tables -- no argument depends on the sample, so the launches can be captured once (hipGraph) and
+        replayed after every search that filled the slot.  The caller orders the streams (events of the SearchResult)."""
+        C = self.in_channels
+        packs = self._packed()
+        cat4 = slot.cat4
+        gather_conv_rows(cat4, 0, packs["knn"], slot.rows, slot.lin[1], cat4, 2 * C, C, C, count_dev=slot.counts[1:2])
+        gather_conv_rows(cat4, C, packs["knn"], slot.rows_p, slot.lin[0], cat4, 3 * C, 0, C, count_dev=slot.counts[0:1])
+        X, Y, Z = slot.grid
+        return Rows(cat4, 1, X, Y, Z, 4 * C)
+
+    def forward_static(self, slot):
+        """G1 + con_enc over a ``SearchSlot`` (see ``finish_static``): [V, out] rows."""
+        packs = self._packed()
+        cat4 = self.finish_static(slot)
+        x = self.con_enc0(cat4, slot.lin[1], packs, count_dev=slot.counts[1:2])
+        return conv_rows(x, packs["c3"], relu=True)
 
     def finish_bookkeeping(self, sr):
         """Make a SearchResult issued on another stream safe to consume on the current one (training path)."""
@@ -382,7 +429,12 @@ class BiFuser_N(nn.Module):
         x = conv_rows(x, packs["c3"], relu=True)
         return x.as_ncdhw()
 
-    def con_enc0(self, cat4, lin_pts, packs):
+    @staticmethod
+    def c0_capacity(V):
+        """Rows the scatter-form half of con_enc.0 is sized for in the static (hipGraph) form."""
+        return int(SPLIT_C0_MAX_DENSITY * V)
+
+    def con_enc0(self, cat4, lin_pts, packs, count_dev=None):
         """con_enc[0:3] (Conv3d 4C -> 2C + BN + ReLU) on the concat rows.  When the LiDAR voxels are a small share of the grid
         the layer is split by input-channel support: img | fused_pts through the Winograd GEMM (half the K), pts | fused_img
         (non-zero on ``lin_pts`` only) in scatter form -- one row-table GEMM over the occupied rows into per-tap
@@ -392,7 +444,13 @@ class BiFuser_N(nn.Module):
         Np = int(lin_pts.numel())
         pd = packs["c0_dense"]
         plan = core.wino_plan(cat4, pd, V, 1) if (SPLIT_C0 and core.CONV_DTYPE == "f32") else None
-        if plan is None or Np == 0 or Np > SPLIT_C0_MAX_DENSITY * V or cat4.B != 1:
+        if count_dev is not None:
+            # static form (hipGraph replay): lin_pts is the capacity-sized list, its length sits on the device; the
+            # scatter-form GEMM is sized for the densest sweep the split is used for (the caller checks the host-side count
+            # of the sample against ``c0_capacity`` before replaying)
+            assert plan is not None and cat4.B == 1, "static con_enc0 needs the channel-support split"
+            Np = self.c0_capacity(V)
+        elif plan is None or Np == 0 or Np > SPLIT_C0_MAX_DENSITY * V or cat4.B != 1:
             return conv_rows(cat4, packs["c0"], relu=True)
         ps = packs["c0_sparse"]
         Co = pd.Cout
@@ -412,10 +470,15 @@ class BiFuser_N(nn.Module):
         d.Xi = V                      # number of input rows (lets coocc_conv_fwd pick the pipelined row-table kernel)
         d.ksize, d.stride, d.pad = 1, 1, 0
         d.relu, d.res_mode, d.splitk, d.tile_hint = 0, 0, 1, core.TILE_HINT
+        if count_dev is not None:
+            d.M_dev, d.gather_stride = ptr(count_dev, _I32), lin_pts.numel()
         with core.TIMER.region(core.conv_kernel_name(Np, 27 * Co, True) + " c0-sparse", 2.0 * Np * 2 * C * 27 * Co):
             _lib.conv_fwd(d, dev)
         vmap = torch.empty(V, device=dev, dtype=_I32)
-        call("coocc_voxel_index_map", ptr(lin_pts), Np, V, ptr(vmap))
+        if count_dev is not None:
+            call("coocc_voxel_index_map_dev", ptr(lin_pts), int(lin_pts.numel()), ptr(count_dev, _I32), V, ptr(vmap))
+        else:
+            call("coocc_voxel_index_map", ptr(lin_pts), Np, V, ptr(vmap))
         S = core.Rows(torch.empty(V, Co, device=dev, dtype=_F32), cat4.B, cat4.X, cat4.Y, cat4.Z, Co)
         call("coocc_sparse_tap_sum", ptr(P), ptr(vmap), cat4.B, cat4.X, cat4.Y, cat4.Z, Co, ptr(pd.scale), ptr(S.t), Co)
         out = core.Rows(torch.empty(V, Co, device=dev, dtype=_F32), cat4.B, cat4.X, cat4.Y, cat4.Z, Co)

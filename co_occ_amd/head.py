@@ -131,8 +131,11 @@ class OccHead(nn.Module):
         return {'out_voxel_feats': [out.as_ncdhw()], 'occ': [occ.as_ncdhw()]}
 
     # ---------------------------------------------------------------- C4
-    def _fine(self, ovf, occ, img_feats, transform):
-        """occ_head.py:180-237, eval branch, B == 1."""
+    def _fine(self, ovf, occ, img_feats, transform, static=False):
+        """occ_head.py:180-237, eval branch, B == 1.  ``static``: nothing is read back -- the foreground count stays on
+        the device (third return value), every buffer has its worst-case size (all V coarse voxels foreground) and the
+        launches take the count from the device (``*_dev`` entry points), so the branch can be captured into a hipGraph;
+        rows past count * ratio^3 of the returned logits / coordinates are undefined."""
         p = self._packed()
         dev = ovf.t.device
         V, r = ovf.V, self.cascade_ratio
@@ -157,6 +160,8 @@ class OccHead(nn.Module):
             call("coocc_groupnorm_nhwc", ptr(g), N_i, Hf * Wf, g.shape[1], gn.num_groups, ptr(gn.weight.detach()),
                  ptr(gn.bias.detach()), float(gn.eps), 1)
             params = self._projection_params(transform, ovf, dev)
+        if static:
+            return self._fine_static(p, ovf, lin, cnt, g if use_img else None, params if use_img else None, (N_i, Hf, Wf) if use_img else None)
         n = int(_lib.host_read(cnt)[0])
         assert n > 0, 'no foreground in coarse voxel'
         nf = n * r ** 3
@@ -214,6 +219,34 @@ class OccHead(nn.Module):
              ptr(gn.bias.detach()), float(gn.eps), 1)
         return linear_rows(h, p["fine3"]), fine_xyz
 
+    def _fine_static(self, p, ovf, lin, cnt, g, params, img_dims):
+        """The fused (Linear-first) fine branch with the foreground count on the device; see ``_fine(static=True)``."""
+        dev = ovf.t.device
+        V, r = ovf.V, self.cascade_ratio
+        ok = (FUSED_FINE_MLP and FINE_LINEAR_FIRST and g is not None and self.sample_from_voxel and ovf.C == 128 and g.shape[1] == 128
+              and self.out_channel <= 32 and self.img_mlp[1].num_groups == 16 and self.fine_mlp[1].num_groups == 16
+              and p.get("mlp_aligned", False) and "img_nb" in p and r in (2, 4))
+        if not ok:
+            raise _lib.CooccError("OccHead static fine branch: only the fused Linear-first configuration (cascade 2 / 4, image + "
+                                  "voxel samples, 128-channel features) has device-count kernels")
+        N_i, Hf, Wf = img_dims
+        nf = V * r ** 3
+        fine_xyz = torch.empty(3 * nf, device=dev, dtype=_I64)
+        P = linear_rows(g, p["img_nb"])
+        Q = linear_rows(ovf.t, p["f0_vox_nb"], in_coff=ovf.coff, in_C=128)
+        vq = torch.empty(nf, 64, device=dev, dtype=_F32)
+        call("coocc_fine_sample_voxel_dev", ptr(Q), 64, ovf.X, ovf.Y, ovf.Z, ptr(lin), V, ptr(cnt), r,
+             host_i32(self.final_occ_size), ptr(fine_xyz), ptr(vq), 64)
+        samp = torch.empty(nf, 64, device=dev, dtype=_F32)
+        call("coocc_fine_sample_img_dev", ptr(P), N_i, 64, Hf, Wf, ptr(params), ptr(fine_xyz), nf, ptr(cnt), ptr(samp), 64, r)
+        li, gi, l0, g0, l3 = self.img_mlp[0], self.img_mlp[1], self.fine_mlp[0], self.fine_mlp[1], self.fine_mlp[3]
+        logits = torch.empty(nf, self.out_channel, device=dev, dtype=_F32)
+        d = lambda t: ptr(t.detach())
+        call("coocc_fine_mlp_pre_dev", ptr(samp), 64, ptr(vq), 64, nf, ptr(cnt), r ** 3, d(li.bias), d(gi.weight), d(gi.bias),
+             float(gi.eps), d(l0.weight), d(l0.bias), d(g0.weight), d(g0.bias), float(g0.eps), d(l3.weight), d(l3.bias),
+             self.out_channel, ptr(logits))
+        return logits, fine_xyz, cnt
+
     def _projection_params(self, transform, ovf, dev):
         """Per-sample matrices of project_points_on_img (coordinate_transform.py:25-65), b = 0, packed by one
         device kernel (no torch.inverse: it synchronises with the host)."""
@@ -270,15 +303,25 @@ class OccHead(nn.Module):
         res = {'output_voxels': [occ.as_ncdhw()], 'output_voxels_fine': None, 'output_coords_fine': None,
                'output_points': None}
         if self.cascade_ratio != 1 and (self.sample_from_img or self.sample_from_voxel):
-            fine, xyz = self._fine(ovf, occ, img_feats, transform)
+            if kwargs.get("static"):
+                # capacity-sized outputs + the number of foreground coarse voxels on the device (hipGraph capture)
+                fine, xyz, cnt = self._fine(ovf, occ, img_feats, transform, static=True)
+                res['fine_count'] = cnt
+            else:
+                fine, xyz = self._fine(ovf, occ, img_feats, transform)
             res['output_voxels_fine'], res['output_coords_fine'] = [fine], [xyz]
         self.last_out_voxel_feats = ovf
         return res
 
-    def scatter_fine(self, fine_pred, fine_coord, out_size):
-        """``pred_f`` of simple_test (coocc_ray.py:546-550): [1,ncls,Xf,Yf,Zf]."""
+    def scatter_fine(self, fine_pred, fine_coord, out_size, count_dev=None):
+        """``pred_f`` of simple_test (coocc_ray.py:546-550): [1,ncls,Xf,Yf,Zf].  ``count_dev``: the capacity-sized outputs of
+        the static fine branch + the device-side count of foreground coarse voxels."""
         ncls = fine_pred.shape[1]
         grid = torch.empty(1, ncls, *out_size, device=fine_pred.device, dtype=_F32)
+        if count_dev is not None:
+            call("coocc_scatter_fine_dev", ptr(fine_pred), fine_pred.shape[0], ptr(count_dev), self.cascade_ratio ** 3, ncls,
+                 fine_pred.shape[1], ptr(fine_coord), ptr(grid), out_size[0], out_size[1], out_size[2], float(self.empty_idx))
+            return grid
         call("coocc_scatter_fine", ptr(fine_pred), fine_pred.shape[0], ncls, fine_pred.shape[1], ptr(fine_coord), ptr(grid),
              out_size[0], out_size[1], out_size[2], float(self.empty_idx))
         return grid

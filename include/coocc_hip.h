@@ -102,6 +102,10 @@ int coocc_ball_query(int b, int n, int m, float min_radius, float max_radius, in
  * coocc_ball_query / coocc_knn_topk on the same points, 20-100x less work (no 2048 x N distance sweep). */
 /* map[v] = ordinal of voxel v in lin[0..n) or -1.  map:[nvox] i32. */
 int coocc_voxel_index_map(const int32_t* lin, int n, int nvox, int32_t* map, void* stream);
+/* Device-side counts (no host round trip; grids sized for the capacity, surplus workgroups leave at once): the *_dev forms of
+ * the entry points whose work list is a data-dependent voxel / point list -- what lets the whole dense stage replay as one
+ * captured hipGraph (co_occ_amd/graph.py).  n_dev: int32 on the device, the list length (clamped to the capacity). */
+int coocc_voxel_index_map_dev(const int32_t* lin, int n_cap, const int32_t* n_dev, int nvox, int32_t* map, void* stream);
 /* ball_query (bifuser_n.py:109) for m centres given as ordinals into the query list lin_q; map_q = its index map.
  * idx:[m,nsample] query ordinals, first-hit padded, zeros when a centre has no hit (ball_query_cuda.cu:11-54). */
 int coocc_ball_query_voxels(int m, float min_radius, float max_radius, int nsample, int X, int Y, int Z,
@@ -178,6 +182,10 @@ typedef struct coocc_conv_desc {
                                 [2 k16 steps][hi | lo][64 lanes][8 f16]; Cin % 32 == 0; stride-1 "same" geometry, kz <= 3, geometric
                                 taps only; wgroup_rows a multiple of 128 */
   float alpha;            /* mfma_dtype 3: the accumulators are multiplied by alpha (1 / operand scale) before the epilogue; 0 = 1 */
+  const int32_t* M_dev;   /* row-table launches (gather != NULL, splitk = 1): the number of rows read on the DEVICE (<= M; the grid
+                             is sized for M = capacity and tiles past *M_dev leave at once) -- lets a captured hipGraph run over
+                             voxel lists whose length is only known on the device; NULL: M rows */
+  int gather_stride;      /* entries per tap of `gather` (0 = M) */
 } coocc_conv_desc;
 
 /* nn.Conv3d(k=3|1)+BN(eval)+ReLU(+residual) (bifuser_n.py:23-30, resnet3d.py:34-64,
@@ -397,6 +405,23 @@ int coocc_fine_mlp_pre(const float* samp64, int samp_stride, const float* vox64,
                        const float* b_img, const float* gn_img_w, const float* gn_img_b, float eps_img,
                        const float* w_f0, const float* b_f0, const float* gn_f0_w, const float* gn_f0_b,
                        float eps_f0, const float* w_f3, const float* b_f3, int ncls, float* out, void* stream);
+/* Device-count forms of the fine-branch entry points (see coocc_voxel_index_map_dev): n_dev = number of foreground COARSE
+ * voxels (the count coocc_compact_flags leaves on the device), capacities sized for the worst case (every voxel foreground).
+ * The packed layouts (fine point f = o*n + i, fine_xyz planes of n*r^3 entries) follow the ACTUAL count, exactly as the
+ * host-count forms; n_mul = r^3 converts the coarse count to fine points. */
+int coocc_fine_sample_voxel_dev(const float* vol, int C, int X, int Y, int Z, const int32_t* coarse_lin, int n_cap,
+                                const int32_t* n_dev, int ratio, const int* final_size_host, int64_t* fine_xyz,
+                                float* feat, int out_stride, void* stream);
+int coocc_fine_sample_img_dev(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf, const float* params,
+                              const int64_t* fine_xyz, int64_t nfine_cap, const int32_t* n_dev, float* feat,
+                              int out_stride, int group, void* stream);
+int coocc_fine_mlp_pre_dev(const float* samp64, int samp_stride, const float* vox64, int vox_stride, int64_t nfine_cap,
+                           const int32_t* n_dev, int n_mul, const float* b_img, const float* gn_img_w,
+                           const float* gn_img_b, float eps_img, const float* w_f0, const float* b_f0,
+                           const float* gn_f0_w, const float* gn_f0_b, float eps_f0, const float* w_f3, const float* b_f3,
+                           int ncls, float* out, void* stream);
+int coocc_scatter_fine_dev(const float* fine_logits, int64_t nfine_cap, const int32_t* n_dev, int n_mul, int ncls, int stride,
+                           const int64_t* fine_xyz, float* grid, int Xf, int Yf, int Zf, float empty_val, void* stream);
 /* nn.GroupNorm on 2-D rows [n,C] (+ReLU), in place (occ_head.py:70-83) */
 int coocc_groupnorm_rows(float* x, int64_t n, int C, int stride, int groups, const float* gamma,
                          const float* beta, float eps, int relu, void* stream);

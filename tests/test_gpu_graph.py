@@ -1,0 +1,63 @@
+"""The captured dense stage (co_occ_amd.graph.DenseGraph: one hipGraphLaunch per sample, every data-dependent count read on
+the device) against the eager path on the same samples, bit for bit."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _eager(model, s, dev):
+    import bench
+    with torch.no_grad():
+        img = bench.pool(model, s)
+        sr = model.search(img, s["pts"])
+        out = model.forward_hot_path(img, s["pts"], s["gemo"], s["img_feats"], s["transform"], render=True, search=sr)
+    torch.cuda.synchronize()
+    return {k: out[k].clone() for k in ("pred_c", "pred_f", "rgbs", "depths")}, sr.counts
+
+
+def test_dense_graph_replay_equals_eager(dev):
+    import bench
+    from co_occ_amd import graph as cg
+    bench.CFGNAME[0] = "r50"
+    model, _ = bench.build_model("r50", dev)
+    a = bench.make_inputs("r50", 1234, dev, model)
+    b = bench.make_inputs("r50", 99, dev, model)
+    # the graph binds the per-sample tensors it reads besides the slot: give sample b the rig of sample a
+    for k in ("gemo", "img_feats", "transform", "cams"):
+        b[k] = a[k]
+    want_a, counts_a = _eager(model, a, dev)
+    want_b, counts_b = _eager(model, b, dev)
+    assert counts_a != counts_b
+    X, Y, Z = a["pts"].shape[2:]
+    slot = cg.make_slot(model, (X, Y, Z), dev)
+    stream = torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream(dev)
+
+    def search(s):
+        with torch.no_grad():
+            sr = cg.search_into_slot(model, slot, s["depth"], s["ctx"], s["cams"], s["pts"])
+        stream.wait_event(sr.done_main)
+        stream.wait_event(sr.done_side)
+        return sr
+
+    sr = search(a)
+    g = cg.DenseGraph(model, slot, a, stream).capture()
+    assert g.fits(sr.counts)
+    for s, want, counts in ((a, want_a, counts_a), (b, want_b, counts_b), (a, want_a, counts_a)):
+        cur.wait_stream(stream)          # the slot is rewritten only after the previous replay has finished with it
+        sr = search(s)
+        assert sr.counts == counts and g.fits(sr.counts)
+        with torch.cuda.stream(stream):
+            out = g.replay()
+        stream.synchronize()
+        n = int(out["fine_count"].item())
+        assert n > 0
+        for k in ("pred_c", "pred_f", "rgbs", "depths"):
+            assert torch.equal(out[k], want[k]), "%s differs between the graph replay and the eager path" % k
