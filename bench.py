@@ -27,6 +27,11 @@ import os
 import sys
 import time
 
+# The serving loop keeps 2 dense + up to 4 search streams (+ their side streams) busy; with ROCm's default of 4 hardware queues
+# per process several of them share one in-order queue and a search stage waits behind whole dense graphs (search latency
+# 10.5 -> 7 ms, 143 -> 158 samples/s measured with 16).  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -492,6 +497,107 @@ class Pipeline:
             st.synchronize()
 
 
+class GraphPipeline:
+    """The default serving loop: the dense stage of every sample is ONE hipGraphLaunch (co_occ_amd.graph.DenseGraph, captured
+    once per slot before the timed region), issued by the calling thread on one dense stream; pooling + index search of the
+    next ``nslots - 1`` samples run eagerly on high-priority prefetch streams (helper threads: the search has one
+    device->host read of the two voxel counts).  Sample i lives in slot i mod nslots (its own synthetic inputs, resident in
+    HBM); a slot is rewritten only after the replay that read it has finished (event)."""
+
+    def __init__(self, model, samples, dev, world=1, ndense=1):
+        from concurrent.futures import ThreadPoolExecutor
+        from co_occ_amd import graph as cg
+        self.model, self.samples, self.dev, self.world = model, samples, dev, world
+        self.n = len(samples)
+        self.ndense = max(1, min(ndense, self.n - 1))
+        X, Y, Z = samples[0]["pts"].shape[2:]
+        self.render = X >= 100 and Y >= 100 and Z >= 8
+        # slot k replays on dense stream k mod ndense (graphs own the per-stream scratch of the stream they were captured on)
+        self.dense_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ndense)]
+        prio = int(os.environ.get("COOCC_SEARCH_PRIO", "0"))    # high-priority search streams slow the dense graphs by 40 % (measured)
+        self.search_streams = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(self.n)]
+        self.slots = [cg.make_slot(model, (X, Y, Z), dev) for _ in range(self.n)]
+        self.done = [None] * self.n
+        self.tpool = ThreadPoolExecutor(max(1, self.n - self.ndense))
+        self.cg = cg
+        self.graphs = []
+        self.dense_ev = []
+        self.fallbacks = 0
+        # capture: every slot once, after an eager search filled it
+        for k in range(self.n):
+            sr = self.do_search(k)
+            ds = self.dense_streams[k % self.ndense]
+            ds.wait_event(sr.done_main)
+            if sr.done_side is not None:
+                ds.wait_event(sr.done_side)
+            self.graphs.append(cg.DenseGraph(model, self.slots[k], samples[k], ds, render=self.render).capture())
+        torch.cuda.synchronize()
+
+    def do_search(self, i):
+        k = i % self.n
+        s = self.samples[k]
+        torch.cuda.set_device(self.dev)
+        st = self.search_streams[k]
+        t0 = time.perf_counter()
+        with torch.cuda.stream(st), torch.no_grad():
+            if self.done[k] is not None:
+                st.wait_event(self.done[k])             # the replay that read this slot last
+            if TRACE[0] is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            sr = self.cg.search_into_slot(self.model, self.slots[k], s["depth"], s["ctx"], s["cams"], s["pts"])
+            if TRACE[0] is not None:
+                st.wait_event(sr.done_side)
+                e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                TRACE[0].append(("search", i, e0, e1, time.perf_counter() - t0))
+            return sr
+
+    def run(self, nsteps, collect=None, time_dense=False):
+        futs = {}
+        ahead = self.n - self.ndense
+
+        def submit(i):
+            if i < nsteps:
+                futs[i] = self.tpool.submit(self.do_search, i)
+        for i in range(min(ahead, nsteps)):
+            submit(i)
+        with torch.no_grad():
+            for i in range(nsteps):
+                k = i % self.n
+                tw = time.perf_counter()
+                sr = futs.pop(i).result()
+                if TRACE[0] is not None:
+                    TRACE[0].append(("wait", i, time.perf_counter() - tw))
+                ds = self.dense_streams[k % self.ndense]
+                ds.wait_event(sr.done_main)
+                if sr.done_side is not None:
+                    ds.wait_event(sr.done_side)
+                with torch.cuda.stream(ds):
+                    if time_dense:
+                        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                    if self.graphs[k].fits(sr.counts):
+                        out = self.graphs[k].replay()
+                    else:           # a sweep denser than the captured capacity: eager dense stage for this sample
+                        self.fallbacks += 1
+                        s = self.samples[k]
+                        vf = self.model.occ_fuser(self.slots[k].img_rows().as_ncdhw(), s["pts"], search=sr)
+                        out = self.model.decode(vf, s["gemo"], s["img_feats"], s["transform"], self.render)
+                    if time_dense:
+                        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                        self.dense_ev.append((e0, e1))
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self.done[k] = ev
+                    if collect is not None:
+                        collect(i, out)
+                    if self.world > 1:
+                        _gather(out)
+                submit(i + ahead)       # its slot's last replay (sample i + ahead - n) has been issued: the search waits on its event
+            with torch.cuda.stream(self.dense_streams[0]):
+                drain_gathers()
+        for ds in self.dense_streams:
+            ds.synchronize()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -518,6 +624,10 @@ def main():
     ap.add_argument("--no-pool", action="store_true",
                     help="start the step from an already-pooled camera volume (round-1 definition) instead of the lifted "
                          "depth/context pair (SURVEY.md 8d: 'lifted features + sweep volume -> logits')")
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1 (default): the dense stage of a sample is one captured hipGraph launch (GraphPipeline); 0: every launch "
+                         "issued from Python (Pipeline, --streams)")
+    ap.add_argument("--slots", type=int, default=6, help="--graph 1: samples in flight (1 in its dense stage + slots-1 in the prefetched search)")
     ap.add_argument("--diag", action="store_true", help="host-side issue times per sample to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -555,7 +665,7 @@ def main():
         args.streams = 2
     STAGGER[0] = args.stagger if args.streams > 1 else 0
     model, sd = build_model(args.config, dev)
-    samples = [make_inputs(args.config, 1234 + 17 * rank + i, dev, model) for i in range(2)]
+    samples = [make_inputs(args.config, 1234 + 17 * rank + i, dev, model) for i in range(max(2, args.slots if args.graph else 2))]
     if args.reserve_cus > 0:
         # CU partition: the FPS chains get private CUs, everything else runs on the remaining ones
         from co_occ_amd import streams as cstreams
@@ -576,6 +686,18 @@ def main():
     # allocation + zero fill: seen once as 110 instead of 54 ms per step at stress200 with --warmup 1)
     run(2 * S, False)
     probe = None
+    gp = None
+    if args.graph and WITH_POOL[0]:
+        try:
+            gp = GraphPipeline(model, samples[:max(2, args.slots)], dev, world, ndense=max(1, args.streams if not auto_streams else 3))
+            gp.run(2 * gp.n)
+        except Exception as e:           # configurations the static form does not cover run the eager pipeline
+            print("bench: hipGraph pipeline unavailable for this configuration (%s: %s); eager pipeline" % (type(e).__name__, e), file=sys.stderr)
+            gp = None
+    if gp is not None:
+        auto_streams, S = False, 1
+        run_eager = run
+        run = (lambda n, timed, S=1: gp.run(n, time_dense=timed))
     if auto_streams:
         # One or two samples in flight?  Two win by ~8 % when the host keeps up (four Python threads share the GIL) and lose
         # that margin when neighbours saturate the box's CPUs (profiles/r2_streams_ab.txt) -- so ask the box: two untimed
@@ -595,8 +717,9 @@ def main():
                      chosen=S)
         run = (lambda n, timed, S=S: pipe.run(n, S))
     run(args.warmup, False)
-    core.TIMER.enabled = 0 if args.no_kernel_timing else (2 if args.kernel_table else 1)
-    core.TIMER.only = ("k_conv", "k_render_nearest", "k_lift_splat")      # what the roofline objects below need
+    if gp is None:
+        core.TIMER.enabled = 0 if args.no_kernel_timing else (2 if args.kernel_table else 1)
+    core.TIMER.only = ("k_conv", "k_gemm", "k_render_nearest", "k_lift_splat")      # what the roofline objects below need
     core.TIMER.reset()
     cdist.barrier()
     torch.cuda.synchronize()
@@ -611,6 +734,13 @@ def main():
     cdist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if args.diag and rank == 0 and TRACE[0] and gp is not None:
+        sl = [(e0.elapsed_time(e1), h) for t, i, e0, e1, h in [x for x in TRACE[0] if x[0] == "search"]]
+        wt = [x[2] for x in TRACE[0] if x[0] == "wait"]
+        print("diag(graph): search GPU latency mean %.2f ms max %.2f | search host mean %.2f ms | main thread waited for a search "
+              "result mean %.2f ms max %.2f" % (sum(a for a, _ in sl) / len(sl), max(a for a, _ in sl), 1e3 * sum(h for _, h in sl) / len(sl),
+                                                1e3 * sum(wt) / len(wt), 1e3 * max(wt)), file=sys.stderr)
+        TRACE[0] = None
     if args.diag and rank == 0 and TRACE[0]:
         for i, w, a, b, c, ev in sorted(TRACE[0]):
             print("trace: sample %2d stream %d  host: search ready %.1f  issue %.1f -> %.1f ms   GPU done %.1f ms" % (
@@ -624,8 +754,28 @@ def main():
     dt = cdist.max_over_ranks(dt, dev)
 
     c = synth.CONFIGS[args.config]
-    roof, extra = rooflines(core.TIMER.summary(), args.steps, args, rank, args.kernel_table)
-    if S > 1 and not args.no_kernel_timing:
+    graph_info = None
+    if gp is not None:
+        dense_ms = [a.elapsed_time(b) for a, b in gp.dense_ev]
+        graph_info = dict(slots=gp.n, eager_fallbacks=gp.fallbacks,
+                          dense_stage_ms=round(sum(dense_ms) / max(1, len(dense_ms)), 3),
+                          note="dense stage = ONE hipGraphLaunch per sample (HIP events around every replay inside the timed region: "
+                               "dense_stage_ms); pooling + index search eager on prefetch streams")
+        if not args.no_kernel_timing:
+            # per-kernel durations cannot be taken inside a graph launch: an eager pass of the same step (one sample in flight,
+            # search prefetched) with HIP events around every launch, right after the timed region
+            n_e = max(8, min(20, args.steps))
+            run_eager(3, False, S=1)
+            core.TIMER.enabled = 2 if args.kernel_table else 1
+            core.TIMER.reset()
+            run_eager(n_e, False, S=1)
+            torch.cuda.synchronize()
+            core.TIMER.enabled = False
+    roof, extra = rooflines(core.TIMER.summary(), (max(8, min(20, args.steps)) if gp is not None else args.steps), args, rank, args.kernel_table)
+    if gp is not None and roof:
+        roof["measured"] = ("HIP events around every launch of an eager pass of the same steps right after the timed region "
+                            "(inside it the dense stage is one hipGraphLaunch per sample)")
+    if S > 1 and gp is None and not args.no_kernel_timing:
         # Kernel durations inside the S-stream pipeline include the contention between the samples in flight (that is the
         # point of it: one sample's low-occupancy tail runs under the other's GEMMs).  A short pass of the same pipeline with ONE
         # sample in flight (the next sample's pooling + search still prefetched) gives each kernel's own rate next to it.
@@ -660,11 +810,17 @@ def main():
                             occupancy_grid="x".join(str(v) for v in c.get("final_occ_size", [2 * g for g in c["grid"]])), cams=c["ncam"],
                             render_maps="%dx%dx%d" % (c["ncam"], c["fmap"][0] * 16, c["fmap"][1] * 16), knum=c["knum"],
                             parallelism="dp%d (1 scene per GPU, RCCL all-gather of maps)" % world,
-                            samples_in_flight=S, prefetched_search=bool(tpool), weights="random",
+                            samples_in_flight=(gp.n if gp is not None else S), prefetched_search=bool(tpool), weights="random",
+                            pipeline=("hipGraph dense stage + eager prefetched search" if gp is not None else "eager (Python-issued launches)"),
+                            conv_engine=(core.CONV_ENGINE if args.dtype == "f32" else args.dtype),
                             step_starts_from=("lifted depth/context pair (fused lift-splat pooling inside the step)" if WITH_POOL[0]
                                               else "pooled camera volume")),
                 roofline=roof)
     line.update(extra)
+    if graph_info is not None:
+        line["graph"] = graph_info
+    knobs = {k: v for k, v in sorted(os.environ.items()) if k.startswith("COOCC_")}
+    line["env_knobs"] = knobs           # every dispatch-changing environment variable that was set for this run
     if probe is not None:
         line["stream_probe"] = dict(probe, note="untimed bursts before the warm-up: samples in flight chosen by the faster total "
                                                 "(--streams 1 / 2 fixes it)")

@@ -27,6 +27,15 @@ class ConvDesc(ctypes.Structure):
                                      "wgroup_rows", "mfma_dtype")] + [("alpha", ctypes.c_float), ("M_dev", c_void_p), ("gather_stride", c_int)]
 
 
+class SearchDesc(ctypes.Structure):
+    """struct coocc_search_desc (include/coocc_hip.h)."""
+    _fields_ = [("cat4", c_void_p), ("pts", c_void_p), ("pts_rows", c_int), ("pts_stride", c_int)] + \
+               [(n, c_int) for n in ("C", "X", "Y", "Z", "K", "fps_num", "max_cluster")] + \
+               [("radius", ctypes.c_float), ("dist_thresh", ctypes.c_float), ("offsets", c_void_p), ("noff", c_int)] + \
+               [(n, c_void_p) for n in ("lin", "counts", "near_img", "near_pts", "rows", "rows_p", "ws")] + \
+               [("ws_bytes", ctypes.c_size_t), ("counts_host", c_void_p)]
+
+
 P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_int64
 # name -> (restype, argtypes); mirrors include/coocc_hip.h one to one (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -62,6 +71,8 @@ SIGNATURES = {
     "coocc_index_rows_i32": (I, [P, I, P, I, P, P]),
     "coocc_conv_pack_weights": (L, [P, I, I, I, I, P]),
     "coocc_conv_fwd": (I, [ctypes.POINTER(ConvDesc), P]),
+    "coocc_fuser_search_ws": (Z, [ctypes.POINTER(SearchDesc)]),
+    "coocc_fuser_search": (I, [ctypes.POINTER(SearchDesc), P, P]),
     "coocc_upsample_add_trilinear": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "coocc_occhead_mix": (I, [P, P, I, P, P, I, I, P]),
     "coocc_argmax_flags": (I, [P, I, I, I, I, P, P]),

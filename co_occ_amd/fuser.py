@@ -31,6 +31,8 @@ def _side_stream(dev, cur, which=0):
     return _side[key]
 
 
+FPS_HIGH_PRIORITY = __import__("os").environ.get("COOCC_FPS_HIGH_PRIORITY", "0") != "0"     # measured: any high-priority stream slows the dense graphs (bench: 140 -> 122 samples/s)
+_fps_hi = {}
 FPS_MAX_BUCKETS = 8 * 1024     # FPS_RMAX * threads of csrc/knn.hip k_fps_voxels
 
 
@@ -41,6 +43,14 @@ def _fps_voxels(q_lin, grid, fps_num, which=0, home=None):
     dev = q_lin.device
     cur = torch.cuda.current_stream(dev)
     fstream = streams.fps_stream_for(home if home is not None else cur, which)
+    if fstream is None and FPS_HIGH_PRIORITY:
+        # the 2047-step chain alone on a high-priority stream (one workgroup: it costs the other kernels nothing, but queued
+        # at normal priority behind a saturated GPU it waits for a CU slot at every launch); the all-CU kernels of the
+        # search stay at their stream's priority -- at high priority they slow the dense stage by 40 % (measured)
+        key = (dev.index, cur.cuda_stream, which)
+        if key not in _fps_hi:
+            _fps_hi[key] = torch.cuda.Stream(device=dev, priority=-1)
+        fstream = _fps_hi[key]
     if fstream is not None:
         fstream.wait_stream(cur)
         with torch.cuda.stream(fstream):
@@ -182,9 +192,35 @@ class SearchSlot:
         self.rows = torch.zeros(knum, V, device=device, dtype=_I32)
         self.rows_p = torch.zeros(knum, V, device=device, dtype=_I32)
 
+        self.knum = knum
+        self.near = torch.zeros(2, knum * V, device=device, dtype=_I32)     # near_img, near_pts (dense [K, count] inside)
+        self._native = None
+
     def img_rows(self):
         X, Y, Z = self.grid
         return Rows(self.cat4, 1, X, Y, Z, self.C, 0)
+
+    def native_desc(self):
+        """coocc_search_desc over this slot's buffers (csrc/search.hip), workspace included; built once."""
+        if self._native is None:
+            import ctypes
+            X, Y, Z = self.grid
+            d = _lib.SearchDesc()
+            d.cat4 = self.cat4.data_ptr()
+            d.C, d.X, d.Y, d.Z, d.K = self.C, X, Y, Z, self.knum
+            d.fps_num, d.max_cluster, d.radius, d.dist_thresh = 2048, 200, 6.0, 13.3
+            off = offset_table(Z, self.cat4.device)
+            d.offsets, d.noff = off.data_ptr(), off.numel()
+            d.lin, d.counts = self.lin.data_ptr(), self.counts.data_ptr()
+            d.near_img, d.near_pts = self.near[0].data_ptr(), self.near[1].data_ptr()
+            d.rows, d.rows_p = self.rows.data_ptr(), self.rows_p.data_ptr()
+            need = int(_lib.load().coocc_fuser_search_ws(ctypes.byref(d)))
+            ws = torch.empty(need, device=self.cat4.device, dtype=torch.uint8)
+            d.ws, d.ws_bytes = ws.data_ptr(), need
+            host = (ctypes.c_int32 * 2)()
+            d.counts_host = ctypes.addressof(host)
+            self._native = (d, ws, host, off)
+        return self._native
 
 
 class SearchResult:
@@ -357,6 +393,45 @@ class BiFuser_N(nn.Module):
         sr.done_main.record()
         return sr
 
+    def search_native(self, pts_voxel_feats, slot):
+        """``search(slot.img_rows(), pts, slot=slot)`` through ONE C-ABI call (``coocc_fuser_search``, csrc/search.hip): the
+        launches, the two-stream fork / join and the count read are issued from C++ with the GIL released.  Falls back to
+        ``search`` for what the native driver does not cover (a list with <= 2048 voxels, grids too large for the bucketed
+        FPS, batch > 1).  The camera rows must already sit in slot 0 of ``slot.cat4``."""
+        import ctypes
+        X, Y, Z = slot.grid
+        dev = slot.cat4.device
+        pts_r = _as_rows_view(pts_voxel_feats)
+        B = pts_r.B if pts_r is not None else pts_voxel_feats.shape[0]
+        if B != 1 or (X + 3) // 4 * ((Y + 3) // 4) * ((Z + 7) // 8) > FPS_MAX_BUCKETS:
+            return self.search(slot.img_rows().as_ncdhw(), pts_voxel_feats, slot=slot)
+        d, _, host, _ = slot.native_desc()
+        if pts_r is not None:
+            d.pts, d.pts_rows, d.pts_stride = pts_r.t.data_ptr() + 4 * pts_r.coff, 1, pts_r.stride
+            keep = pts_r.t
+        else:
+            keep = pts_voxel_feats.float().contiguous()
+            d.pts, d.pts_rows, d.pts_stride = keep.data_ptr(), 0, 0
+        cur = torch.cuda.current_stream(dev)
+        side = _side_stream(dev, cur)
+        rc = _lib.load().coocc_fuser_search(ctypes.byref(d), ctypes.c_void_p(cur.cuda_stream), ctypes.c_void_p(side.cuda_stream))
+        if rc == 1:           # COOCC_SEARCH_SMALL: the reference's other branch
+            return self.search(slot.img_rows().as_ncdhw(), pts_voxel_feats, slot=slot)
+        _lib.check(rc)
+        Ni, Np = int(host[0]), int(host[1])
+        self.last_counts = (Ni, Np)
+        K, V = self.knum, slot.V
+        sr = SearchResult(Rows(slot.cat4, 1, X, Y, Z, 4 * self.in_channels), slot.lin[0, :Ni], slot.lin[1, :Np])
+        sr.slot = slot
+        sr.near_img = slot.near[0, :K * Np].view(K, Np)
+        sr.near_pts = slot.near[1, :K * Ni].view(K, Ni)
+        sr.rows, sr.rows_p = slot.rows[:, :Np], slot.rows_p[:, :Ni]
+        sr.keep = (keep,)
+        sr.done_main = torch.cuda.Event()
+        sr.done_main.record()
+        sr.done_side = sr.done_main          # the native call joins the side stream before it returns
+        return sr
+
     def finish(self, sr):
         """G1 on the current stream: the two gather -> knn_enc -> gate -> scatter GEMMs that complete the concat
         rows of a ``SearchResult`` (bifuser_n.py:138-169).  Returns (rows [B*V,4C], (lin_img, lin_pts))."""
@@ -368,7 +443,12 @@ class BiFuser_N(nn.Module):
         cur.wait_event(sr.done_main)
         for t in sr.tensors():
             t.record_stream(cur)             # allocated on the search stream(s), consumed here
-        if sr.rows is not None:
+        if sr.rows is not None and sr.slot is not None:
+            # the search wrote into a SearchSlot: its tables are capacity-strided views, use the device-count form
+            cur.wait_event(sr.done_side)
+            self.finish_static(sr.slot)
+            self.last_near = (sr.near_img, sr.near_pts)
+        elif sr.rows is not None:
             gather_conv_rows(cat4, 0, packs["knn"], sr.rows, sr.lin_pts, cat4, 2 * C, C, C)
             cur.wait_event(sr.done_side)
             gather_conv_rows(cat4, C, packs["knn"], sr.rows_p, sr.lin_img, cat4, 3 * C, 0, C)
@@ -448,7 +528,8 @@ class BiFuser_N(nn.Module):
             # static form (hipGraph replay): lin_pts is the capacity-sized list, its length sits on the device; the
             # scatter-form GEMM is sized for the densest sweep the split is used for (the caller checks the host-side count
             # of the sample against ``c0_capacity`` before replaying)
-            assert plan is not None and cat4.B == 1, "static con_enc0 needs the channel-support split"
+            if plan is None or cat4.B != 1:
+                return conv_rows(cat4, packs["c0"], relu=True)      # one dense GEMM: nothing depends on the count
             Np = self.c0_capacity(V)
         elif plan is None or Np == 0 or Np > SPLIT_C0_MAX_DENSITY * V or cat4.B != 1:
             return conv_rows(cat4, packs["c0"], relu=True)

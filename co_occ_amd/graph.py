@@ -25,6 +25,9 @@ from . import _lib, core
 from .fuser import SearchSlot
 
 
+NATIVE_SEARCH = __import__("os").environ.get("COOCC_NATIVE_SEARCH", "1") != "0"     # 0: the Python-issued search stage
+
+
 class DenseGraph:
     """The dense stage of one sample slot as a hipGraph.  ``inputs``: dict(pts [1,C,X,Y,Z], gemo, img_feats, transform) of the
     sample bound to this slot; the slot's concat buffer must have been filled by ``search_into_slot`` at least once before
@@ -66,6 +69,8 @@ def search_into_slot(model, slot, depth, ctx, cams, pts):
     """Pooling (fused Lift (x) Splat into slot 0 of the slot's concat rows) + index search of one sample on the CURRENT
     stream, outputs in the slot's static buffers.  Returns the ``SearchResult`` (events, host-side counts)."""
     img = model.img_view_transformer.lift_splat(depth, ctx, cams=cams, out=slot.img_rows())
+    if NATIVE_SEARCH:
+        return model.occ_fuser.search_native(pts, slot)
     return model.occ_fuser.search(img, pts, slot=slot)
 
 

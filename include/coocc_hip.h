@@ -100,6 +100,35 @@ int coocc_ball_query(int b, int n, int m, float min_radius, float max_radius, in
 /* ---- K3 / K4 when both point sets are the non-empty voxels of ONE dense X x Y x Z grid (the fuser's case: the lists
  * are ascending linear voxel ids v = (x*Y + y)*Z + z, so "index order" == lexicographic voxel order).  Bit-identical to
  * coocc_ball_query / coocc_knn_topk on the same points, 20-100x less work (no 2048 x N distance sweep). */
+/* The whole index-search stage of BiFuser_N.forward (bifuser_n.py:129-162: non-empty voxel lists, and for both directions FPS ->
+ * top-K -> ball query -> assignment -> neighbour row tables) as ONE call: every launch, the fork / join of the two directions
+ * over `stream` / `side_stream` and the stage's single device->host read (the two counts) are issued from C++ (csrc/search.hip).
+ * B == 1; grid small enough for coocc_fps_voxels.  Returns COOCC_OK, COOCC_SEARCH_SMALL (a list has <= fps_num voxels: the
+ * reference takes its other branch, bifuser_n.py:54-60 -- nothing was launched after the count read, use the generic entry
+ * points), or a negative error.  On return everything is enqueued and `stream` has joined `side_stream`. */
+#define COOCC_SEARCH_SMALL 1
+typedef struct coocc_search_desc {
+  float* cat4;             /* [V,4C] concat rows; slot 0 (camera rows) already written, slots 1..3 written here / by G1 */
+  const float* pts;        /* LiDAR volume: NCDHW [C,V] (pts_rows = 0) or channels-last rows [V,pts_stride] (pts_rows = 1) */
+  int pts_rows, pts_stride;
+  int C, X, Y, Z, K;       /* channels per slot, grid, knum */
+  int fps_num, max_cluster;/* 2048, 200 (bifuser_n.py:137) */
+  float radius, dist_thresh;   /* 6, 13.3 */
+  const uint32_t* offsets; /* coocc_knn_topk_voxels' sorted offset table */
+  int noff;
+  int32_t* lin;            /* out [2][V]: ascending non-empty voxel ids of (img, pts) */
+  int32_t* counts;         /* out [2] (device) */
+  int32_t* near_img;       /* out [K][Np] dense: img ordinal assigned to each pts voxel (-1 none)   (capacity K*V) */
+  int32_t* near_pts;       /* out [K][Ni] dense                                                    (capacity K*V) */
+  int32_t* rows;           /* out [K][V]: concat-buffer row of the k-th img neighbour of pts voxel j (first Np entries) */
+  int32_t* rows_p;         /* out [K][V]: ... of img voxel j (first Ni entries); K > 1 indexes inds_img (bifuser_n.py:158) */
+  void* ws;                /* >= coocc_fuser_search_ws(desc) bytes (device) */
+  size_t ws_bytes;
+  int32_t* counts_host;    /* out [2] (host): Ni, Np */
+} coocc_search_desc;
+size_t coocc_fuser_search_ws(const coocc_search_desc* d);
+int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side_stream);
+
 /* map[v] = ordinal of voxel v in lin[0..n) or -1.  map:[nvox] i32. */
 int coocc_voxel_index_map(const int32_t* lin, int n, int nvox, int32_t* map, void* stream);
 /* Device-side counts (no host round trip; grids sized for the capacity, surplus workgroups leave at once): the *_dev forms of

@@ -61,3 +61,29 @@ def test_dense_graph_replay_equals_eager(dev):
         assert n > 0
         for k in ("pred_c", "pred_f", "rgbs", "depths"):
             assert torch.equal(out[k], want[k]), "%s differs between the graph replay and the eager path" % k
+
+
+def test_native_search_equals_python_search(dev):
+    """coocc_fuser_search (the whole index-search stage issued from C++, csrc/search.hip) against BiFuser_N.search: voxel lists,
+    counts, neighbour ordinals and row tables bit for bit, concat rows included."""
+    import bench
+    from co_occ_amd import graph as cg
+    bench.CFGNAME[0] = "r50"
+    model, _ = bench.build_model("r50", dev)
+    s = bench.make_inputs("r50", 4321, dev, model)
+    X, Y, Z = s["pts"].shape[2:]
+    f = model.occ_fuser
+    with torch.no_grad():
+        a, b = cg.make_slot(model, (X, Y, Z), dev), cg.make_slot(model, (X, Y, Z), dev)
+        for slot in (a, b):
+            model.img_view_transformer.lift_splat(s["depth"], s["ctx"], cams=s["cams"], out=slot.img_rows())
+        sa = f.search(a.img_rows().as_ncdhw(), s["pts"], slot=a)
+        sb = f.search_native(s["pts"], b)
+    torch.cuda.synchronize()
+    assert sa.counts == sb.counts and min(sa.counts) > 2048
+    assert torch.equal(sa.lin_img, sb.lin_img) and torch.equal(sa.lin_pts, sb.lin_pts)
+    assert torch.equal(sa.near_img, sb.near_img) and torch.equal(sa.near_pts, sb.near_pts)
+    assert torch.equal(sa.rows, sb.rows) and torch.equal(sa.rows_p, sb.rows_p)
+    C = f.in_channels
+    assert torch.equal(a.cat4[:, :2 * C], b.cat4[:, :2 * C])
+    assert torch.equal(a.counts, b.counts)
