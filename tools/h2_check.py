@@ -110,6 +110,40 @@ def bench():
         print(line + "  |f32-h2| %.1e" % d, flush=True)
 
 
+def direct():
+    """Stride-1 3x3x3 layers outside the Winograd path (small grids): h2 direct kernel vs the fp32-MFMA kernel, error vs fp64."""
+    core.TIMER.enabled = 0
+    core.WINO = 1
+    core.WINO_MIN_ROWS = 8192
+    for (name, Cin, Cout, grid, use_res) in [("enc.l2", 512, 512, (25, 25, 2), True), ("enc.l3", 1024, 1024, (13, 13, 1), True),
+                                            ("fpn.out2", 256, 256, (25, 25, 2), False), ("head.occ3", 256, 128, (13, 13, 1), False),
+                                            ("odd", 96, 160, (11, 9, 3), False)]:
+        g = torch.Generator().manual_seed(3)
+        X, Y, Z = grid
+        x = torch.relu(torch.randn(1, Cin, X, Y, Z, generator=g)) * torch.exp(torch.randn(1, Cin, X, Y, Z, generator=g))
+        w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (2.0 / (Cin * 27)) ** 0.5
+        bn = bn_like(Cout, g)
+        res = torch.randn(1, Cout, X, Y, Z, generator=g) if use_res else None
+        ref = F.conv3d(x.double(), w.double(), padding=1)
+        sc, bi = core.fold_bn(bn)
+        ref = ref * sc.double().view(1, -1, 1, 1, 1) + bi.double().view(1, -1, 1, 1, 1)
+        if use_res:
+            ref = ref + res.double()
+        ref = torch.relu(ref)
+        rms = ref.pow(2).mean().sqrt()
+        pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=3, stride=1, pad=1)
+        xr = rows_of(x)
+        rr = rows_of(res) if use_res else None
+        line = "%-10s %4d->%4d %-12s:" % (name, Cin, Cout, grid)
+        for eng in ("f32", "h2"):
+            core.CONV_ENGINE = eng
+            out = core.conv_rows(xr, pc, relu=True, res=rr)
+            e = out.as_ncdhw().cpu().double() - ref
+            t = timeit(lambda: core.conv_rows(xr, pc, relu=True, res=rr))
+            line += "  %-3s rms %.2e max %.2e  %.3f ms |" % (eng, float(e.pow(2).mean().sqrt() / rms), float(e.abs().max() / rms), t)
+        print(line, flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["acc", "time"]
     with torch.no_grad():
@@ -117,3 +151,5 @@ if __name__ == "__main__":
             acc()
         if "time" in what:
             bench()
+        if "direct" in what:
+            direct()
