@@ -47,6 +47,7 @@ SIGNATURES = {
     "coocc_ncdhw_to_ndhwc": (I, [P, P, I, I, I, I, I, P]),
     "coocc_rows_to_bf16": (I, [P, I, L, I, P, P]),
     "coocc_rows_to_h2": (I, [P, I, L, I, F, P, P]),
+    "coocc_rows_to_h2_gather": (I, [P, I, P, L, P, I, F, P, P]),
     "coocc_wino_input_h2": (I, [P, I, I, I, I, I, I, I, P, I, L, F, P]),
     "coocc_ndhwc_to_ncdhw": (I, [P, P, I, I, I, I, I, P]),
     "coocc_fuser_prepare": (I, [P, P, P, P, P, I, I, I, P]),

@@ -464,15 +464,15 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
             d.kx, d.ky, d.kz, d.px, d.py, d.pz = 3, 3, hi - lo + 1, pc.pad, pc.pad, pc.pad - lo
             d.taps = taps = 9 * (hi - lo + 1)
     same = pc.stride == 1 and (Xo, Yo, Zo) == (x.X, x.Y, x.Z)
-    if (not bf16 and CONV_ENGINE == "h2" and H2_DIRECT and same and pc.ksize == 3 and pc.Cin % 32 == 0 and pc._w_taps is not None
+    if (not bf16 and CONV_ENGINE == "h2" and H2_DIRECT and pc.Cin % 32 == 0 and pc._w_taps is not None
             and rm in (0, 1) and x.B * x.V * pc.Cin * 4 < (1 << 32) - 256 and 2.0 * M * pc.Cin * pc.Cout * taps >= H2_DIRECT_MIN_FLOPS):
-        # fp32-accurate split-f16 GEMM (csrc/gemm_h2.hip) for the stride-1 3x3xkz layers the Winograd path leaves out (small
-        # grids): the input rows are split into H2 rows once per layer (a few MB), the (dx, dy) groups share one LDS image per
-        # 3 z taps, the epilogue (folded BN, residual, ReLU) is the usual one
+        # fp32-accurate split-f16 GEMM (csrc/gemm_h2.hip) for the layers the Winograd path leaves out (small grids, strided,
+        # 1x1x1): the input rows are split into H2 rows once per layer, stride-1 "same" layers share one LDS image per 3 z taps
+        # (k_gemm_h2z), the rest fetch one image per (chunk, tap) (k_gemm_h2w); the epilogue (folded BN, residual, ReLU) is the usual one
         xh = scratch(x.t.device, "h2in", x.B * x.V * pc.Cin)
         call("coocc_rows_to_h2", x.data(), x.stride, x.B * x.V, pc.Cin, 1.0, ptr(xh))
         d.in_, d.in_stride, d.w, d.mfma_dtype, d.alpha = ptr(xh), pc.Cin, ptr(pc.h2_pack(trim)), 3, 1.0
-        with TIMER.region("k_gemm_h2z direct", 2.0 * M * pc.Cin * pc.Cout * taps):
+        with TIMER.region("k_gemm_h2z direct" if (same and taps > 1) else "k_gemm_h2w", 2.0 * M * pc.Cin * pc.Cout * taps):
             _lib.conv_fwd(d, pc.w.device)
         return out
     if bf16 and BF16_PRECONVERT and pc.Cin % 64 == 0 and pc._w_taps is not None and taps > 1:    # 1x1x1: HBM-bound either way

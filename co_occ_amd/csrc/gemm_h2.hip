@@ -298,28 +298,245 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
   }
 }
 
+// k_gemm_h2w: the general form -- any stride / padding / tap set (one LDS image of 128 rows per (chunk, tap), rows fetched by
+// per-lane addresses: the strided and 1x1x1 layers) and row tables (TABLE: input row of (tap t, output m) = gather[t * gstride + m];
+// row count optionally on the device).  Same tile, transposed MFMA order, phases and epilogue as k_gemm_h2z; rows that fall
+// outside the grid (or table entries < 0) are fetched from the zero row, so no fragment needs masking.
+template <bool TABLE>
+__global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
+  constexpr int BM = 128, TM = 4;
+  constexpr unsigned STAGE = BM * 128;
+  __shared__ __attribute__((aligned(16))) char As[2 * BM * 128];
+
+  const int id = blockIdx.x;
+  int mtile, nt, slot_ = id >> 3;
+  if (p.mtiles_per_xcd > 0) {
+    const int xcd = id & 7;
+    const int mt_local = slot_ / p.ntiles;
+    nt = slot_ - mt_local * p.ntiles;
+    mtile = xcd * p.mtiles_per_xcd + mt_local;
+    if (mt_local >= p.mtiles_per_xcd || mtile >= p.mtiles) return;
+  } else {
+    mtile = id / p.ntiles;
+    nt = id - mtile * p.ntiles;
+  }
+  const int m0 = mtile * BM, n0 = nt * 128;
+  if (p.M_dev) {                       // row count on the device (grid sized for the capacity p.M): whole tiles past it leave
+    p.M = min(p.M, *p.M_dev);
+    if (m0 >= p.M) return;
+  }
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, h = lane >> 5;
+  const int srow = lane >> 3, slot = lane & 7;
+
+  const int kx = p.kx, ky = p.ky, kz = p.kz, Xi = p.Xi, Yi = p.Yi, Zi = p.Zi, taps = p.taps;
+  const long long rowbytes = (long long)p.in_stride * 4;
+  const char* inb = (const char*)p.in;
+  const char* zrow = (const char*)p.zrow;
+  const unsigned aq = (unsigned)((slot ^ ((4 * (wave & 1) + (srow >> 1)) & 7)) * 16);
+  // this lane's four staging rows r = (4 j + wave) 8 + srow: input coordinates of tap (0,0,0) and its row index
+  int rix[4], riy[4], riz[4], rrow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + (j * 4 + wave) * 8 + srow;
+    if (TABLE) {
+      rix[j] = m < p.M ? m : -1; riy[j] = riz[j] = rrow[j] = 0;
+    } else {
+      int oz = m % p.Zo; int q = m / p.Zo;
+      int oy = q % p.Yo; q /= p.Yo;
+      int ox = q % p.Xo; const int b = q / p.Xo;
+      rix[j] = m < p.M ? ox * p.stride - p.px : -(1 << 20);
+      riy[j] = oy * p.stride - p.py;
+      riz[j] = oz * p.stride - p.pz;
+      rrow[j] = ((b * Xi + rix[j]) * Yi + riy[j]) * Zi + riz[j];
+    }
+  }
+  const int it0 = blockIdx.y * p.iters_per_split;
+  const int it1 = min(it0 + p.iters_per_split, p.total_iters);
+  const int nsteps = it1 - it0;
+  int ckc = it0 / taps, ct = it0 - ckc * taps;
+  int ckw = ct % kz, ckh = (ct / kz) % ky, ckd = ct / (kz * ky);
+  const long long wstep = (long long)(p.Npad >> 5) * 4096;
+  const char* wcur = (const char*)p.w + (long long)it0 * wstep + (long long)((n0 >> 5) + wave) * 4096 + lane * 16;
+  const int gstride = p.gstride;
+  int tnext[4];                    // TABLE: the source rows of the NEXT iteration (fetched one iteration ahead)
+  auto tload = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tnext[j] = rix[j] >= 0 ? p.gather[(size_t)ct * gstride + rix[j]] : -1;
+  };
+  if (TABLE && nsteps > 0) tload();
+
+  auto issueA = [&](int buf) {
+    const long long coff = (long long)ckc * 128 + aq;
+    if (TABLE) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const char* src = tnext[j] >= 0 ? inb + ((long long)tnext[j] * rowbytes + coff) : zrow;
+        glds16_(src, &As[buf * STAGE + (j * 4 + wave) * 8 * 128]);
+      }
+      if (++ct == taps) { ct = 0; ++ckc; }
+      tload();                     // harmless past the last iteration: ct < taps always
+    } else {
+      const int tapoff = (ckd * Yi + ckh) * Zi + ckw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = (unsigned)(rix[j] + ckd) < (unsigned)Xi && (unsigned)(riy[j] + ckh) < (unsigned)Yi &&
+                        (unsigned)(riz[j] + ckw) < (unsigned)Zi;
+        const char* src = ok ? inb + ((long long)(rrow[j] + tapoff) * rowbytes + coff) : zrow;
+        glds16_(src, &As[buf * STAGE + (j * 4 + wave) * 8 * 128]);
+      }
+      if (++ckw == kz) { ckw = 0; if (++ckh == ky) { ckh = 0; if (++ckd == kx) { ckd = 0; ++ckc; } } }
+    }
+  };
+  f16x8 breg[2][2][2];        // [register set][k16 step][plane]
+  auto loadB = [&](auto bufc) {
+    constexpr int B_ = decltype(bufc)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) breg[B_][s][pl] = *(const f16x8*)(wcur + (s * 2 + pl) * 1024);
+    wcur += wstep;
+  };
+  unsigned fragoff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int sl = (q & 1) * 4 + 2 * (q >> 1) + h;            // q = 2 s + plane
+    fragoff[q] = li * 128 + ((sl ^ ((li >> 1) & 7)) << 4);
+  }
+  f16x8 fhi[TM], flo[TM];
+  auto load_plane = [&](auto planec, auto stagec, auto sc) {
+    constexpr int PL = decltype(planec)::value, ST = decltype(stagec)::value, S_ = decltype(sc)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (PL == 0) fhi[i] = *(const f16x8*)&As[fragoff[2 * S_ + PL] + (ST * STAGE + i * 4096)];
+      else flo[i] = *(const f16x8*)&As[fragoff[2 * S_ + PL] + (ST * STAGE + i * 4096)];
+    }
+  };
+  f32x16 hh[TM], xx[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hh[i][r] = 0.f; xx[i][r] = 0.f; }
+  auto p01 = [&](auto setc, auto sc) {
+    constexpr int B_ = decltype(setc)::value, S_ = decltype(sc)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) hh[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], fhi[i], hh[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][1], fhi[i], xx[i], 0, 0, 0);
+  };
+  auto p2 = [&](auto setc, auto sc) {
+    constexpr int B_ = decltype(setc)::value, S_ = decltype(sc)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], flo[i], xx[i], 0, 0, 0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  // one (chunk, tap) iteration in stage ST (= weight set ST); A_hi of its first step is already in registers
+  auto step = [&](auto stc, bool more) {
+    constexpr int ST = decltype(stc)::value;
+    using STC = std::integral_constant<int, ST>; using SNC = std::integral_constant<int, ST ^ 1>;
+    if (more) { issueA(ST ^ 1); loadB(SNC{}); }
+    load_plane(I1{}, STC{}, I0{});
+    p01(STC{}, I0{});
+    H2_FENCE();
+    load_plane(I0{}, STC{}, I1{});
+    p2(STC{}, I0{});
+    H2_FENCE();
+    load_plane(I1{}, STC{}, I1{});
+    p01(STC{}, I1{});
+    H2_FENCE();
+    __syncthreads();            // every wave has read this stage for the last time; the next image has landed
+    if (more) load_plane(I0{}, SNC{}, I0{});
+    p2(STC{}, I1{});
+    H2_FENCE();
+  };
+  if (nsteps > 0) {
+    issueA(0);
+    loadB(I0{});
+  }
+  __syncthreads();
+  if (nsteps > 0) load_plane(I0{}, I0{}, I0{});
+  for (int st = 0; st < nsteps; st += 2) {
+    step(I0{}, st + 1 < nsteps);
+    if (st + 1 < nsteps) step(I1{}, st + 2 < nsteps);
+  }
+
+  // epilogue: lane (li, h) holds, for output row m0 + i*32 + li, the channels n0 + 32 wave + 8 j + 4 h + 0..3 (j = 0..3)
+  const int nb = n0 + wave * 32 + 4 * h;
+  const float alpha = p.alpha, lo = p.alpha * (1.f / H2_LO_SCALE);
+  if (p.splitk > 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + i * 32 + li;
+      if (m >= p.M) continue;
+      float* o = p.ws + ((size_t)blockIdx.y * p.M + m) * p.Npad + nb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo;
+        *(f32x4*)(o + 8 * j) = v;
+      }
+    }
+  } else {
+    const bool vec = (p.Cout & 3) == 0 && (p.out_stride & 3) == 0 && (!p.res || (p.res_stride & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + i * 32 + li;
+      if (m >= p.M) continue;
+      const size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = nb + 8 * j;
+        if (n >= p.Cout) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo;
+        if (vec) {
+          if (p.res_mode == 3) v = v + *(const f32x4*)(p.res + orow * p.res_stride + n);
+          if (p.scale) v = v * *(const f32x4*)(p.scale + n);
+          if (p.bias) v = v + *(const f32x4*)(p.bias + n);
+          if (p.res_mode == 1) v = v + *(const f32x4*)(p.res + orow * p.res_stride + n);
+          if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          if (p.res_mode == 2) v = v * *(const f32x4*)(p.res + orow * p.res_stride + n);
+          *(f32x4*)(p.out + orow * p.out_stride + n) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.Cout) p.out[orow * p.out_stride + n + e] = epilogue(p, v[e], n + e, orow);
+        }
+      }
+    }
+  }
+}
+
 int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
-  COOCC_CHECK_ARG(!d->gather && !d->out_rows, "conv_fwd: the split-f16 path covers geometric taps only");
   COOCC_CHECK_ARG(d->Cin % 32 == 0 && d->in_stride % 32 == 0, "conv_fwd: H2 operands need Cin % 32 == 0 and in_stride % 32 == 0");
-  COOCC_CHECK_ARG(k.stride == 1 && k.Xo == k.Xi && k.Yo == k.Yi && k.Zo == k.Zi && k.kz >= 1 && k.kz <= 3,
-                  "conv_fwd: the split-f16 kernel covers stride-1 'same' layers with 1..3 z taps");
   COOCC_CHECK_ARG(d->wgroup_rows == 0 || d->wgroup_rows % 128 == 0, "conv_fwd: wgroup_rows must be a multiple of 128");
+  const bool table = d->gather != nullptr;
+  // stride-1 "same" geometry with <= 3 z taps: one LDS image per (chunk, dx, dy) serves the z taps (k_gemm_h2z); everything else
+  // (strided, 1x1x1, row tables) one image per (chunk, tap) (k_gemm_h2w)
+  const bool zshare = !table && !d->out_rows && !d->M_dev && k.stride == 1 && k.Xo == k.Xi && k.Yo == k.Yi && k.Zo == k.Zi && k.kz >= 1 && k.kz <= 3 &&
+                      k.taps > 1;
+  COOCC_CHECK_ARG(zshare || d->wgroup_rows == 0, "conv_fwd: weight groups need the stride-1 same geometry");
   k.kchunks = d->Cin / 32;
   k.total_iters = k.taps * k.kchunks;
   k.wgroup_floats = (size_t)k.taps * k.kchunks * k.Npad * 32;       // 128 bytes per (chunk, tap, column)
   k.alpha = d->alpha != 0.f ? d->alpha : 1.f;
+  k.M_dev = d->M_dev;
   int rc = coocc_zero_row(&k.zrow);
   if (rc != COOCC_OK) return rc;
   k.ntiles = (k.Cout + 127) / 128;
   k.mtiles = (k.M + 127) / 128;
   k.mtiles_per_xcd = k.mtiles >= 64 ? (k.mtiles + 7) / 8 : 0;
-  // split-K on whole (dx, dy) groups
+  // split-K on whole groups (k_gemm_h2z: (dx, dy) groups of kz taps; k_gemm_h2w: single iterations)
+  const int gsz = zshare ? k.kz : 1;
   int splitk = d->splitk;
   const long long blocks = (long long)k.mtiles * k.ntiles;
-  const int ngroups = k.total_iters / k.kz;
+  const int ngroups = k.total_iters / gsz;
   if (splitk <= 0) {
     splitk = 1;
-    if (blocks < 256 && ngroups >= 8 && d->ws) {
+    if (blocks < 256 && ngroups >= 8 && d->ws && !d->M_dev && !d->out_rows) {
       splitk = (int)(512 / blocks);
       if (splitk > ngroups / 4) splitk = ngroups / 4;
       if (splitk > 64) splitk = 64;
@@ -328,10 +545,17 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
     }
   }
   int gps = (ngroups + splitk - 1) / splitk;
-  k.iters_per_split = gps * k.kz;
+  k.iters_per_split = gps * gsz;
   k.splitk = (k.total_iters + k.iters_per_split - 1) / k.iters_per_split;
-  COOCC_CHECK_ARG(k.splitk == 1 || (d->ws && (long long)k.splitk * d->M * k.Npad <= d->ws_floats), "conv_fwd: split-K workspace too small");
+  COOCC_CHECK_ARG(k.splitk == 1 || (d->ws && !d->M_dev && !d->out_rows && (long long)k.splitk * d->M * k.Npad <= d->ws_floats),
+                  "conv_fwd: split-K workspace too small (or split-K with a device row count / row scatter)");
   dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
+  if (!zshare) {
+    if (table) hipLaunchKernelGGL(k_gemm_h2w<true>, grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL(k_gemm_h2w<false>, grid, dim3(256), 0, s, k);
+    COOCC_LAUNCH_CHECK("k_gemm_h2w");
+    return COOCC_OK;
+  }
   COOCC_CHECK_ARG((unsigned long long)d->B * d->Xi * d->Yi * d->Zi * d->in_stride * 4ull < 0xFFFFFF00ull && (long long)d->M < (1ll << 30),
                   "conv_fwd: the split-f16 kernel addresses its input with 32-bit byte offsets (< 4 GB)");
   const bool xy = !(k.kx == 1 && k.ky == 1 && k.px == 0 && k.py == 0);
@@ -350,13 +574,16 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
 
 // fp32 rows (row stride in_stride floats, first C columns, C % 32 == 0) * scale -> H2 rows [rows][C/32][hi 32 | lo 32] (4 C bytes per row)
 __global__ __launch_bounds__(256) void k_rows_to_h2(const float* __restrict__ in, int in_stride, long long rows, int C, float scale,
-                                                     char* __restrict__ out) {
+                                                     char* __restrict__ out, const int32_t* __restrict__ row_ids,
+                                                     const int32_t* __restrict__ n_dev) {
+  if (n_dev) rows = min(rows, (long long)*n_dev);
   const int c8 = C >> 3;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * c8) return;
   const long long r = i / c8;
   const int c = (int)(i - r * c8) * 8;
-  const f32x4 a = *(const f32x4*)(in + r * in_stride + c), b = *(const f32x4*)(in + r * in_stride + c + 4);
+  const long long sr = row_ids ? (long long)row_ids[r] : r;
+  const f32x4 a = *(const f32x4*)(in + sr * in_stride + c), b = *(const f32x4*)(in + sr * in_stride + c + 4);
   f16x8 hi, lo;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -374,7 +601,20 @@ extern "C" int coocc_rows_to_h2(const float* in, int in_stride, int64_t rows, in
   COOCC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)out_h2 & 15) == 0, "rows_to_h2: pointers must be 16-byte aligned");
   if (rows == 0) return COOCC_OK;
   hipLaunchKernelGGL(k_rows_to_h2, dim3(cdiv(rows * (C / 8), 256)), dim3(256), 0, as_stream(stream), in, in_stride, (long long)rows, C,
-                     scale, (char*)out_h2);
+                     scale, (char*)out_h2, (const int32_t*)nullptr, (const int32_t*)nullptr);
+  COOCC_LAUNCH_CHECK("k_rows_to_h2");
+  return COOCC_OK;
+}
+
+// out row j = H2(in[row_ids[j]]) for j < n (n_dev != NULL: n = min(n_cap, *n_dev) read on the device): the compact operand of a
+// GEMM over a voxel list (the scatter-form half of con_enc.0)
+extern "C" int coocc_rows_to_h2_gather(const float* in, int in_stride, const int32_t* row_ids, int64_t n_cap, const int32_t* n_dev,
+                                       int C, float scale, void* out_h2, void* stream) {
+  COOCC_CHECK_ARG(in && out_h2 && row_ids && n_cap >= 0 && C > 0 && C % 32 == 0 && in_stride % 4 == 0, "rows_to_h2_gather: bad args");
+  COOCC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)out_h2 & 15) == 0, "rows_to_h2_gather: pointers must be 16-byte aligned");
+  if (n_cap == 0) return COOCC_OK;
+  hipLaunchKernelGGL(k_rows_to_h2, dim3(cdiv(n_cap * (C / 8), 256)), dim3(256), 0, as_stream(stream), in, in_stride, (long long)n_cap, C,
+                     scale, (char*)out_h2, row_ids, n_dev);
   COOCC_LAUNCH_CHECK("k_rows_to_h2");
   return COOCC_OK;
 }

@@ -553,7 +553,17 @@ class BiFuser_N(nn.Module):
         d.relu, d.res_mode, d.splitk, d.tile_hint = 0, 0, 1, core.TILE_HINT
         if count_dev is not None:
             d.M_dev, d.gather_stride = ptr(count_dev, _I32), lin_pts.numel()
-        with core.TIMER.region(core.conv_kernel_name(Np, 27 * Co, True) + " c0-sparse", 2.0 * Np * 2 * C * 27 * Co):
+        kname = core.conv_kernel_name(Np, 27 * Co, True)
+        if core.CONV_ENGINE == "h2" and core.H2_DIRECT and (2 * C) % 32 == 0:
+            # split-f16 engine: the occupied rows are gathered into a compact H2 operand [Np, 2C] (count on the device in
+            # the static form), then a plain GEMM against the [27 Cout, 2C] matrix
+            rh = core.scratch(dev, "c0rows", Np * 2 * C)
+            call("coocc_rows_to_h2_gather", src, cat4.stride, ptr(lin_pts), Np, ptr(count_dev, _I32) if count_dev is not None else None,
+                 2 * C, 1.0, ptr(rh))
+            d.in_, d.in_stride, d.w, d.gather, d.gather_stride = ptr(rh), 2 * C, ptr(ps.h2_pack()), None, 0
+            d.Xi, d.Xo = Np, Np
+            d.mfma_dtype, d.alpha, kname = 3, 1.0, "k_gemm_h2w"
+        with core.TIMER.region(kname + " c0-sparse", 2.0 * Np * 2 * C * 27 * Co):
             _lib.conv_fwd(d, dev)
         vmap = torch.empty(V, device=dev, dtype=_I32)
         if count_dev is not None:

@@ -208,10 +208,10 @@ typedef struct coocc_conv_desc {
                                 f16 halves (hi + lo * 2^-11, 22 significand bits), three v_mfma_f32_32x32x16_f16 per step, fp32
                                 accumulation -- measured error vs fp64 is half that of mfma_dtype 0.  `in` = H2 rows
                                 (coocc_rows_to_h2 / coocc_wino_input_h2), `w` = H2 pack [(Cin/32 chunk, tap)][roundup(Cout,128)/32]
-                                [2 k16 steps][hi | lo][64 lanes][8 f16]; Cin % 32 == 0; stride-1 "same" geometry, kz <= 3, geometric
-                                taps only; wgroup_rows a multiple of 128 */
+                                [2 k16 steps][hi | lo][64 lanes][8 f16]; Cin % 32 == 0; any geometry or row table (stride-1 "same"
+                                layers with <= 3 z taps share one LDS image between the z taps); wgroup_rows a multiple of 128 */
   float alpha;            /* mfma_dtype 3: the accumulators are multiplied by alpha (1 / operand scale) before the epilogue; 0 = 1 */
-  const int32_t* M_dev;   /* row-table launches (gather != NULL, splitk = 1): the number of rows read on the DEVICE (<= M; the grid
+  const int32_t* M_dev;   /* row-table launches (gather != NULL; mfma_dtype 3: any launch), splitk = 1: the number of rows read on the DEVICE (<= M; the grid
                              is sized for M = capacity and tiles past *M_dev leave at once) -- lets a captured hipGraph run over
                              voxel lists whose length is only known on the device; NULL: M rows */
   int gather_stride;      /* entries per tap of `gather` (0 = M) */
@@ -232,6 +232,9 @@ int coocc_rows_to_bf16(const float* in, int in_stride, int64_t rows, int C, void
  * Replaces nothing in the reference (its convolutions are cuDNN fp32, resnet3d.py:34-64): it is how the same fp32 sums are
  * evaluated on the 16-bit matrix pipe. */
 int coocc_rows_to_h2(const float* in, int in_stride, int64_t rows, int C, float scale, void* out_h2, void* stream);
+/* out row j = H2(in[row_ids[j]] * scale), j < n_cap (n_dev != NULL: j < min(n_cap, *n_dev), the count read on the device) */
+int coocc_rows_to_h2_gather(const float* in, int in_stride, const int32_t* row_ids, int64_t n_cap, const int32_t* n_dev,
+                            int C, float scale, void* out_h2, void* stream);
 
 /* Winograd F(m x m, 3x3), m = tile = 2 or 4, over (x,y) for 3x3x3 stride-1 pad-1 convs (z stays a direct 3-tap
  * conv): input transform, then ONE coocc_conv_fwd launch over (m+2)^2 x group_rows rows (kx=ky=1, kz=3, pz=1,

@@ -144,6 +144,37 @@ def direct():
         print(line, flush=True)
 
 
+def general():
+    """Strided 3x3x3 and 1x1x1 layers on the general h2 kernel (k_gemm_h2w) vs the fp32-MFMA kernels, error vs fp64."""
+    core.TIMER.enabled = 0
+    core.WINO, core.WINO_MIN_ROWS = 1, 8192
+    for (name, Cin, Cout, grid, k, stride) in [("enc.l1.0 s2", 128, 256, (100, 100, 8), 3, 2), ("enc.l2.0 s2", 256, 512, (50, 50, 4), 3, 2),
+                                               ("enc.l3.0 s2", 512, 1024, (25, 25, 2), 3, 2), ("lateral0 1x1", 128, 256, (100, 100, 8), 1, 1),
+                                               ("proj 1x1", 128, 128, (100, 100, 8), 1, 1), ("ds 1x1 s2", 128, 256, (100, 100, 8), 1, 2),
+                                               ("odd s2", 96, 160, (11, 9, 5), 3, 2)]:
+        g = torch.Generator().manual_seed(5)
+        X, Y, Z = grid
+        big = X * Y * Z > 20000
+        x = torch.relu(torch.randn(1, Cin, X, Y, Z, generator=g)) * torch.exp(torch.randn(1, Cin, X, Y, Z, generator=g))
+        w = torch.randn(Cout, Cin, k, k, k, generator=g) * (2.0 / (Cin * k ** 3)) ** 0.5
+        bn = bn_like(Cout, g)
+        pad = 1 if k == 3 else 0
+        ref = F.conv3d(x.double(), w.double(), padding=pad, stride=stride) if not big else F.conv3d(x.to(dev), w.to(dev), padding=pad, stride=stride).cpu().double()
+        sc, bi = core.fold_bn(bn)
+        ref = torch.relu(ref * sc.double().view(1, -1, 1, 1, 1) + bi.double().view(1, -1, 1, 1, 1))
+        rms = ref.pow(2).mean().sqrt()
+        pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=k, stride=stride, pad=pad)
+        xr = rows_of(x)
+        line = "%-13s %4d->%4d %-14s%s:" % (name, Cin, Cout, grid, " (ref: torch fp32 on the GPU)" if big else "")
+        for eng in ("f32", "h2"):
+            core.CONV_ENGINE = eng
+            out = core.conv_rows(xr, pc, relu=True)
+            e = out.as_ncdhw().cpu().double() - ref
+            t = timeit(lambda: core.conv_rows(xr, pc, relu=True))
+            line += "  %-3s rms %.2e max %.2e  %.3f ms |" % (eng, float(e.pow(2).mean().sqrt() / rms), float(e.abs().max() / rms), t)
+        print(line, flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["acc", "time"]
     with torch.no_grad():
@@ -153,3 +184,5 @@ if __name__ == "__main__":
             bench()
         if "direct" in what:
             direct()
+        if "general" in what:
+            general()
