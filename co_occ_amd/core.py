@@ -320,6 +320,12 @@ def _lcm(a, b):
     return a * b // math.gcd(a, b)
 
 
+def h2_capable(pc):
+    """The split-f16 engine takes this layer's Winograd-domain GEMM (inference packs only: the training path re-packs its
+    weights on the device every step and stays on the fp32-MFMA kernels)."""
+    return CONV_ENGINE == "h2" and pc.Cin % 32 == 0 and hasattr(pc, "wino_h2_pack")
+
+
 def wino_plan(x, pc, M, res_mode):
     """None, or (tile, points, Tx, Ty, rows, G, tile_hint) for the Winograd path of this layer."""
     if not WINO or pc._w_raw is None or M < WINO_MIN_ROWS or res_mode not in (0, 1) or pc.Cin % 4:
@@ -334,7 +340,7 @@ def wino_plan(x, pc, M, res_mode):
     g640, g128 = _lcm(640, x.Z), _lcm(128, x.Z)
     G640, G128 = -(-rows // g640) * g640, -(-rows // g128) * g128
     G, hint = (G640, 0) if G640 <= 1.05 * G128 else (G128, 128)
-    if CONV_ENGINE == "h2" and pc.Cin % 32 == 0:
+    if h2_capable(pc):
         g256 = _lcm(256, x.Z)           # 256-row tiles of the persistent split-f16 GEMM (k_gemm_h2p)
         G, hint = -(-rows // g256) * g256, 0
     pts = (tile + 2) ** 2
@@ -366,7 +372,7 @@ def conv_rows_wino(x, pc, out, relu, res, plan, in_ranges=None):
     tile, pts, Tx, Ty, rows, G, hint = plan
     V = _wino_buffer(dev, "V", pts * G * pc.Cin)
     Mb = _wino_buffer(dev, "M", pts * G * pc.Cout)
-    h2 = CONV_ENGINE == "h2" and pc.Cin % 32 == 0 and all(c % 32 == 0 for _, c in (in_ranges or []))
+    h2 = h2_capable(pc) and all(c % 32 == 0 for _, c in (in_ranges or []))
     wp = pc.wino_h2_pack(tile) if h2 else pc.wino_pack(tile)
     vscale = H2_WINO_SCALE[tile]
     with TIMER.region("k_wino_in", 4.0 * x.V * pc.Cin + 4.0 * pts * rows * pc.Cin):
@@ -465,7 +471,7 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
             d.taps = taps = 9 * (hi - lo + 1)
     same = pc.stride == 1 and (Xo, Yo, Zo) == (x.X, x.Y, x.Z)
     if (not bf16 and CONV_ENGINE == "h2" and H2_DIRECT and pc.Cin % 32 == 0 and pc._w_taps is not None
-            and rm in (0, 1) and x.B * x.V * pc.Cin * 4 < (1 << 32) - 256 and 2.0 * M * pc.Cin * pc.Cout * taps >= H2_DIRECT_MIN_FLOPS):
+            and rm in (0, 1) and 2.0 * M * pc.Cin * pc.Cout * taps >= H2_DIRECT_MIN_FLOPS):
         # fp32-accurate split-f16 GEMM (csrc/gemm_h2.hip) for the layers the Winograd path leaves out (small grids, strided,
         # 1x1x1): the input rows are split into H2 rows once per layer, stride-1 "same" layers share one LDS image per 3 z taps
         # (k_gemm_h2z), the rest fetch one image per (chunk, tap) (k_gemm_h2w); the epilogue (folded BN, residual, ReLU) is the usual one

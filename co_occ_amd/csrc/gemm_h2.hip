@@ -57,6 +57,7 @@ __device__ __forceinline__ void split_h2(float v, _Float16& hi, _Float16& lo) {
 // spills -> scratch reloads that wait vmcnt(0), i.e. for the weight loads just issued).  Two workgroups per CU (<= 256 registers)
 // cover each other's barriers, prologues and epilogues.
 #define H2_FENCE() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ const char* inb_(const ConvK& p) { return (const char*)p.in; }
 template <int KZ, bool XY>
 __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
   constexpr int BM = 128, TM = 4;
@@ -88,12 +89,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
   const int kx = p.kx, ky = p.ky, px = p.px, py = p.py, Xi = p.Xi, Yi = p.Yi, Zi = p.Zi;
   const unsigned rowbytes = (unsigned)p.in_stride * 4;
   const int total_rows = Xi * Yi * Zi * (p.M / (p.Xo * p.Yo * p.Zo));
-  const char* inb = (const char*)p.in;
   const char* zrow = (const char*)p.zrow;
-  // staging: LDS row r holds input row  m0 + r - pz + ((dx - px) Yi + (dy - py)) Zi  (any row of the buffer, else zeros);
-  // 32-bit byte offsets (the launcher checks that the input is smaller than 4 GB).  The swizzle term of a row does not depend
-  // on the instruction: ((r >> 1) & 7) with r = (4 j + wave) 8 + srow  is  (4 (wave & 1) + (srow >> 1)) & 7
+  // staging: LDS row r holds input row  m0 + r - pz + ((dx - px) Yi + (dy - py)) Zi  (any row of the buffer, else zeros).
+  // Addresses are a 64-bit tile base (the lowest row any tap of this tile can touch) + 32-bit offsets inside the tile's window
+  // (a few thousand rows), so inputs past 4 GB work (the Winograd V of a 200x200x16x512 volume is 5.2 GB).  The swizzle term of a
+  // row does not depend on the instruction: ((r >> 1) & 7) with r = (4 j + wave) 8 + srow  is  (4 (wave & 1) + (srow >> 1)) & 7
   const int arow0 = m0 + srow - p.pz;
+  const int minoff = XY ? -(px * Yi + py) * Zi : 0;
+  const char* tbase = inb_(p) + (long long)(m0 - p.pz + minoff) * (long long)rowbytes;
   const unsigned aq = (unsigned)((slot ^ ((4 * (wave & 1) + (srow >> 1)) & 7)) * 16);
   // the output voxels this lane's A fragments belong to (fragment i: row i*32 + li); zbits: bit (i*3 + dz) = z tap dz in range
   int vx[TM], vy[TM];
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
       if (j == 4 && wave != 0) break;
       const int r8 = j < 4 ? (j * 4 + wave) * 8 : 128;
       const int L = arow0 + r8 + off;
-      const char* src = (unsigned)L < (unsigned)total_rows ? inb + ((unsigned)L * rowbytes + coff) : zrow;
+      const char* src = (unsigned)L < (unsigned)total_rows ? tbase + ((unsigned)(srow + r8 + off - minoff) * rowbytes + coff) : zrow;
       glds16_(src, &As[buf * STAGE + r8 * 128]);
     }
     if (XY) { if (++gh == ky) { gh = 0; if (++gd == kx) { gd = 0; ++gkc; } } }
@@ -556,8 +559,8 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
     COOCC_LAUNCH_CHECK("k_gemm_h2w");
     return COOCC_OK;
   }
-  COOCC_CHECK_ARG((unsigned long long)d->B * d->Xi * d->Yi * d->Zi * d->in_stride * 4ull < 0xFFFFFF00ull && (long long)d->M < (1ll << 30),
-                  "conv_fwd: the split-f16 kernel addresses its input with 32-bit byte offsets (< 4 GB)");
+  COOCC_CHECK_ARG((long long)d->M < (1ll << 30) && (136ull + 2ull * ((unsigned long long)k.Yi + 2) * k.Zi) * d->in_stride * 4ull < 0xFFFFFF00ull,
+                  "conv_fwd: the split-f16 kernel addresses a tile's window with 32-bit byte offsets");
   const bool xy = !(k.kx == 1 && k.ky == 1 && k.px == 0 && k.py == 0);
   if (!xy) {
     if (k.kz == 3) hipLaunchKernelGGL((k_gemm_h2z<3, false>), grid, dim3(256), 0, s, k);

@@ -36,9 +36,20 @@ def _check_contract(d, steps, warmup):
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 0.05 * d["value"]
 
 
-def test_default_line_has_the_contract_fields_and_reports_its_stream_probe():
-    """The driver's command: the number of samples in flight is chosen from untimed bursts and reported."""
-    d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"])
+def test_default_line_is_the_graph_pipeline_with_the_contract_fields():
+    """The driver's command: the dense stage of every sample is one hipGraph launch; the line says so and carries the roofline
+    objects (per-kernel HIP events from the eager pass after the timed region)."""
+    d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "12", "--warmup", "2", "--no-cpu-baseline"])
+    _check_contract(d, 12, 2)
+    g = d["graph"]
+    assert g["slots"] == d["config"]["samples_in_flight"] == 6 and g["eager_fallbacks"] == 0 and g["dense_stage_ms"] > 0
+    assert "hipGraph" in d["config"]["pipeline"] and d["config"]["conv_engine"] == "h2" and "stream_probe" not in d
+    assert "measured" in d["roofline"] and isinstance(d["env_knobs"], dict)
+
+
+def test_eager_line_reports_its_stream_probe():
+    """--graph 0: every launch issued from Python; the number of samples in flight is chosen from untimed bursts and reported."""
+    d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--graph", "0"])
     _check_contract(d, 8, 2)
     p = d["stream_probe"]
     assert p["chosen"] == d["config"]["samples_in_flight"] and p["chosen"] in (1, 2)
@@ -48,22 +59,23 @@ def test_default_line_has_the_contract_fields_and_reports_its_stream_probe():
 
 
 def test_two_streams_line_carries_the_alone_figures():
-    d = _run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--streams", "2", "--no-cpu-baseline"])
+    d = _run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--streams", "2", "--no-cpu-baseline", "--graph", "0"])
     _check_contract(d, 6, 2)
     assert d["config"]["samples_in_flight"] == 2 and "stream_probe" not in d
     assert 0 < d["roofline"]["frac_alone"] < 1 and "roofline_isolated" in d
 
 
-def test_two_ranks_two_streams_each_on_one_gpu():
+@pytest.mark.parametrize("graph", [0, 1])
+def test_two_ranks_two_streams_each_on_one_gpu(graph):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
               "--master-port", str(port), "bench.py", "--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "6",
-              "--warmup", "2", "--streams", "2", "--no-cpu-baseline", "--no-kernel-timing"])
+              "--warmup", "2", "--streams", "2", "--slots", "4", "--graph", str(graph), "--no-cpu-baseline", "--no-kernel-timing"])
     assert d["n_gpus"] == 2 and d["world_size_seen_by_backend"] == 2 and d["backend"] == "gloo"
-    assert d["config"]["samples_in_flight"] == 2
+    assert d["config"]["samples_in_flight"] == (4 if graph else 2)
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 0.05 * d["value"]      # whole-job rate: both ranks' samples
 
 
@@ -105,4 +117,30 @@ def test_two_stream_pipeline_outputs_equal_sequential_calls():
         for k, v in g.items():
             assert torch.equal(v, ref[i % 2][k]), (i, k)
     # the two samples really differ (the comparison above is not vacuous)
+    assert not torch.equal(ref[0]["pred_c"], ref[1]["pred_c"])
+
+
+def test_graph_pipeline_outputs_equal_sequential_calls():
+    """The default serving loop (bench.GraphPipeline: native search driver on prefetch streams, the dense stage of every sample one
+    hipGraph launch on one of several dense streams) produces bit for bit the outputs of plain sequential eager calls."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    model, _ = bench.build_model("r50", dev)
+    samples = [bench.make_inputs("r50", 177 + i, dev, model) for i in range(4)]
+    keys = ("pred_c", "pred_f", "rgbs", "depths")
+    with torch.no_grad():
+        ref = [{k: bench.step(model, s, 1)[k].clone() for k in keys} for s in samples]
+    torch.cuda.synchronize()
+    gp = bench.GraphPipeline(model, samples, dev, world=1, ndense=2)
+    got = {}
+    gp.run(6)
+    gp.run(11, collect=lambda i, out: got.__setitem__(i, {k: out[k].clone() for k in keys}))
+    torch.cuda.synchronize()
+    assert sorted(got) == list(range(11)) and gp.fallbacks == 0
+    for i, g in got.items():
+        for k, v in g.items():
+            assert torch.equal(v, ref[i % 4][k]), (i, k)
     assert not torch.equal(ref[0]["pred_c"], ref[1]["pred_c"])
