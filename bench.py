@@ -45,7 +45,7 @@ from co_occ_amd import _lib, core  # noqa: E402
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, fp32-input MFMA (spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA (spec; 2:1-sparse figures are not used)
 HBM_PEAK_GBS = 8000.0          # HBM3E spec
-TRAFFIC_FILE = "r2_traffic.json"
+TRAFFIC_FILE = "r3_traffic.json"
 
 
 def make_inputs(cfgname, seed, dev, model):
@@ -309,17 +309,22 @@ def rooflines(ksum, nsteps, args, rank, table):
         # (k_conv2<BM,PF,0,true>); keep their direct-convolution-equivalent flops alongside the executed ones
         convs = {}
         for k, v in ksum.items():
-            if not k.startswith("k_conv"):
+            if not (k.startswith("k_conv") or k.startswith("k_gemm")):
                 continue
             sym = k.split(" wino")[0] + (",wg> wino" if " wino" in k else "")
             sym = sym.replace(">,wg>", ",wg>").replace("k_conv2p,wg>", "k_conv2p")
+            if k.startswith("k_gemm_h2"):
+                sym = k.split()[0] + (" wino" if " wino" in k else (" direct" if "direct" in k else ""))
             c_ = convs.setdefault(sym, dict(launches=0, ms=0.0, work=0.0, equiv=0.0))
             c_["launches"] += v["launches"]; c_["ms"] += v["ms"]; c_["work"] += v["work"]
             c_["equiv"] += v["work"] * {"wino2": 2.25, "wino4": 4.0}.get(k.split()[-1], 1.0)
         dom = max(convs, key=lambda k: convs[k]["ms"]) if convs else None
         if dom:
             v = convs[dom]
-            ach = v["work"] / (v["ms"] * 1e-3) / 1e12      # flops the matrix cores execute (Winograd-domain for "wino")
+            h2 = dom.startswith("k_gemm_h2")
+            # flops the matrix cores execute: Winograd-domain for "wino"; the split-f16 engine issues THREE f16 MFMAs per
+            # fp32-accurate product (hi*hi, hi*lo, lo*hi), all of which count against the f16 peak
+            ach = v["work"] / (v["ms"] * 1e-3) / 1e12 * (3.0 if h2 else 1.0)
             traffic = None
             try:   # HBM bytes per launch from the committed PMC passes (cannot be collected inside this process)
                 tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
@@ -329,8 +334,9 @@ def rooflines(ksum, nsteps, args, rank, table):
             # direct-convolution-equivalent rate of the same launches: F(m x m,3x3) needs 9 m^2/(m+2)^2 x fewer multiplies
             equiv = v["equiv"] / v["work"]
             symbol = {"k_conv2<160,wg> wino": "k_conv2<160, 2, true, 2, false>", "k_conv2p wino": "k_conv2p<true, false>",
-                      "k_conv2<128,wg> wino": "k_conv2<128, 1, true, 3, false>"}.get(dom, dom)     # name in the rocprofv3 trace
-            peak = MFMA_BF16_PEAK_TFLOPS if dom.startswith("k_conv_bf16") else MFMA_F32_PEAK_TFLOPS
+                      "k_conv2<128,wg> wino": "k_conv2<128, 1, true, 3, false>", "k_gemm_h2z wino": "k_gemm_h2z<3, false>",
+                      "k_gemm_h2z direct": "k_gemm_h2z<*, true>", "k_gemm_h2w": "k_gemm_h2w<false>"}.get(dom, dom)     # name in the rocprofv3 trace
+            peak = MFMA_BF16_PEAK_TFLOPS if (dom.startswith("k_conv_bf16") or h2) else MFMA_F32_PEAK_TFLOPS
             roof = dict(bound="mfma", kernel=dom, symbol=symbol, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
                         frac=round(ach / peak, 4), traffic=traffic,
                         traffic_source=("profiles/%s (rocprofv3 --pmc passes of this command, replayed: HBM counters cannot be "
@@ -338,15 +344,22 @@ def rooflines(ksum, nsteps, args, rank, table):
                         launches=v["launches"],
                         avg_launch_ms=round(v["ms"] / v["launches"], 4),
                         share_of_timed_kernels=round(v["ms"] / tot, 3),
-                        flops="executed on the MFMA pipe (direct-conv-equivalent x%.2f = %.1f TFLOP/s)" % (equiv, ach * equiv))
-            for tag, sel, pk in (("roofline_all_convs", lambda k: not k.startswith("k_conv_bf16"), MFMA_F32_PEAK_TFLOPS),
-                                 ("roofline_bf16_convs", lambda k: k.startswith("k_conv_bf16"), MFMA_BF16_PEAK_TFLOPS)):
+                        flops=("executed on the f16 MFMA pipe: 3 v_mfma_f32_32x32x16_f16 per fp32-accurate product (hi*hi, hi*lo, lo*hi), "
+                               "peak = dense f16; fp32-equivalent %.1f TFLOP/s = %.2f x the fp32-MFMA peak of %.1f; "
+                               "direct-conv-equivalent x%.2f = %.1f TFLOP/s" % (ach / 3, ach / 3 / MFMA_F32_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS,
+                                                                                 equiv, ach / 3 * equiv)) if h2 else
+                              "executed on the MFMA pipe (direct-conv-equivalent x%.2f = %.1f TFLOP/s)" % (equiv, ach * equiv))
+            for tag, sel, pk, mul, label in (
+                    ("roofline_all_convs", lambda k: k.startswith("k_conv") and not k.startswith("k_conv_bf16"), MFMA_F32_PEAK_TFLOPS, 1.0,
+                     "every fp32-MFMA k_conv* launch"),
+                    ("roofline_bf16_convs", lambda k: k.startswith("k_conv_bf16"), MFMA_BF16_PEAK_TFLOPS, 1.0, "every k_conv_bf16 launch"),
+                    ("roofline_h2_gemms", lambda k: k.startswith("k_gemm_h2"), MFMA_BF16_PEAK_TFLOPS, 3.0,
+                     "every split-f16 k_gemm_h2* launch (3 f16 MFMAs per product counted)")):
                 grp = [v2 for k2, v2 in convs.items() if sel(k2)]
                 if not grp:
                     continue
-                allc = sum(v2["work"] for v2 in grp) / (sum(v2["ms"] for v2 in grp) * 1e-3) / 1e12
-                extra[tag] = dict(bound="mfma", kernel="every fp32-MFMA k_conv* launch" if pk == MFMA_F32_PEAK_TFLOPS else "every k_conv_bf16 launch",
-                                  achieved=round(allc, 2), peak=pk, unit="TFLOP/s", frac=round(allc / pk, 4),
+                allc = mul * sum(v2["work"] for v2 in grp) / (sum(v2["ms"] for v2 in grp) * 1e-3) / 1e12
+                extra[tag] = dict(bound="mfma", kernel=label, achieved=round(allc, 2), peak=pk, unit="TFLOP/s", frac=round(allc / pk, 4),
                                   ms_per_step=round(sum(v2["ms"] for v2 in grp) / nsteps, 3))
         if "k_lift_splat" in ksum:
             v = ksum["k_lift_splat"]
@@ -781,7 +794,7 @@ def main():
         # sample in flight (the next sample's pooling + search still prefetched) gives each kernel's own rate next to it.
         n_iso = max(8, min(20, args.steps // 2))
         run(3, False, S=1)
-        core.TIMER.enabled, core.TIMER.only = 1, ("k_conv", "k_render_nearest", "k_lift_splat")
+        core.TIMER.enabled, core.TIMER.only = 1, ("k_conv", "k_gemm", "k_render_nearest", "k_lift_splat")
         core.TIMER.reset()
         run(n_iso, False, S=1)
         torch.cuda.synchronize()
