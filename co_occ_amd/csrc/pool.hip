@@ -273,21 +273,31 @@ __global__ __launch_bounds__(1024) void k_scan_local(const int32_t* __restrict__
   if (tid == 1023) tops[blockIdx.x] = off + c;
 }
 
+// exclusive scan of the per-block totals: one workgroup walks them 1024 at a time with a running carry (grids past 2^20
+// voxels have more than 1024 blocks: B = 2 at 200x200x16, OpenOccupancy-size batches)
 __global__ __launch_bounds__(1024) void k_scan_tops(int32_t* __restrict__ tops, int nblk) {
   __shared__ int wsum[16];
+  __shared__ int carry_s;
   const int tid = threadIdx.x;
-  const int c = tid < nblk ? tops[tid] : 0;
-  int inc = c;
-  for (int o = 1; o < 64; o <<= 1) {
-    int n = __shfl_up(inc, o);
-    if ((tid & 63) >= o) inc += n;
+  int carry = 0;
+  for (int base = 0; base < nblk; base += 1024) {
+    const int i = base + tid;
+    const int c = i < nblk ? tops[i] : 0;
+    int inc = c;
+    for (int o = 1; o < 64; o <<= 1) {
+      int n = __shfl_up(inc, o);
+      if ((tid & 63) >= o) inc += n;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    int off = carry + inc - c;
+    for (int w = 0; w < (tid >> 6); ++w) off += wsum[w];
+    if (i < nblk) tops[i] = off;
+    if (tid == 1023) carry_s = off + c;
+    __syncthreads();
+    carry = carry_s;
   }
-  if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-  __syncthreads();
-  int off = inc - c;
-  for (int w = 0; w < (tid >> 6); ++w) off += wsum[w];
-  if (tid < nblk) tops[tid] = off;
-  if (tid == nblk - 1) tops[nblk] = off + c;      // grand total
+  if (tid == 0) tops[nblk] = carry;      // grand total
 }
 
 __global__ __launch_bounds__(1024) void k_scan_finish(const int32_t* __restrict__ count, int nvox, int nblk,
@@ -539,10 +549,11 @@ __global__ __launch_bounds__(256) void k_pool_sum_csr(const float* __restrict__ 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // workspace: keys[npts] | ids[npts] | slot[npts] | count[nvox+1] | nlong[64] (one memset clears these two) | start[nvox+1] |
-// long_list[nvox] | tops[1025]
+// long_list[nvox] | tops[nvox / 1024 + 2]
 extern "C" size_t coocc_voxel_pool_ws(int npts, int nvox) {
   if (npts <= 0 || nvox <= 0) return 0;
-  return 3 * align256(sizeof(uint32_t) * (size_t)npts) + 3 * align256(sizeof(int32_t) * ((size_t)nvox + 1)) + 256 + 8192 + 256;
+  return 3 * align256(sizeof(uint32_t) * (size_t)npts) + 3 * align256(sizeof(int32_t) * ((size_t)nvox + 1)) + 256 +
+         align256(sizeof(int32_t) * ((size_t)nvox / 1024 + 2)) + 8192 + 256;
 }
 
 struct PoolWs { uint32_t *keys, *ids; int32_t *slot, *count, *nlong, *start, *long_list, *tops; size_t zero_bytes; };
@@ -550,7 +561,6 @@ struct PoolWs { uint32_t *keys, *ids; int32_t *slot, *count, *nlong, *start, *lo
 static int carve(void* ws, size_t ws_bytes, int npts, int nvox, PoolWs* p) {
   size_t need = coocc_voxel_pool_ws(npts, nvox);
   if (!ws || ws_bytes < need) return coocc_set_error(COOCC_ENOMEM, "voxel_pool: workspace %zu < %zu bytes", ws_bytes, need);
-  if (nvox > 1024 * 1024) return coocc_set_error(COOCC_EINVAL, "voxel_pool: more than 2^20 voxels");
   char* c = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   size_t a = align256(sizeof(uint32_t) * (size_t)npts), v = align256(sizeof(int32_t) * ((size_t)nvox + 1));
   p->keys = (uint32_t*)c; c += a; p->ids = (uint32_t*)c; c += a; p->slot = (int32_t*)c; c += a;

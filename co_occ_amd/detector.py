@@ -74,6 +74,12 @@ class COOCC_Ray(nn.Module):
         if pts_middle_encoder:
             if pts_middle_encoder.get("type") in lidar.MIDDLE_ENCODERS:
                 self.pts_middle_encoder = lidar.MIDDLE_ENCODERS.build(pts_middle_encoder)
+                # FROZEN LiDAR branch: the sparse encoder has an eval-mode path only (folded BN1d, no autograd), so it
+                # stays in eval mode under model.train() (``train`` below) and its parameters take no gradient -- DDP with
+                # find_unused_parameters=False then does not wait for them.  The reference trains this encoder
+                # (sparse_lidar_enc.py:125-176); INTEGRATION.md section 6 says what that means for fine-tuning.
+                for prm in self.pts_middle_encoder.parameters():
+                    prm.requires_grad_(False)
             elif not external_encoders:
                 raise NotImplementedError("COOCC_Ray: pts_middle_encoder type %r is not on the MI355X path (SparseLiDAREnc8x / "
                                           "SparseLiDAREnc4x are); pass external_encoders=True to attach it yourself"
@@ -154,6 +160,20 @@ class COOCC_Ray(nn.Module):
         voxel_feats = self.fuse(img_voxel_feats, pts_voxel_feats, search)
         return voxel_feats, img_feats, pts_feats, depth, geom, img_voxel_feats
 
+    def train(self, mode=True):
+        """``nn.Module.train`` for everything but the frozen sparse LiDAR encoder, which keeps its eval-mode path (an
+        unchanged tools/train.py calls ``model.train()`` on the whole detector)."""
+        super().train(mode)
+        enc = getattr(self, "pts_middle_encoder", None)
+        if mode and enc is not None and isinstance(enc, tuple(lidar.MIDDLE_ENCODERS.module_dict.values())):
+            enc.eval()
+            if not getattr(self, "_warned_frozen_lidar", False):
+                self._warned_frozen_lidar = True
+                import warnings
+                warnings.warn("COOCC_Ray: the sparse LiDAR encoder (pts_middle_encoder) is frozen on this path: eval-mode "
+                              "statistics, no gradients (co_occ_amd/lidar.py); the rest of the detector trains")
+        return self
+
     def fuse(self, img_voxel_feats, pts_voxel_feats, search=None):
         """coocc_ray.py:252-256."""
         if self.occ_fuser is not None:
@@ -212,9 +232,9 @@ class COOCC_Ray(nn.Module):
         Returns rows / tensors with ``grad_fn``: ``voxel_rows`` [V,C] (con_enc output), ``levels`` [(rows, geom)],
         ``out_voxel_rows`` [V,128], ``logit_rows`` [V,ncls], ``fine_logits`` [8n,ncls] + ``fine_xyz`` [3,8n], ``rgbs`` /
         ``depths`` of the render block.  ``coarse_lin``: int32 rows of the coarse voxels whose children the fine branch
-        evaluates; default: the foreground voxels (argmax != empty), randomly thinned to ``fine_topk // ratio^3`` of them
-        (the reference draws its training-time top-k among fine points, occ_head.py:204-205; here whole coarse voxels are
-        drawn)."""
+        evaluates; default: ``OccHead.draw_fine_voxels`` -- the foreground voxels (argmax != empty), randomly thinned to
+        ``fine_topk`` whole coarse voxels when there are more, as the reference does (coordinate_transform.py:17-21 permutes the
+        COARSE columns and keeps the first ``topk``, each with all of its ratio^3 children)."""
         from . import autograd as ag
         one = img_voxel_feats if img_voxel_feats is not None else pts_voxel_feats
         B, C, X, Y, Z = one.shape

@@ -176,6 +176,23 @@ def _as_rows_view(x):
     return Rows(base, B, X, Y, Z, C, coff)
 
 
+_concat_buffers = {}          # data_ptr -> weak reference of the storage's owner tensor
+
+
+def _register_concat(t):
+    import weakref
+    for k in [k for k, r in _concat_buffers.items() if r() is None]:
+        del _concat_buffers[k]
+    _concat_buffers[t.data_ptr()] = weakref.ref(t)
+
+
+def _is_concat(t):
+    """``t`` shares its memory with a live buffer that ``concat_buffer`` handed out (views keep the base tensor alive)."""
+    r = _concat_buffers.get(t.data_ptr())
+    base = r() if r is not None else None
+    return base is not None and base.data_ptr() == t.data_ptr() and base.numel() == t.numel()
+
+
 class SearchSlot:
     """Static buffers of one sample in flight (serving loop over captured hipGraphs, ``co_occ_amd.graph``): everything the
     dense stage reads from the search stage lives at fixed addresses with capacity-sized shapes -- the concat rows
@@ -187,6 +204,7 @@ class SearchSlot:
         V = X * Y * Z
         self.grid, self.C, self.V = (X, Y, Z), C, V
         self.cat4 = torch.empty(V, 4 * C, device=device, dtype=_F32)
+        _register_concat(self.cat4)
         self.lin = torch.zeros(2, V, device=device, dtype=_I32)
         self.counts = torch.zeros(2, device=device, dtype=_I32)
         self.rows = torch.zeros(knum, V, device=device, dtype=_I32)
@@ -301,9 +319,12 @@ class BiFuser_N(nn.Module):
 
     def concat_buffer(self, B, X, Y, Z, device):
         """A fresh [B*X*Y*Z, 4C] concat buffer and the Rows of its slot 0: a producer that writes the camera volume there
-        (``ViewTransformerLiftSplatShootVoxel.lift_splat(out=...)``) saves the prologue its copy."""
+        (``ViewTransformerLiftSplatShootVoxel.lift_splat(out=...)``) saves the prologue its copy.  Only buffers handed out
+        here (or owned by a ``SearchSlot``) are completed IN PLACE by ``search``: any other channels-last tensor -- e.g.
+        ``feats[:, :C]`` of a wider buffer the caller still uses -- is copied into a fresh concat buffer."""
         C = self.in_channels
         cat4 = torch.empty(B * X * Y * Z, 4 * C, device=device, dtype=_F32)
+        _register_concat(cat4)
         return Rows(cat4, B, X, Y, Z, C, 0)
 
     # ---------------------------------------------------------------- forward
@@ -333,7 +354,8 @@ class BiFuser_N(nn.Module):
         else:
             # a producer handed over channels-last rows (fused lift-splat, sparse LiDAR encoder): no NCDHW round trip; rows
             # that already sit in slot 0 of a [V,4C] concat buffer (lift_splat(out=BiFuser_N.concat_buffer(...))) stay there
-            in_place = img_r is not None and img_r.t.shape[1] == 4 * C and img_r.coff == 0 and img_r.t.is_contiguous()
+            in_place = (img_r is not None and img_r.t.shape[1] == 4 * C and img_r.coff == 0 and img_r.t.is_contiguous()
+                        and (_is_concat(img_r.t) or (slot is not None and img_r.t.data_ptr() == slot.cat4.data_ptr())))
             if slot is not None:
                 assert in_place and img_r.t.data_ptr() == slot.cat4.data_ptr() and B == 1, \
                     "search(slot=...): the camera rows must already sit in slot 0 of the slot's concat buffer"

@@ -41,7 +41,12 @@ class DenseGraph:
     def _run(self):
         m, s = self.model, self.inputs
         vf = m.occ_fuser.forward_static(self.slot)
-        return m.decode(vf, s.get("gemo"), s["img_feats"], s["transform"], self.render, static=True)
+        gemo = s.get("gemo")
+        if self.render and s.get("cams") is not None:
+            # P1 per sample (ViewTransformerLSSBEVDepth.py:117-150 via coocc_ray.py:186): the frustum geometry the render
+            # block samples is recomputed from the camera matrices inside the stage, not read from a pre-baked tensor
+            gemo = m.img_view_transformer.get_geometry(*s["cams"])
+        return m.decode(vf, gemo, s["img_feats"], s["transform"], self.render, static=True)
 
     def capture(self, warmup=2):
         """Eager warm-up on the capture stream (weight packs, per-stream scratch), then the capture itself."""

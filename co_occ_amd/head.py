@@ -341,7 +341,7 @@ class OccHead(nn.Module):
         """occ_head.py:265-293: labels majority-pooled to the logits' grid, then the four terms (class-weighted CE)."""
         from .losses import pool_labels
         B, C, H, W, D = output_voxels.shape
-        target = pool_labels(target_voxels, H, W, D, self.empty_idx)
+        target = pool_labels(target_voxels, H, W, D, self.empty_idx, num_cls=self.out_channel)
         return self._loss_terms(output_voxels, target, tag, self.class_weights.to(output_voxels))
 
     def loss_point(self, fine_coord, fine_output, target_voxels, tag):

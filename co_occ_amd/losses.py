@@ -104,7 +104,7 @@ def lovasz_softmax(probas, labels, ignore=None):
     return (errors_sorted * jac).sum(0).mean()
 
 
-def pool_labels(target_voxels, H, W, D, empty_idx=0):
+def pool_labels(target_voxels, H, W, D, empty_idx=0, num_cls=17):
     """Label volume [B,rH,rW,rD] -> [B,H,W,D] by the majority vote of ``loss_voxel`` (occ_head.py:269-281): a cell whose
     children are all empty stays empty; otherwise the most frequent NON-empty label wins (smallest label on ties); when no
     non-empty label occurs twice the upstream trick (empty children get unique negative ids, torch.mode returns the
@@ -114,12 +114,15 @@ def pool_labels(target_voxels, H, W, D, empty_idx=0):
     if ratio == 1:
         return target_voxels.long()
     t = target_voxels.reshape(B, H, ratio, W, ratio, D, ratio).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, H, W, D, ratio ** 3).long()
-    nlab = 256
+    # labels are 0 .. num_cls-1 and 255 (ignore): 255 takes the extra bin num_cls, which keeps it the LARGEST label in the
+    # "smallest label on ties" order (a [.., 256] histogram was 82 MB per step at 100x100x8)
+    nlab = num_cls + 1
     counts = torch.zeros(B, H, W, D, nlab, dtype=torch.int32, device=t.device)
-    counts.scatter_add_(-1, t.clamp(0, nlab - 1), torch.ones_like(t, dtype=torch.int32))
+    counts.scatter_add_(-1, torch.where(t == 255, torch.full_like(t, num_cls), t.clamp(0, num_cls - 1)), torch.ones_like(t, dtype=torch.int32))
     n_empty = counts[..., empty_idx].clone()
     all_empty = t.sum(-1) == empty_idx
     counts[..., empty_idx] = 0
     m, arg = counts.max(-1)                                   # first (= smallest label) maximum
+    arg = torch.where(arg == num_cls, torch.full_like(arg, 255), arg)
     out = torch.where((m == 1) & (n_empty > 0), torch.full_like(arg, 255), arg)
     return torch.where(all_empty, torch.full_like(arg, empty_idx), out).long()

@@ -102,11 +102,41 @@ def bev_pool_rows(feats, coords, B, D, H, W):
     return out
 
 
+class _BevPoolFn(torch.autograd.Function):
+    """QuickCumsumCuda (M/ops/bev_pool/bev_pool.py:37-80): forward = per-voxel sums, backward = every point receives the
+    gradient row of its voxel (bev_pool_cuda.cu:61-84) -- here a row gather by the linear voxel id (``coocc_gather_rows``), no
+    sort and no interval bookkeeping to save."""
+
+    @staticmethod
+    def forward(ctx, feats, coords, B, D, H, W):
+        rows = bev_pool_rows(feats, coords, B, D, H, W)
+        c = coords.long()
+        lin = (((c[:, 3] * H + c[:, 0]) * W + c[:, 1]) * D + c[:, 2]).to(torch.int32).contiguous()
+        ctx.save_for_backward(lin)
+        ctx.dims = (B, D, H, W)
+        ctx.mark_non_differentiable(lin)
+        return rows.view(B, H, W, D, -1).permute(0, 4, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (lin,) = ctx.saved_tensors
+        B, D, H, W = ctx.dims
+        C = dout.shape[1]
+        drows = dout.permute(0, 3, 4, 2, 1).reshape(B * H * W * D, C).float().contiguous()     # (b, x, y, z) rows
+        n = lin.numel()
+        dfeats = torch.empty(n, C, device=dout.device, dtype=_F32)
+        if n:
+            call("coocc_gather_rows", ptr(drows), C, ptr(lin, torch.int32), n, C, ptr(dfeats), C)
+        return dfeats, None, None, None, None, None
+
+
 def bev_pool(feats, coords, B, D, H, W):
     """``bev_pool(feats[n,c], coords[n,4] (x,y,z,b), B, D, H, W) -> [B,c,D,H,W]``
-    (M/ops/bev_pool/bev_pool.py:83-97).  No argsort: stable radix sort on the voxel key, each
-    voxel sums its rows in ascending row index.  Forward only (backward is SURVEY 8f)."""
+    (M/ops/bev_pool/bev_pool.py:83-97), differentiable in ``feats`` like the reference's autograd Function (:37-80).
+    No argsort: sort-free CSR binning on the voxel key (csrc/pool.hip), each voxel sums its rows in ascending row index."""
     assert feats.shape[0] == coords.shape[0]
     B, D, H, W = int(B), int(D), int(H), int(W)
+    if feats.requires_grad and torch.is_grad_enabled():
+        return _BevPoolFn.apply(feats, coords, B, D, H, W)
     rows = bev_pool_rows(feats, coords, B, D, H, W)            # [(b,x,y,z), c]
     return rows.view(B, H, W, D, -1).permute(0, 4, 3, 1, 2)   # [B,c,D,H,W] view

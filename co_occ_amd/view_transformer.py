@@ -220,7 +220,9 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
                 call("coocc_lift_splat_cams", ptr(dp), ptr(feat), ptr(mats), ptr(xs), ptr(ys), ptr(ds), BN, D, H, W, C,
                      npts // B, lo, B, X, Y, Z, out_ptr, out_stride, ptr(ws), ws.numel())
         if out is not None:
-            return out.as_ncdhw()
+            v = out.as_ncdhw()
+            v._coocc_keep = out.t            # the buffer object BiFuser_N.concat_buffer registered stays alive with the view
+            return v
         return out_t.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
 
     def forward(self, input):

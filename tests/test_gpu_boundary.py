@@ -164,8 +164,10 @@ def test_forward_train_with_the_reference_call_signature(dev):
     dict (coocc_ray.py:339-434); training-mode BN (batch statistics, running stats updated); gradients reach every
     hot-path parameter and flow back into the upstream encoders."""
     model = _full_model(dev)
-    model.train()
-    model.pts_middle_encoder.eval()          # the sparse LiDAR encoder has an eval-mode path only (refuses train mode)
+    with pytest.warns(UserWarning, match="frozen"):
+        model.train()                        # what an unchanged tools/train.py does: the frozen LiDAR encoder stays in eval mode
+    assert not model.pts_middle_encoder.training and model.semantic_encoder.training
+    assert all(not prm.requires_grad for prm in model.pts_middle_encoder.parameters())
     img_inputs, points, gt = _sample(dev)
     rm0 = model.semantic_encoder.layers[0][0].bn1.running_mean.clone()
     losses = model(return_loss=True, points=points, img_metas=None, img_inputs=img_inputs, gt_occ=gt,

@@ -158,6 +158,13 @@ def test_bev_pool_op_and_ext_vs_oracle(dev):
     gout = torch.from_numpy(rng.standard_normal((B, Z, X, Y, C)).astype(np.float32))
     xg = pkg.ops.bev_pool_ext.bev_pool_backward(gout.to(dev), c2.int().to(dev), lengths.to(dev), starts.to(dev), B, Z, X, Y)
     assert torch.equal(xg.cpu(), gout[c2[:, 3], c2[:, 2], c2[:, 0], c2[:, 1]])
+    # the op itself is differentiable in feats, like the reference's autograd Function (bev_pool.py:37-80)
+    fg = feats.to(dev).requires_grad_(True)
+    out = pkg.bev_pool(fg, coords.to(dev), B, Z, X, Y)
+    assert out.requires_grad and torch.equal(out.detach().cpu(), want)
+    go = torch.from_numpy(rng.standard_normal((B, C, Z, X, Y)).astype(np.float32))
+    out.backward(go.to(dev))
+    assert torch.equal(fg.grad.cpu(), go[coords[:, 3], :, coords[:, 2], coords[:, 0], coords[:, 1]])
 
 
 def test_pooling_checksum_full_size(dev):
@@ -599,6 +606,14 @@ def test_lift_splat_into_the_fuser_concat_buffer(dev):
         cview = f(plain, pts.to(dev))                     # channels-last view of a [V,C] buffer -> rows prologue with a copy
     assert torch.equal(a, b) and torch.equal(a, cview)
     assert torch.equal(na[0], nb[0]) and torch.equal(na[1], nb[1])
+    # a caller's OWN [V,4C] buffer whose first C columns hold the camera rows is not clobbered: only buffers handed out by
+    # concat_buffer (or a SearchSlot) are completed in place
+    mine = torch.full((X * Y * Z, 4 * C), 7.0, device=dev)
+    mine[:, :C] = slot0.t[:, :C]
+    view = mine[:, :C].view(1, X, Y, Z, C).permute(0, 4, 1, 2, 3)
+    with torch.no_grad():
+        d = f(view, pts.to(dev))
+    assert torch.equal(d, a) and bool((mine[:, C:] == 7.0).all())
 
 
 @pytest.mark.parametrize("name", ["fuser_k2", "fuser_k2_far", "fuser_k3"])
