@@ -184,6 +184,18 @@ def step(model, s, world, search=None, img=None, ticket=None):
         if STAGGER[0] == 1:
             passed()
         out = model.decode(vf, s["gemo"], s["img_feats"], s["transform"], do_render, after_encoder=passed if STAGGER[0] == 2 else None)
+    elif SHARD[0]:
+        # config 5 (--shard rays): ONE scene over all ranks -- every rank runs K / G / C on the same sample (the conv stack
+        # does not shard: a slab decomposition needs halos at 13 layers), renders its contiguous chunk of the
+        # (camera, row) ray space and the 16-byte-per-ray map chunks are all-gathered (equal-padded, one collective)
+        from co_occ_amd.render import render_block_sharded
+        out = model.forward_hot_path(img, s["pts"], s["gemo"], s["img_feats"], s["transform"], render=False, search=search)
+        if do_render:
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            out["rgbs"], out["depths"], out["render_maps"] = render_block_sharded(model.sigma_head, model.rgb_head, out["voxel_feats"], s["gemo"], 16)
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
+            SHARD_EV.append((e0, e1))
+        return out
     else:
         out = model.forward_hot_path(img, s["pts"], s["gemo"], s["img_feats"], s["transform"], render=do_render, search=search)
     if world > 1 and ticket is not None:
@@ -213,6 +225,8 @@ def _gather(out):
 
 _pending = []
 _async_ok = [True]
+SHARD = [False]
+SHARD_EV = []
 WITH_POOL = [True]
 CFGNAME = ["r50"]
 
@@ -641,6 +655,10 @@ def main():
                     help="1 (default): the dense stage of a sample is one captured hipGraph launch (GraphPipeline); 0: every launch "
                          "issued from Python (Pipeline, --streams)")
     ap.add_argument("--slots", type=int, default=6, help="--graph 1: samples in flight (1 in its dense stage + slots-1 in the prefetched search)")
+    ap.add_argument("--shard", default="samples", choices=["samples", "rays"],
+                    help="samples (default): one scene per GPU, weak scaling (configs[3]).  rays: ONE scene over all ranks -- K / G / C "
+                         "replicated, the render rays sharded, map chunks all-gathered (configs[4]'s 'per-camera render shard'); "
+                         "strong scaling: value = scenes/s of the whole job")
     ap.add_argument("--diag", action="store_true", help="host-side issue times per sample to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -677,8 +695,11 @@ def main():
     if auto_streams:
         args.streams = 2
     STAGGER[0] = args.stagger if args.streams > 1 else 0
+    SHARD[0] = args.shard == "rays"
+    if SHARD[0]:
+        args.graph, args.streams = 0, 1           # the sharded render has a collective inside the step: eager, one sample in flight
     model, sd = build_model(args.config, dev)
-    samples = [make_inputs(args.config, 1234 + 17 * rank + i, dev, model) for i in range(max(2, args.slots if args.graph else 2))]
+    samples = [make_inputs(args.config, 1234 + (0 if SHARD[0] else 17 * rank) + i, dev, model) for i in range(max(2, args.slots if args.graph else 2))]
     if args.reserve_cus > 0:
         # CU partition: the FPS chains get private CUs, everything else runs on the remaining ones
         from co_occ_amd import streams as cstreams
@@ -813,16 +834,18 @@ def main():
                                           pool=e_iso.get("roofline_pool"))
     if rank == 0 and args.config == "r50" and not args.no_kernel_timing:
         extra["roofline_render_r101"] = render_r101_roofline(model, dev)
-    line = dict(metric="samples/sec (6-cam frame + sweep -> occ+render), 200x200x16 grid", value=round(world * args.steps / dt, 4),
+    jobs = 1 if SHARD[0] else world          # --shard rays: all ranks work on the same scene
+    line = dict(metric="samples/sec (6-cam frame + sweep -> occ+render), 200x200x16 grid", value=round(jobs * args.steps / dt, 4),
                 unit="samples/s", n_gpus=world, world_size_seen_by_backend=seen_world, backend=backend_name, steps=args.steps,
                 warmup=args.warmup,
-                ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+                ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True, scaling=("strong" if SHARD[0] else "weak"), vs_baseline=None,
                 dtype=args.dtype, data="synthetic",
                 config=dict(workload="coocc_multi_r50_256x704 hot path" if args.config == "r50" else args.config,
                             fused_grid="x".join(map(str, c["grid"])) + "x%d" % c["C"],
                             occupancy_grid="x".join(str(v) for v in c.get("final_occ_size", [2 * g for g in c["grid"]])), cams=c["ncam"],
                             render_maps="%dx%dx%d" % (c["ncam"], c["fmap"][0] * 16, c["fmap"][1] * 16), knum=c["knum"],
-                            parallelism="dp%d (1 scene per GPU, RCCL all-gather of maps)" % world,
+                            parallelism=("ray-shard x%d (ONE scene: K/G/C replicated on every rank, render rays sharded, all-gather of the "
+                                         "map chunks)" % world if SHARD[0] else "dp%d (1 scene per GPU, RCCL all-gather of maps)" % world),
                             samples_in_flight=(gp.n if gp is not None else S), prefetched_search=bool(tpool), weights="random",
                             pipeline=("hipGraph dense stage + eager prefetched search" if gp is not None else "eager (Python-issued launches)"),
                             conv_engine=(core.CONV_ENGINE if args.dtype == "f32" else args.dtype),
@@ -832,6 +855,13 @@ def main():
     line.update(extra)
     if graph_info is not None:
         line["graph"] = graph_info
+    if SHARD[0] and SHARD_EV:
+        torch.cuda.synchronize()
+        rms = sum(a.elapsed_time(b) for a, b in SHARD_EV[-args.steps:]) / min(len(SHARD_EV), args.steps)
+        line["ray_shard"] = dict(render_ms_per_step=round(rms, 3), sharded_fraction_of_step=round(rms / (1e3 * dt / args.steps), 4),
+                                 note="only the render block shards (table build + rays + gather + upsample); the index search and the "
+                                      "3-D conv stack are replicated on every rank, so this mode cannot scale: one scene per GPU "
+                                      "(--shard samples) is the scaling configuration")
     knobs = {k: v for k, v in sorted(os.environ.items()) if k.startswith("COOCC_")}
     line["env_knobs"] = knobs           # every dispatch-changing environment variable that was set for this run
     if probe is not None:

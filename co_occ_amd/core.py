@@ -530,6 +530,41 @@ def linear_rows(x2d, pc, relu=False, out=None, out_coff=0, in_coff=0, in_C=None)
     return out
 
 
+def linear_rows_h2(xh, n, Cin, pc, relu=False, out=None, out_coff=0, out_h2=False):
+    """Row-wise nn.Linear on the split-f16 engine: ``xh`` = H2 rows [n, Cin] (``rows_to_h2`` or a producer's ``out_h2``
+    epilogue).  ``out_h2``: the result is written as H2 rows too (a float32-typed [n, Cout] tensor holding them)."""
+    dev = xh.device
+    if out is None:
+        out = torch.empty(n, pc.Cout, device=dev, dtype=_F32)
+    ws = workspace(dev)
+    d = ConvDesc()
+    d.in_, d.w = ptr(xh), ptr(pc.h2_pack())
+    d.out = ctypes.c_void_p(out.data_ptr() + 4 * out_coff)
+    d.scale, d.bias = ptr(pc.scale), ptr(pc.bias)
+    d.res = d.gather = d.out_rows = None
+    d.ws, d.ws_floats = ptr(ws), ws.numel()
+    d.M, d.Cin, d.Cout, d.taps = n, Cin, pc.Cout, 1
+    d.in_stride, d.out_stride, d.res_stride = Cin, out.shape[1], 0
+    d.B, d.Xi, d.Yi, d.Zi, d.Xo, d.Yo, d.Zo = 1, n, 1, 1, n, 1, 1
+    d.ksize, d.stride, d.pad = 1, 1, 0
+    d.relu, d.res_mode, d.splitk = int(relu), 0, 1
+    d.mfma_dtype, d.alpha, d.out_h2 = 3, 1.0, int(out_h2)
+    with TIMER.region("k_gemm_h2w linear", 2.0 * n * Cin * pc.Cout):
+        _lib.conv_fwd(d, dev)
+    return out
+
+
+def rows_to_h2(x2d, C=None, coff=0, name="h2rows"):
+    """H2 copy of the first C channels (from ``coff``) of a [n, stride] fp32 tensor (per-stream scratch)."""
+    n = x2d.shape[0]
+    C = C if C is not None else x2d.shape[1]
+    xh = scratch(x2d.device, name, n * C)
+    src = _lib.DevPtr(x2d.data_ptr() + 4 * coff)
+    src._keep = x2d
+    call("coocc_rows_to_h2", src, x2d.shape[1], n, C, 1.0, ptr(xh))
+    return xh
+
+
 def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_coff, C, relu=True, count_dev=None):
     """GSFusion G1: dst[out_rows[m], dst_coff:+C] = relu(sum_k W_k . src[gather[k,m], src_coff:+C] + b)
     * dst[out_rows[m], gate_coff:+C]   (bifuser_n.py:138-169).  src/dst: [rows, stride] tensors.

@@ -20,6 +20,7 @@ struct ConvK {
   float alpha;                  // k_gemm_h2z: accumulators are multiplied by alpha before the epilogue (1 / operand scale)
   const int32_t* M_dev;         // row-table kernels: actual row count on the device (<= M, the grid's capacity), or NULL
   int gstride;                  // row-table kernels: entries per tap of `gather` (>= M)
+  int out_h2;                   // split-f16 kernels: write the output rows in H2 format (the next layer's operand)
 };
 
 __device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t rrow) {

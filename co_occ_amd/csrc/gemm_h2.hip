@@ -56,14 +56,30 @@ __device__ __forceinline__ void split_h2(float v, _Float16& hi, _Float16& lo) {
 // under P2 of step u; sched_barrier(0) between the phases keeps hipcc from hoisting the reads (more live fragment registers ->
 // spills -> scratch reloads that wait vmcnt(0), i.e. for the weight loads just issued).  Two workgroups per CU (<= 256 registers)
 // cover each other's barriers, prologues and epilogues.
+// epilogue option out_h2: the output row is written as an H2 row (the next split-f16 layer's operand) instead of fp32:
+// channels n .. n+3 of row `row` (out_stride = channels per row, a multiple of 32)
+__device__ __forceinline__ void store_h2(float* out, size_t row, int out_stride, int n, f32x4 v) {
+  f16x4 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (_Float16)v[e];
+    lo[e] = (_Float16)((v[e] - (float)hi[e]) * H2_LO_SCALE);
+  }
+  char* o = (char*)out + row * (size_t)out_stride * 4 + (n >> 5) * 128 + (n & 31) * 2;
+  *(f16x4*)o = hi;
+  *(f16x4*)(o + 64) = lo;
+}
 #define H2_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ const char* inb_(const ConvK& p) { return (const char*)p.in; }
-template <int KZ, bool XY>
+template <int KZ, bool XY, int ABL = 0>    // ABL (timing ablations, wrong results): 1 no A image, 2 no weight loads, 4 no fragment reads, 8 no stores
 __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
   constexpr int BM = 128, TM = 4;
   constexpr int AROWS = 136;                       // 128 + KZ - 1 rounded up to whole 8-row wave instructions
-  constexpr unsigned STAGE = AROWS * 128, ZOFF = 2 * STAGE;     // two stages + one row of zeros (masked fragments read it)
-  __shared__ __attribute__((aligned(16))) char As[2 * AROWS * 128 + 128];
+  // two stages + 256 zero bytes: a masked fragment reads the zero word that sits in the SAME banks as its real address
+  // (ZOFF | (address & 255)), so masking adds no bank conflict (a single zero row cost 2.0e9 conflict cycles per 442 launches)
+  constexpr unsigned STAGE = AROWS * 128, ZOFF = 2 * STAGE;
+  static_assert(STAGE % 256 == 0 && ZOFF % 256 == 0, "zero block must keep the bank of the address it replaces");
+  __shared__ __attribute__((aligned(256))) char As[2 * AROWS * 128 + 256];
 
   const int id = blockIdx.x;
   int mtile, nt, slot_ = id >> 3;
@@ -82,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 31, h = lane >> 5;
   const int srow = lane >> 3, slot = lane & 7;
-  if (tid < 8) *(f32x4*)&As[ZOFF + tid * 16] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < 16) *(f32x4*)&As[ZOFF + tid * 16] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // everything the K loop needs in registers (a field of `p` read inside the loop is a scalar load whose lgkmcnt(0) also waits
   // for the LDS reads in flight)
@@ -124,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
                      (long long)it0 * wstep + (long long)((n0 >> 5) + wave) * 4096 + lane * 16;
 
   auto issueA = [&](int buf) {
+    if (ABL & 1) { if (XY) { if (++gh == ky) { gh = 0; if (++gd == kx) { gd = 0; ++gkc; } } } else ++gkc; return; }
     const int off = XY ? ((gd - px) * Yi + (gh - py)) * Zi : 0;
     const unsigned coff = (unsigned)gkc * 128 + aq;
 #pragma unroll
@@ -140,6 +157,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
   f16x8 breg[2][2][2];        // [register set][k16 step][plane]
   auto loadB = [&](auto bufc) {
     constexpr int B_ = decltype(bufc)::value;
+    if (ABL & 2) { if (B_ == 0 && wcur == (const char*)1) breg[0][0][0] = *(const f16x8*)wcur; return; }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -156,15 +174,28 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
       fragoff[dz][q] = (li + dz) * 128 + ((sl ^ (((li + dz) >> 1) & 7)) << 4);
     }
   f16x8 fhi[TM], flo[TM];
+  if (ABL & 4) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { fhi[i] = *(const f16x8*)&As[lane * 16 + i * 64]; flo[i] = *(const f16x8*)&As[lane * 16 + i * 64 + 32]; }
+  }
+  if (ABL & 2) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) breg[a][s2][pl] = *(const f16x8*)(wcur + (a * 4 + s2 * 2 + pl) * 1024);
+  }
   // a lane whose output voxel's tap leaves the grid reads the zero row instead: one select on the LDS address, the loads stay
   // unconditional (hipcc turns "ok ? fragment : 0" into a branch around the loads)
   auto load_plane = [&](auto planec, auto stagec, auto dzc, auto sc, unsigned bits) {
     constexpr int PL = decltype(planec)::value, ST = decltype(stagec)::value, DZ = decltype(dzc)::value, S_ = decltype(sc)::value;
+    if (ABL & 4) return;
     asm volatile("" : "+v"(bits));      // keep the address selects here: hoisted out of the K loop they are dozens of live registers
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const bool ok = (bits >> (i * 3 + DZ)) & 1;
-      const unsigned a = ok ? fragoff[DZ][2 * S_ + PL] + (ST * STAGE + i * 4096) : ZOFF;
+      const unsigned a = ok ? fragoff[DZ][2 * S_ + PL] + (ST * STAGE + i * 4096) : (ZOFF | (fragoff[DZ][2 * S_ + PL] & 255u));
       if (PL == 0) fhi[i] = *(const f16x8*)&As[a];
       else flo[i] = *(const f16x8*)&As[a];
     }
@@ -280,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
       for (int j = 0; j < 4; ++j) {
         const int n = nb + 8 * j;
         if (n >= p.Cout) continue;
+        if ((ABL & 8) && hh[i][4 * j] != 12345.f) continue;
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo;
@@ -290,7 +322,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
           if (p.res_mode == 1) v = v + *(const f32x4*)(p.res + (size_t)m * p.res_stride + n);
           if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
           if (p.res_mode == 2) v = v * *(const f32x4*)(p.res + (size_t)m * p.res_stride + n);
-          *(f32x4*)(p.out + (size_t)m * p.out_stride + n) = v;
+          if (p.out_h2) store_h2(p.out, (size_t)m, p.out_stride, n, v);
+          else *(f32x4*)(p.out + (size_t)m * p.out_stride + n) = v;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -502,7 +535,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
           if (p.res_mode == 1) v = v + *(const f32x4*)(p.res + orow * p.res_stride + n);
           if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
           if (p.res_mode == 2) v = v * *(const f32x4*)(p.res + orow * p.res_stride + n);
-          *(f32x4*)(p.out + orow * p.out_stride + n) = v;
+          if (p.out_h2) store_h2(p.out, orow, p.out_stride, n, v);
+          else *(f32x4*)(p.out + orow * p.out_stride + n) = v;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -527,6 +561,9 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   k.wgroup_floats = (size_t)k.taps * k.kchunks * k.Npad * 32;       // 128 bytes per (chunk, tap, column)
   k.alpha = d->alpha != 0.f ? d->alpha : 1.f;
   k.M_dev = d->M_dev;
+  k.out_h2 = d->out_h2;
+  COOCC_CHECK_ARG(!d->out_h2 || (d->Cout % 4 == 0 && d->out_stride % 32 == 0 && !d->out_rows && (d->splitk == 1 || d->splitk == 0)),
+                  "conv_fwd: out_h2 needs Cout % 4 == 0, out_stride % 32 == 0, no row scatter");
   int rc = coocc_zero_row(&k.zrow);
   if (rc != COOCC_OK) return rc;
   k.ntiles = (k.Cout + 127) / 128;
@@ -539,7 +576,7 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   const int ngroups = k.total_iters / gsz;
   if (splitk <= 0) {
     splitk = 1;
-    if (blocks < 256 && ngroups >= 8 && d->ws && !d->M_dev && !d->out_rows) {
+    if (blocks < 256 && ngroups >= 8 && d->ws && !d->M_dev && !d->out_rows && !d->out_h2) {
       splitk = (int)(512 / blocks);
       if (splitk > ngroups / 4) splitk = ngroups / 4;
       if (splitk > 64) splitk = 64;
@@ -562,6 +599,19 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   COOCC_CHECK_ARG((long long)d->M < (1ll << 30) && (136ull + 2ull * ((unsigned long long)k.Yi + 2) * k.Zi) * d->in_stride * 4ull < 0xFFFFFF00ull,
                   "conv_fwd: the split-f16 kernel addresses a tile's window with 32-bit byte offsets");
   const bool xy = !(k.kx == 1 && k.ky == 1 && k.px == 0 && k.py == 0);
+  static const int abl = getenv("COOCC_H2_ABLATE") ? atoi(getenv("COOCC_H2_ABLATE")) : 0;     // timing ablations (wrong results)
+  if (abl && !xy && k.kz == 3) {
+    switch (abl) {
+      case 1: hipLaunchKernelGGL((k_gemm_h2z<3, false, 1>), grid, dim3(256), 0, s, k); break;
+      case 2: hipLaunchKernelGGL((k_gemm_h2z<3, false, 2>), grid, dim3(256), 0, s, k); break;
+      case 4: hipLaunchKernelGGL((k_gemm_h2z<3, false, 4>), grid, dim3(256), 0, s, k); break;
+      case 8: hipLaunchKernelGGL((k_gemm_h2z<3, false, 8>), grid, dim3(256), 0, s, k); break;
+      case 7: hipLaunchKernelGGL((k_gemm_h2z<3, false, 7>), grid, dim3(256), 0, s, k); break;
+      default: hipLaunchKernelGGL((k_gemm_h2z<3, false, 15>), grid, dim3(256), 0, s, k); break;
+    }
+    COOCC_LAUNCH_CHECK("k_gemm_h2z<ablation>");
+    return COOCC_OK;
+  }
   if (!xy) {
     if (k.kz == 3) hipLaunchKernelGGL((k_gemm_h2z<3, false>), grid, dim3(256), 0, s, k);
     else if (k.kz == 2) hipLaunchKernelGGL((k_gemm_h2z<2, false>), grid, dim3(256), 0, s, k);

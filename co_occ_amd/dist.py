@@ -103,8 +103,16 @@ def gather_ray_shards(local_maps, n_rows_total):
     mx = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros((mx,) + tuple(local_maps.shape[1:]), device=local_maps.device, dtype=local_maps.dtype)
     pad[: local_maps.shape[0]] = local_maps
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad)
+    if dist.get_backend() == "gloo":
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+    else:
+        # RCCL: ONE all_gather_into_tensor over the equal-padded chunks (a list all_gather is world point-to-point copies)
+        out = torch.empty((world,) + tuple(pad.shape), device=pad.device, dtype=pad.dtype)
+        dist.all_gather_into_tensor(out, pad)
+        parts = list(out.unbind(0))
+    if all(hi - lo == mx for lo, hi in sizes):
+        return torch.cat(parts, 0) if dist.get_backend() == "gloo" else out.reshape((world * mx,) + tuple(pad.shape[1:]))
     return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)
 
 

@@ -57,8 +57,24 @@ class MLP(nn.Module):
             return [PackedConv(l.weight, bias=l.bias) for l in list(self.hidden_layers) + [self.output_layer]]
         return self._packs.get_modules((self,), build)
 
-    def forward_rows(self, x2d, out=None, out_coff=0):
+    def forward_rows(self, x2d, out=None, out_coff=0, xh=None):
+        """``xh``: an H2 copy of ``x2d`` made by the caller (``core.rows_to_h2``), shared between heads."""
+        from . import core
         p = self._packed()
+        n = x2d.shape[0]
+        if (core.CONV_ENGINE == "h2" and core.CONV_DTYPE == "f32" and core.H2_DIRECT and n >= 8192 and self.input_dim % 32 == 0
+                and self.net_width % 32 == 0):
+            # split-f16 engine: every hidden layer's epilogue writes the next layer's H2 operand, the output layer (1 or 3
+            # columns, padded to one 128-column tile in the pack) writes fp32 into the caller's table
+            h = xh if xh is not None else core.rows_to_h2(x2d, self.input_dim, name="mlp_in")
+            cin = self.input_dim
+            for li, pc in enumerate(p[:-1]):
+                nxt = core.scratch(x2d.device, "mlp_h%d" % (li & 1), n * pc.Cout)[:n * pc.Cout].view(n, pc.Cout)
+                core.linear_rows_h2(h, n, cin, pc, relu=True, out=nxt, out_h2=True)
+                h, cin = nxt, pc.Cout
+            if out is None:
+                out = torch.empty(n, p[-1].Cout, device=x2d.device, dtype=_F32)
+            return core.linear_rows_h2(h, n, cin, p[-1], relu=False, out=out, out_coff=out_coff)
         for pc in p[:-1]:
             x2d = linear_rows(x2d, pc, relu=True)
         return linear_rows(x2d, p[-1], relu=False, out=out, out_coff=out_coff)
@@ -75,10 +91,14 @@ def voxel_table(sigma_head, rgb_head, vf):
     V = vf.t.shape[0]
     dev = vf.t.device
     table = torch.empty(V, 4, device=dev, dtype=_F32) if rgb_head is not None else torch.zeros(V, 4, device=dev, dtype=_F32)
+    from . import core
     x = vf.t if (vf.coff == 0 and vf.stride == vf.C) else vf.t[:, vf.coff:vf.coff + vf.C].contiguous()
-    sigma_head.forward_rows(x, out=table, out_coff=0)
+    xh = None
+    if core.CONV_ENGINE == "h2" and core.CONV_DTYPE == "f32" and core.H2_DIRECT and V >= 8192 and vf.C % 32 == 0:
+        xh = core.rows_to_h2(x, vf.C, name="mlp_in")            # one H2 copy of the voxel features for both heads
+    sigma_head.forward_rows(x, out=table, out_coff=0, xh=xh)
     if rgb_head is not None:
-        rgb_head.forward_rows(x, out=table, out_coff=1)
+        rgb_head.forward_rows(x, out=table, out_coff=1, xh=xh)
     return table
 
 

@@ -215,6 +215,8 @@ typedef struct coocc_conv_desc {
                              is sized for M = capacity and tiles past *M_dev leave at once) -- lets a captured hipGraph run over
                              voxel lists whose length is only known on the device; NULL: M rows */
   int gather_stride;      /* entries per tap of `gather` (0 = M) */
+  int out_h2;             /* mfma_dtype 3: write the output as H2 rows (out_stride = channels per row, % 32 == 0) -- the producer's
+                             epilogue emits the next split-f16 layer's operand, no conversion pass in between */
 } coocc_conv_desc;
 
 /* nn.Conv3d(k=3|1)+BN(eval)+ReLU(+residual) (bifuser_n.py:23-30, resnet3d.py:34-64,

@@ -144,3 +144,34 @@ def test_graph_pipeline_outputs_equal_sequential_calls():
         for k, v in g.items():
             assert torch.equal(v, ref[i % 4][k]), (i, k)
     assert not torch.equal(ref[0]["pred_c"], ref[1]["pred_c"])
+
+
+def _torchrun(nproc, extra, timeout=900):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                 "--master-port", str(port), "bench.py", "--gpus", str(nproc)] + extra, timeout=timeout)
+
+
+def test_ray_shard_mode_two_ranks_on_one_gpu():
+    """--shard rays (configs[4]'s per-camera render shard): ONE scene over 2 ranks (gloo, both on cuda:0): strong scaling, the
+    sharded share of the step is reported."""
+    d = _torchrun(2, ["--same-device", "--backend", "gloo", "--steps", "4", "--warmup", "1", "--shard", "rays", "--no-cpu-baseline",
+                      "--no-kernel-timing"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "ray-shard x2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 0.05 * d["value"]           # scenes/s of the whole job, not x world
+    assert 0 < d["ray_shard"]["sharded_fraction_of_step"] < 0.2
+
+
+def test_rccl_two_ranks_when_two_gpus_are_present():
+    """The N = 2 path over RCCL (backend nccl, one rank per GPU): both bench modes.  Skipped on single-GPU boxes -- so that the
+    first multi-GPU box that runs the suite is not also the first RCCL run of this code."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    d = _torchrun(2, ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timing"])
+    assert d["n_gpus"] == 2 and d["backend"] == "nccl" and d["world_size_seen_by_backend"] == 2
+    d = _torchrun(2, ["--steps", "4", "--warmup", "1", "--shard", "rays", "--no-cpu-baseline", "--no-kernel-timing"])
+    assert d["backend"] == "nccl" and d["scaling"] == "strong"
