@@ -94,6 +94,7 @@ SIGNATURES = {
     "coocc_lift_splat_cams": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, I, I, I, I, P, I, P, Z, P]),
     "coocc_bev_pool_coords": (I, [P, P, I, I, I, I, I, I, P, I, P, Z, P]),
     "coocc_render_nearest": (I, [P, I, I, I, P, P, I, I, I, I, P, I, P, P]),
+    "coocc_render_nearest_cams": (I, [P, I, I, I, P, P, P, P, P, I, I, I, I, P, I, P, P]),
     "coocc_render_activate_table": (I, [P, I, P]),
     "coocc_upsample_maps": (I, [P, I, I, I, I, P, P, P]),
     "coocc_volume_sampling": (I, [P, I, I, I, I, P, I, P, P, P, P]),

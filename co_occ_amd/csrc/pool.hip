@@ -26,26 +26,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // else 0), bda[:3,3] of a 4x4 bda (:145-148, else 0)} (COOCC_CAM_FLOATS = 39 floats); xs/ys/ds = the frustum axes of
 // create_frustum (:104-115) computed by the host with the same torch calls.  The same chain is the module-level
 // get_frustum of the detector (P/coocc/detectors/coocc_ray.py:732-776).
-__device__ __forceinline__ void geometry_point(const float* __restrict__ mats, const float* __restrict__ xs,
-                                               const float* __restrict__ ys, const float* __restrict__ ds, size_t i, int D,
-                                               int fH, int fW, float& gx, float& gy, float& gz) {
-  int w = (int)(i % fW); size_t r = i / fW;
-  int h = (int)(r % fH); r /= fH;
-  int d = (int)(r % D); int cam = (int)(r / D);
-  const float* m = mats + (size_t)cam * COOCC_CAM_FLOATS;
-  float px = xs[w] - m[9], py = ys[h] - m[10], pz = ds[d] - m[11];
-  float qx = m[0] * px + m[1] * py + m[2] * pz;
-  float qy = m[3] * px + m[4] * py + m[5] * pz;
-  float qz = m[6] * px + m[7] * py + m[8] * pz;
-  qx *= qz; qy *= qz;
-  qx -= m[33]; qy -= m[34]; qz -= m[35];
-  float ex = m[12] * qx + m[13] * qy + m[14] * qz + m[21];
-  float ey = m[15] * qx + m[16] * qy + m[17] * qz + m[22];
-  float ez = m[18] * qx + m[19] * qy + m[20] * qz + m[23];
-  gx = m[24] * ex + m[25] * ey + m[26] * ez + m[36];
-  gy = m[27] * ex + m[28] * ey + m[29] * ez + m[37];
-  gz = m[30] * ex + m[31] * ey + m[32] * ez + m[38];
-}
+#include "geometry.h"
 
 // The 39 per-camera constants from the raw calibration tensors in ONE tiny launch (3x3 inverses by the adjugate in fp64,
 // rounded to fp32).  The host-side torch form needs two torch.inverse calls, which synchronise with the host to read their

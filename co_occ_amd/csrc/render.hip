@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "geometry.h"
 #include <algorithm>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -69,12 +70,17 @@ struct __attribute__((packed, aligned(4))) Geo3 { float x, y, z; };
 // registers under phase 2 -- 38-48 us vs 27, the 48 extra VGPRs cost more occupancy than the overlap returned --
 // and swapping the two phases between wave pairs over a double-buffered LDS tile -- 38 us at 2 tiles per
 // workgroup, 59 at 4: with so few tiles, one workgroup per tile, all resident at once, is the better use of the chip.)
-template <int ACT, int CHT>
+// GEO: the sample positions are not read from a [N,D,H,W,3] tensor but evaluated in place from the 39 per-camera constants and
+// the frustum axes (geom = mats, xs / ys / ds passed separately) with get_geometry's own chain (geometry.h): the kernel then
+// reads 16 bytes of table per sample and nothing else (12 bytes per sample less: 45 of the 47 MB it moves at r101).
+template <int ACT, int CHT, bool GEO = false>
 __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict__ table, int Y, int Z,
                                                          const float* __restrict__ geom,
                                                          const float* __restrict__ zvals, int D, int H, int W, int rt,
                                                          float lox, float loy, float loz, float dx, float dy, float dz,
-                                                         float nx, float ny, float nz, float* __restrict__ maps) {
+                                                         float nx, float ny, float nz, float* __restrict__ maps,
+                                                         const float* __restrict__ xs = nullptr, const float* __restrict__ ys = nullptr,
+                                                         const float* __restrict__ ds = nullptr) {
   extern __shared__ int s_pos[];    // [rt][D+1]
   const int DS = D + 1;
   const int wt = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
@@ -86,7 +92,9 @@ __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict_
 #pragma unroll 4
   for (int d = tid >> 5, r = tid & 31; d < D; d += 8) {
     if (r >= nray) continue;
-    const Geo3 g = *(const Geo3*)(geom + ((((size_t)n * D + d) * H + h) * W + w0 + r) * 3);
+    Geo3 g;
+    if (GEO) geometry_point(geom, xs, ys, ds, (((size_t)n * D + d) * H + h) * W + w0 + r, D, H, W, g.x, g.y, g.z);
+    else g = *(const Geo3*)(geom + ((((size_t)n * D + d) * H + h) * W + w0 + r) * 3);
     float gx = __fdiv_rn(g.x - lox, dx), gy = __fdiv_rn(g.y - loy, dy), gz = __fdiv_rn(g.z - loz, dz);
     bool in = gx >= 0.f && gx < nx && gy >= 0.f && gy < ny && gz >= 0.f && gz < nz;
     int ix = in ? (int)gx : 0, iy = in ? (int)gy : 0, iz = in ? (int)gz : 0;
@@ -193,9 +201,23 @@ extern "C" int coocc_render_activate_table(float* table, int V, void* stream) {
   return COOCC_OK;
 }
 
+static int render_nearest_impl(const float* table, int X, int Y, int Z, const float* geom, const float* xs, const float* ys,
+                               const float* ds, const float* zvals, int N, int D, int H, int W, const float* bounds_host,
+                               int activated, float* maps, void* stream);
 extern "C" int coocc_render_nearest(const float* table, int X, int Y, int Z, const float* geom,
                                     const float* zvals, int N, int D, int H, int W, const float* bounds_host,
                                     int activated, float* maps, void* stream) {
+  return render_nearest_impl(table, X, Y, Z, geom, nullptr, nullptr, nullptr, zvals, N, D, H, W, bounds_host, activated, maps, stream);
+}
+extern "C" int coocc_render_nearest_cams(const float* table, int X, int Y, int Z, const float* mats, const float* xs, const float* ys,
+                                         const float* ds, const float* zvals, int N, int D, int H, int W,
+                                         const float* bounds_host, int activated, float* maps, void* stream) {
+  COOCC_CHECK_ARG(xs && ys && ds, "render_nearest_cams: null frustum axes");
+  return render_nearest_impl(table, X, Y, Z, mats, xs, ys, ds, zvals, N, D, H, W, bounds_host, activated, maps, stream);
+}
+static int render_nearest_impl(const float* table, int X, int Y, int Z, const float* geom, const float* xs, const float* ys,
+                               const float* ds, const float* zvals, int N, int D, int H, int W, const float* bounds_host,
+                               int activated, float* maps, void* stream) {
   COOCC_CHECK_ARG(table && geom && zvals && maps && bounds_host, "render_nearest: null pointer");
   COOCC_CHECK_ARG(N > 0 && D > 0 && D <= 256 && H > 0 && W > 0, "render_nearest: bad sizes (D <= 256)");
   const float* bd = bounds_host;  // xbound(3), ybound(3), zbound(3) = lo, hi, step (coocc_ray.py:577)
@@ -213,19 +235,17 @@ extern "C" int coocc_render_nearest(const float* table, int X, int Y, int Z, con
   const int tiles = (W + rt - 1) / rt;
   size_t lds = sizeof(int) * (size_t)rt * (D + 1);
   dim3 grid(tiles, H, N);
-  if (D > 128) {     // up to 8 samples per lane
-    if (activated)
-      hipLaunchKernelGGL((k_render_nearest<1, 8>), grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
-                         lox, loy, loz, dx, dy, dz, nx, ny, nz, maps);
-    else
-      hipLaunchKernelGGL((k_render_nearest<0, 8>), grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
-                         lox, loy, loz, dx, dy, dz, nx, ny, nz, maps);
-  } else if (activated)
-    hipLaunchKernelGGL((k_render_nearest<1, 4>), grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
-                       lox, loy, loz, dx, dy, dz, nx, ny, nz, maps);
-  else
-    hipLaunchKernelGGL((k_render_nearest<0, 4>), grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt,
-                       lox, loy, loz, dx, dy, dz, nx, ny, nz, maps);
+#define RN_LAUNCH(ACT, CHT, GEO)                                                                                                  \
+  hipLaunchKernelGGL((k_render_nearest<ACT, CHT, GEO>), grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt, \
+                     lox, loy, loz, dx, dy, dz, nx, ny, nz, maps, xs, ys, ds)
+  if (xs) {
+    if (D > 128) { if (activated) RN_LAUNCH(1, 8, true); else RN_LAUNCH(0, 8, true); }
+    else { if (activated) RN_LAUNCH(1, 4, true); else RN_LAUNCH(0, 4, true); }
+  } else {
+    if (D > 128) { if (activated) RN_LAUNCH(1, 8, false); else RN_LAUNCH(0, 8, false); }    // up to 8 samples per lane
+    else { if (activated) RN_LAUNCH(1, 4, false); else RN_LAUNCH(0, 4, false); }
+  }
+#undef RN_LAUNCH
   COOCC_LAUNCH_CHECK("k_render_nearest");
   return COOCC_OK;
 }

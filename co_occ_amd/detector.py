@@ -197,7 +197,7 @@ class COOCC_Ray(nn.Module):
         return self.decode(voxel_feats, gemo, img_feats, transform, render, dense_fine)
 
     def decode(self, voxel_feats, gemo=None, img_feats=None, transform=None, render=None, dense_fine=True,
-               depth_only=False, fine_size=None, after_encoder=None, static=False):
+               depth_only=False, fine_size=None, after_encoder=None, static=False, cam_geo=None):
         """Everything after ``extract_feat`` and before the metrics (coocc_ray.py:525-627).  ``after_encoder``: callback run
         once the encoder's launches are enqueued (a serving loop with two samples in flight staggers them there).
         ``static``: no host read anywhere (the fine branch keeps its count on the device and returns capacity-sized
@@ -220,7 +220,7 @@ class COOCC_Ray(nn.Module):
         do_render = (self.use_rendering and self.test_rendering) if render is None else render
         if do_render:
             rgbs, depths, maps = render_block(self.sigma_head, getattr(self, "rgb_head", None), to_rows(voxel_feats), gemo, 16,
-                                              depth_only=depth_only or not hasattr(self, "rgb_head"))
+                                              depth_only=depth_only or not hasattr(self, "rgb_head"), cam_geo=cam_geo)
             res.update(rgbs=rgbs, depths=depths, render_maps=maps)
         return res
 

@@ -41,12 +41,15 @@ class DenseGraph:
     def _run(self):
         m, s = self.model, self.inputs
         vf = m.occ_fuser.forward_static(self.slot)
-        gemo = s.get("gemo")
+        gemo, cam_geo = s.get("gemo"), None
         if self.render and s.get("cams") is not None:
             # P1 per sample (ViewTransformerLSSBEVDepth.py:117-150 via coocc_ray.py:186): the frustum geometry the render
-            # block samples is recomputed from the camera matrices inside the stage, not read from a pre-baked tensor
-            gemo = m.img_view_transformer.get_geometry(*s["cams"])
-        return m.decode(vf, gemo, s["img_feats"], s["transform"], self.render, static=True)
+            # block samples comes from the camera matrices inside the stage -- the 39 constants per camera by one tiny kernel,
+            # the per-sample chain in the ray kernel itself -- not from a pre-baked [N,D,H,W,3] tensor
+            cam_geo = m.img_view_transformer._camera_mats(*s["cams"])
+            mats = cam_geo[0].reshape(-1, cam_geo[0].shape[-1])
+            cam_geo = (mats,) + tuple(cam_geo[1:])
+        return m.decode(vf, gemo, s["img_feats"], s["transform"], self.render, static=True, cam_geo=cam_geo)
 
     def capture(self, warmup=2):
         """Eager warm-up on the capture stream (weight packs, per-stream scratch), then the capture itself."""

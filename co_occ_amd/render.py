@@ -102,20 +102,29 @@ def voxel_table(sigma_head, rgb_head, vf):
     return table
 
 
-def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16, depth_only=False):
+def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16, depth_only=False, cam_geo=None):
     """coocc_ray.py:570-627: voxel_feats Rows/[1,C,X,Y,Z], gemo [1,N,D,H,W,3] ->
     rgbs [N,16H,16W,3], depths [N,16H,16W] (+ the pre-upsample maps [N,H,W,4]).
     ``depth_only`` (or ``rgb_head=None``): the LiDAR-only branch (:436-484, geometry from ``get_frustum``) -- only the sigma
-    head is evaluated and only the depth maps are written; ``rgbs`` is None."""
+    head is evaluated and only the depth maps are written; ``rgbs`` is None.
+    ``cam_geo`` = (mats [N,39], xs [W], ys [H], ds [D]) (``ViewTransformer._camera_mats``) instead of ``gemo``: the ray kernel
+    evaluates get_geometry's chain in place (same bits), the [N,D,H,W,3] tensor is never read."""
     if depth_only or rgb_head is None:
         return _render_depth_only(sigma_head, voxel_feats, gemo, scale)
     from .core import to_rows
     vf = to_rows(voxel_feats)
-    B, N, D, H, W, _ = gemo.shape
-    assert B == 1 and vf.B == 1
+    if cam_geo is not None:
+        mats, xs, ys, ds = cam_geo
+        N, D, H, W = mats.shape[0], ds.numel(), ys.numel(), xs.numel()
+        g = None
+        dev = mats.device
+    else:
+        B, N, D, H, W, _ = gemo.shape
+        assert B == 1
+        g = gemo.reshape(N, D, H, W, 3).float().contiguous()
+        dev = g.device
+    assert vf.B == 1
     table = voxel_table(sigma_head, rgb_head, vf)
-    g = gemo.reshape(N, D, H, W, 3).float().contiguous()
-    dev = g.device
     zvals = torch.linspace(0, D, D, device=dev)
     maps = torch.empty(N, H, W, 4, device=dev, dtype=_F32)
     from .core import TIMER
@@ -129,13 +138,17 @@ def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16, depth_only=F
     per = -(-N // chunks)
     cur = torch.cuda.current_stream(dev)
     side = _render_side(dev, cur) if chunks > 1 else None
-    by_rays = 12.0 * N * D * H * W + 16.0 * vf.V + 16.0 * N * H * W
+    by_rays = (12.0 * N * D * H * W if g is not None else 0.0) + 16.0 * vf.V + 16.0 * N * H * W
     by_up = 16.0 * N * H * W + 16.0 * N * H * W * scale * scale
     with TIMER.region("k_render_nearest+k_upsample_maps", by_rays + by_up):
         for c0 in range(0, N, per):
             nc = min(per, N - c0)
-            call("coocc_render_nearest", ptr(table), vf.X, vf.Y, vf.Z, ptr(g[c0:c0 + nc]), ptr(zvals), nc, D, H, W,
-                 host_f32(RENDER_BOUNDS), 1, ptr(maps[c0:c0 + nc]))
+            if g is None:
+                call("coocc_render_nearest_cams", ptr(table), vf.X, vf.Y, vf.Z, ptr(mats[c0:c0 + nc]), ptr(xs), ptr(ys), ptr(ds),
+                     ptr(zvals), nc, D, H, W, host_f32(RENDER_BOUNDS), 1, ptr(maps[c0:c0 + nc]))
+            else:
+                call("coocc_render_nearest", ptr(table), vf.X, vf.Y, vf.Z, ptr(g[c0:c0 + nc]), ptr(zvals), nc, D, H, W,
+                     host_f32(RENDER_BOUNDS), 1, ptr(maps[c0:c0 + nc]))
             if side is None:
                 call("coocc_upsample_maps", ptr(maps[c0:c0 + nc]), nc, H, W, scale, ptr(rgbs[c0:c0 + nc]), ptr(depths[c0:c0 + nc]))
             else:

@@ -529,6 +529,13 @@ int coocc_bev_pool_coords(const float* x, const int64_t* coords, int n, int C, i
 int coocc_render_nearest(const float* table, int X, int Y, int Z, const float* geom,
                          const float* zvals, int N, int D, int H, int W, const float* bounds_host,
                          int activated, float* maps, void* stream);
+/* The same composite with the sample positions evaluated IN the kernel from the camera constants (coocc_camera_mats) and the
+ * frustum axes -- get_geometry's chain (ViewTransformerLSSBEVDepth.py:117-150), bit for bit -- instead of read from the
+ * [N,D,H,W,3] geometry tensor: 12 bytes per sample less HBM traffic ("if geometry is computed in-kernel the geom
+ * term is dropped"). */
+int coocc_render_nearest_cams(const float* table, int X, int Y, int Z, const float* mats, const float* xs, const float* ys,
+                              const float* ds, const float* zvals, int N, int D, int H, int W,
+                              const float* bounds_host, int activated, float* maps, void* stream);
 /* sigmoid of the rgb logits once per voxel, in place on columns 1..3 of table:[V,4] (3 exp + 3 rcp per voxel
  * instead of per ray sample). */
 int coocc_render_activate_table(float* table, int V, void* stream);

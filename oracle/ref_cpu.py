@@ -246,7 +246,7 @@ def project_points_on_img(points, rots, trans, intrins, post_rots, post_trans, b
 
 
 def occhead_forward(sd, voxel_feats, img_feats, transform, cascade_ratio=2, final_occ_size=(200, 200, 16),
-                    point_cloud_range=(-50, -50, -5.0, 50, 50, 3.0), empty_idx=0, soft_weights=True):
+                    point_cloud_range=(-50, -50, -5.0, 50, 50, 3.0), empty_idx=0, soft_weights=True, fine_subset=None):
     """C3+C4: ``OccHead.forward`` eval branch (occ_head.py:173-265) with
     sample_from_voxel and sample_from_img, nuScenes data type, B == 1.
 
@@ -262,6 +262,13 @@ def occhead_forward(sd, voxel_feats, img_feats, transform, cascade_ratio=2, fina
     _, W, H, D = mask.shape
     coarse_coord = torch.nonzero(mask[0]).t()                  # [3,N] ascending (x,y,z) == masked meshgrid
     fine = coarse_to_fine_coordinates(coarse_coord, cascade_ratio)
+    fine_all = fine
+    if fine_subset is not None:
+        # test hook for grids whose fine branch has ~1e7 points (OpenOccupancy, cascade 4): every fine point is an independent
+        # row of the branch, so evaluating a subset of the columns gives exactly the rows of the full evaluation.
+        # fine_subset: callable(n_fine) -> LongTensor of column indices
+        sel = fine_subset(fine.shape[1]) if callable(fine_subset) else fine_subset
+        fine = fine[:, sel]
     dt = ovf.dtype
     new_coord = fine[None].permute(0, 2, 1).to(dt).contiguous()
     g = fine.to(dt)
@@ -288,7 +295,7 @@ def occhead_forward(sd, voxel_feats, img_feats, transform, cascade_ratio=2, fina
     x = F.linear(x, sd["fine_mlp.0.weight"], sd["fine_mlp.0.bias"])
     x = F.relu(F.group_norm(x, 16, sd["fine_mlp.1.weight"], sd["fine_mlp.1.bias"]))
     x = F.linear(x, sd["fine_mlp.3.weight"], sd["fine_mlp.3.bias"])
-    res.update(fine_output=x, fine_coord=fine)
+    res.update(fine_output=x, fine_coord=fine, fine_coord_all=fine_all)
     return res
 
 
@@ -524,7 +531,7 @@ def get_weights(sigma, z_vals):
 # --------------------------------------------------------------------------- whole path
 def hot_path_forward(sd, img_voxel_feats, pts_voxel_feats, gemo, img_feats, transform, knum=2,
                      cascade_ratio=2, final_occ_size=(200, 200, 16), literal_render=True, dtype=None,
-                     point_cloud_range=(-50, -50, -5.0, 50, 50, 3.0), render=True):
+                     point_cloud_range=(-50, -50, -5.0, 50, 50, 3.0), render=True, fine_subset=None):
     """``COOCC_Ray.simple_test`` between the encoders and the metrics (coocc_ray.py:523-627)
     with ``test_rendering=True``: fuser -> encoder -> neck -> head -> render.
     ``dtype=torch.float64`` evaluates the same restatement in double precision (the anchor of the fp32 parity tests)."""
@@ -535,12 +542,12 @@ def hot_path_forward(sd, img_voxel_feats, pts_voxel_feats, gemo, img_feats, tran
     mid = resnet3d_forward(_sub(sd, "semantic_encoder."), vf)
     sem = fpn3d_forward(_sub(sd, "semantic_neck."), mid)
     head = occhead_forward(_sub(sd, "pts_bbox_head."), sem, img_feats, transform, cascade_ratio, final_occ_size,
-                           point_cloud_range)
+                           point_cloud_range, fine_subset=fine_subset)
     rgbs = depths = None
     if render:
         rgbs, depths = render_block(_sub(sd, "sigma_head."), _sub(sd, "rgb_head."), vf, gemo, literal_render)
     return dict(voxel_feats=vf, output_voxels=head["output_voxels"], fine_output=head["fine_output"],
-                fine_coord=head["fine_coord"], rgbs=rgbs, depths=depths)
+                fine_coord=head["fine_coord"], fine_coord_all=head.get("fine_coord_all"), rgbs=rgbs, depths=depths)
 
 
 def fast_hist(pred, label, max_label=18):

