@@ -664,9 +664,10 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs set aside for the FPS chains (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL on GPUs)")
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (single-GPU check of the N > 1 path, gloo)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
                     help="f32: exact-fp32 MFMA (the parity path).  bf16: C0-C3 run k_conv_bf16 (operands rounded to bf16, fp32 "
-                         "accumulate / epilogue / storage, direct form) -- the reduced-precision path of configs[4]")
+                         "accumulate / epilogue / storage, direct form) -- round 2's reduced-precision path of configs[4].  f16: the same layers on "
+                         "v_mfma_f32_32x32x16_f16 with f16 operands in HBM (2 bytes per element), written by the producing layer's epilogue")
     ap.add_argument("--no-pool", action="store_true",
                     help="start the step from an already-pooled camera volume (round-1 definition) instead of the lifted "
                          "depth/context pair (SURVEY.md 8d: 'lifted features + sweep volume -> logits')")

@@ -24,7 +24,7 @@ class ConvDesc(ctypes.Structure):
                [(n, c_int) for n in ("M", "Cin", "Cout", "taps", "in_stride", "out_stride", "res_stride",
                                      "B", "Xi", "Yi", "Zi", "Xo", "Yo", "Zo", "ksize", "stride", "pad",
                                      "relu", "res_mode", "splitk", "tile_hint", "kx", "ky", "kz", "px", "py", "pz",
-                                     "wgroup_rows", "mfma_dtype")] + [("alpha", ctypes.c_float), ("M_dev", c_void_p), ("gather_stride", c_int), ("out_h2", c_int)]
+                                     "wgroup_rows", "mfma_dtype")] + [("alpha", ctypes.c_float), ("M_dev", c_void_p), ("gather_stride", c_int), ("out16", c_void_p), ("out16_stride", c_int), ("out_h2", c_int)]
 
 
 class SearchDesc(ctypes.Structure):
@@ -48,6 +48,7 @@ SIGNATURES = {
     "coocc_rows_to_bf16": (I, [P, I, L, I, P, P]),
     "coocc_rows_to_h2": (I, [P, I, L, I, F, P, P]),
     "coocc_rows_to_h2_gather": (I, [P, I, P, L, P, I, F, P, P]),
+    "coocc_rows_to_f16": (I, [P, I, L, I, P, P]),
     "coocc_wino_input_h2": (I, [P, I, I, I, I, I, I, I, P, I, L, F, P]),
     "coocc_ndhwc_to_ncdhw": (I, [P, P, I, I, I, I, I, P]),
     "coocc_fuser_prepare": (I, [P, P, P, P, P, I, I, I, P]),

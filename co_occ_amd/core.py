@@ -74,10 +74,11 @@ def conv_kernel_name(M, Cout, table, hint=0, iters=1 << 30, one_by_one=False):
 class Rows:
     """A dense voxel volume as channels-last rows: t[B*X*Y*Z, stride], C channels at `coff`."""
 
-    __slots__ = ("t", "B", "X", "Y", "Z", "C", "coff")
+    __slots__ = ("t", "B", "X", "Y", "Z", "C", "coff", "h16")
 
     def __init__(self, t, B, X, Y, Z, C, coff=0):
         self.t, self.B, self.X, self.Y, self.Z, self.C, self.coff = t, B, X, Y, Z, C, coff
+        self.h16 = None       # f16 twin [B*V, C] written by the producing convolution's epilogue (CONV_DTYPE == "f16")
 
     @property
     def stride(self):
@@ -235,6 +236,25 @@ class PackedConv:
             wp = torch.zeros(npad, self.Cin, w.shape[2], dtype=torch.float64)
             wp[:self.Cout] = w.double()
             self._bf16[key] = self._h2_layout(wp).to(self.w.device)
+        return self._bf16[key]
+
+    def h1_pack(self, ztrim=None):
+        """One-term f16 pack (mfma_dtype 4): [(Cin/64 chunk, tap)][Npad/32][4 k16 steps][64 lanes][8 f16], RNE; all taps or the z
+        taps lo..hi of a 3x3x3 kernel.  None when Cin % 64."""
+        if self._w_taps is None or self.Cin % 64:
+            return None
+        key = ("h1", ztrim)
+        if key not in self._bf16:
+            w = self._w_taps
+            if ztrim is not None:
+                w = self._w_cube[:, :, :, :, ztrim[0]:ztrim[1] + 1].reshape(self.Cout, self.Cin, -1)
+            taps = w.shape[2]
+            npad = -(-self.Cout // 128) * 128
+            wp = torch.zeros(npad, self.Cin, taps, dtype=_F32)
+            wp[:self.Cout] = w
+            # nt, li, chunk, s, hf, e, t -> chunk, t, nt, s, hf, li, e        (k = 64 chunk + 16 s + 8 hf + e)
+            pack = wp.view(npad // 32, 32, self.Cin // 64, 4, 2, 8, taps).permute(2, 6, 0, 3, 4, 1, 5)
+            self._bf16[key] = pack.contiguous().to(torch.float16).to(self.w.device)
         return self._bf16[key]
 
     def wino_h2_pack(self, tile):
@@ -439,7 +459,8 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
     assert x.C == pc.Cin, "channel mismatch: %d vs %d" % (x.C, pc.Cin)
     rm = res_mode or (1 if res is not None else 0)
     bf16 = CONV_DTYPE == "bf16"
-    plan = None if bf16 else wino_plan(x, pc, M, rm)
+    f16 = CONV_DTYPE == "f16"
+    plan = None if (bf16 or f16) else wino_plan(x, pc, M, rm)
     if plan is not None:
         return conv_rows_wino(x, pc, out, relu, res, plan)
     ws = workspace(x.t.device)
@@ -470,7 +491,24 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
             d.kx, d.ky, d.kz, d.px, d.py, d.pz = 3, 3, hi - lo + 1, pc.pad, pc.pad, pc.pad - lo
             d.taps = taps = 9 * (hi - lo + 1)
     same = pc.stride == 1 and (Xo, Yo, Zo) == (x.X, x.Y, x.Z)
-    if (not bf16 and CONV_ENGINE == "h2" and H2_DIRECT and pc.Cin % 32 == 0 and pc._w_taps is not None
+    if f16 and pc.Cin % 64 == 0 and pc._w_taps is not None and rm in (0, 1) and splitk in (0, 1) and out.coff == 0 and out.stride == pc.Cout:
+        # configs[4]'s reduced-precision path: ONE v_mfma_f32_32x32x16_f16 per step on f16 operands that live in HBM as f16 rows
+        # (2 bytes per element) -- written by the PRODUCER's epilogue (out16; Rows.h16) or, for inputs that came from a non-conv
+        # kernel, by one conversion pass -- fp32 accumulate / BN / residual / ReLU; the fp32 rows are written as well (the
+        # resampling / mixing / fine-branch kernels and the residual adds read those).  Direct form (no Winograd: its transform
+        # constants cost bits f16 does not have).
+        xh = x.h16
+        if xh is None:
+            xh = torch.empty(x.B * x.V, pc.Cin, device=x.t.device, dtype=torch.float16)
+            call("coocc_rows_to_f16", x.data(), x.stride, x.B * x.V, pc.Cin, ptr(xh))
+        out.h16 = torch.empty(M, pc.Cout, device=x.t.device, dtype=torch.float16) if pc.Cout % 4 == 0 else None
+        d.in_, d.in_stride, d.w, d.mfma_dtype, d.alpha, d.splitk = ptr(xh), pc.Cin, ptr(pc.h1_pack(trim)), 4, 1.0, 1
+        if out.h16 is not None:
+            d.out16, d.out16_stride = ptr(out.h16), pc.Cout
+        with TIMER.region("k_gemm_h1z" if (same and taps > 1) else "k_gemm_h1w", 2.0 * M * pc.Cin * pc.Cout * taps):
+            _lib.conv_fwd(d, pc.w.device)
+        return out
+    if (not bf16 and not f16 and CONV_ENGINE == "h2" and H2_DIRECT and pc.Cin % 32 == 0 and pc._w_taps is not None
             and rm in (0, 1) and 2.0 * M * pc.Cin * pc.Cout * taps >= H2_DIRECT_MIN_FLOPS):
         # fp32-accurate split-f16 GEMM (csrc/gemm_h2.hip) for the layers the Winograd path leaves out (small grids, strided,
         # 1x1x1): the input rows are split into H2 rows once per layer, stride-1 "same" layers share one LDS image per 3 z taps

@@ -1188,9 +1188,9 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   memset(&k, 0, sizeof(k));
   k.in = d->in; k.w = d->w; k.out = d->out; k.scale = d->scale; k.bias = d->bias; k.res = d->res;
   k.gather = d->gather; k.out_rows = d->out_rows; k.ws = d->ws;
-  k.M_dev = (d->gather || d->mfma_dtype == 3) ? d->M_dev : nullptr;
+  k.M_dev = (d->gather || d->mfma_dtype >= 3) ? d->M_dev : nullptr;
   k.gstride = d->gather_stride > 0 ? d->gather_stride : d->M;
-  COOCC_CHECK_ARG(!d->M_dev || ((d->gather || d->mfma_dtype == 3) && d->splitk == 1), "conv_fwd: M_dev needs a row table (gather) or mfma_dtype 3, and splitk = 1");
+  COOCC_CHECK_ARG(!d->M_dev || ((d->gather || d->mfma_dtype >= 3) && d->splitk == 1), "conv_fwd: M_dev needs a row table (gather) or mfma_dtype 3, and splitk = 1");
   COOCC_CHECK_ARG(k.gstride >= d->M, "conv_fwd: gather_stride smaller than M");
   k.M = d->M; k.Cin = d->Cin; k.Cout = d->Cout; k.taps = d->taps;
   k.kchunks = (d->Cin + KC - 1) / KC;
@@ -1204,7 +1204,7 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   k.wgroup_floats = (size_t)k.taps * k.kchunks * k.Npad * KC;
   k.relu = d->relu; k.res_mode = d->res_mode;
   k.total_iters = k.taps * k.kchunks;
-  if (d->mfma_dtype == 3) {      // H2 operands (fp32 split into two f16 halves): gemm_h2.hip
+  if (d->mfma_dtype == 3 || d->mfma_dtype == 4) {      // H2 operands (fp32 split into two f16 halves) / one-term f16 operands: gemm_h2.hip
     hipStream_t s3 = as_stream(stream);
     const int rc = coocc_launch_h2(k, d, s3);
     if (rc != COOCC_OK) return rc;

@@ -21,6 +21,8 @@ struct ConvK {
   const int32_t* M_dev;         // row-table kernels: actual row count on the device (<= M, the grid's capacity), or NULL
   int gstride;                  // row-table kernels: entries per tap of `gather` (>= M)
   int out_h2;                   // split-f16 kernels: write the output rows in H2 format (the next layer's operand)
+  void* out16;                  // split-f16 / f16 kernels: second, f16 copy of the output rows, or NULL
+  int out16_stride;             // its row stride in f16 elements
 };
 
 __device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t rrow) {

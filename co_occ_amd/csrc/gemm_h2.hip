@@ -69,9 +69,19 @@ __device__ __forceinline__ void store_h2(float* out, size_t row, int out_stride,
   *(f16x4*)o = hi;
   *(f16x4*)(o + 64) = lo;
 }
+// epilogue option out16: a second, f16 copy of the output rows ([rows][out16_stride] f16) -- the operand of the next layer on the
+// one-term f16 path, written by the producer instead of a conversion pass
+__device__ __forceinline__ void store_f16(void* out16, size_t row, int stride, int n, f32x4 v) {
+  f16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+  *(f16x4*)((char*)out16 + (row * (size_t)stride + n) * 2) = o;
+}
 #define H2_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ const char* inb_(const ConvK& p) { return (const char*)p.in; }
-template <int KZ, bool XY, int ABL = 0>    // ABL (timing ablations, wrong results): 1 no A image, 2 no weight loads, 4 no fragment reads, 8 no stores
+// TERMS = 3: split operands (H2 rows, fp32-accurate); TERMS = 1: plain f16 operands ("H1 rows": [rows][C] f16, 64 channels per
+// 128-byte LDS row, four k16 steps per stage, one MFMA per step) -- the reduced-precision path of configs[4].
+template <int KZ, bool XY, int ABL = 0, int TERMS = 3>    // ABL (timing ablations, wrong results): 1 no A image, 2 no weight loads, 4 no fragment reads, 8 no stores
 __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
   constexpr int BM = 128, TM = 4;
   constexpr int AROWS = 136;                       // 128 + KZ - 1 rounded up to whole 8-row wave instructions
@@ -103,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
   // everything the K loop needs in registers (a field of `p` read inside the loop is a scalar load whose lgkmcnt(0) also waits
   // for the LDS reads in flight)
   const int kx = p.kx, ky = p.ky, px = p.px, py = p.py, Xi = p.Xi, Yi = p.Yi, Zi = p.Zi;
-  const unsigned rowbytes = (unsigned)p.in_stride * 4;
+  const unsigned rowbytes = (unsigned)p.in_stride * (TERMS == 3 ? 4 : 2);
   const int total_rows = Xi * Yi * Zi * (p.M / (p.Xo * p.Yo * p.Zo));
   const char* zrow = (const char*)p.zrow;
   // staging: LDS row r holds input row  m0 + r - pz + ((dx - px) Yi + (dy - py)) Zi  (any row of the buffer, else zeros).
@@ -170,13 +180,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
   for (int dz = 0; dz < KZ; ++dz)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int sl = (q & 1) * 4 + 2 * (q >> 1) + h;            // q = 2 s + plane
+      const int sl = TERMS == 3 ? (q & 1) * 4 + 2 * (q >> 1) + h : 2 * q + h;            // TERMS 3: q = 2 s + plane; TERMS 1: q = k16 step
       fragoff[dz][q] = (li + dz) * 128 + ((sl ^ (((li + dz) >> 1) & 7)) << 4);
     }
-  f16x8 fhi[TM], flo[TM];
+  f16x8 fr[TERMS == 3 ? 2 : 4][TM];          // TERMS 3: A_hi / A_lo of the current step; TERMS 1: the fragments of four k16 steps
   if (ABL & 4) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) { fhi[i] = *(const f16x8*)&As[lane * 16 + i * 64]; flo[i] = *(const f16x8*)&As[lane * 16 + i * 64 + 32]; }
+    for (int i = 0; i < TM; ++i) { fr[0][i] = *(const f16x8*)&As[lane * 16 + i * 64]; fr[1][i] = *(const f16x8*)&As[lane * 16 + i * 64 + 32]; }
   }
   if (ABL & 2) {
 #pragma unroll
@@ -188,17 +198,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
   }
   // a lane whose output voxel's tap leaves the grid reads the zero row instead: one select on the LDS address, the loads stay
   // unconditional (hipcc turns "ok ? fragment : 0" into a branch around the loads)
-  auto load_plane = [&](auto planec, auto stagec, auto dzc, auto sc, unsigned bits) {
-    constexpr int PL = decltype(planec)::value, ST = decltype(stagec)::value, DZ = decltype(dzc)::value, S_ = decltype(sc)::value;
+  auto load_frag = [&](auto bufc, auto stagec, auto dzc, auto qc, unsigned bits) {
+    constexpr int BUF = decltype(bufc)::value, ST = decltype(stagec)::value, DZ = decltype(dzc)::value, Q = decltype(qc)::value;
     if (ABL & 4) return;
     asm volatile("" : "+v"(bits));      // keep the address selects here: hoisted out of the K loop they are dozens of live registers
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const bool ok = (bits >> (i * 3 + DZ)) & 1;
-      const unsigned a = ok ? fragoff[DZ][2 * S_ + PL] + (ST * STAGE + i * 4096) : (ZOFF | (fragoff[DZ][2 * S_ + PL] & 255u));
-      if (PL == 0) fhi[i] = *(const f16x8*)&As[a];
-      else flo[i] = *(const f16x8*)&As[a];
+      const unsigned a = ok ? fragoff[DZ][Q] + (ST * STAGE + i * 4096) : (ZOFF | (fragoff[DZ][Q] & 255u));
+      fr[BUF][i] = *(const f16x8*)&As[a];
     }
+  };
+  auto load_plane = [&](auto planec, auto stagec, auto dzc, auto sc, unsigned bits) {
+    constexpr int PL = decltype(planec)::value, S_ = decltype(sc)::value;
+    load_frag(planec, stagec, dzc, std::integral_constant<int, 2 * S_ + PL>{}, bits);
   };
 
   f32x16 hh[TM], xx[TM];
@@ -209,14 +222,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
   auto p01 = [&](auto setc, auto sc) {
     constexpr int B_ = decltype(setc)::value, S_ = decltype(sc)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) hh[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], fhi[i], hh[i], 0, 0, 0);
+    for (int i = 0; i < TM; ++i) hh[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], fr[0][i], hh[i], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][1], fhi[i], xx[i], 0, 0, 0);
+    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][1], fr[0][i], xx[i], 0, 0, 0);
   };
   auto p2 = [&](auto setc, auto sc) {
     constexpr int B_ = decltype(setc)::value, S_ = decltype(sc)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], flo[i], xx[i], 0, 0, 0);
+    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], fr[1][i], xx[i], 0, 0, 0);
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
 
@@ -229,6 +242,31 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
     using DZC = std::integral_constant<int, DZ>; using DZN = std::integral_constant<int, (DZ + 1 < KZ ? DZ + 1 : 0)>;
     using BBC = std::integral_constant<int, BB>;
     if (more_taps) loadB(std::integral_constant<int, BB ^ 1>{});
+    if constexpr (TERMS == 1) {
+      // four k16 steps, two per phase: steps 2, 3 are fetched under steps 0, 1; the first two steps of the next tap (or of the next
+      // group, behind the barrier) under steps 2, 3
+      using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+      auto pq = [&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) hh[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[BB][Q >> 1][Q & 1], fr[Q][i], hh[i], 0, 0, 0);
+      };
+      load_frag(I2{}, STC{}, DZC{}, I2{}, okbits);
+      load_frag(I3{}, STC{}, DZC{}, I3{}, okbits);
+      pq(I0{}); pq(I1{});
+      H2_FENCE();
+      if constexpr (DZ + 1 < KZ) {
+        load_frag(I0{}, STC{}, DZN{}, I0{}, okbits);
+        load_frag(I1{}, STC{}, DZN{}, I1{}, okbits);
+      } else {
+        __syncthreads();
+        load_frag(I0{}, SNC{}, I0{}, I0{}, okbits_next);
+        load_frag(I1{}, SNC{}, I0{}, I1{}, okbits_next);
+      }
+      pq(I2{}); pq(I3{});
+      H2_FENCE();
+      return;
+    }
     load_plane(I1{}, STC{}, DZC{}, I0{}, okbits);
     p01(BBC{}, I0{});
     H2_FENCE();
@@ -278,7 +316,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
     loadB(I0{});
   }
   __syncthreads();
-  if (ngroups > 0) load_plane(I0{}, I0{}, I0{}, I0{}, okbits);
+  if (ngroups > 0) {
+    load_frag(I0{}, I0{}, I0{}, I0{}, okbits);
+    if (TERMS == 1) load_frag(I1{}, I0{}, I0{}, I1{}, okbits);
+  }
   for (int g = 0; g < ngroups; g += 2) {
     group(I0{}, g);
     if (g + 1 < ngroups) group(I1{}, g + 1);
@@ -286,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
 
   // epilogue: lane (li, h) holds, for output row m0 + i*32 + li, the channels n0 + 32 wave + 8 j + 4 h + 0..3 (j = 0..3)
   const int nb = n0 + wave * 32 + 4 * h;
-  const float alpha = p.alpha, lo = p.alpha * (1.f / H2_LO_SCALE);
+  const float alpha = p.alpha, lo = TERMS == 3 ? p.alpha * (1.f / H2_LO_SCALE) : 0.f;
   if (p.splitk > 1) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -297,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
       for (int j = 0; j < 4; ++j) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo;
+        for (int e = 0; e < 4; ++e) v[e] = (TERMS == 3 ? hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo : hh[i][4 * j + e] * alpha);
         *(f32x4*)(o + 8 * j) = v;
       }
     }
@@ -314,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
         if ((ABL & 8) && hh[i][4 * j] != 12345.f) continue;
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo;
+        for (int e = 0; e < 4; ++e) v[e] = (TERMS == 3 ? hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo : hh[i][4 * j + e] * alpha);
         if (vec) {
           if (p.res_mode == 3) v = v + *(const f32x4*)(p.res + (size_t)m * p.res_stride + n);
           if (p.scale) v = v * *(const f32x4*)(p.scale + n);
@@ -324,6 +365,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
           if (p.res_mode == 2) v = v * *(const f32x4*)(p.res + (size_t)m * p.res_stride + n);
           if (p.out_h2) store_h2(p.out, (size_t)m, p.out_stride, n, v);
           else *(f32x4*)(p.out + (size_t)m * p.out_stride + n) = v;
+          if (p.out16) store_f16(p.out16, (size_t)m, p.out16_stride, n, v);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -338,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
 // per-lane addresses: the strided and 1x1x1 layers) and row tables (TABLE: input row of (tap t, output m) = gather[t * gstride + m];
 // row count optionally on the device).  Same tile, transposed MFMA order, phases and epilogue as k_gemm_h2z; rows that fall
 // outside the grid (or table entries < 0) are fetched from the zero row, so no fragment needs masking.
-template <bool TABLE>
+template <bool TABLE, int TERMS = 3>
 __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
   constexpr int BM = 128, TM = 4;
   constexpr unsigned STAGE = BM * 128;
@@ -367,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
   const int srow = lane >> 3, slot = lane & 7;
 
   const int kx = p.kx, ky = p.ky, kz = p.kz, Xi = p.Xi, Yi = p.Yi, Zi = p.Zi, taps = p.taps;
-  const long long rowbytes = (long long)p.in_stride * 4;
+  const long long rowbytes = (long long)p.in_stride * (TERMS == 3 ? 4 : 2);
   const char* inb = (const char*)p.in;
   const char* zrow = (const char*)p.zrow;
   const unsigned aq = (unsigned)((slot ^ ((4 * (wave & 1) + (srow >> 1)) & 7)) * 16);
@@ -437,17 +479,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
   unsigned fragoff[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int sl = (q & 1) * 4 + 2 * (q >> 1) + h;            // q = 2 s + plane
+    const int sl = TERMS == 3 ? (q & 1) * 4 + 2 * (q >> 1) + h : 2 * q + h;            // TERMS 3: q = 2 s + plane; TERMS 1: q = k16 step
     fragoff[q] = li * 128 + ((sl ^ ((li >> 1) & 7)) << 4);
   }
-  f16x8 fhi[TM], flo[TM];
-  auto load_plane = [&](auto planec, auto stagec, auto sc) {
-    constexpr int PL = decltype(planec)::value, ST = decltype(stagec)::value, S_ = decltype(sc)::value;
+  f16x8 fr[TERMS == 3 ? 2 : 4][TM];
+  auto load_frag = [&](auto bufc, auto stagec, auto qc) {
+    constexpr int BUF = decltype(bufc)::value, ST = decltype(stagec)::value, Q = decltype(qc)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      if (PL == 0) fhi[i] = *(const f16x8*)&As[fragoff[2 * S_ + PL] + (ST * STAGE + i * 4096)];
-      else flo[i] = *(const f16x8*)&As[fragoff[2 * S_ + PL] + (ST * STAGE + i * 4096)];
-    }
+    for (int i = 0; i < TM; ++i) fr[BUF][i] = *(const f16x8*)&As[fragoff[Q] + (ST * STAGE + i * 4096)];
+  };
+  auto load_plane = [&](auto planec, auto stagec, auto sc) {
+    constexpr int PL = decltype(planec)::value, S_ = decltype(sc)::value;
+    load_frag(planec, stagec, std::integral_constant<int, 2 * S_ + PL>{});
   };
   f32x16 hh[TM], xx[TM];
 #pragma unroll
@@ -457,14 +500,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
   auto p01 = [&](auto setc, auto sc) {
     constexpr int B_ = decltype(setc)::value, S_ = decltype(sc)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) hh[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], fhi[i], hh[i], 0, 0, 0);
+    for (int i = 0; i < TM; ++i) hh[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], fr[0][i], hh[i], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][1], fhi[i], xx[i], 0, 0, 0);
+    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][1], fr[0][i], xx[i], 0, 0, 0);
   };
   auto p2 = [&](auto setc, auto sc) {
     constexpr int B_ = decltype(setc)::value, S_ = decltype(sc)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], flo[i], xx[i], 0, 0, 0);
+    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], fr[1][i], xx[i], 0, 0, 0);
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   // one (chunk, tap) iteration in stage ST (= weight set ST); A_hi of its first step is already in registers
@@ -472,6 +515,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
     constexpr int ST = decltype(stc)::value;
     using STC = std::integral_constant<int, ST>; using SNC = std::integral_constant<int, ST ^ 1>;
     if (more) { issueA(ST ^ 1); loadB(SNC{}); }
+    if constexpr (TERMS == 1) {
+      using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+      auto pq = [&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) hh[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[ST][Q >> 1][Q & 1], fr[Q][i], hh[i], 0, 0, 0);
+      };
+      load_frag(I2{}, STC{}, I2{});
+      load_frag(I3{}, STC{}, I3{});
+      pq(I0{}); pq(I1{});
+      H2_FENCE();
+      __syncthreads();
+      if (more) { load_frag(I0{}, SNC{}, I0{}); load_frag(I1{}, SNC{}, I1{}); }
+      pq(I2{}); pq(I3{});
+      H2_FENCE();
+      return;
+    }
     load_plane(I1{}, STC{}, I0{});
     p01(STC{}, I0{});
     H2_FENCE();
@@ -491,7 +551,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
     loadB(I0{});
   }
   __syncthreads();
-  if (nsteps > 0) load_plane(I0{}, I0{}, I0{});
+  if (nsteps > 0) {
+    load_frag(I0{}, I0{}, I0{});
+    if (TERMS == 1) load_frag(I1{}, I0{}, I1{});
+  }
   for (int st = 0; st < nsteps; st += 2) {
     step(I0{}, st + 1 < nsteps);
     if (st + 1 < nsteps) step(I1{}, st + 2 < nsteps);
@@ -499,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
 
   // epilogue: lane (li, h) holds, for output row m0 + i*32 + li, the channels n0 + 32 wave + 8 j + 4 h + 0..3 (j = 0..3)
   const int nb = n0 + wave * 32 + 4 * h;
-  const float alpha = p.alpha, lo = p.alpha * (1.f / H2_LO_SCALE);
+  const float alpha = p.alpha, lo = TERMS == 3 ? p.alpha * (1.f / H2_LO_SCALE) : 0.f;
   if (p.splitk > 1) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -510,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
       for (int j = 0; j < 4; ++j) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo;
+        for (int e = 0; e < 4; ++e) v[e] = (TERMS == 3 ? hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo : hh[i][4 * j + e] * alpha);
         *(f32x4*)(o + 8 * j) = v;
       }
     }
@@ -527,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
         if (n >= p.Cout) continue;
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo;
+        for (int e = 0; e < 4; ++e) v[e] = (TERMS == 3 ? hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo : hh[i][4 * j + e] * alpha);
         if (vec) {
           if (p.res_mode == 3) v = v + *(const f32x4*)(p.res + orow * p.res_stride + n);
           if (p.scale) v = v * *(const f32x4*)(p.scale + n);
@@ -537,6 +600,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
           if (p.res_mode == 2) v = v * *(const f32x4*)(p.res + orow * p.res_stride + n);
           if (p.out_h2) store_h2(p.out, orow, p.out_stride, n, v);
           else *(f32x4*)(p.out + orow * p.out_stride + n) = v;
+          if (p.out16) store_f16(p.out16, orow, p.out16_stride, n, v);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -548,7 +612,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
 }
 
 int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
-  COOCC_CHECK_ARG(d->Cin % 32 == 0 && d->in_stride % 32 == 0, "conv_fwd: H2 operands need Cin % 32 == 0 and in_stride % 32 == 0");
+  const bool one = d->mfma_dtype == 4;          // one-term f16 operands ([rows][C] f16), 64 channels per stage
+  const int kc = one ? 64 : 32;
+  COOCC_CHECK_ARG(d->Cin % kc == 0 && d->in_stride % kc == 0, "conv_fwd: H2 operands need Cin and in_stride % 32 == 0 (f16 operands: % 64)");
+  COOCC_CHECK_ARG(!one || (d->wgroup_rows == 0 && !d->out_h2), "conv_fwd: the one-term f16 path has no weight groups / H2 output");
   COOCC_CHECK_ARG(d->wgroup_rows == 0 || d->wgroup_rows % 128 == 0, "conv_fwd: wgroup_rows must be a multiple of 128");
   const bool table = d->gather != nullptr;
   // stride-1 "same" geometry with <= 3 z taps: one LDS image per (chunk, dx, dy) serves the z taps (k_gemm_h2z); everything else
@@ -556,9 +623,13 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   const bool zshare = !table && !d->out_rows && !d->M_dev && k.stride == 1 && k.Xo == k.Xi && k.Yo == k.Yi && k.Zo == k.Zi && k.kz >= 1 && k.kz <= 3 &&
                       k.taps > 1;
   COOCC_CHECK_ARG(zshare || d->wgroup_rows == 0, "conv_fwd: weight groups need the stride-1 same geometry");
-  k.kchunks = d->Cin / 32;
+  k.kchunks = d->Cin / kc;
   k.total_iters = k.taps * k.kchunks;
   k.wgroup_floats = (size_t)k.taps * k.kchunks * k.Npad * 32;       // 128 bytes per (chunk, tap, column)
+  k.out16 = d->out16;
+  k.out16_stride = d->out16_stride;
+  COOCC_CHECK_ARG(!d->out16 || (d->Cout % 4 == 0 && d->out16_stride % 4 == 0 && !d->out_rows && ((uintptr_t)d->out16 & 7) == 0),
+                  "conv_fwd: out16 needs Cout % 4 == 0, out16_stride % 4 == 0, no row scatter");
   k.alpha = d->alpha != 0.f ? d->alpha : 1.f;
   k.M_dev = d->M_dev;
   k.out_h2 = d->out_h2;
@@ -576,7 +647,7 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   const int ngroups = k.total_iters / gsz;
   if (splitk <= 0) {
     splitk = 1;
-    if (blocks < 256 && ngroups >= 8 && d->ws && !d->M_dev && !d->out_rows && !d->out_h2) {
+    if (blocks < 256 && ngroups >= 8 && d->ws && !d->M_dev && !d->out_rows && !d->out_h2 && !d->out16) {
       splitk = (int)(512 / blocks);
       if (splitk > ngroups / 4) splitk = ngroups / 4;
       if (splitk > 64) splitk = 64;
@@ -591,14 +662,26 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
                   "conv_fwd: split-K workspace too small (or split-K with a device row count / row scatter)");
   dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
   if (!zshare) {
-    if (table) hipLaunchKernelGGL(k_gemm_h2w<true>, grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL(k_gemm_h2w<false>, grid, dim3(256), 0, s, k);
+    if (one) {
+      if (table) hipLaunchKernelGGL((k_gemm_h2w<true, 1>), grid, dim3(256), 0, s, k);
+      else hipLaunchKernelGGL((k_gemm_h2w<false, 1>), grid, dim3(256), 0, s, k);
+    } else {
+      if (table) hipLaunchKernelGGL(k_gemm_h2w<true>, grid, dim3(256), 0, s, k);
+      else hipLaunchKernelGGL(k_gemm_h2w<false>, grid, dim3(256), 0, s, k);
+    }
     COOCC_LAUNCH_CHECK("k_gemm_h2w");
     return COOCC_OK;
   }
   COOCC_CHECK_ARG((long long)d->M < (1ll << 30) && (136ull + 2ull * ((unsigned long long)k.Yi + 2) * k.Zi) * d->in_stride * 4ull < 0xFFFFFF00ull,
                   "conv_fwd: the split-f16 kernel addresses a tile's window with 32-bit byte offsets");
   const bool xy = !(k.kx == 1 && k.ky == 1 && k.px == 0 && k.py == 0);
+  if (one) {
+    if (k.kz == 3) { if (xy) hipLaunchKernelGGL((k_gemm_h2z<3, true, 0, 1>), grid, dim3(256), 0, s, k); else hipLaunchKernelGGL((k_gemm_h2z<3, false, 0, 1>), grid, dim3(256), 0, s, k); }
+    else if (k.kz == 2) { if (xy) hipLaunchKernelGGL((k_gemm_h2z<2, true, 0, 1>), grid, dim3(256), 0, s, k); else hipLaunchKernelGGL((k_gemm_h2z<2, false, 0, 1>), grid, dim3(256), 0, s, k); }
+    else { if (xy) hipLaunchKernelGGL((k_gemm_h2z<1, true, 0, 1>), grid, dim3(256), 0, s, k); else hipLaunchKernelGGL((k_gemm_h2z<1, false, 0, 1>), grid, dim3(256), 0, s, k); }
+    COOCC_LAUNCH_CHECK("k_gemm_h2z<f16>");
+    return COOCC_OK;
+  }
   static const int abl = getenv("COOCC_H2_ABLATE") ? atoi(getenv("COOCC_H2_ABLATE")) : 0;     // timing ablations (wrong results)
   if (abl && !xy && k.kz == 3) {
     switch (abl) {
@@ -669,5 +752,29 @@ extern "C" int coocc_rows_to_h2_gather(const float* in, int in_stride, const int
   hipLaunchKernelGGL(k_rows_to_h2, dim3(cdiv(n_cap * (C / 8), 256)), dim3(256), 0, as_stream(stream), in, in_stride, (long long)n_cap, C,
                      scale, (char*)out_h2, row_ids, n_dev);
   COOCC_LAUNCH_CHECK("k_rows_to_h2");
+  return COOCC_OK;
+}
+
+// fp32 rows -> f16 rows [rows][C] (RNE): the activation operand of the one-term f16 path when the producer did not write it (out16)
+__global__ __launch_bounds__(256) void k_rows_to_f16(const float* __restrict__ in, int in_stride, long long rows, int C, _Float16* __restrict__ out) {
+  const int c8 = C >> 3;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * c8) return;
+  const long long r = i / c8;
+  const int c = (int)(i - r * c8) * 8;
+  const f32x4 a = *(const f32x4*)(in + r * in_stride + c), b = *(const f32x4*)(in + r * in_stride + c + 4);
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = (_Float16)a[e]; o[4 + e] = (_Float16)b[e]; }
+  *(f16x8*)(out + r * C + c) = o;
+}
+
+extern "C" int coocc_rows_to_f16(const float* in, int in_stride, int64_t rows, int C, void* out_f16, void* stream) {
+  COOCC_CHECK_ARG(in && out_f16 && rows >= 0 && C > 0 && C % 8 == 0 && in_stride % 4 == 0 && in_stride >= C, "rows_to_f16: bad args");
+  COOCC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)out_f16 & 15) == 0, "rows_to_f16: pointers must be 16-byte aligned");
+  if (rows == 0) return COOCC_OK;
+  hipLaunchKernelGGL(k_rows_to_f16, dim3(cdiv(rows * (C / 8), 256)), dim3(256), 0, as_stream(stream), in, in_stride, (long long)rows, C,
+                     (_Float16*)out_f16);
+  COOCC_LAUNCH_CHECK("k_rows_to_f16");
   return COOCC_OK;
 }

@@ -209,12 +209,20 @@ typedef struct coocc_conv_desc {
                                 accumulation -- measured error vs fp64 is half that of mfma_dtype 0.  `in` = H2 rows
                                 (coocc_rows_to_h2 / coocc_wino_input_h2), `w` = H2 pack [(Cin/32 chunk, tap)][roundup(Cout,128)/32]
                                 [2 k16 steps][hi | lo][64 lanes][8 f16]; Cin % 32 == 0; any geometry or row table (stride-1 "same"
-                                layers with <= 3 z taps share one LDS image between the z taps); wgroup_rows a multiple of 128 */
+                                layers with <= 3 z taps share one LDS image between the z taps); wgroup_rows a multiple of 128;
+                             4: ONE-term f16 (the reduced-precision path of configs[4], coocc_multi_r101_openoccupancy.py + the fp16
+                                hooks coocc_ray.py:136,142,265 / fpn3d.py:69): `in` = f16 rows [rows][in_stride] (coocc_rows_to_f16 or a
+                                producer's out16), `w` = f16 pack [(Cin/64 chunk, tap)][roundup(Cout,128)/32][4 k16 steps][64 lanes][8 f16];
+                                fp32 accumulate / epilogue; Cin % 64 == 0; same kernels as 3 (csrc/gemm_h2.hip, TERMS = 1) */
   float alpha;            /* mfma_dtype 3: the accumulators are multiplied by alpha (1 / operand scale) before the epilogue; 0 = 1 */
   const int32_t* M_dev;   /* row-table launches (gather != NULL; mfma_dtype 3: any launch), splitk = 1: the number of rows read on the DEVICE (<= M; the grid
                              is sized for M = capacity and tiles past *M_dev leave at once) -- lets a captured hipGraph run over
                              voxel lists whose length is only known on the device; NULL: M rows */
   int gather_stride;      /* entries per tap of `gather` (0 = M) */
+  void* out16;            /* mfma_dtype 3 / 4: a second, f16 copy of the output rows ([rows][out16_stride] f16, after the epilogue) --
+                             16-bit activations written by the PRODUCER's epilogue: the next f16 layer reads 2 bytes per element and no
+                             conversion pass runs in between; NULL = none */
+  int out16_stride;
   int out_h2;             /* mfma_dtype 3: write the output as H2 rows (out_stride = channels per row, % 32 == 0) -- the producer's
                              epilogue emits the next split-f16 layer's operand, no conversion pass in between */
 } coocc_conv_desc;
@@ -234,6 +242,8 @@ int coocc_rows_to_bf16(const float* in, int in_stride, int64_t rows, int C, void
  * Replaces nothing in the reference (its convolutions are cuDNN fp32, resnet3d.py:34-64): it is how the same fp32 sums are
  * evaluated on the 16-bit matrix pipe. */
 int coocc_rows_to_h2(const float* in, int in_stride, int64_t rows, int C, float scale, void* out_h2, void* stream);
+/* fp32 rows -> f16 rows [rows][C], round to nearest even (C % 8 == 0): the operand of mfma_dtype 4 when no producer wrote it */
+int coocc_rows_to_f16(const float* in, int in_stride, int64_t rows, int C, void* out_f16, void* stream);
 /* out row j = H2(in[row_ids[j]] * scale), j < n_cap (n_dev != NULL: j < min(n_cap, *n_dev), the count read on the device) */
 int coocc_rows_to_h2_gather(const float* in, int in_stride, const int32_t* row_ids, int64_t n_cap, const int32_t* n_dev,
                             int C, float scale, void* out_h2, void* stream);

@@ -210,3 +210,47 @@ def test_openocc_end_to_end_vs_subsampled_oracle(dev):
         f.write("\n".join(lines) + "\n")
     for l in lines:
         print(l, flush=True)
+
+
+def _f16(x):
+    return x.to(torch.float16).float()
+
+
+@pytest.mark.parametrize("Cin,Cout,grid,k,stride,relu,use_res", [(128, 128, (24, 20, 10), 3, 1, True, True), (256, 128, (16, 18, 4), 3, 1, True, False),
+                                                                  (128, 256, (20, 20, 8), 3, 2, True, False), (512, 512, (13, 12, 2), 3, 1, True, True),
+                                                                  (1024, 1024, (7, 7, 1), 3, 1, True, True), (128, 256, (30, 20, 10), 1, 1, True, False),
+                                                                  (64, 160, (11, 9, 3), 3, 1, False, False)])
+def test_conv_f16_mfma_equals_conv_on_f16_rounded_operands(dev, monkeypatch, Cin, Cout, grid, k, stride, relu, use_res):
+    """mfma_dtype 4 (csrc/gemm_h2.hip with TERMS = 1: operands f16 in memory, ONE v_mfma_f32_32x32x16_f16 per step, fp32
+    accumulate / BN / residual / ReLU) against torch's conv on f16-ROUNDED operands: same rounding rule, only the accumulation
+    order differs.  The producer-side 16-bit copy (out16 -> Rows.h16) is the RNE rounding of the fp32 output, and a second
+    layer fed from it equals the layer fed from a fresh conversion."""
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout + 7)
+    X, Y, Z = grid
+    x = torch.randn(1, Cin, X, Y, Z, generator=g)
+    w = torch.randn(Cout, Cin, k, k, k, generator=g) * (2.0 / (Cin * k ** 3)) ** 0.5
+    bn = bn_like(Cout, g)
+    pad = k // 2
+    ref = bn(F.conv3d(_f16(x), _f16(w), stride=stride, padding=pad))
+    exact = bn(F.conv3d(x, w, stride=stride, padding=pad))
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref, exact = ref + res, exact + res
+    if relu:
+        ref, exact = F.relu(ref), F.relu(exact)
+    pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=k, stride=stride, pad=pad)
+    monkeypatch.setattr(core, "CONV_DTYPE", "f16")
+    out = core.conv_rows(rows_of(x, dev), pc, relu=relu, res=rows_of(res, dev) if use_res else None)
+    got = out.as_ncdhw().cpu()
+    assert_close(got, ref.detach(), tol=2e-5, what="f16-MFMA conv vs f16-rounded operands")
+    e = rel_err(got, exact.detach())
+    assert 1e-6 < e < 5e-3, e                      # it IS a reduced-precision result: ~2^-12 relative per operand
+    assert out.h16 is not None and out.h16.dtype == torch.float16
+    assert torch.equal(out.h16.cpu(), out.t.cpu().to(torch.float16))
+    if Cout % 64 == 0:                             # a second layer reads the producer's 16-bit copy: no conversion pass
+        w2 = torch.randn(64, Cout, 1, 1, 1, generator=g) * (2.0 / Cout) ** 0.5
+        pc2 = core.PackedConv(w2.to(dev), bn=bn_like(64, g).to(dev), ksize=1, stride=1, pad=0)
+        a = core.conv_rows(out, pc2, relu=False)
+        out.h16 = None
+        b = core.conv_rows(out, pc2, relu=False)
+        assert torch.equal(a.t, b.t)
