@@ -336,6 +336,7 @@ def rooflines(ksum, nsteps, args, rank, table):
         if dom:
             v = convs[dom]
             h2 = dom.startswith("k_gemm_h2")
+            h1 = dom.startswith("k_gemm_h1")
             # flops the matrix cores execute: Winograd-domain for "wino"; the split-f16 engine issues THREE f16 MFMAs per
             # fp32-accurate product (hi*hi, hi*lo, lo*hi), all of which count against the f16 peak
             ach = v["work"] / (v["ms"] * 1e-3) / 1e12 * (3.0 if h2 else 1.0)
@@ -350,7 +351,7 @@ def rooflines(ksum, nsteps, args, rank, table):
             symbol = {"k_conv2<160,wg> wino": "k_conv2<160, 2, true, 2, false>", "k_conv2p wino": "k_conv2p<true, false>",
                       "k_conv2<128,wg> wino": "k_conv2<128, 1, true, 3, false>", "k_gemm_h2z wino": "k_gemm_h2z<3, false>",
                       "k_gemm_h2z direct": "k_gemm_h2z<*, true>", "k_gemm_h2w": "k_gemm_h2w<false>"}.get(dom, dom)     # name in the rocprofv3 trace
-            peak = MFMA_BF16_PEAK_TFLOPS if (dom.startswith("k_conv_bf16") or h2) else MFMA_F32_PEAK_TFLOPS
+            peak = MFMA_BF16_PEAK_TFLOPS if (dom.startswith("k_conv_bf16") or h2 or h1) else MFMA_F32_PEAK_TFLOPS
             roof = dict(bound="mfma", kernel=dom, symbol=symbol, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
                         frac=round(ach / peak, 4), traffic=traffic,
                         traffic_source=("profiles/%s (rocprofv3 --pmc passes of this command, replayed: HBM counters cannot be "
@@ -367,6 +368,7 @@ def rooflines(ksum, nsteps, args, rank, table):
                     ("roofline_all_convs", lambda k: k.startswith("k_conv") and not k.startswith("k_conv_bf16"), MFMA_F32_PEAK_TFLOPS, 1.0,
                      "every fp32-MFMA k_conv* launch"),
                     ("roofline_bf16_convs", lambda k: k.startswith("k_conv_bf16"), MFMA_BF16_PEAK_TFLOPS, 1.0, "every k_conv_bf16 launch"),
+                    ("roofline_f16_convs", lambda k: k.startswith("k_gemm_h1"), MFMA_BF16_PEAK_TFLOPS, 1.0, "every one-term f16 k_gemm_h1* launch"),
                     ("roofline_h2_gemms", lambda k: k.startswith("k_gemm_h2"), MFMA_BF16_PEAK_TFLOPS, 3.0,
                      "every split-f16 k_gemm_h2* launch (3 f16 MFMAs per product counted)")):
                 grp = [v2 for k2, v2 in convs.items() if sel(k2)]

@@ -93,6 +93,7 @@ SIGNATURES = {
     "coocc_voxel_pool": (I, [P, P, I, I, I, P, I, I, I, I, P, I, P, Z, P]),
     "coocc_lift_splat": (I, [P, P, P, I, I, I, I, I, I, P, I, I, I, I, P, I, P, Z, P]),
     "coocc_lift_splat_cams": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, I, I, I, I, P, I, P, Z, P]),
+    "coocc_lift_splat_reuse": (I, [P, P, I, I, I, I, I, I, I, I, I, P, I, P, Z, P]),
     "coocc_bev_pool_coords": (I, [P, P, I, I, I, I, I, I, P, I, P, Z, P]),
     "coocc_render_nearest": (I, [P, I, I, I, P, P, I, I, I, I, P, I, P, P]),
     "coocc_render_nearest_cams": (I, [P, I, I, I, P, P, P, P, P, I, I, I, I, P, I, P, P]),

@@ -555,7 +555,14 @@ static int carve(void* ws, size_t ws_bytes, int npts, int nvox, PoolWs* p) {
 // LIFT: x = context rows [N*H*W, C], depth [npts], product formed inside the sum (fused lift (x) splat).
 template <bool LIFT>
 static int pool_csr(const float* x, const float* depth, int npts, int C, int D, int HW, int nvox, float* out, int out_stride,
-                    const PoolWs& p, hipStream_t s) {
+                    const PoolWs& p, hipStream_t s, bool build = true) {
+  if (!build) {      // the CSR (start, ids, long-voxel list) of an earlier call over the same geometry is still in the workspace
+    static const int long_blocks_r = getenv("COOCC_POOL_LONG_BLOCKS") ? atoi(getenv("COOCC_POOL_LONG_BLOCKS")) : 1024;
+    hipLaunchKernelGGL(k_pool_sum_csr<LIFT>, dim3(long_blocks_r + cdiv(nvox, 4)), dim3(256), 0, s, x, depth, p.ids, p.start,
+                       p.long_list, p.nlong, long_blocks_r, nvox, C, D, HW, out, out_stride);
+    COOCC_LAUNCH_CHECK("voxel_pool");
+    return COOCC_OK;
+  }
   COOCC_HIP(hipMemsetAsync(p.count, 0, p.zero_bytes, s));
   const int nblk = (nvox + 1023) / 1024;
   hipLaunchKernelGGL(k_key_hist, dim3(cdiv(npts, 256)), dim3(256), 0, s, p.keys, npts, nvox, p.count, p.slot);
@@ -638,6 +645,21 @@ extern "C" int coocc_lift_splat_cams(const float* depth, const float* feat_nhwc,
   COOCC_CHECK_ARG(mats && xs && ys && ds, "lift_splat_cams: null camera data");
   return lift_splat_impl(depth, feat_nhwc, nullptr, mats, xs, ys, ds, N, D, H, W, C, pts_per_batch, lo_dx_host, B, X, Y,
                          Z, out, out_stride, ws, ws_bytes, stream);
+}
+
+// The per-voxel sums alone over the CSR a previous coocc_lift_splat[_cams] call left in `ws` (same N, D, H, W, grid and
+// GEOMETRY: a calibrated rig does not move between frames): one launch instead of eight, bit-equal to the full call.
+extern "C" int coocc_lift_splat_reuse(const float* depth, const float* feat_nhwc, int N, int D, int H, int W, int C, int B, int X,
+                                      int Y, int Z, float* out, int out_stride, void* ws, size_t ws_bytes, void* stream) {
+  COOCC_CHECK_ARG(depth && feat_nhwc && out && N > 0 && D > 0 && H > 0 && W > 0, "lift_splat_reuse: bad args");
+  COOCC_CHECK_ARG(C > 0 && C % 4 == 0 && ((uintptr_t)feat_nhwc & 15) == 0 && out_stride % 4 == 0 && out_stride >= C &&
+                      ((uintptr_t)out & 15) == 0, "lift_splat_reuse: C % 4 == 0 and 16-byte aligned rows");
+  const long long npts_ll = (long long)N * D * H * W, nvox_ll = (long long)B * X * Y * Z;
+  COOCC_CHECK_ARG(npts_ll < (1ll << 31) && nvox_ll > 0 && nvox_ll < (1ll << 31), "lift_splat_reuse: sizes");
+  PoolWs p;
+  int rc = carve(ws, ws_bytes, (int)npts_ll, (int)nvox_ll, &p);
+  if (rc) return rc;
+  return pool_csr<true>(feat_nhwc, depth, (int)npts_ll, C, D, H * W, (int)nvox_ll, out, out_stride, p, as_stream(stream), false);
 }
 
 extern "C" int coocc_bev_pool_coords(const float* x, const int64_t* coords, int n, int C, int B, int X, int Y, int Z,

@@ -54,6 +54,7 @@ class FPN3D(nn.Module):
         for i in range(self.num_out - 1, 0, -1):
             c, f = lat[i], lat[i - 1]
             call("coocc_upsample_add_trilinear", ptr(c.t), ptr(f.t), f.B, f.C, c.X, c.Y, c.Z, f.X, f.Y, f.Z)
+            f.h16 = None          # the rows changed in place: the 16-bit copy the lateral conv's epilogue wrote is stale
         return [conv_rows(x, p["out"][i], relu=True) for i, x in enumerate(lat)]
 
     def forward(self, inputs):

@@ -206,6 +206,21 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
             out_ptr = ptr(out_t)
         ws = _pool_workspace(dev, npts, B * X * Y * Z)
         dp = depth_prob.float().contiguous()
+        if getattr(self, "accelerate", False):
+            # fixed camera rig (the reference's ``accelerate`` flag, ViewTransformerLSSBEVDepth.py:67,242-300): the voxel binning
+            # of the first call is kept in a private workspace and every later call only runs the per-voxel sums
+            key = (dev.index, npts, B * X * Y * Z)
+            cache = getattr(self, "_geometry_cache", None)
+            if cache is not None and cache[0] == key:
+                call("coocc_lift_splat_reuse", ptr(dp), ptr(feat), BN, D, H, W, C, B, X, Y, Z, out_ptr, out_stride, ptr(cache[1]),
+                     cache[1].numel())
+                if out is not None:
+                    v = out.as_ncdhw()
+                    v._coocc_keep = out.t
+                    return v
+                return out_t.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
+            ws = torch.empty_like(ws)
+            self._geometry_cache = (key, ws)
         from ._lib import TIMER
         # algorithmic HBM bytes of the fused form: depth + context rows read, pooled rows written
         with TIMER.region("k_lift_splat", 4.0 * npts + 4.0 * BN * H * W * C + 4.0 * B * X * Y * Z * C):

@@ -524,6 +524,12 @@ int coocc_lift_splat_cams(const float* depth, const float* feat_nhwc, const floa
                           const float* ys, const float* ds, int N, int D, int H, int W, int C,
                           int pts_per_batch, const float* lo_dx_host, int B, int X, int Y, int Z, float* out,
                           int out_stride, void* ws, size_t ws_bytes, void* stream);
+/* The per-voxel sums alone, over the CSR binning a previous coocc_lift_splat[_cams] call left in `ws` (same shapes, same
+ * geometry): what a fixed camera rig needs per frame -- one launch, bit-equal to the full call.  The reference has the idea as
+ * voxel_pooling_accelerated (ViewTransformerLSSBEVDepth.py:242-300: geometry / sort cached on the first call; that variant also
+ * caps a voxel at 300 points, this one keeps every point). */
+int coocc_lift_splat_reuse(const float* depth, const float* feat_nhwc, int N, int D, int H, int W, int C, int B, int X,
+                           int Y, int Z, float* out, int out_stride, void* ws, size_t ws_bytes, void* stream);
 /* bev_pool(feats, coords, ...) drop-in (M/ops/bev_pool/bev_pool.py:83-97): coords:[n,4]
  * (x,y,z,b) i64; same sort-and-sum, out NDHWC rows. */
 int coocc_bev_pool_coords(const float* x, const int64_t* coords, int n, int C, int B, int X, int Y,

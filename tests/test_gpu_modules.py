@@ -703,3 +703,22 @@ def test_render_with_in_kernel_geometry_equals_the_geometry_tensor_path(dev):
         b = R.render_block(sig, rgb, vf, None, 16, cam_geo=(camera_mats(*mats).reshape(-1, 39), xs, ys, ds))
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_lift_splat_with_cached_geometry_equals_the_full_call(dev):
+    """``accelerate=True`` (the reference's flag for a fixed rig, ViewTransformerLSSBEVDepth.py:67,242-300): the voxel binning of the
+    first call is reused, later calls run the per-voxel sums alone -- bit-equal to the full call on new depth / context inputs."""
+    cfgm = synth.model_cfg()["img_view_transformer"]
+    vt = pkg.ViewTransformerLiftSplatShootVoxel(**{k: v for k, v in cfgm.items() if k != "type"}).to(dev)
+    rig = synth.camera_rig(6, (256, 704), seed=3)
+    cams = tuple(rig[k].to(dev) for k in ("rots", "trans", "intrins", "post_rots", "post_trans", "bda"))
+    plain = []
+    ins = []
+    for seed in (1, 2, 3):
+        depth, ctx = synth.lift_inputs(6, vt.D, (16, 44), 128, seed=seed)
+        ins.append((depth.to(dev), ctx.to(dev)))
+        plain.append(vt.lift_splat(*ins[-1], cams=cams).clone())
+    vt.accelerate = True
+    for (d, c), want in zip(ins, plain):
+        assert torch.equal(vt.lift_splat(d, c, cams=cams), want)
+    assert vt._geometry_cache is not None
