@@ -89,7 +89,15 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
   SRC(coocc_compact_flags(w.flags, V, lin_img, d->counts, w.cws, (size_t)(V / 1024 + 2) * 4, stream));
   SRC(coocc_compact_flags(w.flags + V, V, lin_pts, d->counts + 1, w.cws + (V / 1024 + 2), (size_t)(V / 1024 + 2) * 4, stream));
   COOCC_HIP(hipMemcpyAsync(d->counts_host, d->counts, 8, hipMemcpyDeviceToHost, s0));
-  COOCC_HIP(hipStreamSynchronize(s0));                 // the one host sync of the stage
+  {
+    // the one host sync of the stage.  A BLOCKING event: the calling thread sleeps instead of spinning (hipStreamSynchronize may
+    // spin), so several prefetch threads per rank -- and 8 ranks per node -- do not burn the host cores the issuing threads need
+    hipEvent_t got;
+    COOCC_HIP(hipEventCreateWithFlags(&got, hipEventBlockingSync | hipEventDisableTiming));
+    COOCC_HIP(hipEventRecord(got, s0));
+    COOCC_HIP(hipEventSynchronize(got));
+    COOCC_HIP(hipEventDestroy(got));
+  }
   const int Ni = d->counts_host[0], Np = d->counts_host[1];
   if (Ni <= d->fps_num || Np <= d->fps_num) return COOCC_SEARCH_SMALL;
 
