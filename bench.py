@@ -191,10 +191,10 @@ def step(model, s, world, search=None, img=None, ticket=None):
         from co_occ_amd.render import render_block_sharded
         out = model.forward_hot_path(img, s["pts"], s["gemo"], s["img_feats"], s["transform"], render=False, search=search)
         if do_render:
-            e0 = torch.cuda.Event(enable_timing=True); e0.record()
-            out["rgbs"], out["depths"], out["render_maps"] = render_block_sharded(model.sigma_head, model.rgb_head, out["voxel_feats"], s["gemo"], 16)
-            e1 = torch.cuda.Event(enable_timing=True); e1.record()
-            SHARD_EV.append((e0, e1))
+            ev = []
+            out["rgbs"], out["depths"], out["render_maps"] = render_block_sharded(model.sigma_head, model.rgb_head, out["voxel_feats"], s["gemo"], 16,
+                                                                                  events=ev)
+            SHARD_EV.append(ev)
         return out
     else:
         out = model.forward_hot_path(img, s["pts"], s["gemo"], s["img_feats"], s["transform"], render=do_render, search=search)
@@ -720,6 +720,7 @@ def main():
     SHARD[0] = args.shard == "rays"
     if SHARD[0]:
         args.graph, args.streams = 0, 1           # the sharded render has a collective inside the step: eager, one sample in flight
+        auto_streams = False
     model, sd = build_model(args.config, dev)
     samples = [make_inputs(args.config, 1234 + (0 if SHARD[0] else 17 * rank) + i, dev, model) for i in range(max(2, args.slots if args.graph else 2))]
     if args.reserve_cus > 0:
@@ -879,8 +880,11 @@ def main():
         line["graph"] = graph_info
     if SHARD[0] and SHARD_EV:
         torch.cuda.synchronize()
-        rms = sum(a.elapsed_time(b) for a, b in SHARD_EV[-args.steps:]) / min(len(SHARD_EV), args.steps)
-        line["ray_shard"] = dict(render_ms_per_step=round(rms, 3), sharded_fraction_of_step=round(rms / (1e3 * dt / args.steps), 4),
+        evs = SHARD_EV[-args.steps:]
+        rms = sum(e[0].elapsed_time(e[1]) + e[2].elapsed_time(e[3]) for e in evs) / len(evs)      # table build + rays, upsample
+        gms = sum(e[1].elapsed_time(e[2]) for e in evs) / len(evs)                                 # the all-gather, incl. the wait for the slowest rank
+        line["ray_shard"] = dict(render_ms_per_step=round(rms, 3), gather_ms_per_step=round(gms, 3),
+                                 sharded_fraction_of_step=round(rms / (1e3 * dt / args.steps), 4),
                                  note="only the render block shards (table build + rays + gather + upsample); the index search and the "
                                       "3-D conv stack are replicated on every rank, so this mode cannot scale: one scene per GPU "
                                       "(--shard samples) is the scaling configuration")

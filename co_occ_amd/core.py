@@ -163,7 +163,8 @@ class PackedConv:
         self._ztrim = {}
         self._wino = {}
         self._bf16 = {}
-        self._w_taps = w if not tap_major else None      # [Cout, Cin, taps] on the host: source of the bf16 packs
+        # [Cout, Cin, taps] on the host: source of the bf16 / f16 packs (tap-major weights are [Cout, taps * Cin])
+        self._w_taps = w if not tap_major else w.view(self.Cout, taps, self.Cin).permute(0, 2, 1).contiguous()
         self.wino_tile = None        # per-layer override of WINO_TILE (2 | 3 | 4)
         lib = _lib.load()
         n = lib.coocc_conv_pack_weights(ctypes.c_void_p(w.data_ptr()), self.Cout, self.Cin, taps, int(tap_major), None)
@@ -629,7 +630,13 @@ def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_co
     d.tile_hint = TILE_HINT
     if count_dev is not None:
         d.M_dev, d.gather_stride = ptr(count_dev, torch.int32), M
-    with TIMER.region(conv_kernel_name(M, pc.Cout, True), 2.0 * M * C * pc.Cout * K):
+    kname = conv_kernel_name(M, pc.Cout, True)
+    if CONV_ENGINE == "h2" and H2_DIRECT and CONV_DTYPE == "f32" and C % 32 == 0 and h2_capable(pc) and pc.h2_pack() is not None:
+        # split-f16 engine: the source slot is converted once ([rows, C] H2 rows: 13 us for 80 k rows), the row-table kernel
+        # gathers 128-byte chunks of it (k_gemm_h2w<TABLE>); 118 -> ~40 us per call at configs[1]
+        sh = rows_to_h2(src, C, src_coff, name="g1rows")
+        d.in_, d.in_stride, d.w, d.mfma_dtype, d.alpha, kname = ptr(sh), C, ptr(pc.h2_pack()), 3, 1.0, "k_gemm_h2w"
+    with TIMER.region(kname, 2.0 * M * C * pc.Cout * K):
         _lib.conv_fwd(d, src.device)
 
 

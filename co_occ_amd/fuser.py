@@ -78,7 +78,11 @@ def _fps_voxels_on_current(q_lin, grid, fps_num):
 GRID_SEARCH = __import__("os").environ.get("COOCC_GRID_SEARCH", "1") != "0"   # 0: brute-force top-K / ball query
 # con_enc.0 split by input-channel support (csrc/sparse_taps.hip): the pts / fused_img slots are non-zero on the LiDAR voxels
 # only, so they are convolved in scatter form over those rows while img / fused_pts go through the Winograd GEMM.
-SPLIT_C0 = __import__("os").environ.get("COOCC_SPLIT_C0", "1") != "0"
+# Round 3: under the split-f16 engine the whole layer runs F(4x4) at 2.5x the GEMM rate and the ONE dense 4C-channel GEMM is
+# the cheaper form at every occupancy the hipGraph is sized for (measured at 12 % occupancy: dense 0.60 ms against 0.36 + 0.46 ms
+# for the split -- the scatter form writes and re-reads a [Np, 27, Cout] fp32 tensor, 265 MB): default off there (+4 % samples/s),
+# COOCC_SPLIT_C0=1 restores it; default on for the fp32-MFMA engine.
+SPLIT_C0 = __import__("os").environ.get("COOCC_SPLIT_C0", "0" if __import__("co_occ_amd.core", fromlist=["x"]).CONV_ENGINE == "h2" else "1") != "0"
 SPLIT_C0_MAX_DENSITY = 0.30      # above this share of LiDAR voxels the dense 4C-channel GEMM is the cheaper form
 _offset_tables = {}
 

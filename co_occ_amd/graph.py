@@ -66,7 +66,9 @@ class DenseGraph:
     def fits(self, counts):
         """Host-side check of a sample's voxel counts against the capacities the graph was captured with."""
         Ni, Np = counts
-        return 0 < Np <= self.model.occ_fuser.c0_capacity(self.slot.V) and Ni > 0
+        from . import fuser
+        cap = self.model.occ_fuser.c0_capacity(self.slot.V) if fuser.SPLIT_C0 else self.slot.V   # the dense form of con_enc.0 has no capacity
+        return 0 < Np <= cap and Ni > 0
 
     def replay(self):
         self.graph.replay()

@@ -181,12 +181,14 @@ def _render_depth_only(sigma_head, voxel_feats, gemo, scale):
     return None, depths, maps
 
 
-def render_block_sharded(sigma_head, rgb_head, voxel_feats, gemo, scale=16, rank=None, world=None):
+def render_block_sharded(sigma_head, rgb_head, voxel_feats, gemo, scale=16, rank=None, world=None, events=None):
     """Config 5: ONE scene rendered by `world` ranks.  The flattened (camera, row) space of the
     feature-map rays is cut into `world` contiguous chunks (6 cameras do not divide 8 GPUs); every rank holds the
     fused volume, evaluates the per-voxel table, composites its chunk of rays, the 16-byte-per-ray maps are
     all-gathered (dist.gather_ray_shards, RCCL) and every rank upsamples the full maps (35 us at r101).
-    Returns the same (rgbs, depths, maps) as render_block."""
+    Returns the same (rgbs, depths, maps) as render_block.  ``events``: a list that receives four timing events (start, before
+    the gather, after the gather, end) so a caller can separate the sharded compute from the collective (which also carries
+    the wait for the slowest rank)."""
     from . import dist as cdist
     from .core import to_rows
     import torch.distributed as tdist
@@ -197,6 +199,14 @@ def render_block_sharded(sigma_head, rgb_head, voxel_feats, gemo, scale=16, rank
         world = tdist.get_world_size() if (tdist.is_available() and tdist.is_initialized()) else 1
         rank = tdist.get_rank() if world > 1 else 0
     dev = gemo.device
+
+    def mark():
+        if events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            events.append(e)
+
+    mark()
     table = voxel_table(sigma_head, rgb_head, vf)
     call("coocc_render_activate_table", ptr(table), vf.V)
     zvals = torch.linspace(0, D, D, device=dev)
@@ -211,10 +221,13 @@ def render_block_sharded(sigma_head, rgb_head, voxel_feats, gemo, scale=16, rank
         call("coocc_render_nearest", ptr(table), vf.X, vf.Y, vf.Z, ptr(piece), ptr(zvals), 1, D, h1 - h0, W,
              host_f32(RENDER_BOUNDS), 1, ptr(local[r - lo:r - lo + (h1 - h0)]))
         r += h1 - h0
+    mark()
     maps = cdist.gather_ray_shards(local, N * H).view(N, H, W, 4).contiguous()
+    mark()
     rgbs = torch.empty(N, H * scale, W * scale, 3, device=dev, dtype=_F32)
     depths = torch.empty(N, H * scale, W * scale, device=dev, dtype=_F32)
     call("coocc_upsample_maps", ptr(maps), N, H, W, scale, ptr(rgbs), ptr(depths))
+    mark()
     return rgbs, depths, maps
 
 

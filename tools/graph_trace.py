@@ -29,3 +29,12 @@ span = int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])
 print("dense stage: %.3f ms of kernels per replay, %.3f ms wall per replay, %d launches per replay" % (tot / n / 1e6, span / n / 1e6, len(sel) // n))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-62s x%5.1f  %.3f ms/replay  avg %6.1f us" % (k, v[0] / n, v[1] / n / 1e6, v[1] / v[0] / 1e3))
+if len(sys.argv) > 2 and sys.argv[2] == "--seq":
+    # the launches of the LAST replay in issue order: name, grid (workgroups), duration
+    last = rows[idx[-2] + 1: idx[-1] + 1]
+    print("\nlast replay, launch by launch (shifted: starts right after the previous replay's k_occhead_mix):")
+    t0 = int(last[0]["Start_Timestamp"])
+    for r in last:
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        wg = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(1, int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"]))
+        print("%8.1f us  %-50s wgs %6d  %6.1f us" % ((int(r["Start_Timestamp"]) - t0) / 1e3, r["Kernel_Name"].split("(")[0][:50], wg, d / 1e3))
