@@ -90,11 +90,11 @@ SIGNATURES = {
     "coocc_bev_pool_forward": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
     "coocc_bev_pool_backward": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
     "coocc_voxel_pool_ws": (Z, [I, I]),
-    "coocc_voxel_pool": (I, [P, P, I, I, I, P, I, I, I, I, P, I, P, Z, P]),
-    "coocc_lift_splat": (I, [P, P, P, I, I, I, I, I, I, P, I, I, I, I, P, I, P, Z, P]),
-    "coocc_lift_splat_cams": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, I, I, I, I, P, I, P, Z, P]),
+    "coocc_voxel_pool": (I, [P, P, I, I, I, P, I, I, I, I, P, I, P, Z, I, P]),
+    "coocc_lift_splat": (I, [P, P, P, I, I, I, I, I, I, P, I, I, I, I, P, I, P, Z, I, P]),
+    "coocc_lift_splat_cams": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, I, I, I, I, P, I, P, Z, I, P]),
     "coocc_lift_splat_reuse": (I, [P, P, I, I, I, I, I, I, I, I, I, P, I, P, Z, P]),
-    "coocc_bev_pool_coords": (I, [P, P, I, I, I, I, I, I, P, I, P, Z, P]),
+    "coocc_bev_pool_coords": (I, [P, P, I, I, I, I, I, I, P, I, P, Z, I, P]),
     "coocc_render_nearest": (I, [P, I, I, I, P, P, I, I, I, I, P, I, P, P]),
     "coocc_render_nearest_cams": (I, [P, I, I, I, P, P, P, P, P, I, I, I, I, P, I, P, P]),
     "coocc_render_activate_table": (I, [P, I, P]),

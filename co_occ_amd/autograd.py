@@ -411,8 +411,10 @@ class LiftSplatFn(torch.autograd.Function):
         ws = _pool_workspace(dev, npts, B * X * Y * Z)
         dp = depth_prob.float().contiguous()
         g = geom_feats.reshape(-1, 3).float().contiguous()
+        from .ops import pool_ws_clean, pool_ws_done
         call("coocc_lift_splat", ptr(dp), ptr(feat), ptr(g), BN, D, H, W, C, npts // B, host_f32(lo), B, X, Y, Z, ptr(out), C,
-             ptr(ws), ws.numel())
+             ptr(ws), ws.numel(), pool_ws_clean(ws, npts, B * X * Y * Z))
+        pool_ws_done(ws, npts, B * X * Y * Z)
         ctx.save_for_backward(dp, feat, g)
         ctx.cfg = (BN, D, H, W, C, npts // B, lo, B, X, Y, Z)
         return out.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)

@@ -172,49 +172,42 @@ __device__ __forceinline__ uint32_t voxel_key(float x, float y, float z, int b, 
   return kept ? (uint32_t)((((size_t)b * X + ix) * Y + iy) * Z + iz) : (uint32_t)nvox;
 }
 
-__global__ __launch_bounds__(256) void k_quantize_geom(const float* __restrict__ geom, int npts, int pts_per_batch,
-                                                        float lox, float loy, float loz, float dx, float dy, float dz,
-                                                        int X, int Y, int Z, int nvox, uint32_t* __restrict__ keys) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npts) return;
-  keys[i] = voxel_key(geom[(size_t)i * 3 + 0], geom[(size_t)i * 3 + 1], geom[(size_t)i * 3 + 2], i / pts_per_batch, lox,
-                      loy, loz, dx, dy, dz, X, Y, Z, nvox);
-}
-
-// geometry computed in-kernel from the camera matrices (no [npts,3] geom tensor)
-__global__ __launch_bounds__(256) void k_quantize_cams(const float* __restrict__ mats, const float* __restrict__ xs,
-                                                        const float* __restrict__ ys, const float* __restrict__ ds, int D,
-                                                        int fH, int fW, int npts, int pts_per_batch, float lox, float loy,
-                                                        float loz, float dx, float dy, float dz, int X, int Y, int Z,
-                                                        int nvox, uint32_t* __restrict__ keys) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npts) return;
-  float gx, gy, gz;
-  geometry_point(mats, xs, ys, ds, (size_t)i, D, fH, fW, gx, gy, gz);
-  keys[i] = voxel_key(gx, gy, gz, i / pts_per_batch, lox, loy, loz, dx, dy, dz, X, Y, Z, nvox);
-}
-
-// keys from integer coords (bev_pool drop-in): coords [n,4] = (x,y,z,b) int64
-__global__ __launch_bounds__(256) void k_keys_from_coords(const int64_t* __restrict__ coords, int n, int B, int X, int Y,
-                                                           int Z, int nvox, uint32_t* __restrict__ keys) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  long long x = coords[(size_t)i * 4 + 0], y = coords[(size_t)i * 4 + 1], z = coords[(size_t)i * 4 + 2],
-            b = coords[(size_t)i * 4 + 3];
-  bool ok = x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z && b >= 0 && b < B;
-  keys[i] = ok ? (uint32_t)(((b * X + x) * Y + y) * Z + z) : (uint32_t)nvox;
-}
-
 // ------------------------------------------------------------------ CSR build: histogram -> scan -> fill
 // One atomic pass: the lanes of a wave that hold the same key are combined (a voxel next to a camera receives up to 2600
 // points, consecutive ids mostly -- one atomicAdd per lane would serialise on that address), the group leader adds the
 // group size to count[key] and every member keeps (old value + its position in the group) as its slot inside the voxel.
 // After the scan the fill is a plain scatter: ids[start[key] + slot] = id.
-__global__ __launch_bounds__(256) void k_key_hist(const uint32_t* __restrict__ keys, int npts, int nvox,
-                                                   int32_t* __restrict__ count, int32_t* __restrict__ slot) {
+constexpr int POOL_MEDIUM = 256;     // <= 64 points: wave rank sort in registers; <= 256: wave rank sort through LDS; else workgroup
+
+// Launch 1 of 3: voxel key of every point (written for the fill pass) + the histogram above, in one kernel.
+// MODE 0: geometry tensor [npts,3]; 1: geometry from the camera matrices; 2: integer coords [n,4] (bev_pool drop-in)
+struct KeySrc {
+  const float* geom; const float* mats; const float* xs; const float* ys; const float* ds; const int64_t* coords;
+  int D, fH, fW, pts_per_batch, B;
+  float lox, loy, loz, dx, dy, dz;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void k_keys_hist(KeySrc a, int npts, int X, int Y, int Z, int nvox, uint32_t* __restrict__ keys,
+                                                    int32_t* __restrict__ count, int32_t* __restrict__ slot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  const uint32_t k = i < npts ? keys[i] : 0xFFFFFFFFu;
+  uint32_t k = 0xFFFFFFFFu;
+  if (i < npts) {
+    if (MODE == 0) {
+      k = voxel_key(a.geom[(size_t)i * 3 + 0], a.geom[(size_t)i * 3 + 1], a.geom[(size_t)i * 3 + 2], i / a.pts_per_batch, a.lox, a.loy,
+                    a.loz, a.dx, a.dy, a.dz, X, Y, Z, nvox);
+    } else if (MODE == 1) {
+      float gx, gy, gz;
+      geometry_point(a.mats, a.xs, a.ys, a.ds, (size_t)i, a.D, a.fH, a.fW, gx, gy, gz);
+      k = voxel_key(gx, gy, gz, i / a.pts_per_batch, a.lox, a.loy, a.loz, a.dx, a.dy, a.dz, X, Y, Z, nvox);
+    } else {
+      long long x = a.coords[(size_t)i * 4 + 0], y = a.coords[(size_t)i * 4 + 1], z = a.coords[(size_t)i * 4 + 2],
+                b = a.coords[(size_t)i * 4 + 3];
+      bool ok = x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z && b >= 0 && b < a.B;
+      k = ok ? (uint32_t)(((b * X + x) * Y + y) * Z + z) : (uint32_t)nvox;
+    }
+    keys[i] = k;
+  }
   const bool valid = k < (uint32_t)nvox;
   unsigned long long remaining = __ballot(valid);
   int myslot = 0;
@@ -231,74 +224,102 @@ __global__ __launch_bounds__(256) void k_key_hist(const uint32_t* __restrict__ k
   if (valid) slot[i] = myslot;
 }
 
-// exclusive scan of count[0..nvox): 1024 voxels per workgroup -> local prefix + block total; one workgroup scans the
-// (<= 1024) block totals; a third pass adds the block offset, writes start[nvox] = total and appends the voxels with more
-// than POOL_MEDIUM points to long_list (their order does not matter).  A single-workgroup scan of 80 k counts took 140 us.
-constexpr int POOL_MEDIUM = 256;     // <= 64 points: wave rank sort in registers; <= 256: wave rank sort through LDS; else workgroup
-
-__global__ __launch_bounds__(1024) void k_scan_local(const int32_t* __restrict__ count, int nvox, int32_t* __restrict__ start,
-                                                      int32_t* __restrict__ tops) {
-  __shared__ int wsum[16];
-  const int tid = threadIdx.x, v = blockIdx.x * 1024 + tid;
-  const int c = v < nvox ? count[v] : 0;
-  int inc = c;
-  for (int o = 1; o < 64; o <<= 1) {
-    int n = __shfl_up(inc, o);
-    if ((tid & 63) >= o) inc += n;
-  }
-  if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+// Launch 2 of 3: exclusive scan of count[0..nvox) -> start[], list of the voxels with more than POOL_MEDIUM points, the CSR
+// fill  ids[start[key] + slot] = id  -- and count[] zeroed again for the next call on this workspace -- in ONE kernel of at most
+// 256 workgroups (all resident: one per CU) separated by two grid barriers.  Round 2 ran this as four launches (local scan, scan
+// of the block totals, finish, fill) + a memset; the launches, not the work, were the cost (5 x ~5 us on a prefetch stream that
+// shares the GPU with the dense stage).
+// Grid barrier: bar[0] counts arrivals and is reset by the last one (so it is zero between barriers and between calls), bar[1] is a
+// generation number that only ever grows -- no initial value needed.
+__device__ __forceinline__ void pool_grid_barrier(int32_t* bar, int G) {
   __syncthreads();
-  int off = inc - c;
-  for (int w = 0; w < (tid >> 6); ++w) off += wsum[w];
-  if (v < nvox) start[v] = off;
-  if (tid == 1023) tops[blockIdx.x] = off + c;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int old = atomicAdd(&bar[0], 1);
+    if (old == G - 1) {
+      atomicExch(&bar[0], 0);
+      __threadfence();
+      atomicAdd(&bar[1], 1);
+    } else {
+      while (__hip_atomic_load(&bar[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(4);
+    }
+    __threadfence();
+  }
+  __syncthreads();
 }
 
-// exclusive scan of the per-block totals: one workgroup walks them 1024 at a time with a running carry (grids past 2^20
-// voxels have more than 1024 blocks: B = 2 at 200x200x16, OpenOccupancy-size batches)
-__global__ __launch_bounds__(1024) void k_scan_tops(int32_t* __restrict__ tops, int nblk) {
+__global__ __launch_bounds__(1024) void k_scan_fill(int32_t* __restrict__ count, int nvox, int nblk, int32_t* __restrict__ start,
+                                                     int32_t* __restrict__ tops, int32_t* __restrict__ long_list,
+                                                     int32_t* __restrict__ nlong, int32_t* __restrict__ bar,
+                                                     const uint32_t* __restrict__ keys, int npts, const int32_t* __restrict__ slot,
+                                                     uint32_t* __restrict__ ids) {
   __shared__ int wsum[16];
-  __shared__ int carry_s;
-  const int tid = threadIdx.x;
-  int carry = 0;
-  for (int base = 0; base < nblk; base += 1024) {
-    const int i = base + tid;
-    const int c = i < nblk ? tops[i] : 0;
-    int inc = c;
+  __shared__ int bsum;
+  const int tid = threadIdx.x, G = gridDim.x;
+  // phase A: exclusive scan inside each 1024-voxel chunk, chunk totals
+  if (blockIdx.x == 0 && tid == 0) *nlong = 0;          // the previous call's list length (its consumer ran before this launch)
+  for (int c = blockIdx.x; c < nblk; c += G) {
+    const int v = c * 1024 + tid;
+    const int cn = v < nvox ? count[v] : 0;
+    int inc = cn;
     for (int o = 1; o < 64; o <<= 1) {
       int n = __shfl_up(inc, o);
       if ((tid & 63) >= o) inc += n;
     }
     if ((tid & 63) == 63) wsum[tid >> 6] = inc;
     __syncthreads();
-    int off = carry + inc - c;
+    int off = inc - cn;
     for (int w = 0; w < (tid >> 6); ++w) off += wsum[w];
-    if (i < nblk) tops[i] = off;
-    if (tid == 1023) carry_s = off + c;
+    if (v < nvox) start[v] = off;
+    if (tid == 1023) tops[c] = off + cn;
     __syncthreads();
-    carry = carry_s;
   }
-  if (tid == 0) tops[nblk] = carry;      // grand total
-}
-
-__global__ __launch_bounds__(1024) void k_scan_finish(const int32_t* __restrict__ count, int nvox, int nblk,
-                                                       const int32_t* __restrict__ tops, int32_t* __restrict__ start,
-                                                       int32_t* __restrict__ long_list, int32_t* __restrict__ nlong) {
-  const int v = blockIdx.x * 1024 + threadIdx.x;
-  if (v < nvox) {
-    start[v] += tops[blockIdx.x];
-    if (count[v] > POOL_MEDIUM) long_list[atomicAdd(nlong, 1)] = v;
+  pool_grid_barrier(bar, G);
+  // phase B: chunk offset = sum of the totals of the chunks before it (nblk is 80 .. a few thousand: one block-wide sum per chunk)
+  for (int c = blockIdx.x; c < nblk; c += G) {
+    int part = 0;
+    for (int i = tid; i < c; i += 1024) part += __hip_atomic_load(&tops[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((tid & 63) == 0) wsum[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wsum[w];
+      bsum = t;
+    }
+    __syncthreads();
+    const int off = bsum;
+    const int v = c * 1024 + tid;
+    if (v < nvox) {
+      const int cn = count[v];
+      start[v] += off;
+      if (cn > POOL_MEDIUM) long_list[atomicAdd(nlong, 1)] = v;
+      count[v] = 0;                                     // the next call's histogram starts from a clean array
+    }
+    if (c == nblk - 1 && tid == 0) start[nvox] = off + __hip_atomic_load(&tops[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
   }
-  if (v == 0) start[nvox] = tops[nblk];
-}
-
-__global__ __launch_bounds__(256) void k_csr_fill(const uint32_t* __restrict__ keys, int npts, int nvox,
-                                                   const int32_t* __restrict__ start, const int32_t* __restrict__ slot,
-                                                   uint32_t* __restrict__ ids) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npts) return;
-  const uint32_t k = keys[i];
-  if (k < (uint32_t)nvox) ids[start[k] + slot[i]] = (uint32_t)i;
+  pool_grid_barrier(bar, G);
+  // phase C: plain scatter, no atomics; the order inside a voxel is whatever the histogram's atomics produced
+  // (four independent points per thread and iteration: the chain key -> start[key] -> store is pure latency)
+  const long long step = (long long)G * 1024;
+  for (long long i0 = (long long)blockIdx.x * 1024 + tid; i0 < npts; i0 += 4 * step) {
+    uint32_t k[4];
+    int sl[4], st[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * step;
+      k[u] = i < npts ? keys[i] : 0xFFFFFFFFu;
+      sl[u] = i < npts ? slot[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      st[u] = k[u] < (uint32_t)nvox ? __hip_atomic_load(&start[k[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k[u] < (uint32_t)nvox) ids[st[u] + sl[u]] = (uint32_t)(i0 + u * step);
+  }
 }
 
 // One wave per voxel row, VEC channels per lane.  Rows are summed in ascending point id with a single accumulator, the
@@ -529,8 +550,8 @@ __global__ __launch_bounds__(256) void k_pool_sum_csr(const float* __restrict__ 
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// workspace: keys[npts] | ids[npts] | slot[npts] | count[nvox+1] | nlong[64] (one memset clears these two) | start[nvox+1] |
-// long_list[nvox] | tops[nvox / 1024 + 2]
+// workspace: keys[npts] | ids[npts] | slot[npts] | count[nvox+1] | nlong, barrier words [64] (one memset clears these two when the
+// caller does not vouch for them) | start[nvox+1] | long_list[nvox] | tops[nvox / 1024 + 2]
 extern "C" size_t coocc_voxel_pool_ws(int npts, int nvox) {
   if (npts <= 0 || nvox <= 0) return 0;
   return 3 * align256(sizeof(uint32_t) * (size_t)npts) + 3 * align256(sizeof(int32_t) * ((size_t)nvox + 1)) + 256 +
@@ -551,25 +572,11 @@ static int carve(void* ws, size_t ws_bytes, int npts, int nvox, PoolWs* p) {
   return COOCC_OK;
 }
 
-// keys[npts] (voxel row or nvox = dropped) -> CSR (start, ids) -> per-voxel sums in ascending point id.
-// LIFT: x = context rows [N*H*W, C], depth [npts], product formed inside the sum (fused lift (x) splat).
+// per-voxel sums over the CSR (start, ids, long-voxel list) in the workspace: launch 3 of 3, and the only launch of the
+// geometry-cached form.  LIFT: x = context rows [N*H*W, C], depth [npts], product formed inside the sum (fused lift (x) splat).
 template <bool LIFT>
-static int pool_csr(const float* x, const float* depth, int npts, int C, int D, int HW, int nvox, float* out, int out_stride,
-                    const PoolWs& p, hipStream_t s, bool build = true) {
-  if (!build) {      // the CSR (start, ids, long-voxel list) of an earlier call over the same geometry is still in the workspace
-    static const int long_blocks_r = getenv("COOCC_POOL_LONG_BLOCKS") ? atoi(getenv("COOCC_POOL_LONG_BLOCKS")) : 1024;
-    hipLaunchKernelGGL(k_pool_sum_csr<LIFT>, dim3(long_blocks_r + cdiv(nvox, 4)), dim3(256), 0, s, x, depth, p.ids, p.start,
-                       p.long_list, p.nlong, long_blocks_r, nvox, C, D, HW, out, out_stride);
-    COOCC_LAUNCH_CHECK("voxel_pool");
-    return COOCC_OK;
-  }
-  COOCC_HIP(hipMemsetAsync(p.count, 0, p.zero_bytes, s));
-  const int nblk = (nvox + 1023) / 1024;
-  hipLaunchKernelGGL(k_key_hist, dim3(cdiv(npts, 256)), dim3(256), 0, s, p.keys, npts, nvox, p.count, p.slot);
-  hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(1024), 0, s, p.count, nvox, p.start, p.tops);
-  hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, p.tops, nblk);
-  hipLaunchKernelGGL(k_scan_finish, dim3(nblk), dim3(1024), 0, s, p.count, nvox, nblk, p.tops, p.start, p.long_list, p.nlong);
-  hipLaunchKernelGGL(k_csr_fill, dim3(cdiv(npts, 256)), dim3(256), 0, s, p.keys, npts, nvox, p.start, p.slot, p.ids);
+static int pool_sums(const float* x, const float* depth, int C, int D, int HW, int nvox, float* out, int out_stride,
+                     const PoolWs& p, hipStream_t s) {
   // workgroups that walk the list of long voxels (> POOL_MEDIUM points; 24 at r50, 554 at r101, up to 2614 points each): their
   // per-voxel sort + ordered accumulation is the launch's critical path, so there are enough of them for one voxel each at r101
   // (r101, whole pooling call: 128 workgroups 0.60 ms, 512 0.43, 1024 0.375; idle ones exit after one load)
@@ -580,9 +587,30 @@ static int pool_csr(const float* x, const float* depth, int npts, int C, int D, 
   return COOCC_OK;
 }
 
+// points -> keys + histogram (launch 1) -> scan + CSR fill (launch 2) -> per-voxel sums in ascending point id (launch 3).
+// ws_clean != 0: the caller vouches that this workspace was last written by a pooling call of the SAME (npts, nvox) that returned
+// COOCC_OK (every such call leaves the count array and the barrier words zeroed); otherwise one memset clears them first.
+template <bool LIFT, int MODE>
+static int pool_build(const KeySrc& ks, const float* x, const float* depth, int npts, int C, int D, int HW, int X, int Y, int Z, int nvox,
+                      float* out, int out_stride, const PoolWs& p, int ws_clean, hipStream_t s) {
+  if (!ws_clean) COOCC_HIP(hipMemsetAsync(p.count, 0, p.zero_bytes, s));
+  hipLaunchKernelGGL(k_keys_hist<MODE>, dim3(cdiv(npts, 256)), dim3(256), 0, s, ks, npts, X, Y, Z, nvox, p.keys, p.count, p.slot);
+  const int nblk = (nvox + 1023) / 1024;
+  // at most one 1024-thread workgroup per CU (all resident: the kernel has grid barriers); more than nblk when the fill pass has
+  // the work for it
+  static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  // grid: a barrier costs ~G serialised atomics, the fill wants parallelism: 80 workgroups at r50 (473 k points), all CUs at r101
+  // (3.8 M points); measured alone: r50 0.166 ms with 80, 0.192 with 256
+  int G = max(nblk, cdiv(npts, 16384));
+  if (G > ncu) G = ncu;
+  hipLaunchKernelGGL(k_scan_fill, dim3(G), dim3(1024), 0, s, p.count, nvox, nblk, p.start, p.tops, p.long_list, p.nlong, p.nlong + 16,
+                     p.keys, npts, p.slot, p.ids);
+  return pool_sums<LIFT>(x, depth, C, D, HW, nvox, out, out_stride, p, s);
+}
+
 extern "C" int coocc_voxel_pool(const float* x, const float* geom, int npts, int pts_per_batch, int C,
                                 const float* lo_dx_host, int B, int X, int Y, int Z, float* out, int out_stride,
-                                void* ws, size_t ws_bytes, void* stream) {
+                                void* ws, size_t ws_bytes, int ws_clean, void* stream) {
   COOCC_CHECK_ARG(x && geom && out && lo_dx_host && npts > 0 && pts_per_batch > 0 && C > 0 && C % 4 == 0, "voxel_pool: bad args");
   COOCC_CHECK_ARG(((uintptr_t)x & 15) == 0 && out_stride % 4 == 0 && out_stride >= C, "voxel_pool: alignment");
   const long long nvox_ll = (long long)B * X * Y * Z;
@@ -591,11 +619,11 @@ extern "C" int coocc_voxel_pool(const float* x, const float* geom, int npts, int
   PoolWs p;
   int rc = carve(ws, ws_bytes, npts, nvox, &p);
   if (rc) return rc;
-  hipStream_t s = as_stream(stream);
   const float* l = lo_dx_host;
-  hipLaunchKernelGGL(k_quantize_geom, dim3(cdiv(npts, 256)), dim3(256), 0, s, geom, npts, pts_per_batch, l[0], l[1], l[2],
-                     l[3], l[4], l[5], X, Y, Z, nvox, p.keys);
-  return pool_csr<false>(x, nullptr, npts, C, 0, 0, nvox, out, out_stride, p, s);
+  KeySrc ks = {};
+  ks.geom = geom; ks.pts_per_batch = pts_per_batch; ks.B = B;
+  ks.lox = l[0]; ks.loy = l[1]; ks.loz = l[2]; ks.dx = l[3]; ks.dy = l[4]; ks.dz = l[5];
+  return pool_build<false, 0>(ks, x, nullptr, npts, C, 0, 0, X, Y, Z, nvox, out, out_stride, p, ws_clean, as_stream(stream));
 }
 
 // ------------------------------------------------------------------ fused lift (x) splat
@@ -607,7 +635,7 @@ extern "C" int coocc_voxel_pool(const float* x, const float* geom, int npts, int
 static int lift_splat_impl(const float* depth, const float* feat_nhwc, const float* geom, const float* mats,
                            const float* xs, const float* ys, const float* ds, int N, int D, int H, int W, int C,
                            int pts_per_batch, const float* lo_dx_host, int B, int X, int Y, int Z, float* out,
-                           int out_stride, void* ws, size_t ws_bytes, void* stream) {
+                           int out_stride, void* ws, size_t ws_bytes, int ws_clean, void* stream) {
   COOCC_CHECK_ARG(depth && feat_nhwc && out && lo_dx_host && N > 0 && D > 0 && H > 0 && W > 0, "lift_splat: bad args");
   COOCC_CHECK_ARG(geom || (mats && xs && ys && ds), "lift_splat: geometry missing");
   COOCC_CHECK_ARG(C > 0 && C % 4 == 0 && ((uintptr_t)feat_nhwc & 15) == 0 && out_stride % 4 == 0 && out_stride >= C &&
@@ -621,30 +649,29 @@ static int lift_splat_impl(const float* depth, const float* feat_nhwc, const flo
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   const float* l = lo_dx_host;
-  if (geom)
-    hipLaunchKernelGGL(k_quantize_geom, dim3(cdiv(npts, 256)), dim3(256), 0, s, geom, npts, pts_per_batch, l[0], l[1], l[2],
-                       l[3], l[4], l[5], X, Y, Z, nvox, p.keys);
-  else
-    hipLaunchKernelGGL(k_quantize_cams, dim3(cdiv(npts, 256)), dim3(256), 0, s, mats, xs, ys, ds, D, H, W, npts,
-                       pts_per_batch, l[0], l[1], l[2], l[3], l[4], l[5], X, Y, Z, nvox, p.keys);
-  return pool_csr<true>(feat_nhwc, depth, npts, C, D, H * W, nvox, out, out_stride, p, s);
+  KeySrc ks = {};
+  ks.geom = geom; ks.mats = mats; ks.xs = xs; ks.ys = ys; ks.ds = ds; ks.D = D; ks.fH = H; ks.fW = W;
+  ks.pts_per_batch = pts_per_batch; ks.B = B;
+  ks.lox = l[0]; ks.loy = l[1]; ks.loz = l[2]; ks.dx = l[3]; ks.dy = l[4]; ks.dz = l[5];
+  if (geom) return pool_build<true, 0>(ks, feat_nhwc, depth, npts, C, D, H * W, X, Y, Z, nvox, out, out_stride, p, ws_clean, s);
+  return pool_build<true, 1>(ks, feat_nhwc, depth, npts, C, D, H * W, X, Y, Z, nvox, out, out_stride, p, ws_clean, s);
 }
 
 extern "C" int coocc_lift_splat(const float* depth, const float* feat_nhwc, const float* geom, int N, int D, int H, int W,
                                 int C, int pts_per_batch, const float* lo_dx_host, int B, int X, int Y, int Z, float* out,
-                                int out_stride, void* ws, size_t ws_bytes, void* stream) {
+                                int out_stride, void* ws, size_t ws_bytes, int ws_clean, void* stream) {
   COOCC_CHECK_ARG(geom, "lift_splat: null geom");
   return lift_splat_impl(depth, feat_nhwc, geom, nullptr, nullptr, nullptr, nullptr, N, D, H, W, C, pts_per_batch,
-                         lo_dx_host, B, X, Y, Z, out, out_stride, ws, ws_bytes, stream);
+                         lo_dx_host, B, X, Y, Z, out, out_stride, ws, ws_bytes, ws_clean, stream);
 }
 
 extern "C" int coocc_lift_splat_cams(const float* depth, const float* feat_nhwc, const float* mats, const float* xs,
                                      const float* ys, const float* ds, int N, int D, int H, int W, int C,
                                      int pts_per_batch, const float* lo_dx_host, int B, int X, int Y, int Z, float* out,
-                                     int out_stride, void* ws, size_t ws_bytes, void* stream) {
+                                     int out_stride, void* ws, size_t ws_bytes, int ws_clean, void* stream) {
   COOCC_CHECK_ARG(mats && xs && ys && ds, "lift_splat_cams: null camera data");
   return lift_splat_impl(depth, feat_nhwc, nullptr, mats, xs, ys, ds, N, D, H, W, C, pts_per_batch, lo_dx_host, B, X, Y,
-                         Z, out, out_stride, ws, ws_bytes, stream);
+                         Z, out, out_stride, ws, ws_bytes, ws_clean, stream);
 }
 
 // The per-voxel sums alone over the CSR a previous coocc_lift_splat[_cams] call left in `ws` (same N, D, H, W, grid and
@@ -659,11 +686,11 @@ extern "C" int coocc_lift_splat_reuse(const float* depth, const float* feat_nhwc
   PoolWs p;
   int rc = carve(ws, ws_bytes, (int)npts_ll, (int)nvox_ll, &p);
   if (rc) return rc;
-  return pool_csr<true>(feat_nhwc, depth, (int)npts_ll, C, D, H * W, (int)nvox_ll, out, out_stride, p, as_stream(stream), false);
+  return pool_sums<true>(feat_nhwc, depth, C, D, H * W, (int)nvox_ll, out, out_stride, p, as_stream(stream));
 }
 
 extern "C" int coocc_bev_pool_coords(const float* x, const int64_t* coords, int n, int C, int B, int X, int Y, int Z,
-                                     float* out, int out_stride, void* ws, size_t ws_bytes, void* stream) {
+                                     float* out, int out_stride, void* ws, size_t ws_bytes, int ws_clean, void* stream) {
   COOCC_CHECK_ARG(x && coords && out && n > 0 && C > 0 && C % 4 == 0, "bev_pool_coords: bad args");
   COOCC_CHECK_ARG(((uintptr_t)x & 15) == 0 && out_stride % 4 == 0 && out_stride >= C, "bev_pool_coords: alignment");
   const long long nvox_ll = (long long)B * X * Y * Z;
@@ -672,7 +699,7 @@ extern "C" int coocc_bev_pool_coords(const float* x, const int64_t* coords, int 
   PoolWs p;
   int rc = carve(ws, ws_bytes, n, nvox, &p);
   if (rc) return rc;
-  hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(k_keys_from_coords, dim3(cdiv(n, 256)), dim3(256), 0, s, coords, n, B, X, Y, Z, nvox, p.keys);
-  return pool_csr<false>(x, nullptr, n, C, 0, 0, nvox, out, out_stride, p, s);
+  KeySrc ks = {};
+  ks.coords = coords; ks.B = B; ks.pts_per_batch = 1;
+  return pool_build<false, 2>(ks, x, nullptr, n, C, 0, 0, X, Y, Z, nvox, out, out_stride, p, ws_clean, as_stream(stream));
 }

@@ -87,6 +87,20 @@ def _pool_workspace(device, npts, nvox):
     return _pool_ws[key]
 
 
+def pool_ws_clean(ws, npts, nvox):
+    """``ws_clean`` argument of the pooling entry points (include/coocc_hip.h): 1 when the last write to this workspace tensor was
+    a pooling call of the same (npts, nvox) that returned without error -- it left its histogram zeroed, so the memset launch
+    is skipped.  The mark lives on the tensor object and is taken off for the duration of the call (``pool_ws_done`` puts it back
+    on success), so an exception leaves the workspace marked dirty."""
+    state = getattr(ws, "_coocc_pool_state", None)
+    ws._coocc_pool_state = None
+    return int(state == (int(npts), int(nvox)))
+
+
+def pool_ws_done(ws, npts, nvox):
+    ws._coocc_pool_state = (int(npts), int(nvox))
+
+
 def bev_pool_rows(feats, coords, B, D, H, W):
     """Pooling core: returns channels-last rows [B*H*W*D, C] with voxel order (b, x, y, z)
     where x < H, y < W, z < D (the reference's argument naming: D = nz, H = nx, W = ny)."""
@@ -98,7 +112,8 @@ def bev_pool_rows(feats, coords, B, D, H, W):
         return out.zero_()
     ws = _pool_workspace(feats.device, n, nvox)
     call("coocc_bev_pool_coords", ptr(feats.contiguous(), _F32), ptr(coords.long().contiguous(), torch.int64), n, C,
-         B, H, W, D, ptr(out), C, ptr(ws), ws.numel())
+         B, H, W, D, ptr(out), C, ptr(ws), ws.numel(), pool_ws_clean(ws, n, nvox))
+    pool_ws_done(ws, n, nvox)
     return out
 
 

@@ -8,7 +8,7 @@ import torch
 from torch import nn
 
 from ._lib import call, host_f32, ptr
-from .ops import _pool_workspace
+from .ops import _pool_workspace, pool_ws_clean, pool_ws_done
 from .registry import NECKS
 
 _F32 = torch.float32
@@ -178,7 +178,8 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         out = torch.empty(B * X * Y * Z, C, device=x.device, dtype=_F32)
         ws = _pool_workspace(x.device, Nprime, B * X * Y * Z)
         call("coocc_voxel_pool", ptr(xf), ptr(g), Nprime, Nprime // B, C, host_f32(lo), B, X, Y, Z,
-             ptr(out), C, ptr(ws), ws.numel())
+             ptr(out), C, ptr(ws), ws.numel(), pool_ws_clean(ws, Nprime, B * X * Y * Z))
+        pool_ws_done(ws, Nprime, B * X * Y * Z)
         return out.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
 
     def lift_splat(self, depth_prob, img_feat, geom_feats=None, cams=None, out=None):
@@ -228,12 +229,13 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
                 assert geom_feats.numel() == npts * 3
                 g = geom_feats.reshape(-1, 3).float().contiguous()
                 call("coocc_lift_splat", ptr(dp), ptr(feat), ptr(g), BN, D, H, W, C, npts // B, lo, B, X, Y, Z, out_ptr, out_stride,
-                     ptr(ws), ws.numel())
+                     ptr(ws), ws.numel(), pool_ws_clean(ws, npts, B * X * Y * Z))
             else:
                 mats, xs, ys, ds = self._camera_mats(*cams)
                 assert (ds.numel(), ys.numel(), xs.numel()) == (D, H, W)
                 call("coocc_lift_splat_cams", ptr(dp), ptr(feat), ptr(mats), ptr(xs), ptr(ys), ptr(ds), BN, D, H, W, C,
-                     npts // B, lo, B, X, Y, Z, out_ptr, out_stride, ptr(ws), ws.numel())
+                     npts // B, lo, B, X, Y, Z, out_ptr, out_stride, ptr(ws), ws.numel(), pool_ws_clean(ws, npts, B * X * Y * Z))
+            pool_ws_done(ws, npts, B * X * Y * Z)
         if out is not None:
             v = out.as_ncdhw()
             v._coocc_keep = out.t            # the buffer object BiFuser_N.concat_buffer registered stays alive with the view

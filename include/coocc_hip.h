@@ -504,26 +504,29 @@ int coocc_bev_pool_backward(const float* out_grad, const int32_t* geom,
                             const int32_t* interval_lengths, const int32_t* interval_starts, int b,
                             int d, int h, int w, int n, int c, int n_intervals, float* x_grad,
                             void* stream);
-/* voxel_pooling (P/coocc/image2bev/ViewTransformerLSSVoxel.py:100-123) without argsort:
- * quantise (truncate, then range filter), stable radix sort of (voxel, point id), each voxel
- * sums its rows in ascending point id.  x:[npts,C]; geom:[npts,3]; lo_dx_host = {bx-dx/2 (3),
- * dx (3)}; out: NDHWC rows [B*X*Y*Z, out_stride].  ws >= coocc_voxel_pool_ws(npts, B*X*Y*Z). */
+/* voxel_pooling (P/coocc/image2bev/ViewTransformerLSSVoxel.py:100-123) without argsort and without sorting the points:
+ * THREE launches -- (1) quantise (truncate, then range filter) + per-voxel histogram with per-point slots, (2) scan + CSR fill
+ * (one kernel, two grid barriers), (3) each voxel sums its rows in ascending point id.  x:[npts,C]; geom:[npts,3];
+ * lo_dx_host = {bx-dx/2 (3), dx (3)}; out: NDHWC rows [B*X*Y*Z, out_stride].  ws >= coocc_voxel_pool_ws(npts, B*X*Y*Z).
+ * ws_clean (all pooling entry points): non-zero = the caller vouches that the LAST write to `ws` was a pooling call with the
+ * same (npts, nvox) that returned COOCC_OK -- such a call leaves its histogram zeroed, so the memset (a fourth launch) is
+ * skipped; pass 0 for a fresh / reused-for-something-else / differently-sized workspace. */
 size_t coocc_voxel_pool_ws(int npts, int nvox);
 int coocc_voxel_pool(const float* x, const float* geom, int npts, int pts_per_batch, int C,
                      const float* lo_dx_host, int B, int X, int Y, int Z, float* out, int out_stride,
-                     void* ws, size_t ws_bytes, void* stream);
+                     void* ws, size_t ws_bytes, int ws_clean, void* stream);
 /* Fused lift (x) splat (ViewTransformerLSSVoxel.py:135-143 + voxel_pooling): the lifted
  * volume depth_prob[n,d,h,w] * img_feat[n,c,h,w] is never materialised.  depth:[N,D,H,W]; feat_nhwc:
  * [N,H,W,C]; geom:[N*D*H*W,3]; out NDHWC rows; same workspace as coocc_voxel_pool(N*D*H*W, B*X*Y*Z).
  * Bit-equal to pooling the materialised volume (products rounded before the add, ascending point id). */
 int coocc_lift_splat(const float* depth, const float* feat_nhwc, const float* geom, int N, int D, int H, int W,
                      int C, int pts_per_batch, const float* lo_dx_host, int B, int X, int Y, int Z, float* out,
-                     int out_stride, void* ws, size_t ws_bytes, void* stream);
+                     int out_stride, void* ws, size_t ws_bytes, int ws_clean, void* stream);
 /* Same, with the geometry of coocc_get_geometry computed inside the key kernel (no [npts,3] tensor in HBM). */
 int coocc_lift_splat_cams(const float* depth, const float* feat_nhwc, const float* mats, const float* xs,
                           const float* ys, const float* ds, int N, int D, int H, int W, int C,
                           int pts_per_batch, const float* lo_dx_host, int B, int X, int Y, int Z, float* out,
-                          int out_stride, void* ws, size_t ws_bytes, void* stream);
+                          int out_stride, void* ws, size_t ws_bytes, int ws_clean, void* stream);
 /* The per-voxel sums alone, over the CSR binning a previous coocc_lift_splat[_cams] call left in `ws` (same shapes, same
  * geometry): what a fixed camera rig needs per frame -- one launch, bit-equal to the full call.  The reference has the idea as
  * voxel_pooling_accelerated (ViewTransformerLSSBEVDepth.py:242-300: geometry / sort cached on the first call; that variant also
@@ -533,7 +536,7 @@ int coocc_lift_splat_reuse(const float* depth, const float* feat_nhwc, int N, in
 /* bev_pool(feats, coords, ...) drop-in (M/ops/bev_pool/bev_pool.py:83-97): coords:[n,4]
  * (x,y,z,b) i64; same sort-and-sum, out NDHWC rows. */
 int coocc_bev_pool_coords(const float* x, const int64_t* coords, int n, int C, int B, int X, int Y,
-                          int Z, float* out, int out_stride, void* ws, size_t ws_bytes, void* stream);
+                          int Z, float* out, int out_stride, void* ws, size_t ws_bytes, int ws_clean, void* stream);
 
 /* ---------------------------------------------------------------- R1..R3, L1 */
 /* inline render block, one launch for all cameras (P/coocc/detectors/coocc_ray.py:575-616).
