@@ -58,6 +58,7 @@ SIGNATURES = {
     "coocc_furthest_point_sampling": (I, [I, I, I, P, P, P, P]),
     "coocc_fps_voxels_ws": (Z, [I, I, I]),
     "coocc_fps_voxels": (I, [P, I, I, I, I, I, P, P, Z, P]),
+    "coocc_fps_voxels_pair": (I, [P, I, P, P, P, I, P, P, Z, I, I, I, I, P]),
     "coocc_ball_query": (I, [I, I, I, F, F, I, P, P, P, P]),
     "coocc_knn_topk": (I, [I, I, I, P, P, P, P, P]),
     "coocc_voxel_index_map": (I, [P, I, I, P, P]),

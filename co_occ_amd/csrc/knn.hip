@@ -379,6 +379,144 @@ __global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int
   }
 }
 
+// ------------------------------------------------------------------ K2, register-resident form (round 3)
+// k_fps_voxels refreshes a dirty bucket through L2 (load 128 {temp, rank} cells, min, store): one L2 round trip on the critical
+// path of every one of the 2047 dependent iterations -- 1.2 us per iteration.  For grids of at most FPSR_SLOTS * 16 buckets
+// (100 x 100 x 8: 625) the whole table fits the register file instead: a position's state IS its 32-bit key
+// (temp << RB | rmask - rank; 0 = empty), wave w holds buckets w, w + 16, ... in registers (positions lane, lane + 64 of slot s:
+// element s of two 32-wide + two 8-wide register vectors), 80 VGPRs of the 128 a 1024-thread workgroup may use.  A refresh is then
+// ~60 VALU / DPP instructions with no memory access; the dirty slot is wave-uniform, so its registers are addressed through the
+// VGPR index mode (ext-vector element with an SGPR index -> s_set_gpr_idx; a 40-way switch over named registers made hipcc spill
+// 127 of them).  Same arithmetic, same selections as k_fps_voxels (and so as the reference kernel).  gridDim.x = number of
+// independent problems: the two search directions of BiFuser_N run as ONE launch, one workgroup (= one CU) each.
+#define FPSR_SLOTS 40
+struct FpsRegProblem { const int32_t* lin; const FpsCell* cell; int32_t* idx; int n, L, q, RB; };
+struct FpsRegArgs { FpsRegProblem p[2]; int m, Y, Z, NBY, NBZ, NB; long long* dbg; };
+
+__global__ __launch_bounds__(1024) void k_fps_voxels_reg(FpsRegArgs a) {
+  constexpr int NW = 16;
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ unsigned wbest[2][NW];
+  __shared__ int wloc[2][NW];
+  const FpsRegProblem pr = a.p[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int RB = pr.RB, Y = a.Y, Z = a.Z, NB = a.NB, m = a.m;
+  const unsigned rmask = (1u << RB) - 1u;
+  const unsigned tmax = (1u << (32 - RB)) - 1u;
+  long long* dbg = a.dbg;
+  long long tA = 0, tM = 0, tB = 0, tT = 0, nd = 0;
+
+  typedef unsigned u32x32 __attribute__((ext_vector_type(32)));
+  typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+  u32x32 ca0, ca1;        // positions lane / lane + 64 of slots 0..31
+  u32x8 cb0, cb1;         // slots 32..39
+  // lane s owns the bookkeeping of the wave's slot s (bucket s * NW + wave): best key, its position, the bucket origin
+  unsigned key = 0;
+  int org = 0, pos = 0;
+  {
+    const int b = lane * NW + wave;
+    if (lane < FPSR_SLOTS && b < NB) {
+      int bz = b % a.NBZ; int qq = b / a.NBZ;
+      org = ((qq / a.NBY) * FT_X) | (((qq % a.NBY) * FT_Y) << 10) | ((bz * FT_Z) << 20);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FPSR_SLOTS; ++i) {
+    const int b = i * NW + wave;                  // wave-uniform
+    unsigned k0 = 0, k1 = 0;
+    if (b < NB) {
+      const int r0 = pr.cell[(size_t)b * FT_P + lane].r, r1 = pr.cell[(size_t)b * FT_P + lane + 64].r;
+      k0 = r0 >= 0 ? ((tmax << RB) | (rmask - (unsigned)r0)) : 0u;
+      k1 = r1 >= 0 ? ((tmax << RB) | (rmask - (unsigned)r1)) : 0u;
+      const unsigned best = max(k0, k1);
+      const int bp = k1 > k0 ? lane + 64 : lane;
+      const unsigned wb = wave_max_key(best);
+      const u64 own = __ballot(best == wb);
+      const int wp = __builtin_amdgcn_readlane(bp, (int)__ffsll((long long)own) - 1);
+      if (lane == i) { key = wb; pos = wp; }
+    }
+    if (i < 32) { ca0[i] = k0; ca1[i] = k1; }
+    else { cb0[i - 32] = k0; cb1[i - 32] = k1; }
+  }
+  if (tid == 0) pr.idx[0] = 0;
+  int sx, sy, sz;
+  {
+    int l = pr.lin[0];                            // sample 0 is list entry 0 (furthest_point_sample_cuda.cu:46-47)
+    sz = l % Z; l /= Z;
+    sy = l % Y; sx = l / Y;
+  }
+
+  for (int j = 1; j < m; ++j) {
+    long long c0 = dbg ? clock64() : 0;
+    // (A) dirty test of the owned bucket, refresh of the wave's dirty slots straight in registers
+    bool d = false;
+    if (key) {
+      const int x0 = org & 1023, y0 = (org >> 10) & 1023, z0 = org >> 20;
+      const int dx = max(max(x0 - sx, sx - (x0 + FT_X - 1)), 0);
+      const int dy = max(max(y0 - sy, sy - (y0 + FT_Y - 1)), 0);
+      const int dz = max(max(z0 - sz, sz - (z0 + FT_Z - 1)), 0);
+      d = (unsigned)(dx * dx + dy * dy + dz * dz) < (key >> RB);
+    }
+    u64 bal = __ballot(d);
+    nd += __popcll(bal);
+    const int exb = (lane >> 5) - sx, eyb = ((lane >> 3) & 3) - sy, ezb = (lane & 7) - sz;
+    while (bal) {
+      const int s0 = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)bal) - 1);
+      bal &= bal - 1;
+      const int o = __builtin_amdgcn_readlane(org, s0);
+      // squared distances of this lane's two positions of the bucket (lane, lane + 64: x + 2) to the new sample
+      const int ex = (o & 1023) + exb, ey = ((o >> 10) & 1023) + eyb, ez = (o >> 20) + ezb;
+      const int yz = ey * ey + ez * ez;
+      const unsigned d0 = (unsigned)(ex * ex + yz), d1 = (unsigned)((ex + 2) * (ex + 2) + yz);
+      unsigned k0, k1;
+      if (s0 < 32) { k0 = ca0[s0]; k1 = ca1[s0]; }
+      else { k0 = cb0[s0 - 32]; k1 = cb1[s0 - 32]; }
+      if (k0) k0 = (min(d0, k0 >> RB) << RB) | (k0 & rmask);
+      if (k1) k1 = (min(d1, k1 >> RB) << RB) | (k1 & rmask);
+      if (s0 < 32) { ca0[s0] = k0; ca1[s0] = k1; }
+      else { cb0[s0 - 32] = k0; cb1[s0 - 32] = k1; }
+      const unsigned best = max(k0, k1);
+      const int bp = k1 > k0 ? lane + 64 : lane;
+      const unsigned wb = wave_max_key(best);
+      const int wp = __builtin_amdgcn_readlane(bp, (int)__ffsll((long long)__ballot(best == wb)) - 1);
+      if (lane == s0) { key = wb; pos = wp; }
+    }
+    long long c1 = dbg ? clock64() : 0;
+    // (B) wave maximum over the owned buckets, published with the sample coordinates
+    const int loc = org + (pos >> 5) + (((pos >> 3) & 3) << 10) + ((pos & 7) << 20);
+    const unsigned wb = wave_max_key(key);
+    if (key == wb && wb) { wbest[j & 1][wave] = wb; wloc[j & 1][wave] = loc; }
+    if (!wb && lane == 0) wbest[j & 1][wave] = 0;
+    long long c2 = dbg ? clock64() : 0;
+    lds_barrier();
+    long long c3 = dbg ? clock64() : 0;
+    // (C) global winner: lanes 0..15 each fetch one wave's candidate, one 16-lane DPP max + two readlanes
+    const int li = lane & 15;
+    const unsigned mine = wbest[j & 1][li];
+    const int ml = wloc[j & 1][li];
+    unsigned v = mine;
+    v = max(v, dpp_u32<0xB1>(v));
+    v = max(v, dpp_u32<0x4E>(v));
+    v = max(v, dpp_u32<0x141>(v));
+    v = max(v, dpp_u32<0x140>(v));
+    const unsigned g = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    const u64 own = __ballot(mine == g) & 0xFFFFull;
+    const int gl = __builtin_amdgcn_readlane(ml, (int)__ffsll((long long)own) - 1);
+    sx = gl & 1023; sy = (gl >> 10) & 1023; sz = gl >> 20;
+    if (tid == 0) {   // list ordinal of the winner from its tie rank (off the critical path)
+      const unsigned rr = rmask - (g & rmask);
+      const unsigned hi = rr / (unsigned)pr.q, lo = rr - hi * (unsigned)pr.q;
+      const unsigned rev = pr.L ? (__brev(hi) >> (32 - pr.L)) : 0u;
+      pr.idx[j] = (int)((lo << pr.L) | rev);
+    }
+    if (dbg) { long long c4 = clock64(); tA += c1 - c0; tM += c2 - c1; tB += c3 - c2; tT += c4 - c3; }
+  }
+  if (dbg && lane == 0 && blockIdx.x == 0) {
+    long long* o = dbg + wave * 8;
+    o[0] = tA; o[1] = tM; o[2] = tB; o[3] = tT; o[4] = 0; o[5] = nd;
+  }
+}
+
 extern "C" size_t coocc_fps_voxels_ws(int X, int Y, int Z) {
   size_t nb = (size_t)((X + FT_X - 1) / FT_X) * ((Y + FT_Y - 1) / FT_Y) * ((Z + FT_Z - 1) / FT_Z);
   return nb * FT_P * sizeof(FpsCell);
@@ -389,33 +527,65 @@ static long long* g_fps_dbg = nullptr;
 extern "C" void coocc_fps_voxels_set_debug(long long* p) { g_fps_dbg = p; }
 extern "C" void coocc_fps_voxels_set_threads(int t) { g_fps_threads = t; }
 
-extern "C" int coocc_fps_voxels(const int32_t* lin, int n, int X, int Y, int Z, int m, int32_t* idx, void* ws,
-                                size_t ws_bytes, void* stream) {
+struct FpsPrep { int NBX, NBY, NBZ, L, q, RB, tinit, threads, R; long long NB; bool key32; };
+
+// argument checks + tie-rank layout + the initial cell table ({tinit, rank} per position, -1 = empty): memset + scatter
+static int fps_prepare(const int32_t* lin, int n, int X, int Y, int Z, int m, const int32_t* idx, void* ws, size_t ws_bytes,
+                       hipStream_t s, FpsPrep* o) {
   COOCC_CHECK_ARG(lin && idx && ws && n > 0 && m >= 0 && X > 0 && Y > 0 && Z > 0, "fps_voxels: bad args");
   COOCC_CHECK_ARG(n < (1 << FPS_KBITS), "fps_voxels: n must be < 2^22");
   COOCC_CHECK_ARG(X <= 1020 && Y <= 1020 && Z <= 1016, "fps_voxels: grid dims must fit 10-bit packed coordinates");
-  if (m == 0) return COOCC_OK;
-  const int NBX = (X + FT_X - 1) / FT_X, NBY = (Y + FT_Y - 1) / FT_Y, NBZ = (Z + FT_Z - 1) / FT_Z;
-  const long long NB = (long long)NBX * NBY * NBZ;
+  o->NBX = (X + FT_X - 1) / FT_X; o->NBY = (Y + FT_Y - 1) / FT_Y; o->NBZ = (Z + FT_Z - 1) / FT_Z;
+  o->NB = (long long)o->NBX * o->NBY * o->NBZ;
   // 4 waves (one per SIMD) keep the per-sample instruction stream short; larger bucket tables
   // spread over more waves so that a lane owns at most 8 buckets.
   int threads = g_fps_threads;
-  while (NB > 8ll * threads && threads < 1024) threads *= 2;
-  COOCC_CHECK_ARG(NB <= 8ll * threads, "fps_voxels: grid has too many buckets (use coocc_furthest_point_sampling)");
+  while (o->NB > 8ll * threads && threads < 1024) threads *= 2;
+  COOCC_CHECK_ARG(o->NB <= 8ll * threads, "fps_voxels: grid has too many buckets (use coocc_furthest_point_sampling)");
   if (ws_bytes < coocc_fps_voxels_ws(X, Y, Z)) return coocc_set_error(COOCC_ENOMEM, "fps_voxels: workspace too small");
-  const int R = (int)((NB + threads - 1) / threads);
+  o->threads = threads;
+  o->R = (int)((o->NB + threads - 1) / threads);
   int L = 0;
   while ((2 << L) <= n && L < 10) ++L;            // block = min(2^floor(log2 n), 1024) = 1 << L
   const int q = (n + (1 << L) - 1) >> L;          // tie ranks live in [0, q << L)
   int RB = L;
   while ((1ll << RB) <= ((long long)q << L)) ++RB;   // strict: rank rmask is never used, key 0 stays "empty"
   const long long d2max = (long long)(X - 1) * (X - 1) + (long long)(Y - 1) * (Y - 1) + (long long)(Z - 1) * (Z - 1);
-  const bool key32 = RB < 31 && d2max + 1 < (1ll << (32 - RB)) - 1;
-  const int tinit = key32 ? (int)((1u << (32 - RB)) - 1u) : 0x7FFFFFFF;
+  o->key32 = RB < 31 && d2max + 1 < (1ll << (32 - RB)) - 1;
+  o->tinit = o->key32 ? (int)((1u << (32 - RB)) - 1u) : 0x7FFFFFFF;
+  o->L = L; o->q = q; o->RB = RB;
+  if (m == 0) return COOCC_OK;
   FpsCell* cell = (FpsCell*)ws;
+  COOCC_HIP(hipMemsetAsync(cell, 0xFF, sizeof(FpsCell) * (size_t)o->NB * FT_P, s));
+  hipLaunchKernelGGL(k_fpsv_scatter, dim3(cdiv(n, 256)), dim3(256), 0, s, lin, n, Y, Z, o->NBY, o->NBZ, L, q, o->tinit, cell);
+  COOCC_LAUNCH_CHECK("k_fpsv_scatter");
+  return COOCC_OK;
+}
+
+static int g_fps_reg = -1;      // COOCC_FPS_REG=0: always the L2-resident kernel
+static bool fps_reg_ok(const FpsPrep& o) {
+  if (g_fps_reg < 0) g_fps_reg = getenv("COOCC_FPS_REG") ? atoi(getenv("COOCC_FPS_REG")) : 1;
+  return g_fps_reg && o.key32 && o.NB <= (long long)FPSR_SLOTS * 16;
+}
+
+extern "C" int coocc_fps_voxels(const int32_t* lin, int n, int X, int Y, int Z, int m, int32_t* idx, void* ws,
+                                size_t ws_bytes, void* stream) {
   hipStream_t s = as_stream(stream);
-  COOCC_HIP(hipMemsetAsync(cell, 0xFF, sizeof(FpsCell) * (size_t)NB * FT_P, s));
-  hipLaunchKernelGGL(k_fpsv_scatter, dim3(cdiv(n, 256)), dim3(256), 0, s, lin, n, Y, Z, NBY, NBZ, L, q, tinit, cell);
+  FpsPrep o;
+  int rc = fps_prepare(lin, n, X, Y, Z, m, idx, ws, ws_bytes, s, &o);
+  if (rc != COOCC_OK || m == 0) return rc;
+  FpsCell* cell = (FpsCell*)ws;
+  const int NBY = o.NBY, NBZ = o.NBZ, L = o.L, q = o.q, RB = o.RB, R = o.R, threads = o.threads;
+  const long long NB = o.NB;
+  const bool key32 = o.key32;
+  if (fps_reg_ok(o)) {
+    FpsRegArgs a = {};
+    a.p[0] = FpsRegProblem{lin, cell, idx, n, L, q, RB};
+    a.m = m; a.Y = Y; a.Z = Z; a.NBY = NBY; a.NBZ = NBZ; a.NB = (int)NB; a.dbg = g_fps_dbg;
+    hipLaunchKernelGGL(k_fps_voxels_reg, dim3(1), dim3(1024), 0, s, a);
+    COOCC_LAUNCH_CHECK("k_fps_voxels_reg");
+    return COOCC_OK;
+  }
 #define FPS_LAUNCH(T, RM, KT) \
   hipLaunchKernelGGL((k_fps_voxels<T, RM, KT>), dim3(1), dim3(T), 0, s, n, m, Y, Z, NBY, NBZ, (int)NB, lin, cell, idx, L, q, \
                      key32 ? RB : 32, g_fps_dbg)
@@ -435,6 +605,43 @@ extern "C" int coocc_fps_voxels(const int32_t* lin, int n, int X, int Y, int Z, 
   else if (threads == 512) FPS_PICK(512);
   else FPS_PICK(1024);
   COOCC_LAUNCH_CHECK("k_fps_voxels");
+  return COOCC_OK;
+}
+
+// Both search directions of BiFuser_N (bifuser_n.py:132,152: FPS over the pts list and over the img list, same grid, same m) in
+// ONE launch of two workgroups.  Returns COOCC_OK, or 2 (nothing launched, no error text) when the grid is too large for the
+// register-resident kernel: the caller then issues two coocc_fps_voxels calls on two streams.
+extern "C" int coocc_fps_voxels_pair(const int32_t* lin0, int n0, int32_t* idx0, void* ws0, const int32_t* lin1, int n1, int32_t* idx1,
+                                     void* ws1, size_t ws_bytes_each, int X, int Y, int Z, int m, void* stream) {
+  COOCC_CHECK_ARG(X > 0 && Y > 0 && Z > 0 && n0 > 0 && n1 > 0, "fps_voxels_pair: bad args");
+  {
+    // eligibility before anything is enqueued (same rules as fps_prepare / fps_reg_ok)
+    const long long NB = (long long)((X + FT_X - 1) / FT_X) * ((Y + FT_Y - 1) / FT_Y) * ((Z + FT_Z - 1) / FT_Z);
+    if (NB > (long long)FPSR_SLOTS * 16) return 2;
+    const long long d2max = (long long)(X - 1) * (X - 1) + (long long)(Y - 1) * (Y - 1) + (long long)(Z - 1) * (Z - 1);
+    for (int n : {n0, n1}) {
+      int L = 0;
+      while ((2 << L) <= n && L < 10) ++L;
+      const int q = (n + (1 << L) - 1) >> L;
+      int RB = L;
+      while ((1ll << RB) <= ((long long)q << L)) ++RB;
+      if (!(RB < 31 && d2max + 1 < (1ll << (32 - RB)) - 1)) return 2;
+    }
+    if (g_fps_reg < 0) g_fps_reg = getenv("COOCC_FPS_REG") ? atoi(getenv("COOCC_FPS_REG")) : 1;
+    if (!g_fps_reg) return 2;
+  }
+  hipStream_t s = as_stream(stream);
+  FpsPrep o0, o1;
+  int rc = fps_prepare(lin0, n0, X, Y, Z, m, idx0, ws0, ws_bytes_each, s, &o0);
+  if (rc != COOCC_OK) return rc;
+  rc = fps_prepare(lin1, n1, X, Y, Z, m, idx1, ws1, ws_bytes_each, s, &o1);
+  if (rc != COOCC_OK || m == 0) return rc;
+  FpsRegArgs a = {};
+  a.p[0] = FpsRegProblem{lin0, (const FpsCell*)ws0, idx0, n0, o0.L, o0.q, o0.RB};
+  a.p[1] = FpsRegProblem{lin1, (const FpsCell*)ws1, idx1, n1, o1.L, o1.q, o1.RB};
+  a.m = m; a.Y = Y; a.Z = Z; a.NBY = o0.NBY; a.NBZ = o0.NBZ; a.NB = (int)o0.NB; a.dbg = g_fps_dbg;
+  hipLaunchKernelGGL(k_fps_voxels_reg, dim3(2), dim3(1024), 0, s, a);
+  COOCC_LAUNCH_CHECK("k_fps_voxels_reg");
   return COOCC_OK;
 }
 

@@ -110,6 +110,12 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
   SRC(coocc_voxel_index_map(lin_img, Ni, V, map_img, stream));
   SRC(coocc_voxel_index_map(lin_pts, Np, V, map_pts, stream));
 
+  // K2 of BOTH directions as one launch of two workgroups when the grid fits the register-resident kernel (csrc/knn.hip); the
+  // rest of each direction then forks onto its own stream.  Otherwise each direction runs its own FPS on its stream.
+  const int pair_rc = coocc_fps_voxels_pair(lin_pts, Np, w.rep[0], w.fps[0], lin_img, Ni, w.rep[1], w.fps[1], w.fps_bytes, d->X, d->Y, d->Z,
+                                            d->fps_num, stream);
+  if (pair_rc != COOCC_OK && pair_rc != 2) return pair_rc;
+  const bool paired = pair_rc == COOCC_OK;
   hipEvent_t fork, join;
   COOCC_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
   COOCC_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
@@ -119,7 +125,7 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
   // one direction: queries (lin_q, Q, xyz_q, map_q) <- keys (Nk, xyz_k, map_k); near: [K][Q] key ordinals (-1 = none)
   auto direction = [&](int dd, void* st, const int32_t* lin_q, int Q, const float* xyz_q, const int32_t* map_q, int Nk,
                        const float* xyz_k, const int32_t* map_k, int32_t* near) -> int {
-    SRC(coocc_fps_voxels(lin_q, Q, d->X, d->Y, d->Z, d->fps_num, w.rep[dd], w.fps[dd], w.fps_bytes, st));
+    if (!paired) SRC(coocc_fps_voxels(lin_q, Q, d->X, d->Y, d->Z, d->fps_num, w.rep[dd], w.fps[dd], w.fps_bytes, st));
     hipLaunchKernelGGL(k_gather_xyz, dim3(cdiv(d->fps_num, 256)), dim3(256), 0, as_stream(st), xyz_q, w.rep[dd], d->fps_num, w.rep_xyz[dd]);
     COOCC_LAUNCH_CHECK("k_gather_xyz");
     SRC(coocc_knn_topk_voxels(d->fps_num, Nk, K, d->X, d->Y, d->Z, w.rep[dd], lin_q, map_k, d->offsets, d->noff, w.rep_xyz[dd], xyz_k,

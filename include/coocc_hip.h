@@ -90,6 +90,12 @@ int coocc_furthest_point_sampling(int b, int n, int m, const float* points, floa
 size_t coocc_fps_voxels_ws(int X, int Y, int Z);
 int coocc_fps_voxels(const int32_t* lin, int n, int X, int Y, int Z, int m, int32_t* idx, void* ws,
                      size_t ws_bytes, void* stream);
+/* The two FPS problems of BiFuser_N's search (bifuser_n.py:132 over the pts list, :152 over the img list; same grid, same m) as
+ * ONE launch of two workgroups.  Taken when the grid has at most 640 buckets of 4x4x8 voxels (100x100x8: 625), where the whole
+ * distance table lives in the register file (no memory access inside the 2047 dependent iterations).  Returns COOCC_OK, or 2
+ * with nothing enqueued when the grid is too large (call coocc_fps_voxels twice instead).  Same selections as coocc_fps_voxels. */
+int coocc_fps_voxels_pair(const int32_t* lin0, int n0, int32_t* idx0, void* ws0, const int32_t* lin1, int n1, int32_t* idx1,
+                          void* ws1, size_t ws_bytes_each, int X, int Y, int Z, int m, void* stream);
 
 /* [EXT] ball_query_wrapper (M/ops/ball_query/src/ball_query.cpp:32-45; kernel
  * ball_query_cuda.cu:11-54).  new_xyz:[b,m,3] centres, xyz:[b,n,3], idx:[b,m,nsample]
