@@ -503,13 +503,16 @@ __global__ __launch_bounds__(1024) void k_fps_voxels_reg(FpsRegArgs a) {
     const u64 own = __ballot(mine == g) & 0xFFFFull;
     const int gl = __builtin_amdgcn_readlane(ml, (int)__ffsll((long long)own) - 1);
     sx = gl & 1023; sy = (gl >> 10) & 1023; sz = gl >> 20;
-    if (tid == 0) {   // list ordinal of the winner from its tie rank (off the critical path)
-      const unsigned rr = rmask - (g & rmask);
-      const unsigned hi = rr / (unsigned)pr.q, lo = rr - hi * (unsigned)pr.q;
-      const unsigned rev = pr.L ? (__brev(hi) >> (32 - pr.L)) : 0u;
-      pr.idx[j] = (int)((lo << pr.L) | rev);
-    }
+    if (tid == 0) pr.idx[j] = (int)(g & rmask);      // the winner's tie rank; turned into its list ordinal after the loop (a division:
+                                                     // inside the loop it made wave 0 the one every barrier waits for)
     if (dbg) { long long c4 = clock64(); tA += c1 - c0; tM += c2 - c1; tB += c3 - c2; tT += c4 - c3; }
+  }
+  __syncthreads();
+  for (int j = 1 + tid; j < m; j += 1024) {
+    const unsigned rr = rmask - (unsigned)pr.idx[j];
+    const unsigned hi = rr / (unsigned)pr.q, lo = rr - hi * (unsigned)pr.q;
+    const unsigned rev = pr.L ? (__brev(hi) >> (32 - pr.L)) : 0u;
+    pr.idx[j] = (int)((lo << pr.L) | rev);
   }
   if (dbg && lane == 0 && blockIdx.x == 0) {
     long long* o = dbg + wave * 8;
