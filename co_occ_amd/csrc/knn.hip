@@ -957,6 +957,10 @@ __global__ void k_assign_winner(int nc, int K, int ns, int nq, float thresh, con
   if (i >= nc * ns) return;
   int c = i / ns;
   int qi = group[i];
+  // ball_query pads a short group with its FIRST member (ball_query_cuda.cu:47-52): those entries repeat the atomic entry 0 of the
+  // group already issues (atomicMax with the same value is idempotent) -- and at 12 % LiDAR occupancy they are half of all
+  // entries, all serialising on one address per centre
+  if (i != c * ns && qi == group[c * ns]) return;
   for (int k = 0; k < K; ++k)
     if (val[c * K + k] < thresh) atomicMax(&winner[(size_t)k * nq + qi], c);
 }
