@@ -37,6 +37,23 @@ __global__ __launch_bounds__(256) void k_ncdhw_to_ndhwc(const float* __restrict_
   // still spread over the whole chip
   const int c0 = blockIdx.z * TC;
   const int cn = min(TC, C - c0);
+  if (cn == TC) {
+    // full slab (every shipped shape): 32 independent loads per thread in flight, no division in the store loop
+    const int v = v0 + (t & 63);
+    const float* sp = src + ((size_t)b * C + c0 + (t >> 6)) * V + v;
+    float r[TC / 4];
+#pragma unroll
+    for (int k = 0; k < TC / 4; ++k) r[k] = v < V ? sp[(size_t)(4 * k) * V] : 0.f;
+#pragma unroll
+    for (int k = 0; k < TC / 4; ++k) tile[t & 63][(t >> 6) + 4 * k] = r[k];
+    __syncthreads();
+#pragma unroll 8
+    for (int i = t; i < TV * TC; i += 256) {
+      const int vv = i >> 7, c = i & (TC - 1);
+      if (v0 + vv < V) dst[((size_t)b * V + v0 + vv) * dst_stride + dst_coff + c0 + c] = tile[vv][c];
+    }
+    return;
+  }
   for (int c = t >> 6; c < cn; c += 4) {
     int v = v0 + (t & 63);
     tile[t & 63][c] = v < V ? src[((size_t)b * C + c0 + c) * V + v] : 0.f;

@@ -164,6 +164,7 @@ class COOCC_Ray(nn.Module):
         """``nn.Module.train`` for everything but the frozen sparse LiDAR encoder, which keeps its eval-mode path (an
         unchanged tools/train.py calls ``model.train()`` on the whole detector)."""
         super().train(mode)
+        from . import lidar
         enc = getattr(self, "pts_middle_encoder", None)
         if mode and enc is not None and isinstance(enc, tuple(lidar.MIDDLE_ENCODERS.module_dict.values())):
             enc.eval()

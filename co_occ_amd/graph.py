@@ -67,7 +67,8 @@ class DenseGraph:
         """Host-side check of a sample's voxel counts against the capacities the graph was captured with."""
         Ni, Np = counts
         from . import fuser
-        cap = self.model.occ_fuser.c0_capacity(self.slot.V) if fuser.SPLIT_C0 else self.slot.V   # the dense form of con_enc.0 has no capacity
+        split = fuser.SPLIT_C0 or self.slot.V > fuser.DENSE_C0_MAX_VOXELS
+        cap = self.model.occ_fuser.c0_capacity(self.slot.V) if split else self.slot.V   # the dense form of con_enc.0 has no capacity
         return 0 < Np <= cap and Ni > 0
 
     def replay(self):

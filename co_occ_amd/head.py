@@ -19,6 +19,11 @@ FUSED_FINE_MLP = __import__("os").environ.get("COOCC_FUSED_FINE_MLP", "1") != "0
 # ... and the two Linear layers that precede a resampling applied before it, on the (much smaller) source grids
 # (coocc_fine_mlp_pre); 0 = sample the 128-channel sources as the reference does
 FINE_LINEAR_FIRST = __import__("os").environ.get("COOCC_FINE_LINEAR_FIRST", "1") != "0"
+# the whole fine branch (two resamplings + MLP chain) in one launch (csrc/fine_fused.hip): 0 = three kernels, 1 = one launch for
+# cascade ratio 4 (OpenOccupancy: 64 children per coarse voxel, 5 GB of intermediates saved, +6 % samples/s), 2 = also for ratio 2
+# (measured at configs[1]: 383 us against 334 us for the three kernels -- the wave-serial phases at 2 waves per SIMD hide less gather
+# latency than the samplers' own launches at 4+; kept off there)
+FINE_FUSED = int(__import__("os").environ.get("COOCC_FINE_FUSED", "1"))
 
 
 def _conv3d(conv_cfg, cin, cout, k, pad):
@@ -176,6 +181,10 @@ class OccHead(nn.Module):
             # voxels instead of on the 8 V fine points: a Linear commutes with the interpolation that follows it
             P = linear_rows(g, p["img_nb"])
             Q = linear_rows(ovf.t, p["f0_vox_nb"], in_coff=ovf.coff, in_C=128)
+            if self._fused_fine_ok(ovf, N_i):
+                logits = torch.empty(nf, self.out_channel, device=dev, dtype=_F32)
+                self._fine_fused(p, ovf, Q, P, params, (N_i, Hf, Wf), lin, n, None, fine_xyz, logits)
+                return logits, fine_xyz
             vq = torch.empty(nf, 64, device=dev, dtype=_F32)
             call("coocc_fine_sample_voxel", ptr(Q), 64, ovf.X, ovf.Y, ovf.Z, ptr(lin), n, r,
                  host_i32(self.final_occ_size), ptr(fine_xyz), ptr(vq), 64)
@@ -234,6 +243,10 @@ class OccHead(nn.Module):
         fine_xyz = torch.empty(3 * nf, device=dev, dtype=_I64)
         P = linear_rows(g, p["img_nb"])
         Q = linear_rows(ovf.t, p["f0_vox_nb"], in_coff=ovf.coff, in_C=128)
+        if self._fused_fine_ok(ovf, N_i):
+            logits = torch.empty(nf, self.out_channel, device=dev, dtype=_F32)
+            self._fine_fused(p, ovf, Q, P, params, (N_i, Hf, Wf), lin, V, cnt, fine_xyz, logits)
+            return logits, fine_xyz, cnt
         vq = torch.empty(nf, 64, device=dev, dtype=_F32)
         call("coocc_fine_sample_voxel_dev", ptr(Q), 64, ovf.X, ovf.Y, ovf.Z, ptr(lin), V, ptr(cnt), r,
              host_i32(self.final_occ_size), ptr(fine_xyz), ptr(vq), 64)
@@ -246,6 +259,23 @@ class OccHead(nn.Module):
              float(gi.eps), d(l0.weight), d(l0.bias), d(g0.weight), d(g0.bias), float(g0.eps), d(l3.weight), d(l3.bias),
              self.out_channel, ptr(logits))
         return logits, fine_xyz, cnt
+
+    def _fused_fine_ok(self, ovf, ncam):
+        """One-launch fine branch (csrc/fine_fused.hip): ratio 2 | 4, final grid = ratio x coarse grid, <= 8 cameras."""
+        r = self.cascade_ratio
+        return (((FINE_FUSED >= 1 and r == 4) or (FINE_FUSED >= 2 and r == 2)) and ncam <= 8 and self.out_channel <= 32
+                and tuple(int(v) for v in self.final_occ_size) == (r * ovf.X, r * ovf.Y, r * ovf.Z))
+
+    def _fine_fused(self, p, ovf, Q, P, params, img_dims, lin, n_cap, cnt, fine_xyz, logits):
+        N_i, Hf, Wf = img_dims
+        gi, l0, g0, l3, li = self.img_mlp[1], self.fine_mlp[0], self.fine_mlp[1], self.fine_mlp[3], self.img_mlp[0]
+        d = lambda t: ptr(t.detach())
+        nf = n_cap * self.cascade_ratio ** 3
+        with TIMER.region("k_fine_fused", 2.0 * nf * 64 * (64 + self.out_channel)):
+            call("coocc_fine_fused", ptr(Q), ovf.X, ovf.Y, ovf.Z, ptr(P), N_i, Hf, Wf, ptr(params), ptr(lin), int(n_cap),
+                 ptr(cnt, _I32) if cnt is not None else None, self.cascade_ratio, host_i32(self.final_occ_size), d(li.bias), d(gi.weight),
+                 d(gi.bias), float(gi.eps), d(l0.weight), d(l0.bias), d(g0.weight), d(g0.bias), float(g0.eps), d(l3.weight), d(l3.bias),
+                 self.out_channel, ptr(fine_xyz), ptr(logits))
 
     def _projection_params(self, transform, ovf, dev):
         """Per-sample matrices of project_points_on_img (coordinate_transform.py:25-65), b = 0, packed by one

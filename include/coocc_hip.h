@@ -544,6 +544,19 @@ int coocc_lift_splat_reuse(const float* depth, const float* feat_nhwc, int N, in
 int coocc_bev_pool_coords(const float* x, const int64_t* coords, int n, int C, int B, int X, int Y,
                           int Z, float* out, int out_stride, void* ws, size_t ws_bytes, int ws_clean, void* stream);
 
+/* OccHead fine branch in ONE launch (occ_head.py:205-233, eval, B == 1): fine coordinates + trilinear resampling of Q + bilinear
+ * resampling of P over the cameras that see each point + GroupNorm / ReLU / Linear chain -> logits, for cascade ratio 2 | 4.
+ * Q: [X*Y*Z, 64] = W_f0[:, :128] . voxel features, P: [ncam*Hf*Wf, 64] = W_img . image features (both Linear layers applied
+ * BEFORE the resampling they commute with, as for coocc_fine_mlp_pre); coarse_lin: the foreground coarse voxels (n_dev != NULL:
+ * at most n_cap of them, count read on the device); final_size_host = ratio * (X, Y, Z).  Outputs as coocc_fine_sample_voxel +
+ * coocc_fine_mlp_pre (fine_xyz [3][n ratio^3], logits [n ratio^3, ncls], row o * n + i), bit-identical to that three-kernel
+ * path, without its two [n ratio^3, 64] intermediates in HBM. */
+int coocc_fine_fused(const float* Q, int X, int Y, int Z, const float* P, int ncam, int Hf, int Wf, const float* params,
+                     const int32_t* coarse_lin, int n_cap, const int32_t* n_dev, int ratio, const int* final_size_host,
+                     const float* b_img, const float* gn_img_w, const float* gn_img_b, float eps_img, const float* w_f0,
+                     const float* b_f0, const float* gn_f0_w, const float* gn_f0_b, float eps_f0, const float* w_f3,
+                     const float* b_f3, int ncls, int64_t* fine_xyz, float* out, void* stream);
+
 /* ---------------------------------------------------------------- R1..R3, L1 */
 /* inline render block, one launch for all cameras (P/coocc/detectors/coocc_ray.py:575-616).
  * table:[X*Y*Z,4] = raw (sigma, r, g, b) head outputs per voxel -- the heads are pointwise,

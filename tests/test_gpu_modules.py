@@ -494,6 +494,35 @@ def test_fine_mlp_fused_equals_layerwise(dev, monkeypatch):
     assert float((outs[2] - outs[1]).abs().max()) <= 2e-5 * sc
 
 
+@pytest.mark.parametrize("ratio", [2, 4])
+def test_fused_fine_branch_equals_three_kernel_path(dev, monkeypatch, ratio):
+    """csrc/fine_fused.hip (two resamplings + MLP chain in one launch, samples in an LDS tile) against the three-kernel path it
+    replaces (k_fine_sample_voxel_r2 / _rn -> k_fine_sample_img_grp -> k_fine_mlp<pre>): the same expressions in the same
+    order, so the fine coordinates are equal and the logits bit-identical; a foreground count that is not a multiple of the
+    8 coarse voxels a wave owns (ratio 2) is part of the case."""
+    from co_occ_amd import head as H
+    c = cases.DECODER_CASE
+    grid = (9, 7, 4) if ratio == 2 else (8, 8, 4)
+    final = tuple(v * ratio for v in grid)
+    cfg = synth.model_cfg(C=c["C"], block_inplanes=c["block_inplanes"], out_channels=c["fpn_out"], cascade_ratio=ratio,
+                          final_occ_size=final, point_cloud_range=c["point_cloud_range"])
+    head, _ = load_seeded(pkg.build_head(cfg["pts_bbox_head"]), 31, dev)
+    g = torch.Generator().manual_seed(9)
+    sem = [torch.randn(1, c["fpn_out"], *[max(1, -(-v // 2 ** l)) for v in grid], generator=g).to(dev) for l in range(4)]
+    rig = synth.camera_rig(c["ncam"], c["input_size"], seed=9)
+    img_feats = [synth.image_feats(c["ncam"], c["fmap"], 512, seed=9).to(dev)]
+    tr = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synth.rig_transform(rig))
+    outs = []
+    with torch.no_grad():
+        for fused in (0, 2):
+            monkeypatch.setattr(H, "FINE_FUSED", fused)
+            res = head(voxel_feats=sem, img_feats=img_feats, transform=tr)
+            outs.append((res["output_voxels_fine"][0].clone(), res["output_coords_fine"][0].clone()))
+    assert outs[0][0].shape[0] > 0 and outs[0][0].shape[0] % ratio ** 3 == 0
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[1][0])
+
+
 def test_predict_labels_and_nuscenes_dump(dev, tmp_path):
     """Prediction dump (output formats): device-side resample + argmax -> uint8 labels equal the
     oracle's except inside the float tolerance of an argmax tie; the pickle has the upstream keys and types."""

@@ -41,5 +41,21 @@ for k, c in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"])[:18]:
     print("%-46s %6d %10.3f %10.3f %10.3f %10.3f %12.0f" % (k, calls[k], c["SQ_VALU_MFMA_BUSY_CYCLES"] / busy, c["SQ_WAIT_ANY"] / wave, c["SQ_WAIT_INST_ANY"] / wave, c["SQ_WAIT_INST_LDS"] / wave, c["SQ_LDS_BANK_CONFLICT"]))
 PY
 timeout 300 python $R/tools/h2_check.py acc time direct general 2>&1 | grep -v amdgpu.ids > $O/r3_h2_check.txt
+# the two stages alone: dense-stage ceiling at 1..4 graphs in flight, the prefetch stage (pooling + search) kernel by kernel
+timeout 300 python $R/tools/dense_concurrency.py 2>&1 | grep -v amdgpu.ids > $O/r3_dense_concurrency.txt
+rm -rf /tmp/sp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sp -o s -- python $R/tools/search_probe.py > $O/r3_search_stage.txt 2>&1
+python - >> $O/r3_search_stage.txt 2>&1 < /dev/null <<PY
+import csv
+rows = list(csv.DictReader(open("/tmp/sp/s_kernel_stats.csv")))
+tot = 0.0
+print("per sample (23 calls traced), kernel trace of tools/search_probe.py:")
+for r in rows[:32]:
+    per = float(r["TotalDurationNs"]) / 23 / 1e3
+    tot += per
+    print("%-62s x%5.1f  %8.1f us/sample  avg %7.1f us" % (r["Name"][:62], int(r["Calls"]) / 23, per, float(r["AverageNs"]) / 1e3))
+print("sum %.1f us per sample" % tot)
+PY
+timeout 300 python $R/tools/kbench.py fps fpsdbg pool 2>&1 | grep -v amdgpu.ids > $O/r3_kbench_search.txt
 cut -c1-1200 $O/r3_bench_default.json
 head -30 $O/r3_dense_stage_kernels.txt; head -12 $O/r3_bench_pmc_hbm.txt; head -8 $O/r3_bench_pmc_sq.txt
