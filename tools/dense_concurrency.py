@@ -2,6 +2,7 @@
 no index search) -> samples/s the dense stage alone allows at N graphs in flight.  Compare with bench.py's pipeline number to see
 what the prefetched search stage costs."""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")       # as bench.py: before HIP starts
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
