@@ -224,101 +224,89 @@ __global__ __launch_bounds__(256) void k_keys_hist(KeySrc a, int npts, int X, in
   if (valid) slot[i] = myslot;
 }
 
-// Launch 2 of 3: exclusive scan of count[0..nvox) -> start[], list of the voxels with more than POOL_MEDIUM points, the CSR
-// fill  ids[start[key] + slot] = id  -- and count[] zeroed again for the next call on this workspace -- in ONE kernel of at most
-// 256 workgroups (all resident: one per CU) separated by two grid barriers.  Round 2 ran this as four launches (local scan, scan
-// of the block totals, finish, fill) + a memset; the launches, not the work, were the cost (5 x ~5 us on a prefetch stream that
-// shares the GPU with the dense stage).
-// Grid barrier: bar[0] counts arrivals and is reset by the last one (so it is zero between barriers and between calls), bar[1] is a
-// generation number that only ever grows -- no initial value needed.
-__device__ __forceinline__ void pool_grid_barrier(int32_t* bar, int G) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const int gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int old = atomicAdd(&bar[0], 1);
-    if (old == G - 1) {
-      atomicExch(&bar[0], 0);
-      __threadfence();
-      atomicAdd(&bar[1], 1);
-    } else {
-      while (__hip_atomic_load(&bar[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(4);
-    }
-    __threadfence();
+// Launches 2 and 3 of 4: the CSR.  k_scan_local: exclusive scan of count[] inside each 1024-voxel chunk (lstart[]) + the chunk
+// totals (tops[]).  k_csr_fill: every workgroup first scans the (<= POOL_MAX_CHUNKS) chunk totals into LDS, then
+// (a) scatters its points, ids[lstart[key] + prefix[key >> 10] + slot] = id, no atomics, four independent points per thread and
+// iteration (the chain key -> lstart[key] -> store is pure latency), and (b) for the voxels of its own index range writes the
+// global start[] the sums read, appends the voxels with more than POOL_MEDIUM points to long_list and zeroes count[] again -- so
+// the NEXT call on the workspace needs no memset.  Readers of (a) never read what (b) writes: no ordering between workgroups.
+// (A first version of this round ran scan + fill as ONE kernel with two grid barriers: 3 launches, fine alone -- and 10x slower
+// inside the pipeline at r101 / stress200, where its 232-256 spinning workgroups wait for CU slots behind the dense graphs'
+// workgroups: 17 instead of 190 samples/s.  No grid barriers on a GPU that is shared between streams.)
+constexpr int POOL_MAX_CHUNKS = 8192;       // 8.4 M voxels (32 KB of LDS for the chunk prefix)
+
+__global__ __launch_bounds__(1024) void k_scan_local(const int32_t* __restrict__ count, int nvox, int32_t* __restrict__ lstart,
+                                                      int32_t* __restrict__ tops, int32_t* __restrict__ nlong) {
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, v = blockIdx.x * 1024 + tid;
+  if (v == 0) *nlong = 0;                       // the previous call's list length (its consumer ran before this launch)
+  const int c = v < nvox ? count[v] : 0;
+  int inc = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    int n = __shfl_up(inc, o);
+    if ((tid & 63) >= o) inc += n;
   }
+  if ((tid & 63) == 63) wsum[tid >> 6] = inc;
   __syncthreads();
+  int off = inc - c;
+  for (int w = 0; w < (tid >> 6); ++w) off += wsum[w];
+  if (v < nvox) lstart[v] = off;
+  if (tid == 1023) tops[blockIdx.x] = off + c;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_fill(int32_t* __restrict__ count, int nvox, int nblk, int32_t* __restrict__ start,
-                                                     int32_t* __restrict__ tops, int32_t* __restrict__ long_list,
-                                                     int32_t* __restrict__ nlong, int32_t* __restrict__ bar,
-                                                     const uint32_t* __restrict__ keys, int npts, const int32_t* __restrict__ slot,
-                                                     uint32_t* __restrict__ ids) {
-  __shared__ int wsum[16];
-  __shared__ int bsum;
-  const int tid = threadIdx.x, G = gridDim.x;
-  // phase A: exclusive scan inside each 1024-voxel chunk, chunk totals
-  if (blockIdx.x == 0 && tid == 0) *nlong = 0;          // the previous call's list length (its consumer ran before this launch)
-  for (int c = blockIdx.x; c < nblk; c += G) {
-    const int v = c * 1024 + tid;
-    const int cn = v < nvox ? count[v] : 0;
-    int inc = cn;
+__global__ __launch_bounds__(256) void k_csr_fill(const uint32_t* __restrict__ keys, int npts, int nvox, int nblk,
+                                                   const int32_t* __restrict__ lstart, const int32_t* __restrict__ tops,
+                                                   const int32_t* __restrict__ slot, int32_t* __restrict__ count,
+                                                   int32_t* __restrict__ start, int32_t* __restrict__ long_list,
+                                                   int32_t* __restrict__ nlong, uint32_t* __restrict__ ids) {
+  extern __shared__ int prefix[];               // [nblk + 1] exclusive prefix of the chunk totals
+  __shared__ int wsum[4];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x;
+  int carry = 0;
+  for (int base = 0; base < nblk; base += 256) {
+    const int i = base + tid;
+    const int c = i < nblk ? tops[i] : 0;
+    int inc = c;
     for (int o = 1; o < 64; o <<= 1) {
       int n = __shfl_up(inc, o);
       if ((tid & 63) >= o) inc += n;
     }
     if ((tid & 63) == 63) wsum[tid >> 6] = inc;
     __syncthreads();
-    int off = inc - cn;
+    int off = carry + inc - c;
     for (int w = 0; w < (tid >> 6); ++w) off += wsum[w];
-    if (v < nvox) start[v] = off;
-    if (tid == 1023) tops[c] = off + cn;
+    if (i < nblk) prefix[i] = off;
+    if (tid == 255) carry_s = off + c;
     __syncthreads();
+    carry = carry_s;
   }
-  pool_grid_barrier(bar, G);
-  // phase B: chunk offset = sum of the totals of the chunks before it (nblk is 80 .. a few thousand: one block-wide sum per chunk)
-  for (int c = blockIdx.x; c < nblk; c += G) {
-    int part = 0;
-    for (int i = tid; i < c; i += 1024) part += __hip_atomic_load(&tops[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    if ((tid & 63) == 0) wsum[tid >> 6] = part;
-    __syncthreads();
-    if (tid == 0) {
-      int t = 0;
-      for (int w = 0; w < 16; ++w) t += wsum[w];
-      bsum = t;
-    }
-    __syncthreads();
-    const int off = bsum;
-    const int v = c * 1024 + tid;
-    if (v < nvox) {
-      const int cn = count[v];
-      start[v] += off;
-      if (cn > POOL_MEDIUM) long_list[atomicAdd(nlong, 1)] = v;
-      count[v] = 0;                                     // the next call's histogram starts from a clean array
-    }
-    if (c == nblk - 1 && tid == 0) start[nvox] = off + __hip_atomic_load(&tops[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
+  if (tid == 0) prefix[nblk] = carry;
+  __syncthreads();
+  // (b) this workgroup's share of the voxel-side bookkeeping
+  const long long gsz = (long long)gridDim.x * 256;
+  for (long long v = (long long)blockIdx.x * 256 + tid; v <= nvox; v += gsz) {
+    if (v == nvox) { start[nvox] = prefix[nblk]; break; }
+    const int cn = count[v];
+    start[v] = lstart[v] + prefix[v >> 10];
+    if (cn > POOL_MEDIUM) long_list[atomicAdd(nlong, 1)] = (int)v;
+    count[v] = 0;
   }
-  pool_grid_barrier(bar, G);
-  // phase C: plain scatter, no atomics; the order inside a voxel is whatever the histogram's atomics produced
-  // (four independent points per thread and iteration: the chain key -> start[key] -> store is pure latency)
-  const long long step = (long long)G * 1024;
-  for (long long i0 = (long long)blockIdx.x * 1024 + tid; i0 < npts; i0 += 4 * step) {
+  // (a) the scatter
+  for (long long i0 = (long long)blockIdx.x * 256 + tid; i0 < npts; i0 += 4 * gsz) {
     uint32_t k[4];
     int sl[4], st[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const long long i = i0 + u * step;
+      const long long i = i0 + u * gsz;
       k[u] = i < npts ? keys[i] : 0xFFFFFFFFu;
       sl[u] = i < npts ? slot[i] : 0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      st[u] = k[u] < (uint32_t)nvox ? __hip_atomic_load(&start[k[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    for (int u = 0; u < 4; ++u) st[u] = k[u] < (uint32_t)nvox ? lstart[k[u]] + prefix[k[u] >> 10] : 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (k[u] < (uint32_t)nvox) ids[st[u] + sl[u]] = (uint32_t)(i0 + u * step);
+      if (k[u] < (uint32_t)nvox) ids[st[u] + sl[u]] = (uint32_t)(i0 + u * gsz);
   }
 }
 
@@ -550,15 +538,15 @@ __global__ __launch_bounds__(256) void k_pool_sum_csr(const float* __restrict__ 
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// workspace: keys[npts] | ids[npts] | slot[npts] | count[nvox+1] | nlong, barrier words [64] (one memset clears these two when the
-// caller does not vouch for them) | start[nvox+1] | long_list[nvox] | tops[nvox / 1024 + 2]
+// workspace: keys[npts] | ids[npts] | slot[npts] | count[nvox+1] | nlong [64] (one memset clears these two when the caller does
+// not vouch for them) | start[nvox+1] | lstart[nvox+1] | long_list[nvox] | tops[nvox / 1024 + 2]
 extern "C" size_t coocc_voxel_pool_ws(int npts, int nvox) {
   if (npts <= 0 || nvox <= 0) return 0;
-  return 3 * align256(sizeof(uint32_t) * (size_t)npts) + 3 * align256(sizeof(int32_t) * ((size_t)nvox + 1)) + 256 +
+  return 3 * align256(sizeof(uint32_t) * (size_t)npts) + 4 * align256(sizeof(int32_t) * ((size_t)nvox + 1)) + 256 +
          align256(sizeof(int32_t) * ((size_t)nvox / 1024 + 2)) + 8192 + 256;
 }
 
-struct PoolWs { uint32_t *keys, *ids; int32_t *slot, *count, *nlong, *start, *long_list, *tops; size_t zero_bytes; };
+struct PoolWs { uint32_t *keys, *ids; int32_t *slot, *count, *nlong, *start, *lstart, *long_list, *tops; size_t zero_bytes; };
 
 static int carve(void* ws, size_t ws_bytes, int npts, int nvox, PoolWs* p) {
   size_t need = coocc_voxel_pool_ws(npts, nvox);
@@ -568,7 +556,7 @@ static int carve(void* ws, size_t ws_bytes, int npts, int nvox, PoolWs* p) {
   p->keys = (uint32_t*)c; c += a; p->ids = (uint32_t*)c; c += a; p->slot = (int32_t*)c; c += a;
   p->count = (int32_t*)c; c += v; p->nlong = (int32_t*)c; c += 256;
   p->zero_bytes = v + 256;
-  p->start = (int32_t*)c; c += v; p->long_list = (int32_t*)c; c += v; p->tops = (int32_t*)c;
+  p->start = (int32_t*)c; c += v; p->lstart = (int32_t*)c; c += v; p->long_list = (int32_t*)c; c += v; p->tops = (int32_t*)c;
   return COOCC_OK;
 }
 
@@ -587,24 +575,21 @@ static int pool_sums(const float* x, const float* depth, int C, int D, int HW, i
   return COOCC_OK;
 }
 
-// points -> keys + histogram (launch 1) -> scan + CSR fill (launch 2) -> per-voxel sums in ascending point id (launch 3).
+// points -> keys + histogram (launch 1) -> chunk scan (2) -> CSR fill + global starts (3) -> per-voxel sums in ascending point id (4).
 // ws_clean != 0: the caller vouches that this workspace was last written by a pooling call of the SAME (npts, nvox) that returned
-// COOCC_OK (every such call leaves the count array and the barrier words zeroed); otherwise one memset clears them first.
+// COOCC_OK (every such call leaves the count array zeroed); otherwise one memset clears it first.
 template <bool LIFT, int MODE>
 static int pool_build(const KeySrc& ks, const float* x, const float* depth, int npts, int C, int D, int HW, int X, int Y, int Z, int nvox,
                       float* out, int out_stride, const PoolWs& p, int ws_clean, hipStream_t s) {
+  COOCC_CHECK_ARG((nvox + 1023) / 1024 <= POOL_MAX_CHUNKS, "voxel_pool: grids above 8.4 M voxels are not supported");
   if (!ws_clean) COOCC_HIP(hipMemsetAsync(p.count, 0, p.zero_bytes, s));
   hipLaunchKernelGGL(k_keys_hist<MODE>, dim3(cdiv(npts, 256)), dim3(256), 0, s, ks, npts, X, Y, Z, nvox, p.keys, p.count, p.slot);
   const int nblk = (nvox + 1023) / 1024;
-  // at most one 1024-thread workgroup per CU (all resident: the kernel has grid barriers); more than nblk when the fill pass has
-  // the work for it
-  static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-  // grid: a barrier costs ~G serialised atomics, the fill wants parallelism: 80 workgroups at r50 (473 k points), all CUs at r101
-  // (3.8 M points); measured alone: r50 0.166 ms with 80, 0.192 with 256
-  int G = max(nblk, cdiv(npts, 16384));
-  if (G > ncu) G = ncu;
-  hipLaunchKernelGGL(k_scan_fill, dim3(G), dim3(1024), 0, s, p.count, nvox, nblk, p.start, p.tops, p.long_list, p.nlong, p.nlong + 16,
-                     p.keys, npts, p.slot, p.ids);
+  hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(1024), 0, s, p.count, nvox, p.lstart, p.tops, p.nlong);
+  // a quarter of the points per grid pass (four per thread and iteration); every workgroup re-scans the nblk chunk totals
+  const int fill_blocks = max(cdiv(npts, 1024), 1);
+  hipLaunchKernelGGL(k_csr_fill, dim3(fill_blocks), dim3(256), sizeof(int) * ((size_t)nblk + 1), s, p.keys, npts, nvox, nblk, p.lstart, p.tops,
+                     p.slot, p.count, p.start, p.long_list, p.nlong, p.ids);
   return pool_sums<LIFT>(x, depth, C, D, HW, nvox, out, out_stride, p, s);
 }
 

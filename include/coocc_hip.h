@@ -511,11 +511,12 @@ int coocc_bev_pool_backward(const float* out_grad, const int32_t* geom,
                             int d, int h, int w, int n, int c, int n_intervals, float* x_grad,
                             void* stream);
 /* voxel_pooling (P/coocc/image2bev/ViewTransformerLSSVoxel.py:100-123) without argsort and without sorting the points:
- * THREE launches -- (1) quantise (truncate, then range filter) + per-voxel histogram with per-point slots, (2) scan + CSR fill
- * (one kernel, two grid barriers), (3) each voxel sums its rows in ascending point id.  x:[npts,C]; geom:[npts,3];
+ * FOUR launches, none of which waits for another workgroup -- (1) quantise (truncate, then range filter) + per-voxel histogram
+ * with per-point slots, (2) scan inside 1024-voxel chunks, (3) CSR fill (every workgroup re-scans the few chunk totals) + global
+ * starts + histogram zeroed again, (4) each voxel sums its rows in ascending point id.  x:[npts,C]; geom:[npts,3];
  * lo_dx_host = {bx-dx/2 (3), dx (3)}; out: NDHWC rows [B*X*Y*Z, out_stride].  ws >= coocc_voxel_pool_ws(npts, B*X*Y*Z).
  * ws_clean (all pooling entry points): non-zero = the caller vouches that the LAST write to `ws` was a pooling call with the
- * same (npts, nvox) that returned COOCC_OK -- such a call leaves its histogram zeroed, so the memset (a fourth launch) is
+ * same (npts, nvox) that returned COOCC_OK -- such a call leaves its histogram zeroed, so the memset (a fifth launch) is
  * skipped; pass 0 for a fresh / reused-for-something-else / differently-sized workspace. */
 size_t coocc_voxel_pool_ws(int npts, int nvox);
 int coocc_voxel_pool(const float* x, const float* geom, int npts, int pts_per_batch, int C,
