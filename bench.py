@@ -831,7 +831,23 @@ def main():
     roof, extra = rooflines(core.TIMER.summary(), (max(8, min(20, args.steps)) if gp is not None else args.steps), args, rank, args.kernel_table)
     if gp is not None and roof:
         roof["measured"] = ("HIP events around every launch of an eager pass of the same steps right after the timed region "
-                            "(inside it the dense stage is one hipGraphLaunch per sample)")
+                            "(inside it the dense stage is one hipGraphLaunch per sample); the next sample's pooling + index search run "
+                            "beside it as in the timed region")
+        if not args.no_kernel_timing:
+            # the dominant kernel's own rate: the same eager steps with NOTHING else on the GPU (no prefetch: search, then dense stage)
+            pipe_alone = Pipeline(model, samples, dev, streams[:1], prefetch=False, world=1)
+            pipe_alone.run(2, 1)
+            core.TIMER.enabled, core.TIMER.only = 1, ("k_conv", "k_gemm")
+            core.TIMER.reset()
+            pipe_alone.run(6, 1)
+            torch.cuda.synchronize()
+            core.TIMER.enabled, core.TIMER.only = False, None
+            r_al, _ = rooflines(core.TIMER.summary(), 6, args, rank, False)
+            core.TIMER.reset()
+            if r_al and r_al.get("kernel") == roof.get("kernel"):
+                roof.update(achieved_alone=r_al["achieved"], frac_alone=r_al["frac"], avg_launch_ms_alone=r_al["avg_launch_ms"],
+                            note="achieved / frac: launches that share the CUs with the prefetched search of the next sample (as in the "
+                                 "timed pipeline); *_alone: the same launches with nothing else on the GPU (6 samples, no prefetch)")
     if S > 1 and gp is None and not args.no_kernel_timing:
         # Kernel durations inside the S-stream pipeline include the contention between the samples in flight (that is the
         # point of it: one sample's low-occupancy tail runs under the other's GEMMs).  A short pass of the same pipeline with ONE
