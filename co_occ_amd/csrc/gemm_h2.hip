@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
       const int r8 = j < 4 ? (j * 4 + wave) * 8 : 128;
       const int L = arow0 + r8 + off;
       const char* src = (unsigned)L < (unsigned)total_rows ? tbase + ((unsigned)(srow + r8 + off - minoff) * rowbytes + coff) : zrow;
+      if (ABL & 16) src = zrow;       // ablation: the same instructions, every lane reads the 16 zero bytes (no HBM traffic)
       glds16_(src, &As[buf * STAGE + r8 * 128]);
     }
     if (XY) { if (++gh == ky) { gh = 0; if (++gd == kx) { gd = 0; ++gkc; } } }
@@ -236,12 +237,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
   // one tap (two k16 steps) of the group in stage ST with weight set BB; `nxt`: what the A_hi fragments fetched under the last P2
   // belong to -- the next tap of this group (stage ST, tap DZ + 1), or, for the last tap, step 0 of the next group (other stage,
   // after the barrier that retires this one)
+  bool pendingA = false;
   auto tap = [&](auto stc, auto bbc, auto dzc, bool more_taps, unsigned okbits, unsigned okbits_next) {
     constexpr int ST = decltype(stc)::value, BB = decltype(bbc)::value, DZ = decltype(dzc)::value;
     using STC = std::integral_constant<int, ST>; using SNC = std::integral_constant<int, ST ^ 1>;
     using DZC = std::integral_constant<int, DZ>; using DZN = std::integral_constant<int, (DZ + 1 < KZ ? DZ + 1 : 0)>;
     using BBC = std::integral_constant<int, BB>;
     if (more_taps) loadB(std::integral_constant<int, BB ^ 1>{});
+    // the next group's A image is issued AFTER this tap's weight loads: vector-memory data returns in issue order, so the wait for
+    // these weights (start of the next tap) would otherwise also wait for the image (HBM latency, one tap after its issue)
+    if (DZ == 0 && pendingA) issueA(ST ^ 1);
     if constexpr (TERMS == 1) {
       // four k16 steps, two per phase: steps 2, 3 are fetched under steps 0, 1; the first two steps of the next tap (or of the next
       // group, behind the barrier) under steps 2, 3
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
     constexpr int GP = decltype(gpc)::value;
     using GPC = std::integral_constant<int, GP>;
     const bool last = g + 1 >= ngroups;
-    if (!last) issueA(GP ^ 1);
+    pendingA = !last;
     if (XY) { if (++ch_ == ky) { ch_ = 0; if (++cd == kx) cd = 0; } }
     const unsigned nextbits = xybits();
     tap(GPC{}, std::integral_constant<int, (GP * KZ) & 1>{}, I0{}, KZ > 1 || !last, okbits, nextbits);
@@ -690,6 +695,8 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
       case 4: hipLaunchKernelGGL((k_gemm_h2z<3, false, 4>), grid, dim3(256), 0, s, k); break;
       case 8: hipLaunchKernelGGL((k_gemm_h2z<3, false, 8>), grid, dim3(256), 0, s, k); break;
       case 7: hipLaunchKernelGGL((k_gemm_h2z<3, false, 7>), grid, dim3(256), 0, s, k); break;
+      case 16: hipLaunchKernelGGL((k_gemm_h2z<3, false, 16>), grid, dim3(256), 0, s, k); break;
+      case 24: hipLaunchKernelGGL((k_gemm_h2z<3, false, 24>), grid, dim3(256), 0, s, k); break;
       default: hipLaunchKernelGGL((k_gemm_h2z<3, false, 15>), grid, dim3(256), 0, s, k); break;
     }
     COOCC_LAUNCH_CHECK("k_gemm_h2z<ablation>");
