@@ -552,7 +552,7 @@ class GraphPipeline:
     device->host read of the two voxel counts).  Sample i lives in slot i mod nslots (its own synthetic inputs, resident in
     HBM); a slot is rewritten only after the replay that read it has finished (event)."""
 
-    def __init__(self, model, samples, dev, world=1, ndense=1):
+    def __init__(self, model, samples, dev, world=1, ndense=1, ahead=0):
         from concurrent.futures import ThreadPoolExecutor
         from co_occ_amd import graph as cg
         self.model, self.samples, self.dev, self.world = model, samples, dev, world
@@ -566,7 +566,10 @@ class GraphPipeline:
         self.search_streams = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(self.n)]
         self.slots = [cg.make_slot(model, (X, Y, Z), dev) for _ in range(self.n)]
         self.done = [None] * self.n
-        self.tpool = ThreadPoolExecutor(max(1, self.n - self.ndense))
+        # searches submitted ahead of the dense stage: at most slots - dense streams (a slot is rewritten only after its replay
+        # finished); --ahead limits it further (searches in flight contend with each other and with the dense graphs)
+        self.ahead = self.n - self.ndense if ahead <= 0 else max(1, min(ahead, self.n - self.ndense))
+        self.tpool = ThreadPoolExecutor(max(1, self.ahead))
         self.cg = cg
         self.graphs = []
         self.dense_ev = []
@@ -601,7 +604,7 @@ class GraphPipeline:
 
     def run(self, nsteps, collect=None, time_dense=False):
         futs = {}
-        ahead = self.n - self.ndense
+        ahead = self.ahead
 
         def submit(i):
             if i < nsteps:
@@ -676,6 +679,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default): the dense stage of a sample is one captured hipGraph launch (GraphPipeline); 0: every launch "
                          "issued from Python (Pipeline, --streams)")
+    ap.add_argument("--ahead", type=int, default=0, help="--graph 1: searches submitted ahead of the dense stage (0: slots - dense streams)")
     ap.add_argument("--slots", type=int, default=6, help="--graph 1: samples in flight (1 in its dense stage + slots-1 in the prefetched search)")
     ap.add_argument("--shard", default="samples", choices=["samples", "rays"],
                     help="samples (default): one scene per GPU, weak scaling (configs[3]).  rays: ONE scene over all ranks -- K / G / C "
@@ -746,7 +750,8 @@ def main():
     gp = None
     if args.graph and WITH_POOL[0]:
         try:
-            gp = GraphPipeline(model, samples[:max(2, args.slots)], dev, world, ndense=max(1, args.streams if not auto_streams else 3))
+            gp = GraphPipeline(model, samples[:max(2, args.slots)], dev, world, ndense=max(1, args.streams if not auto_streams else 3),
+                               ahead=args.ahead)
             gp.run(2 * gp.n)
         except Exception as e:           # configurations the static form does not cover run the eager pipeline
             print("bench: hipGraph pipeline unavailable for this configuration (%s: %s); eager pipeline" % (type(e).__name__, e), file=sys.stderr)
