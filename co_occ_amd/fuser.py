@@ -11,6 +11,7 @@ from torch import nn
 
 from . import _lib, streams
 from ._lib import call, ptr
+from . import core as _core_mod
 from .core import PackCache, PackedConv, Rows, conv_rows, gather_conv_rows
 from .registry import FUSION_LAYERS
 
@@ -82,7 +83,7 @@ GRID_SEARCH = __import__("os").environ.get("COOCC_GRID_SEARCH", "1") != "0"   # 
 # the cheaper form at every occupancy the hipGraph is sized for (measured at 12 % occupancy: dense 0.60 ms against 0.36 + 0.46 ms
 # for the split -- the scatter form writes and re-reads a [Np, 27, Cout] fp32 tensor, 265 MB): default off there (+4 % samples/s),
 # COOCC_SPLIT_C0=1 restores it; default on for the fp32-MFMA engine.
-SPLIT_C0 = __import__("os").environ.get("COOCC_SPLIT_C0", "0" if __import__("co_occ_amd.core", fromlist=["x"]).CONV_ENGINE == "h2" else "1") != "0"
+SPLIT_C0 = __import__("os").environ.get("COOCC_SPLIT_C0", "0" if _core_mod.CONV_ENGINE == "h2" else "1") != "0"
 SPLIT_C0_MAX_DENSITY = 0.30      # above this share of LiDAR voxels the dense 4C-channel GEMM is the cheaper form
 # ... and only where it is validated end to end: with all 4C channels in F(4x4) the configs[1] scenes hold north_star's 1e-4
 # (tests/test_gpu_parity_full.py), the OpenOccupancy scene (128x128x10, 6x896x1600 maps) renders 1.25e-4 / 2.3e-4 from the CPU
