@@ -49,6 +49,31 @@ def test_fps_voxels_bucketed_equals_reference_rule(dev, grid, p, m):
     assert np.array_equal(pkg.furthest_point_sample(xyz[None].contiguous().to(dev), m)[0].cpu().numpy(), want)
 
 
+def test_fps_voxels_pair_equals_two_single_calls(dev):
+    """coocc_fps_voxels_pair (both search directions of BiFuser_N as ONE launch of two workgroups, distance table in registers)
+    against two coocc_fps_voxels calls and the reference rule; a grid above 640 buckets reports 2 and launches nothing."""
+    from co_occ_amd import _lib
+    from co_occ_amd.fuser import _fps_voxels
+    X, Y, Z, m = 100, 100, 8, 2048
+    g = torch.Generator().manual_seed(77)
+    lins = [torch.nonzero(torch.rand(X * Y * Z, generator=g) < p)[:, 0].int().to(dev) for p in (0.12, 0.65)]
+    lib = _lib.load()
+    wsb = int(lib.coocc_fps_voxels_ws(X, Y, Z))
+    ws = [torch.empty(wsb, device=dev, dtype=torch.uint8) for _ in range(2)]
+    out = [torch.full((m,), -7, device=dev, dtype=I32) for _ in range(2)]
+    rc = call("coocc_fps_voxels_pair", ptr(lins[0]), lins[0].numel(), ptr(out[0]), ptr(ws[0]), ptr(lins[1]), lins[1].numel(), ptr(out[1]),
+              ptr(ws[1]), wsb, X, Y, Z, m)
+    assert rc in (0, None)
+    for lin, o in zip(lins, out):
+        single = _fps_voxels(lin, (X, Y, Z), m)[0]
+        assert torch.equal(o, single)
+        xyz = torch.stack([lin // (Y * Z), (lin // Z) % Y, lin % Z], 1).float().cpu()
+        assert np.array_equal(o.cpu().numpy(), native.fps(xyz[None].numpy(), m)[0])
+    big = lib.coocc_fps_voxels_pair(ptr(lins[0]), lins[0].numel(), ptr(out[0]), ptr(ws[0]), ptr(lins[1]), lins[1].numel(), ptr(out[1]),
+                                    ptr(ws[1]), wsb, 200, 200, 16, m, None)
+    assert big == 2
+
+
 def test_fps_float_coordinates(dev):
     rng = np.random.default_rng(7)
     pts = (rng.integers(-400, 400, (1, 5000, 3)) / 8.0).astype(np.float32)   # exactly representable
@@ -89,6 +114,26 @@ def test_knn_assign_last_writer(dev):
     val = (rng.random((nc, K)) * 20).astype(np.float32)
     nn = rng.integers(0, 9999, (nc, K)).astype(np.int32)
     group = rng.integers(0, nq, (nc, ns)).astype(np.int32)
+    winner = torch.empty(K, nq, device=dev, dtype=I32)
+    out = torch.empty(K, nq, device=dev, dtype=I32)
+    call("coocc_knn_assign", nc, K, ns, nq, 13.3, ptr(T(val, dev)), ptr(T(nn, dev)), ptr(T(group, dev)), ptr(winner), ptr(out))
+    assert np.array_equal(out.cpu().numpy(), native.knn_assign(val, nn, group, nq, 13.3).astype(np.int32))
+
+
+def test_knn_assign_with_ball_query_padding(dev):
+    """Groups as ball_query writes them: short groups padded with their FIRST member (ball_query_cuda.cu:47-52) -- the kernel
+    skips those repeats (idempotent atomicMax), the result is the reference's."""
+    rng = np.random.default_rng(9)
+    nc, K, ns, nq = 300, 2, 40, 2500
+    val = (rng.random((nc, K)) * 20).astype(np.float32)
+    nn = rng.integers(0, 9999, (nc, K)).astype(np.int32)
+    group = np.zeros((nc, ns), np.int32)
+    for c in range(nc):
+        k = int(rng.integers(0, ns + 1))                 # members found; 0: the row stays all zeros (query 0), as the CUDA op leaves it
+        if k:
+            mem = rng.choice(nq, size=k, replace=False).astype(np.int32)
+            group[c, :k] = mem
+            group[c, k:] = mem[0]
     winner = torch.empty(K, nq, device=dev, dtype=I32)
     out = torch.empty(K, nq, device=dev, dtype=I32)
     call("coocc_knn_assign", nc, K, ns, nq, 13.3, ptr(T(val, dev)), ptr(T(nn, dev)), ptr(T(group, dev)), ptr(winner), ptr(out))

@@ -608,6 +608,48 @@ def test_sort_free_pooling_orders_every_voxel_by_point_id(dev, n, grid):
         assert torch.equal(got.cpu(), want)
 
 
+def test_pooling_workspace_reuse_and_size_changes(dev):
+    """The pooling entry points leave their histogram zeroed for the next call on the same workspace (``ws_clean``: no memset
+    launch) -- calls of the same size back to back, then a different size on the same stream (the mark must not carry over),
+    then the first size again: every result bit-equal to the oracle's stable order."""
+    from co_occ_amd import ops
+    rng = np.random.default_rng(11)
+    C = 8
+    shapes = [(6000, (1, 12, 10, 4)), (6000, (1, 12, 10, 4)), (2500, (2, 7, 5, 3)), (6000, (1, 12, 10, 4)), (6000, (1, 12, 10, 4))]
+    seen_clean = []
+    orig = ops.pool_ws_clean
+    ops_clean = lambda ws, npts, nvox: (seen_clean.append(orig(ws, npts, nvox)) or seen_clean[-1])
+    ops.pool_ws_clean = ops_clean
+    try:
+        for it, (n, (B, X, Y, Z)) in enumerate(shapes):
+            feats = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32))
+            coords = torch.from_numpy(np.stack([rng.integers(0, X, n), rng.integers(0, Y, n), rng.integers(0, Z, n), rng.integers(0, B, n)], 1))
+            want = ref_cpu.bev_pool(feats, coords, B, Z, X, Y)
+            got = pkg.bev_pool(feats.to(dev), coords.to(dev), B, Z, X, Y)
+            assert torch.equal(got.cpu(), want), it
+    finally:
+        ops.pool_ws_clean = orig
+    # second call of a size: clean; after a size change and after the workspace was regrown: not
+    assert seen_clean[1] == 1 and seen_clean[2] == 0 and seen_clean[3] == 0 and seen_clean[4] == 1, seen_clean
+
+
+def test_pooling_grid_past_one_million_voxels(dev):
+    """More than 1024 chunks of 1024 voxels (the chunk prefix of k_csr_fill is scanned in several passes): B = 2 grids of
+    128x128x40; sums checked against an index_add reference (unique rows per voxel here, so the order does not matter)."""
+    B, X, Y, Z, C = 2, 128, 128, 40, 4
+    nvox = B * X * Y * Z
+    assert nvox > 1024 * 1024
+    g = torch.Generator().manual_seed(5)
+    n = 300000
+    lin = torch.randperm(nvox, generator=g)[:n]
+    b, r = lin // (X * Y * Z), lin % (X * Y * Z)
+    coords = torch.stack([r // (Y * Z), (r // Z) % Y, r % Z, b], 1)
+    feats = torch.randn(n, C, generator=g)
+    got = pkg.bev_pool(feats.to(dev), coords.to(dev), B, Z, X, Y)           # [B, C, Z, X, Y]
+    want = torch.zeros(nvox, C).index_add_(0, lin, feats).view(B, X, Y, Z, C).permute(0, 4, 3, 1, 2)
+    assert torch.equal(got.cpu(), want)
+
+
 def test_lift_splat_into_the_fuser_concat_buffer(dev):
     """P2 -> K1 without a layout round trip: lift_splat(out=BiFuser_N.concat_buffer(...)) writes the camera rows into slot 0
     of the [V,4C] buffer, the rows prologue only computes its flag; everything downstream equals the NCDHW path bit for bit."""
