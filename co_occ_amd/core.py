@@ -631,7 +631,7 @@ def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_co
     if count_dev is not None:
         d.M_dev, d.gather_stride = ptr(count_dev, torch.int32), M
     kname = conv_kernel_name(M, pc.Cout, True)
-    if CONV_ENGINE == "h2" and H2_DIRECT and CONV_DTYPE == "f32" and C % 32 == 0 and h2_capable(pc) and pc.h2_pack() is not None:
+    if CONV_ENGINE == "h2" and H2_DIRECT and C % 32 == 0 and h2_capable(pc) and pc.h2_pack() is not None:
         # split-f16 engine: the source slot is converted once ([rows, C] H2 rows: 13 us for 80 k rows), the row-table kernel
         # gathers 128-byte chunks of it (k_gemm_h2w<TABLE>); 118 -> ~40 us per call at configs[1]
         sh = rows_to_h2(src, C, src_coff, name="g1rows")
