@@ -65,6 +65,31 @@ def test_abi_version_and_error_path():
     assert rc == -1 and b"knn_topk" in lib.coocc_last_error()
 
 
+def test_round3_entry_points_validate_before_launching():
+    """The entry points added in round 3 reject bad arguments with COOCC_EINVAL and a message naming them -- before any launch,
+    so this needs no GPU: the fused fine branch (ratio, null pointers), the FPS pair (sizes; grids above 640 buckets report 2 =
+    'not taken' without touching the error text), the search driver (null descriptor), the cached-geometry pooling sums."""
+    lib = _lib.load()
+    i32 = (ctypes.c_int * 3)(8, 8, 4)
+    one = ctypes.c_void_p(16)              # a non-null, 16-byte aligned dummy address: validation never dereferences device pointers
+    rc = lib.coocc_fine_fused(one, 4, 4, 2, one, 6, 4, 4, one, one, 10, None, 3, i32, one, one, one, 1e-5, one, one, one, one, 1e-5, one, one,
+                              17, one, one, None)
+    assert rc == -1 and b"fine_fused" in lib.coocc_last_error()
+    rc = lib.coocc_fine_fused(None, 4, 4, 2, one, 6, 4, 4, one, one, 10, None, 2, i32, one, one, one, 1e-5, one, one, one, one, 1e-5, one, one,
+                              17, one, one, None)
+    assert rc == -1 and b"null" in lib.coocc_last_error()
+    rc = lib.coocc_fine_fused(one, 4, 4, 2, one, 6, 4, 4, one, one, 10, None, 2, (ctypes.c_int * 3)(9, 8, 4), one, one, one, 1e-5, one, one, one,
+                              one, 1e-5, one, one, 17, one, one, None)
+    assert rc == -1 and b"final_occ_size" in lib.coocc_last_error()
+    assert lib.coocc_fps_voxels_pair(one, 100, one, one, one, 100, one, one, 1 << 20, 200, 200, 16, 64, None) == 2      # too many buckets: not taken
+    rc = lib.coocc_fps_voxels_pair(one, 0, one, one, one, 100, one, one, 1 << 20, 100, 100, 8, 64, None)
+    assert rc == -1 and b"fps_voxels_pair" in lib.coocc_last_error()
+    rc = lib.coocc_fuser_search(None, None, None)
+    assert rc == -1 and b"fuser_search" in lib.coocc_last_error()
+    rc = lib.coocc_lift_splat_reuse(None, one, 6, 112, 16, 44, 128, 1, 100, 100, 8, one, 128, one, 1 << 30, None)
+    assert rc == -1 and b"lift_splat_reuse" in lib.coocc_last_error()
+
+
 def _wfrag_index(chunk, ngroups, n, kk):
     """csrc/conv3d.hip wfrag_index: [chunk][128-col group][wn][q][lane = 32h + li][4]."""
     g, wn, li, q, h, e = n >> 7, (n >> 5) & 3, n & 31, kk >> 3, (kk >> 2) & 1, kk & 3
