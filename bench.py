@@ -656,7 +656,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="r50", choices=sorted(synth.CONFIGS))
     ap.add_argument("--streams", type=int, default=0,
-                    help="dense stages in flight: S host threads / HIP streams, sample i on stream i mod S.  With 2, one "
+                    help="dense stages in flight.  --graph 1 (default): dense streams the captured graphs replay on (0 = 3, the "
+                         "measured optimum with 6 slots: DESIGN 5).  --graph 0: S host threads / HIP streams, sample i on stream i mod S.  With 2, one "
                          "sample's low-occupancy tail (25x25x2 / 13x13x1 layers, heads, fine branch) runs under the other's GEMMs: "
                          "120.4-127.0 samples/s over 12 processes against 112.5-116.3 at S = 1 on a quiet host, but no gain and "
                          "more spread when neighbours saturate the host's CPUs (profiles/r2_streams_ab.txt).  Default 0: decide "
