@@ -24,7 +24,8 @@ class ConvDesc(ctypes.Structure):
                [(n, c_int) for n in ("M", "Cin", "Cout", "taps", "in_stride", "out_stride", "res_stride",
                                      "B", "Xi", "Yi", "Zi", "Xo", "Yo", "Zo", "ksize", "stride", "pad",
                                      "relu", "res_mode", "splitk", "tile_hint", "kx", "ky", "kz", "px", "py", "pz",
-                                     "wgroup_rows", "mfma_dtype")] + [("alpha", ctypes.c_float), ("M_dev", c_void_p), ("gather_stride", c_int), ("out16", c_void_p), ("out16_stride", c_int), ("out_h2", c_int)]
+                                     "wgroup_rows", "mfma_dtype")] + [("alpha", ctypes.c_float), ("M_dev", c_void_p), ("gather_stride", c_int), ("out16", c_void_p), ("out16_stride", c_int), ("out_h2", c_int),
+                                                                   ("out_h2_twin", c_void_p), ("tile_sem", c_void_p), ("tile_sem_ints", c_int)]
 
 
 class SearchDesc(ctypes.Structure):
@@ -78,7 +79,9 @@ SIGNATURES = {
     "coocc_fuser_search_ws": (Z, [ctypes.POINTER(SearchDesc)]),
     "coocc_fuser_search": (I, [ctypes.POINTER(SearchDesc), P, P]),
     "coocc_upsample_add_trilinear": (I, [P, P, I, I, I, I, I, I, I, I, P]),
+    "coocc_upsample_add_trilinear_ex": (I, [P, P, I, I, I, I, I, I, I, I, P, P]),
     "coocc_occhead_mix": (I, [P, P, I, P, P, I, I, P]),
+    "coocc_occhead_mix_ex": (I, [P, P, I, P, P, I, I, P, P]),
     "coocc_argmax_flags": (I, [P, I, I, I, I, P, P]),
     "coocc_fine_sample_voxel": (I, [P, I, I, I, I, P, I, I, P, P, P, I, P]),
     "coocc_fine_sample_img": (I, [P, I, I, I, I, P, P, L, P, I, I, P]),
@@ -124,6 +127,8 @@ SIGNATURES = {
     "coocc_wino_input_strided": (I, [P, I, I, I, I, I, I, I, P, I, L, P]),
     "coocc_sparse_tap_sum": (I, [P, P, I, I, I, I, I, P, P, I, P]),
     "coocc_wino_output": (I, [P, L, I, I, I, I, I, I, P, I, P, P, P, I, I, P]),
+    "coocc_wino_output_ex": (I, [P, L, I, I, I, I, I, I, P, I, P, P, P, I, I, P, P]),
+    "coocc_h2_overflow": (I, [I]),
     "coocc_projection_params": (I, [P, P, P, P, P, P, I, P, P, P]),
     "coocc_occhead_mix_bwd": (I, [P, P, I, P, P, P, P, I, I, P]),
     "coocc_fine_sample_voxel_bwd": (I, [P, I, I, I, I, I, P, L, P, P, P]),

@@ -56,3 +56,38 @@ def save_output_nuscenes(img_inputs, output_voxels, save_path, scene_token, samp
     with open(filepath, "wb") as handle:
         pickle.dump(out_dict, handle)
     return filepath
+
+
+def pipelined_test(model, data_iter, slots=6, dense_streams=3, ahead=0):
+    """The loop of ``custom_single_gpu_test`` (P/coocc/apis/test.py:43-45: ``result = model(return_loss=False, **data)`` once per
+    sample) with ``slots`` samples in flight (``co_occ_amd.serving``): a generator of ``(data, result)`` in sample order, ``result``
+    = what ``COOCC_Ray.simple_test`` returns for that sample (same tensors, same metrics).  ``data``: the keyword arguments of
+    ``simple_test`` (``img_inputs`` / ``img``, ``points``, ``gt_occ``, ``visible_mask``, ``precomputed``).  The encoders upstream
+    of the hot path run eagerly at submit time; pooling + index search of the next samples are prefetched under the dense stage
+    (one captured hipGraph launch per sample) of the current ones.  Result tensors of a sample stay valid until ``slots`` more
+    samples have been submitted: consume (or clone) them inside the loop body, as the upstream loop does."""
+    import collections
+    model.eval()
+    pipe = None
+    inflight = collections.deque()
+
+    def finish(item):
+        data, t = item
+        out = t.result(wait=True)
+        return data, model.finish_test_result(out, data.get("gt_occ"), data.get("visible_mask"))
+
+    with torch.no_grad():
+        for data in data_iter:
+            img = data.get("img_inputs", data.get("img"))
+            fr = model.serving_frame(img=img, points=data.get("points"), img_metas=data.get("img_metas"),
+                                     precomputed=data.get("precomputed"))
+            if pipe is None:
+                pipe = model.serving(fr, slots=slots, dense_streams=dense_streams, ahead=ahead,
+                                     render=bool(model.use_rendering and model.test_rendering))
+            inflight.append((data, pipe.submit(fr)))
+            while len(inflight) > pipe.ahead:
+                yield finish(inflight.popleft())
+        while inflight:
+            yield finish(inflight.popleft())
+    if pipe is not None:
+        pipe.close()

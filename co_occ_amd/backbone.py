@@ -51,11 +51,12 @@ class BasicBlock(nn.Module):
             d["ds"] = PackedConv(self.downsample[0].weight, bn=self.downsample[1], ksize=1, stride=self.stride)
         return d
 
-    def run(self, x, p):
-        """resnet3d.py:47-64 on Rows."""
-        out = conv_rows(x, p["c1"], relu=True)
+    def run(self, x, p, readers=()):
+        """resnet3d.py:47-64 on Rows.  ``readers``: the layers that read the block's output next (the next block's conv1 /
+        downsample, an FPN lateral): a split-f16 layer among them gets its H2 operand from conv2's epilogue."""
+        out = conv_rows(x, p["c1"], relu=True, twin_for=(p["c2"],))
         res = conv_rows(x, p["ds"], relu=False) if "ds" in p else x
-        return conv_rows(out, p["c2"], relu=True, res=res)
+        return conv_rows(out, p["c2"], relu=True, res=res, twin_for=readers)
 
 
 @BACKBONES.register_module()
@@ -103,14 +104,22 @@ class CustomResNet3D(nn.Module):
                         blocks=[[b.packed() for b in layer] for layer in self.layers])
         return self._packs.get_modules((self,), build)
 
-    def forward_rows(self, x):
+    def forward_rows(self, x, readers=None):
+        """``readers``: per output level, the layers outside this module that read it next (FPN3D's laterals)."""
         _eval_only(self)
         p = self._packed()
-        x = conv_rows(to_rows(x), p["proj"], relu=True)
+        flat = [bp for layer in p["blocks"] for bp in layer]
+        x = conv_rows(to_rows(x), p["proj"], relu=True, twin_for=(flat[0]["c1"], flat[0].get("ds")))
         res = []
+        n = 0
         for i, layer in enumerate(self.layers):
             for blk, bp in zip(layer, p["blocks"][i]):
-                x = blk.run(x, bp)
+                n += 1
+                nxt = flat[n] if n < len(flat) else {}
+                rd = [nxt.get("c1"), nxt.get("ds")]
+                if readers is not None and i in self.out_indices and bp is p["blocks"][i][-1]:
+                    rd += list(readers[self.out_indices.index(i)])
+                x = blk.run(x, bp, tuple(rd))
             if i in self.out_indices:
                 res.append(x)
         return res

@@ -40,6 +40,9 @@ CONV_ENGINE = __import__("os").environ.get("COOCC_CONV_ENGINE", "h2")
 # amp = 100 for F(4x4), 25 for F(3x3), 4 for F(2x2))
 H2_WINO_SCALE = {2: 0.5, 3: 0.25, 4: 0.125}
 H2_DIRECT = __import__("os").environ.get("COOCC_H2_DIRECT", "1") != "0"     # stride-1 3x3xkz layers outside the Winograd path
+# split-K layers of the split-f16 engine reduce in-kernel (arrival counters; the last workgroup of a tile sums the slabs in slice
+# order and runs the epilogue): no k_conv_reduce launch.  0 = the two-launch form (same bits)
+INKERNEL_REDUCE = __import__("os").environ.get("COOCC_INKERNEL_REDUCE", "1") != "0"
 H2_DIRECT_MIN_FLOPS = 1e9      # below this the input split + split-K reduce launches cost more than the faster GEMM saves (measured)
 
 
@@ -74,11 +77,15 @@ def conv_kernel_name(M, Cout, table, hint=0, iters=1 << 30, one_by_one=False):
 class Rows:
     """A dense voxel volume as channels-last rows: t[B*X*Y*Z, stride], C channels at `coff`."""
 
-    __slots__ = ("t", "B", "X", "Y", "Z", "C", "coff", "h16")
+    __slots__ = ("t", "B", "X", "Y", "Z", "C", "coff", "h16", "h2")
 
     def __init__(self, t, B, X, Y, Z, C, coff=0):
         self.t, self.B, self.X, self.Y, self.Z, self.C, self.coff = t, B, X, Y, Z, C, coff
         self.h16 = None       # f16 twin [B*V, C] written by the producing convolution's epilogue (CONV_DTYPE == "f16")
+        # H2 twin [B*V, C] (split-f16 operand rows, csrc/h2_rows.h) of these rows: written by the PRODUCER's epilogue when the
+        # consumer is a split-f16 layer outside the Winograd path (``conv_rows(twin_for=...)``), else made once by
+        # ``h2_rows`` and shared by every consumer.  Any in-place writer of ``t`` must refresh or drop it.
+        self.h2 = None
 
     @property
     def stride(self):
@@ -93,17 +100,27 @@ class Rows:
         return ctypes.c_void_p(self.t.data_ptr() + 4 * self.coff)
 
     def as_ncdhw(self):
-        """Reference-layout view [B,C,X,Y,Z] (no copy)."""
+        """Reference-layout view [B,C,X,Y,Z] (no copy).  The view remembers these Rows (and the tensor version they were
+        valid at), so handing it to the next module of this package finds the 16-bit twins again (``to_rows``)."""
         v = self.t.view(self.B, self.X, self.Y, self.Z, self.stride)
         if self.coff or self.stride != self.C:
             v = v[..., self.coff:self.coff + self.C]
-        return v.permute(0, 4, 1, 2, 3)
+        v = v.permute(0, 4, 1, 2, 3)
+        v._coocc_rows = (self, v._version)
+        return v
 
 
 def to_rows(x):
     """[B,C,X,Y,Z] tensor (any strides) -> Rows, converting with the HIP transpose if needed."""
     if isinstance(x, Rows):
         return x
+    back = getattr(x, "_coocc_rows", None)
+    if back is not None:
+        # the zero-copy view of Rows this package produced, untouched since (any in-place torch op bumps the version counter
+        # the view shares with its base): the same Rows, 16-bit twins included
+        r, ver = back
+        if ver == x._version and x.dim() == 5 and tuple(x.shape) == (r.B, r.C, r.X, r.Y, r.Z):
+            return r
     if x.dim() != 5:
         raise ValueError("expected a [B,C,X,Y,Z] tensor")
     if not x.is_cuda:
@@ -217,6 +234,9 @@ class PackedConv:
         """[Npad, Cin, taps] fp64 -> H2 pack [(chunk, tap)][Npad/32][2 k16 steps][hi | lo][64 lanes][8 f16] (csrc/gemm_h2.hip):
         lane l of step s holds k = 32 chunk + 16 s + 8 (l >> 5) + 0..7 of column 32 nt + (l & 31)."""
         npad, cin, taps = w64.shape
+        if w64.numel() and float(w64.abs().max()) >= 32768.0:
+            raise _lib.CooccError("split-f16 engine: a weight of magnitude %.3g does not fit the f16 operand range (|w| < 32768); "
+                                  "set COOCC_CONV_ENGINE=f32 for this model" % float(w64.abs().max()))
         hi = w64.to(torch.float16)
         lo = ((w64 - hi.double()) * 2048.0).to(torch.float16)
         planes = torch.stack([hi, lo], 0)                                     # [pl, n, c, t]
@@ -349,20 +369,24 @@ def h2_capable(pc):
 
 def wino_plan(x, pc, M, res_mode):
     """None, or (tile, points, Tx, Ty, rows, G, tile_hint) for the Winograd path of this layer."""
+    return _wino_plan_geom(x.B, x.X, x.Y, x.Z, pc, M, res_mode)
+
+
+def _wino_plan_geom(B, X, Y, Z, pc, M, res_mode):
     if not WINO or pc._w_raw is None or M < WINO_MIN_ROWS or res_mode not in (0, 1) or pc.Cin % 4:
         return None
     tile = pc.wino_tile or WINO_TILE
-    if tile not in (2, 3, 4) or min(x.X, x.Y) < 2 * tile:
+    if tile not in (2, 3, 4) or min(X, Y) < 2 * tile:
         tile = 2
-    Tx, Ty = -(-x.X // tile), -(-x.Y // tile)
-    rows = x.B * Tx * Ty * x.Z
+    Tx, Ty = -(-X // tile), -(-Y // tile)
+    rows = B * Tx * Ty * Z
     # group rows: a multiple of the GEMM's M tile and of Z.  640 = lcm(128, 160) leaves the tile choice to the
     # kernel; when that would pad much more than a 128-row granule (50x50x4: 676 -> 1280 vs 768), pin 128-row tiles
-    g640, g128 = _lcm(640, x.Z), _lcm(128, x.Z)
+    g640, g128 = _lcm(640, Z), _lcm(128, Z)
     G640, G128 = -(-rows // g640) * g640, -(-rows // g128) * g128
     G, hint = (G640, 0) if G640 <= 1.05 * G128 else (G128, 128)
     if h2_capable(pc):
-        g256 = _lcm(256, x.Z)           # 256-row tiles of the persistent split-f16 GEMM (k_gemm_h2p)
+        g256 = _lcm(256, Z)           # 256-row tiles of the persistent split-f16 GEMM (k_gemm_h2p)
         G, hint = -(-rows // g256) * g256, 0
     pts = (tile + 2) ** 2
     if pts * G >= 1 << 31:
@@ -384,7 +408,81 @@ def scratch(device, kind, nfloats):
     return t
 
 
-def conv_rows_wino(x, pc, out, relu, res, plan, in_ranges=None):
+_sem_ws = {}
+
+
+def tile_sem(device, n=4096):
+    """Per-stream arrival counters of the in-kernel split-K reduction (coocc_conv_desc.tile_sem): zero on entry, left zero by
+    every launch, so one buffer serves every layer issued on the stream."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _sem_ws.get(key)
+    if t is None:
+        t = _sem_ws[key] = torch.zeros(n, device=device, dtype=torch.int32)
+    return t
+
+
+def stream_scratch(device, stream):
+    """Every per-stream scratch tensor of ``stream`` (Winograd V / M, split-K slabs, H2 inputs, arrival counters): a captured
+    hipGraph holds raw pointers into them and must keep them alive (``graph.DenseGraph``)."""
+    h = stream.cuda_stream
+    out = [t for k, t in _wino_ws.items() if k[0] == device.index and k[-1] == h]
+    out += [t for k, t in _ws_cache.items() if k[0] == device.index and k[-1] == h]
+    out += [t for k, t in _bf16_ws.items() if k[0] == device.index and k[-1] == h]
+    out += [t for k, t in _sem_ws.items() if k[0] == device.index and k[-1] == h]
+    return out
+
+
+def h2_rows(x):
+    """The H2 twin of Rows ``x`` (whole rows: coff 0): the producer's, or one conversion pass whose result every later consumer
+    of the same Rows shares (a block's output feeds the strided conv1, the 1x1x1 downsample and the FPN lateral)."""
+    if x.h2 is None:
+        assert x.C % 32 == 0
+        xh = torch.empty(x.B * x.V, x.C, device=x.t.device, dtype=_F32)
+        call("coocc_rows_to_h2", x.data(), x.stride, x.B * x.V, x.C, 1.0, ptr(xh))
+        x.h2 = xh
+    return x.h2
+
+
+def check_h2_overflow(reset=True):
+    """Raise if a kernel of the split-f16 engine wrote a 16-bit operand outside its guarded range since the last check
+    (csrc/h2_rows.h h2_guard: |v| >= 32768 after the writer's scale, or NaN).  Call after the stream(s) have been synchronised
+    -- the detector does at its own host reads (the fine-branch count, the metrics) and ``serving`` when a result is fetched."""
+    if _lib.load().coocc_h2_overflow(1 if reset else 0):
+        raise _lib.CooccError(
+            "split-f16 engine: an activation left the f16 operand range (|x| >= 32768, or %g for the F(4x4) Winograd layers whose "
+            "transform amplifies by up to 100 at scale 1/8; NaN counts) -- the outputs of this sample are not trustworthy.  "
+            "Set COOCC_CONV_ENGINE=f32 (exact-fp32 MFMA kernels, no range limit; ~1.8x slower) or rescale the inputs "
+            "(INTEGRATION.md, 'Operand range of the split-f16 engine')." % (32768.0 / (100 * H2_WINO_SCALE[4])))
+
+
+def route(B, X, Y, Z, pc, rm=0, splitk=0):
+    """Which kernel family ``conv_rows`` takes for layer ``pc`` on an input grid [B, X, Y, Z]: "wino" | "h2" | "f16" | "other".
+    One rule for the dispatch itself and for the producers that decide whether to write an H2 twin for their consumer."""
+    Xo, Yo, Zo = out_dim(X, pc.ksize, pc.stride, pc.pad), out_dim(Y, pc.ksize, pc.stride, pc.pad), out_dim(Z, pc.ksize, pc.stride, pc.pad)
+    M = B * Xo * Yo * Zo
+    bf16, f16 = CONV_DTYPE == "bf16", CONV_DTYPE == "f16"
+    if not (bf16 or f16) and _wino_plan_geom(B, X, Y, Z, pc, M, rm) is not None:
+        return "wino"
+    taps = pc.taps
+    if ZTRIM and pc._w_cube is not None:
+        ok = [kz for kz in range(3) if any(0 <= zo * pc.stride - pc.pad + kz < Z for zo in range(Zo))]
+        if ok[-1] - ok[0] + 1 < 3:
+            taps = 9 * (ok[-1] - ok[0] + 1)
+    if f16 and pc.Cin % 64 == 0 and pc._w_taps is not None and rm in (0, 1) and splitk in (0, 1):
+        return "f16"
+    if (not bf16 and not f16 and CONV_ENGINE == "h2" and H2_DIRECT and pc.Cin % 32 == 0 and pc._w_taps is not None
+            and rm in (0, 1) and 2.0 * M * pc.Cin * pc.Cout * taps >= H2_DIRECT_MIN_FLOPS):
+        return "h2"
+    return "other"
+
+
+def takes_h2(rows, consumers):
+    """True when one of the layers ``consumers`` (PackedConv or None) reads ``rows`` (a Rows, or a (B, X, Y, Z) grid) as H2 rows."""
+    g = (rows.B, rows.X, rows.Y, rows.Z) if isinstance(rows, Rows) else rows
+    return any(pc is not None and route(*g, pc) == "h2" for pc in consumers)
+
+
+def conv_rows_wino(x, pc, out, relu, res, plan, in_ranges=None, twin=False):
     """3x3x3 stride-1 conv as Winograd F(m x m,3x3) over (x,y) + direct z taps: input transform, one grouped
     GEMM launch (one weight pack per transform point), output transform with the epilogue.
     ``in_ranges``: [(channel offset, count), ...] inside x's rows whose concatenation is the layer's input (sum = pc.Cin);
@@ -432,9 +530,12 @@ def conv_rows_wino(x, pc, out, relu, res, plan, in_ranges=None):
         d.mfma_dtype, d.alpha, kname = 3, 1.0 / vscale, "k_gemm_h2z"
     with TIMER.region(kname + " wino%d" % tile, 2.0 * pts * rows * pc.Cin * pc.Cout * 3):
         _lib.conv_fwd(d, V.device)
-    with TIMER.region("k_wino_out", 4.0 * pts * rows * pc.Cout + 4.0 * x.V * pc.Cout):
-        call("coocc_wino_output", ptr(Mb), G, x.B, x.X, x.Y, x.Z, pc.Cout, tile, out.data(), out.stride, ptr(pc.scale),
-             ptr(pc.bias), res.data() if res is not None else None, res.stride if res is not None else 0, int(relu))
+    tw = None
+    if twin and h2 and pc.Cout % 32 == 0 and out.coff == 0 and out.stride % 4 == 0:
+        tw = out.h2 = torch.empty(out.B * out.V, pc.Cout, device=dev, dtype=_F32)
+    with TIMER.region("k_wino_out", 4.0 * pts * rows * pc.Cout + 4.0 * x.V * pc.Cout * (2 if tw is not None else 1)):
+        call("coocc_wino_output_ex", ptr(Mb), G, x.B, x.X, x.Y, x.Z, pc.Cout, tile, out.data(), out.stride, ptr(pc.scale),
+             ptr(pc.bias), res.data() if res is not None else None, res.stride if res is not None else 0, int(relu), ptr(tw))
     return out
 
 
@@ -450,20 +551,25 @@ def out_dim(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
 
-def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
-    """out = epi(conv(x)) on Rows.  res: Rows added before ReLU (res_mode 1)."""
+def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0, twin_for=()):
+    """out = epi(conv(x)) on Rows.  res: Rows added before ReLU (res_mode 1).  ``twin_for``: the layers (PackedConv) that
+    read the result next -- when one of them takes the split-f16 direct path the epilogue writes the H2 twin it needs
+    (``out.h2``) next to the fp32 rows, which replaces that layer's conversion pass."""
     Xo, Yo, Zo = (out_dim(x.X, pc.ksize, pc.stride, pc.pad), out_dim(x.Y, pc.ksize, pc.stride, pc.pad),
                   out_dim(x.Z, pc.ksize, pc.stride, pc.pad))
     M = x.B * Xo * Yo * Zo
     if out is None:
         out = Rows(torch.empty(M, pc.Cout, device=x.t.device, dtype=_F32), x.B, Xo, Yo, Zo, pc.Cout)
+    else:
+        out.h2 = None                  # a caller-provided buffer is overwritten: whatever twin it carried is stale
     assert x.C == pc.Cin, "channel mismatch: %d vs %d" % (x.C, pc.Cin)
     rm = res_mode or (1 if res is not None else 0)
     bf16 = CONV_DTYPE == "bf16"
     f16 = CONV_DTYPE == "f16"
     plan = None if (bf16 or f16) else wino_plan(x, pc, M, rm)
+    twin = bool(twin_for) and CONV_ENGINE == "h2" and not (bf16 or f16) and pc.Cout % 32 == 0 and takes_h2(out, twin_for)
     if plan is not None:
-        return conv_rows_wino(x, pc, out, relu, res, plan)
+        return conv_rows_wino(x, pc, out, relu, res, plan, twin=twin)
     ws = workspace(x.t.device)
     d = ConvDesc()
     d.in_, d.w, d.out = x.data(), ptr(pc.w), out.data()
@@ -514,9 +620,18 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0):
         # fp32-accurate split-f16 GEMM (csrc/gemm_h2.hip) for the layers the Winograd path leaves out (small grids, strided,
         # 1x1x1): the input rows are split into H2 rows once per layer, stride-1 "same" layers share one LDS image per 3 z taps
         # (k_gemm_h2z), the rest fetch one image per (chunk, tap) (k_gemm_h2w); the epilogue (folded BN, residual, ReLU) is the usual one
-        xh = scratch(x.t.device, "h2in", x.B * x.V * pc.Cin)
-        call("coocc_rows_to_h2", x.data(), x.stride, x.B * x.V, pc.Cin, 1.0, ptr(xh))
+        if x.coff == 0 and x.C == pc.Cin:
+            xh = h2_rows(x)                 # the producer's twin, or one conversion shared by every consumer of x
+        else:
+            xh = scratch(x.t.device, "h2in", x.B * x.V * pc.Cin)
+            call("coocc_rows_to_h2", x.data(), x.stride, x.B * x.V, pc.Cin, 1.0, ptr(xh))
         d.in_, d.in_stride, d.w, d.mfma_dtype, d.alpha = ptr(xh), pc.Cin, ptr(pc.h2_pack(trim)), 3, 1.0
+        if INKERNEL_REDUCE:
+            sem = tile_sem(x.t.device)      # split-K layers reduce in-kernel (last workgroup of a tile): no k_conv_reduce launch
+            d.tile_sem, d.tile_sem_ints = ptr(sem), sem.numel()
+        if twin and out.coff == 0 and out.stride % 4 == 0 and (res is None or res.stride % 4 == 0):
+            out.h2 = torch.empty(M, pc.Cout, device=x.t.device, dtype=_F32)
+            d.out_h2_twin = ptr(out.h2)
         with TIMER.region("k_gemm_h2z direct" if (same and taps > 1) else "k_gemm_h2w", 2.0 * M * pc.Cin * pc.Cout * taps):
             _lib.conv_fwd(d, pc.w.device)
         return out

@@ -1208,7 +1208,7 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
     hipStream_t s3 = as_stream(stream);
     const int rc = coocc_launch_h2(k, d, s3);
     if (rc != COOCC_OK) return rc;
-    if (k.splitk > 1) {
+    if (k.splitk > 1 && !k.tile_sem) {      // with arrival counters the last workgroup of every tile has reduced in-kernel
       hipLaunchKernelGGL(k_conv_reduce, dim3(cdiv((long long)k.M * k.Cout, 256)), dim3(256), 0, s3, k);
       COOCC_LAUNCH_CHECK("k_conv_reduce");
     }

@@ -23,6 +23,10 @@ struct ConvK {
   int out_h2;                   // split-f16 kernels: write the output rows in H2 format (the next layer's operand)
   void* out16;                  // split-f16 / f16 kernels: second, f16 copy of the output rows, or NULL
   int out16_stride;             // its row stride in f16 elements
+  void* out_h2t;                // split-f16 kernels: H2 twin of the fp32 output rows ([rows][Cout] as H2 chunks; Cout % 32 == 0), or NULL
+  int32_t* tile_sem;            // split-f16 kernels, split-K: per-(M tile, N tile) arrival counters (zero on entry, left zero): the last
+                                // workgroup of a tile sums the slabs in slice order and runs the epilogue -- no k_conv_reduce launch
+  int* h2_flag;                 // host-mapped word, OR-ed with 1 when a value written as an H2 / f16 operand leaves the guarded range
 };
 
 __device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t rrow) {
@@ -39,3 +43,4 @@ __device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t
 // gemm_h2.hip: fp32-accurate GEMM on the f16 matrix cores (operands split hi + lo * 2^-11); called by coocc_conv_fwd for mfma_dtype 3
 int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s);
 int coocc_zero_row(const void** out);
+int coocc_h2_flag_ptr(int** out);      // gemm_h2.hip: the host-mapped range-guard flag of the 16-bit operand writers

@@ -31,21 +31,14 @@
 
 #include "conv_k.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#include "h2_rows.h"
 
-#define H2_LO_SCALE 2048.f
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void glds16_(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l,
                                    16, 0, 0);
-}
-
-__device__ __forceinline__ void split_h2(float v, _Float16& hi, _Float16& lo) {
-  hi = (_Float16)v;
-  lo = (_Float16)((v - (float)hi) * H2_LO_SCALE);
 }
 
 // XY = false: kx = ky = 1 (the Winograd-domain grouped GEMM: only the z taps), no (dx, dy) cursor and no x / y range checks.
@@ -58,24 +51,59 @@ __device__ __forceinline__ void split_h2(float v, _Float16& hi, _Float16& lo) {
 // cover each other's barriers, prologues and epilogues.
 // epilogue option out_h2: the output row is written as an H2 row (the next split-f16 layer's operand) instead of fp32:
 // channels n .. n+3 of row `row` (out_stride = channels per row, a multiple of 32)
-__device__ __forceinline__ void store_h2(float* out, size_t row, int out_stride, int n, f32x4 v) {
-  f16x4 hi, lo;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    hi[e] = (_Float16)v[e];
-    lo[e] = (_Float16)((v[e] - (float)hi[e]) * H2_LO_SCALE);
-  }
-  char* o = (char*)out + row * (size_t)out_stride * 4 + (n >> 5) * 128 + (n & 31) * 2;
-  *(f16x4*)o = hi;
-  *(f16x4*)(o + 64) = lo;
+// the vector epilogue of both kernels (and of the in-kernel split-K reduction): 4 consecutive channels n .. n+3 of output row orow
+__device__ __forceinline__ void h2_epilogue_vec(const ConvK& p, size_t orow, int n, f32x4 v) {
+  if (p.res_mode == 3) v = v + *(const f32x4*)(p.res + orow * p.res_stride + n);
+  if (p.scale) v = v * *(const f32x4*)(p.scale + n);
+  if (p.bias) v = v + *(const f32x4*)(p.bias + n);
+  if (p.res_mode == 1) v = v + *(const f32x4*)(p.res + orow * p.res_stride + n);
+  if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+  if (p.res_mode == 2) v = v * *(const f32x4*)(p.res + orow * p.res_stride + n);
+  if (p.out_h2) { store_h2(p.out, orow, p.out_stride, n, v); h2_guard(p.h2_flag, v); }
+  else *(f32x4*)(p.out + orow * p.out_stride + n) = v;
+  if (p.out16) { store_f16(p.out16, orow, p.out16_stride, n, v); h2_guard(p.h2_flag, v); }
+  if (p.out_h2t) { store_h2(p.out_h2t, orow, p.Cout, n, v); h2_guard(p.h2_flag, v); }
 }
-// epilogue option out16: a second, f16 copy of the output rows ([rows][out16_stride] f16) -- the operand of the next layer on the
-// one-term f16 path, written by the producer instead of a conversion pass
-__device__ __forceinline__ void store_f16(void* out16, size_t row, int stride, int n, f32x4 v) {
-  f16x4 o;
+// In-kernel split-K reduction (p.tile_sem != NULL): every workgroup of an (M tile, N tile) has written its partial slab; the one
+// that arrives LAST sums the slabs in slice order 0 .. splitk-1 (the order k_conv_reduce uses: same bits whichever workgroup is
+// last) and runs the epilogue.  Release / acquire at agent scope around the arrival counter (__threadfence: L2 write-back /
+// invalidate across the XCDs); the counter is left at zero for the next launch.  Returns true for the workgroup that reduces.
+__device__ __forceinline__ bool h2_splitk_arrive(const ConvK& p, int tile) {
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = atomicAdd(&p.tile_sem[tile], 1);
+    s_last = old == p.splitk - 1;
+    if (s_last) p.tile_sem[tile] = 0;
+  }
+  __syncthreads();
+  if (!s_last) return false;
+  __threadfence();
+  return true;
+}
+template <int TM>
+__device__ __forceinline__ void h2_splitk_reduce(const ConvK& p, int m0, int nb, int li) {
+  const bool vec = (p.Cout & 3) == 0 && (p.out_stride & 3) == 0 && (!p.res || (p.res_stride & 3) == 0);
+#pragma unroll 1
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + i * 32 + li;
+    if (m >= p.M) continue;
+    const size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-  *(f16x4*)((char*)out16 + (row * (size_t)stride + n) * 2) = o;
+    for (int j = 0; j < 4; ++j) {
+      const int n = nb + 8 * j;
+      if (n >= p.Cout) continue;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int z = 0; z < p.splitk; ++z) v = v + *(const f32x4*)(p.ws + ((size_t)z * p.M + m) * p.Npad + n);
+      if (vec) h2_epilogue_vec(p, orow, n, v);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.Cout) p.out[orow * p.out_stride + n + e] = epilogue(p, v[e], n + e, orow);
+      }
+    }
+  }
 }
 #define H2_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ const char* inb_(const ConvK& p) { return (const char*)p.in; }
@@ -347,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
         *(f32x4*)(o + 8 * j) = v;
       }
     }
+    if (p.tile_sem && h2_splitk_arrive(p, mtile * p.ntiles + nt)) h2_splitk_reduce<TM>(p, m0, nb, li);
   } else {
     const bool vec = (p.Cout & 3) == 0 && (p.out_stride & 3) == 0 && (!p.res || (p.res_stride & 3) == 0);
 #pragma unroll
@@ -362,15 +391,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (TERMS == 3 ? hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo : hh[i][4 * j + e] * alpha);
         if (vec) {
-          if (p.res_mode == 3) v = v + *(const f32x4*)(p.res + (size_t)m * p.res_stride + n);
-          if (p.scale) v = v * *(const f32x4*)(p.scale + n);
-          if (p.bias) v = v + *(const f32x4*)(p.bias + n);
-          if (p.res_mode == 1) v = v + *(const f32x4*)(p.res + (size_t)m * p.res_stride + n);
-          if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-          if (p.res_mode == 2) v = v * *(const f32x4*)(p.res + (size_t)m * p.res_stride + n);
-          if (p.out_h2) store_h2(p.out, (size_t)m, p.out_stride, n, v);
-          else *(f32x4*)(p.out + (size_t)m * p.out_stride + n) = v;
-          if (p.out16) store_f16(p.out16, (size_t)m, p.out16_stride, n, v);
+          h2_epilogue_vec(p, (size_t)m, n, v);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -582,6 +603,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
         *(f32x4*)(o + 8 * j) = v;
       }
     }
+    if (p.tile_sem && h2_splitk_arrive(p, mtile * p.ntiles + nt)) h2_splitk_reduce<TM>(p, m0, nb, li);
   } else {
     const bool vec = (p.Cout & 3) == 0 && (p.out_stride & 3) == 0 && (!p.res || (p.res_stride & 3) == 0);
 #pragma unroll
@@ -597,15 +619,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (TERMS == 3 ? hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo : hh[i][4 * j + e] * alpha);
         if (vec) {
-          if (p.res_mode == 3) v = v + *(const f32x4*)(p.res + orow * p.res_stride + n);
-          if (p.scale) v = v * *(const f32x4*)(p.scale + n);
-          if (p.bias) v = v + *(const f32x4*)(p.bias + n);
-          if (p.res_mode == 1) v = v + *(const f32x4*)(p.res + orow * p.res_stride + n);
-          if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-          if (p.res_mode == 2) v = v * *(const f32x4*)(p.res + orow * p.res_stride + n);
-          if (p.out_h2) store_h2(p.out, orow, p.out_stride, n, v);
-          else *(f32x4*)(p.out + orow * p.out_stride + n) = v;
-          if (p.out16) store_f16(p.out16, orow, p.out16_stride, n, v);
+          h2_epilogue_vec(p, orow, n, v);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -614,6 +628,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
       }
     }
   }
+}
+
+// One host-mapped word for the whole process (every device sees host-pinned memory at its host address): raised by the H2 / f16
+// writers (h2_guard), read by coocc_h2_overflow without any device synchronisation of its own.
+static int* g_h2_flag = nullptr;
+int coocc_h2_flag_ptr(int** out) {
+  if (!g_h2_flag) {
+    void* p = nullptr;
+    COOCC_HIP(hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(p, 0, 64);
+    g_h2_flag = (int*)p;
+  }
+  *out = g_h2_flag;
+  return COOCC_OK;
+}
+extern "C" int coocc_h2_overflow(int reset) {
+  if (!g_h2_flag) return 0;
+  const int v = *(volatile int*)g_h2_flag != 0;
+  if (reset) *(volatile int*)g_h2_flag = 0;
+  return v;
 }
 
 int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
@@ -638,9 +672,16 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   k.alpha = d->alpha != 0.f ? d->alpha : 1.f;
   k.M_dev = d->M_dev;
   k.out_h2 = d->out_h2;
-  COOCC_CHECK_ARG(!d->out_h2 || (d->Cout % 4 == 0 && d->out_stride % 32 == 0 && !d->out_rows && (d->splitk == 1 || d->splitk == 0)),
+  COOCC_CHECK_ARG(!d->out_h2 || (d->Cout % 4 == 0 && d->out_stride % 32 == 0 && !d->out_rows && (d->splitk == 1 || d->splitk == 0 || d->tile_sem)),
                   "conv_fwd: out_h2 needs Cout % 4 == 0, out_stride % 32 == 0, no row scatter");
+  k.out_h2t = d->out_h2_twin;
+  COOCC_CHECK_ARG(!d->out_h2_twin || (!one && d->Cout % 32 == 0 && !d->out_rows && ((uintptr_t)d->out_h2_twin & 15) == 0 && (d->out_stride & 3) == 0 &&
+                                      (!d->res || (d->res_stride & 3) == 0)),
+                  "conv_fwd: out_h2_twin needs mfma_dtype 3, Cout % 32 == 0, 16-byte aligned rows, no row scatter");
+  k.tile_sem = d->tile_sem;
   int rc = coocc_zero_row(&k.zrow);
+  if (rc != COOCC_OK) return rc;
+  rc = coocc_h2_flag_ptr(&k.h2_flag);
   if (rc != COOCC_OK) return rc;
   k.ntiles = (k.Cout + 127) / 128;
   k.mtiles = (k.M + 127) / 128;
@@ -652,7 +693,9 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   const int ngroups = k.total_iters / gsz;
   if (splitk <= 0) {
     splitk = 1;
-    if (blocks < 256 && ngroups >= 8 && d->ws && !d->M_dev && !d->out_rows && !d->out_h2 && !d->out16) {
+    // without arrival counters the reduction is a second launch (k_conv_reduce) whose epilogue has no H2 / f16 / twin outputs
+    const bool second_pass_ok = !d->out_h2 && !d->out16 && !d->out_h2_twin;
+    if (blocks < 256 && ngroups >= 8 && d->ws && !d->M_dev && (d->tile_sem ? true : (!d->out_rows && second_pass_ok))) {
       splitk = (int)(512 / blocks);
       if (splitk > ngroups / 4) splitk = ngroups / 4;
       if (splitk > 64) splitk = 64;
@@ -663,8 +706,12 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   int gps = (ngroups + splitk - 1) / splitk;
   k.iters_per_split = gps * gsz;
   k.splitk = (k.total_iters + k.iters_per_split - 1) / k.iters_per_split;
-  COOCC_CHECK_ARG(k.splitk == 1 || (d->ws && !d->M_dev && !d->out_rows && (long long)k.splitk * d->M * k.Npad <= d->ws_floats),
-                  "conv_fwd: split-K workspace too small (or split-K with a device row count / row scatter)");
+  COOCC_CHECK_ARG(k.splitk == 1 || (d->ws && !d->M_dev && (long long)k.splitk * d->M * k.Npad <= d->ws_floats),
+                  "conv_fwd: split-K workspace too small (or split-K with a device row count)");
+  COOCC_CHECK_ARG(k.splitk == 1 || d->tile_sem || (!d->out_h2 && !d->out16 && !d->out_h2_twin),
+                  "conv_fwd: split-K with an H2 / f16 output needs tile_sem (the in-kernel reduction)");
+  COOCC_CHECK_ARG(k.splitk == 1 || !d->tile_sem || (long long)k.mtiles * k.ntiles <= d->tile_sem_ints,
+                  "conv_fwd: tile_sem holds fewer counters than the launch has output tiles");
   dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
   if (!zshare) {
     if (one) {
@@ -718,7 +765,7 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
 // fp32 rows (row stride in_stride floats, first C columns, C % 32 == 0) * scale -> H2 rows [rows][C/32][hi 32 | lo 32] (4 C bytes per row)
 __global__ __launch_bounds__(256) void k_rows_to_h2(const float* __restrict__ in, int in_stride, long long rows, int C, float scale,
                                                      char* __restrict__ out, const int32_t* __restrict__ row_ids,
-                                                     const int32_t* __restrict__ n_dev) {
+                                                     const int32_t* __restrict__ n_dev, int* __restrict__ flag) {
   if (n_dev) rows = min(rows, (long long)*n_dev);
   const int c8 = C >> 3;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -737,14 +784,18 @@ __global__ __launch_bounds__(256) void k_rows_to_h2(const float* __restrict__ in
   char* o = out + r * (long long)C * 4 + (c >> 5) * 128 + (c & 31) * 2;
   *(f16x8*)o = hi;
   *(f16x8*)(o + 64) = lo;
+  h2_guard(flag, a * scale);
+  h2_guard(flag, b * scale);
 }
 
 extern "C" int coocc_rows_to_h2(const float* in, int in_stride, int64_t rows, int C, float scale, void* out_h2, void* stream) {
   COOCC_CHECK_ARG(in && out_h2 && rows >= 0 && C > 0 && C % 32 == 0 && in_stride % 4 == 0 && in_stride >= C, "rows_to_h2: bad args");
   COOCC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)out_h2 & 15) == 0, "rows_to_h2: pointers must be 16-byte aligned");
   if (rows == 0) return COOCC_OK;
+  int* flag = nullptr;
+  if (coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
   hipLaunchKernelGGL(k_rows_to_h2, dim3(cdiv(rows * (C / 8), 256)), dim3(256), 0, as_stream(stream), in, in_stride, (long long)rows, C,
-                     scale, (char*)out_h2, (const int32_t*)nullptr, (const int32_t*)nullptr);
+                     scale, (char*)out_h2, (const int32_t*)nullptr, (const int32_t*)nullptr, flag);
   COOCC_LAUNCH_CHECK("k_rows_to_h2");
   return COOCC_OK;
 }
@@ -756,8 +807,10 @@ extern "C" int coocc_rows_to_h2_gather(const float* in, int in_stride, const int
   COOCC_CHECK_ARG(in && out_h2 && row_ids && n_cap >= 0 && C > 0 && C % 32 == 0 && in_stride % 4 == 0, "rows_to_h2_gather: bad args");
   COOCC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)out_h2 & 15) == 0, "rows_to_h2_gather: pointers must be 16-byte aligned");
   if (n_cap == 0) return COOCC_OK;
+  int* flag = nullptr;
+  if (coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
   hipLaunchKernelGGL(k_rows_to_h2, dim3(cdiv(n_cap * (C / 8), 256)), dim3(256), 0, as_stream(stream), in, in_stride, (long long)n_cap, C,
-                     scale, (char*)out_h2, row_ids, n_dev);
+                     scale, (char*)out_h2, row_ids, n_dev, flag);
   COOCC_LAUNCH_CHECK("k_rows_to_h2");
   return COOCC_OK;
 }

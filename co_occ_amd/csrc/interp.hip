@@ -2,9 +2,8 @@
 // FPN3D top-down add, OccHead multi-level softmax mix, render-map x16 upsample.
 // Source index rule (ATen area_pixel_compute_source_index): src = max(0, scale*(dst+0.5)-0.5),
 // scale = in/out (fp32), i0 = floor(src), i1 = i0 + (i0 < in-1), lambda = src - i0.
-#include "common.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "conv_k.h"
+#include "h2_rows.h"
 
 struct Lin1 { int i0, i1; float w0, w1; };
 
@@ -36,30 +35,42 @@ __device__ __forceinline__ f32x4 tri_sample(const float* __restrict__ vol, int b
 
 // fpn3d.py:88-92  laterals[i-1] += interpolate(laterals[i], size=prev_shape, trilinear)
 __global__ __launch_bounds__(256) void k_upsample_add(const float* __restrict__ coarse, float* __restrict__ fine,
-                                                       int B, int C, int Xc, int Yc, int Zc, int Xf, int Yf, int Zf) {
+                                                       int B, int C, int Xc, int Yc, int Zc, int Xf, int Yf, int Zf,
+                                                       void* __restrict__ twin, int* __restrict__ flag) {
   const int c4 = C >> 2;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)B * Xf * Yf * Zf * c4;
   if (i >= total) return;
   int c = (int)(i % c4) * 4;
   size_t v = i / c4;
+  const size_t row = v;
   int z = (int)(v % Zf); v /= Zf;
   int y = (int)(v % Yf); v /= Yf;
   int x = (int)(v % Xf); int b = (int)(v / Xf);
   Lin1 lx = lin_src(x, Xc, Xf), ly = lin_src(y, Yc, Yf), lz = lin_src(z, Zc, Zf);
   f32x4 s = tri_sample(coarse, b, C, Xc, Yc, Zc, lx, ly, lz, c);
   f32x4* o = (f32x4*)(fine + ((((size_t)b * Xf + x) * Yf + y) * Zf + z) * C + c);
-  *o = *o + s;
+  const f32x4 r = *o + s;
+  *o = r;
+  if (twin) { store_h2(twin, row, C, c, r); h2_guard(flag, r); }      // H2 twin of the updated rows (the fpn_conv that reads them next)
+}
+
+extern "C" int coocc_upsample_add_trilinear_ex(const float* coarse, float* fine, int B, int C, int Xc, int Yc,
+                                               int Zc, int Xf, int Yf, int Zf, void* fine_h2_twin, void* stream) {
+  COOCC_CHECK_ARG(coarse && fine && B > 0 && C > 0 && C % 4 == 0, "upsample_add: bad args (C % 4 == 0)");
+  COOCC_CHECK_ARG(!fine_h2_twin || (C % 32 == 0 && ((uintptr_t)fine_h2_twin & 15) == 0), "upsample_add: the H2 twin needs C % 32 == 0");
+  int* flag = nullptr;
+  if (fine_h2_twin && coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
+  size_t total = (size_t)B * Xf * Yf * Zf * (C / 4);
+  hipLaunchKernelGGL(k_upsample_add, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), coarse, fine, B, C, Xc,
+                     Yc, Zc, Xf, Yf, Zf, fine_h2_twin, flag);
+  COOCC_LAUNCH_CHECK("k_upsample_add");
+  return COOCC_OK;
 }
 
 extern "C" int coocc_upsample_add_trilinear(const float* coarse, float* fine, int B, int C, int Xc, int Yc,
                                             int Zc, int Xf, int Yf, int Zf, void* stream) {
-  COOCC_CHECK_ARG(coarse && fine && B > 0 && C > 0 && C % 4 == 0, "upsample_add: bad args (C % 4 == 0)");
-  size_t total = (size_t)B * Xf * Yf * Zf * (C / 4);
-  hipLaunchKernelGGL(k_upsample_add, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), coarse, fine, B, C, Xc,
-                     Yc, Zc, Xf, Yf, Zf);
-  COOCC_LAUNCH_CHECK("k_upsample_add");
-  return COOCC_OK;
+  return coocc_upsample_add_trilinear_ex(coarse, fine, B, C, Xc, Yc, Zc, Xf, Yf, Zf, nullptr, stream);
 }
 
 // occ_head.py:155-166: softmax over the level logits, then
@@ -67,7 +78,8 @@ extern "C" int coocc_upsample_add_trilinear(const float* coarse, float* fine, in
 struct MixLevels { const float* p[4]; int X[4], Y[4], Z[4]; int L; };
 
 __global__ __launch_bounds__(256) void k_occhead_mix(MixLevels lv, const float* __restrict__ wlogit,
-                                                      float* __restrict__ out, int B, int C) {
+                                                      float* __restrict__ out, int B, int C, void* __restrict__ twin,
+                                                      int* __restrict__ flag) {
   const int c4 = C >> 2;
   const int X0 = lv.X[0], Y0 = lv.Y[0], Z0 = lv.Z[0];
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -91,11 +103,15 @@ __global__ __launch_bounds__(256) void k_occhead_mix(MixLevels lv, const float* 
     acc = acc + s * (w[l] / sum);
   }
   *(f32x4*)(out + row * C + c) = acc;
+  if (twin) { store_h2(twin, row, C, c, acc); h2_guard(flag, acc); }     // H2 twin for occ_pred_conv's first 1x1x1 layer
 }
 
-extern "C" int coocc_occhead_mix(const float* const* levels_host, const int* dims_host, int L, const float* wlogit,
-                                 float* out, int B, int C, void* stream) {
+extern "C" int coocc_occhead_mix_ex(const float* const* levels_host, const int* dims_host, int L, const float* wlogit,
+                                    float* out, int B, int C, void* out_h2_twin, void* stream) {
   COOCC_CHECK_ARG(levels_host && dims_host && out && L >= 1 && L <= 4 && C % 4 == 0, "occhead_mix: bad args");
+  COOCC_CHECK_ARG(!out_h2_twin || (C % 32 == 0 && ((uintptr_t)out_h2_twin & 15) == 0), "occhead_mix: the H2 twin needs C % 32 == 0");
+  int* flag = nullptr;
+  if (out_h2_twin && coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
   MixLevels lv;
   lv.L = L;
   for (int l = 0; l < 4; ++l) {
@@ -105,9 +121,14 @@ extern "C" int coocc_occhead_mix(const float* const* levels_host, const int* dim
     lv.Z[l] = l < L ? dims_host[l * 3 + 2] : 1;
   }
   size_t total = (size_t)B * lv.X[0] * lv.Y[0] * lv.Z[0] * (C / 4);
-  hipLaunchKernelGGL(k_occhead_mix, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), lv, wlogit, out, B, C);
+  hipLaunchKernelGGL(k_occhead_mix, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), lv, wlogit, out, B, C, out_h2_twin, flag);
   COOCC_LAUNCH_CHECK("k_occhead_mix");
   return COOCC_OK;
+}
+
+extern "C" int coocc_occhead_mix(const float* const* levels_host, const int* dims_host, int L, const float* wlogit,
+                                 float* out, int B, int C, void* stream) {
+  return coocc_occhead_mix_ex(levels_host, dims_host, L, wlogit, out, B, C, nullptr, stream);
 }
 
 // coocc_ray.py:617-622: F.interpolate(scale_factor=16, mode='bilinear') of depth_map and rgb_map.

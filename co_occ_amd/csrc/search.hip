@@ -94,9 +94,10 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
     // spin), so several prefetch threads per rank -- and 8 ranks per node -- do not burn the host cores the issuing threads need
     hipEvent_t got;
     COOCC_HIP(hipEventCreateWithFlags(&got, hipEventBlockingSync | hipEventDisableTiming));
-    COOCC_HIP(hipEventRecord(got, s0));
-    COOCC_HIP(hipEventSynchronize(got));
-    COOCC_HIP(hipEventDestroy(got));
+    const hipError_t e1 = hipEventRecord(got, s0);
+    const hipError_t e2 = e1 == hipSuccess ? hipEventSynchronize(got) : e1;
+    (void)hipEventDestroy(got);
+    if (e2 != hipSuccess) return coocc_set_error(COOCC_EHIP, "fuser_search: waiting for the voxel counts failed: %s", hipGetErrorString(e2));
   }
   const int Ni = d->counts_host[0], Np = d->counts_host[1];
   if (Ni <= d->fps_num || Np <= d->fps_num) return COOCC_SEARCH_SMALL;
@@ -116,11 +117,34 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
                                             d->fps_num, stream);
   if (pair_rc != COOCC_OK && pair_rc != 2) return pair_rc;
   const bool paired = pair_rc == COOCC_OK;
-  hipEvent_t fork, join;
+  // fork / join of the two search directions.  Whatever happens after the fork, the side stream is joined back into `stream` and
+  // the events are destroyed before this call returns (a failure in the middle must not leave the caller's side stream forked
+  // behind an unjoined event, nor leak two events per failed call).
+  hipEvent_t fork = nullptr, join = nullptr;
   COOCC_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-  COOCC_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
-  COOCC_HIP(hipEventRecord(fork, s0));
-  COOCC_HIP(hipStreamWaitEvent(s1, fork, 0));
+  if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
+    (void)hipEventDestroy(fork);
+    return coocc_set_error(COOCC_EHIP, "fuser_search: hipEventCreate failed");
+  }
+  bool forked = false;
+  auto finish = [&](int rc) -> int {
+    if (forked) {
+      if (hipEventRecord(join, s1) != hipSuccess || hipStreamWaitEvent(s0, join, 0) != hipSuccess) {
+        if (rc == COOCC_OK) rc = coocc_set_error(COOCC_EHIP, "fuser_search: joining the side stream failed");
+      }
+    }
+    (void)hipEventDestroy(fork);
+    (void)hipEventDestroy(join);
+    return rc;
+  };
+#define SRF(call)                                \
+  do {                                           \
+    int rc__ = (call);                           \
+    if (rc__ != COOCC_OK) return finish(rc__);   \
+  } while (0)
+  if (hipEventRecord(fork, s0) != hipSuccess || hipStreamWaitEvent(s1, fork, 0) != hipSuccess)
+    return finish(coocc_set_error(COOCC_EHIP, "fuser_search: forking the side stream failed"));
+  forked = true;
 
   // one direction: queries (lin_q, Q, xyz_q, map_q) <- keys (Nk, xyz_k, map_k); near: [K][Q] key ordinals (-1 = none)
   auto direction = [&](int dd, void* st, const int32_t* lin_q, int Q, const float* xyz_q, const int32_t* map_q, int Nk,
@@ -136,16 +160,13 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
   };
   // img queries <- nearest pts keys (bifuser_n.py:150-162) on the side stream; for knum > 1 the reference indexes inds_img
   // with the pts ordinals (:158) -- kept
-  SRC(direction(1, side_stream, lin_img, Ni, xyz_img, map_img, Np, xyz_pts, map_pts, d->near_pts));
+  SRF(direction(1, side_stream, lin_img, Ni, xyz_img, map_img, Np, xyz_pts, map_pts, d->near_pts));
   for (int k = 0; k < K; ++k)
-    SRC(coocc_index_rows_i32(K == 1 ? lin_pts : lin_img, K == 1 ? Np : Ni, d->near_pts + (size_t)k * Ni, Ni, d->rows_p + (size_t)k * V, side_stream));
-  COOCC_HIP(hipEventRecord(join, s1));
+    SRF(coocc_index_rows_i32(K == 1 ? lin_pts : lin_img, K == 1 ? Np : Ni, d->near_pts + (size_t)k * Ni, Ni, d->rows_p + (size_t)k * V, side_stream));
   // pts queries <- nearest img keys (bifuser_n.py:137-148)
-  SRC(direction(0, stream, lin_pts, Np, xyz_pts, map_pts, Ni, xyz_img, map_img, d->near_img));
+  SRF(direction(0, stream, lin_pts, Np, xyz_pts, map_pts, Ni, xyz_img, map_img, d->near_img));
   for (int k = 0; k < K; ++k)
-    SRC(coocc_index_rows_i32(lin_img, Ni, d->near_img + (size_t)k * Np, Np, d->rows + (size_t)k * V, stream));
-  COOCC_HIP(hipStreamWaitEvent(s0, join, 0));
-  COOCC_HIP(hipEventDestroy(fork));
-  COOCC_HIP(hipEventDestroy(join));
-  return COOCC_OK;
+    SRF(coocc_index_rows_i32(lin_img, Ni, d->near_img + (size_t)k * Np, Np, d->rows + (size_t)k * V, stream));
+#undef SRF
+  return finish(COOCC_OK);
 }

@@ -13,9 +13,8 @@
 // (tests/test_gpu_conv.py checks both tile sizes against torch's direct conv).
 // Layout: V / M are [(m+2)^2][Gpad][C], p = a*(m+2) + e (a along x), row = ((b*Tx + tx)*Ty + ty)*Z + z,
 // Tx = ceil(X/m), Gpad = roundup(rows, lcm(640, Z)).
-#include "common.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "conv_k.h"
+#include "h2_rows.h"
 
 template <int N> struct Wino;
 template <> struct Wino<4> {   // F(2,3)
@@ -120,11 +119,10 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ in, i
 
 // The same transform writing V * scale as "H2 rows" (gemm_h2.hip): per row and 32-channel chunk 64 bytes of f16 hi followed by
 // 64 bytes of f16 lo = f16((v - hi) * 2^11).  A thread owns 4 channels: 8-byte stores.
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int N>
 __global__ __launch_bounds__(256) void k_wino_in_h2(const float* __restrict__ in, int in_stride, int B, int X, int Y, int Z,
                                                      int C, int Tx, int Ty, size_t gstride_bytes, int vstride, float scale,
-                                                     char* __restrict__ V) {
+                                                     char* __restrict__ V, int* __restrict__ flag) {
   constexpr int MO = Wino<N>::M;
   const int c4 = C >> 2;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -170,6 +168,7 @@ __global__ __launch_bounds__(256) void k_wino_in_h2(const float* __restrict__ in
       char* oo = o + (size_t)(a * N + e) * gstride_bytes;
       *(f16x4*)oo = hi;
       *(f16x4*)(oo + 64) = lo;
+      h2_guard(flag, q[e] * scale);
     }
   }
 }
@@ -186,12 +185,14 @@ extern "C" int coocc_wino_input_h2(const float* in, int in_stride, int B, int X,
   const dim3 grid(cdiv(rows * (C / 4), 256));
   const size_t gstride = (size_t)group_rows * vstride * 4;
   hipStream_t s = as_stream(stream);
+  int* flag = nullptr;
+  if (coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
   if (tile == 2)
-    hipLaunchKernelGGL(k_wino_in_h2<4>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V);
+    hipLaunchKernelGGL(k_wino_in_h2<4>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V, flag);
   else if (tile == 3)
-    hipLaunchKernelGGL(k_wino_in_h2<5>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V);
+    hipLaunchKernelGGL(k_wino_in_h2<5>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V, flag);
   else
-    hipLaunchKernelGGL(k_wino_in_h2<6>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V);
+    hipLaunchKernelGGL(k_wino_in_h2<6>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V, flag);
   COOCC_LAUNCH_CHECK("k_wino_in_h2");
   return COOCC_OK;
 }
@@ -232,7 +233,8 @@ template <int N>
 __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ Mb, size_t gstride, int B, int X, int Y, int Z,
                                                    int C, int Tx, int Ty, float* __restrict__ out, int out_stride,
                                                    const float* __restrict__ scale, const float* __restrict__ bias,
-                                                   const float* __restrict__ res, int res_stride, int relu) {
+                                                   const float* __restrict__ res, int res_stride, int relu,
+                                                   void* __restrict__ twin, int* __restrict__ flag) {
   constexpr int MO = Wino<N>::M;
   const int c4 = (C + 3) >> 2;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ Mb, 
         if (rr) v = v + *(const f32x4*)rr;
         if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         *(f32x4*)o = v;
+        if (twin) { store_h2(twin, orow, C, c, v); h2_guard(flag, v); }      // the next split-f16 layer's operand, written by the producer
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -298,27 +301,37 @@ __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ Mb, 
   }
 }
 
-extern "C" int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, int tile, float* out,
-                                 int out_stride, const float* scale, const float* bias, const float* res, int res_stride,
-                                 int relu, void* stream) {
+extern "C" int coocc_wino_output_ex(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, int tile, float* out,
+                                    int out_stride, const float* scale, const float* bias, const float* res, int res_stride,
+                                    int relu, void* out_h2_twin, void* stream) {
   COOCC_CHECK_ARG(Mb && out && B > 0 && X > 0 && Y > 0 && Z > 0 && C > 0, "wino_output: bad args");
   COOCC_CHECK_ARG(tile >= 2 && tile <= 4, "wino_output: tile must be 2, 3 or 4");
   COOCC_CHECK_ARG(((uintptr_t)out & 15) == 0 && (!res || ((uintptr_t)res & 15) == 0), "wino_output: out/res must be 16-byte aligned");
+  COOCC_CHECK_ARG(!out_h2_twin || (C % 32 == 0 && (out_stride & 3) == 0 && (!res || (res_stride & 3) == 0) && ((uintptr_t)out_h2_twin & 15) == 0),
+                  "wino_output: the H2 twin needs C % 32 == 0 and 16-byte aligned rows");
   const int Tx = (X + tile - 1) / tile, Ty = (Y + tile - 1) / tile;
   const long long rows = (long long)B * Tx * Ty * Z;
   COOCC_CHECK_ARG(group_rows >= rows, "wino_output: group_rows too small");
+  int* flag = nullptr;
+  if (out_h2_twin && coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
   const dim3 grid(cdiv(rows * ((C + 3) / 4), 256));
   if (tile == 2)
     hipLaunchKernelGGL(k_wino_out<4>, grid, dim3(256), 0, as_stream(stream), Mb, (size_t)group_rows * C, B, X, Y, Z, C, Tx, Ty,
-                       out, out_stride, scale, bias, res, res_stride, relu);
+                       out, out_stride, scale, bias, res, res_stride, relu, out_h2_twin, flag);
   else if (tile == 3)
     hipLaunchKernelGGL(k_wino_out<5>, grid, dim3(256), 0, as_stream(stream), Mb, (size_t)group_rows * C, B, X, Y, Z, C, Tx, Ty,
-                       out, out_stride, scale, bias, res, res_stride, relu);
+                       out, out_stride, scale, bias, res, res_stride, relu, out_h2_twin, flag);
   else
     hipLaunchKernelGGL(k_wino_out<6>, grid, dim3(256), 0, as_stream(stream), Mb, (size_t)group_rows * C, B, X, Y, Z, C, Tx, Ty,
-                       out, out_stride, scale, bias, res, res_stride, relu);
+                       out, out_stride, scale, bias, res, res_stride, relu, out_h2_twin, flag);
   COOCC_LAUNCH_CHECK("k_wino_out");
   return COOCC_OK;
+}
+
+extern "C" int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, int tile, float* out,
+                                 int out_stride, const float* scale, const float* bias, const float* res, int res_stride,
+                                 int relu, void* stream) {
+  return coocc_wino_output_ex(Mb, group_rows, B, X, Y, Z, C, tile, out, out_stride, scale, bias, res, res_stride, relu, nullptr, stream);
 }
 
 // ------------------------------------------------------------------ gradient of the output transform (training)
@@ -391,8 +404,6 @@ extern "C" int coocc_wino_gradout(const float* dy, int dy_stride, int B, int X, 
 // the grouped GEMM reads (one pack per transform point, conv_layout.h).  Training re-packs every step, so the host
 // fp64 einsum of the inference path (core.PackedConv.wino_pack) is replaced by this kernel (fp64 accumulation kept).
 // dgrad != 0: packs of the transposed convolution dx = conv(dy, W'), W'[c][n][a][b][dz] = w[n][c][2-a][2-b][2-dz].
-#include "conv_layout.h"
-
 __constant__ double c_G4[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
 __constant__ double c_G5[5][3] = {{1, 0, 0}, {-2. / 9, 2. / 9, -2. / 9}, {1. / 9, 2. / 9, 4. / 9}, {-8. / 9, -4. / 9, -2. / 9}, {0, 0, 1}};
 __constant__ double c_G6[6][3] = {{1, 0, 0}, {1. / 3, 1. / 3, 1. / 3}, {-1. / 3, 1. / 3, -1. / 3}, {-16. / 15, -8. / 15, -4. / 15},

@@ -48,6 +48,29 @@ def _build_upstream(kind, cfg, external):
     return getattr(m3b, "build_" + kind)(cfg)
 
 
+class _FusedReaders:
+    """The layers that read the fuser's output: the encoder's ``input_proj`` and the first layer of each render MLP (callable
+    handed to ``BiFuser_N.output_readers``; holds the detector weakly so the module tree stays a tree)."""
+
+    def __init__(self, det):
+        import weakref
+        self._det = weakref.ref(det)
+
+    def __call__(self):
+        det = self._det()
+        if det is None:
+            return ()
+        out = []
+        enc = getattr(det, "semantic_encoder", None)
+        if enc is not None and hasattr(enc, "_packed") and not enc.training:
+            out.append(enc._packed()["proj"])
+        for name in ("sigma_head", "rgb_head"):
+            h = getattr(det, name, None)
+            if h is not None and det.use_rendering:
+                out.append(h._packed()[0])
+        return out
+
+
 @DETECTORS.register_module()
 class COOCC_Ray(nn.Module):
     WITH_RGB_HEAD = True          # COOCC_Ray_L has the sigma head only (coocc_ray_lidar.py:111-112)
@@ -95,6 +118,11 @@ class COOCC_Ray(nn.Module):
         self.loss_cfg, self.disable_loss_depth = loss_cfg, disable_loss_depth
         self.use_rendering, self.test_rendering = use_rendering, test_rendering
         self.metrics_on_device = False              # True: SC/SSC histograms stay int64 device tensors (no sync)
+        # eval-mode ``simple_test`` runs its dense stage as ONE captured hipGraph launch (co_occ_amd.serving, one slot, results
+        # identical to the eager path); COOCC_SIMPLE_TEST_GRAPH=0 or ``model.graph_simple_test = False`` keeps every launch eager
+        self.graph_simple_test = __import__("os").environ.get("COOCC_SIMPLE_TEST_GRAPH", "1") != "0"
+        self._pipe1 = None                          # (shape key, ServingPipeline) of simple_test
+        self.graph_unavailable = None               # why simple_test fell back to the eager path, if it did
         self.img_view_transformer = registry.build_neck(img_view_transformer) if img_view_transformer else None
         self.pts_bbox_head = registry.build_head(pts_bbox_head) if pts_bbox_head else None
         self.occ_fuser = registry.build_fusion_layer(occ_fuser) if occ_fuser is not None else None
@@ -104,6 +132,8 @@ class COOCC_Ray(nn.Module):
             self.sigma_head = MLP(input_dim=128, output_dim=1, net_depth=1, skip_layer=None)
             if self.WITH_RGB_HEAD:
                 self.rgb_head = MLP(input_dim=128, output_dim=3, net_depth=3, skip_layer=None)
+        if self.occ_fuser is not None and hasattr(self.occ_fuser, "output_readers"):
+            self.occ_fuser.output_readers = _FusedReaders(self)
 
     # ------------------------------------------------------------------ encoders (coocc_ray.py:120-256)
     @property
@@ -203,10 +233,11 @@ class COOCC_Ray(nn.Module):
         once the encoder's launches are enqueued (a serving loop with two samples in flight staggers them there).
         ``static``: no host read anywhere (the fine branch keeps its count on the device and returns capacity-sized
         tensors + ``fine_count``): the form ``co_occ_amd.graph`` captures into a hipGraph."""
-        mid = self.semantic_encoder.forward_rows(voxel_feats)
+        neck, head = self.semantic_neck, self.pts_bbox_head
+        mid = self.semantic_encoder.forward_rows(voxel_feats, readers=neck.lateral_packs() if hasattr(neck, "lateral_packs") else None)
         if after_encoder is not None:
             after_encoder()
-        sem = self.semantic_neck.forward_rows(mid)
+        sem = neck.forward_rows(mid, readers=head.level_readers() if hasattr(head, "level_readers") else None)
         output = self.pts_bbox_head(voxel_feats=sem, img_feats=img_feats, transform=transform, static=static)
         res = dict(voxel_feats=voxel_feats, pred_c=output['output_voxels'][0], pred_f=None,
                    output_voxels_fine=output['output_voxels_fine'], output_coords_fine=output['output_coords_fine'])
@@ -296,25 +327,114 @@ class COOCC_Ray(nn.Module):
                 res["SSC_occ_metric_fine"] = occ
         return res
 
+    # ------------------------------------------------------------------ serving (co_occ_amd.serving)
+    def serving(self, example, **kw):
+        """A ``ServingPipeline`` over this detector: ``submit(frame) -> Ticket`` with several frames in flight (the dense stage
+        of each is one captured hipGraph launch).  ``example``: a frame dict that fixes the shapes (``serving_frame``)."""
+        from .serving import ServingPipeline
+        return ServingPipeline(self, example, **kw)
+
+    def serving_frame(self, img=None, points=None, img_metas=None, precomputed=None):
+        """The ``frame`` dict ``ServingPipeline.submit`` takes, from ``simple_test``'s arguments: runs what is UPSTREAM of the hot
+        path (2-D image encoder + DepthNet, the LiDAR producer) eagerly and stops before Lift (x) Splat.  ``precomputed`` may
+        carry ``depth`` + ``ctx`` (the lifted pair) or ``img_voxel_feats`` (already pooled), ``pts_voxel_feats``, ``img_feats``,
+        ``gemo`` / ``cams``, ``transform``."""
+        pc = precomputed or {}
+        fr = dict(depth=pc.get("depth"), ctx=pc.get("ctx"), img_voxel_feats=pc.get("img_voxel_feats"), pts=pc.get("pts_voxel_feats"),
+                  img_feats=pc.get("img_feats"), gemo=pc.get("gemo"), cams=pc.get("cams"),
+                  transform=(img[1:] if img is not None else pc.get("transform")))
+        if precomputed is None:
+            enc = self.image_encoder(img[0])
+            rots, trans, intrins, post_rots, post_trans, bda = img[1:7]
+            vt = self.img_view_transformer
+            mlp_input = vt.get_mlp_input(rots, trans, intrins, post_rots, post_trans, bda)
+            fr["depth"], fr["ctx"] = vt.lift([enc['x'], rots, trans, intrins, post_rots, post_trans, bda, mlp_input])
+            fr["img_feats"] = enc['img_feats']
+            fr["pts"] = self.extract_pts_feat(points)[0]
+        if fr["cams"] is None and fr["gemo"] is None and fr["transform"] is not None:
+            fr["cams"] = tuple(fr["transform"][:6])
+        return fr
+
+    def _simple_test_graph(self, fr, fine_size):
+        """The dense stage of one frame through a one-slot ``ServingPipeline`` (built on first use, rebuilt when the shapes
+        change).  Returns the output dict, or None when this configuration / frame cannot take the captured form."""
+        from . import _lib
+        if fr["pts"] is None or fr["img_feats"] is None or fr["transform"] is None or (fr["depth"] is None and fr["img_voxel_feats"] is None):
+            return None
+        if fr["depth"] is not None and fr["cams"] is None:
+            return None
+        do_render = bool(self.use_rendering and self.test_rendering)
+        key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(fr.items()) if torch.is_tensor(v)) + \
+            (tuple(fr["img_feats"][0].shape), do_render, str(fr["pts"].device))
+        if self._pipe1 is None or self._pipe1[0] != key:
+            if self.graph_unavailable is not None and self.graph_unavailable[0] == key:
+                return None
+            try:
+                self._pipe1 = (key, self.serving(fr, slots=1, dense_streams=1, render=do_render))
+            except (_lib.CooccError, NotImplementedError, AssertionError, RuntimeError) as e:
+                self.graph_unavailable = (key, "%s: %s" % (type(e).__name__, e))
+                self._pipe1 = None
+                return None
+        pipe = self._pipe1[1]
+        X, Y, Z = pipe.grid
+        cf = self.pts_bbox_head.cascade_ratio
+        if fine_size is not None and list(fine_size) != [X * cf, Y * cf, Z * cf]:
+            return None                                       # the captured scatter writes the default fine grid
+        t = pipe.submit(fr, copy=True)
+        out = dict(t.result(wait=True))
+        res = pipe.graphs[0].out if not t.fallback else None
+        if res is not None and res.get("output_voxels_fine") is not None and out.get("fine_count") is not None:
+            # capacity-sized fine outputs of the captured form -> the exact-size tensors the eager path returns
+            n = int(out["fine_count"].item()) * cf ** 3
+            out["output_voxels_fine"] = [res["output_voxels_fine"][0][:n].clone()]
+            xyz = res["output_coords_fine"][0]
+            out["output_coords_fine"] = [xyz.view(3, -1)[:, :n].clone()]
+        return out
+
     def simple_test(self, img_metas=None, img=None, gt_depths=None, points=None, rescale=False, points_occ=None,
                     gt_occ=None, visible_mask=None, precomputed=None):
         """Reference signature and result dict (coocc_ray.py:520-656).  ``img`` = img_inputs (imgs, rots, trans, intrins,
-        post_rots, post_trans, bda, ...); ``points`` = [points [N,5]].  ``precomputed=dict(img_voxel_feats=,
-        pts_voxel_feats=, gemo=, img_feats=)`` (an extension) bypasses the upstream encoders."""
+        post_rots, post_trans, bda, ...); ``points`` = [points [N,5]].  ``precomputed=dict(img_voxel_feats= | depth= + ctx=,
+        pts_voxel_feats=, gemo=, img_feats=)`` (an extension) bypasses the upstream encoders.
+        In eval mode the dense stage runs as one captured hipGraph launch (``graph_simple_test``; same bits as the eager
+        launches, which remain the fallback for configurations / frames the captured form does not cover)."""
         if points_occ is not None:
             raise NotImplementedError("lidarseg evaluation (forward_lidarseg) is not on the hot path")
-        if precomputed is not None:
+        fine_size = list(gt_occ.shape[1:]) if gt_occ is not None else None
+        out = None
+        lifted = precomputed is not None and precomputed.get("depth") is not None
+        if (self.graph_simple_test or lifted) and not self.training and self.occ_fuser is not None and self.img_view_transformer is not None:
+            fr = self.serving_frame(img, points, img_metas, precomputed)
+            out = self._simple_test_graph(fr, fine_size) if self.graph_simple_test else None
+            if out is None:                                   # eager path from the frame that was just built
+                if fr["img_voxel_feats"] is None:
+                    fr["img_voxel_feats"] = self.img_view_transformer.lift_splat(fr["depth"], fr["ctx"], cams=fr["cams"])
+                gemo = fr["gemo"]
+                if gemo is None and fr["cams"] is not None and self.use_rendering and self.test_rendering:
+                    gemo = self.img_view_transformer.get_geometry(*fr["cams"])
+                voxel_feats = self.fuse(fr["img_voxel_feats"], fr["pts"], (precomputed or {}).get("search"))
+                out = self.decode(voxel_feats, gemo, fr["img_feats"], fr["transform"], fine_size=fine_size)
+        elif precomputed is not None:
             voxel_feats = self.fuse(precomputed.get("img_voxel_feats"), precomputed.get("pts_voxel_feats"), precomputed.get("search"))
             img_feats, gemo = precomputed.get("img_feats"), precomputed.get("gemo")
             transform = img[1:] if img is not None else precomputed.get("transform")
+            out = self.decode(voxel_feats, gemo, img_feats, transform, fine_size=fine_size)
         else:
             voxel_feats, img_feats, _, _, gemo, _ = self.extract_feat(points, img=img, img_metas=img_metas)
             transform = img[1:] if img is not None else None
-        fine_size = list(gt_occ.shape[1:]) if gt_occ is not None else None
-        out = self.decode(voxel_feats, gemo, img_feats, transform, fine_size=fine_size)
+            out = self.decode(voxel_feats, gemo, img_feats, transform, fine_size=fine_size)
+        return self.finish_test_result(out, gt_occ, visible_mask)
+
+    def finish_test_result(self, out, gt_occ=None, visible_mask=None):
+        """The tail of ``simple_test`` (coocc_ray.py:539-560, 629-656) on a decoded sample: the reference's result keys and,
+        with ground truth, the SC / SSC confusion matrices."""
+        out = dict(out)
         out.update(output_voxels=out["pred_c"], target_voxels=gt_occ)
         if gt_occ is not None:
             out.update(self._metrics(out, gt_occ, visible_mask))
+            if not self.metrics_on_device:
+                from . import core
+                core.check_h2_overflow()      # the metrics were read back: the whole sample has finished on this stream
         return out
 
     def evaluation_semantic(self, pred, gt, eval_type, visible_mask=None):

@@ -283,6 +283,10 @@ class BiFuser_N(nn.Module):
         self.knn_enc = nn.Sequential(nn.Linear(in_channels * knum, out_channels), nn.ReLU())
         self._packs = PackCache(self)
         self.last_counts = None
+        # callable -> the layers (PackedConv) that read the fused features next (the detector sets it: the encoder's input_proj
+        # and the render MLPs' first layers are split-f16 GEMMs outside the Winograd path, so con_enc.3's output transform
+        # writes their H2 operand next to the fp32 rows)
+        self.output_readers = None
 
     # ---------------------------------------------------------------- packing
     def _packed(self):
@@ -514,7 +518,7 @@ class BiFuser_N(nn.Module):
         packs = self._packed()
         cat4 = self.finish_static(slot)
         x = self.con_enc0(cat4, slot.lin[1], packs, count_dev=slot.counts[1:2])
-        return conv_rows(x, packs["c3"], relu=True)
+        return conv_rows(x, packs["c3"], relu=True, twin_for=self._readers())
 
     def finish_bookkeeping(self, sr):
         """Make a SearchResult issued on another stream safe to consume on the current one (training path)."""
@@ -548,8 +552,11 @@ class BiFuser_N(nn.Module):
         packs = self._packed()
         cat4, (_, lin_pts) = self.fuse(img_voxel_feats, pts_voxel_feats, search)
         x = self.con_enc0(cat4, lin_pts, packs)
-        x = conv_rows(x, packs["c3"], relu=True)
+        x = conv_rows(x, packs["c3"], relu=True, twin_for=self._readers())
         return x.as_ncdhw()
+
+    def _readers(self):
+        return tuple(self.output_readers()) if self.output_readers is not None else ()
 
     @staticmethod
     def c0_capacity(V):

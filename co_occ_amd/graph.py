@@ -61,6 +61,11 @@ class DenseGraph:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
             self.out = self._run()
+        # The captured launches hold RAW pointers into the stream's scratch buffers (Winograd V / M, split-K slabs, arrival
+        # counters): keep those tensors alive for as long as the graph exists.  A later eager call on the same stream that
+        # needs a larger buffer REPLACES the dict entry (core.scratch / _wino_buffer) -- without this reference the old tensor
+        # would be freed, handed to someone else by the caching allocator, and every replay would scribble over it.
+        self._pinned = core.stream_scratch(self.slot.cat4.device, self.stream)
         return self
 
     def fits(self, counts):

@@ -8,6 +8,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from . import core as core_mod
 from ._lib import TIMER, call, host_f32, host_i32, ptr
 from .backbone import build_bn
 from .core import PackCache, PackedConv, Rows, conv_rows, linear_rows, to_rows
@@ -115,8 +116,11 @@ class OccHead(nn.Module):
     # ---------------------------------------------------------------- C3
     def forward_coarse_rows(self, voxel_feats):
         """occ_head.py:149-171 on Rows: returns (out_voxel_feats Rows, occ logits Rows)."""
+        from . import core
         p = self._packed()
-        occs = [conv_rows(to_rows(f), p["occ"][i], relu=True) for i, f in enumerate(voxel_feats)]
+        # level 0's output is read by the soft-weight branch's first 1x1x1 layer (a split-f16 GEMM at configs[1]'s size: H2 twin)
+        occs = [conv_rows(to_rows(f), p["occ"][i], relu=True, twin_for=((p["soft"][0],) if (i == 0 and self.soft_weights) else ()))
+                for i, f in enumerate(voxel_feats)]
         o0 = occs[0]
         wlogit = None
         if self.soft_weights:
@@ -126,10 +130,17 @@ class OccHead(nn.Module):
         levels = (_lib.c_void_p * L)(*[o.t.data_ptr() for o in occs])
         dims = host_i32([v for o in occs for v in (o.X, o.Y, o.Z)])
         out = Rows(torch.empty_like(o0.t), o0.B, o0.X, o0.Y, o0.Z, o0.C)
-        call("coocc_occhead_mix", levels, dims, L, ptr(wlogit), ptr(out.t), o0.B, o0.C)
+        tw = None
+        if core.CONV_ENGINE == "h2" and core.CONV_DTYPE == "f32" and o0.C % 32 == 0 and core.takes_h2(out, (p["pred"][0],)):
+            tw = out.h2 = torch.empty_like(o0.t)
+        call("coocc_occhead_mix_ex", levels, dims, L, ptr(wlogit), ptr(out.t), o0.B, o0.C, ptr(tw))
         h = conv_rows(out, p["pred"][0], relu=True)
         occ = conv_rows(h, p["pred"][1], relu=False)
         return out, occ
+
+    def level_readers(self):
+        """Per input level, the layers that read it (the neck's fpn_convs write H2 twins for the split-f16 ones)."""
+        return [(pc,) for pc in self._packed()["occ"]]
 
     def forward_coarse_voxel(self, voxel_feats):
         out, occ = self.forward_coarse_rows(voxel_feats)
@@ -168,6 +179,7 @@ class OccHead(nn.Module):
         if static:
             return self._fine_static(p, ovf, lin, cnt, g if use_img else None, params if use_img else None, (N_i, Hf, Wf) if use_img else None)
         n = int(_lib.host_read(cnt)[0])
+        core_mod.check_h2_overflow()          # the stage's one host read: every conv up to the coarse head has finished
         assert n > 0, 'no foreground in coarse voxel'
         nf = n * r ** 3
         fine_xyz = torch.empty(3, nf, device=dev, dtype=_I64)

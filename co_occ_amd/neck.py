@@ -46,16 +46,31 @@ class FPN3D(nn.Module):
                 out=[PackedConv(m[0].conv.weight, bn=m[0].bn, bias=m[0].conv.bias, ksize=3, pad=1) for m in self.fpn_convs])
         return self._packs.get_modules((self,), build)
 
-    def forward_rows(self, inputs):
+    def lateral_packs(self):
+        """The 1x1x1 laterals, per input level: what the backbone's last block of each stage is read by (H2 twins)."""
+        return [(pc,) for pc in self._packed()["lat"]]
+
+    def forward_rows(self, inputs, readers=None):
+        """``readers``: per output level, the layers that read it next (OccHead's occ_convs)."""
+        import torch
+        from . import core
         assert len(inputs) == len(self.in_channels)
         _eval_only(self)
         p = self._packed()
-        lat = [conv_rows(to_rows(x), p["lat"][i], relu=True) for i, x in enumerate(inputs)]
+        top = self.num_out - 1
+        # only the top lateral reaches its fpn_conv unchanged; the others are updated in place by the top-down pass below,
+        # which then writes the H2 twin of the UPDATED rows itself
+        lat = [conv_rows(to_rows(x), p["lat"][i], relu=True, twin_for=((p["out"][i],) if i == top else ()))
+               for i, x in enumerate(inputs)]
         for i in range(self.num_out - 1, 0, -1):
             c, f = lat[i], lat[i - 1]
-            call("coocc_upsample_add_trilinear", ptr(c.t), ptr(f.t), f.B, f.C, c.X, c.Y, c.Z, f.X, f.Y, f.Z)
-            f.h16 = None          # the rows changed in place: the 16-bit copy the lateral conv's epilogue wrote is stale
-        return [conv_rows(x, p["out"][i], relu=True) for i, x in enumerate(lat)]
+            f.h16 = f.h2 = None   # the rows change in place: the 16-bit copies the lateral conv's epilogue wrote are stale
+            tw = None
+            if core.CONV_ENGINE == "h2" and core.CONV_DTYPE == "f32" and f.C % 32 == 0 and core.takes_h2(f, (p["out"][i - 1],)):
+                tw = f.h2 = torch.empty(f.B * f.V, f.C, device=f.t.device, dtype=torch.float32)
+            call("coocc_upsample_add_trilinear_ex", ptr(c.t), ptr(f.t), f.B, f.C, c.X, c.Y, c.Z, f.X, f.Y, f.Z, ptr(tw))
+        return [conv_rows(x, p["out"][i], relu=True, twin_for=(readers[i] if readers is not None else ()))
+                for i, x in enumerate(lat)]
 
     def forward(self, inputs):
         """list of [B,C_i,...] -> list of [B,out,...] (fpn3d.py:70-108); training mode: batch-statistics BN + autograd."""

@@ -126,7 +126,11 @@ class _BevPoolFn(torch.autograd.Function):
     def forward(ctx, feats, coords, B, D, H, W):
         rows = bev_pool_rows(feats, coords, B, D, H, W)
         c = coords.long()
-        lin = (((c[:, 3] * H + c[:, 0]) * W + c[:, 1]) * D + c[:, 2]).to(torch.int32).contiguous()
+        # the forward kernel DROPS points outside [0,H) x [0,W) x [0,D) x [0,B) (key = nvox): they must receive a zero gradient,
+        # not the row of whatever voxel their out-of-range linear id aliases (coocc_gather_rows skips ids < 0)
+        ok = (c[:, 0] >= 0) & (c[:, 0] < H) & (c[:, 1] >= 0) & (c[:, 1] < W) & (c[:, 2] >= 0) & (c[:, 2] < D) & (c[:, 3] >= 0) & (c[:, 3] < B)
+        lin = (((c[:, 3] * H + c[:, 0]) * W + c[:, 1]) * D + c[:, 2])
+        lin = torch.where(ok, lin, torch.full_like(lin, -1)).to(torch.int32).contiguous()
         ctx.save_for_backward(lin)
         ctx.dims = (B, D, H, W)
         ctx.mark_non_differentiable(lin)

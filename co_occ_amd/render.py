@@ -95,7 +95,9 @@ def voxel_table(sigma_head, rgb_head, vf):
     x = vf.t if (vf.coff == 0 and vf.stride == vf.C) else vf.t[:, vf.coff:vf.coff + vf.C].contiguous()
     xh = None
     if core.CONV_ENGINE == "h2" and core.CONV_DTYPE == "f32" and core.H2_DIRECT and V >= 8192 and vf.C % 32 == 0:
-        xh = core.rows_to_h2(x, vf.C, name="mlp_in")            # one H2 copy of the voxel features for both heads
+        # one H2 copy of the voxel features for both heads: the twin con_enc.3's epilogue wrote (shared with the encoder's
+        # input_proj), or one conversion pass
+        xh = core.h2_rows(vf) if (vf.coff == 0 and vf.stride == vf.C) else core.rows_to_h2(x, vf.C, name="mlp_in")
     sigma_head.forward_rows(x, out=table, out_coff=0, xh=xh)
     if rgb_head is not None:
         rgb_head.forward_rows(x, out=table, out_coff=1, xh=xh)

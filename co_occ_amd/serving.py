@@ -1,0 +1,291 @@
+"""Serving loop of the hot path: frames in, occupancy + rendered maps out, one ``hipGraphLaunch`` per dense stage.
+
+The reference serves one sample per call (``COOCC_Ray.simple_test``, coocc_ray.py:520-656, driven by
+``custom_single_gpu_test``, P/coocc/apis/test.py:22-60).  On MI355X a sample is ~4 ms of GPU work behind ~250 launches, so the
+product keeps SEVERAL samples in flight instead (round 3 measured this loop inside ``bench.py``; it now lives here, behind the
+reference's call):
+
+* a frame is bound to one of ``slots`` sample slots.  The slot's ``SearchSlot`` (concat rows, voxel lists, device-side counts,
+  neighbour tables) and the few inputs the DENSE stage reads (2-D image features, camera matrices) sit at fixed addresses;
+  ``submit(frame)`` COPIES the new frame's tensors there -- there is no per-frame capture;
+* pooling (fused Lift (x) Splat) + the index search (K1-K5, one C-ABI call, ``coocc_fuser_search``) run EAGERLY on the slot's
+  prefetch stream from a helper thread -- they read the frame's own tensors, have one device->host read, and are
+  latency-bound on two CUs, hidden under the dense stages of earlier frames;
+* the dense stage (G1 -> con_enc -> CustomResNet3D -> FPN3D -> OccHead coarse + fine -> render) is the slot's captured
+  ``DenseGraph``: one launch on one of ``dense_streams`` streams.  A frame whose LiDAR sweep is denser than the captured
+  capacity takes the eager dense stage (``eager_fallbacks``).
+
+``Ticket.result()`` hands back the graph's output tensors (valid until the slot is reused ``slots`` submits later; ask for
+``copy=True`` to own them) after checking the split-f16 engine's range guard.  Everything here is stream-ordered: results are
+bit-identical to sequential eager calls (tests/test_gpu_serving.py).
+"""
+import collections
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import torch
+
+from . import core, graph as cg
+
+CAM_KEYS = ("rots", "trans", "intrins", "post_rots", "post_trans", "bda")
+
+
+def _tensors_of(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_of(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_of(v)
+
+
+class Ticket:
+    """One submitted frame.  ``result()`` issues every dense stage up to this frame (if the caller has not pumped them yet),
+    optionally waits for it, and returns the output dict."""
+
+    __slots__ = ("pipe", "index", "slot", "frame", "search", "out", "done", "copy", "events", "fallback", "ready")
+
+    def __init__(self, pipe, index, slot, frame, copy):
+        self.pipe, self.index, self.slot, self.frame, self.copy = pipe, index, slot, frame, copy
+        self.search = self.out = self.done = self.events = None
+        self.fallback = False
+        # whatever produced the frame's tensors on the submitting thread's stream (the upstream encoders) is waited for by the
+        # prefetch stream that reads them
+        self.ready = torch.cuda.Event()
+        self.ready.record(torch.cuda.current_stream(pipe.dev))
+
+    def result(self, wait=True):
+        self.pipe._issue_through(self.index)
+        if wait:
+            self.done.synchronize()
+            core.check_h2_overflow()
+        return self.out
+
+
+class ServingPipeline:
+    """``model``: a ``COOCC_Ray`` in eval mode.  ``example``: one frame (dict, see ``submit``) that fixes the shapes; it is
+    used for the warm-up and the capture of every slot.  ``after_replay(out)`` (optional) runs on the dense stream right after
+    a frame's dense stage has been issued (bench.py issues its RCCL all-gather there)."""
+
+    def __init__(self, model, example, slots=6, dense_streams=3, ahead=0, render=None, search_priority=0, after_replay=None,
+                 time_dense=False):
+        assert not model.training, "ServingPipeline serves the eval-mode (folded-BN) path"
+        self.model = model
+        pts = example["pts"]
+        self.dev = dev = pts.device
+        _, _, X, Y, Z = pts.shape
+        self.grid = (X, Y, Z)
+        self.render = (X >= 100 and Y >= 100 and Z >= 8 and model.use_rendering) if render is None else render
+        self.n = n = max(1, int(slots))
+        self.ndense = max(1, min(int(dense_streams), max(1, n - 1)))
+        # searches in flight ahead of the dense stage: at most slots - dense streams (a slot is rewritten only after the replay
+        # that read it finished); `ahead` limits it further (concurrent searches contend with each other and with the graphs)
+        most = max(1, n - self.ndense) if n > 1 else 1
+        self.ahead = most if ahead <= 0 else max(1, min(int(ahead), most))
+        self.after_replay, self.time_dense = after_replay, time_dense
+        self.dense_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ndense)]
+        self.search_streams = [torch.cuda.Stream(device=dev, priority=search_priority) for _ in range(n)]
+        self.slots = [cg.make_slot(model, self.grid, dev) for _ in range(n)]
+        self.static = [self._make_static(example) for _ in range(n)]
+        self.slot_done = [None] * n            # event: the last replay that read slot k
+        self.graphs = [None] * n
+        self.tpool = ThreadPoolExecutor(self.ahead)
+        self.fallbacks = 0
+        self.dense_ev = []
+        self._lock = threading.Lock()
+        self._pending = collections.deque()    # tickets whose search has not been dispatched yet (their slot is still in use)
+        self._queue = collections.deque()      # tickets with a dispatched search, dense stage not issued yet
+        self._submitted = self._issued = 0
+        self._issued_of_slot = [0] * n
+        self._dispatched_of_slot = [0] * n
+        self._capture(example)
+
+    # ------------------------------------------------------------------ static inputs of the dense stage
+    def _make_static(self, fr):
+        dev = self.dev
+        cams = fr.get("cams")
+        tr = fr["transform"]
+        size = tr[-1]
+        size = tuple(int(v[0]) if torch.is_tensor(v) else int(v) for v in size)       # image size: fixed per pipeline
+        st = dict(img_feats=[torch.empty_like(fr["img_feats"][0], device=dev)],
+                  cams=tuple(torch.empty_like(t, device=dev) for t in cams) if cams is not None else None,
+                  transform=tuple(torch.empty_like(t, device=dev) if torch.is_tensor(t) else t for t in tr[:-1]) + (size,),
+                  gemo=None)
+        if cams is None:                       # geometry tensor instead of camera matrices (render reads it)
+            st["gemo"] = torch.empty_like(fr["gemo"], device=dev) if fr.get("gemo") is not None else None
+        return st
+
+    def _copy_in(self, k, fr):
+        """The new frame's dense-stage inputs -> slot k's static tensors (on the current = the slot's prefetch stream)."""
+        st = self.static[k]
+        st["img_feats"][0].copy_(fr["img_feats"][0], non_blocking=True)
+        if st["cams"] is not None:
+            for d, s in zip(st["cams"], fr["cams"]):
+                d.copy_(s, non_blocking=True)
+        for d, s in zip(st["transform"][:-1], fr["transform"][:-1]):
+            if torch.is_tensor(d):
+                d.copy_(s, non_blocking=True)
+        if st["gemo"] is not None:
+            st["gemo"].copy_(fr["gemo"], non_blocking=True)
+
+    # ------------------------------------------------------------------ search stage (helper threads)
+    def _search(self, t):
+        k, fr = t.slot, t.frame
+        torch.cuda.set_device(self.dev)
+        st = self.search_streams[k]
+        with torch.cuda.stream(st), torch.no_grad():
+            st.wait_event(t.ready)
+            if self.slot_done[k] is not None:
+                st.wait_event(self.slot_done[k])           # the replay that read this slot last
+            if self.time_dense:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            for v in _tensors_of(fr):
+                if v.is_cuda:
+                    v.record_stream(st)            # allocated on the caller's stream, read by this one
+            self._copy_in(k, fr)
+            slot = self.slots[k]
+            if fr.get("depth") is not None:
+                sr = cg.search_into_slot(self.model, slot, fr["depth"], fr["ctx"], fr["cams"], fr["pts"])
+            else:
+                # an already-pooled camera volume: into slot 0 of the concat rows, then the same search
+                vol = fr["img_voxel_feats"]
+                slot.img_rows().as_ncdhw().copy_(vol)
+                sr = self.model.occ_fuser.search_native(fr["pts"], slot) if cg.NATIVE_SEARCH else \
+                    self.model.occ_fuser.search(slot.img_rows().as_ncdhw(), fr["pts"], slot=slot)
+            if self.time_dense:
+                if sr.done_side is not None:
+                    st.wait_event(sr.done_side)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                t.events = (e0, e1)
+        return sr
+
+    # ------------------------------------------------------------------ capture
+    def _capture(self, example):
+        for k in range(self.n):
+            t = Ticket(self, -1, k, example, False)
+            sr = self._search(t)
+            ds = self.dense_streams[k % self.ndense]
+            ds.wait_event(sr.done_main)
+            if sr.done_side is not None:
+                ds.wait_event(sr.done_side)
+            self.graphs[k] = cg.DenseGraph(self.model, self.slots[k], self.static[k], ds, render=self.render).capture()
+        torch.cuda.synchronize(self.dev)
+        core.check_h2_overflow()
+
+    # ------------------------------------------------------------------ the loop
+    def submit(self, frame, copy=False):
+        """``frame``: dict(depth [N,D,fH,fW], ctx [N,C,fH,fW], cams=(rots, trans, intrins, post_rots, post_trans, bda),
+        pts [1,C,X,Y,Z], img_feats=[[1,N,512,fH,fW]], transform=img_inputs[1:]) -- or ``img_voxel_feats`` [1,C,X,Y,Z] instead
+        of depth / ctx.  Shapes as the example's.  Returns a ``Ticket``.  The frame's tensors are read by the prefetched
+        search: do not overwrite them before ``Ticket.result()``."""
+        with self._lock:
+            i = self._submitted
+            self._submitted += 1
+            t = Ticket(self, i, i % self.n, frame, copy)
+            self._pending.append(t)
+        self._pump()
+        return t
+
+    def _pump(self, block_until=None):
+        """Dispatch the searches whose slot is free and issue the dense stages whose search has finished (in submit order).
+        ``block_until``: ticket index whose dense stage must have been issued on return."""
+        while True:
+            with self._lock:
+                # a ticket's search may start once its slot's previous occupant (n submits earlier) has had its replay ISSUED
+                # (the search then waits for that replay's event on the device), and at most `ahead` searches are in flight
+                while self._pending and len(self._queue) < self.ahead:
+                    t = self._pending[0]
+                    if self._dispatched_of_slot[t.slot] > self._issued_of_slot[t.slot]:
+                        break
+                    self._pending.popleft()
+                    self._dispatched_of_slot[t.slot] += 1
+                    t.search = self.tpool.submit(self._search, t)
+                    self._queue.append(t)
+                head = self._queue[0] if self._queue else None
+            if head is None:
+                return
+            must = block_until is not None and self._issued <= block_until
+            if not (must or head.search.done()):
+                return
+            sr = head.search.result()              # blocks only when the caller asked for this ticket
+            self._issue(head, sr)
+            with self._lock:
+                self._queue.popleft()
+                self._issued += 1
+                self._issued_of_slot[head.slot] += 1
+
+    def _issue_through(self, index):
+        if self._issued <= index:
+            self._pump(block_until=index)
+        assert self._issued > index
+
+    def _issue(self, t, sr):
+        k = t.slot
+        ds = self.dense_streams[k % self.ndense]
+        ds.wait_event(sr.done_main)
+        if sr.done_side is not None:
+            ds.wait_event(sr.done_side)
+        with torch.cuda.stream(ds), torch.no_grad():
+            if self.time_dense:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            g = self.graphs[k]
+            if g.fits(sr.counts):
+                out = g.replay()
+            else:                                  # a sweep denser than the captured capacity: eager dense stage
+                self.fallbacks += 1
+                t.fallback = True
+                st = self.static[k]
+                vf = self.model.occ_fuser(self.slots[k].img_rows().as_ncdhw(), t.frame["pts"], search=sr)
+                cam_geo = None
+                if self.render and st["cams"] is not None:
+                    cam_geo = self.model.img_view_transformer._camera_mats(*st["cams"])
+                    cam_geo = (cam_geo[0].reshape(-1, cam_geo[0].shape[-1]),) + tuple(cam_geo[1:])
+                out = self.model.decode(vf, st["gemo"], st["img_feats"], st["transform"], self.render, cam_geo=cam_geo)
+            if self.time_dense:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self.dense_ev.append((e0, e1))
+            if t.copy:                             # own copies of the tensors (lists -- the capacity-sized fine outputs -- by reference)
+                out = {kk: (v.clone() if torch.is_tensor(v) else (v.as_ncdhw().clone() if isinstance(v, core.Rows) else v))
+                       for kk, v in out.items()}
+            if self.after_replay is not None:
+                self.after_replay(out)
+            ev = torch.cuda.Event()
+            ev.record()
+        self.slot_done[k] = ev
+        t.out, t.done = out, ev
+        t.frame = None                             # the search has consumed the frame's tensors (stream-ordered before `ev`)
+
+    def drain(self):
+        """Issue everything submitted so far and wait for it."""
+        if self._submitted:
+            self._issue_through(self._submitted - 1)
+        for ds in self.dense_streams:
+            ds.synchronize()
+        core.check_h2_overflow()
+
+    def run(self, frames, nsteps, collect=None):
+        """Bench / test driver: frame i = frames[i % len(frames)], `ahead` submits in flight.  ``collect(i, out)`` is called in
+        order right after frame i's dense stage has been issued (stream-ordered, no host wait)."""
+        tickets = collections.deque()
+        nxt = 0
+        for i in range(nsteps):
+            while nxt < nsteps and nxt <= i + self.ahead:
+                tickets.append(self.submit(frames[nxt % len(frames)]))
+                nxt += 1
+            t = tickets.popleft()
+            out = t.result(wait=False)
+            if collect is not None:
+                with torch.cuda.stream(self.dense_streams[t.slot % self.ndense]):
+                    collect(i, out)
+        for ds in self.dense_streams:
+            ds.synchronize()
+        core.check_h2_overflow()
+
+    def close(self):
+        self.tpool.shutdown(wait=True)

@@ -16,6 +16,8 @@ CONFIGS = {
     "r50": dict(grid=(100, 100, 8), ncam=6, fmap=(16, 44), knum=2, C=128),          # coocc_multi_r50_256x704
     "r101": dict(grid=(100, 100, 8), ncam=6, fmap=(56, 100), knum=2, C=128),        # coocc_multi_r101_896x1600
     "stress200": dict(grid=(200, 200, 16), ncam=6, fmap=(16, 44), knum=2, C=128),   # north_star stress grid
+    # north_star's literal stress workload: the 200x200x16 FUSED grid together with the 6 x 896 x 1600 frames
+    "stress200_r101": dict(grid=(200, 200, 16), ncam=6, fmap=(56, 100), knum=2, C=128),
     # configs[4]: coocc_multi_r101_openoccupancy.py -- 512x512x40 occupancy grid, fused grid 128x128x10 (0.8 m), cascade 4
     "openocc": dict(grid=(128, 128, 10), ncam=6, fmap=(56, 100), knum=2, C=128, cascade_ratio=4, final_occ_size=(512, 512, 40),
                     point_cloud_range=(-51.2, -51.2, -5.0, 51.2, 51.2, 3.0), input_size=(896, 1600)),

@@ -207,12 +207,19 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
             out_ptr = ptr(out_t)
         ws = _pool_workspace(dev, npts, B * X * Y * Z)
         dp = depth_prob.float().contiguous()
-        if getattr(self, "accelerate", False):
-            # fixed camera rig (the reference's ``accelerate`` flag, ViewTransformerLSSBEVDepth.py:67,242-300): the voxel binning
-            # of the first call is kept in a private workspace and every later call only runs the per-voxel sums
+        if getattr(self, "accelerate", False) and not self.training:
+            # fixed camera rig (the reference's ``accelerate`` flag, ViewTransformerLSSBEVDepth.py:67,242-300 -- the CALLER asserts
+            # that rots / trans / intrins / post_* / bda do not change between frames, exactly as upstream; training-time bda
+            # augmentation changes them every step, so the cache is bypassed under ``train()``; ``invalidate_geometry_cache()``
+            # after a rig change): the voxel binning of the first call is kept in a private workspace and every later call only
+            # runs the per-voxel sums.  The binning was built on ONE stream: its completion event is waited for by any other
+            # stream that reuses it (per-slot prefetch streams).
             key = (dev.index, npts, B * X * Y * Z)
             cache = getattr(self, "_geometry_cache", None)
             if cache is not None and cache[0] == key:
+                cur = torch.cuda.current_stream(dev)
+                if cache[3] != cur.cuda_stream:
+                    cur.wait_event(cache[2])
                 call("coocc_lift_splat_reuse", ptr(dp), ptr(feat), BN, D, H, W, C, B, X, Y, Z, out_ptr, out_stride, ptr(cache[1]),
                      cache[1].numel())
                 if out is not None:
@@ -221,7 +228,7 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
                     return v
                 return out_t.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
             ws = torch.empty_like(ws)
-            self._geometry_cache = (key, ws)
+            self._geometry_cache_pending = (key, ws)
         from ._lib import TIMER
         # algorithmic HBM bytes of the fused form: depth + context rows read, pooled rows written
         with TIMER.region("k_lift_splat", 4.0 * npts + 4.0 * BN * H * W * C + 4.0 * B * X * Y * Z * C):
@@ -236,11 +243,32 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
                 call("coocc_lift_splat_cams", ptr(dp), ptr(feat), ptr(mats), ptr(xs), ptr(ys), ptr(ds), BN, D, H, W, C,
                      npts // B, lo, B, X, Y, Z, out_ptr, out_stride, ptr(ws), ws.numel(), pool_ws_clean(ws, npts, B * X * Y * Z))
             pool_ws_done(ws, npts, B * X * Y * Z)
+        pend = getattr(self, "_geometry_cache_pending", None)
+        if pend is not None and pend[1] is ws:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._geometry_cache = (pend[0], ws, ev, torch.cuda.current_stream(dev).cuda_stream)
+            self._geometry_cache_pending = None
         if out is not None:
             v = out.as_ncdhw()
             v._coocc_keep = out.t            # the buffer object BiFuser_N.concat_buffer registered stays alive with the view
             return v
         return out_t.view(B, X, Y, Z, C).permute(0, 4, 1, 2, 3)
+
+    def lift(self, input):
+        """The Lift half alone (ViewTransformerLSSVoxel.py:125-134): (x [B,N,C,H,W], rots, ..., bda, mlp_input) ->
+        (depth_prob [B*N,D,H,W], img_feat [B*N,C,H,W]) -- what ``lift_splat`` / ``serving.ServingPipeline`` consume."""
+        x = input[0]
+        if self.depth_net is None:
+            raise NotImplementedError("ViewTransformerLiftSplatShootVoxel.lift: DepthNet is upstream of the hot path and "
+                                      "could not be built here (needs the reference plugin + mmcv DCN); pass depth_net=<module>")
+        B, N, C, H, W = x.shape
+        y = self.depth_net(x.view(B * N, C, H, W), input[7])
+        return self.get_depth_dist(y[:, :self.D, ...]), y[:, self.D:self.D + self.numC_Trans, ...]
+
+    def invalidate_geometry_cache(self):
+        """Drop the cached voxel binning of ``accelerate`` (call after the camera rig changed)."""
+        self._geometry_cache = self._geometry_cache_pending = None
 
     def forward(self, input):
         """ViewTransformerLSSVoxel.py:125-145, reference signature:

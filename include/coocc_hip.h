@@ -231,6 +231,14 @@ typedef struct coocc_conv_desc {
   int out16_stride;
   int out_h2;             /* mfma_dtype 3: write the output as H2 rows (out_stride = channels per row, % 32 == 0) -- the producer's
                              epilogue emits the next split-f16 layer's operand, no conversion pass in between */
+  void* out_h2_twin;      /* mfma_dtype 3: an H2 copy [M][Cout] (Cout % 32 == 0) of the fp32 output rows, written next to them by the
+                             epilogue: the operand of a following split-f16 layer that is NOT on the Winograd path (strided, 1x1x1,
+                             small grids, the render MLPs) -- replaces that layer's coocc_rows_to_h2 pass; NULL = none */
+  int32_t* tile_sem;      /* mfma_dtype 3 / 4, split-K: arrival counters, one per 128 x 128 output tile, zero on entry and left zero.
+                             When given, the LAST workgroup of a tile sums the partial slabs in slice order (the order of the
+                             second-pass kernel: same bits) and runs the epilogue itself -- no reduction launch, and the H2 / f16
+                             outputs above become available to split-K layers; NULL = the two-launch form */
+  int tile_sem_ints;      /* capacity of tile_sem */
 } coocc_conv_desc;
 
 /* nn.Conv3d(k=3|1)+BN(eval)+ReLU(+residual) (bifuser_n.py:23-30, resnet3d.py:34-64,
@@ -277,6 +285,16 @@ int coocc_sparse_tap_sum(const float* P, const int32_t* map, int B, int X, int Y
 int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, int tile, float* out,
                       int out_stride, const float* scale, const float* bias, const float* res, int res_stride,
                       int relu, void* stream);
+/* ... and, with out_h2_twin != NULL (C % 32 == 0), an H2 copy [B*X*Y*Z][C] of the finished rows next to them: the operand of a
+ * following split-f16 layer outside the Winograd path (see coocc_conv_desc.out_h2_twin). */
+int coocc_wino_output_ex(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, int tile, float* out,
+                         int out_stride, const float* scale, const float* bias, const float* res, int res_stride,
+                         int relu, void* out_h2_twin, void* stream);
+/* Range guard of the split-f16 engine (resnet3d.py / fpn3d.py / occ_head.py convolutions are fp32 upstream and have no such
+ * limit): every kernel that writes a 16-bit operand (H2 rows, f16 twins, the Winograd-domain V) raises a host-visible flag when a
+ * value reaches half the f16 range (|v| >= 32768 after the writer's own scale; NaN counts).  Returns the flag (0 / 1) and clears it
+ * when reset != 0; no synchronisation of its own -- call it after the stream(s) of interest have been synchronised. */
+int coocc_h2_overflow(int reset);
 /* Winograd weight packs made on the device (training re-packs every step): w:[Cout,Cin,3,3,3] -> (tile+2)^2 packs
  * U[p] = G g G^T in the layout coocc_conv_fwd reads with wgroup_rows (taps = 3, the z taps).  dgrad != 0: packs of the
  * transposed convolution (W'[c][n] = w[n][c] with all three tap axes flipped; GEMM N = Cin, K = Cout).
@@ -402,11 +420,17 @@ int coocc_bn_backward_dx(const float* x, const float* y, const float* dy, int M,
  * align_corners=False.  Rows NDHWC with C channels. */
 int coocc_upsample_add_trilinear(const float* coarse, float* fine, int B, int C, int Xc, int Yc,
                                  int Zc, int Xf, int Yf, int Zf, void* stream);
+/* ... and, with fine_h2_twin != NULL (C % 32 == 0), an H2 copy of the updated fine rows (the fpn_conv that reads them next) */
+int coocc_upsample_add_trilinear_ex(const float* coarse, float* fine, int B, int C, int Xc, int Yc,
+                                    int Zc, int Xf, int Yf, int Zf, void* fine_h2_twin, void* stream);
 
 /* OccHead.forward_coarse_voxel mix (occ_head.py:155-166): out = sum_l softmax(wlogit)[l] *
  * trilinear(level_l -> level-0 size).  levels: up to 4 NDHWC volumes. */
 int coocc_occhead_mix(const float* const* levels_host, const int* dims_host /*[L][3]*/, int L,
                       const float* wlogit /*[V0,L]*/, float* out, int B, int C, void* stream);
+/* ... and, with out_h2_twin != NULL (C % 32 == 0), an H2 copy of `out` (occ_pred_conv's first layer reads it next) */
+int coocc_occhead_mix_ex(const float* const* levels_host, const int* dims_host /*[L][3]*/, int L,
+                         const float* wlogit /*[V0,L]*/, float* out, int B, int C, void* out_h2_twin, void* stream);
 
 /* ---------------------------------------------------------------- C4 fine branch */
 /* coarse_occ.argmax(1) != empty_idx over [V] rows of `stride` floats (occ_head.py:182) */

@@ -121,29 +121,32 @@ def test_two_stream_pipeline_outputs_equal_sequential_calls():
 
 
 def test_graph_pipeline_outputs_equal_sequential_calls():
-    """The default serving loop (bench.GraphPipeline: native search driver on prefetch streams, the dense stage of every sample one
-    hipGraph launch on one of several dense streams) produces bit for bit the outputs of plain sequential eager calls."""
+    """The default serving loop of bench.py -- the PRODUCT's ``COOCC_Ray.serving()`` (co_occ_amd.serving.ServingPipeline: native search
+    driver on prefetch streams, the dense stage of every sample one hipGraph launch on one of several dense streams, every frame's
+    dense-stage inputs copied into its slot) -- produces bit for bit the outputs of plain sequential eager calls."""
     import torch
     sys.path.insert(0, ROOT)
     import bench
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     model, _ = bench.build_model("r50", dev)
-    samples = [bench.make_inputs("r50", 177 + i, dev, model) for i in range(4)]
+    samples = [bench.make_inputs("r50", 177 + i, dev, model) for i in range(5)]       # 5 frames over 4 slots: frames move between slots
     keys = ("pred_c", "pred_f", "rgbs", "depths")
     with torch.no_grad():
         ref = [{k: bench.step(model, s, 1)[k].clone() for k in keys} for s in samples]
     torch.cuda.synchronize()
-    gp = bench.GraphPipeline(model, samples, dev, world=1, ndense=2)
+    frames = [bench.frame_of(s) for s in samples]
+    gp = model.serving(frames[0], slots=4, dense_streams=2)
     got = {}
-    gp.run(6)
-    gp.run(11, collect=lambda i, out: got.__setitem__(i, {k: out[k].clone() for k in keys}))
+    gp.run(frames, 6)
+    gp.run(frames, 11, collect=lambda i, out: got.__setitem__(i, {k: out[k].clone() for k in keys}))
     torch.cuda.synchronize()
     assert sorted(got) == list(range(11)) and gp.fallbacks == 0
     for i, g in got.items():
         for k, v in g.items():
-            assert torch.equal(v, ref[i % 4][k]), (i, k)
-    assert not torch.equal(ref[0]["pred_c"], ref[1]["pred_c"])
+            assert torch.equal(v, ref[i % 5][k]), (i, k)
+    assert not torch.equal(ref[0]["pred_c"], ref[1]["pred_c"]) and not torch.equal(ref[0]["rgbs"], ref[1]["rgbs"])
+    gp.close()
 
 
 def _torchrun(nproc, extra, timeout=900):

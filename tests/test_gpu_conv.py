@@ -244,14 +244,24 @@ def test_conv3d_winograd_persistent_kernel(dev, monkeypatch, Cin, Cout, grid, ti
     w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (2.0 / (Cin * 27)) ** 0.5
     bn = bn_like(Cout, g)
     ref = F.relu(bn(F.conv3d(x, w, padding=1))).detach() if Cin == 32 else None
+    # the persistent kernel belongs to the exact-fp32 MFMA engine (COOCC_CONV_ENGINE=f32, the documented way out of the
+    # split-f16 engine's operand range): under the default engine these layers run k_gemm_h2z and k_conv2p would never launch
+    monkeypatch.setattr(core, "CONV_ENGINE", "f32")
     pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=3, stride=1, pad=1)
     monkeypatch.setattr(core, "WINO_TILE", tile)
     monkeypatch.setattr(core, "WINO", 1)
     xr = rows_of(x, dev)
     plan = core.wino_plan(xr, pc, X * Y * Z, 0)
-    assert plan is not None and plan[0] == tile
+    assert plan is not None and plan[0] == tile and not core.h2_capable(pc)
     assert (plan[1] * plan[5] // 128) * -(-Cout // 128) > 768 and 3 * -(-Cin // 32) <= 24     # the k_conv2p dispatch rule
+    core.TIMER.enabled, core.TIMER.only = 1, None
+    core.TIMER.reset()
     out = core.conv_rows(xr, pc, relu=True)
+    torch.cuda.synchronize()
+    names = set(core.TIMER.summary())
+    core.TIMER.enabled = False
+    core.TIMER.reset()
+    assert any(n.startswith("k_conv2p") for n in names), "the persistent kernel was not dispatched: %s" % sorted(names)
     monkeypatch.setattr(core, "WINO", 0)
     direct = core.conv_rows(xr, pc, relu=True)
     assert_close(out.as_ncdhw().cpu(), direct.as_ncdhw().cpu(), what="persistent winograd GEMM vs direct")

@@ -1,0 +1,150 @@
+"""The split-f16 engine's round-4 plumbing (csrc/gemm_h2.hip, csrc/h2_rows.h):
+
+* H2 twins written by producer epilogues (GEMM, Winograd output transform, trilinear upsample-add, OccHead mix) are
+  bit-identical to a conversion pass over the fp32 rows they accompany -- so the consumer computes the same bits whether its
+  operand came from the producer or from ``coocc_rows_to_h2``;
+* the in-kernel split-K reduction (arrival counters, last workgroup sums the slabs in slice order) is bit-identical to the
+  two-launch form (``k_conv_reduce``) and leaves its counters at zero;
+* the f16 range guard: activations that leave the operand range raise instead of silently producing inf / NaN, and the
+  documented escape hatch (``COOCC_CONV_ENGINE=f32``) computes the same layer correctly.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from co_occ_amd import _lib, core
+from co_occ_amd._lib import call, ptr
+from test_gpu_conv import bn_like, rows_of
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def h2_of(t):
+    """Conversion pass over fp32 rows [n, C] -> H2 rows (as an int32 view for exact comparison)."""
+    out = torch.empty_like(t)
+    call("coocc_rows_to_h2", ptr(t), t.shape[1], t.shape[0], t.shape[1], 1.0, ptr(out))
+    return out.view(torch.int32)
+
+
+def consumer(C, dev, ksize=1, stride=1):
+    g = torch.Generator().manual_seed(C)
+    w = torch.randn(64, C, ksize, ksize, ksize, generator=g) * 0.05
+    return core.PackedConv(w.to(dev), ksize=ksize, stride=stride, pad=ksize // 2)
+
+
+@pytest.mark.parametrize("Cin,Cout,grid,k,stride,use_res", [
+    (64, 128, (40, 40, 8), 3, 1, True),       # Winograd path: the output transform writes the twin
+    (128, 256, (50, 50, 4), 3, 2, False),     # strided direct split-f16 GEMM (k_gemm_h2w), split-K -> in-kernel reduce + twin
+    (256, 256, (25, 25, 2), 3, 1, True),      # stride-1 small grid (k_gemm_h2z direct), split-K, residual
+    (128, 128, (30, 30, 8), 1, 1, False),     # 1x1x1
+])
+def test_producer_h2_twin_equals_conversion_pass(dev, monkeypatch, Cin, Cout, grid, k, stride, use_res):
+    monkeypatch.setattr(core, "H2_DIRECT_MIN_FLOPS", 0.0)
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    X, Y, Z = grid
+    x = torch.randn(1, Cin, X, Y, Z, generator=g)
+    w = torch.randn(Cout, Cin, k, k, k, generator=g) * (2.0 / (Cin * k ** 3)) ** 0.5
+    bn = bn_like(Cout, g)
+    pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=k, stride=stride, pad=k // 2)
+    ref = bn(F.conv3d(x, w, stride=stride, padding=k // 2))
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res
+    ref = F.relu(ref).detach()
+    nxt = consumer(Cout, dev)
+    assert core.route(1, *ref.shape[2:], nxt) == "h2"
+    rr = rows_of(res, dev) if use_res else None
+    out = core.conv_rows(rows_of(x, dev), pc, relu=True, res=rr, twin_for=(nxt,))
+    assert out.h2 is not None, "the producer did not write the twin its split-f16 consumer asked for"
+    assert torch.equal(out.h2.view(torch.int32), h2_of(out.t))
+    assert_close(out.as_ncdhw().cpu(), ref, what="producer with twin")
+    plain = core.conv_rows(rows_of(x, dev), pc, relu=True, res=rr)
+    assert plain.h2 is None and torch.equal(plain.t, out.t)
+    # the consumer's result does not depend on where its operand came from
+    a = core.conv_rows(out, nxt, relu=False)
+    b = core.conv_rows(plain, nxt, relu=False)
+    assert plain.h2 is not None            # ... and the conversion it had to run is cached on the Rows for the next reader
+    assert torch.equal(a.t, b.t)
+    core.check_h2_overflow()
+
+
+def test_twin_survives_the_ncdhw_view_and_dies_with_an_inplace_write(dev, monkeypatch):
+    """Modules hand each other zero-copy [B,C,X,Y,Z] views; ``to_rows`` finds the Rows (and twin) behind an untouched view and
+    refuses it once torch has written to the tensor in place."""
+    monkeypatch.setattr(core, "H2_DIRECT_MIN_FLOPS", 0.0)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 64, 24, 24, 4, generator=g)
+    pc = core.PackedConv((torch.randn(64, 64, 1, 1, 1, generator=g) * 0.1).to(dev), ksize=1)
+    nxt = consumer(64, dev)
+    out = core.conv_rows(rows_of(x, dev), pc, relu=True, twin_for=(nxt,))
+    v = out.as_ncdhw()
+    assert core.to_rows(v) is out
+    v.mul_(2.0)
+    r2 = core.to_rows(v)
+    assert r2 is not out and r2.h2 is None
+    assert torch.equal(core.h2_rows(r2).view(torch.int32), h2_of(r2.t))
+
+
+@pytest.mark.parametrize("Cin,Cout,grid,k,stride", [(256, 512, (25, 25, 2), 3, 2), (512, 512, (13, 13, 1), 3, 1), (256, 256, (50, 50, 4), 1, 1),
+                                                      (128, 256, (50, 50, 4), 3, 2)])
+def test_inkernel_splitk_reduction_equals_two_launch_form(dev, monkeypatch, Cin, Cout, grid, k, stride):
+    monkeypatch.setattr(core, "H2_DIRECT_MIN_FLOPS", 0.0)
+    g = torch.Generator().manual_seed(Cin + Cout)
+    X, Y, Z = grid
+    x = torch.randn(1, Cin, X, Y, Z, generator=g)
+    w = torch.randn(Cout, Cin, k, k, k, generator=g) * (2.0 / (Cin * k ** 3)) ** 0.5
+    bn = bn_like(Cout, g)
+    pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=k, stride=stride, pad=k // 2)
+    xr = rows_of(x, dev)
+    outs = []
+    for inkernel in (True, False, True):
+        monkeypatch.setattr(core, "INKERNEL_REDUCE", inkernel)
+        outs.append(core.conv_rows(xr, pc, relu=True).t.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert int(core.tile_sem(dev).abs().sum()) == 0, "arrival counters must be left at zero"
+    ref = F.relu(bn(F.conv3d(x, w, stride=stride, padding=k // 2))).detach()
+    assert_close(core.Rows(outs[0], 1, *ref.shape[2:], Cout).as_ncdhw().cpu(), ref, what="in-kernel split-K")
+
+
+def test_f16_range_guard_raises_and_the_f32_engine_is_the_way_out(dev, monkeypatch):
+    """Activations x 1e4 through an F(4x4) Winograd layer leave the f16 operand range (the transform amplifies by up to 100 at
+    scale 1/8): the guard must flag it; the same layer under COOCC_CONV_ENGINE=f32 is computed correctly."""
+    g = torch.Generator().manual_seed(1)
+    Cin, Cout, (X, Y, Z) = 64, 128, (40, 40, 8)
+    x = torch.randn(1, Cin, X, Y, Z, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (2.0 / (Cin * 27)) ** 0.5
+    pc = core.PackedConv(w.to(dev), ksize=3, pad=1)
+    assert core.CONV_ENGINE == "h2"
+    core.check_h2_overflow()                      # clean start
+    out = core.conv_rows(rows_of(x, dev), pc, relu=False)
+    torch.cuda.synchronize()
+    core.check_h2_overflow()                      # ordinary activations: no flag
+    assert torch.isfinite(out.t).all()
+    big = x * 3.0e4
+    core.conv_rows(rows_of(big, dev), pc, relu=False)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.CooccError, match="COOCC_CONV_ENGINE=f32"):
+        core.check_h2_overflow()
+    core.check_h2_overflow()                      # the check cleared the flag
+    # the direct (non-Winograd) writers: conversion pass and a GEMM epilogue's twin
+    t = torch.full((256, 64), 7.0e4, device=dev)
+    h2_of(t)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.CooccError):
+        core.check_h2_overflow()
+    monkeypatch.setattr(core, "CONV_ENGINE", "f32")
+    pc32 = core.PackedConv(w.to(dev), ksize=3, pad=1)
+    out32 = core.conv_rows(rows_of(big, dev), pc32, relu=False)
+    torch.cuda.synchronize()
+    core.check_h2_overflow()
+    assert_close(out32.as_ncdhw().cpu(), F.conv3d(big, w, padding=1), what="f32 engine on out-of-range activations")
+
+
+def test_weight_pack_refuses_out_of_range_weights(dev):
+    w = torch.zeros(32, 32, 1, 1, 1)
+    w[0, 0] = 1.0e5
+    pc = core.PackedConv(w.to(dev), ksize=1)
+    with pytest.raises(_lib.CooccError, match="f16"):
+        pc.h2_pack()

@@ -167,6 +167,29 @@ def test_bev_pool_op_and_ext_vs_oracle(dev):
     assert torch.equal(fg.grad.cpu(), go[coords[:, 3], :, coords[:, 2], coords[:, 0], coords[:, 1]])
 
 
+def test_bev_pool_out_of_range_points_get_zero_gradient(dev):
+    """Points outside the grid are DROPPED by the forward kernel (key = nvox): their gradient must be zero -- not the row of a
+    voxel their out-of-range linear id happens to alias, and never a read past the gradient volume."""
+    rng = np.random.default_rng(11)
+    n, C, B, X, Y, Z = 5000, 8, 2, 6, 5, 3
+    feats = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32))
+    coords = np.stack([rng.integers(-2, X + 2, n), rng.integers(-2, Y + 2, n), rng.integers(-1, Z + 2, n), rng.integers(0, B + 1, n)], 1)
+    ok = ((coords[:, 0] >= 0) & (coords[:, 0] < X) & (coords[:, 1] >= 0) & (coords[:, 1] < Y) & (coords[:, 2] >= 0) & (coords[:, 2] < Z)
+          & (coords[:, 3] < B))
+    assert 0 < ok.sum() < n
+    coords = torch.from_numpy(coords)
+    fg = feats.to(dev).requires_grad_(True)
+    out = pkg.bev_pool(fg, coords.to(dev), B, Z, X, Y)
+    want = ref_cpu.bev_pool(feats[ok], coords[ok], B, Z, X, Y)
+    assert torch.equal(out.detach().cpu(), want)
+    go = torch.from_numpy(rng.standard_normal((B, C, Z, X, Y)).astype(np.float32))
+    out.backward(go.to(dev))
+    grad = fg.grad.cpu()
+    ci = coords[ok]
+    assert torch.equal(grad[ok], go[ci[:, 3], :, ci[:, 2], ci[:, 0], ci[:, 1]])
+    assert float(grad[~torch.from_numpy(ok)].abs().max()) == 0.0
+
+
 def test_pooling_checksum_full_size(dev):
     """BASELINE-size property (r50 lift: 6x112x16x44 points, C=128): every kept point lands in
     exactly one voxel, so column sums are preserved."""

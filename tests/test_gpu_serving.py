@@ -1,0 +1,102 @@
+"""``co_occ_amd.serving`` behind the reference's calls: ``COOCC_Ray.simple_test`` with its dense stage as one captured hipGraph
+launch, and the pipelined test loop, against the eager path -- 8 DIFFERENT frames (inputs, camera rigs and image features all
+change), bit for bit."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("pred_c", "pred_f", "rgbs", "depths", "output_voxels")
+
+
+def _setup(dev, n=8):
+    import bench
+    bench.CFGNAME[0] = "r50"
+    model, _ = bench.build_model("r50", dev)
+    model.test_rendering = True
+    samples = [bench.make_inputs("r50", 4000 + 13 * i, dev, model) for i in range(n)]
+    g = torch.Generator().manual_seed(5)
+    gts = [torch.randint(0, 17, (1, 200, 200, 16), generator=g).to(dev) for _ in range(n)]
+    return bench, model, samples, gts
+
+
+def _grab(out):
+    d = {k: out[k].clone() for k in KEYS}
+    d["fine"] = out["output_voxels_fine"][0].clone()
+    d["fine_xyz"] = out["output_coords_fine"][0].reshape(3, -1).clone()
+    for k in ("SC_metric", "SSC_metric", "SSC_metric_fine"):
+        d[k] = out[k].copy()
+    return d
+
+
+def _same(a, b, tag):
+    for k in a:
+        if torch.is_tensor(a[k]):
+            assert torch.equal(a[k], b[k]), "%s: %s differs" % (tag, k)
+        else:
+            assert (a[k] == b[k]).all(), "%s: %s differs" % (tag, k)
+
+
+def test_simple_test_with_graphs_equals_eager_on_eight_different_frames(dev):
+    bench, model, samples, gts = _setup(dev)
+    kws = [dict(bench.simple_test_kwargs(s), gt_occ=g) for s, g in zip(samples, gts)]
+    with torch.no_grad():
+        model.graph_simple_test = False
+        ref = [_grab(model.simple_test(**kw)) for kw in kws]
+        assert model._pipe1 is None
+        model.graph_simple_test = True
+        got = [_grab(model.simple_test(**kw)) for kw in kws]
+        again = _grab(model.simple_test(**kws[2]))              # an earlier frame again, after the slot has seen five others
+    assert model._pipe1 is not None and model.graph_unavailable is None, model.graph_unavailable
+    assert model._pipe1[1].fallbacks == 0
+    for i, (a, b) in enumerate(zip(ref, got)):
+        _same(a, b, "frame %d" % i)
+    _same(ref[2], again, "frame 2 again")
+    assert not torch.equal(ref[0]["pred_c"], ref[1]["pred_c"]) and not torch.equal(ref[0]["rgbs"], ref[3]["rgbs"])
+    assert int(ref[0]["SSC_metric"].sum()) > 0
+
+
+def test_pipelined_test_loop_equals_per_sample_calls(dev):
+    """``apis.pipelined_test`` = custom_single_gpu_test's loop with several samples in flight: same results, same order."""
+    from co_occ_amd import apis
+    bench, model, samples, gts = _setup(dev)
+    kws = [dict(bench.simple_test_kwargs(s), gt_occ=g) for s, g in zip(samples, gts)]
+    with torch.no_grad():
+        model.graph_simple_test = False
+        ref = [_grab(model.simple_test(**kw)) for kw in kws]
+    data = [dict(precomputed=kw["precomputed"], gt_occ=kw["gt_occ"]) for kw in kws] * 2          # 16 samples through 4 slots
+    n = 0
+    for i, (d, res) in enumerate(apis.pipelined_test(model, iter(data), slots=4, dense_streams=2)):
+        assert d is data[i]
+        got = {k: res[k].clone() for k in KEYS}
+        for k in ("SC_metric", "SSC_metric", "SSC_metric_fine"):
+            got[k] = res[k]
+        want = {k: ref[i % 8][k] for k in got}
+        _same(want, got, "sample %d" % i)
+        n += 1
+    assert n == 16
+
+
+def test_serving_takes_a_pooled_camera_volume_too(dev):
+    """``precomputed=dict(img_voxel_feats=...)`` (the camera volume already pooled) through the captured form."""
+    bench, model, samples, gts = _setup(dev, n=2)
+    with torch.no_grad():
+        outs = []
+        for flag in (False, True):
+            model.graph_simple_test = flag
+            o = []
+            for s in samples:
+                vol = model.img_view_transformer.lift_splat(s["depth"], s["ctx"], cams=s["cams"]).contiguous()
+                r = model.simple_test(img=None, precomputed=dict(img_voxel_feats=vol, pts_voxel_feats=s["pts"], img_feats=s["img_feats"],
+                                                                transform=s["transform"], gemo=s["gemo"]))
+                o.append({k: r[k].clone() for k in KEYS})
+            outs.append(o)
+    assert model._pipe1 is not None, model.graph_unavailable
+    for a, b in zip(*outs):
+        _same(a, b, "pooled volume")
