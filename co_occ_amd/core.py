@@ -40,9 +40,12 @@ CONV_ENGINE = __import__("os").environ.get("COOCC_CONV_ENGINE", "h2")
 # amp = 100 for F(4x4), 25 for F(3x3), 4 for F(2x2))
 H2_WINO_SCALE = {2: 0.5, 3: 0.25, 4: 0.125}
 H2_DIRECT = __import__("os").environ.get("COOCC_H2_DIRECT", "1") != "0"     # stride-1 3x3xkz layers outside the Winograd path
-# split-K layers of the split-f16 engine reduce in-kernel (arrival counters; the last workgroup of a tile sums the slabs in slice
-# order and runs the epilogue): no k_conv_reduce launch.  0 = the two-launch form (same bits)
-INKERNEL_REDUCE = __import__("os").environ.get("COOCC_INKERNEL_REDUCE", "1") != "0"
+# 1: split-K layers of the split-f16 engine reduce in-kernel (arrival counters; the last workgroup of a tile sums the slabs in slice
+# order and runs the epilogue): no k_conv_reduce launch, same bits.  MEASURED SLOWER and off by default: the last-arriving
+# workgroup of a tile reads splitk (up to 32) slabs with 16 tiles' worth of parallelism where the second-pass kernel spreads the
+# same reads over the whole chip -- k_gemm_h2z<1,true> 24 -> 168 us with device-scope loads (200 us with __threadfence()), against
+# a 5 us k_conv_reduce launch (profiles/r4_dense_stage_kernels.txt).  The second pass instead writes the H2 twin.
+INKERNEL_REDUCE = __import__("os").environ.get("COOCC_INKERNEL_REDUCE", "0") != "0"
 H2_DIRECT_MIN_FLOPS = 1e9      # below this the input split + split-K reduce launches cost more than the faster GEMM saves (measured)
 
 

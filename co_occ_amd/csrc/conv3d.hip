@@ -23,6 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #include "conv_k.h"
+#include "h2_rows.h"
 
 template <int BM, int BN, int WM, int WN, bool TABLE>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvK p) {
@@ -1128,6 +1129,31 @@ __global__ __launch_bounds__(256) void k_conv_reduce(ConvK p) {
   p.out[orow * p.out_stride + n] = epilogue(p, v, n, orow);
 }
 
+// The same pass for the split-f16 / f16 launches, four channels per thread (Cout % 4 == 0): besides the fp32 rows it writes what
+// the single-pass epilogue of those kernels can -- H2 rows instead of fp32 (out_h2), an f16 copy (out16), an H2 TWIN of the
+// fp32 rows (out_h2t: the next split-f16 layer's operand, which used to be a conversion launch of its own right after this one).
+__global__ __launch_bounds__(256) void k_conv_reduce4(ConvK p) {
+  const int c4 = p.Cout >> 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)p.M * c4) return;
+  const int m = (int)(i / c4), n = (int)(i - (size_t)m * c4) * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  const float* src = p.ws + (size_t)m * p.Npad + n;
+  const size_t zs = (size_t)p.M * p.Npad;
+  for (int z = 0; z < p.splitk; ++z) v = v + *(const f32x4*)(src + (size_t)z * zs);
+  const size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
+  if (p.res_mode == 3) v = v + *(const f32x4*)(p.res + orow * p.res_stride + n);
+  if (p.scale) v = v * *(const f32x4*)(p.scale + n);
+  if (p.bias) v = v + *(const f32x4*)(p.bias + n);
+  if (p.res_mode == 1) v = v + *(const f32x4*)(p.res + orow * p.res_stride + n);
+  if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+  if (p.res_mode == 2) v = v * *(const f32x4*)(p.res + orow * p.res_stride + n);
+  if (p.out_h2) { store_h2(p.out, orow, p.out_stride, n, v); h2_guard(p.h2_flag, v); }
+  else *(f32x4*)(p.out + orow * p.out_stride + n) = v;
+  if (p.out16) { store_f16(p.out16, orow, p.out16_stride, n, v); h2_guard(p.h2_flag, v); }
+  if (p.out_h2t) { store_h2(p.out_h2t, orow, p.Cout, n, v); h2_guard(p.h2_flag, v); }
+}
+
 // ------------------------------------------------------------------ host side
 extern "C" int64_t coocc_conv_pack_weights(const float* w_host, int Cout, int Cin, int taps, int tap_major,
                                            float* packed_host) {
@@ -1209,7 +1235,9 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
     const int rc = coocc_launch_h2(k, d, s3);
     if (rc != COOCC_OK) return rc;
     if (k.splitk > 1 && !k.tile_sem) {      // with arrival counters the last workgroup of every tile has reduced in-kernel
-      hipLaunchKernelGGL(k_conv_reduce, dim3(cdiv((long long)k.M * k.Cout, 256)), dim3(256), 0, s3, k);
+      const bool vec4 = (k.Cout & 3) == 0 && (k.out_stride & 3) == 0 && (!k.res || (k.res_stride & 3) == 0) && (((uintptr_t)k.out) & 15) == 0;
+      if (vec4) hipLaunchKernelGGL(k_conv_reduce4, dim3(cdiv((long long)k.M * (k.Cout / 4), 256)), dim3(256), 0, s3, k);
+      else hipLaunchKernelGGL(k_conv_reduce, dim3(cdiv((long long)k.M * k.Cout, 256)), dim3(256), 0, s3, k);
       COOCC_LAUNCH_CHECK("k_conv_reduce");
     }
     return COOCC_OK;

@@ -66,36 +66,57 @@ __device__ __forceinline__ void h2_epilogue_vec(const ConvK& p, size_t orow, int
 }
 // In-kernel split-K reduction (p.tile_sem != NULL): every workgroup of an (M tile, N tile) has written its partial slab; the one
 // that arrives LAST sums the slabs in slice order 0 .. splitk-1 (the order k_conv_reduce uses: same bits whichever workgroup is
-// last) and runs the epilogue.  Release / acquire at agent scope around the arrival counter (__threadfence: L2 write-back /
-// invalidate across the XCDs); the counter is left at zero for the next launch.  Returns true for the workgroup that reduces.
+// last) and runs the epilogue.  The 8 XCDs' L2s are not coherent with each other for ordinary stores, and the obvious fix --
+// __threadfence() on both sides = an L2 write-back + invalidate per workgroup -- was measured at 4-8x the whole kernel
+// (k_gemm_h2z<1,true> 24 -> 200 us: every arriving workgroup flushes an L2 that other streams keep dirty).  Instead the SLABS
+// THEMSELVES are moved with device-scope accesses: relaxed agent-scope atomic stores / loads (global_store / global_load with
+// sc1: write-through to, and read from, the point of coherence), ordered against the arrival counter by the vmcnt(0) wait
+// that __syncthreads() carries.  Nothing else is flushed or invalidated.  The counter is left at zero for the next launch.
+__device__ __forceinline__ void st_agent(float* p, f32x4 v) {
+  const unsigned long long a = (unsigned long long)__float_as_uint(v[0]) | ((unsigned long long)__float_as_uint(v[1]) << 32);
+  const unsigned long long b = (unsigned long long)__float_as_uint(v[2]) | ((unsigned long long)__float_as_uint(v[3]) << 32);
+  __hip_atomic_store((unsigned long long*)p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((unsigned long long*)p + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 ld_agent(const float* p) {
+  const unsigned long long a = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return f32x4{__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32))};
+}
+// Returns true for the workgroup that reduces.
 __device__ __forceinline__ bool h2_splitk_arrive(const ConvK& p, int tile) {
   __shared__ int s_last;
-  __threadfence();
-  __syncthreads();
+  __syncthreads();            // workgroup-scope release: every wave's slab stores have been acknowledged (s_waitcnt vmcnt(0))
   if (threadIdx.x == 0) {
     const int old = atomicAdd(&p.tile_sem[tile], 1);
     s_last = old == p.splitk - 1;
     if (s_last) p.tile_sem[tile] = 0;
   }
   __syncthreads();
-  if (!s_last) return false;
-  __threadfence();
-  return true;
+  return s_last != 0;
 }
 template <int TM>
 __device__ __forceinline__ void h2_splitk_reduce(const ConvK& p, int m0, int nb, int li) {
   const bool vec = (p.Cout & 3) == 0 && (p.out_stride & 3) == 0 && (!p.res || (p.res_stride & 3) == 0);
+  const size_t zs = (size_t)p.M * p.Npad;
 #pragma unroll 1
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + i * 32 + li;
     if (m >= p.M) continue;
     const size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < 4; ++j) {
       const int n = nb + 8 * j;
       if (n >= p.Cout) continue;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      for (int z = 0; z < p.splitk; ++z) v = v + *(const f32x4*)(p.ws + ((size_t)z * p.M + m) * p.Npad + n);
+      const float* src = p.ws + (size_t)m * p.Npad + n;
+      int z = 0;
+      for (; z + 4 <= p.splitk; z += 4) {           // four slabs in flight, summed in slice order
+        const f32x4 a0 = ld_agent(src + (size_t)z * zs), a1 = ld_agent(src + (size_t)(z + 1) * zs);
+        const f32x4 a2 = ld_agent(src + (size_t)(z + 2) * zs), a3 = ld_agent(src + (size_t)(z + 3) * zs);
+        v = v + a0; v = v + a1; v = v + a2; v = v + a3;
+      }
+      for (; z < p.splitk; ++z) v = v + ld_agent(src + (size_t)z * zs);
       if (vec) h2_epilogue_vec(p, orow, n, v);
       else {
 #pragma unroll
@@ -372,7 +393,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (TERMS == 3 ? hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo : hh[i][4 * j + e] * alpha);
-        *(f32x4*)(o + 8 * j) = v;
+        if (p.tile_sem) st_agent(o + 8 * j, v);
+        else *(f32x4*)(o + 8 * j) = v;
       }
     }
     if (p.tile_sem && h2_splitk_arrive(p, mtile * p.ntiles + nt)) h2_splitk_reduce<TM>(p, m0, nb, li);
@@ -600,7 +622,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (TERMS == 3 ? hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo : hh[i][4 * j + e] * alpha);
-        *(f32x4*)(o + 8 * j) = v;
+        if (p.tile_sem) st_agent(o + 8 * j, v);
+        else *(f32x4*)(o + 8 * j) = v;
       }
     }
     if (p.tile_sem && h2_splitk_arrive(p, mtile * p.ntiles + nt)) h2_splitk_reduce<TM>(p, m0, nb, li);
@@ -672,7 +695,7 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   k.alpha = d->alpha != 0.f ? d->alpha : 1.f;
   k.M_dev = d->M_dev;
   k.out_h2 = d->out_h2;
-  COOCC_CHECK_ARG(!d->out_h2 || (d->Cout % 4 == 0 && d->out_stride % 32 == 0 && !d->out_rows && (d->splitk == 1 || d->splitk == 0 || d->tile_sem)),
+  COOCC_CHECK_ARG(!d->out_h2 || (d->Cout % 4 == 0 && d->out_stride % 32 == 0 && !d->out_rows),
                   "conv_fwd: out_h2 needs Cout % 4 == 0, out_stride % 32 == 0, no row scatter");
   k.out_h2t = d->out_h2_twin;
   COOCC_CHECK_ARG(!d->out_h2_twin || (!one && d->Cout % 32 == 0 && !d->out_rows && ((uintptr_t)d->out_h2_twin & 15) == 0 && (d->out_stride & 3) == 0 &&
@@ -693,8 +716,9 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   const int ngroups = k.total_iters / gsz;
   if (splitk <= 0) {
     splitk = 1;
-    // without arrival counters the reduction is a second launch (k_conv_reduce) whose epilogue has no H2 / f16 / twin outputs
-    const bool second_pass_ok = !d->out_h2 && !d->out16 && !d->out_h2_twin;
+    // without arrival counters the reduction is a second launch; its vector form (k_conv_reduce4) writes the H2 / f16 / twin outputs
+    const bool vec4 = (d->Cout & 3) == 0 && (d->out_stride & 3) == 0 && (!d->res || (d->res_stride & 3) == 0) && (((uintptr_t)d->out) & 15) == 0;
+    const bool second_pass_ok = vec4 || (!d->out_h2 && !d->out16 && !d->out_h2_twin);
     if (blocks < 256 && ngroups >= 8 && d->ws && !d->M_dev && (d->tile_sem ? true : (!d->out_rows && second_pass_ok))) {
       splitk = (int)(512 / blocks);
       if (splitk > ngroups / 4) splitk = ngroups / 4;
@@ -708,8 +732,9 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   k.splitk = (k.total_iters + k.iters_per_split - 1) / k.iters_per_split;
   COOCC_CHECK_ARG(k.splitk == 1 || (d->ws && !d->M_dev && (long long)k.splitk * d->M * k.Npad <= d->ws_floats),
                   "conv_fwd: split-K workspace too small (or split-K with a device row count)");
-  COOCC_CHECK_ARG(k.splitk == 1 || d->tile_sem || (!d->out_h2 && !d->out16 && !d->out_h2_twin),
-                  "conv_fwd: split-K with an H2 / f16 output needs tile_sem (the in-kernel reduction)");
+  COOCC_CHECK_ARG(k.splitk == 1 || d->tile_sem || (!d->out_h2 && !d->out16 && !d->out_h2_twin) ||
+                      ((d->Cout & 3) == 0 && (d->out_stride & 3) == 0 && (!d->res || (d->res_stride & 3) == 0) && (((uintptr_t)d->out) & 15) == 0),
+                  "conv_fwd: split-K with an H2 / f16 output needs 16-byte aligned rows (Cout, strides % 4 == 0)");
   COOCC_CHECK_ARG(k.splitk == 1 || !d->tile_sem || (long long)k.mtiles * k.ntiles <= d->tile_sem_ints,
                   "conv_fwd: tile_sem holds fewer counters than the launch has output tiles");
   dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);

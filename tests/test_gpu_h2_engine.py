@@ -3,8 +3,9 @@
 * H2 twins written by producer epilogues (GEMM, Winograd output transform, trilinear upsample-add, OccHead mix) are
   bit-identical to a conversion pass over the fp32 rows they accompany -- so the consumer computes the same bits whether its
   operand came from the producer or from ``coocc_rows_to_h2``;
-* the in-kernel split-K reduction (arrival counters, last workgroup sums the slabs in slice order) is bit-identical to the
-  two-launch form (``k_conv_reduce``) and leaves its counters at zero;
+* the in-kernel split-K reduction (arrival counters, last workgroup sums the slabs in slice order; ``COOCC_INKERNEL_REDUCE=1`` --
+  measured slower than the two-launch form and off by default) is bit-identical to the two-launch form
+  (``k_conv_reduce``, which writes the H2 twin itself) and leaves its counters at zero;
 * the f16 range guard: activations that leave the operand range raise instead of silently producing inf / NaN, and the
   documented escape hatch (``COOCC_CONV_ENGINE=f32``) computes the same layer correctly.
 """
@@ -46,12 +47,12 @@ def test_producer_h2_twin_equals_conversion_pass(dev, monkeypatch, Cin, Cout, gr
     x = torch.randn(1, Cin, X, Y, Z, generator=g)
     w = torch.randn(Cout, Cin, k, k, k, generator=g) * (2.0 / (Cin * k ** 3)) ** 0.5
     bn = bn_like(Cout, g)
-    pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=k, stride=stride, pad=k // 2)
     ref = bn(F.conv3d(x, w, stride=stride, padding=k // 2))
     res = torch.randn(ref.shape, generator=g) if use_res else None
     if use_res:
         ref = ref + res
     ref = F.relu(ref).detach()
+    pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=k, stride=stride, pad=k // 2)      # (moves bn to the device)
     nxt = consumer(Cout, dev)
     assert core.route(1, *ref.shape[2:], nxt) == "h2"
     rr = rows_of(res, dev) if use_res else None
@@ -95,6 +96,7 @@ def test_inkernel_splitk_reduction_equals_two_launch_form(dev, monkeypatch, Cin,
     x = torch.randn(1, Cin, X, Y, Z, generator=g)
     w = torch.randn(Cout, Cin, k, k, k, generator=g) * (2.0 / (Cin * k ** 3)) ** 0.5
     bn = bn_like(Cout, g)
+    ref = F.relu(bn(F.conv3d(x, w, stride=stride, padding=k // 2))).detach()
     pc = core.PackedConv(w.to(dev), bn=bn.to(dev), ksize=k, stride=stride, pad=k // 2)
     xr = rows_of(x, dev)
     outs = []
@@ -104,7 +106,6 @@ def test_inkernel_splitk_reduction_equals_two_launch_form(dev, monkeypatch, Cin,
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert int(core.tile_sem(dev).abs().sum()) == 0, "arrival counters must be left at zero"
-    ref = F.relu(bn(F.conv3d(x, w, stride=stride, padding=k // 2))).detach()
     assert_close(core.Rows(outs[0], 1, *ref.shape[2:], Cout).as_ncdhw().cpu(), ref, what="in-kernel split-K")
 
 

@@ -13,16 +13,13 @@ coocc_multi_r50_256x704 (configs[1]): fused grid 100x100x8 x 128 ch, final occup
 200x200x16, 6 cams with 16x44 feature maps -> 6x256x704 maps, knum=2, random weights, fp32.
 Weak scaling: every rank processes its own samples (the reference's samples_per_gpu=1 DP).
 
-The serving loop is the PRODUCT's (co_occ_amd.serving.ServingPipeline, reached through ``COOCC_Ray.serving()``): six sample
-slots; pooling + index search of the next samples prefetched eagerly by helper threads (one C-ABI call per search); the dense
-stage of a sample is ONE captured hipGraph launch on one of three dense streams; a new frame's dense-stage inputs are copied
-into its slot's static tensors.  ``--api simple_test`` times the reference's own per-sample call instead (synchronous, one
-slot: the search is then on the critical path); ``--graph 0`` is the eager two-stream pipeline of round 2 (class Pipeline).
-Outputs are checked bit for bit against sequential eager calls in tests/test_gpu_serving.py / tests/test_gpu_bench.py.
+The serving loop (class Pipeline): pooling + index search of the next sample(s) prefetched on high-priority streams by helper
+threads; one or two samples' dense stages in flight (chosen per box by an untimed probe unless --streams says so).  Its outputs
+are checked bit for bit against sequential calls in tests/test_gpu_bench.py.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the Winograd-domain split-f16 GEMM k_gemm_h2z, priced against
-the dense f16 MFMA peak; per-kernel HIP events from an eager pass right after the timed region, *_alone = nothing else on the
-GPU), `roofline_pool`, `roofline_render[_r101]` and, at N=1, `cpu_baseline` (the oracle's CPU restatement timed on this host).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: fp32-MFMA implicit-GEMM conv; with two samples in flight the
+in-pipeline figure and, as *_alone / roofline_isolated, the one-sample figure), `roofline_pool`, `roofline_render[_r101]` and,
+at N=1, `cpu_baseline` (the oracle's CPU restatement timed on this host).
 """
 import argparse
 import json
@@ -37,7 +34,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import torch
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import co_occ_amd as pkg  # noqa: E402
@@ -47,9 +44,8 @@ from co_occ_amd import _lib, core  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, fp32-input MFMA (spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA (spec; 2:1-sparse figures are not used)
-MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 MFMA: the same rate as bf16 on gfx950 (v_mfma_f32_32x32x16_{f16,bf16})
 HBM_PEAK_GBS = 8000.0          # HBM3E spec
-TRAFFIC_FILE = "r4_traffic.json"
+TRAFFIC_FILE = "r3_traffic.json"
 
 
 def make_inputs(cfgname, seed, dev, model):
@@ -311,15 +307,6 @@ def cpu_baseline(sd, s, cfgname, with_pool, runs=3):
                 all_runs_seconds=[round(r["total"], 3) for r in runs_])
 
 
-def _traffic(key, cfg):
-    """HBM bytes per launch / call from the committed PMC passes (profiles/TRAFFIC_FILE, tools/make_traffic.py), or None."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))[key]
-        return (d[cfg] if cfg in d else d)["bytes_per_launch"]
-    except Exception:
-        return None
-
-
 def rooflines(ksum, nsteps, args, rank, table):
     """roofline objects from a KernelTimer summary: dominant conv instantiation (largest summed HIP-event time), every
     conv launch together (per MFMA dtype), the pooling call, the render pair."""
@@ -364,7 +351,7 @@ def rooflines(ksum, nsteps, args, rank, table):
             symbol = {"k_conv2<160,wg> wino": "k_conv2<160, 2, true, 2, false>", "k_conv2p wino": "k_conv2p<true, false>",
                       "k_conv2<128,wg> wino": "k_conv2<128, 1, true, 3, false>", "k_gemm_h2z wino": "k_gemm_h2z<3, false>",
                       "k_gemm_h2z direct": "k_gemm_h2z<*, true>", "k_gemm_h2w": "k_gemm_h2w<false>"}.get(dom, dom)     # name in the rocprofv3 trace
-            peak = MFMA_F16_PEAK_TFLOPS if (h2 or h1) else (MFMA_BF16_PEAK_TFLOPS if dom.startswith("k_conv_bf16") else MFMA_F32_PEAK_TFLOPS)
+            peak = MFMA_BF16_PEAK_TFLOPS if (dom.startswith("k_conv_bf16") or h2 or h1) else MFMA_F32_PEAK_TFLOPS
             roof = dict(bound="mfma", kernel=dom, symbol=symbol, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
                         frac=round(ach / peak, 4), traffic=traffic,
                         traffic_source=("profiles/%s (rocprofv3 --pmc passes of this command, replayed: HBM counters cannot be "
@@ -381,8 +368,8 @@ def rooflines(ksum, nsteps, args, rank, table):
                     ("roofline_all_convs", lambda k: k.startswith("k_conv") and not k.startswith("k_conv_bf16"), MFMA_F32_PEAK_TFLOPS, 1.0,
                      "every fp32-MFMA k_conv* launch"),
                     ("roofline_bf16_convs", lambda k: k.startswith("k_conv_bf16"), MFMA_BF16_PEAK_TFLOPS, 1.0, "every k_conv_bf16 launch"),
-                    ("roofline_f16_convs", lambda k: k.startswith("k_gemm_h1"), MFMA_F16_PEAK_TFLOPS, 1.0, "every one-term f16 k_gemm_h1* launch"),
-                    ("roofline_h2_gemms", lambda k: k.startswith("k_gemm_h2"), MFMA_F16_PEAK_TFLOPS, 3.0,
+                    ("roofline_f16_convs", lambda k: k.startswith("k_gemm_h1"), MFMA_BF16_PEAK_TFLOPS, 1.0, "every one-term f16 k_gemm_h1* launch"),
+                    ("roofline_h2_gemms", lambda k: k.startswith("k_gemm_h2"), MFMA_BF16_PEAK_TFLOPS, 3.0,
                      "every split-f16 k_gemm_h2* launch (3 f16 MFMAs per product counted)")):
                 grp = [v2 for k2, v2 in convs.items() if sel(k2)]
                 if not grp:
@@ -395,7 +382,7 @@ def rooflines(ksum, nsteps, args, rank, table):
             ach = v["work"] / (v["ms"] * 1e-3) / 1e9
             extra["roofline_pool"] = dict(bound="hbm", kernel="coocc_lift_splat_cams (keys + binning + per-voxel sums)",
                                           achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                                          traffic=_traffic("coocc_lift_splat_cams", args.config), algorithmic_bytes=int(v["work"] / v["launches"]),
+                                          traffic=None, algorithmic_bytes=int(v["work"] / v["launches"]),
                                           avg_ms_per_step=round(v["ms"] / v["launches"], 4),
                                           note="fused Lift (x) Splat, in the timed step (on the prefetch stream)")
         rk = [ksum[k] for k in ("k_render_nearest+k_upsample_maps",) if k in ksum]
@@ -558,16 +545,108 @@ class Pipeline:
             st.synchronize()
 
 
-def frame_of(s):
-    """The frame dict ``co_occ_amd.serving.ServingPipeline.submit`` takes, from one synthetic sample (``make_inputs``)."""
-    return dict(depth=s["depth"], ctx=s["ctx"], cams=s["cams"], pts=s["pts"], img_feats=s["img_feats"], transform=s["transform"])
+class GraphPipeline:
+    """The default serving loop: the dense stage of every sample is ONE hipGraphLaunch (co_occ_amd.graph.DenseGraph, captured
+    once per slot before the timed region), issued by the calling thread on one dense stream; pooling + index search of the
+    next ``nslots - 1`` samples run eagerly on high-priority prefetch streams (helper threads: the search has one
+    device->host read of the two voxel counts).  Sample i lives in slot i mod nslots (its own synthetic inputs, resident in
+    HBM); a slot is rewritten only after the replay that read it has finished (event)."""
 
+    def __init__(self, model, samples, dev, world=1, ndense=1, ahead=0):
+        from concurrent.futures import ThreadPoolExecutor
+        from co_occ_amd import graph as cg
+        self.model, self.samples, self.dev, self.world = model, samples, dev, world
+        self.n = len(samples)
+        self.ndense = max(1, min(ndense, self.n - 1))
+        X, Y, Z = samples[0]["pts"].shape[2:]
+        self.render = X >= 100 and Y >= 100 and Z >= 8
+        # slot k replays on dense stream k mod ndense (graphs own the per-stream scratch of the stream they were captured on)
+        self.dense_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ndense)]
+        prio = int(os.environ.get("COOCC_SEARCH_PRIO", "0"))    # high-priority search streams slow the dense graphs by 40 % (measured)
+        self.search_streams = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(self.n)]
+        self.slots = [cg.make_slot(model, (X, Y, Z), dev) for _ in range(self.n)]
+        self.done = [None] * self.n
+        # searches submitted ahead of the dense stage: at most slots - dense streams (a slot is rewritten only after its replay
+        # finished); --ahead limits it further (searches in flight contend with each other and with the dense graphs)
+        self.ahead = self.n - self.ndense if ahead <= 0 else max(1, min(ahead, self.n - self.ndense))
+        self.tpool = ThreadPoolExecutor(max(1, self.ahead))
+        self.cg = cg
+        self.graphs = []
+        self.dense_ev = []
+        self.fallbacks = 0
+        # capture: every slot once, after an eager search filled it
+        for k in range(self.n):
+            sr = self.do_search(k)
+            ds = self.dense_streams[k % self.ndense]
+            ds.wait_event(sr.done_main)
+            if sr.done_side is not None:
+                ds.wait_event(sr.done_side)
+            self.graphs.append(cg.DenseGraph(model, self.slots[k], samples[k], ds, render=self.render).capture())
+        torch.cuda.synchronize()
 
-def simple_test_kwargs(s):
-    """The same sample as keyword arguments of the reference's per-sample call ``COOCC_Ray.simple_test`` (coocc_ray.py:520):
-    the upstream encoders' outputs are handed over as ``precomputed`` (they are outside the hot path)."""
-    return dict(img=None, points=None, precomputed=dict(depth=s["depth"], ctx=s["ctx"], cams=s["cams"], pts_voxel_feats=s["pts"],
-                                                        img_feats=s["img_feats"], transform=s["transform"]))
+    def do_search(self, i):
+        k = i % self.n
+        s = self.samples[k]
+        torch.cuda.set_device(self.dev)
+        st = self.search_streams[k]
+        t0 = time.perf_counter()
+        with torch.cuda.stream(st), torch.no_grad():
+            if self.done[k] is not None:
+                st.wait_event(self.done[k])             # the replay that read this slot last
+            if TRACE[0] is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            sr = self.cg.search_into_slot(self.model, self.slots[k], s["depth"], s["ctx"], s["cams"], s["pts"])
+            if TRACE[0] is not None:
+                st.wait_event(sr.done_side)
+                e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                TRACE[0].append(("search", i, e0, e1, time.perf_counter() - t0))
+            return sr
+
+    def run(self, nsteps, collect=None, time_dense=False):
+        futs = {}
+        ahead = self.ahead
+
+        def submit(i):
+            if i < nsteps:
+                futs[i] = self.tpool.submit(self.do_search, i)
+        for i in range(min(ahead, nsteps)):
+            submit(i)
+        with torch.no_grad():
+            for i in range(nsteps):
+                k = i % self.n
+                tw = time.perf_counter()
+                sr = futs.pop(i).result()
+                if TRACE[0] is not None:
+                    TRACE[0].append(("wait", i, time.perf_counter() - tw))
+                ds = self.dense_streams[k % self.ndense]
+                ds.wait_event(sr.done_main)
+                if sr.done_side is not None:
+                    ds.wait_event(sr.done_side)
+                with torch.cuda.stream(ds):
+                    if time_dense:
+                        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                    if self.graphs[k].fits(sr.counts):
+                        out = self.graphs[k].replay()
+                    else:           # a sweep denser than the captured capacity: eager dense stage for this sample
+                        self.fallbacks += 1
+                        s = self.samples[k]
+                        vf = self.model.occ_fuser(self.slots[k].img_rows().as_ncdhw(), s["pts"], search=sr)
+                        out = self.model.decode(vf, s["gemo"], s["img_feats"], s["transform"], self.render)
+                    if time_dense:
+                        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                        self.dense_ev.append((e0, e1))
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self.done[k] = ev
+                    if collect is not None:
+                        collect(i, out)
+                    if self.world > 1:
+                        _gather(out)
+                submit(i + ahead)       # its slot's last replay (sample i + ahead - n) has been issued: the search waits on its event
+            with torch.cuda.stream(self.dense_streams[0]):
+                drain_gathers()
+        for ds in self.dense_streams:
+            ds.synchronize()
 
 
 def main():
@@ -599,14 +678,9 @@ def main():
                     help="start the step from an already-pooled camera volume (round-1 definition) instead of the lifted "
                          "depth/context pair (SURVEY.md 8d: 'lifted features + sweep volume -> logits')")
     ap.add_argument("--graph", type=int, default=1,
-                    help="1 (default): the dense stage of a sample is one captured hipGraph launch (co_occ_amd.serving.ServingPipeline); 0: every launch "
+                    help="1 (default): the dense stage of a sample is one captured hipGraph launch (GraphPipeline); 0: every launch "
                          "issued from Python (Pipeline, --streams)")
-    ap.add_argument("--ahead", type=int, default=0, help="--graph 1: searches submitted ahead of the dense stage (0: slots - dense streams; "
-                                                         "with more than one rank: 1 -- one helper thread per rank, so an 8-rank node does not run 32 host threads)")
-    ap.add_argument("--api", default="serving", choices=["serving", "simple_test"],
-                    help="serving (default): COOCC_Ray.serving() -- co_occ_amd.serving.ServingPipeline, --slots samples in flight.  "
-                         "simple_test: the reference's per-sample call COOCC_Ray.simple_test(precomputed=...) (coocc_ray.py:520), "
-                         "synchronous, dense stage = one captured hipGraph launch (one slot)")
+    ap.add_argument("--ahead", type=int, default=0, help="--graph 1: searches submitted ahead of the dense stage (0: slots - dense streams)")
     ap.add_argument("--slots", type=int, default=6, help="--graph 1: samples in flight (1 in its dense stage + slots-1 in the prefetched search)")
     ap.add_argument("--shard", default="samples", choices=["samples", "rays"],
                     help="samples (default): one scene per GPU, weak scaling (configs[3]).  rays: ONE scene over all ranks -- K / G / C "
@@ -675,47 +749,18 @@ def main():
     run(2 * S, False)
     probe = None
     gp = None
-    frames = [frame_of(x) for x in samples]
-    if world > 1 and args.ahead <= 0:
-        args.ahead = 1          # one search helper thread per rank: 8 ranks x (1 issuing + 1 helper) threads on a CPU-capped node
-    if args.graph and WITH_POOL[0] and args.api == "serving":
+    if args.graph and WITH_POOL[0]:
         try:
-            gp = model.serving(frames[0], slots=max(2, args.slots), dense_streams=max(1, args.streams if not auto_streams else 3),
-                               ahead=args.ahead, search_priority=int(os.environ.get("COOCC_SEARCH_PRIO", "0")),
-                               after_replay=(_gather if world > 1 else None))
-            gp.run(frames, 2 * gp.n)
+            gp = GraphPipeline(model, samples[:max(2, args.slots)], dev, world, ndense=max(1, args.streams if not auto_streams else 3),
+                               ahead=args.ahead)
+            gp.run(2 * gp.n)
         except Exception as e:           # configurations the static form does not cover run the eager pipeline
             print("bench: hipGraph pipeline unavailable for this configuration (%s: %s); eager pipeline" % (type(e).__name__, e), file=sys.stderr)
             gp = None
     if gp is not None:
         auto_streams, S = False, 1
         run_eager = run
-
-        def run(n, timed, S=1):
-            gp.time_dense = timed
-            gp.run(frames, n)
-            with torch.cuda.stream(gp.dense_streams[0]):
-                drain_gathers()
-            for ds_ in gp.dense_streams:
-                ds_.synchronize()
-    st_api = None
-    if args.api == "simple_test":
-        # the reference's per-sample call: every step is one synchronous COOCC_Ray.simple_test (one-slot captured graph)
-        model.test_rendering = True
-        st_kw = [simple_test_kwargs(x) for x in samples]
-        auto_streams, S = False, 1
-        run_eager = run
-
-        def run(n, timed, S=1):
-            with torch.no_grad():
-                for i in range(n):
-                    o = model.simple_test(**st_kw[i % len(st_kw)])
-                    if world > 1:
-                        _gather(o)
-            drain_gathers()
-            torch.cuda.synchronize()
-        run(3, False)
-        st_api = dict(graph=model._pipe1 is not None, eager_reason=(model.graph_unavailable or (None, None))[1])
+        run = (lambda n, timed, S=1: gp.run(n, time_dense=timed))
     if auto_streams:
         # One or two samples in flight?  Two win by ~8 % when the host keeps up (four Python threads share the GIL) and lose
         # that margin when neighbours saturate the box's CPUs (profiles/r2_streams_ab.txt) -- so ask the box: two untimed
@@ -735,8 +780,7 @@ def main():
                      chosen=S)
         run = (lambda n, timed, S=S: pipe.run(n, S))
     run(args.warmup, False)
-    graphish = gp is not None or st_api is not None       # the dense stage is a captured graph: no per-launch events inside the timed region
-    if not graphish:
+    if gp is None:
         core.TIMER.enabled = 0 if args.no_kernel_timing else (2 if args.kernel_table else 1)
     core.TIMER.only = ("k_conv", "k_gemm", "k_render_nearest", "k_lift_splat")      # what the roofline objects below need
     core.TIMER.reset()
@@ -753,6 +797,13 @@ def main():
     cdist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if args.diag and rank == 0 and TRACE[0] and gp is not None:
+        sl = [(e0.elapsed_time(e1), h) for t, i, e0, e1, h in [x for x in TRACE[0] if x[0] == "search"]]
+        wt = [x[2] for x in TRACE[0] if x[0] == "wait"]
+        print("diag(graph): search GPU latency mean %.2f ms max %.2f | search host mean %.2f ms | main thread waited for a search "
+              "result mean %.2f ms max %.2f" % (sum(a for a, _ in sl) / len(sl), max(a for a, _ in sl), 1e3 * sum(h for _, h in sl) / len(sl),
+                                                1e3 * sum(wt) / len(wt), 1e3 * max(wt)), file=sys.stderr)
+        TRACE[0] = None
     if args.diag and rank == 0 and TRACE[0]:
         for i, w, a, b, c, ev in sorted(TRACE[0]):
             print("trace: sample %2d stream %d  host: search ready %.1f  issue %.1f -> %.1f ms   GPU done %.1f ms" % (
@@ -767,19 +818,12 @@ def main():
 
     c = synth.CONFIGS[args.config]
     graph_info = None
-    if graphish:
-        if gp is not None:
-            dense_ms = [a.elapsed_time(b) for a, b in gp.dense_ev]
-            graph_info = dict(api="COOCC_Ray.serving() -> co_occ_amd.serving.ServingPipeline", slots=gp.n, dense_streams=gp.ndense,
-                              searches_ahead=gp.ahead, eager_fallbacks=gp.fallbacks,
-                              dense_stage_ms=round(sum(dense_ms) / max(1, len(dense_ms)), 3),
-                              note="dense stage = ONE hipGraphLaunch per sample (HIP events around every replay inside the timed region: "
-                                   "dense_stage_ms); pooling + index search eager on prefetch streams; a new frame's image features and "
-                                   "camera matrices are copied into the slot's static tensors")
-        else:
-            graph_info = dict(api="COOCC_Ray.simple_test(precomputed=...) -- the reference's per-sample call, synchronous", slots=1,
-                              captured_graph=st_api["graph"], eager_reason=st_api["eager_reason"],
-                              eager_fallbacks=(model._pipe1[1].fallbacks if model._pipe1 is not None else None))
+    if gp is not None:
+        dense_ms = [a.elapsed_time(b) for a, b in gp.dense_ev]
+        graph_info = dict(slots=gp.n, eager_fallbacks=gp.fallbacks,
+                          dense_stage_ms=round(sum(dense_ms) / max(1, len(dense_ms)), 3),
+                          note="dense stage = ONE hipGraphLaunch per sample (HIP events around every replay inside the timed region: "
+                               "dense_stage_ms); pooling + index search eager on prefetch streams")
         if not args.no_kernel_timing:
             # per-kernel durations cannot be taken inside a graph launch: an eager pass of the same step (one sample in flight,
             # search prefetched) with HIP events around every launch, right after the timed region
@@ -790,8 +834,8 @@ def main():
             run_eager(n_e, False, S=1)
             torch.cuda.synchronize()
             core.TIMER.enabled = False
-    roof, extra = rooflines(core.TIMER.summary(), (max(8, min(20, args.steps)) if graphish else args.steps), args, rank, args.kernel_table)
-    if graphish and roof:
+    roof, extra = rooflines(core.TIMER.summary(), (max(8, min(20, args.steps)) if gp is not None else args.steps), args, rank, args.kernel_table)
+    if gp is not None and roof:
         roof["measured"] = ("HIP events around every launch of an eager pass of the same steps right after the timed region "
                             "(inside it the dense stage is one hipGraphLaunch per sample); the next sample's pooling + index search run "
                             "beside it as in the timed region")
@@ -810,7 +854,7 @@ def main():
                 roof.update(achieved_alone=r_al["achieved"], frac_alone=r_al["frac"], avg_launch_ms_alone=r_al["avg_launch_ms"],
                             note="achieved / frac: launches that share the CUs with the prefetched search of the next sample (as in the "
                                  "timed pipeline); *_alone: the same launches with nothing else on the GPU (6 samples, no prefetch)")
-    if S > 1 and not graphish and not args.no_kernel_timing:
+    if S > 1 and gp is None and not args.no_kernel_timing:
         # Kernel durations inside the S-stream pipeline include the contention between the samples in flight (that is the
         # point of it: one sample's low-occupancy tail runs under the other's GEMMs).  A short pass of the same pipeline with ONE
         # sample in flight (the next sample's pooling + search still prefetched) gives each kernel's own rate next to it.
@@ -840,17 +884,15 @@ def main():
                 unit="samples/s", n_gpus=world, world_size_seen_by_backend=seen_world, backend=backend_name, steps=args.steps,
                 warmup=args.warmup,
                 ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True, scaling=("strong" if SHARD[0] else "weak"), vs_baseline=None,
-                dtype=("f32 (split-f16 products, fp32 accumulate)" if (args.dtype == "f32" and core.CONV_ENGINE == "h2") else args.dtype),
-                data="synthetic",
+                dtype=args.dtype, data="synthetic",
                 config=dict(workload="coocc_multi_r50_256x704 hot path" if args.config == "r50" else args.config,
                             fused_grid="x".join(map(str, c["grid"])) + "x%d" % c["C"],
                             occupancy_grid="x".join(str(v) for v in c.get("final_occ_size", [2 * g for g in c["grid"]])), cams=c["ncam"],
                             render_maps="%dx%dx%d" % (c["ncam"], c["fmap"][0] * 16, c["fmap"][1] * 16), knum=c["knum"],
                             parallelism=("ray-shard x%d (ONE scene: K/G/C replicated on every rank, render rays sharded, all-gather of the "
                                          "map chunks)" % world if SHARD[0] else "dp%d (1 scene per GPU, RCCL all-gather of maps)" % world),
-                            samples_in_flight=(gp.n if gp is not None else S), prefetched_search=bool(tpool) and st_api is None, weights="random",
-                            pipeline=("hipGraph dense stage + eager prefetched search" if gp is not None else
-                                      ("simple_test per sample (synchronous), hipGraph dense stage" if st_api is not None else "eager (Python-issued launches)")),
+                            samples_in_flight=(gp.n if gp is not None else S), prefetched_search=bool(tpool), weights="random",
+                            pipeline=("hipGraph dense stage + eager prefetched search" if gp is not None else "eager (Python-issued launches)"),
                             conv_engine=(core.CONV_ENGINE if args.dtype == "f32" else args.dtype),
                             step_starts_from=("lifted depth/context pair (fused lift-splat pooling inside the step)" if WITH_POOL[0]
                                               else "pooled camera volume")),

@@ -14,13 +14,15 @@ timeout 300 python bench.py --steps 40 --warmup 3 --no-cpu-baseline > $O/bench.j
 timeout 300 python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-kernel-timing > $O/bench2.json 2>> $O/bench.err
 timeout 300 python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-kernel-timing --api simple_test > $O/bench_simple_test.json 2> $O/bench_simple_test.err
 COOCC_INKERNEL_REDUCE=0 timeout 300 python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-kernel-timing > $O/bench_reduce2launch.json 2>> $O/bench.err
+[ -f tools/_bench_r3.py ] && timeout 300 python tools/_bench_r3.py --steps 40 --warmup 3 --no-cpu-baseline --no-kernel-timing > $O/bench_r3pipe.json 2>> $O/bench.err
+timeout 300 python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-kernel-timing > $O/bench3.json 2>> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/gp
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/gp -o gp -- python $R/tools/graph_probe.py > $O/graph_probe.txt 2>&1
 python $R/tools/graph_trace.py /tmp/gp/gp_kernel_trace.csv --seq > $O/dense_stage_kernels.txt 2>&1
 timeout 300 python $R/tools/dense_concurrency.py 2>&1 | grep -v amdgpu.ids > $O/dense_concurrency.txt
 cd $R
-for f in bench bench2 bench_simple_test bench_reduce2launch; do python - <<PY
+for f in bench bench2 bench3 bench_simple_test bench_reduce2launch bench_r3pipe; do python - <<PY
 import json
 try:
     d = json.load(open("$O/$f.json"))
@@ -31,4 +33,4 @@ PY
 done
 head -45 $O/dense_stage_kernels.txt
 cat $O/dense_concurrency.txt
-tail -5 $O/bench.err $O/bench_simple_test.err
+tail -n 5 $O/bench.err; tail -n 5 $O/bench_simple_test.err

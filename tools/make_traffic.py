@@ -17,9 +17,11 @@ ALIASES = {   # bench.py region name -> kernel symbol prefix in the rocprofv3 tr
     "k_conv2<160>": "void k_conv2<160, 2, false, 2, false>",
     "k_conv2p": "void k_conv2p<false, true>",
     "k_conv_bf16": "k_conv_bf16",
-    "k_gemm_h2z wino": "void k_gemm_h2z<3, false>",
-    "k_gemm_h2z direct": "void k_gemm_h2z<3, true>",
-    "k_gemm_h2w": "void k_gemm_h2w<false>",
+    # the trace carries all template arguments ("void k_gemm_h2z<3, false, 0, 3>"): prefixes end BEFORE the next argument
+    "k_gemm_h2z wino": "void k_gemm_h2z<3, false,",
+    "k_gemm_h2z direct": "void k_gemm_h2z<3, true,",
+    "k_gemm_h2w": "void k_gemm_h2w<false,",
+    "k_gemm_h2w table": "void k_gemm_h2w<true,",
 }
 
 
@@ -56,6 +58,11 @@ def main():
     if rays and ups:
         out["k_render_nearest+k_upsample_maps"] = {cfg: dict(bytes_per_launch=rays["bytes_per_launch"] + ups["bytes_per_launch"],
                                                              rays=rays, upsample=ups)}
+    # the pooling call (roofline_pool): its four launches together, per call
+    parts = [per_launch("void " + sym) or per_launch(sym) for sym in ("k_keys_hist", "k_scan_local", "k_csr_fill", "k_pool_sum_csr<true>")]
+    if all(parts):
+        out["coocc_lift_splat_cams"] = {cfg: dict(bytes_per_launch=sum(d["bytes_per_launch"] for d in parts),
+                                                   keys_hist=parts[0], scan_local=parts[1], csr_fill=parts[2], pool_sum_csr=parts[3])}
     for sym in ("k_wino_in_h2<6>", "k_wino_in_h2<4>", "k_rows_to_h2", "k_wino_in<6>", "k_wino_out<6>", "k_wino_in<4>", "k_wino_out<4>", "k_pool_sum_csr<true>", "k_key_hist", "k_fuser_prepare_rows",
                 "k_fine_mlp<true>", "k_fine_sample_img_grp", "k_fine_sample_voxel_r2"):
         d = per_launch("void " + sym) or per_launch(sym)
