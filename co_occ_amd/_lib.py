@@ -129,6 +129,7 @@ SIGNATURES = {
     "coocc_wino_output": (I, [P, L, I, I, I, I, I, I, P, I, P, P, P, I, I, P]),
     "coocc_wino_output_ex": (I, [P, L, I, I, I, I, I, I, P, I, P, P, P, I, I, P, P]),
     "coocc_h2_overflow": (I, [I]),
+    "coocc_render_heads_h2": (I, [P, I, I, I, P, P, P, P, P, P, I, P, P, P, I, P]),
     "coocc_projection_params": (I, [P, P, P, P, P, P, I, P, P, P]),
     "coocc_occhead_mix_bwd": (I, [P, P, I, P, P, P, P, I, I, P]),
     "coocc_fine_sample_voxel_bwd": (I, [P, I, I, I, I, I, P, L, P, P, P]),

@@ -387,8 +387,8 @@ class COOCC_Ray(nn.Module):
             # capacity-sized fine outputs of the captured form -> the exact-size tensors the eager path returns
             n = int(out["fine_count"].item()) * cf ** 3
             out["output_voxels_fine"] = [res["output_voxels_fine"][0][:n].clone()]
-            xyz = res["output_coords_fine"][0]
-            out["output_coords_fine"] = [xyz.view(3, -1)[:, :n].clone()]
+            xyz = res["output_coords_fine"][0]                # the device-count kernels pack [3][n] at the start of the buffer
+            out["output_coords_fine"] = [xyz.reshape(-1)[:3 * n].view(3, n).clone()]
         return out
 
     def simple_test(self, img_metas=None, img=None, gt_depths=None, points=None, rescale=False, points_occ=None,

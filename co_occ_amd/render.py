@@ -85,23 +85,84 @@ class MLP(nn.Module):
         return y.view(*shp[:-1], self.output_dim)
 
 
-def voxel_table(sigma_head, rgb_head, vf):
+FUSED_HEADS = __import__("os").environ.get("COOCC_FUSED_RENDER_HEADS", "1") != "0"      # 0: layer-by-layer GEMM launches
+
+
+def _fused_heads_args(sigma_head, rgb_head):
+    """Device pointers of the one-launch render heads (csrc/mlp_h2.hip), or None when the heads do not have the shape it covers
+    (COOCC_Ray's: input 128, width 256, sigma depth 1, rgb depth 1..4)."""
+    import ctypes
+    heads = [sigma_head] + ([rgb_head] if rgb_head is not None else [])
+    if sigma_head.net_depth != 1 or any(h.input_dim != 128 or h.net_width != 256 for h in heads):
+        return None
+    if rgb_head is not None and not (1 <= rgb_head.net_depth <= 4 and rgb_head.output_dim == 3):
+        return None
+    if sigma_head.output_dim != 1:
+        return None
+    ps = sigma_head._packed()
+    keep = [ps[0].h2_pack(), ps[0].bias, sigma_head.output_layer.weight.detach().float().contiguous(),
+            sigma_head.output_layer.bias.detach().float().contiguous()]
+    args = dict(ws0=keep[0], bs0=keep[1], ws1=keep[2], bs1=keep[3], n=0, wr=None, br=None, wro=None, bro=None)
+    if rgb_head is not None:
+        pr = rgb_head._packed()
+        n = rgb_head.net_depth
+        packs = [pr[l].h2_pack() for l in range(n)]
+        biases = [pr[l].bias for l in range(n)]
+        wro = rgb_head.output_layer.weight.detach().float().contiguous()
+        bro = rgb_head.output_layer.bias.detach().float().contiguous()
+        keep += packs + biases + [wro, bro]
+        args.update(n=n, wr=(ctypes.c_void_p * n)(*[t.data_ptr() for t in packs]), br=(ctypes.c_void_p * n)(*[t.data_ptr() for t in biases]),
+                    wro=wro, bro=bro)
+    if any(t is None for t in keep) or any(t.data_ptr() % 16 for t in keep):
+        return None
+    args["keep"] = keep
+    return args
+
+
+def voxel_table(sigma_head, rgb_head, vf, activate=False):
     """R1 per voxel: [V,4] = (sigma_head(f), rgb_head(f)) raw outputs (pointwise heads, F5); ``rgb_head=None`` (depth-only
-    branch) leaves the colour columns zero."""
+    branch) leaves the colour columns zero.  ``activate``: the colour columns hold sigmoid(logit) (the form the ray kernel
+    reads; the backward path keeps raw logits)."""
     V = vf.t.shape[0]
     dev = vf.t.device
-    table = torch.empty(V, 4, device=dev, dtype=_F32) if rgb_head is not None else torch.zeros(V, 4, device=dev, dtype=_F32)
     from . import core
-    x = vf.t if (vf.coff == 0 and vf.stride == vf.C) else vf.t[:, vf.coff:vf.coff + vf.C].contiguous()
+    h2 = core.CONV_ENGINE == "h2" and core.CONV_DTYPE == "f32" and core.H2_DIRECT and V >= 8192 and vf.C % 32 == 0
+    whole = vf.coff == 0 and vf.stride == vf.C
+    if h2 and FUSED_HEADS and vf.C == 128 and not sigma_head.training:
+        # both heads in ONE launch (csrc/mlp_h2.hip): hidden activations stay in LDS, output layers are fp32 dot products
+        fa = _cached_fused(sigma_head, rgb_head)
+        if fa is not None:
+            xh = core.h2_rows(vf) if whole else core.rows_to_h2(vf.t[:, vf.coff:vf.coff + vf.C].contiguous(), vf.C, name="mlp_in")
+            table = torch.empty(V, 4, device=dev, dtype=_F32)
+            with core.TIMER.region("k_render_heads_h2", 2.0 * V * (128 * 256 * (2 if rgb_head is not None else 1) + 256 +
+                                                                 (256 * 256 * (rgb_head.net_depth - 1) + 768 if rgb_head is not None else 0))):
+                call("coocc_render_heads_h2", ptr(xh), V, 128, 256, ptr(fa["ws0"]), ptr(fa["bs0"]), ptr(fa["ws1"]), ptr(fa["bs1"]),
+                     fa["wr"], fa["br"], fa["n"], ptr(fa["wro"]), ptr(fa["bro"]), ptr(table), int(activate))
+            return table
+    table = torch.empty(V, 4, device=dev, dtype=_F32) if rgb_head is not None else torch.zeros(V, 4, device=dev, dtype=_F32)
+    x = vf.t if whole else vf.t[:, vf.coff:vf.coff + vf.C].contiguous()
     xh = None
-    if core.CONV_ENGINE == "h2" and core.CONV_DTYPE == "f32" and core.H2_DIRECT and V >= 8192 and vf.C % 32 == 0:
+    if h2:
         # one H2 copy of the voxel features for both heads: the twin con_enc.3's epilogue wrote (shared with the encoder's
         # input_proj), or one conversion pass
-        xh = core.h2_rows(vf) if (vf.coff == 0 and vf.stride == vf.C) else core.rows_to_h2(x, vf.C, name="mlp_in")
+        xh = core.h2_rows(vf) if whole else core.rows_to_h2(x, vf.C, name="mlp_in")
     sigma_head.forward_rows(x, out=table, out_coff=0, xh=xh)
     if rgb_head is not None:
         rgb_head.forward_rows(x, out=table, out_coff=1, xh=xh)
+    if activate:
+        call("coocc_render_activate_table", ptr(table), V)           # sigmoid(rgb) once per voxel, not per ray sample
     return table
+
+
+def _cached_fused(sigma_head, rgb_head):
+    """``_fused_heads_args`` cached on the sigma head, rebuilt when either head's weights change (their PackCache rebuilds)."""
+    ps = sigma_head._packed()
+    pr = rgb_head._packed() if rgb_head is not None else None
+    c = getattr(sigma_head, "_fused_cache", None)
+    if c is None or c[0] is not ps or c[1] is not pr:
+        c = (ps, pr, _fused_heads_args(sigma_head, rgb_head))
+        sigma_head._fused_cache = c
+    return c[2]
 
 
 def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16, depth_only=False, cam_geo=None):
@@ -126,13 +187,12 @@ def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16, depth_only=F
         g = gemo.reshape(N, D, H, W, 3).float().contiguous()
         dev = g.device
     assert vf.B == 1
-    table = voxel_table(sigma_head, rgb_head, vf)
+    table = voxel_table(sigma_head, rgb_head, vf, activate=True)      # sigmoid(rgb) once per voxel, not per ray sample
     zvals = torch.linspace(0, D, D, device=dev)
     maps = torch.empty(N, H, W, 4, device=dev, dtype=_F32)
     from .core import TIMER
     rgbs = torch.empty(N, H * scale, W * scale, 3, device=dev, dtype=_F32)
     depths = torch.empty(N, H * scale, W * scale, device=dev, dtype=_F32)
-    call("coocc_render_activate_table", ptr(table), vf.V)           # sigmoid(rgb) once per voxel, not per ray sample
     # algorithmic HBM bytes: geom read + table read + small maps written, then small maps read +
     # upsampled maps written.  The ray kernel is ALU-bound (alpha, scan), the x16 upsample store-bound: cameras are
     # processed in chunks and the upsample of chunk c runs on a side stream under the rays of chunk c+1.
@@ -209,8 +269,7 @@ def render_block_sharded(sigma_head, rgb_head, voxel_feats, gemo, scale=16, rank
             events.append(e)
 
     mark()
-    table = voxel_table(sigma_head, rgb_head, vf)
-    call("coocc_render_activate_table", ptr(table), vf.V)
+    table = voxel_table(sigma_head, rgb_head, vf, activate=True)
     zvals = torch.linspace(0, D, D, device=dev)
     lo, hi = cdist.shard_range(N * H, rank, world)
     g = gemo.reshape(N, D, H, W, 3).float()

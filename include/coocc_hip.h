@@ -290,6 +290,18 @@ int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int X, int Y, 
 int coocc_wino_output_ex(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, int tile, float* out,
                          int out_stride, const float* scale, const float* bias, const float* res, int res_stride,
                          int relu, void* out_h2_twin, void* stream);
+/* R1, both render heads in ONE launch (csrc/mlp_h2.hip): the per-voxel table [V][4] = (sigma, r, g, b) of
+ *   sigma = w_s1 . relu(W_s0 x + b_s0) + b_s1,   rgb = W_ro . relu(... relu(W_r0 x + b_r0) ...) + b_ro
+ * (P/utils/nerf_mlp.py:14-105 with COOCC_Ray's hyper-parameters, coocc_ray.py:111-113: input_dim 128, net_width 256, skip_layer
+ * None; evaluated at :583-590) on the split-f16 engine.  x_h2: H2 rows [V][128] (coocc_rows_to_h2 or a producer's twin);
+ * ws0_pack / wr_packs_host[l]: H2 weight packs of the hidden Linear layers (the mfma_dtype 3 layout of coocc_conv_desc with
+ * taps = 1); biases and the output layers' weights (ws1 [256], wr_out [3][256]) plain fp32.  n_rgb_hidden = 0: sigma head only
+ * (the depth-only branch :436-484; rgb columns are written as 0).  activate != 0: rgb columns hold sigmoid(logit), as
+ * coocc_render_activate_table would leave them.  Replaces six coocc_conv_fwd launches and their 330 MB of hidden activations. */
+int coocc_render_heads_h2(const void* x_h2, int V, int Cin, int width, const void* ws0_pack, const float* bs0,
+                          const float* ws1, const float* bs1, const void* const* wr_packs_host,
+                          const float* const* br_host, int n_rgb_hidden, const float* wr_out, const float* br_out,
+                          float* table, int activate, void* stream);
 /* Range guard of the split-f16 engine (resnet3d.py / fpn3d.py / occ_head.py convolutions are fp32 upstream and have no such
  * limit): every kernel that writes a 16-bit operand (H2 rows, f16 twins, the Winograd-domain V) raises a host-visible flag when a
  * value reaches half the f16 range (|v| >= 32768 after the writer's own scale; NaN counts).  Returns the flag (0 / 1) and clears it

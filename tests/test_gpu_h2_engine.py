@@ -149,3 +149,44 @@ def test_weight_pack_refuses_out_of_range_weights(dev):
     pc = core.PackedConv(w.to(dev), ksize=1)
     with pytest.raises(_lib.CooccError, match="f16"):
         pc.h2_pack()
+
+
+@pytest.mark.parametrize("V,depth", [(10007, 3), (8192, 1), (20000, 4)])
+def test_fused_render_heads_equal_layerwise_path_and_torch(dev, monkeypatch, V, depth):
+    """csrc/mlp_h2.hip (both render heads in one launch, hidden activations in LDS) against the layer-by-layer GEMM launches it
+    replaces and against torch's fp64 evaluation of the same MLPs (nerf_mlp.py:14-105); ragged last tile, 1..4 hidden layers,
+    the depth-only form, the in-kernel sigmoid."""
+    import numpy as np
+    from co_occ_amd import render as R
+    import co_occ_amd.synth as synth
+    g = torch.Generator().manual_seed(V + depth)
+    x = torch.randn(V, 128, generator=g)
+    x *= (torch.rand(V, 1, generator=g) < 0.8).float() * 3.0
+    sig, rgb = R.MLP(128, 1, net_depth=1, skip_layer=None), R.MLP(128, 3, net_depth=depth, skip_layer=None)
+    sig.load_state_dict(synth.random_state_dict(sig.state_dict(), 5))
+    rgb.load_state_dict(synth.random_state_dict(rgb.state_dict(), 6))
+    with torch.no_grad():
+        def ref(m, v):
+            v = v.double()
+            for l in m.hidden_layers:
+                v = torch.relu(torch.nn.functional.linear(v, l.weight.double(), l.bias.double()))
+            return torch.nn.functional.linear(v, m.output_layer.weight.double(), m.output_layer.bias.double())
+        want = torch.cat([ref(sig, x), ref(rgb, x)], 1)
+    sig, rgb = sig.to(dev).eval(), rgb.to(dev).eval()
+    vf = core.Rows(x.to(dev), 1, V, 1, 1, 128)
+    with torch.no_grad():
+        fused = R.voxel_table(sig, rgb, vf)
+        assert R._cached_fused(sig, rgb) is not None
+        act = R.voxel_table(sig, rgb, vf, activate=True)
+        donly = R.voxel_table(sig, None, vf)
+        monkeypatch.setattr(R, "FUSED_HEADS", False)
+        layer = R.voxel_table(sig, rgb, vf)
+        act_l = R.voxel_table(sig, rgb, vf, activate=True)
+    torch.cuda.synchronize()
+    core.check_h2_overflow()
+    assert_close(fused.cpu(), want, what="fused heads vs torch fp64")
+    assert_close(layer.cpu(), want, what="layer-by-layer heads vs torch fp64")
+    assert_close(fused.cpu(), layer.cpu(), tol=2e-5, what="fused vs layer-by-layer")
+    assert torch.equal(act[:, 0], fused[:, 0])
+    assert_close(act.cpu(), act_l.cpu(), tol=2e-5, what="activated tables")
+    assert torch.equal(donly[:, 0], fused[:, 0]) and float(donly[:, 1:].abs().max()) == 0.0
