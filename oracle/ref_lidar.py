@@ -8,12 +8,27 @@ bench cpu_baseline) -- the product never imports this.
 * ``vfe_mean``: mmdet3d/models/voxel_encoders/voxel_encoder.py:43-45.
 * ``sparse_encoder_forward``: P/coocc/voxel_encoder/sparse_lidar_enc.py:66-190 with spconv 2.3.6's SubMConv3d /
   SparseConv3d written as masked dense convolutions.  spconv 2.3.6 is an un-vendored dependency
-  (docs/requirements_ref.txt:166) and cannot be imported or built here, so no golden from the real library exists
-  ("parity unpinned" for this half); its semantics (SubM: outputs only at active inputs; SparseConv3d: an output is
-  active iff its receptive field holds an active input; ``dense()`` zero-fills) are CROSS-CHECKED against the spconv v1
-  rule-book code that mmdetection3d vendors (M/ops/spconv/include/spconv/geometry.h, ops.py; ``spconv_v1_*`` below,
-  tests/test_oracle.py::test_sparse_conv_rules_match_vendored_spconv_v1_rulebook).  What stays an assumption is the 2.x
-  weight layout [Cout, kd, kh, kw, Cin] (v1 stores [kd, kh, kw, Cin, Cout]).
+  (docs/requirements_ref.txt:166) and cannot be imported or built here (the vendored v1 sources need <cuda_runtime_api.h>
+  even for their CPU functors: M/ops/spconv/include/tensorview/tensorview.h:16), so no golden from the real library
+  exists ("parity unpinned" against the LIBRARY).  The layer semantics are instead pinned by three independent sources
+  that must all agree (tests/test_oracle.py, tests/test_gpu_lidar.py):
+    1. the published definitions -- Graham, Engelcke, van der Maaten, "3D Semantic Segmentation with Submanifold Sparse
+       Convolutional Networks" (CVPR 2018), sec. 3: a submanifold convolution SC(m, n, f, s = 1) computes an output ONLY at
+       sites whose CENTRE input is active and sums over the active inputs of its receptive field (the active set never
+       dilates); Yan, Mao, Li, "SECOND: Sparsely Embedded Convolutional Detection" (Sensors 2018), sec. 3.1: a regular
+       sparse convolution makes an output site active iff ANY input of its receptive field is active, via a rule book
+       R[k] = {(input row, output row)} per kernel offset; spconv's own docs (docs/USAGE.md: "SubMConv3d ... indices
+       unchanged"; SparseConv3d output shape (in + 2p - d(k-1) - 1)//s + 1; ``.dense()`` zero-fills the inactive sites;
+       docs/SPCONV_2_BREAKING_CHANGEs.md: 2.x weights are KRSC = [out_channels, *kernel_size, in_channels], v1 RSCK =
+       [*kernel_size, in_channels, out_channels]).  Both are cross-correlations (tap k reads input o*s - p + k);
+    2. the spconv v1 rule-book code mmdetection3d vendors (M/ops/spconv/include/spconv/geometry.h, ops.py), restated in
+       ``spconv_v1_*`` below (tests/test_oracle.py::test_sparse_conv_rules_match_vendored_spconv_v1_rulebook);
+    3. a HAND-COMPUTED known-answer vector on a 5x5x5 grid (tests/golden/sparse_rules_5x5x5.json: five active voxels,
+       two channels, weights 1 + kx + 3 ky + 9 kz in the 2.x layout; every output derived on paper in the file) that the
+       masked-dense form, the v1 rule book AND the HIP rule-table kernels all reproduce exactly
+       (test_sparse_conv_rules_match_hand_computed_fixture, test_sparse_layers_match_hand_computed_fixture).
+  Row ORDER of a SparseConv3d output is library-internal (hash-table order) and not observable: every consumer is
+  row-wise (BN1d / GroupNorm / ReLU) and the encoder ends in ``dense()``.
 """
 import numpy as np
 import torch
@@ -85,6 +100,23 @@ def _gn_active(x, mask, sd, prefix, groups=16):
     out = torch.zeros_like(x)
     out[0][:, idx[:, 0], idx[:, 1], idx[:, 2]] = rows.t()
     return out
+
+
+def subm_conv3d(feats, coors, shape_zyx, weight_2x, bias=None):
+    """One SubMConv3d(k3) in the masked-dense form used below: weight [Cout, kd, kh, kw, Cin] -> rows at ``coors`` (same order)."""
+    x, mask = _to_dense(torch.as_tensor(feats).float(), torch.as_tensor(coors), shape_zyx)
+    y = F.conv3d(x, torch.as_tensor(weight_2x).float().permute(0, 4, 1, 2, 3).contiguous(), bias, padding=1) * mask
+    c = torch.as_tensor(coors).long()
+    return y[0][:, c[:, 0], c[:, 1], c[:, 2]].t()
+
+
+def sparse_conv3d(feats, coors, shape_zyx, weight_2x, k=3, s=2, p=1):
+    """One SparseConv3d(k, s, p) in the masked-dense form used below -> (rows, out coords in ascending (z,y,x) order, out shape)."""
+    x, mask = _to_dense(torch.as_tensor(feats).float(), torch.as_tensor(coors), shape_zyx)
+    newmask = F.max_pool3d(mask.float(), k, s, p) > 0
+    y = F.conv3d(x, torch.as_tensor(weight_2x).float().permute(0, 4, 1, 2, 3).contiguous(), stride=s, padding=p) * newmask
+    idx = newmask[0, 0].nonzero()
+    return y[0][:, idx[:, 0], idx[:, 1], idx[:, 2]].t(), idx, list(y.shape[2:])
 
 
 def sparse_encoder_forward(sd, feats, coors, shape_zyx, variant="8x", bn_eps=1e-5):

@@ -105,3 +105,25 @@ def test_detector_extract_pts_feat_from_reference_config_slice(dev):
     keys = set(model.state_dict().keys())
     assert {"pts_middle_encoder.conv_input.0.weight", "pts_middle_encoder.conv1.0.0.weight", "pts_middle_encoder.conv3.2.net.4.running_var",
             "pts_middle_encoder.conv_out.1.bias"} <= keys
+
+
+def test_sparse_layers_match_hand_computed_fixture(dev):
+    """The HIP rule-table layers (index map -> SubM / SparseConv3d(k3,s2,p1) tables -> row-table GEMM) against the hand-computed
+    5x5x5 known-answer vector (tests/golden/sparse_rules_5x5x5.json): active sets, output coordinates and values exactly."""
+    from test_oracle import _hand_fixture
+    fx, W = _hand_fixture()
+    coors = torch.tensor(fx["coors_zyx"], dtype=torch.int32, device=dev)
+    feats = torch.tensor(fx["feats"], dtype=torch.float32, device=dev)
+    x = torch.cat([feats, feats.new_zeros(feats.shape[0], 2)], 1).contiguous()            # rows padded to 4 channels
+    conv = L._SpConv(2, 2, 3).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(W.to(dev))
+    pc = conv.packed()
+    cur = L.SparseRows(None, coors, fx["grid_zyx"])
+    got = L.sparse_conv(x, 4, pc, cur.subm_table("t"), relu=False)
+    assert np.array_equal(got.cpu().numpy(), np.asarray(fx["subm_k3"]["out"], np.float32))
+    coors_o, shape_o, table = cur.downsample(3, 2, 1)
+    assert list(shape_o) == fx["sparse_k3_s2_p1"]["out_shape_zyx"]
+    assert np.array_equal(coors_o.cpu().numpy(), np.asarray(fx["sparse_k3_s2_p1"]["coors_zyx"]))
+    got = L.sparse_conv(x, 4, pc, table, relu=False)
+    assert np.array_equal(got.cpu().numpy(), np.asarray(fx["sparse_k3_s2_p1"]["out"], np.float32))

@@ -222,3 +222,42 @@ def test_sparse_conv_rules_match_vendored_spconv_v1_rulebook(shape, n):
     got = dense[0][:, oc[:, 0], oc[:, 1], oc[:, 2]].t()
     assert torch.allclose(got, out, atol=1e-5)
     assert float((dense * ~newmask).abs().max()) == 0.0          # nothing outside the active set
+
+
+def _hand_fixture():
+    import json
+    import os
+    from conftest import GOLDEN
+    fx = json.load(open(os.path.join(GOLDEN, "sparse_rules_5x5x5.json")))
+    W = torch.zeros(2, 3, 3, 3, 2)                       # spconv 2.x layout [Cout, kd, kh, kw, Cin]
+    for co in range(2):
+        for ci in range(2):
+            for kz in range(3):
+                for ky in range(3):
+                    for kx in range(3):
+                        W[co, kz, ky, kx, ci] = (1, -1)[co] * (1, 10)[ci] * (1 + kx + 3 * ky + 9 * kz)
+    return fx, W
+
+
+def test_sparse_conv_rules_match_hand_computed_fixture():
+    """SubMConv3d / SparseConv3d(k3, s2, p1) on a 5x5x5 grid against outputs derived BY HAND (tests/golden/sparse_rules_5x5x5.json,
+    every number justified in its 'derivation'): the masked-dense form the encoder oracle uses AND the spconv-v1 rule book
+    (vendored geometry.h restated) give exactly those active sets and values -- weight layout [Cout, kd, kh, kw, Cin] included."""
+    from oracle import ref_lidar as RL
+    fx, W = _hand_fixture()
+    feats, coors, shape = np.asarray(fx["feats"], np.float32), np.asarray(fx["coors_zyx"]), fx["grid_zyx"]
+    got = RL.subm_conv3d(feats, coors, shape, W)
+    assert np.array_equal(got.numpy(), np.asarray(fx["subm_k3"]["out"], np.float32))
+    rows, oc, osz = RL.sparse_conv3d(feats, coors, shape, W)
+    assert osz == fx["sparse_k3_s2_p1"]["out_shape_zyx"]
+    assert np.array_equal(oc.numpy(), np.asarray(fx["sparse_k3_s2_p1"]["coors_zyx"]))       # ascending (z,y,x): the fixture's order
+    assert np.array_equal(rows.numpy(), np.asarray(fx["sparse_k3_s2_p1"]["out"], np.float32))
+    # the vendored v1 rule book (weights [kd, kh, kw, Cin, Cout])
+    w1 = W.permute(1, 2, 3, 4, 0).contiguous().numpy()
+    out, oc1, _ = RL.spconv_v1_conv(feats, coors, shape, w1, subm=True)
+    assert np.array_equal(oc1, coors) and np.array_equal(out.numpy(), np.asarray(fx["subm_k3"]["out"], np.float32))
+    out, oc1, osz1 = RL.spconv_v1_conv(feats, coors, shape, w1, k=3, s=2, p=1)
+    assert osz1 == fx["sparse_k3_s2_p1"]["out_shape_zyx"]
+    order = np.lexsort((oc1[:, 2], oc1[:, 1], oc1[:, 0]))                                     # v1 creates sites in first-touch order
+    assert np.array_equal(oc1[order], np.asarray(fx["sparse_k3_s2_p1"]["coors_zyx"]))
+    assert np.array_equal(out.numpy()[order], np.asarray(fx["sparse_k3_s2_p1"]["out"], np.float32))

@@ -5,9 +5,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r4b
 mkdir -p $O
 cd $R
-timeout 2400 python -m pytest tests -m gpu -q -x --durations=15 > $O/pytest.txt 2>&1
+timeout 2400 python -m pytest tests -m gpu -q --durations=15 > $O/pytest.txt 2>&1
 echo "pytest rc $?" >> $O/pytest.txt
-tail -n 40 $O/pytest.txt
+grep -E 'FAILED|ERROR|passed|failed' $O/pytest.txt | tail -n 40
 timeout 300 python bench.py --steps 40 --warmup 3 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
 timeout 300 python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-kernel-timing > $O/bench2.json 2>> $O/bench.err
 COOCC_FUSED_RENDER_HEADS=0 timeout 300 python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-kernel-timing > $O/bench_layerwise_heads.json 2>> $O/bench.err
