@@ -570,6 +570,82 @@ def simple_test_kwargs(s):
                                                         img_feats=s["img_feats"], transform=s["transform"]))
 
 
+def train_main(args, model, dev, rank, world, seen_world, backend_name):
+    """``--train``: one step = forward + backward of the differentiable hot path on one resident sample (batch size 1 per GPU, as
+    upstream: coocc_ray.py:365).  The semantic losses (CE / lovasz / scal, host-side torch like upstream) are outside the path:
+    squared-mean surrogates close the graph.  Weak scaling: every rank trains on its own sample, gradients are NOT all-reduced
+    here (the optimiser / DDP wrapper is upstream)."""
+    from co_occ_amd import autograd as ag
+    c = synth.CONFIGS[args.config]
+    s = make_inputs(args.config, 1234 + 17 * rank, dev, model)
+    model.train()
+    g = torch.Generator(device=dev).manual_seed(1)
+    N, D, fH, fW = s["gemo"].shape[1:5]
+    rgb_gt = torch.rand(N * fH * 16 * fW * 16, 3, device=dev)
+    depth_gt = torch.rand(N * fH * 16 * fW * 16, device=dev) * 50
+    render = c["grid"][0] >= 100 and c["grid"][1] >= 100 and c["grid"][2] >= 8
+    img = s["img"].clone().requires_grad_()
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        img.grad = None
+        res = model.forward_train_hot_path(img, s["pts"], s["gemo"], s["img_feats"], s["transform"], render=render, generator=g)
+        loss = res["logit_rows"].square().mean()
+        if "fine_logits" in res:
+            loss = loss + res["fine_logits"].square().mean()
+        if render:
+            L = ag.render_losses(res["rgbs"].reshape(-1, 3), res["depths"].reshape(-1), rgb_gt, depth_gt, D)
+            loss = loss + L["loss_rgb"] + L["loss_depth_render"]
+        loss.backward()
+    for _ in range(max(1, args.warmup)):
+        step()
+    core.TIMER.enabled, core.TIMER.only = (0 if args.no_kernel_timing else 1), ("k_wgrad", "k_gemm", "k_conv", "conv_fwd", "conv_dgrad")
+    core.TIMER.reset()
+    cdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    cdist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    core.TIMER.enabled = False
+    dt = cdist.max_over_ranks(dt, dev)
+    ksum = core.TIMER.summary()
+    roof = None
+    wg = {k: v for k, v in ksum.items() if k.startswith("k_wgrad")}
+    if wg:
+        ms, work, n = sum(v["ms"] for v in wg.values()), sum(v["work"] for v in wg.values()), sum(v["launches"] for v in wg.values())
+        ach = work / (ms * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel="k_wgrad (direct + Winograd-domain weight gradients, fp32 MFMA)", achieved=round(ach, 2),
+                    peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, launches=n,
+                    ms_per_step=round(ms / args.steps, 3),
+                    note="HIP events around every wgrad launch inside the timed region; flops = those the matrix cores execute "
+                         "(Winograd-domain for the 3x3x3 stride-1 layers)")
+    groups = {}
+    for k, v in ksum.items():
+        tag = "wgrad" if k.startswith("k_wgrad") else ("fwd/dgrad GEMMs, split-f16 engine" if k.startswith("k_gemm_h2") else "fwd/dgrad GEMMs, fp32 MFMA")
+        gq = groups.setdefault(tag, dict(ms=0.0, launches=0))
+        gq["ms"] += v["ms"]; gq["launches"] += v["launches"]
+    line = dict(metric="training samples/sec (hot path forward + backward), 200x200x16 grid", value=round(world * args.steps / dt, 4), unit="samples/s",
+                n_gpus=world, world_size_seen_by_backend=seen_world, backend=backend_name, steps=args.steps, warmup=args.warmup,
+                ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+                dtype=("f32 (forward Winograd GEMMs: split-f16 products, fp32 accumulate; dgrad / wgrad: fp32 MFMA)" if ag.TRAIN_H2 and core.CONV_ENGINE == "h2" else "f32"),
+                data="synthetic",
+                config=dict(workload=("coocc_multi_r50_256x704 hot path, TRAINING step" if args.config == "r50" else args.config + " training step"),
+                            fused_grid="x".join(map(str, c["grid"])) + "x%d" % c["C"], cams=c["ncam"], knum=c["knum"],
+                            batchnorm="batch statistics (model.train())", issue="eager (Python-issued launches)",
+                            parallelism="dp%d (1 scene per GPU; gradient all-reduce belongs to the optimiser wrapper upstream)" % world,
+                            step="index search + G1 + con_enc + encoder + neck + coarse / fine head + render block, forward + backward; "
+                                 "surrogate squared-mean losses on the logits + the two render losses"),
+                roofline=roof,
+                kernel_groups_ms_per_step={k: dict(ms=round(v["ms"] / args.steps, 3), launches_per_step=v["launches"] // args.steps) for k, v in groups.items()},
+                env_knobs={k: v for k, v in sorted(os.environ.items()) if k.startswith("COOCC_")})
+    if rank == 0:
+        print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -603,6 +679,10 @@ def main():
                          "issued from Python (Pipeline, --streams)")
     ap.add_argument("--ahead", type=int, default=0, help="--graph 1: searches submitted ahead of the dense stage (0: slots - dense streams; "
                                                          "with more than one rank: 1 -- one helper thread per rank, so an 8-rank node does not run 32 host threads)")
+    ap.add_argument("--train", action="store_true",
+                    help="time the TRAINING step of the hot path instead (SURVEY.md 8f rank 1: COOCC_Ray.forward_train_hot_path -- index "
+                         "search, G1, con_enc, encoder, neck, coarse + fine head, render block -- forward + backward with batch-statistics "
+                         "BatchNorm, surrogate scalar losses closing the graph) and print its own JSON line with a wgrad roofline")
     ap.add_argument("--api", default="serving", choices=["serving", "simple_test"],
                     help="serving (default): COOCC_Ray.serving() -- co_occ_amd.serving.ServingPipeline, --slots samples in flight.  "
                          "simple_test: the reference's per-sample call COOCC_Ray.simple_test(precomputed=...) (coocc_ray.py:520), "
@@ -653,6 +733,8 @@ def main():
         args.graph, args.streams = 0, 1           # the sharded render has a collective inside the step: eager, one sample in flight
         auto_streams = False
     model, sd = build_model(args.config, dev)
+    if args.train:
+        return train_main(args, model, dev, rank, world, seen_world, backend_name)
     samples = [make_inputs(args.config, 1234 + (0 if SHARD[0] else 17 * rank) + i, dev, model) for i in range(max(2, args.slots if args.graph else 2))]
     if args.reserve_cus > 0:
         # CU partition: the FPS chains get private CUs, everything else runs on the remaining ones

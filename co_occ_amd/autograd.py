@@ -21,6 +21,14 @@ _tables = {}
 TRAIN_WINO = __import__("os").environ.get("COOCC_TRAIN_WINO", "1") != "0"
 # weight gradients of those layers in the Winograd domain too (COOCC_TRAIN_WINO_WGRAD=0: direct k_wgrad)
 TRAIN_WINO_WGRAD = TRAIN_WINO and __import__("os").environ.get("COOCC_TRAIN_WINO_WGRAD", "1") != "0"
+# Winograd forward / dgrad GEMMs of the training path on the split-f16 engine (weights transformed + split on the device every
+# step, coocc_wino_pack_weights_h2_dev); 0: the fp32-MFMA kernels of rounds 1-3
+TRAIN_H2 = __import__("os").environ.get("COOCC_TRAIN_H2", "1") != "0"
+# ... and the dgrad GEMMs too.  Off by default: the operand of a dgrad GEMM is a GRADIENT, whose magnitude is set by the loss
+# scale, not by BatchNorm -- below 6.1e-5 an f16 is subnormal, so at |dy| ~ 1e-6 the hi half keeps a handful of bits and the split
+# ~12 instead of 22 (arithmetic of the format, not a measurement).  1 is safe when the loss is scaled so that max|dy| stays in
+# [1e-3, 1e3] (the Winograd transform scales by 1/8 and amplifies by up to 100).
+TRAIN_H2_DGRAD = TRAIN_H2 and __import__("os").environ.get("COOCC_TRAIN_H2_DGRAD", "0") != "0"
 
 
 def _pad4(n):
@@ -93,7 +101,7 @@ def pack_weights_dev(w, Cout, Cin, taps, mode):
     return packed
 
 
-class _DevWino:
+class _DevWinoF32:
     """What core.conv_rows_wino needs of a PackedConv, with the Winograd packs transformed on the device from the live
     parameter (training re-packs every step): forward packs, or (``dgrad``) the packs of dx = conv(dy, W')."""
 
@@ -119,13 +127,32 @@ class _DevWino:
         return self._packs[tile]
 
 
+class _DevWino(_DevWinoF32):
+    def wino_h2_pack(self, tile):
+        """The same packs for the split-f16 engine (csrc/gemm_h2.hip), transformed + split on the device from the live parameter:
+        training's Winograd forward / dgrad GEMMs run on the f16 matrix cores like inference's (core.h2_capable)."""
+        key = ("h2", tile)
+        if key not in self._packs:
+            lib = _lib.load()
+            Cout, Cin = self._w5.shape[:2]
+            n = lib.coocc_wino_pack_weights_h2_dev(None, Cout, Cin, tile, self._dgrad, None, None)
+            if n < 0:
+                _lib.check(int(n))
+            packed = torch.empty((tile + 2) ** 2, n // (tile + 2) ** 2, dtype=_F32, device=self._w5.device)
+            n = lib.coocc_wino_pack_weights_h2_dev(ptr(self._w5), Cout, Cin, tile, self._dgrad, ptr(packed), _lib.stream(self._w5.device))
+            if n < 0:
+                _lib.check(int(n))
+            self._packs[key] = packed
+        return self._packs[key]
+
+
 def _wino_train(x2d, geom, w5, dgrad, out2d, scale, shift, res2d, relu):
     """Winograd path of a 3x3x3 stride-1 pad-1 convolution in training (forward or dgrad); False if not eligible."""
     from . import core
     if not TRAIN_WINO:
         return False
     B, X, Y, Z = geom
-    pk = _DevWino(w5, dgrad, scale, shift)
+    pk = (_DevWino if (TRAIN_H2_DGRAD if dgrad else TRAIN_H2) else _DevWinoF32)(w5, dgrad, scale, shift)
     xr = core.Rows(x2d, B, X, Y, Z, pk.Cin)
     plan = core.wino_plan(xr, pk, out2d.shape[0], 1 if res2d is not None else 0)
     if plan is None:
@@ -146,7 +173,7 @@ def _wino_wgrad(x2d, dacc, geom, Cin, Cout, dw):
     B, X, Y, Z = geom
     dev = x2d.device
     xr = core.Rows(x2d, B, X, Y, Z, Cin)
-    pk = _DevWino(torch.empty(Cout, Cin, 0, device=dev), False)      # geometry only: no packs are made
+    pk = _DevWinoF32(torch.empty(Cout, Cin, 0, device=dev), False)      # geometry only: no packs are made (fp32 V / dM rows)
     plan = core.wino_plan(xr, pk, x2d.shape[0], 0)
     if plan is None:
         return False

@@ -46,7 +46,7 @@ H2_DIRECT = __import__("os").environ.get("COOCC_H2_DIRECT", "1") != "0"     # st
 # same reads over the whole chip -- k_gemm_h2z<1,true> 24 -> 168 us with device-scope loads (200 us with __threadfence()), against
 # a 5 us k_conv_reduce launch (profiles/r4_dense_stage_kernels.txt).  The second pass instead writes the H2 twin.
 INKERNEL_REDUCE = __import__("os").environ.get("COOCC_INKERNEL_REDUCE", "0") != "0"
-H2_DIRECT_MIN_FLOPS = 1e9      # below this the input split + split-K reduce launches cost more than the faster GEMM saves (measured)
+H2_DIRECT_MIN_FLOPS = float(__import__("os").environ.get("COOCC_H2_MIN_FLOPS", "1e9"))      # below this the input split + split-K reduce launches cost more than the faster GEMM saves (measured)
 
 
 def conv_kernel_name(M, Cout, table, hint=0, iters=1 << 30, one_by_one=False):

@@ -98,8 +98,15 @@ __global__ __launch_bounds__(256) void k_occhead_mix(MixLevels lv, const float* 
   for (int l = 0; l < lv.L; ++l) { w[l] = expf(w[l] - mx); sum += w[l]; }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int l = 0; l < lv.L; ++l) {
-    Lin1 lx = lin_src(x, lv.X[l], X0), ly = lin_src(y, lv.Y[l], Y0), lz = lin_src(z, lv.Z[l], Z0);
-    f32x4 s = tri_sample(lv.p[l], b, C, lv.X[l], lv.Y[l], lv.Z[l], lx, ly, lz, c);
+    f32x4 s;
+    if (lv.X[l] == X0 && lv.Y[l] == Y0 && lv.Z[l] == Z0) {
+      // a level already on the output grid (level 0): the trilinear sample IS the voxel (weights 1, 0 -- the eight-tap
+      // expression below returns exactly this value: 1 * v + 0 * v), one 16-byte load instead of eight
+      s = *(const f32x4*)(lv.p[l] + row * C + c);
+    } else {
+      Lin1 lx = lin_src(x, lv.X[l], X0), ly = lin_src(y, lv.Y[l], Y0), lz = lin_src(z, lv.Z[l], Z0);
+      s = tri_sample(lv.p[l], b, C, lv.X[l], lv.Y[l], lv.Z[l], lx, ly, lz, c);
+    }
     acc = acc + s * (w[l] / sum);
   }
   *(f32x4*)(out + row * C + c) = acc;

@@ -89,13 +89,22 @@ __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict_
   const int tid = threadIdx.x;
 
   // lane -> (ray r = tid & 31, depth phase tid >> 5): no integer division in the loop
+  // GEO: the ray's frustum coordinates are loop invariants (this lane always works on ray tid & 31), the camera's 39 constants
+  // are read through a uniform base; a sample costs get_geometry's ~45 flops and no index arithmetic.  x / 1.0f == x exactly, so
+  // the three IEEE divisions (a dozen instructions each) are skipped for unit voxels (every shipped config renders on the
+  // hard-coded 1 m grid of coocc_ray.py:577); the branch is uniform.
+  const float* mcam = GEO ? geom + (size_t)n * COOCC_CAM_FLOATS : nullptr;
+  const float xw = GEO && (tid & 31) < nray ? xs[w0 + (tid & 31)] : 0.f, yh = GEO ? ys[h] : 0.f;
+  const bool unit = dx == 1.f && dy == 1.f && dz == 1.f;
 #pragma unroll 4
   for (int d = tid >> 5, r = tid & 31; d < D; d += 8) {
     if (r >= nray) continue;
     Geo3 g;
-    if (GEO) geometry_point(geom, xs, ys, ds, (((size_t)n * D + d) * H + h) * W + w0 + r, D, H, W, g.x, g.y, g.z);
+    if (GEO) geometry_sample(mcam, xw, yh, ds[d], g.x, g.y, g.z);
     else g = *(const Geo3*)(geom + ((((size_t)n * D + d) * H + h) * W + w0 + r) * 3);
-    float gx = __fdiv_rn(g.x - lox, dx), gy = __fdiv_rn(g.y - loy, dy), gz = __fdiv_rn(g.z - loz, dz);
+    float gx, gy, gz;
+    if (unit) { gx = g.x - lox; gy = g.y - loy; gz = g.z - loz; }
+    else { gx = __fdiv_rn(g.x - lox, dx); gy = __fdiv_rn(g.y - loy, dy); gz = __fdiv_rn(g.z - loz, dz); }
     bool in = gx >= 0.f && gx < nx && gy >= 0.f && gy < ny && gz >= 0.f && gz < nz;
     int ix = in ? (int)gx : 0, iy = in ? (int)gy : 0, iz = in ? (int)gz : 0;
     s_pos[r * DS + d] = ix | (iy << 10) | (iz << 20) | (in ? 0 : (1 << 31));

@@ -458,3 +458,67 @@ extern "C" int64_t coocc_wino_pack_weights_dev(const float* w, int Cout, int Cin
   if (hipGetLastError() != hipSuccess) return coocc_set_error(COOCC_EHIP, "wino_pack_weights_dev: launch failed");
   return total;
 }
+
+// The same device-side weight transform writing the SPLIT-F16 packs of gemm_h2.hip (mfma_dtype 3): U = G g G^T in fp64, split
+// hi = f16(U), lo = f16((U - hi) * 2^11), laid out [(tile+2)^2][(K chunk, dz)][Npad/32][2 k16 steps][hi | lo][64 lanes][8 f16]
+// (core.PackedConv._h2_layout).  With it the training path -- which re-packs from the live parameter every step -- runs its
+// Winograd forward and dgrad GEMMs on the f16 matrix cores like inference does.  K (Cin forward, Cout dgrad) % 32 == 0.
+template <int N>
+__global__ __launch_bounds__(256) void k_wino_weights_h2(const float* __restrict__ w, int Cout, int Cin, int dgrad, int Npad,
+                                                          size_t pack_halfs, _Float16* __restrict__ packed, int* __restrict__ flag) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)Cout * Cin * 3) return;
+  const int dz = (int)(i % 3);
+  const int c = (int)((i / 3) % Cin), n = (int)(i / (3LL * Cin));
+  const double (*G)[3] = N == 4 ? c_G4 : (N == 5 ? c_G5 : c_G6);
+  const float* g = w + ((size_t)n * Cin + c) * 27;
+  double t[N][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    double col[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) col[a] = dgrad ? (double)g[((2 - a) * 3 + (2 - b)) * 3 + (2 - dz)] : (double)g[(a * 3 + b) * 3 + dz];
+#pragma unroll
+    for (int xi = 0; xi < N; ++xi) t[xi][b] = G[xi][0] * col[0] + G[xi][1] * col[1] + G[xi][2] * col[2];
+  }
+  const int kk = dgrad ? n : c, nn = dgrad ? c : n;          // GEMM roles: forward K = Cin, N = Cout; dgrad K = Cout, N = Cin
+  const int chunk = kk >> 5, k32 = kk & 31, sidx = k32 >> 4, hf = (k32 >> 3) & 1, e = k32 & 7;
+  const int nt = nn >> 5, li = nn & 31;
+  // halfs: ((((chunk * 3 + dz) * (Npad / 32) + nt) * 2 + s) * 2 + plane) * 512 + (hf * 32 + li) * 8 + e
+  const size_t base = ((((size_t)chunk * 3 + dz) * (Npad >> 5) + nt) * 2 + sidx) * 2 * 512 + (size_t)(hf * 32 + li) * 8 + e;
+#pragma unroll
+  for (int xi = 0; xi < N; ++xi)
+#pragma unroll
+    for (int eta = 0; eta < N; ++eta) {
+      const double u = G[eta][0] * t[xi][0] + G[eta][1] * t[xi][1] + G[eta][2] * t[xi][2];
+      const _Float16 hi = (_Float16)u;
+      const _Float16 lo = (_Float16)((u - (double)hi) * 2048.0);
+      _Float16* o = packed + (size_t)(xi * N + eta) * pack_halfs + base;
+      o[0] = hi;
+      o[512] = lo;
+      if (flag && !(fabs(u) < 32768.0)) *(volatile int*)flag = 1;
+    }
+}
+
+extern "C" int64_t coocc_wino_pack_weights_h2_dev(const float* w, int Cout, int Cin, int tile, int dgrad, void* packed, void* stream) {
+  if (Cout <= 0 || Cin <= 0 || tile < 2 || tile > 4) return coocc_set_error(COOCC_EINVAL, "wino_pack_weights_h2_dev: bad args");
+  const int N = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+  if (K % 32) return coocc_set_error(COOCC_EINVAL, "wino_pack_weights_h2_dev: the GEMM's K (Cin forward, Cout dgrad) must be a multiple of 32");
+  const int Npad = (N + NPAD_TO - 1) / NPAD_TO * NPAD_TO;
+  const size_t pack_halfs = (size_t)3 * (K / 32) * Npad * 32 * 2;          // hi + lo halves per (k, n, dz)
+  const int pts = (tile + 2) * (tile + 2);
+  const int64_t total_floats = (int64_t)pts * (int64_t)(pack_halfs / 2);   // reported in 4-byte units, like the fp32 variant
+  if (!packed) return total_floats;
+  if (!w) return coocc_set_error(COOCC_EINVAL, "wino_pack_weights_h2_dev: null weights");
+  hipStream_t s = as_stream(stream);
+  if (Npad != N && hipMemsetAsync(packed, 0, (size_t)total_floats * 4, s) != hipSuccess)
+    return coocc_set_error(COOCC_EHIP, "wino_pack_weights_h2_dev: memset failed");
+  int* flag = nullptr;
+  if (coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
+  const dim3 grid(cdiv((long long)Cout * Cin * 3, 256));
+  if (tile == 2) hipLaunchKernelGGL(k_wino_weights_h2<4>, grid, dim3(256), 0, s, w, Cout, Cin, dgrad, Npad, pack_halfs, (_Float16*)packed, flag);
+  else if (tile == 3) hipLaunchKernelGGL(k_wino_weights_h2<5>, grid, dim3(256), 0, s, w, Cout, Cin, dgrad, Npad, pack_halfs, (_Float16*)packed, flag);
+  else hipLaunchKernelGGL(k_wino_weights_h2<6>, grid, dim3(256), 0, s, w, Cout, Cin, dgrad, Npad, pack_halfs, (_Float16*)packed, flag);
+  if (hipGetLastError() != hipSuccess) return coocc_set_error(COOCC_EHIP, "wino_pack_weights_h2_dev: launch failed");
+  return total_floats;
+}

@@ -302,6 +302,12 @@ int coocc_render_heads_h2(const void* x_h2, int V, int Cin, int width, const voi
                           const float* ws1, const float* bs1, const void* const* wr_packs_host,
                           const float* const* br_host, int n_rgb_hidden, const float* wr_out, const float* br_out,
                           float* table, int activate, void* stream);
+/* coocc_wino_pack_weights_dev for the split-f16 engine (mfma_dtype 3): U = G g G^T in fp64, split into f16 hi / lo, in the H2 pack
+ * layout [(tile+2)^2][(K chunk, dz)][roundup(N,128)/32][2 k16 steps][hi | lo][64 lanes][8 f16].  The GEMM's K (Cin forward, Cout
+ * dgrad) must be a multiple of 32.  packed == NULL: returns the size in 4-byte units.  Lets the TRAINING path (which re-packs from
+ * the live parameter every step; the reference trains these layers through cuDNN, resnet3d.py:34-64) run its Winograd forward and
+ * dgrad GEMMs on the f16 matrix cores. */
+int64_t coocc_wino_pack_weights_h2_dev(const float* w, int Cout, int Cin, int tile, int dgrad, void* packed, void* stream);
 /* Range guard of the split-f16 engine (resnet3d.py / fpn3d.py / occ_head.py convolutions are fp32 upstream and have no such
  * limit): every kernel that writes a 16-bit operand (H2 rows, f16 twins, the Winograd-domain V) raises a host-visible flag when a
  * value reaches half the f16 range (|v| >= 32768 after the writer's own scale; NaN counts).  Returns the flag (0 / 1) and clears it

@@ -803,7 +803,7 @@ def test_lift_splat_with_cached_geometry_equals_the_full_call(dev):
     """``accelerate=True`` (the reference's flag for a fixed rig, ViewTransformerLSSBEVDepth.py:67,242-300): the voxel binning of the
     first call is reused, later calls run the per-voxel sums alone -- bit-equal to the full call on new depth / context inputs."""
     cfgm = synth.model_cfg()["img_view_transformer"]
-    vt = pkg.ViewTransformerLiftSplatShootVoxel(**{k: v for k, v in cfgm.items() if k != "type"}).to(dev)
+    vt = pkg.ViewTransformerLiftSplatShootVoxel(**{k: v for k, v in cfgm.items() if k != "type"}).to(dev).eval()
     rig = synth.camera_rig(6, (256, 704), seed=3)
     cams = tuple(rig[k].to(dev) for k in ("rots", "trans", "intrins", "post_rots", "post_trans", "bda"))
     plain = []
@@ -813,6 +813,18 @@ def test_lift_splat_with_cached_geometry_equals_the_full_call(dev):
         ins.append((depth.to(dev), ctx.to(dev)))
         plain.append(vt.lift_splat(*ins[-1], cams=cams).clone())
     vt.accelerate = True
+    vt.train()                    # training-time bda augmentation moves the rig every step: the cache is bypassed under train()
+    assert torch.equal(vt.lift_splat(*ins[0], cams=cams), plain[0]) and getattr(vt, "_geometry_cache", None) is None
+    vt.eval()
     for (d, c), want in zip(ins, plain):
         assert torch.equal(vt.lift_splat(d, c, cams=cams), want)
     assert vt._geometry_cache is not None
+    # a second stream reuses the binning the first one built: it waits for the build's event
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        got = vt.lift_splat(*ins[1], cams=cams)
+    side.synchronize()
+    assert torch.equal(got, plain[1])
+    vt.invalidate_geometry_cache()
+    assert vt._geometry_cache is None
