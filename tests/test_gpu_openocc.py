@@ -221,7 +221,8 @@ def test_openocc_end_to_end_vs_subsampled_oracle(dev, monkeypatch, dtype):
     if dtype == "f16":
         if "o16" not in _E2E:
             monkeypatch.setattr(ref_cpu, "CONV_OPERAND_DTYPE", torch.float16)
-            _E2E["o16"] = ref_cpu.hot_path_forward(sd, S["img"], S["pts"], S["gemo"], S["img_feats"], S["tr"], literal_render=True, **S["kw"])
+            # (the per-voxel table form of the render block: equal to the literal gather-then-MLP form to 2e-7, minutes faster)
+            _E2E["o16"] = ref_cpu.hot_path_forward(sd, S["img"], S["pts"], S["gemo"], S["img_feats"], S["tr"], literal_render=False, **S["kw"])
             monkeypatch.setattr(ref_cpu, "CONV_OPERAND_DTYPE", None)
         o16 = _E2E["o16"]
     for k_hip, k_ref in (("voxel_feats", "voxel_feats"), ("pred_c", "output_voxels")):
