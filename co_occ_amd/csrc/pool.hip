@@ -208,20 +208,26 @@ __global__ __launch_bounds__(256) void k_keys_hist(KeySrc a, int npts, int X, in
     }
     keys[i] = k;
   }
+  // Lanes that hold the same key form a group: its leader adds the group size to count[key], every member takes
+  // (old value + its position in the group) as its slot.  The grouping loop is pure ALU (one ballot per DISTINCT key of the
+  // wave); the atomics of all leaders are then issued TOGETHER and waited for once -- issuing one per loop iteration and waiting
+  // for its return value put up to 64 memory round trips in series per wave (far depth bins: 64 pixels, 64 voxels).
   const bool valid = k < (uint32_t)nvox;
   unsigned long long remaining = __ballot(valid);
-  int myslot = 0;
+  int leader_of = lane, pos = 0, gsize = 0;
   while (remaining) {
     const int leader = (int)__ffsll((long long)remaining) - 1;
     const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)k, leader);
-    const unsigned long long grp = __ballot(valid && k == k0);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&count[k0], (int)__popcll(grp));
-    base = __builtin_amdgcn_readlane(base, leader);
-    if (valid && k == k0) myslot = base + (int)__popcll(grp & ((1ull << lane) - 1ull));
+    const bool mine = valid && k == k0;
+    const unsigned long long grp = __ballot(mine);
+    if (mine) { leader_of = leader; pos = (int)__popcll(grp & ((1ull << lane) - 1ull)); }
+    if (lane == leader) gsize = (int)__popcll(grp);
     remaining &= ~grp;
   }
-  if (valid) slot[i] = myslot;
+  int base = 0;
+  if (valid && lane == leader_of) base = atomicAdd(&count[k], gsize);
+  base = __shfl(base, leader_of);
+  if (valid) slot[i] = base + pos;
 }
 
 // Launches 2 and 3 of 4: the CSR.  k_scan_local: exclusive scan of count[] inside each 1024-voxel chunk (lstart[]) + the chunk
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256) void k_csr_fill(const uint32_t* __restrict__ k
 // time so that the loads run ahead of the dependent adds.  n > 256 (24 voxels of 57 k at r50, 554 of 73 k at r101, up to
 // 2614 points each, next to the cameras): a whole workgroup bitonic-sorts the ids in LDS and thread c sums channel c; these
 // workgroups are the FIRST blocks of the same launch, so the long tail runs under the short voxels instead of after them.
-constexpr int POOL_BATCH = 16;
+constexpr int POOL_BATCH = 16;     // row loads in flight per lane and batch (8: 7 instead of 6 waves per SIMD, r50 the same, r101 0.35 -> 0.40 ms: measured)
 constexpr int POOL_LONG_CAP = 4096;   // ids a workgroup sorts in LDS; beyond: a slow selection path (never seen)
 
 template <int VEC> struct PoolVec;
@@ -454,7 +460,7 @@ __device__ __forceinline__ void pool_long(const float* __restrict__ x, const flo
     __syncthreads();
     // the serial chain of the longest voxel (2614 points at r101) bounds the whole launch: 64 row loads in flight per batch
     // (one memory latency per 64 points instead of per 16), then the 64 dependent adds
-    constexpr int LB = 64;
+    constexpr int LB = 64;        // (128, and a rank sort instead of the bitonic network, measured SLOWER in round 4: 233 -> 303 us at r101)
     for (int c = tid; c < C; c += 256) {
       float acc = 0.f;
       for (int j0 = 0; j0 < n; j0 += LB) {
@@ -536,6 +542,11 @@ __global__ __launch_bounds__(256) void k_pool_sum_csr(const float* __restrict__ 
   else pool_row<LIFT, 4>(x, depth, ids, s, e, lane, C, D, HW, out + (size_t)v * out_stride, lds);
 }
 
+// (Round 4 tried the sums as TWO launches -- short / medium voxels, 8 waves per SIMD instead of 3, and the long voxels on a side
+// stream -- and measured no gain at r50 (0.118 ms either way: that round's gain was the batched histogram atomics) and a loss at
+// r101 (0.325 -> 0.410 ms: the long voxels' serial chains, 233 us, are the launch and they run slower next to a denser short
+// kernel); a rank sort instead of the bitonic network and 128 rows in flight made the long path slower still (233 -> 303 us).
+// profiles/r4_pool_experiments.txt.)
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // workspace: keys[npts] | ids[npts] | slot[npts] | count[nvox+1] | nlong [64] (one memset clears these two when the caller does
@@ -565,9 +576,8 @@ static int carve(void* ws, size_t ws_bytes, int npts, int nvox, PoolWs* p) {
 template <bool LIFT>
 static int pool_sums(const float* x, const float* depth, int C, int D, int HW, int nvox, float* out, int out_stride,
                      const PoolWs& p, hipStream_t s) {
-  // workgroups that walk the list of long voxels (> POOL_MEDIUM points; 24 at r50, 554 at r101, up to 2614 points each): their
-  // per-voxel sort + ordered accumulation is the launch's critical path, so there are enough of them for one voxel each at r101
-  // (r101, whole pooling call: 128 workgroups 0.60 ms, 512 0.43, 1024 0.375; idle ones exit after one load)
+  // workgroups that walk the list of long voxels (> POOL_MEDIUM points; 24 at r50, 554 at r101, up to 2614 points each): enough of
+  // them for one voxel each at r101; idle ones exit after one load
   static const int long_blocks = getenv("COOCC_POOL_LONG_BLOCKS") ? atoi(getenv("COOCC_POOL_LONG_BLOCKS")) : 1024;
   hipLaunchKernelGGL(k_pool_sum_csr<LIFT>, dim3(long_blocks + cdiv(nvox, 4)), dim3(256), 0, s, x, depth, p.ids, p.start,
                      p.long_list, p.nlong, long_blocks, nvox, C, D, HW, out, out_stride);

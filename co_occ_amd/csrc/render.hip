@@ -192,6 +192,110 @@ __global__ __launch_bounds__(256) void k_render_nearest(const float* __restrict_
   }
 }
 
+// The in-kernel-geometry form WITHOUT the LDS transpose (round 4).  With the sample positions computed instead of streamed there
+// is nothing to coalesce in a first phase: the lane that composites samples d0 .. d0+CH-1 of a ray evaluates get_geometry's chain
+// for exactly those samples itself (same expressions, same bits as phase 1 of k_render_nearest<.., true>), and takes the position
+// that follows its last one (the step length of its last sample) from its right neighbour's first with one shuffle.  No LDS, no
+// barrier; a workgroup is 4 waves x 2 rays, one pass, (W / 8) x H x N workgroups.
+template <int ACT, int CHT>
+__global__ __launch_bounds__(256) void k_render_rays_geo(const float* __restrict__ table, int Y, int Z, const float* __restrict__ mats,
+                                                          const float* __restrict__ xs, const float* __restrict__ ys,
+                                                          const float* __restrict__ ds, const float* __restrict__ zvals, int D, int H, int W,
+                                                          float lox, float loy, float loz, float dx, float dy, float dz, float nx, float ny,
+                                                          float nz, float* __restrict__ maps) {
+  const int h = blockIdx.y, n = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, hl = lane & 31, half = lane >> 5;
+  const int r = blockIdx.x * 8 + wave * 2 + half;          // this half-wave's ray = pixel column w
+  const bool live = r < W;
+  const int CH = (D + 31) / 32;                  // <= CHT
+  const int d0 = hl * CH;
+  const float* mcam = mats + (size_t)n * COOCC_CAM_FLOATS;
+  const float xw = live ? xs[r] : 0.f, yh = ys[h];
+  const bool unit = dx == 1.f && dy == 1.f && dz == 1.f;
+  int pk[CHT + 1];
+  float zv[CHT];
+#pragma unroll
+  for (int j = 0; j < CHT; ++j) {
+    const int d = d0 + j;
+    pk[j] = 0;
+    zv[j] = 0.f;
+    if (j < CH && d < D && live) {
+      zv[j] = zvals[d];
+      float px, py, pz;
+      geometry_sample(mcam, xw, yh, ds[d], px, py, pz);
+      float gx, gy, gz;
+      if (unit) { gx = px - lox; gy = py - loy; gz = pz - loz; }
+      else { gx = __fdiv_rn(px - lox, dx); gy = __fdiv_rn(py - loy, dy); gz = __fdiv_rn(pz - loz, dz); }
+      const bool in = gx >= 0.f && gx < nx && gy >= 0.f && gy < ny && gz >= 0.f && gz < nz;
+      const int ix = in ? (int)gx : 0, iy = in ? (int)gy : 0, iz = in ? (int)gz : 0;
+      pk[j] = ix | (iy << 10) | (iz << 20) | (in ? 0 : (1 << 31));
+    }
+  }
+  {
+    const int nxt = __shfl_down(pk[0], 1);       // the right neighbour's first sample = the one after this lane's last
+#pragma unroll
+    for (int j = 1; j <= CHT; ++j)
+      if (j == CH) pk[j] = nxt;
+  }
+  float al[CHT], cr[CHT], cg[CHT], cb[CHT], prod = 1.f;
+#pragma unroll
+  for (int j = 0; j < CHT; ++j) {
+    al[j] = 0.f; cr[j] = cg[j] = cb[j] = 0.f;
+    const int d = d0 + j;
+    if (j < CH && d < D && live) {
+      const int p0 = pk[j];
+      const int x0 = p0 & 1023, y0 = (p0 >> 10) & 1023, z0 = (p0 >> 20) & 1023;
+      const f32x4 t = *(const f32x4*)(table + (((size_t)x0 * Y + y0) * Z + z0) * 4);
+      float dist = 1e10f;
+      if (d + 1 < D) {
+        const int p1 = pk[j + 1];
+        float ex = (float)((p1 & 1023) - x0), ey = (float)(((p1 >> 10) & 1023) - y0), ez = (float)(((p1 >> 20) & 1023) - z0);
+        dist = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez);
+      }
+      const bool in = p0 >= 0;
+      al[j] = 1.f - __expf(-fmaxf(fmaxf(t[0], 0.f) * dist, 0.f));
+      if (ACT) {
+        cr[j] = in ? t[1] : 0.5f; cg[j] = in ? t[2] : 0.5f; cb[j] = in ? t[3] : 0.5f;
+      } else {
+        cr[j] = in ? __frcp_rn(1.f + __expf(-t[1])) : 0.5f;
+        cg[j] = in ? __frcp_rn(1.f + __expf(-t[2])) : 0.5f;
+        cb[j] = in ? __frcp_rn(1.f + __expf(-t[3])) : 0.5f;
+      }
+      prod *= 1.f - al[j] + 1e-10f;
+    }
+  }
+  float inc = prod;
+  inc *= dpp_f32_id<0x111>(inc);
+  inc *= dpp_f32_id<0x112>(inc);
+  inc *= dpp_f32_id<0x114>(inc);
+  inc *= dpp_f32_id<0x118>(inc);
+  inc *= __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3F800000, __builtin_bit_cast(int, inc), 0x142, 0xA, 0xF, false));
+  float T = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3F800000, __builtin_bit_cast(int, inc), 0x138, 0xF, 0xF, false));
+  if (hl == 0) T = 1.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < CHT; ++j) {
+    const int d = d0 + j;
+    if (j < CH && d < D) {
+      const float wgt = al[j] * T;
+      acc = acc + wgt * f32x4{cr[j], cg[j], cb[j], zv[j]};
+      T *= 1.f - al[j] + 1e-10f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float v = acc[k];
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+    acc[k] = v;
+  }
+  if (hl == 16 && live) *(f32x4*)(maps + (((size_t)n * H + h) * W + r) * 4) = acc;
+}
+
 // sigmoid of the rgb logits once per voxel (in place on columns 1..3 of the [V,4] table)
 __global__ __launch_bounds__(256) void k_render_activate_table(float* __restrict__ table, int V) {
   const int v = blockIdx.x * 256 + threadIdx.x;
@@ -247,7 +351,16 @@ static int render_nearest_impl(const float* table, int X, int Y, int Z, const fl
 #define RN_LAUNCH(ACT, CHT, GEO)                                                                                                  \
   hipLaunchKernelGGL((k_render_nearest<ACT, CHT, GEO>), grid, dim3(256), lds, as_stream(stream), table, Y, Z, geom, zvals, D, H, W, rt, \
                      lox, loy, loz, dx, dy, dz, nx, ny, nz, maps, xs, ys, ds)
-  if (xs) {
+  static const int geo_lds = getenv("COOCC_RENDER_GEO_LDS") ? atoi(getenv("COOCC_RENDER_GEO_LDS")) : 0;   // 1: round 3's two-phase form
+  if (xs && !geo_lds) {
+    dim3 g2((W + 7) / 8, H, N);
+#define RG_LAUNCH(ACT, CHT)                                                                                                         \
+  hipLaunchKernelGGL((k_render_rays_geo<ACT, CHT>), g2, dim3(256), 0, as_stream(stream), table, Y, Z, geom, xs, ys, ds, zvals, D, H, W, lox, \
+                     loy, loz, dx, dy, dz, nx, ny, nz, maps)
+    if (D > 128) { if (activated) RG_LAUNCH(1, 8); else RG_LAUNCH(0, 8); }
+    else { if (activated) RG_LAUNCH(1, 4); else RG_LAUNCH(0, 4); }
+#undef RG_LAUNCH
+  } else if (xs) {
     if (D > 128) { if (activated) RN_LAUNCH(1, 8, true); else RN_LAUNCH(0, 8, true); }
     else { if (activated) RN_LAUNCH(1, 4, true); else RN_LAUNCH(0, 4, true); }
   } else {
