@@ -851,7 +851,7 @@ def main():
     graph_info = None
     if graphish:
         if gp is not None:
-            dense_ms = [a.elapsed_time(b) for a, b in gp.dense_ev]
+            dense_ms = [ev[0].elapsed_time(ev[1]) for ev in gp.dense_ev]
             graph_info = dict(api="COOCC_Ray.serving() -> co_occ_amd.serving.ServingPipeline", slots=gp.n, dense_streams=gp.ndense,
                               searches_ahead=gp.ahead, eager_fallbacks=gp.fallbacks,
                               dense_stage_ms=round(sum(dense_ms) / max(1, len(dense_ms)), 3),

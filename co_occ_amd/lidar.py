@@ -11,13 +11,18 @@ import ctypes
 import torch
 from torch import nn
 
-from . import _lib
+import os
+
+from . import _lib, core
 from ._lib import ConvDesc, call, host_f32, ptr
 from .backbone import build_bn
 from .core import PackCache, PackedConv, Rows, TILE_HINT, fold_bn, workspace
 from .registry import Registry
 
 _F32, _I32 = torch.float32, torch.int32
+# rule-book GEMMs with Cin % 32 == 0 (16 of the 18 layers of SparseLiDAREnc8x) on the split-f16 engine (k_gemm_h2w<TABLE>, the
+# kernel of the GSFusion gather GEMMs): same fp32 accuracy, operands written by the producing layer's epilogue.  0 = fp32 MFMA.
+LIDAR_H2 = os.environ.get("COOCC_LIDAR_H2", "1") != "0"
 VOXEL_LAYERS = Registry("voxel_layer")
 VOXEL_ENCODERS = Registry("voxel_encoder")
 MIDDLE_ENCODERS = Registry("middle_encoder")
@@ -122,14 +127,18 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
-def sparse_conv(feats, Cin, pc, table, relu=True, res=None, out=None, out_rows=None):
-    """out[o] = epi(sum_t W_t . feats[table[t][o]]): one row-table GEMM launch (BN folded into pc.scale/bias)."""
+def sparse_conv(feats, Cin, pc, table, relu=True, res=None, out=None, out_rows=None, feats_h2=None, twin=False):
+    """out[o] = epi(sum_t W_t . feats[table[t][o]]): one row-table GEMM launch (BN folded into pc.scale/bias).
+    ``feats_h2``: the H2 (split-f16) copy of ``feats`` when the producer wrote one; ``twin``: also return the H2 copy of ``out``
+    (the next rule-book GEMM's operand).  Returns out, or (out, out_h2) with ``twin``."""
     taps, Mo = table.shape
     dev = feats.device
     if out is None:
         out = torch.empty(Mo, pc.Cout, device=dev, dtype=_F32)
+    h2 = LIDAR_H2 and core.CONV_ENGINE == "h2" and Cin % 32 == 0 and feats.shape[1] == Cin and out_rows is None
+    out_h2 = torch.empty(Mo, pc.Cout, device=dev, dtype=_F32) if (twin and h2 and pc.Cout % 32 == 0) else None
     if Mo == 0:
-        return out
+        return (out, out_h2) if twin else out
     ws = workspace(dev)
     d = ConvDesc()
     d.in_, d.w, d.out = ptr(feats), ptr(pc.w), ptr(out)
@@ -145,9 +154,18 @@ def sparse_conv(feats, Cin, pc, table, relu=True, res=None, out=None, out_rows=N
     d.Xi = feats.shape[0]          # number of input rows (lets coocc_conv_fwd pick the pipelined row-table kernel)
     d.ksize, d.stride, d.pad = 1, 1, 0
     d.relu, d.res_mode, d.splitk, d.tile_hint = int(relu), (1 if res is not None else 0), 1, TILE_HINT
-    with _lib.TIMER.region("k_conv<sparse table %d->%d>" % (Cin, pc.Cout), 2.0 * Mo * Cin * pc.Cout * taps):
+    kname = "k_conv"
+    if h2:
+        if feats_h2 is None:
+            feats_h2 = torch.empty(feats.shape[0], Cin, device=dev, dtype=_F32)
+            call("coocc_rows_to_h2", ptr(feats), feats.shape[1], feats.shape[0], Cin, 1.0, ptr(feats_h2))
+        d.in_, d.in_stride, d.w = ptr(feats_h2), Cin, ptr(pc.h2_pack())
+        d.mfma_dtype, d.alpha, kname = 3, 1.0, "k_gemm_h2w"
+        if out_h2 is not None:
+            d.out_h2_twin = ptr(out_h2)
+    with _lib.TIMER.region("%s<sparse table %d->%d>" % (kname, Cin, pc.Cout), 2.0 * Mo * Cin * pc.Cout * taps):
         _lib.conv_fwd(d, pc.w.device)
-    return out
+    return (out, out_h2) if twin else out
 
 
 class _SpConv(nn.Module):
@@ -250,17 +268,20 @@ class _SparseEncoderBase(nn.Module):
             x = torch.cat([x, x.new_zeros(M, cin_p - Cin)], 1).contiguous()
         cur = SparseRows(None, coors, self.sparse_shape_xyz[::-1])
         f = _gn_rows(sparse_conv(x, cin_p, p["inp"], cur.subm_table("in"), relu=False), self.conv_input[1])
+        fh = None                      # H2 copy of f when the layer that made f wrote one (split-f16 engine)
         for si, ps in enumerate(p["stages"]):
             for bi, item in enumerate(ps):
                 if item[0] == "down":
                     coors_o, shape_o, table = cur.downsample(3, 2, 1)
-                    f = sparse_conv(f, f.shape[1], item[1], table, relu=True)
+                    f, fh = sparse_conv(f, f.shape[1], item[1], table, relu=True, feats_h2=fh, twin=True)
                     cur = SparseRows(None, coors_o, shape_o)
                 else:
                     tb = cur.subm_table("res%d" % si)
-                    h = sparse_conv(f, f.shape[1], item[1], tb, relu=True)
-                    f = sparse_conv(h, h.shape[1], item[2], tb, relu=True, res=f)
-        f = _gn_rows(sparse_conv(f, f.shape[1], p["out"], cur.subm_table("out"), relu=False), self.conv_out[1])
+                    h, hh = sparse_conv(f, f.shape[1], item[1], tb, relu=True, feats_h2=fh, twin=True)
+                    f, fh = sparse_conv(h, h.shape[1], item[2], tb, relu=True, res=f, feats_h2=hh, twin=True)
+        f = _gn_rows(sparse_conv(f, f.shape[1], p["out"], cur.subm_table("out"), relu=False, feats_h2=fh), self.conv_out[1])
+        # (the split-f16 range guard is sticky: the flag a layer here may raise is read at the detector's next host read,
+        # core.check_h2_overflow -- head.py / serving.py)
         cur.feats = f
         # dense().permute(0,1,4,3,2): [1, C, W, H, D] = (x, y, z); channels-last rows (x*H + y)*D + z
         D, H, W = cur.shape

@@ -20,7 +20,9 @@ reference's call):
 bit-identical to sequential eager calls (tests/test_gpu_serving.py).
 """
 import collections
+import os
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import torch
@@ -94,6 +96,9 @@ class ServingPipeline:
         self.tpool = ThreadPoolExecutor(self.ahead)
         self.fallbacks = 0
         self.dense_ev = []
+        # COOCC_SERVING_TRACE=1: host timestamps of every stage of every ticket (tools/serving_trace.py prints them next to the
+        # device-side event times of `time_dense`)
+        self.trace = [] if os.environ.get("COOCC_SERVING_TRACE", "0") == "1" else None
         self._lock = threading.Lock()
         self._pending = collections.deque()    # tickets whose search has not been dispatched yet (their slot is still in use)
         self._queue = collections.deque()      # tickets with a dispatched search, dense stage not issued yet
@@ -131,9 +136,14 @@ class ServingPipeline:
             st["gemo"].copy_(fr["gemo"], non_blocking=True)
 
     # ------------------------------------------------------------------ search stage (helper threads)
+    def _mark(self, t, tag):
+        if self.trace is not None:
+            self.trace.append((t.index, tag, time.perf_counter()))
+
     def _search(self, t):
         k, fr = t.slot, t.frame
         torch.cuda.set_device(self.dev)
+        self._mark(t, "search_begin")
         st = self.search_streams[k]
         with torch.cuda.stream(st), torch.no_grad():
             st.wait_event(t.ready)
@@ -146,6 +156,7 @@ class ServingPipeline:
                 if v.is_cuda:
                     v.record_stream(st)            # allocated on the caller's stream, read by this one
             self._copy_in(k, fr)
+            self._mark(t, "search_native")
             slot = self.slots[k]
             if fr.get("depth") is not None:
                 sr = cg.search_into_slot(self.model, slot, fr["depth"], fr["ctx"], fr["cams"], fr["pts"])
@@ -161,6 +172,7 @@ class ServingPipeline:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
                 t.events = (e0, e1)
+        self._mark(t, "search_end")
         return sr
 
     # ------------------------------------------------------------------ capture
@@ -203,6 +215,7 @@ class ServingPipeline:
                         break
                     self._pending.popleft()
                     self._dispatched_of_slot[t.slot] += 1
+                    self._mark(t, "dispatch")
                     t.search = self.tpool.submit(self._search, t)
                     self._queue.append(t)
                 head = self._queue[0] if self._queue else None
@@ -212,7 +225,9 @@ class ServingPipeline:
             if not (must or head.search.done()):
                 return
             sr = head.search.result()              # blocks only when the caller asked for this ticket
+            self._mark(head, "issue_begin")
             self._issue(head, sr)
+            self._mark(head, "issue_end")
             with self._lock:
                 self._queue.popleft()
                 self._issued += 1
@@ -249,7 +264,7 @@ class ServingPipeline:
             if self.time_dense:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
-                self.dense_ev.append((e0, e1))
+                self.dense_ev.append((e0, e1, t.index, t.events))
             if t.copy:                             # own copies of the tensors (lists -- the capacity-sized fine outputs -- by reference)
                 out = {kk: (v.clone() if torch.is_tensor(v) else (v.as_ncdhw().clone() if isinstance(v, core.Rows) else v))
                        for kk, v in out.items()}
