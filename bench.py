@@ -631,7 +631,8 @@ def train_main(args, model, dev, rank, world, seen_world, backend_name):
     line = dict(metric="training samples/sec (hot path forward + backward), 200x200x16 grid", value=round(world * args.steps / dt, 4), unit="samples/s",
                 n_gpus=world, world_size_seen_by_backend=seen_world, backend=backend_name, steps=args.steps, warmup=args.warmup,
                 ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
-                dtype=("f32 (forward Winograd GEMMs: split-f16 products, fp32 accumulate; dgrad / wgrad: fp32 MFMA)" if ag.TRAIN_H2 and core.CONV_ENGINE == "h2" else "f32"),
+                dtype=(("f32 (forward%s GEMMs: split-f16 products, fp32 accumulate; %swgrad: fp32 MFMA)" % ((" / dgrad", "") if ag.TRAIN_H2_DGRAD else ("", "dgrad / ")))
+                       if ag.TRAIN_H2 and core.CONV_ENGINE == "h2" else "f32"),
                 data="synthetic",
                 config=dict(workload=("coocc_multi_r50_256x704 hot path, TRAINING step" if args.config == "r50" else args.config + " training step"),
                             fused_grid="x".join(map(str, c["grid"])) + "x%d" % c["C"], cams=c["ncam"], knum=c["knum"],

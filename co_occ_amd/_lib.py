@@ -110,6 +110,7 @@ SIGNATURES = {
     "coocc_conv_pack_weights_dev": (L, [P, I, I, I, I, P, P]),
     "coocc_wino_pack_weights_dev": (L, [P, I, I, I, I, P, P]),
     "coocc_wino_pack_weights_h2_dev": (L, [P, I, I, I, I, P, P]),
+    "coocc_conv_pack_weights_h2_dev": (L, [P, I, I, I, I, P, P]),
     "coocc_wino_gradout": (I, [P, I, I, I, I, I, I, I, P, L, P]),
     "coocc_wino_ztap_table": (I, [L, I, P, P]),
     "coocc_wino_wgrad": (I, [P, P, L, I, I, I, I, P, P, I, P, L, P]),

@@ -24,12 +24,16 @@ TRAIN_WINO_WGRAD = TRAIN_WINO and __import__("os").environ.get("COOCC_TRAIN_WINO
 # Winograd forward / dgrad GEMMs of the training path on the split-f16 engine (weights transformed + split on the device every
 # step, coocc_wino_pack_weights_h2_dev); 0: the fp32-MFMA kernels of rounds 1-3
 TRAIN_H2 = __import__("os").environ.get("COOCC_TRAIN_H2", "1") != "0"
-# ... and the dgrad GEMMs too.  Off by default: the operand of a dgrad GEMM is a GRADIENT, whose magnitude is set by the loss
-# scale, not by BatchNorm -- below 6.1e-5 an f16 is subnormal, so at |dy| ~ 1e-6 the hi half keeps a handful of bits and the split
-# ~12 instead of 22 (arithmetic of the format, not a measurement).  1 is safe when the loss is scaled so that max|dy| stays in
-# [1e-3, 1e3] (the Winograd transform scales by 1/8 and amplifies by up to 100).
+# ... and the dgrad GEMMs too.  Off by default: the operand of a dgrad GEMM is a GRADIENT, whose magnitude is set by the loss scale,
+# not by BatchNorm, and an f16 is subnormal below 6.1e-5: with a mean-reduced loss over 640 k voxels |dy| ~ 1e-6 and the hi half
+# alone keeps a handful of bits (the pair ~12 instead of 22; arithmetic of the format).  COOCC_TRAIN_H2_DGRAD=1 turns it on with the
+# gradient operand pre-scaled by the fixed power of two COOCC_TRAIN_H2_DGRAD_SCALE (exact; undone by the GEMM's alpha): 4096 puts
+# |dy| in [1e-7, 0.6] into the range where the split keeps 17-22 bits and trips the engine's range guard -- an error, not a wrong
+# number -- above 0.6 (32768 / (4096 x the F(4x4) transform's 100/8)); 1 (default) suits |dy| in [1e-3, 1e3].  A per-tensor
+# dynamic scale would remove the choice; measured gain of the switch at configs[1]: 36.5 -> 33.8 ms per step (profiles/r4_bench_train*.json).
 TRAIN_H2_DGRAD = TRAIN_H2 and __import__("os").environ.get("COOCC_TRAIN_H2_DGRAD", "0") != "0"
-
+TRAIN_H2_DGRAD_SCALE = float(__import__("os").environ.get("COOCC_TRAIN_H2_DGRAD_SCALE", "1"))
+assert TRAIN_H2_DGRAD_SCALE > 0 and __import__("math").frexp(TRAIN_H2_DGRAD_SCALE)[0] == 0.5, "COOCC_TRAIN_H2_DGRAD_SCALE: a power of two"
 
 def _pad4(n):
     return (n + 3) // 4 * 4
@@ -101,6 +105,31 @@ def pack_weights_dev(w, Cout, Cin, taps, mode):
     return packed
 
 
+def pack_weights_h2_dev(w, Cout, Cin, taps, mode):
+    """``pack_weights_dev`` for the split-f16 engine (coocc_conv_pack_weights_h2_dev)."""
+    lib = _lib.load()
+    n = lib.coocc_conv_pack_weights_h2_dev(None, Cout, Cin, taps, mode, None, None)
+    if n < 0:
+        _lib.check(int(n))
+    packed = torch.empty(n, dtype=_F32, device=w.device)
+    n = lib.coocc_conv_pack_weights_h2_dev(ptr(w), Cout, Cin, taps, mode, ptr(packed), _lib.stream(w.device))
+    if n < 0:
+        _lib.check(int(n))
+    return packed
+
+
+def _h2_direct(K, flops):
+    """Direct-form GEMMs of the training path on the split-f16 engine: K % 32 == 0 and enough work to pay for the operand pass."""
+    from . import core
+    return TRAIN_H2 and core.CONV_ENGINE == "h2" and core.H2_DIRECT and K % 32 == 0 and flops >= core.H2_DIRECT_MIN_FLOPS
+
+
+def _rows_h2(x2d, C, scale=1.0):
+    xh = torch.empty(x2d.shape[0], C, device=x2d.device, dtype=_F32)
+    call("coocc_rows_to_h2", ptr(x2d), x2d.shape[1], x2d.shape[0], C, float(scale), ptr(xh))
+    return xh
+
+
 class _DevWinoF32:
     """What core.conv_rows_wino needs of a PackedConv, with the Winograd packs transformed on the device from the live
     parameter (training re-packs every step): forward packs, or (``dgrad``) the packs of dx = conv(dy, W')."""
@@ -111,6 +140,7 @@ class _DevWinoF32:
         self.scale, self.bias = scale, bias
         self._w_raw, self.wino_tile = True, None
         self._w5, self._dgrad, self._packs = w5, int(bool(dgrad)), {}
+        self.dgrad_operand = bool(dgrad)      # split-f16 engine: the input rows are gradients (pre-scaled by TRAIN_H2_DGRAD_SCALE)
 
     def wino_pack(self, tile):
         if tile not in self._packs:
@@ -128,6 +158,10 @@ class _DevWinoF32:
 
 
 class _DevWino(_DevWinoF32):
+    @property
+    def operand_scale(self):
+        return TRAIN_H2_DGRAD_SCALE if self.dgrad_operand else 1.0
+
     def wino_h2_pack(self, tile):
         """The same packs for the split-f16 engine (csrc/gemm_h2.hip), transformed + split on the device from the live parameter:
         training's Winograd forward / dgrad GEMMs run on the f16 matrix cores like inference's (core.h2_capable)."""
@@ -205,7 +239,8 @@ def _zrange(Zin, Zout, stride, pad):
 
 
 def _conv_launch(x2d, in_C, w_packed, out2d, Cout, taps, geom_in, geom_out, ksize, stride, pad, scale, shift, res2d, relu,
-                 table=None, tag="conv_fwd", out_rows=None, kdims=None):
+                 table=None, tag="conv_fwd", out_rows=None, kdims=None, h2_alpha=None):
+    """``h2_alpha``: x2d holds H2 rows (coocc_rows_to_h2, operand scale 1 / h2_alpha) and w_packed an H2 pack: split-f16 engine."""
     d = ConvDesc()
     ws = workspace(x2d.device)
     d.in_, d.w, d.out = ptr(x2d), ptr(w_packed), ptr(out2d)
@@ -225,6 +260,8 @@ def _conv_launch(x2d, in_C, w_packed, out2d, Cout, taps, geom_in, geom_out, ksiz
         d.kx, d.ky, d.kz, d.px, d.py, d.pz = kdims
     d.relu, d.res_mode, d.splitk = int(relu), (1 if res2d is not None else 0), 0
     d.tile_hint = TILE_HINT
+    if h2_alpha is not None:
+        d.in_stride, d.mfma_dtype, d.alpha, tag = in_C, 3, float(h2_alpha), "k_gemm_h2 " + tag
     with _lib.TIMER.region(tag, 2.0 * d.M * in_C * Cout * taps):
         _lib.conv_fwd(d, x2d.device)
 
@@ -255,8 +292,12 @@ class ConvRowsFn(torch.autograd.Function):
                 if hi - lo < 2:         # z taps that only read padding are dropped (exact)
                     wsub = w_.view(Cout, Cin, 3, 3, 3)[..., lo:hi + 1].contiguous().view(Cout, Cin, -1)
                     nt, kd = wsub.shape[2], (3, 3, hi - lo + 1, pad, pad, pad - lo)
-            wp = pack_weights_dev(wsub, Cout, Cin, nt, 0)
-            _conv_launch(x2d, Cin, wp, out, Cout, nt, geom, geom_out, ksize, stride, pad, scale, eff_shift, res2d, relu, kdims=kd)
+            if _h2_direct(Cin, 2.0 * out.shape[0] * Cin * Cout * nt):
+                _conv_launch(_rows_h2(x2d, Cin), Cin, pack_weights_h2_dev(wsub, Cout, Cin, nt, 0), out, Cout, nt, geom, geom_out, ksize,
+                             stride, pad, scale, eff_shift, res2d, relu, kdims=kd, h2_alpha=1.0)
+            else:
+                wp = pack_weights_dev(wsub, Cout, Cin, nt, 0)
+                _conv_launch(x2d, Cin, wp, out, Cout, nt, geom, geom_out, ksize, stride, pad, scale, eff_shift, res2d, relu, kdims=kd)
         ctx.save_for_backward(x2d, weight, out, scale if scale is not None else torch.empty(0, device=x2d.device))
         ctx.cfg = (geom, geom_out, ksize, stride, pad, relu, bias is not None, res2d is not None, scale is not None)
         return out
@@ -297,9 +338,15 @@ class ConvRowsFn(torch.autograd.Function):
                     if hi - lo < 2:
                         wsub = weight.detach().float().view(Cout, Cin, 3, 3, 3)[..., 2 - hi:2 - lo + 1].contiguous().view(Cout, Cin, -1)
                         nt, kd = wsub.shape[2], (3, 3, hi - lo + 1, pd, pd, pd - lo)
-                wp = pack_weights_dev(wsub, Cout, Cin, nt, 2)
-                _conv_launch(dacc, Cp, wp, dx, Cin, nt, geom_out, geom, ksize, 1, pd, None, None, None, False,
-                             tag="conv_dgrad", kdims=kd)
+                if TRAIN_H2_DGRAD and Cp == Cout and _h2_direct(Cout, 2.0 * Mi * Cin * Cout * nt):
+                    # the gradient operand pre-scaled by a power of two (TRAIN_H2_DGRAD_SCALE above), undone by alpha
+                    _conv_launch(_rows_h2(dacc, Cout, TRAIN_H2_DGRAD_SCALE), Cout, pack_weights_h2_dev(wsub, Cout, Cin, nt, 2), dx, Cin,
+                                 nt, geom_out, geom, ksize, 1, pd, None, None, None, False, tag="conv_dgrad", kdims=kd,
+                                 h2_alpha=1.0 / TRAIN_H2_DGRAD_SCALE)
+                else:
+                    wp = pack_weights_dev(wsub, Cout, Cin, nt, 2)
+                    _conv_launch(dacc, Cp, wp, dx, Cin, nt, geom_out, geom, ksize, 1, pd, None, None, None, False,
+                                 tag="conv_dgrad", kdims=kd)
             else:
                 dx.zero_()          # voxels no output reads (and classes without taps) get a zero gradient
                 for rows_c, taps_c, table_c in dgrad_classes(dev, B, Xi, Yi, Zi, ksize, stride, pad):

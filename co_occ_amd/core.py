@@ -496,7 +496,7 @@ def conv_rows_wino(x, pc, out, relu, res, plan, in_ranges=None, twin=False):
     Mb = _wino_buffer(dev, "M", pts * G * pc.Cout)
     h2 = h2_capable(pc) and all(c % 32 == 0 for _, c in (in_ranges or []))
     wp = pc.wino_h2_pack(tile) if h2 else pc.wino_pack(tile)
-    vscale = H2_WINO_SCALE[tile]
+    vscale = H2_WINO_SCALE[tile] * getattr(pc, "operand_scale", 1.0)      # powers of two: exact, undone by the GEMM's alpha
     with TIMER.region("k_wino_in", 4.0 * x.V * pc.Cin + 4.0 * pts * rows * pc.Cin):
         if in_ranges is None and not h2:
             call("coocc_wino_input", x.data(), x.stride, x.B, x.X, x.Y, x.Z, pc.Cin, tile, ptr(V), G)

@@ -3,6 +3,7 @@
 // torch autograd over its eager ops (index_put / cumprod / interpolate backward); here each is one kernel.
 // Index-producing steps (FPS, ball query, top-K, assignment, voxel keys) are non-differentiable.
 #include "common.h"
+#include "colreduce.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -727,6 +728,30 @@ extern "C" int coocc_groupnorm_nhwc_bwd(const float* x, const float* y, const fl
 // ------------------------------------------------------------------ BatchNorm with batch statistics (training mode)
 // Rows [M, C] (channels-last voxels): per-channel mean / biased variance over the M rows, deterministic two-pass column
 // reductions (256-row partials, then one pass over the partials in fp64).
+__global__ __launch_bounds__(256) void k_bn_part4(const float* __restrict__ x, int stride, int M, int C, double* __restrict__ part) {
+  const int q = C >> 2, cq = threadIdx.x % q, r = threadIdx.x / q, R = 256 / q;
+  const int m0 = blockIdx.x * COL_ROWS, m1 = min(M, m0 + COL_ROWS);
+  double acc[2][4] = {};
+  for (int m = m0 + r; m < m1; m += R) {
+    const bn_f4 v = *(const bn_f4*)(x + (size_t)m * stride + 4 * cq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[0][e] += v[e]; acc[1][e] += (double)v[e] * v[e]; }
+  }
+  col_block_reduce<2>(acc, q, r, cq, C, part);
+}
+
+__global__ __launch_bounds__(256) void k_bn_final4(const double* __restrict__ part, int nparts, int M, int C, float* __restrict__ mean,
+                                                    float* __restrict__ var) {
+  double t[2];
+  col_final<2>(part, nparts, C, t);
+  const int c = blockIdx.x * 4 + (threadIdx.x & 3);
+  if ((threadIdx.x >> 2) == 0 && c < C) {
+    const double mu = t[0] / M, v = t[1] / M - mu * mu;
+    mean[c] = (float)mu;
+    var[c] = (float)(v > 0 ? v : 0);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_bn_part(const float* __restrict__ x, int stride, int M, int C, double* __restrict__ part) {
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
@@ -751,11 +776,17 @@ __global__ __launch_bounds__(256) void k_bn_final(const double* __restrict__ par
 extern "C" int coocc_bn_stats(const float* x, int stride, int M, int C, float* mean, float* var, void* ws, size_t ws_bytes,
                               void* stream) {
   COOCC_CHECK_ARG(x && mean && var && M > 0 && C > 0 && stride >= C, "bn_stats: bad args");
-  const int nparts = (M + 255) / 256;
+  const bool fast = col_fast(C) && stride % 4 == 0 && ((uintptr_t)x & 15) == 0;
+  const int nparts = fast ? cdiv(M, COL_ROWS) : (M + 255) / 256;
   COOCC_CHECK_ARG(ws && ws_bytes >= sizeof(double) * 2 * (size_t)nparts * C, "bn_stats: workspace too small");
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(k_bn_part, dim3(nparts, cdiv(C, 256)), dim3(256), 0, s, x, stride, M, C, (double*)ws);
-  hipLaunchKernelGGL(k_bn_final, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)ws, nparts, M, C, mean, var);
+  if (fast) {
+    hipLaunchKernelGGL(k_bn_part4, dim3(nparts), dim3(256), 0, s, x, stride, M, C, (double*)ws);
+    hipLaunchKernelGGL(k_bn_final4, dim3(cdiv(C, 4)), dim3(256), 0, s, (const double*)ws, nparts, M, C, mean, var);
+  } else {
+    hipLaunchKernelGGL(k_bn_part, dim3(nparts, cdiv(C, 256)), dim3(256), 0, s, x, stride, M, C, (double*)ws);
+    hipLaunchKernelGGL(k_bn_final, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)ws, nparts, M, C, mean, var);
+  }
   COOCC_LAUNCH_CHECK("bn_stats");
   return COOCC_OK;
 }
@@ -803,6 +834,39 @@ __global__ __launch_bounds__(256) void k_bn_bwd_part(const float* __restrict__ x
   part[((size_t)blockIdx.x * C + c) * 2 + 1] = b;
 }
 
+__global__ __launch_bounds__(256) void k_bn_bwd_part4(const float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ dy, int M, int C, const float* __restrict__ mean,
+                                                       const float* __restrict__ var, float eps, int relu, double* __restrict__ part) {
+  const int q = C >> 2, cq = threadIdx.x % q, r = threadIdx.x / q, R = 256 / q;
+  const int m0 = blockIdx.x * COL_ROWS, m1 = min(M, m0 + COL_ROWS);
+  const bn_f4 mu = *(const bn_f4*)(mean + 4 * cq), vr = *(const bn_f4*)(var + 4 * cq);
+  float rstd[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) rstd[e] = 1.f / sqrtf(vr[e] + eps);
+  double acc[2][4] = {};
+  for (int m = m0 + r; m < m1; m += R) {
+    const size_t i = (size_t)m * C + 4 * cq;
+    const bn_f4 g4 = *(const bn_f4*)(dy + i), x4 = *(const bn_f4*)(x + i);
+    bn_f4 y4 = {1.f, 1.f, 1.f, 1.f};
+    if (relu) y4 = *(const bn_f4*)(y + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g = (relu && !(y4[e] > 0.f)) ? 0.f : g4[e];
+      acc[0][e] += (double)g * ((x4[e] - mu[e]) * rstd[e]);
+      acc[1][e] += g;
+    }
+  }
+  col_block_reduce<2>(acc, q, r, cq, C, part);
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_final4(const double* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta) {
+  double t[2];
+  col_final<2>(part, nparts, C, t);
+  const int c = blockIdx.x * 4 + (threadIdx.x & 3);
+  if ((threadIdx.x >> 2) == 0 && c < C) { dgamma[c] = (float)t[0]; dbeta[c] = (float)t[1]; }
+}
+
 __global__ __launch_bounds__(256) void k_bn_bwd_final(const double* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
                                                        float* __restrict__ dbeta) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -836,11 +900,17 @@ extern "C" int coocc_bn_backward_sums(const float* x, const float* y, const floa
                                       const float* var, float eps, int relu, float* dgamma, float* dbeta, void* ws,
                                       size_t ws_bytes, void* stream) {
   COOCC_CHECK_ARG(x && y && dy && mean && var && dgamma && dbeta && M > 0 && C > 0, "bn_backward_sums: bad args");
-  const int nparts = (M + 255) / 256;
+  const bool fast = col_fast(C) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)dy | (uintptr_t)mean | (uintptr_t)var) & 15) == 0;
+  const int nparts = fast ? cdiv(M, COL_ROWS) : (M + 255) / 256;
   COOCC_CHECK_ARG(ws && ws_bytes >= sizeof(double) * 2 * (size_t)nparts * C, "bn_backward_sums: workspace too small");
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(k_bn_bwd_part, dim3(nparts, cdiv(C, 256)), dim3(256), 0, s, x, y, dy, M, C, mean, var, eps, relu, (double*)ws);
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)ws, nparts, C, dgamma, dbeta);
+  if (fast) {
+    hipLaunchKernelGGL(k_bn_bwd_part4, dim3(nparts), dim3(256), 0, s, x, y, dy, M, C, mean, var, eps, relu, (double*)ws);
+    hipLaunchKernelGGL(k_bn_bwd_final4, dim3(cdiv(C, 4)), dim3(256), 0, s, (const double*)ws, nparts, C, dgamma, dbeta);
+  } else {
+    hipLaunchKernelGGL(k_bn_bwd_part, dim3(nparts, cdiv(C, 256)), dim3(256), 0, s, x, y, dy, M, C, mean, var, eps, relu, (double*)ws);
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)ws, nparts, C, dgamma, dbeta);
+  }
   COOCC_LAUNCH_CHECK("bn_backward_sums");
   return COOCC_OK;
 }

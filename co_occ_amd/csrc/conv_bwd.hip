@@ -8,6 +8,8 @@
 //             re-packed weights: stride 1 = taps flipped (mode 2); stride 2 = a row table o(i,t) (mode 3)
 //   wgrad     dW[n][c][t] = sum_o in[src(o,t)][c] dacc[o][n]       -> k_wgrad below (K = M on the MFMA)
 #include "conv_layout.h"
+#include "colreduce.h"
+#include "conv_k.h"
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -49,6 +51,48 @@ extern "C" int64_t coocc_conv_pack_weights_dev(const float* w, int Cout, int Cin
                      Npad, packed);
   if (hipGetLastError() != hipSuccess) return coocc_set_error(COOCC_EHIP, "pack_weights_dev: launch failed");
   return total;
+}
+
+// The same packs for the split-f16 engine (csrc/gemm_h2.hip; layout of core.PackedConv._h2_layout):
+// [(K / 32 chunk, tap)][Npad / 32][2 k16 steps][hi | lo][64 lanes][8 f16], lane l of step s holds k = 32 chunk + 16 s + 8 (l >> 5) + 0..7
+// of column 32 nt + (l & 31); hi = f16(w), lo = f16((w - hi) 2^11).  Training re-packs from the live parameter every step, so its
+// direct (strided, 1x1x1, small-grid) forward and stride-1 dgrad GEMMs can run on the f16 matrix cores like inference's.
+__global__ __launch_bounds__(256) void k_pack_weights_h2(const float* __restrict__ w, int Cout, int Cin, int taps, int mode, int Npad,
+                                                          _Float16* __restrict__ packed, int* __restrict__ flag) {
+  const size_t total = (size_t)Cout * Cin * taps;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int n, c, t;
+  if (mode == 1) { c = (int)(i % Cin); size_t r = i / Cin; t = (int)(r % taps); n = (int)(r / taps); }
+  else { t = (int)(i % taps); size_t r = i / taps; c = (int)(r % Cin); n = (int)(r / Cin); }
+  const float v = w[i];
+  const int kk = mode >= 2 ? n : c, nn = mode >= 2 ? c : n, tt = mode == 2 ? taps - 1 - t : t;
+  const int chunk = kk >> 5, k32 = kk & 31, sidx = k32 >> 4, hf = (k32 >> 3) & 1, e = k32 & 7;
+  const int nt = nn >> 5, li = nn & 31;
+  _Float16* o = packed + ((((size_t)chunk * taps + tt) * (Npad >> 5) + nt) * 2 + sidx) * 2 * 512 + (size_t)(hf * 32 + li) * 8 + e;
+  const _Float16 hi = (_Float16)v;
+  o[0] = hi;
+  o[512] = (_Float16)((v - (float)hi) * 2048.0f);       // exact in fp32: v - hi has at most 13 significant bits
+  if (flag && !(fabsf(v) < 32768.0f)) *(volatile int*)flag = 1;
+}
+
+extern "C" int64_t coocc_conv_pack_weights_h2_dev(const float* w, int Cout, int Cin, int taps, int mode, void* packed, void* stream) {
+  if (Cout <= 0 || Cin <= 0 || taps <= 0 || mode < 0 || mode > 3) return coocc_set_error(COOCC_EINVAL, "pack_weights_h2_dev: bad args");
+  const int N = mode >= 2 ? Cin : Cout, K = mode >= 2 ? Cout : Cin;
+  if (K % 32) return coocc_set_error(COOCC_EINVAL, "pack_weights_h2_dev: the GEMM's K (Cin forward, Cout dgrad) must be a multiple of 32");
+  const int Npad = (N + NPAD_TO - 1) / NPAD_TO * NPAD_TO;
+  const int64_t total_floats = (int64_t)taps * (K / 32) * Npad * 32;          // 4 bytes (hi + lo) per (k, n, tap)
+  if (!packed) return total_floats;
+  if (!w) return coocc_set_error(COOCC_EINVAL, "pack_weights_h2_dev: null weights");
+  hipStream_t s = as_stream(stream);
+  if (Npad != N && hipMemsetAsync(packed, 0, (size_t)total_floats * 4, s) != hipSuccess)
+    return coocc_set_error(COOCC_EHIP, "pack_weights_h2_dev: memset failed");
+  int* flag = nullptr;
+  if (coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
+  hipLaunchKernelGGL(k_pack_weights_h2, dim3(cdiv((long long)Cout * Cin * taps, 256)), dim3(256), 0, s, w, Cout, Cin, taps, mode, Npad,
+                     (_Float16*)packed, flag);
+  if (hipGetLastError() != hipSuccess) return coocc_set_error(COOCC_EHIP, "pack_weights_h2_dev: launch failed");
+  return total_floats;
 }
 
 // ------------------------------------------------------------------ row tables
@@ -153,6 +197,29 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
   dbias[c] = accumulate ? dbias[c] + s : s;
 }
 
+__global__ __launch_bounds__(256) void k_colsum_part4(const float* __restrict__ dout, int dout_stride, const float* __restrict__ out,
+                                                       int out_stride, int M, int C, int relu, double* __restrict__ part) {
+  const int q = C >> 2, cq = threadIdx.x % q, r = threadIdx.x / q, R = 256 / q;
+  const int m0 = blockIdx.x * COL_ROWS, m1 = min(M, m0 + COL_ROWS);
+  double acc[1][4] = {};
+  for (int m = m0 + r; m < m1; m += R) {
+    const bn_f4 g4 = *(const bn_f4*)(dout + (size_t)m * dout_stride + 4 * cq);
+    bn_f4 y4 = {1.f, 1.f, 1.f, 1.f};
+    if (relu) y4 = *(const bn_f4*)(out + (size_t)m * out_stride + 4 * cq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[0][e] += (relu && !(y4[e] > 0.f)) ? 0.f : g4[e];
+  }
+  col_block_reduce<1>(acc, q, r, cq, C, part);
+}
+
+__global__ __launch_bounds__(256) void k_colsum_final4(const double* __restrict__ part, int nparts, int C, float* __restrict__ dbias,
+                                                        int accumulate) {
+  double t[1];
+  col_final<1>(part, nparts, C, t);
+  const int c = blockIdx.x * 4 + (threadIdx.x & 3);
+  if ((threadIdx.x >> 2) == 0 && c < C) dbias[c] = accumulate ? dbias[c] + (float)t[0] : (float)t[0];
+}
+
 extern "C" int coocc_conv_epilogue_bwd(const float* dout, int dout_stride, const float* out, int out_stride,
                                        const float* scale, int M, int C, int relu, float* dacc, int dacc_stride,
                                        float* dres, int dres_stride, int dres_accumulate, float* dbias,
@@ -165,11 +232,20 @@ extern "C" int coocc_conv_epilogue_bwd(const float* dout, int dout_stride, const
     COOCC_LAUNCH_CHECK("k_epilogue_bwd");
   }
   if (dbias) {
-    const int nparts = (M + 255) / 256;
-    COOCC_CHECK_ARG(ws && ws_floats >= (int64_t)nparts * C, "conv_epilogue_bwd: workspace too small for dbias");
-    hipLaunchKernelGGL(k_colsum_part, dim3(nparts, cdiv(C, 256)), dim3(256), 0, s, dout, dout_stride, out, out_stride, M, C,
-                       relu, ws);
-    hipLaunchKernelGGL(k_colsum_final, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, nparts, C, dbias, dbias_accumulate);
+    const int nparts4 = cdiv(M, COL_ROWS);
+    const bool fast = col_fast(C) && dout_stride % 4 == 0 && (!relu || out_stride % 4 == 0) &&
+                      (((uintptr_t)dout | (uintptr_t)(relu ? out : nullptr) | (uintptr_t)ws) & 15) == 0 &&
+                      ws && ws_floats >= 2 * (int64_t)nparts4 * C;
+    if (fast) {          // fp64 partials, every lane busy (colreduce.h)
+      hipLaunchKernelGGL(k_colsum_part4, dim3(nparts4), dim3(256), 0, s, dout, dout_stride, out, out_stride, M, C, relu, (double*)ws);
+      hipLaunchKernelGGL(k_colsum_final4, dim3(cdiv(C, 4)), dim3(256), 0, s, (const double*)ws, nparts4, C, dbias, dbias_accumulate);
+    } else {
+      const int nparts = (M + 255) / 256;
+      COOCC_CHECK_ARG(ws && ws_floats >= (int64_t)nparts * C, "conv_epilogue_bwd: workspace too small for dbias");
+      hipLaunchKernelGGL(k_colsum_part, dim3(nparts, cdiv(C, 256)), dim3(256), 0, s, dout, dout_stride, out, out_stride, M, C,
+                         relu, ws);
+      hipLaunchKernelGGL(k_colsum_final, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, nparts, C, dbias, dbias_accumulate);
+    }
     COOCC_LAUNCH_CHECK("k_colsum");
   }
   return COOCC_OK;

@@ -308,6 +308,11 @@ int coocc_render_heads_h2(const void* x_h2, int V, int Cin, int width, const voi
  * the live parameter every step; the reference trains these layers through cuDNN, resnet3d.py:34-64) run its Winograd forward and
  * dgrad GEMMs on the f16 matrix cores. */
 int64_t coocc_wino_pack_weights_h2_dev(const float* w, int Cout, int Cin, int tile, int dgrad, void* packed, void* stream);
+/* coocc_conv_pack_weights_dev (same `mode`s: 0 forward, 1 tap-major Linear, 2 dgrad with flipped taps, 3 dgrad unflipped) for the
+ * split-f16 engine: the direct-form H2 pack [(K chunk, tap)][roundup(N,128)/32][2 k16 steps][hi | lo][64 lanes][8 f16] made on the
+ * device from the live parameter -- the strided / 1x1x1 / small-grid layers of the TRAINING path (resnet3d.py:34-64, fpn3d.py:70-106
+ * under cuDNN upstream) on the f16 matrix cores.  K (Cin forward, Cout dgrad) % 32 == 0.  packed == NULL: size in 4-byte units. */
+int64_t coocc_conv_pack_weights_h2_dev(const float* w, int Cout, int Cin, int taps, int mode, void* packed, void* stream);
 /* Range guard of the split-f16 engine (resnet3d.py / fpn3d.py / occ_head.py convolutions are fp32 upstream and have no such
  * limit): every kernel that writes a 16-bit operand (H2 rows, f16 twins, the Winograd-domain V) raises a host-visible flag when a
  * value reaches half the f16 range (|v| >= 32768 after the writer's own scale; NaN counts).  Returns the flag (0 / 1) and clears it

@@ -190,3 +190,54 @@ def test_fused_render_heads_equal_layerwise_path_and_torch(dev, monkeypatch, V, 
     assert torch.equal(act[:, 0], fused[:, 0])
     assert_close(act.cpu(), act_l.cpu(), tol=2e-5, what="activated tables")
     assert torch.equal(donly[:, 0], fused[:, 0]) and float(donly[:, 1:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_device_made_direct_h2_pack_equals_host_layout(dev, mode):
+    """coocc_conv_pack_weights_h2_dev (training re-packs from the live parameter every step) writes exactly the pack the host
+    builds for inference (core.PackedConv._h2_layout): forward (mode 0) and the stride-1 dgrad form (mode 2: roles of Cin / Cout
+    swapped, taps flipped)."""
+    from co_occ_amd.autograd import pack_weights_h2_dev
+    Cout, Cin, taps = 96, 64, 27
+    g = torch.Generator().manual_seed(5 + mode)
+    w = torch.randn(Cout, Cin, taps, generator=g) * 0.1
+    got = pack_weights_h2_dev(w.to(dev), Cout, Cin, taps, mode).cpu().view(torch.int16).flatten()
+    ref_w = w if mode == 0 else w.permute(1, 0, 2).flip(2)          # [N, K, taps]
+    N, K = ref_w.shape[:2]
+    npad = -(-N // 128) * 128
+    wp = torch.zeros(npad, K, taps, dtype=torch.float64)
+    wp[:N] = ref_w.double()
+    ref = core.PackedConv._h2_layout(wp).view(torch.int16).flatten()
+    assert got.numel() == ref.numel()
+    assert torch.equal(got, ref)
+
+
+def test_training_direct_layers_on_the_split_f16_engine_match_torch(dev, monkeypatch):
+    """A strided 3x3x3 layer and a 1x1x1 layer through ConvRowsFn (forward on k_gemm_h2w / k_gemm_h2z with device-made packs, the
+    1x1x1 dgrad on the same engine with the power-of-two gradient pre-scale) against torch autograd -- at a gradient magnitude of
+    1e-6, where an unscaled f16 operand would be subnormal."""
+    from co_occ_amd import autograd as ag
+    monkeypatch.setattr(core, "H2_DIRECT_MIN_FLOPS", 0.0)
+    monkeypatch.setattr(ag, "TRAIN_H2_DGRAD", True)
+    monkeypatch.setattr(ag, "TRAIN_H2_DGRAD_SCALE", 4096.0)
+    assert ag.TRAIN_H2
+    g = torch.Generator().manual_seed(11)
+    r2d = lambda t: t.permute(0, 2, 3, 4, 1).reshape(-1, t.shape[1]).contiguous()       # [B,C,X,Y,Z] -> rows [B*X*Y*Z, C]
+    B, X, Y, Z, Cin, Cout = 1, 12, 10, 4, 64, 96
+    x = torch.randn(B, Cin, X, Y, Z, generator=g)
+    for k, stride in ((3, 2), (1, 1), (3, 1)):
+        w = torch.randn(Cout, Cin, k, k, k, generator=g) * 0.05
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        yr = F.relu(F.conv3d(xr, wr, stride=stride, padding=k // 2))
+        up = torch.randn(yr.shape, generator=g) * 1e-6
+        yr.backward(up)
+        xd = r2d(x).to(dev).requires_grad_(True)
+        wd = w.to(dev).requires_grad_(True)
+        monkeypatch.setattr(ag, "TRAIN_WINO", False)        # keep the 3x3x3 stride-1 case on the direct kernels too
+        yd, _ = ag.conv3d_rows(xd, wd, (B, X, Y, Z), stride=stride, pad=k // 2, relu=True)
+        yd.backward(r2d(up).to(dev))
+        torch.cuda.synchronize()
+        core.check_h2_overflow()
+        assert_close(yd.detach().cpu(), r2d(yr.detach()), what="h2 train fwd k%d s%d" % (k, stride))
+        assert_close(xd.grad.cpu(), r2d(xr.grad), what="h2 train dgrad k%d s%d" % (k, stride))
+        assert_close(wd.grad.cpu(), wr.grad, what="h2 train wgrad k%d s%d" % (k, stride))
