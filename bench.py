@@ -585,12 +585,24 @@ def train_main(args, model, dev, rank, world, seen_world, backend_name):
     depth_gt = torch.rand(N * fH * 16 * fW * 16, device=dev) * 50
     render = c["grid"][0] >= 100 and c["grid"][1] >= 100 and c["grid"][2] >= 8
     img = s["img"].clone().requires_grad_()
+    # the index search of the NEXT step runs on a side stream under this step (the indices depend on the batch, not on the
+    # weights: what a data-loader-side prefetch does in a training loop); --train-prefetch 0 keeps it inside the step
+    pre = torch.cuda.Stream(device=dev) if (args.train_prefetch and model.occ_fuser is not None) else None
+    ahead = [None]
+
+    def prefetch():
+        with torch.cuda.stream(pre), torch.no_grad():
+            return model.occ_fuser.search(img.detach(), s["pts"])
 
     def step():
         for p in model.parameters():
             p.grad = None
         img.grad = None
-        res = model.forward_train_hot_path(img, s["pts"], s["gemo"], s["img_feats"], s["transform"], render=render, generator=g)
+        sr = None
+        if pre is not None:
+            sr = ahead[0] if ahead[0] is not None else prefetch()
+            ahead[0] = prefetch()
+        res = model.forward_train_hot_path(img, s["pts"], s["gemo"], s["img_feats"], s["transform"], render=render, generator=g, search=sr)
         loss = res["logit_rows"].square().mean()
         if "fine_logits" in res:
             loss = loss + res["fine_logits"].square().mean()
@@ -638,8 +650,9 @@ def train_main(args, model, dev, rank, world, seen_world, backend_name):
                             fused_grid="x".join(map(str, c["grid"])) + "x%d" % c["C"], cams=c["ncam"], knum=c["knum"],
                             batchnorm="batch statistics (model.train())", issue="eager (Python-issued launches)",
                             parallelism="dp%d (1 scene per GPU; gradient all-reduce belongs to the optimiser wrapper upstream)" % world,
-                            step="index search + G1 + con_enc + encoder + neck + coarse / fine head + render block, forward + backward; "
-                                 "surrogate squared-mean losses on the logits + the two render losses"),
+                            step=("index search%s + G1 + con_enc + encoder + neck + coarse / fine head + render block, forward + backward; "
+                                  "surrogate squared-mean losses on the logits + the two render losses"
+                                  % (" (one per step, issued one step ahead on a side stream)" if pre is not None else ""))),
                 roofline=roof,
                 kernel_groups_ms_per_step={k: dict(ms=round(v["ms"] / args.steps, 3), launches_per_step=v["launches"] // args.steps) for k, v in groups.items()},
                 env_knobs={k: v for k, v in sorted(os.environ.items()) if k.startswith("COOCC_")})
@@ -678,6 +691,8 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default): the dense stage of a sample is one captured hipGraph launch (co_occ_amd.serving.ServingPipeline); 0: every launch "
                          "issued from Python (Pipeline, --streams)")
+    ap.add_argument("--train-prefetch", type=int, default=1, help="--train: 1 = the index search of the next step runs on a side stream under "
+                    "the current step (indices depend on the batch only); 0 = inside the step")
     ap.add_argument("--ahead", type=int, default=0, help="--graph 1: searches submitted ahead of the dense stage (0: slots - dense streams; "
                                                          "with more than one rank: 1 -- one helper thread per rank, so an 8-rank node does not run 32 host threads)")
     ap.add_argument("--train", action="store_true",

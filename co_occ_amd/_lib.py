@@ -25,7 +25,8 @@ class ConvDesc(ctypes.Structure):
                                      "B", "Xi", "Yi", "Zi", "Xo", "Yo", "Zo", "ksize", "stride", "pad",
                                      "relu", "res_mode", "splitk", "tile_hint", "kx", "ky", "kz", "px", "py", "pz",
                                      "wgroup_rows", "mfma_dtype")] + [("alpha", ctypes.c_float), ("M_dev", c_void_p), ("gather_stride", c_int), ("out16", c_void_p), ("out16_stride", c_int), ("out_h2", c_int),
-                                                                   ("out_h2_twin", c_void_p), ("tile_sem", c_void_p), ("tile_sem_ints", c_int)]
+                                                                   ("out_h2_twin", c_void_p), ("tile_sem", c_void_p), ("tile_sem_ints", c_int),
+                                                                  ("alpha_dev", c_void_p)]
 
 
 class SearchDesc(ctypes.Structure):
@@ -48,9 +49,11 @@ SIGNATURES = {
     "coocc_ncdhw_to_ndhwc": (I, [P, P, I, I, I, I, I, P]),
     "coocc_rows_to_bf16": (I, [P, I, L, I, P, P]),
     "coocc_rows_to_h2": (I, [P, I, L, I, F, P, P]),
+    "coocc_rows_to_h2_ex": (I, [P, I, L, I, F, P, P, P]),
     "coocc_rows_to_h2_gather": (I, [P, I, P, L, P, I, F, P, P]),
     "coocc_rows_to_f16": (I, [P, I, L, I, P, P]),
     "coocc_wino_input_h2": (I, [P, I, I, I, I, I, I, I, P, I, L, F, P]),
+    "coocc_wino_input_h2_ex": (I, [P, I, I, I, I, I, I, I, P, I, L, F, P, P]),
     "coocc_ndhwc_to_ncdhw": (I, [P, P, I, I, I, I, I, P]),
     "coocc_fuser_prepare": (I, [P, P, P, P, P, I, I, I, P]),
     "coocc_fuser_prepare_rows": (I, [P, I, I, P, I, I, P, P, P, I, I, I, P]),
@@ -116,6 +119,7 @@ SIGNATURES = {
     "coocc_wino_wgrad": (I, [P, P, L, I, I, I, I, P, P, I, P, L, P]),
     "coocc_conv_tap_table": (I, [I, I, I, I, I, I, I, I, I, I, I, P, P]),
     "coocc_conv_epilogue_bwd": (I, [P, I, P, I, P, I, I, I, P, I, P, I, I, P, I, P, L, P]),
+    "coocc_conv_epilogue_bwd_ex": (I, [P, I, P, I, P, I, I, I, P, I, P, I, I, P, I, P, L, P, P, F, P]),
     "coocc_conv_wgrad": (I, [P, I, I, P, I, P, I, I, I, I, P, I, P, L, P]),
     "coocc_gather_rows": (I, [P, I, P, I, I, P, I, P]),
     "coocc_scatter_add_rows": (I, [P, I, P, I, I, P, I, P]),

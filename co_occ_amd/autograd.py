@@ -24,16 +24,31 @@ TRAIN_WINO_WGRAD = TRAIN_WINO and __import__("os").environ.get("COOCC_TRAIN_WINO
 # Winograd forward / dgrad GEMMs of the training path on the split-f16 engine (weights transformed + split on the device every
 # step, coocc_wino_pack_weights_h2_dev); 0: the fp32-MFMA kernels of rounds 1-3
 TRAIN_H2 = __import__("os").environ.get("COOCC_TRAIN_H2", "1") != "0"
-# ... and the dgrad GEMMs too.  Off by default: the operand of a dgrad GEMM is a GRADIENT, whose magnitude is set by the loss scale,
-# not by BatchNorm, and an f16 is subnormal below 6.1e-5: with a mean-reduced loss over 640 k voxels |dy| ~ 1e-6 and the hi half
-# alone keeps a handful of bits (the pair ~12 instead of 22; arithmetic of the format).  COOCC_TRAIN_H2_DGRAD=1 turns it on with the
-# gradient operand pre-scaled by the fixed power of two COOCC_TRAIN_H2_DGRAD_SCALE (exact; undone by the GEMM's alpha): 4096 puts
-# |dy| in [1e-7, 0.6] into the range where the split keeps 17-22 bits and trips the engine's range guard -- an error, not a wrong
-# number -- above 0.6 (32768 / (4096 x the F(4x4) transform's 100/8)); 1 (default) suits |dy| in [1e-3, 1e3].  A per-tensor
-# dynamic scale would remove the choice; measured gain of the switch at configs[1]: 36.5 -> 33.8 ms per step (profiles/r4_bench_train*.json).
-TRAIN_H2_DGRAD = TRAIN_H2 and __import__("os").environ.get("COOCC_TRAIN_H2_DGRAD", "0") != "0"
-TRAIN_H2_DGRAD_SCALE = float(__import__("os").environ.get("COOCC_TRAIN_H2_DGRAD_SCALE", "1"))
-assert TRAIN_H2_DGRAD_SCALE > 0 and __import__("math").frexp(TRAIN_H2_DGRAD_SCALE)[0] == 0.5, "COOCC_TRAIN_H2_DGRAD_SCALE: a power of two"
+# ... and the dgrad GEMMs too.  The operand of a dgrad GEMM is a GRADIENT, whose magnitude is set by the loss scale, not by
+# BatchNorm, and an f16 is subnormal below 6.1e-5 (with a mean-reduced loss over 640 k voxels |dy| ~ 1e-6: the hi half alone would
+# keep a handful of bits).  So the gradient operand gets a per-tensor power-of-two scale chosen ON THE DEVICE: the epilogue-backward
+# pass that produces dacc also collects max |dacc| (coocc_conv_epilogue_bwd_ex), a one-thread kernel turns it into {2^k, 2^-k} with
+# max |dacc| 2^k in [TARGET / 2, TARGET), the operand writers multiply by the first word and the GEMM's alpha by the second --
+# exact, no host read, any loss scale.  TARGET = 1024 leaves the F(4x4) input transform (x 100 / 8) inside the f16 range.
+# COOCC_TRAIN_H2_DGRAD=0: dgrad on the fp32-MFMA kernels.
+TRAIN_H2_DGRAD = TRAIN_H2 and __import__("os").environ.get("COOCC_TRAIN_H2_DGRAD", "1") != "0"
+TRAIN_H2_GRAD_TARGET = 1024.0
+_amax_words = {}
+
+
+def _amax_word(dev):
+    """The zeroed words (COOCC_AMAX_WORDS) coocc_conv_epilogue_bwd_ex collects max |dacc| in (left zero by its second kernel); one
+    set per stream."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    if key not in _amax_words:
+        _amax_words[key] = torch.zeros(2048, device=dev, dtype=torch.int32)
+    return _amax_words[key]
+
+
+def _second_word(t):
+    p = _lib.DevPtr(t.data_ptr() + 4)
+    p._keep = t
+    return p
 
 def _pad4(n):
     return (n + 3) // 4 * 4
@@ -124,9 +139,9 @@ def _h2_direct(K, flops):
     return TRAIN_H2 and core.CONV_ENGINE == "h2" and core.H2_DIRECT and K % 32 == 0 and flops >= core.H2_DIRECT_MIN_FLOPS
 
 
-def _rows_h2(x2d, C, scale=1.0):
+def _rows_h2(x2d, C, scale_dev=None):
     xh = torch.empty(x2d.shape[0], C, device=x2d.device, dtype=_F32)
-    call("coocc_rows_to_h2", ptr(x2d), x2d.shape[1], x2d.shape[0], C, float(scale), ptr(xh))
+    call("coocc_rows_to_h2_ex", ptr(x2d), x2d.shape[1], x2d.shape[0], C, 1.0, ptr(scale_dev), ptr(xh))
     return xh
 
 
@@ -140,7 +155,7 @@ class _DevWinoF32:
         self.scale, self.bias = scale, bias
         self._w_raw, self.wino_tile = True, None
         self._w5, self._dgrad, self._packs = w5, int(bool(dgrad)), {}
-        self.dgrad_operand = bool(dgrad)      # split-f16 engine: the input rows are gradients (pre-scaled by TRAIN_H2_DGRAD_SCALE)
+        self.operand_scale_dev = None         # split-f16 engine, dgrad: {scale, 1 / scale} of the gradient rows, chosen on the device
 
     def wino_pack(self, tile):
         if tile not in self._packs:
@@ -158,10 +173,6 @@ class _DevWinoF32:
 
 
 class _DevWino(_DevWinoF32):
-    @property
-    def operand_scale(self):
-        return TRAIN_H2_DGRAD_SCALE if self.dgrad_operand else 1.0
-
     def wino_h2_pack(self, tile):
         """The same packs for the split-f16 engine (csrc/gemm_h2.hip), transformed + split on the device from the live parameter:
         training's Winograd forward / dgrad GEMMs run on the f16 matrix cores like inference's (core.h2_capable)."""
@@ -180,13 +191,15 @@ class _DevWino(_DevWinoF32):
         return self._packs[key]
 
 
-def _wino_train(x2d, geom, w5, dgrad, out2d, scale, shift, res2d, relu):
-    """Winograd path of a 3x3x3 stride-1 pad-1 convolution in training (forward or dgrad); False if not eligible."""
+def _wino_train(x2d, geom, w5, dgrad, out2d, scale, shift, res2d, relu, grad_scale=None):
+    """Winograd path of a 3x3x3 stride-1 pad-1 convolution in training (forward or dgrad); False if not eligible.
+    ``grad_scale``: dgrad on the split-f16 engine -- the device-side {scale, 1 / scale} of the gradient rows x2d."""
     from . import core
     if not TRAIN_WINO:
         return False
     B, X, Y, Z = geom
-    pk = (_DevWino if (TRAIN_H2_DGRAD if dgrad else TRAIN_H2) else _DevWinoF32)(w5, dgrad, scale, shift)
+    pk = (_DevWino if ((TRAIN_H2_DGRAD and grad_scale is not None) if dgrad else TRAIN_H2) else _DevWinoF32)(w5, dgrad, scale, shift)
+    pk.operand_scale_dev = grad_scale if dgrad else None
     xr = core.Rows(x2d, B, X, Y, Z, pk.Cin)
     plan = core.wino_plan(xr, pk, out2d.shape[0], 1 if res2d is not None else 0)
     if plan is None:
@@ -239,8 +252,9 @@ def _zrange(Zin, Zout, stride, pad):
 
 
 def _conv_launch(x2d, in_C, w_packed, out2d, Cout, taps, geom_in, geom_out, ksize, stride, pad, scale, shift, res2d, relu,
-                 table=None, tag="conv_fwd", out_rows=None, kdims=None, h2_alpha=None):
-    """``h2_alpha``: x2d holds H2 rows (coocc_rows_to_h2, operand scale 1 / h2_alpha) and w_packed an H2 pack: split-f16 engine."""
+                 table=None, tag="conv_fwd", out_rows=None, kdims=None, h2_alpha=None, alpha_dev=None):
+    """``h2_alpha``: x2d holds H2 rows (coocc_rows_to_h2, operand scale 1 / h2_alpha) and w_packed an H2 pack: split-f16 engine;
+    ``alpha_dev``: device word the accumulators are also multiplied by (the inverse of a device-chosen operand scale)."""
     d = ConvDesc()
     ws = workspace(x2d.device)
     d.in_, d.w, d.out = ptr(x2d), ptr(w_packed), ptr(out2d)
@@ -262,6 +276,7 @@ def _conv_launch(x2d, in_C, w_packed, out2d, Cout, taps, geom_in, geom_out, ksiz
     d.tile_hint = TILE_HINT
     if h2_alpha is not None:
         d.in_stride, d.mfma_dtype, d.alpha, tag = in_C, 3, float(h2_alpha), "k_gemm_h2 " + tag
+        d.alpha_dev = alpha_dev
     with _lib.TIMER.region(tag, 2.0 * d.M * in_C * Cout * taps):
         _lib.conv_fwd(d, x2d.device)
 
@@ -319,8 +334,14 @@ class ConvRowsFn(torch.autograd.Function):
         dres = torch.empty(Mo, Cout, device=dev, dtype=_F32) if (has_res and need_res) else None
         dbias = torch.empty(Cout, device=dev, dtype=_F32) if (has_bias and need_b) else None
         ws = workspace(dev)
-        call("coocc_conv_epilogue_bwd", ptr(dout), Cout, ptr(out), Cout, ptr(scale), Mo, Cout, int(relu), ptr(dacc), Cp,
-             ptr(dres), Cout, 0, ptr(dbias), 0, ptr(ws), ws.numel())
+        from . import core
+        # split-f16 dgrad: max |dacc| collected by the pass that writes dacc -> {scale, 1 / scale} on the device (see TRAIN_H2_DGRAD)
+        gscale = None
+        if TRAIN_H2_DGRAD and need_x and core.CONV_ENGINE == "h2" and Cp == Cout and Cout % 32 == 0 and stride == 1:
+            gscale = torch.empty(2, device=dev, dtype=_F32)
+        call("coocc_conv_epilogue_bwd_ex", ptr(dout), Cout, ptr(out), Cout, ptr(scale), Mo, Cout, int(relu), ptr(dacc), Cp,
+             ptr(dres), Cout, 0, ptr(dbias), 0, ptr(ws), ws.numel(), ptr(_amax_word(dev)) if gscale is not None else None,
+             ptr(gscale), TRAIN_H2_GRAD_TARGET)
         if dbias is not None and scale is not None:
             dbias = dbias * scale
         dx = dw = None
@@ -329,7 +350,7 @@ class ConvRowsFn(torch.autograd.Function):
             w3 = weight.reshape(Cout, Cin, taps)
             if (stride == 1 and ksize == 3 and pad == 1 and Cp == Cout and
                     _wino_train(dacc, geom, weight.detach().float().contiguous().view(Cout, Cin, 3, 3, 3), True, dx, None, None,
-                                None, False)):
+                                None, False, grad_scale=gscale)):
                 pass
             elif stride == 1:
                 kd, wsub, nt, pd = None, w3, taps, ksize - 1 - pad
@@ -338,11 +359,11 @@ class ConvRowsFn(torch.autograd.Function):
                     if hi - lo < 2:
                         wsub = weight.detach().float().view(Cout, Cin, 3, 3, 3)[..., 2 - hi:2 - lo + 1].contiguous().view(Cout, Cin, -1)
                         nt, kd = wsub.shape[2], (3, 3, hi - lo + 1, pd, pd, pd - lo)
-                if TRAIN_H2_DGRAD and Cp == Cout and _h2_direct(Cout, 2.0 * Mi * Cin * Cout * nt):
-                    # the gradient operand pre-scaled by a power of two (TRAIN_H2_DGRAD_SCALE above), undone by alpha
-                    _conv_launch(_rows_h2(dacc, Cout, TRAIN_H2_DGRAD_SCALE), Cout, pack_weights_h2_dev(wsub, Cout, Cin, nt, 2), dx, Cin,
+                if gscale is not None and _h2_direct(Cout, 2.0 * Mi * Cin * Cout * nt):
+                    # the gradient operand scaled by gscale[0] (chosen on the device), undone by the GEMM through gscale[1]
+                    _conv_launch(_rows_h2(dacc, Cout, gscale), Cout, pack_weights_h2_dev(wsub, Cout, Cin, nt, 2), dx, Cin,
                                  nt, geom_out, geom, ksize, 1, pd, None, None, None, False, tag="conv_dgrad", kdims=kd,
-                                 h2_alpha=1.0 / TRAIN_H2_DGRAD_SCALE)
+                                 h2_alpha=1.0, alpha_dev=_second_word(gscale))
                 else:
                     wp = pack_weights_dev(wsub, Cout, Cin, nt, 2)
                     _conv_launch(dacc, Cp, wp, dx, Cin, nt, geom_out, geom, ksize, 1, pd, None, None, None, False,

@@ -496,7 +496,8 @@ def conv_rows_wino(x, pc, out, relu, res, plan, in_ranges=None, twin=False):
     Mb = _wino_buffer(dev, "M", pts * G * pc.Cout)
     h2 = h2_capable(pc) and all(c % 32 == 0 for _, c in (in_ranges or []))
     wp = pc.wino_h2_pack(tile) if h2 else pc.wino_pack(tile)
-    vscale = H2_WINO_SCALE[tile] * getattr(pc, "operand_scale", 1.0)      # powers of two: exact, undone by the GEMM's alpha
+    vscale = H2_WINO_SCALE[tile]
+    sdev = getattr(pc, "operand_scale_dev", None) if h2 else None         # training's dgrad: {scale, 1 / scale} of the gradient rows (device)
     with TIMER.region("k_wino_in", 4.0 * x.V * pc.Cin + 4.0 * pts * rows * pc.Cin):
         if in_ranges is None and not h2:
             call("coocc_wino_input", x.data(), x.stride, x.B, x.X, x.Y, x.Z, pc.Cin, tile, ptr(V), G)
@@ -509,7 +510,7 @@ def conv_rows_wino(x, pc, out, relu, res, plan, in_ranges=None, twin=False):
                 dst = _lib.DevPtr(V.data_ptr() + 4 * voff)        # H2 rows: 128 bytes per 32-channel chunk = 4 bytes per channel too
                 dst._keep = V
                 if h2:
-                    call("coocc_wino_input_h2", src, x.stride, x.B, x.X, x.Y, x.Z, cr, tile, dst, pc.Cin, G, vscale)
+                    call("coocc_wino_input_h2_ex", src, x.stride, x.B, x.X, x.Y, x.Z, cr, tile, dst, pc.Cin, G, vscale, ptr(sdev))
                 else:
                     call("coocc_wino_input_strided", src, x.stride, x.B, x.X, x.Y, x.Z, cr, tile, dst, pc.Cin, G)
                 voff += cr
@@ -531,6 +532,10 @@ def conv_rows_wino(x, pc, out, relu, res, plan, in_ranges=None, twin=False):
         kname = "k_conv2p"          # mirror of the dispatch in coocc_conv_fwd: persistent workgroups, >= 2 tiles each
     if h2:
         d.mfma_dtype, d.alpha, kname = 3, 1.0 / vscale, "k_gemm_h2z"
+        if sdev is not None:
+            inv = _lib.DevPtr(sdev.data_ptr() + 4)
+            inv._keep = sdev
+            d.alpha_dev = inv
     with TIMER.region(kname + " wino%d" % tile, 2.0 * pts * rows * pc.Cin * pc.Cout * 3):
         _lib.conv_fwd(d, V.device)
     tw = None

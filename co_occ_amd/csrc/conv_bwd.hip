@@ -135,17 +135,49 @@ extern "C" int coocc_conv_tap_table(int B, int Xi, int Yi, int Zi, int Xo, int Y
 }
 
 // ------------------------------------------------------------------ epilogue backward
+constexpr int AMAX_SLOTS = 64, AMAX_STRIDE = 32;       // coocc_conv_epilogue_bwd_ex: 64 words, 128 bytes apart (8 KB, COOCC_AMAX_WORDS)
 // one thread per 4 channels; dbias partials: per-block column sums -> second pass
 __global__ __launch_bounds__(256) void k_epilogue_bwd(const float* __restrict__ dout, int dout_stride,
                                                        const float* __restrict__ out, int out_stride,
                                                        const float* __restrict__ scale, int M, int C, int relu,
                                                        float* __restrict__ dacc, int dacc_stride, float* __restrict__ dres,
-                                                       int dres_stride, int dres_accumulate) {
+                                                       int dres_stride, int dres_accumulate, uint32_t* __restrict__ amax_word) {
   const int c4 = (C + 3) >> 2;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)M * c4) return;
-  const int m = (int)(i / c4), c = (int)(i % c4) * 4;
+  const bool live = i < (long long)M * c4;
+  if (!live && !amax_word) return;
+  const int m = live ? (int)(i / c4) : 0, c = live ? (int)(i % c4) * 4 : 0;      // (a dead thread of the last block re-reads row 0, stores nothing)
   if (((C | dout_stride | out_stride | dacc_stride | dres_stride) & 3) == 0) {   // whole rows of dwordx4 (the usual case)
+    if (amax_word) {      // only asked for in this form (the training path's rows)
+      f32x4 g = *(const f32x4*)(dout + (size_t)m * dout_stride + c);
+      if (relu) {
+        const f32x4 o = *(const f32x4*)(out + (size_t)m * out_stride + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+      }
+      if (dres && live) {
+        f32x4* d = (f32x4*)(dres + (size_t)m * dres_stride + c);
+        *d = dres_accumulate ? *d + g : g;
+      }
+      if (scale) g = g * *(const f32x4*)(scale + c);
+      if (dacc && live) *(f32x4*)(dacc + (size_t)m * dacc_stride + c) = g;
+      if (!live) g = f32x4{0.f, 0.f, 0.f, 0.f};
+      // max |dacc| of the workgroup (bit patterns of non-negative floats order like the values), then ONE atomic per workgroup
+      // into one of AMAX_SLOTS words 128 bytes apart, and only when a look at the slot says it is needed.  (One word for
+      // everybody -- an atomic, or just an L2 read, per wave: 40 k same-address accesses per pass -- cost 3-8 ms per training step.)
+      __shared__ uint32_t wmax[4];
+      uint32_t a = __float_as_uint(fmaxf(fmaxf(fabsf(g[0]), fabsf(g[1])), fmaxf(fabsf(g[2]), fabsf(g[3]))));
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) a = max(a, (uint32_t)__shfl_xor((int)a, off));
+      if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = a;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        a = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        uint32_t* slot = amax_word + (blockIdx.x % AMAX_SLOTS) * AMAX_STRIDE;
+        if (a > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, a);
+      }
+      return;
+    }
     f32x4 g = *(const f32x4*)(dout + (size_t)m * dout_stride + c);
     if (relu) {
       const f32x4 o = *(const f32x4*)(out + (size_t)m * out_stride + c);
@@ -220,16 +252,43 @@ __global__ __launch_bounds__(256) void k_colsum_final4(const double* __restrict_
   if ((threadIdx.x >> 2) == 0 && c < C) dbias[c] = accumulate ? dbias[c] + (float)t[0] : (float)t[0];
 }
 
-extern "C" int coocc_conv_epilogue_bwd(const float* dout, int dout_stride, const float* out, int out_stride,
-                                       const float* scale, int M, int C, int relu, float* dacc, int dacc_stride,
-                                       float* dres, int dres_stride, int dres_accumulate, float* dbias,
-                                       int dbias_accumulate, float* ws, int64_t ws_floats, void* stream) {
+// scale2 = {2^k, 2^-k} with amax * 2^k in [target / 2, target) (k = 0 for an all-zero gradient); the slots are left zero for the next pass
+__global__ __launch_bounds__(64) void k_amax_scale(uint32_t* __restrict__ amax_word, float target, float* __restrict__ scale2) {
+  uint32_t v = amax_word[threadIdx.x * AMAX_STRIDE];
+  amax_word[threadIdx.x * AMAX_STRIDE] = 0u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+  if (threadIdx.x) return;
+  const float a = __uint_as_float(v);
+  int k = 0;
+  if (a > 0.f && a < 3.0e38f) {
+    int ea, et;
+    (void)frexpf(a, &ea);          // a = m 2^ea, m in [0.5, 1)
+    (void)frexpf(target, &et);
+    k = min(max(et - ea, -100), 100);
+  }
+  scale2[0] = ldexpf(1.f, k);
+  scale2[1] = ldexpf(1.f, -k);
+}
+
+extern "C" int coocc_conv_epilogue_bwd_ex(const float* dout, int dout_stride, const float* out, int out_stride,
+                                          const float* scale, int M, int C, int relu, float* dacc, int dacc_stride,
+                                          float* dres, int dres_stride, int dres_accumulate, float* dbias,
+                                          int dbias_accumulate, float* ws, int64_t ws_floats, uint32_t* amax_word, float* scale2,
+                                          float target, void* stream) {
   COOCC_CHECK_ARG(dout && M > 0 && C > 0 && (!relu || out), "conv_epilogue_bwd: bad args");
+  COOCC_CHECK_ARG((amax_word == nullptr) == (scale2 == nullptr), "conv_epilogue_bwd_ex: amax_word and scale2 come together");
+  COOCC_CHECK_ARG(!amax_word || (dacc && target > 0.f && ((C | dout_stride | out_stride | dacc_stride | dres_stride) & 3) == 0),
+                  "conv_epilogue_bwd_ex: the operand scale needs dacc, target > 0 and rows of whole dwordx4");
   hipStream_t s = as_stream(stream);
   if (dacc || dres) {
     hipLaunchKernelGGL(k_epilogue_bwd, dim3(cdiv((long long)M * ((C + 3) / 4), 256)), dim3(256), 0, s, dout, dout_stride, out,
-                       out_stride, scale, M, C, relu, dacc, dacc_stride, dres, dres_stride, dres_accumulate);
+                       out_stride, scale, M, C, relu, dacc, dacc_stride, dres, dres_stride, dres_accumulate, amax_word);
     COOCC_LAUNCH_CHECK("k_epilogue_bwd");
+    if (amax_word) {
+      hipLaunchKernelGGL(k_amax_scale, dim3(1), dim3(AMAX_SLOTS), 0, s, amax_word, target, scale2);
+      COOCC_LAUNCH_CHECK("k_amax_scale");
+    }
   }
   if (dbias) {
     const int nparts4 = cdiv(M, COL_ROWS);
@@ -249,6 +308,14 @@ extern "C" int coocc_conv_epilogue_bwd(const float* dout, int dout_stride, const
     COOCC_LAUNCH_CHECK("k_colsum");
   }
   return COOCC_OK;
+}
+
+extern "C" int coocc_conv_epilogue_bwd(const float* dout, int dout_stride, const float* out, int out_stride,
+                                       const float* scale, int M, int C, int relu, float* dacc, int dacc_stride,
+                                       float* dres, int dres_stride, int dres_accumulate, float* dbias,
+                                       int dbias_accumulate, float* ws, int64_t ws_floats, void* stream) {
+  return coocc_conv_epilogue_bwd_ex(dout, dout_stride, out, out_stride, scale, M, C, relu, dacc, dacc_stride, dres, dres_stride,
+                                    dres_accumulate, dbias, dbias_accumulate, ws, ws_floats, nullptr, nullptr, 0.f, stream);
 }
 
 // ------------------------------------------------------------------ weight gradient

@@ -27,6 +27,8 @@ struct ConvK {
   int32_t* tile_sem;            // split-f16 kernels, split-K: per-(M tile, N tile) arrival counters (zero on entry, left zero): the last
                                 // workgroup of a tile sums the slabs in slice order and runs the epilogue -- no k_conv_reduce launch
   int* h2_flag;                 // host-mapped word, OR-ed with 1 when a value written as an H2 / f16 operand leaves the guarded range
+  const float* alpha_dev;       // split-f16 kernels: the accumulators are also multiplied by *alpha_dev (the inverse of an operand scale that
+                                // was chosen on the device: the gradient operand of training's dgrad GEMMs), or NULL
 };
 
 __device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t rrow) {

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2z(ConvK p) {
 
   // epilogue: lane (li, h) holds, for output row m0 + i*32 + li, the channels n0 + 32 wave + 8 j + 4 h + 0..3 (j = 0..3)
   const int nb = n0 + wave * 32 + 4 * h;
-  const float alpha = p.alpha, lo = TERMS == 3 ? p.alpha * (1.f / H2_LO_SCALE) : 0.f;
+  const float alpha = p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha, lo = TERMS == 3 ? alpha * (1.f / H2_LO_SCALE) : 0.f;
   if (p.splitk > 1) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
 
   // epilogue: lane (li, h) holds, for output row m0 + i*32 + li, the channels n0 + 32 wave + 8 j + 4 h + 0..3 (j = 0..3)
   const int nb = n0 + wave * 32 + 4 * h;
-  const float alpha = p.alpha, lo = TERMS == 3 ? p.alpha * (1.f / H2_LO_SCALE) : 0.f;
+  const float alpha = p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha, lo = TERMS == 3 ? alpha * (1.f / H2_LO_SCALE) : 0.f;
   if (p.splitk > 1) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -693,6 +693,7 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   COOCC_CHECK_ARG(!d->out16 || (d->Cout % 4 == 0 && d->out16_stride % 4 == 0 && !d->out_rows && ((uintptr_t)d->out16 & 7) == 0),
                   "conv_fwd: out16 needs Cout % 4 == 0, out16_stride % 4 == 0, no row scatter");
   k.alpha = d->alpha != 0.f ? d->alpha : 1.f;
+  k.alpha_dev = d->alpha_dev;
   k.M_dev = d->M_dev;
   k.out_h2 = d->out_h2;
   COOCC_CHECK_ARG(!d->out_h2 || (d->Cout % 4 == 0 && d->out_stride % 32 == 0 && !d->out_rows),
@@ -790,8 +791,10 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
 // fp32 rows (row stride in_stride floats, first C columns, C % 32 == 0) * scale -> H2 rows [rows][C/32][hi 32 | lo 32] (4 C bytes per row)
 __global__ __launch_bounds__(256) void k_rows_to_h2(const float* __restrict__ in, int in_stride, long long rows, int C, float scale,
                                                      char* __restrict__ out, const int32_t* __restrict__ row_ids,
-                                                     const int32_t* __restrict__ n_dev, int* __restrict__ flag) {
+                                                     const int32_t* __restrict__ n_dev, int* __restrict__ flag,
+                                                     const float* __restrict__ scale_dev) {
   if (n_dev) rows = min(rows, (long long)*n_dev);
+  if (scale_dev) scale *= *scale_dev;
   const int c8 = C >> 3;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * c8) return;
@@ -813,16 +816,21 @@ __global__ __launch_bounds__(256) void k_rows_to_h2(const float* __restrict__ in
   h2_guard(flag, b * scale);
 }
 
-extern "C" int coocc_rows_to_h2(const float* in, int in_stride, int64_t rows, int C, float scale, void* out_h2, void* stream) {
+extern "C" int coocc_rows_to_h2_ex(const float* in, int in_stride, int64_t rows, int C, float scale, const float* scale_dev,
+                                   void* out_h2, void* stream) {
   COOCC_CHECK_ARG(in && out_h2 && rows >= 0 && C > 0 && C % 32 == 0 && in_stride % 4 == 0 && in_stride >= C, "rows_to_h2: bad args");
   COOCC_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)out_h2 & 15) == 0, "rows_to_h2: pointers must be 16-byte aligned");
   if (rows == 0) return COOCC_OK;
   int* flag = nullptr;
   if (coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
   hipLaunchKernelGGL(k_rows_to_h2, dim3(cdiv(rows * (C / 8), 256)), dim3(256), 0, as_stream(stream), in, in_stride, (long long)rows, C,
-                     scale, (char*)out_h2, (const int32_t*)nullptr, (const int32_t*)nullptr, flag);
+                     scale, (char*)out_h2, (const int32_t*)nullptr, (const int32_t*)nullptr, flag, scale_dev);
   COOCC_LAUNCH_CHECK("k_rows_to_h2");
   return COOCC_OK;
+}
+
+extern "C" int coocc_rows_to_h2(const float* in, int in_stride, int64_t rows, int C, float scale, void* out_h2, void* stream) {
+  return coocc_rows_to_h2_ex(in, in_stride, rows, C, scale, nullptr, out_h2, stream);
 }
 
 // out row j = H2(in[row_ids[j]]) for j < n (n_dev != NULL: n = min(n_cap, *n_dev) read on the device): the compact operand of a
@@ -835,7 +843,7 @@ extern "C" int coocc_rows_to_h2_gather(const float* in, int in_stride, const int
   int* flag = nullptr;
   if (coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
   hipLaunchKernelGGL(k_rows_to_h2, dim3(cdiv(n_cap * (C / 8), 256)), dim3(256), 0, as_stream(stream), in, in_stride, (long long)n_cap, C,
-                     scale, (char*)out_h2, row_ids, n_dev, flag);
+                     scale, (char*)out_h2, row_ids, n_dev, flag, (const float*)nullptr);
   COOCC_LAUNCH_CHECK("k_rows_to_h2");
   return COOCC_OK;
 }

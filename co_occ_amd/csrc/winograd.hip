@@ -122,8 +122,9 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ in, i
 template <int N>
 __global__ __launch_bounds__(256) void k_wino_in_h2(const float* __restrict__ in, int in_stride, int B, int X, int Y, int Z,
                                                      int C, int Tx, int Ty, size_t gstride_bytes, int vstride, float scale,
-                                                     char* __restrict__ V, int* __restrict__ flag) {
+                                                     char* __restrict__ V, int* __restrict__ flag, const float* __restrict__ scale_dev) {
   constexpr int MO = Wino<N>::M;
+  if (scale_dev) scale *= *scale_dev;
   const int c4 = C >> 2;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long rows = (long long)B * Tx * Ty * Z;
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(256) void k_wino_in_h2(const float* __restrict__ in
   }
 }
 
-extern "C" int coocc_wino_input_h2(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, void* V,
-                                   int vstride, int64_t group_rows, float scale, void* stream) {
+extern "C" int coocc_wino_input_h2_ex(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, void* V,
+                                      int vstride, int64_t group_rows, float scale, const float* scale_dev, void* stream) {
   COOCC_CHECK_ARG(in && V && B > 0 && X > 0 && Y > 0 && Z > 0 && C > 0 && C % 32 == 0 && in_stride % 4 == 0, "wino_input_h2: bad args");
   COOCC_CHECK_ARG(tile >= 2 && tile <= 4, "wino_input_h2: tile must be 2, 3 or 4");
   COOCC_CHECK_ARG(vstride >= C && vstride % 32 == 0 && ((uintptr_t)V & 127) == 0, "wino_input_h2: V row stride / alignment");
@@ -188,13 +189,18 @@ extern "C" int coocc_wino_input_h2(const float* in, int in_stride, int B, int X,
   int* flag = nullptr;
   if (coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
   if (tile == 2)
-    hipLaunchKernelGGL(k_wino_in_h2<4>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V, flag);
+    hipLaunchKernelGGL(k_wino_in_h2<4>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V, flag, scale_dev);
   else if (tile == 3)
-    hipLaunchKernelGGL(k_wino_in_h2<5>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V, flag);
+    hipLaunchKernelGGL(k_wino_in_h2<5>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V, flag, scale_dev);
   else
-    hipLaunchKernelGGL(k_wino_in_h2<6>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V, flag);
+    hipLaunchKernelGGL(k_wino_in_h2<6>, grid, dim3(256), 0, s, in, in_stride, B, X, Y, Z, C, Tx, Ty, gstride, vstride, scale, (char*)V, flag, scale_dev);
   COOCC_LAUNCH_CHECK("k_wino_in_h2");
   return COOCC_OK;
+}
+
+extern "C" int coocc_wino_input_h2(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, void* V,
+                                   int vstride, int64_t group_rows, float scale, void* stream) {
+  return coocc_wino_input_h2_ex(in, in_stride, B, X, Y, Z, C, tile, V, vstride, group_rows, scale, nullptr, stream);
 }
 
 static int wino_input_impl(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, float* V, int vstride,

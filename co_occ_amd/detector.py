@@ -257,7 +257,7 @@ class COOCC_Ray(nn.Module):
         return res
 
     def forward_train_hot_path(self, img_voxel_feats, pts_voxel_feats, gemo=None, img_feats=None, transform=None,
-                               coarse_lin=None, render=True, generator=None, depth_only=False):
+                               coarse_lin=None, render=True, generator=None, depth_only=False, search=None):
         """Differentiable counterpart of ``forward_hot_path``: K1-K5 run as in inference (indices are not differentiated, as
         upstream), everything after them is an autograd Function over the HIP kernels; every BatchNorm follows its own
         ``training`` flag (batch / SyncBN statistics under model.train(), folded running statistics in eval mode).
@@ -266,7 +266,10 @@ class COOCC_Ray(nn.Module):
         ``depths`` of the render block.  ``coarse_lin``: int32 rows of the coarse voxels whose children the fine branch
         evaluates; default: ``OccHead.draw_fine_voxels`` -- the foreground voxels (argmax != empty), randomly thinned to
         ``fine_topk`` whole coarse voxels when there are more, as the reference does (coordinate_transform.py:17-21 permutes the
-        COARSE columns and keeps the first ``topk``, each with all of its ratio^3 children)."""
+        COARSE columns and keeps the first ``topk``, each with all of its ratio^3 children).
+        ``search``: a ``BiFuser_N.search`` result of THIS sample issued earlier (the indices depend on the inputs only, not on the
+        weights, so a training loop may run the search of batch i+1 on a side stream under the backward pass of batch i -- 2 ms of
+        dependent FPS steps off the critical path; ``bench.py --train`` does)."""
         from . import autograd as ag
         one = img_voxel_feats if img_voxel_feats is not None else pts_voxel_feats
         B, C, X, Y, Z = one.shape
@@ -274,9 +277,11 @@ class COOCC_Ray(nn.Module):
         V = X * Y * Z
         rows = lambda t: t.float().permute(0, 2, 3, 4, 1).reshape(V, t.shape[1])
         if self.occ_fuser is not None:
-            with torch.no_grad():
-                sr = self.occ_fuser.search(img_voxel_feats.detach(), pts_voxel_feats.detach())
-            self.occ_fuser.finish_bookkeeping(sr)              # the img->pts direction ran on a side stream
+            sr = search
+            if sr is None:
+                with torch.no_grad():
+                    sr = self.occ_fuser.search(img_voxel_feats.detach(), pts_voxel_feats.detach())
+            self.occ_fuser.finish_bookkeeping(sr)              # the img->pts direction (or all of it) ran on another stream
             cat4 = ag.fuser_fuse_train(self.occ_fuser, rows(img_voxel_feats).contiguous(), rows(pts_voxel_feats).contiguous(), sr)
             vf, geom = ag.con_enc_train(self.occ_fuser.con_enc, cat4, (1, X, Y, Z))
         else:                                                  # coocc_ray.py:255-256: single-modality models

@@ -239,6 +239,9 @@ typedef struct coocc_conv_desc {
                              second-pass kernel: same bits) and runs the epilogue itself -- no reduction launch, and the H2 / f16
                              outputs above become available to split-K layers; NULL = the two-launch form */
   int tile_sem_ints;      /* capacity of tile_sem */
+  const float* alpha_dev; /* mfma_dtype 3 / 4: the accumulators are also multiplied by *alpha_dev, read on the device -- the inverse of an
+                             operand scale that a kernel chose (coocc_conv_epilogue_bwd_ex: the gradient operand of the training
+                             path's dgrad GEMMs); NULL = none */
 } coocc_conv_desc;
 
 /* nn.Conv3d(k=3|1)+BN(eval)+ReLU(+residual) (bifuser_n.py:23-30, resnet3d.py:34-64,
@@ -256,6 +259,9 @@ int coocc_rows_to_bf16(const float* in, int in_stride, int64_t rows, int C, void
  * Replaces nothing in the reference (its convolutions are cuDNN fp32, resnet3d.py:34-64): it is how the same fp32 sums are
  * evaluated on the 16-bit matrix pipe. */
 int coocc_rows_to_h2(const float* in, int in_stride, int64_t rows, int C, float scale, void* out_h2, void* stream);
+/* ... with the scale also multiplied by *scale_dev (device word, NULL = 1): see coocc_conv_epilogue_bwd_ex */
+int coocc_rows_to_h2_ex(const float* in, int in_stride, int64_t rows, int C, float scale, const float* scale_dev, void* out_h2,
+                        void* stream);
 /* fp32 rows -> f16 rows [rows][C], round to nearest even (C % 8 == 0): the operand of mfma_dtype 4 when no producer wrote it */
 int coocc_rows_to_f16(const float* in, int in_stride, int64_t rows, int C, void* out_f16, void* stream);
 /* out row j = H2(in[row_ids[j]] * scale), j < n_cap (n_dev != NULL: j < min(n_cap, *n_dev), the count read on the device) */
@@ -277,6 +283,9 @@ int coocc_wino_input_strided(const float* in, int in_stride, int B, int X, int Y
  * V offset to a 32-channel chunk boundary (128 bytes per chunk). */
 int coocc_wino_input_h2(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, void* V,
                         int vstride, int64_t group_rows, float scale, void* stream);
+/* ... with the scale also multiplied by *scale_dev (device word, NULL = 1): see coocc_conv_epilogue_bwd_ex */
+int coocc_wino_input_h2_ex(const float* in, int in_stride, int B, int X, int Y, int Z, int C, int tile, void* V,
+                           int vstride, int64_t group_rows, float scale, const float* scale_dev, void* stream);
 /* Scatter-form sparse half of a dense 3x3x3 convolution (csrc/sparse_taps.hip): P:[Np][27][Cout] = per occupied input voxel
  * and tap the contribution W_t . in[u] (a row-table coocc_conv_fwd with N = 27*Cout), map: voxel -> row of P or -1
  * (coocc_voxel_index_map); S[v][n] = scale[n] * sum_t P[map[v + t - 1]][t][n], taps in order (deterministic). */
@@ -354,6 +363,18 @@ int coocc_conv_epilogue_bwd(const float* dout, int dout_stride, const float* out
                             const float* scale, int M, int C, int relu, float* dacc, int dacc_stride,
                             float* dres, int dres_stride, int dres_accumulate, float* dbias,
                             int dbias_accumulate, float* ws, int64_t ws_floats, void* stream);
+/* ... and the operand scale of the split-f16 engine for dacc, chosen on the device: amax_word (COOCC_AMAX_WORDS zeroed 32-bit
+ * words, left zero: the workgroups spread their atomics over 64 of them, 128 bytes apart) collects max |dacc| during the pass, then scale2[0] = the power of two that brings it into [target / 2, target) (1 when the
+ * gradient is all zero), scale2[1] = its inverse.  The gradient operand of a dgrad / wgrad GEMM is written as H2 rows with
+ * scale_dev = scale2 (coocc_rows_to_h2_ex, coocc_wino_input_h2_ex) and the GEMM undoes it with coocc_conv_desc.alpha_dev =
+ * scale2 + 1: whatever the loss scale, the f16 halves see values of magnitude <= target (an f16 is subnormal below 6.1e-5; the
+ * reference's cuDNN backward has no such concern, resnet3d.py:34-64).  amax_word / scale2 NULL: coocc_conv_epilogue_bwd. */
+#define COOCC_AMAX_WORDS 2048
+int coocc_conv_epilogue_bwd_ex(const float* dout, int dout_stride, const float* out, int out_stride,
+                               const float* scale, int M, int C, int relu, float* dacc, int dacc_stride,
+                               float* dres, int dres_stride, int dres_accumulate, float* dbias,
+                               int dbias_accumulate, float* ws, int64_t ws_floats, uint32_t* amax_word, float* scale2,
+                               float target, void* stream);
 /* dw[Cout][Cin][taps] (+)= sum_m in[table[t][m]][c] * dacc[m][n]  (table NULL: identity rows, taps == 1).
  * in has in_rows rows; fp32 MFMA with the voxel index as K; M-slices reduced in slice order (deterministic). */
 int coocc_conv_wgrad(const float* in, int in_rows, int in_stride, const float* dacc, int dacc_stride,

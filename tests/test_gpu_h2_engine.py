@@ -212,32 +212,34 @@ def test_device_made_direct_h2_pack_equals_host_layout(dev, mode):
     assert torch.equal(got, ref)
 
 
-def test_training_direct_layers_on_the_split_f16_engine_match_torch(dev, monkeypatch):
-    """A strided 3x3x3 layer and a 1x1x1 layer through ConvRowsFn (forward on k_gemm_h2w / k_gemm_h2z with device-made packs, the
-    1x1x1 dgrad on the same engine with the power-of-two gradient pre-scale) against torch autograd -- at a gradient magnitude of
-    1e-6, where an unscaled f16 operand would be subnormal."""
+@pytest.mark.parametrize("gmag", [1e-6, 1.0, 3e3])
+def test_training_layers_on_the_split_f16_engine_match_torch_at_any_gradient_scale(dev, monkeypatch, gmag):
+    """Strided, 1x1x1, direct stride-1 and Winograd 3x3x3 layers through ConvRowsFn: forward on the split-f16 kernels with
+    device-made packs, stride-1 dgrad on the same engine with the gradient operand scaled by a power of two chosen on the device
+    from max |dacc| (coocc_conv_epilogue_bwd_ex) -- against torch autograd, at upstream-gradient magnitudes from 1e-6 (an unscaled
+    f16 operand would be subnormal) to 3e3 (an unscaled Winograd-transformed operand would overflow)."""
     from co_occ_amd import autograd as ag
     monkeypatch.setattr(core, "H2_DIRECT_MIN_FLOPS", 0.0)
-    monkeypatch.setattr(ag, "TRAIN_H2_DGRAD", True)
-    monkeypatch.setattr(ag, "TRAIN_H2_DGRAD_SCALE", 4096.0)
-    assert ag.TRAIN_H2
+    monkeypatch.setattr(core, "WINO_MIN_ROWS", 0)
+    assert ag.TRAIN_H2 and ag.TRAIN_H2_DGRAD
     g = torch.Generator().manual_seed(11)
     r2d = lambda t: t.permute(0, 2, 3, 4, 1).reshape(-1, t.shape[1]).contiguous()       # [B,C,X,Y,Z] -> rows [B*X*Y*Z, C]
-    B, X, Y, Z, Cin, Cout = 1, 12, 10, 4, 64, 96
+    B, X, Y, Z, Cin, Cout = 1, 12, 12, 4, 64, 96
     x = torch.randn(B, Cin, X, Y, Z, generator=g)
-    for k, stride in ((3, 2), (1, 1), (3, 1)):
+    for k, stride, wino in ((3, 2, False), (1, 1, False), (3, 1, False), (3, 1, True)):
         w = torch.randn(Cout, Cin, k, k, k, generator=g) * 0.05
         xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
         yr = F.relu(F.conv3d(xr, wr, stride=stride, padding=k // 2))
-        up = torch.randn(yr.shape, generator=g) * 1e-6
+        up = torch.randn(yr.shape, generator=g) * gmag
         yr.backward(up)
         xd = r2d(x).to(dev).requires_grad_(True)
         wd = w.to(dev).requires_grad_(True)
-        monkeypatch.setattr(ag, "TRAIN_WINO", False)        # keep the 3x3x3 stride-1 case on the direct kernels too
+        monkeypatch.setattr(ag, "TRAIN_WINO", wino)
         yd, _ = ag.conv3d_rows(xd, wd, (B, X, Y, Z), stride=stride, pad=k // 2, relu=True)
         yd.backward(r2d(up).to(dev))
         torch.cuda.synchronize()
         core.check_h2_overflow()
-        assert_close(yd.detach().cpu(), r2d(yr.detach()), what="h2 train fwd k%d s%d" % (k, stride))
-        assert_close(xd.grad.cpu(), r2d(xr.grad), what="h2 train dgrad k%d s%d" % (k, stride))
-        assert_close(wd.grad.cpu(), wr.grad, what="h2 train wgrad k%d s%d" % (k, stride))
+        what = "k%d s%d wino=%d |dy|~%g" % (k, stride, wino, gmag)
+        assert_close(yd.detach().cpu(), r2d(yr.detach()), what="h2 train fwd " + what)
+        assert_close(xd.grad.cpu(), r2d(xr.grad), what="h2 train dgrad " + what)
+        assert_close(wd.grad.cpu(), wr.grad, what="h2 train wgrad " + what)
