@@ -117,6 +117,10 @@ SIGNATURES = {
     "coocc_wino_gradout": (I, [P, I, I, I, I, I, I, I, P, L, P]),
     "coocc_wino_ztap_table": (I, [L, I, P, P]),
     "coocc_wino_wgrad": (I, [P, P, L, I, I, I, I, P, P, I, P, L, P]),
+    "coocc_rows_to_kh2": (I, [P, I, L, L, I, F, P, P, P]),
+    "coocc_wino_operand_kh2": (I, [I, P, I, I, I, I, I, I, I, P, L, F, P, P]),
+    "coocc_conv_wgrad_h2": (I, [P, P, L, I, I, F, P, P, I, P, L, P]),
+    "coocc_wino_wgrad_h2": (I, [P, P, L, I, I, I, I, F, P, P, I, P, L, P]),
     "coocc_conv_tap_table": (I, [I, I, I, I, I, I, I, I, I, I, I, P, P]),
     "coocc_conv_epilogue_bwd": (I, [P, I, P, I, P, I, I, I, P, I, P, I, I, P, I, P, L, P]),
     "coocc_conv_epilogue_bwd_ex": (I, [P, I, P, I, P, I, I, I, P, I, P, I, I, P, I, P, L, P, P, F, P]),

@@ -33,6 +33,10 @@ TRAIN_H2 = __import__("os").environ.get("COOCC_TRAIN_H2", "1") != "0"
 # COOCC_TRAIN_H2_DGRAD=0: dgrad on the fp32-MFMA kernels.
 TRAIN_H2_DGRAD = TRAIN_H2 and __import__("os").environ.get("COOCC_TRAIN_H2_DGRAD", "1") != "0"
 TRAIN_H2_GRAD_TARGET = 1024.0
+# ... and the weight gradients (csrc/wgrad_h2.hip): the Winograd-domain form of the 3x3x3 stride-1 layers (Z in {2, 4, 8}) and the
+# 1x1x1 / Linear layers, both operands rewritten voxel-major (KH2), the gradient one with the same device-chosen scale.
+# COOCC_TRAIN_H2_WGRAD=0: the fp32-MFMA k_wgrad.
+TRAIN_H2_WGRAD = TRAIN_H2 and __import__("os").environ.get("COOCC_TRAIN_H2_WGRAD", "1") != "0"
 _amax_words = {}
 
 
@@ -212,8 +216,14 @@ def _wino_train(x2d, geom, w5, dgrad, out2d, scale, shift, res2d, relu, grad_sca
 _ztables = {}
 
 
-def _wino_wgrad(x2d, dacc, geom, Cin, Cout, dw):
-    """Weight gradient of a 3x3x3 stride-1 pad-1 layer in the Winograd domain; False if the layer is not eligible."""
+def _kh2(x2d, rows, rows_pad, C, scale, scale_dev, out):
+    call("coocc_rows_to_kh2", ptr(x2d), C, rows, rows_pad, C, float(scale), ptr(scale_dev), ptr(out))
+    return out
+
+
+def _wino_wgrad(x2d, dacc, geom, Cin, Cout, dw, gscale=None):
+    """Weight gradient of a 3x3x3 stride-1 pad-1 layer in the Winograd domain; False if the layer is not eligible.
+    ``gscale``: the device-side {scale, 1 / scale} of dacc -> the GEMM runs on the split-f16 engine (csrc/wgrad_h2.hip)."""
     from . import core
     if not TRAIN_WINO_WGRAD:
         return False
@@ -228,6 +238,19 @@ def _wino_wgrad(x2d, dacc, geom, Cin, Cout, dw):
     ws = workspace(dev)
     if ws.numel() < pts * 3 * Cin * Cout or pts * G * max(Cin, Cout) * 4 >= 0xFFFFFF00:
         return False
+    if TRAIN_H2_WGRAD and gscale is not None and core.CONV_ENGINE == "h2" and Z in (2, 4, 8) and Cin % 4 == 0 and Cout % 4 == 0:
+        # both operands straight into the voxel-major split-f16 form (no fp32 V / dM): V (|V| <= 100 |x|) with the forward path's
+        # static scale; dM = A dY A^T amplifies by up to 15^2 on top of the device-chosen gradient scale (max |dacc| -> [512, 1024)):
+        # 1/16 keeps it below the f16 range
+        vs, ms = core.H2_WINO_SCALE[tile], 1.0 / 16.0
+        Vk = core._wino_buffer(dev, "Vk", pts * G * Cin)
+        Mk = core._wino_buffer(dev, "Mk", pts * G * Cout)
+        call("coocc_wino_operand_kh2", 0, ptr(x2d), x2d.shape[1], B, X, Y, Z, Cin, tile, ptr(Vk), G, vs, None)
+        call("coocc_wino_operand_kh2", 1, ptr(dacc), dacc.shape[1], B, X, Y, Z, Cout, tile, ptr(Mk), G, ms, ptr(gscale))
+        with _lib.TIMER.region("k_wgrad_h2 wino%d" % tile, 2.0 * pts * rows * 3 * Cin * Cout):
+            call("coocc_wino_wgrad_h2", ptr(Vk), ptr(Mk), G, Z, Cin, Cout, tile, 1.0 / (vs * ms), _second_word(gscale), ptr(dw), 0,
+                 ptr(ws), ws.numel())
+        return True
     V = core._wino_buffer(dev, "V", pts * G * Cin)
     dM = core._wino_buffer(dev, "M", pts * G * Cout)
     if G > rows:        # rows past the valid ones (stale from other layers) must not contribute
@@ -337,8 +360,10 @@ class ConvRowsFn(torch.autograd.Function):
         from . import core
         # split-f16 dgrad: max |dacc| collected by the pass that writes dacc -> {scale, 1 / scale} on the device (see TRAIN_H2_DGRAD)
         gscale = None
-        if TRAIN_H2_DGRAD and need_x and core.CONV_ENGINE == "h2" and Cp == Cout and Cout % 32 == 0 and stride == 1:
+        if (core.CONV_ENGINE == "h2" and Cp == Cout and stride == 1 and Cin % 4 == 0 and
+                ((TRAIN_H2_DGRAD and need_x and Cout % 32 == 0) or (TRAIN_H2_WGRAD and need_w))):
             gscale = torch.empty(2, device=dev, dtype=_F32)
+        gscale_d = gscale if (TRAIN_H2_DGRAD and Cout % 32 == 0) else None      # the dgrad GEMM's K is Cout
         call("coocc_conv_epilogue_bwd_ex", ptr(dout), Cout, ptr(out), Cout, ptr(scale), Mo, Cout, int(relu), ptr(dacc), Cp,
              ptr(dres), Cout, 0, ptr(dbias), 0, ptr(ws), ws.numel(), ptr(_amax_word(dev)) if gscale is not None else None,
              ptr(gscale), TRAIN_H2_GRAD_TARGET)
@@ -350,7 +375,7 @@ class ConvRowsFn(torch.autograd.Function):
             w3 = weight.reshape(Cout, Cin, taps)
             if (stride == 1 and ksize == 3 and pad == 1 and Cp == Cout and
                     _wino_train(dacc, geom, weight.detach().float().contiguous().view(Cout, Cin, 3, 3, 3), True, dx, None, None,
-                                None, False, grad_scale=gscale)):
+                                None, False, grad_scale=gscale_d)):
                 pass
             elif stride == 1:
                 kd, wsub, nt, pd = None, w3, taps, ksize - 1 - pad
@@ -359,11 +384,11 @@ class ConvRowsFn(torch.autograd.Function):
                     if hi - lo < 2:
                         wsub = weight.detach().float().view(Cout, Cin, 3, 3, 3)[..., 2 - hi:2 - lo + 1].contiguous().view(Cout, Cin, -1)
                         nt, kd = wsub.shape[2], (3, 3, hi - lo + 1, pd, pd, pd - lo)
-                if gscale is not None and _h2_direct(Cout, 2.0 * Mi * Cin * Cout * nt):
+                if gscale_d is not None and _h2_direct(Cout, 2.0 * Mi * Cin * Cout * nt):
                     # the gradient operand scaled by gscale[0] (chosen on the device), undone by the GEMM through gscale[1]
-                    _conv_launch(_rows_h2(dacc, Cout, gscale), Cout, pack_weights_h2_dev(wsub, Cout, Cin, nt, 2), dx, Cin,
+                    _conv_launch(_rows_h2(dacc, Cout, gscale_d), Cout, pack_weights_h2_dev(wsub, Cout, Cin, nt, 2), dx, Cin,
                                  nt, geom_out, geom, ksize, 1, pd, None, None, None, False, tag="conv_dgrad", kdims=kd,
-                                 h2_alpha=1.0, alpha_dev=_second_word(gscale))
+                                 h2_alpha=1.0, alpha_dev=_second_word(gscale_d))
                 else:
                     wp = pack_weights_dev(wsub, Cout, Cin, nt, 2)
                     _conv_launch(dacc, Cp, wp, dx, Cin, nt, geom_out, geom, ksize, 1, pd, None, None, None, False,
@@ -376,7 +401,19 @@ class ConvRowsFn(torch.autograd.Function):
                                  False, table=table_c, tag="conv_dgrad", out_rows=rows_c)
         if need_w:
             dw = torch.empty(Cout, Cin, taps, device=dev, dtype=_F32)
-            if not (ksize == 3 and stride == 1 and pad == 1 and Cp == Cout and _wino_wgrad(x2d, dacc, geom, Cin, Cout, dw)):
+            if ksize == 3 and stride == 1 and pad == 1 and Cp == Cout and _wino_wgrad(x2d, dacc, geom, Cin, Cout, dw,
+                                                                                        gscale if TRAIN_H2_WGRAD else None):
+                pass
+            elif (TRAIN_H2_WGRAD and gscale is not None and taps == 1 and stride == 1
+                  and 2.0 * Mo * Cin * Cout >= core.H2_DIRECT_MIN_FLOPS):
+                # 1x1x1 / Linear: both operands voxel-major (KH2), the gradient with its device-chosen scale
+                Mp = -(-Mo // 16) * 16
+                xk = _kh2(x2d, Mi, Mp, Cin, 1.0, None, torch.empty(Mp * Cin, device=dev, dtype=_F32))
+                dk = _kh2(dacc, Mo, Mp, Cout, 1.0, gscale, torch.empty(Mp * Cout, device=dev, dtype=_F32))
+                with _lib.TIMER.region("k_wgrad_h2", 2.0 * Mo * Cin * Cout):
+                    call("coocc_conv_wgrad_h2", ptr(xk), ptr(dk), Mp, Cin, Cout, 1.0, _second_word(gscale), ptr(dw), 0, ptr(ws),
+                         ws.numel())
+            else:
                 tb = tap_table(dev, B, Xi, Yi, Zi, ksize, stride, pad, False) if (taps > 1 or stride > 1) else None
                 live = live_taps(dev, B, Xi, Yi, Zi, ksize, stride, pad) if tb is not None else None
                 if live is not None and live[0].numel() < taps:

@@ -405,6 +405,143 @@ extern "C" int coocc_wino_gradout(const float* dy, int dy_stride, int B, int X, 
   return COOCC_OK;
 }
 
+// ------------------------------------------------------------------ transforms that write the weight-gradient operands (KH2)
+// csrc/wgrad_h2.hip reads both operands of the Winograd-domain weight gradient "k-major": [row / 8][hi | lo][C][8 rows as f16].
+// A workgroup owns one group of 8 consecutive (tile, z) rows x 128 channels (thread = (row, channel quad), the arithmetic of
+// k_wino_in_h2 / k_wino_gradout), and after each sixth of the transform (the N points of one a / xi index) the 8 rows trade places
+// through a 24 KB LDS tile so that every (point, plane, channel) leaves as ONE 16-byte store -- the fp32 V / dM and the conversion
+// pass over them (2 x 92 MB at 128 channels and 100x100x8, the most expensive part of the h2 weight gradient) are never written.
+typedef _Float16 f16x8w __attribute__((ext_vector_type(8)));
+
+template <int N>
+__device__ __forceinline__ void kh2_emit(const f32x4 (&q)[N], float scale, char* lds, int rz, int cql, char* out, size_t pstride_bytes,
+                                         long long g, int C, int c0, int* flag) {
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    const f32x4 v = q[e] * scale;
+    h2_guard(flag, v);
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      _Float16 hi, lo;
+      split_h2(v[ch], hi, lo);
+      const int cs = 4 * cql + ch, slot = cs ^ ((cs >> 3) & 7);      // XOR skew: the 32 channel quads of a wave spread over all banks
+      *(_Float16*)(lds + ((e * 2 + 0) * 128 + slot) * 16 + rz * 2) = hi;
+      *(_Float16*)(lds + ((e * 2 + 1) * 128 + slot) * 16 + rz * 2) = lo;
+    }
+  }
+  __syncthreads();
+  for (int u = threadIdx.x; u < N * 256; u += 256) {
+    const int e = u >> 8, plane = (u >> 7) & 1, c = (u & 127) ^ (((u & 127) >> 3) & 7);
+    if (c0 + c < C)
+      *(f16x8w*)(out + (size_t)e * pstride_bytes + (((size_t)g * 2 + plane) * C + c0 + c) * 16) = *(const f16x8w*)(lds + u * 16);
+  }
+  __syncthreads();
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_wino_in_kh2(const float* __restrict__ in, int in_stride, int B, int X, int Y, int Z, int C,
+                                                      int Tx, int Ty, size_t pstride_bytes, float scale,
+                                                      const float* __restrict__ scale_dev, char* __restrict__ Vk, int* __restrict__ flag) {
+  constexpr int MO = Wino<N>::M;
+  __shared__ __attribute__((aligned(16))) char lds[N * 2 * 128 * 16];
+  if (scale_dev) scale *= *scale_dev;
+  const int rz = threadIdx.x >> 5, cql = threadIdx.x & 31, c0 = blockIdx.y * 128, c = c0 + 4 * cql;
+  const long long g = blockIdx.x, row = 8 * g + rz, rows = (long long)B * Tx * Ty * Z;
+  const bool live = row < rows && c < C;
+  long long r = row;
+  const int z = (int)(r % Z); r /= Z;
+  const int ty = (int)(r % Ty); r /= Ty;
+  const int tx = (int)(r % Tx); const int b = (int)(r / Tx);
+  f32x4 t[N][N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    f32x4 d[N], q[N];
+    const int y = MO * ty - 1 + e;
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+      const int x = MO * tx - 1 + a;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (live && (unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y)
+        v = *(const f32x4*)(in + ((((size_t)b * X + x) * Y + y) * Z + z) * in_stride + c);
+      d[a] = v;
+    }
+    Wino<N>::bt(d, q);
+#pragma unroll
+    for (int a = 0; a < N; ++a) t[a][e] = q[a];
+  }
+#pragma unroll
+  for (int a = 0; a < N; ++a) {
+    f32x4 q[N];
+    Wino<N>::bt(t[a], q);
+    kh2_emit<N>(q, scale, lds, rz, cql, Vk + (size_t)(a * N) * pstride_bytes, pstride_bytes, g, C, c0, flag);
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_wino_gradout_kh2(const float* __restrict__ dy, int dy_stride, int B, int X, int Y, int Z, int C,
+                                                           int Tx, int Ty, size_t pstride_bytes, float scale,
+                                                           const float* __restrict__ scale_dev, char* __restrict__ Mk,
+                                                           int* __restrict__ flag) {
+  constexpr int MO = Wino<N>::M;
+  __shared__ __attribute__((aligned(16))) char lds[N * 2 * 128 * 16];
+  if (scale_dev) scale *= *scale_dev;
+  const int rz = threadIdx.x >> 5, cql = threadIdx.x & 31, c0 = blockIdx.y * 128, c = c0 + 4 * cql;
+  const long long g = blockIdx.x, row = 8 * g + rz, rows = (long long)B * Tx * Ty * Z;
+  const bool live = row < rows && c < C;
+  long long r = row;
+  const int z = (int)(r % Z); r /= Z;
+  const int ty = (int)(r % Ty); r /= Ty;
+  const int tx = (int)(r % Tx); const int b = (int)(r / Tx);
+  f32x4 t[N][MO];
+#pragma unroll
+  for (int j = 0; j < MO; ++j) {
+    f32x4 d[MO], q[N];
+    const int y = MO * ty + j;
+#pragma unroll
+    for (int a = 0; a < MO; ++a) {
+      const int x = MO * tx + a;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (live && x < X && y < Y) v = *(const f32x4*)(dy + ((((size_t)b * X + x) * Y + y) * Z + z) * dy_stride + c);
+      d[a] = v;
+    }
+    Wino<N>::a(d, q);
+#pragma unroll
+    for (int xi = 0; xi < N; ++xi) t[xi][j] = q[xi];
+  }
+#pragma unroll
+  for (int xi = 0; xi < N; ++xi) {
+    f32x4 q[N];
+    Wino<N>::a(t[xi], q);
+    kh2_emit<N>(q, scale, lds, rz, cql, Mk + (size_t)(xi * N) * pstride_bytes, pstride_bytes, g, C, c0, flag);
+  }
+}
+
+// which = 0: V (coocc_wino_input's transform), 1: dM (coocc_wino_gradout's) -- as KH2 [(tile+2)^2][group_rows / 8][2][C][8 f16]
+extern "C" int coocc_wino_operand_kh2(int which, const float* x, int x_stride, int B, int X, int Y, int Z, int C, int tile, void* out_kh2,
+                                      int64_t group_rows, float scale, const float* scale_dev, void* stream) {
+  COOCC_CHECK_ARG((which == 0 || which == 1) && x && out_kh2 && B > 0 && X > 0 && Y > 0 && Z > 0 && C > 0 && C % 4 == 0 &&
+                  x_stride % 4 == 0 && scale > 0.f, "wino_operand_kh2: bad args");
+  COOCC_CHECK_ARG(tile >= 2 && tile <= 4 && group_rows % 16 == 0 && ((uintptr_t)out_kh2 & 15) == 0 && ((uintptr_t)x & 15) == 0,
+                  "wino_operand_kh2: tile 2..4, group_rows % 16 == 0, 16-byte aligned pointers");
+  const int Tx = (X + tile - 1) / tile, Ty = (Y + tile - 1) / tile;
+  COOCC_CHECK_ARG(group_rows >= (long long)B * Tx * Ty * Z, "wino_operand_kh2: group_rows too small");
+  const dim3 grid((unsigned)(group_rows / 8), (unsigned)((C + 127) / 128));
+  const size_t ps = (size_t)group_rows * C * 4;
+  hipStream_t s = as_stream(stream);
+  int* flag = nullptr;
+  if (coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
+#define COOCC_KH2_LAUNCH(K, NN) hipLaunchKernelGGL(K<NN>, grid, dim3(256), 0, s, x, x_stride, B, X, Y, Z, C, Tx, Ty, ps, scale, scale_dev, \
+                                                   (char*)out_kh2, flag)
+  if (which == 0) {
+    if (tile == 2) COOCC_KH2_LAUNCH(k_wino_in_kh2, 4); else if (tile == 3) COOCC_KH2_LAUNCH(k_wino_in_kh2, 5); else COOCC_KH2_LAUNCH(k_wino_in_kh2, 6);
+  } else {
+    if (tile == 2) COOCC_KH2_LAUNCH(k_wino_gradout_kh2, 4); else if (tile == 3) COOCC_KH2_LAUNCH(k_wino_gradout_kh2, 5); else COOCC_KH2_LAUNCH(k_wino_gradout_kh2, 6);
+  }
+#undef COOCC_KH2_LAUNCH
+  COOCC_LAUNCH_CHECK("k_wino_operand_kh2");
+  return COOCC_OK;
+}
+
 // ------------------------------------------------------------------ device-side weight transform (training)
 // U[p = xi*(m+2) + eta][dz] = sum_{a,b} G[xi][a] G[eta][b] g[a][b][dz], written straight into the fragment-major packs
 // the grouped GEMM reads (one pack per transform point, conv_layout.h).  Training re-packs every step, so the host

@@ -344,6 +344,25 @@ int coocc_wino_ztap_table(int64_t rows_total, int Z, int32_t* table, void* strea
 int coocc_wino_wgrad(const float* V, const float* dM, int64_t group_rows, int Z, int Cin, int Cout, int tile,
                      const int32_t* ztap_table, float* dw, int accumulate, float* ws, int64_t ws_floats,
                      void* stream);
+/* Weight gradients on the split-f16 engine (csrc/wgrad_h2.hip; the reference's cuDNN fp32 backward of resnet3d.py:34-64,
+ * fpn3d.py:70-106): both operands "k-major" (KH2: [rows_pad / 8][hi | lo][C][8 rows as f16], rows past `rows` zero, rows_pad % 16
+ * == 0) so that a lane's 32x32x16 MFMA fragment -- 8 consecutive voxels of one channel -- is one 16-byte read.
+ * coocc_rows_to_kh2: fp32 rows * scale (* *scale_dev when given: the device-chosen gradient scale of coocc_conv_epilogue_bwd_ex).
+ * coocc_conv_wgrad_h2: dw[Cout][Cin] (=|+=) sum_m x[m][c] dy[m][n] * alpha (* *alpha_dev) -- the 1x1x1 / Linear layers.
+ * coocc_wino_wgrad_h2: coocc_wino_wgrad from the KH2 forms of V and dM, Z in {2, 4, 8} (a group of 8 rows holds whole z columns:
+ * the three z taps reuse one fragment, shifted by an f16 lane).  ws as for the fp32 entry points. */
+int coocc_rows_to_kh2(const float* x, int stride, int64_t rows, int64_t rows_pad, int C, float scale, const float* scale_dev,
+                      void* out_kh2, void* stream);
+/* The two operands of coocc_wino_wgrad_h2 straight from the activations (which = 0: V, the transform of coocc_wino_input) / the
+ * gradients (which = 1: dM, the transform of coocc_wino_gradout) in KH2 form -- no fp32 V / dM, no conversion pass; every row of
+ * the group_rows per point is written (rows past the valid ones: zero). */
+int coocc_wino_operand_kh2(int which, const float* x, int x_stride, int B, int X, int Y, int Z, int C, int tile, void* out_kh2,
+                           int64_t group_rows, float scale, const float* scale_dev, void* stream);
+int coocc_conv_wgrad_h2(const void* x_kh2, const void* dy_kh2, int64_t rows_pad, int Cin, int Cout, float alpha,
+                        const float* alpha_dev, float* dw, int accumulate, float* ws, int64_t ws_floats, void* stream);
+int coocc_wino_wgrad_h2(const void* V_kh2, const void* dM_kh2, int64_t group_rows, int Z, int Cin, int Cout, int tile,
+                        float alpha, const float* alpha_dev, float* dw, int accumulate, float* ws, int64_t ws_floats,
+                        void* stream);
 
 /* ---------------------------------------------------------------- backward of the conv family
  * Frozen-statistics BN (scale/shift constants), as the forward.  torch.autograd computes these through

@@ -216,17 +216,18 @@ def test_device_made_direct_h2_pack_equals_host_layout(dev, mode):
 def test_training_layers_on_the_split_f16_engine_match_torch_at_any_gradient_scale(dev, monkeypatch, gmag):
     """Strided, 1x1x1, direct stride-1 and Winograd 3x3x3 layers through ConvRowsFn: forward on the split-f16 kernels with
     device-made packs, stride-1 dgrad on the same engine with the gradient operand scaled by a power of two chosen on the device
-    from max |dacc| (coocc_conv_epilogue_bwd_ex) -- against torch autograd, at upstream-gradient magnitudes from 1e-6 (an unscaled
+    from max |dacc| (coocc_conv_epilogue_bwd_ex), the 1x1x1 and Winograd-domain (Z = 2, 4, 8) weight gradients on csrc/wgrad_h2.hip
+    with voxel-major operands -- against torch autograd, at upstream-gradient magnitudes from 1e-6 (an unscaled
     f16 operand would be subnormal) to 3e3 (an unscaled Winograd-transformed operand would overflow)."""
     from co_occ_amd import autograd as ag
     monkeypatch.setattr(core, "H2_DIRECT_MIN_FLOPS", 0.0)
     monkeypatch.setattr(core, "WINO_MIN_ROWS", 0)
-    assert ag.TRAIN_H2 and ag.TRAIN_H2_DGRAD
+    assert ag.TRAIN_H2 and ag.TRAIN_H2_DGRAD and ag.TRAIN_H2_WGRAD
     g = torch.Generator().manual_seed(11)
     r2d = lambda t: t.permute(0, 2, 3, 4, 1).reshape(-1, t.shape[1]).contiguous()       # [B,C,X,Y,Z] -> rows [B*X*Y*Z, C]
-    B, X, Y, Z, Cin, Cout = 1, 12, 12, 4, 64, 96
-    x = torch.randn(B, Cin, X, Y, Z, generator=g)
-    for k, stride, wino in ((3, 2, False), (1, 1, False), (3, 1, False), (3, 1, True)):
+    B, X, Y, Cin, Cout = 1, 12, 12, 64, 96
+    for k, stride, wino, Z in ((3, 2, False, 4), (1, 1, False, 4), (3, 1, False, 4), (3, 1, True, 4), (3, 1, True, 8), (3, 1, True, 2)):
+        x = torch.randn(B, Cin, X, Y, Z, generator=g)
         w = torch.randn(Cout, Cin, k, k, k, generator=g) * 0.05
         xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
         yr = F.relu(F.conv3d(xr, wr, stride=stride, padding=k // 2))
@@ -239,7 +240,7 @@ def test_training_layers_on_the_split_f16_engine_match_torch_at_any_gradient_sca
         yd.backward(r2d(up).to(dev))
         torch.cuda.synchronize()
         core.check_h2_overflow()
-        what = "k%d s%d wino=%d |dy|~%g" % (k, stride, wino, gmag)
+        what = "k%d s%d wino=%d Z=%d |dy|~%g" % (k, stride, wino, Z, gmag)
         assert_close(yd.detach().cpu(), r2d(yr.detach()), what="h2 train fwd " + what)
         assert_close(xd.grad.cpu(), r2d(xr.grad), what="h2 train dgrad " + what)
         assert_close(wd.grad.cpu(), wr.grad, what="h2 train wgrad " + what)

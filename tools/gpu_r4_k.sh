@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r4k
 mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests/test_gpu_backward.py tests/test_gpu_h2_engine.py tests/test_abi.py -q > $O/pytest.txt 2>&1
+timeout 1500 python -m pytest tests/test_gpu_h2_engine.py tests/test_gpu_backward.py tests/test_abi.py -q -x > $O/pytest.txt 2>&1
 grep -E "^(FAILED|ERROR)|passed|failed" $O/pytest.txt | tail -n 12
 timeout 600 python bench.py --train --steps 10 --warmup 2 > $O/train.json 2> $O/train.err
 timeout 600 python bench.py --train --steps 10 --warmup 2 --train-prefetch 0 > $O/train_noprefetch.json 2> $O/train_np.err
