@@ -72,7 +72,7 @@ def make_inputs(cfgname, seed, dev, model):
                 cpu=dict(img=img, pts=pts, rig=rig, img_feats=[img_feats[0].cpu()], lift=(depth, ctx)))
 
 
-def build_model(cfgname, dev):
+def build_model(cfgname, dev, with_lidar=False):
     c = synth.CONFIGS[cfgname]
     fH, fW = c["fmap"]
     X, Y, Z = c["grid"]
@@ -82,6 +82,8 @@ def build_model(cfgname, dev):
         cfg = synth.model_cfg(C=c["C"], knum=c["knum"], final_occ_size=(2 * X, 2 * Y, 2 * Z), input_size=(fH * 16, fW * 16))
         cfg["img_view_transformer"]["grid_config"].update(synth.pool_bounds(cfgname))
     c["bounds"] = synth.pool_bounds(cfgname)
+    if with_lidar:          # the LiDAR producer of the reference config (coocc_multi_r50_256x704.py:121-134) joins the step
+        cfg.update(synth.lidar_cfg())
     model = pkg.build_detector(cfg)
     sd = synth.random_state_dict(model.state_dict(), seed=0)
     model.load_state_dict(sd)
@@ -560,7 +562,12 @@ class Pipeline:
 
 def frame_of(s):
     """The frame dict ``co_occ_amd.serving.ServingPipeline.submit`` takes, from one synthetic sample (``make_inputs``)."""
-    return dict(depth=s["depth"], ctx=s["ctx"], cams=s["cams"], pts=s["pts"], img_feats=s["img_feats"], transform=s["transform"])
+    fr = dict(depth=s["depth"], ctx=s["ctx"], cams=s["cams"], img_feats=s["img_feats"], transform=s["transform"])
+    if s.get("points") is not None:        # --with-lidar: raw points, the LiDAR producer runs inside the step
+        fr["points"] = s["points"]
+    else:
+        fr["pts"] = s["pts"]
+    return fr
 
 
 def simple_test_kwargs(s):
@@ -691,6 +698,10 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default): the dense stage of a sample is one captured hipGraph launch (co_occ_amd.serving.ServingPipeline); 0: every launch "
                          "issued from Python (Pipeline, --streams)")
+    ap.add_argument("--with-lidar", action="store_true",
+                    help="the LiDAR producer (hard voxelisation of a synthetic 280 k-point cloud -> HardSimpleVFE -> SparseLiDAREnc8x, "
+                         "coocc_ray.py:215-234) runs inside the step on the prefetch stream instead of a ready-made LiDAR volume "
+                         "(serving pipeline only; its own workload: the encoder's active set is denser than the default volume)")
     ap.add_argument("--train-prefetch", type=int, default=1, help="--train: 1 = the index search of the next step runs on a side stream under "
                     "the current step (indices depend on the batch only); 0 = inside the step")
     ap.add_argument("--ahead", type=int, default=0, help="--graph 1: searches submitted ahead of the dense stage (0: slots - dense streams; "
@@ -748,10 +759,17 @@ def main():
     if SHARD[0]:
         args.graph, args.streams = 0, 1           # the sharded render has a collective inside the step: eager, one sample in flight
         auto_streams = False
-    model, sd = build_model(args.config, dev)
+    model, sd = build_model(args.config, dev, with_lidar=args.with_lidar)
     if args.train:
         return train_main(args, model, dev, rank, world, seen_world, backend_name)
     samples = [make_inputs(args.config, 1234 + (0 if SHARD[0] else 17 * rank) + i, dev, model) for i in range(max(2, args.slots if args.graph else 2))]
+    if args.with_lidar:
+        # raw points per sample; their volume (what the eager warm-up / roofline passes read) from the producer itself, untimed
+        args.no_cpu_baseline = True            # the CPU oracle of the sparse encoder is a test-size restatement (oracle/ref_lidar.py)
+        for i, s_ in enumerate(samples):
+            s_["points"] = synth.lidar_points(seed=8 + i + 17 * rank).to(dev)
+            with torch.no_grad():
+                s_["pts"] = model.extract_pts_feat(s_["points"])[0]
     if args.reserve_cus > 0:
         # CU partition: the FPS chains get private CUs, everything else runs on the remaining ones
         from co_occ_amd import streams as cstreams
@@ -940,7 +958,9 @@ def main():
                 ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True, scaling=("strong" if SHARD[0] else "weak"), vs_baseline=None,
                 dtype=("f32 (split-f16 products, fp32 accumulate)" if (args.dtype == "f32" and core.CONV_ENGINE == "h2") else args.dtype),
                 data="synthetic",
-                config=dict(workload="coocc_multi_r50_256x704 hot path" if args.config == "r50" else args.config,
+                config=dict(workload=("coocc_multi_r50_256x704 hot path" if args.config == "r50" else args.config) +
+                            (" + LiDAR producer in the step (280 k synthetic points -> hard voxelisation -> HardSimpleVFE -> SparseLiDAREnc8x)"
+                             if args.with_lidar else ""),
                             fused_grid="x".join(map(str, c["grid"])) + "x%d" % c["C"],
                             occupancy_grid="x".join(str(v) for v in c.get("final_occ_size", [2 * g for g in c["grid"]])), cams=c["ncam"],
                             render_maps="%dx%dx%d" % (c["ncam"], c["fmap"][0] * 16, c["fmap"][1] * 16), knum=c["knum"],

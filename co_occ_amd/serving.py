@@ -47,11 +47,11 @@ class Ticket:
     """One submitted frame.  ``result()`` issues every dense stage up to this frame (if the caller has not pumped them yet),
     optionally waits for it, and returns the output dict."""
 
-    __slots__ = ("pipe", "index", "slot", "frame", "search", "out", "done", "copy", "events", "fallback", "ready")
+    __slots__ = ("pipe", "index", "slot", "frame", "search", "out", "done", "copy", "events", "fallback", "ready", "pts_vol")
 
     def __init__(self, pipe, index, slot, frame, copy):
         self.pipe, self.index, self.slot, self.frame, self.copy = pipe, index, slot, frame, copy
-        self.search = self.out = self.done = self.events = None
+        self.search = self.out = self.done = self.events = self.pts_vol = None
         self.fallback = False
         # whatever produced the frame's tensors on the submitting thread's stream (the upstream encoders) is waited for by the
         # prefetch stream that reads them
@@ -75,7 +75,10 @@ class ServingPipeline:
                  time_dense=False):
         assert not model.training, "ServingPipeline serves the eval-mode (folded-BN) path"
         self.model = model
-        pts = example["pts"]
+        pts = example.get("pts")
+        if pts is None:            # raw LiDAR points: the producer (voxelisation + VFE + sparse encoder) runs in the search stage
+            with torch.no_grad():
+                pts = model.extract_pts_feat(example["points"])[0]
         self.dev = dev = pts.device
         _, _, X, Y, Z = pts.shape
         self.grid = (X, Y, Z)
@@ -156,16 +159,20 @@ class ServingPipeline:
                 if v.is_cuda:
                     v.record_stream(st)            # allocated on the caller's stream, read by this one
             self._copy_in(k, fr)
+            pts = fr.get("pts")
+            if pts is None:        # coocc_ray.py:215-234: points -> Voxelization -> HardSimpleVFE -> SparseLiDAREnc8x -> [1,C,X,Y,Z]
+                pts = self.model.extract_pts_feat(fr["points"])[0]
+            t.pts_vol = pts
             self._mark(t, "search_native")
             slot = self.slots[k]
             if fr.get("depth") is not None:
-                sr = cg.search_into_slot(self.model, slot, fr["depth"], fr["ctx"], fr["cams"], fr["pts"])
+                sr = cg.search_into_slot(self.model, slot, fr["depth"], fr["ctx"], fr["cams"], pts)
             else:
                 # an already-pooled camera volume: into slot 0 of the concat rows, then the same search
                 vol = fr["img_voxel_feats"]
                 slot.img_rows().as_ncdhw().copy_(vol)
-                sr = self.model.occ_fuser.search_native(fr["pts"], slot) if cg.NATIVE_SEARCH else \
-                    self.model.occ_fuser.search(slot.img_rows().as_ncdhw(), fr["pts"], slot=slot)
+                sr = self.model.occ_fuser.search_native(pts, slot) if cg.NATIVE_SEARCH else \
+                    self.model.occ_fuser.search(slot.img_rows().as_ncdhw(), pts, slot=slot)
             if self.time_dense:
                 if sr.done_side is not None:
                     st.wait_event(sr.done_side)
@@ -192,7 +199,7 @@ class ServingPipeline:
     def submit(self, frame, copy=False):
         """``frame``: dict(depth [N,D,fH,fW], ctx [N,C,fH,fW], cams=(rots, trans, intrins, post_rots, post_trans, bda),
         pts [1,C,X,Y,Z], img_feats=[[1,N,512,fH,fW]], transform=img_inputs[1:]) -- or ``img_voxel_feats`` [1,C,X,Y,Z] instead
-        of depth / ctx.  Shapes as the example's.  Returns a ``Ticket``.  The frame's tensors are read by the prefetched
+        of depth / ctx, and / or raw LiDAR ``points`` [n,F] instead of ``pts`` (the LiDAR producer then runs in the search stage).  Shapes as the example's.  Returns a ``Ticket``.  The frame's tensors are read by the prefetched
         search: do not overwrite them before ``Ticket.result()``."""
         with self._lock:
             i = self._submitted
@@ -255,7 +262,7 @@ class ServingPipeline:
                 self.fallbacks += 1
                 t.fallback = True
                 st = self.static[k]
-                vf = self.model.occ_fuser(self.slots[k].img_rows().as_ncdhw(), t.frame["pts"], search=sr)
+                vf = self.model.occ_fuser(self.slots[k].img_rows().as_ncdhw(), t.pts_vol, search=sr)
                 cam_geo = None
                 if self.render and st["cams"] is not None:
                     cam_geo = self.model.img_view_transformer._camera_mats(*st["cams"])
@@ -274,7 +281,7 @@ class ServingPipeline:
             ev.record()
         self.slot_done[k] = ev
         t.out, t.done = out, ev
-        t.frame = None                             # the search has consumed the frame's tensors (stream-ordered before `ev`)
+        t.frame = t.pts_vol = None                 # the search has consumed the frame's tensors (stream-ordered before `ev`)
 
     def drain(self):
         """Issue everything submitted so far and wait for it."""

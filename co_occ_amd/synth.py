@@ -177,3 +177,21 @@ def model_cfg(C=128, knum=2, block_inplanes=(128, 256, 512, 1024), out_channels=
                                                    dbound=[2.0, 58.0, 0.5]),
                                   data_config=dict(input_size=tuple(input_size))),
     )
+
+
+def lidar_cfg(point_cloud_range=(-50, -50, -5.0, 50, 50, 3.0), out_channel=128):
+    """The LiDAR-producer entries of projects/configs/coocc_nusc/coocc_multi_r50_256x704.py:121-134 (0.125 m voxels, <= 10 points per
+    voxel, <= 120 k voxels at test time, SparseLiDAREnc8x on [800,800,64])."""
+    return dict(pts_voxel_layer=dict(max_num_points=10, point_cloud_range=list(point_cloud_range), voxel_size=[0.125] * 3,
+                                     max_voxels=(90000, 120000)),
+                pts_voxel_encoder=dict(type='HardSimpleVFE', num_features=5),
+                pts_middle_encoder=dict(type='SparseLiDAREnc8x', input_channel=4, base_channel=16, out_channel=out_channel,
+                                        norm_cfg=dict(type='SyncBN', requires_grad=True), sparse_shape_xyz=[800, 800, 64]))
+
+
+def lidar_points(n=280000, seed=8):
+    """A synthetic 10-sweep nuScenes-like cloud [n,4] (x, y, z, intensity): range ~ sqrt(U) * 50 m, ground-hugging z."""
+    g = torch.Generator().manual_seed(seed)
+    r = torch.rand(n, generator=g) ** 0.5 * 50
+    th = torch.rand(n, generator=g) * 6.2832
+    return torch.stack([r * torch.cos(th), r * torch.sin(th), torch.randn(n, generator=g) * 0.8 - 1.5, torch.rand(n, generator=g)], 1)

@@ -100,3 +100,35 @@ def test_serving_takes_a_pooled_camera_volume_too(dev):
     assert model._pipe1 is not None, model.graph_unavailable
     for a, b in zip(*outs):
         _same(a, b, "pooled volume")
+
+
+def test_pipeline_takes_raw_lidar_points_and_matches_the_volume_it_would_have_been_given(dev):
+    """Frames that carry raw LiDAR points: the producer (Voxelization -> HardSimpleVFE -> SparseLiDAREnc8x, coocc_ray.py:215-234)
+    runs in the search stage; the outputs equal those of frames that carry the producer's volume."""
+    import bench
+    from co_occ_amd import synth
+    bench.CFGNAME[0] = "r50"
+    model, _ = bench.build_model("r50", dev, with_lidar=True)
+    samples = [bench.make_inputs("r50", 4100 + 7 * i, dev, model) for i in range(3)]
+    pts = [synth.lidar_points(n=60000, seed=20 + i).to(dev) for i in range(3)]
+    with torch.no_grad():
+        vols = [model.extract_pts_feat(p)[0] for p in pts]
+    base = [dict(bench.frame_of(s)) for s in samples]
+    fr_pts, fr_vol = [], []
+    for f, p, v in zip(base, pts, vols):
+        f.pop("pts", None)
+        fr_pts.append(dict(f, points=p))
+        fr_vol.append(dict(f, pts=v))
+    outs = []
+    for frames in (fr_vol, fr_pts):
+        pipe = model.serving(frames[0], slots=2, dense_streams=1)
+        res = []
+        for f in frames:
+            o = pipe.submit(f, copy=True).result()
+            res.append({k: o[k].clone() for k in ("pred_c", "rgbs", "depths")})
+        pipe.drain()
+        pipe.close()
+        outs.append(res)
+    for i, (a, b) in enumerate(zip(*outs)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), "frame %d: %s differs" % (i, k)
