@@ -311,6 +311,9 @@ class OccHead(nn.Module):
         at most ``fine_topk`` of them, drawn at random (coordinate_transform.py:17-21 permutes the COARSE columns and keeps
         the first topk).  logit_rows [V,ncls] -> int32 rows."""
         fg = torch.nonzero(logit_rows.argmax(1) != self.empty_idx).flatten()
+        # torch.nonzero read the count back: every kernel up to the coarse head (and the previous step's backward pass) has
+        # finished -- the training path's point to look at the split-f16 engine's range guard
+        core_mod.check_h2_overflow()
         if self.training and fg.numel() >= int(self.fine_topk):
             dev = fg.device if generator is None else generator.device
             sel = torch.randperm(fg.numel(), generator=generator, device=dev)[:int(self.fine_topk)]

@@ -18,6 +18,25 @@ timeout 300 python $R/bench.py --steps 40 --warmup 3 --no-cpu-baseline --graph 0
 COOCC_CONV_ENGINE=f32 timeout 300 python $R/bench.py --steps 40 --warmup 3 --no-cpu-baseline > $O/r4_bench_engine_f32.json 2>/dev/null
 timeout 300 python $R/bench.py --train --steps 10 --warmup 2 > $O/r4_bench_train.json 2> $O/r4_bench_train.err
 COOCC_TRAIN_H2=0 timeout 300 python $R/bench.py --train --steps 10 --warmup 2 > $O/r4_bench_train_f32.json 2>/dev/null
+timeout 300 python $R/bench.py --train --steps 10 --warmup 2 --train-prefetch 0 > $O/r4_bench_train_noprefetch.json 2>/dev/null
+COOCC_TRAIN_H2_WGRAD=0 timeout 300 python $R/bench.py --train --steps 10 --warmup 2 > $O/r4_bench_train_wgrad_f32.json 2>/dev/null
+COOCC_TRAIN_H2_DGRAD=0 timeout 300 python $R/bench.py --train --steps 10 --warmup 2 > $O/r4_bench_train_dgrad_f32.json 2>/dev/null
+timeout 300 python $R/bench.py --train --steps 20 --warmup 3 --no-kernel-timing > $O/r4_bench_train_notimers.json 2>/dev/null
+timeout 400 python $R/bench.py --with-lidar --steps 40 --warmup 3 > $O/r4_bench_with_lidar.json 2>/dev/null
+rm -rf /tmp/tt
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tt -o s -- python $R/bench.py --train --steps 10 --warmup 2 > /tmp/tt_train.json 2>/dev/null
+python - > $O/r4_train_kernels.txt 2>&1 < /dev/null <<PY
+import csv, json
+rows = list(csv.DictReader(open("/tmp/tt/s_kernel_stats.csv")))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+d = json.load(open("/tmp/tt_train.json"))
+print("bench.py --train --steps 10 --warmup 2 under rocprofv3 --kernel-trace --stats: %.2f ms/step wall (traced); kernel time %.1f ms over 12 steps + setup" % (d["ms_per_step"], tot / 1e6))
+for r in rows[:60]:
+    print("  %-78s calls %5s total %8.2f ms avg %8.1f us" % (r["Name"][:78], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3))
+PY
+( echo "tools/kbench.py lidar (280 k points -> 120 k voxels -> SparseLiDAREnc8x), MI355X, round 4"; echo; echo "== COOCC_LIDAR_H2=1 (default: rule-book GEMMs with Cin % 32 == 0 on the split-f16 engine)"; COOCC_LIDAR_H2=1 timeout 300 python $R/tools/kbench.py lidar 2>&1 | grep -v amdgpu.ids; echo; echo "== COOCC_LIDAR_H2=0 (fp32-MFMA row-table kernels, rounds 1-3)"; COOCC_LIDAR_H2=0 timeout 300 python $R/tools/kbench.py lidar 2>&1 | grep -v amdgpu.ids ) > $O/r4_kbench_lidar.txt
+timeout 300 python $R/tools/serving_trace.py r50 36 6 3 0 2>&1 | grep -v amdgpu.ids > $O/r4_serving_trace.txt
+( cd $R; mv -f gpurun_out/r4_parity_seed_sweep.txt /tmp/sweep_keep.txt 2>/dev/null; COOCC_CONENC_TILES=2,2 timeout 900 python -m pytest tests/test_gpu_parity_full.py -q -k "seed_sweep" > /dev/null 2>&1; mv -f gpurun_out/r4_parity_seed_sweep.txt $O/r4_parity_seed_sweep_tiles22.txt 2>/dev/null; mv -f /tmp/sweep_keep.txt gpurun_out/r4_parity_seed_sweep.txt 2>/dev/null )
 for cfg in r101 stress200 stress200_r101; do
   timeout 400 python $R/bench.py --config $cfg --steps 20 --warmup 3 --no-cpu-baseline > $O/r4_bench_$cfg.json 2> $O/r4_bench_$cfg.err
 done
