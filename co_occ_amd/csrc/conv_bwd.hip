@@ -57,23 +57,44 @@ extern "C" int64_t coocc_conv_pack_weights_dev(const float* w, int Cout, int Cin
 // [(K / 32 chunk, tap)][Npad / 32][2 k16 steps][hi | lo][64 lanes][8 f16], lane l of step s holds k = 32 chunk + 16 s + 8 (l >> 5) + 0..7
 // of column 32 nt + (l & 31); hi = f16(w), lo = f16((w - hi) 2^11).  Training re-packs from the live parameter every step, so its
 // direct (strided, 1x1x1, small-grid) forward and stride-1 dgrad GEMMs can run on the f16 matrix cores like inference's.
+// One thread per 16-byte unit of the pack (8 consecutive k of one column, both planes): the stores are whole 16-byte runs, 512
+// bytes contiguous per half-wave; the eight strided weight reads hit L2 (a layer's weights are a few MB).  The first version ran
+// one thread per WEIGHT with two scattered 2-byte stores each: 21 us per layer, 42 layers per training step.
 __global__ __launch_bounds__(256) void k_pack_weights_h2(const float* __restrict__ w, int Cout, int Cin, int taps, int mode, int Npad,
                                                           _Float16* __restrict__ packed, int* __restrict__ flag) {
-  const size_t total = (size_t)Cout * Cin * taps;
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  int n, c, t;
-  if (mode == 1) { c = (int)(i % Cin); size_t r = i / Cin; t = (int)(r % taps); n = (int)(r / taps); }
-  else { t = (int)(i % taps); size_t r = i / taps; c = (int)(r % Cin); n = (int)(r / Cin); }
-  const float v = w[i];
-  const int kk = mode >= 2 ? n : c, nn = mode >= 2 ? c : n, tt = mode == 2 ? taps - 1 - t : t;
-  const int chunk = kk >> 5, k32 = kk & 31, sidx = k32 >> 4, hf = (k32 >> 3) & 1, e = k32 & 7;
-  const int nt = nn >> 5, li = nn & 31;
-  _Float16* o = packed + ((((size_t)chunk * taps + tt) * (Npad >> 5) + nt) * 2 + sidx) * 2 * 512 + (size_t)(hf * 32 + li) * 8 + e;
-  const _Float16 hi = (_Float16)v;
-  o[0] = hi;
-  o[512] = (_Float16)((v - (float)hi) * 2048.0f);       // exact in fp32: v - hi has at most 13 significant bits
-  if (flag && !(fabsf(v) < 32768.0f)) *(volatile int*)flag = 1;
+  const int K = mode >= 2 ? Cout : Cin, N = mode >= 2 ? Cin : Cout;
+  // unit index: ((((chunk * taps + tt) * (Npad / 32) + nt) * 2 + s) * 2 + hf) * 32 + li   (plane handled inside)
+  const size_t units = (size_t)(K >> 5) * taps * (Npad >> 5) * 2 * 2 * 32;
+  size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= units) return;
+  const int li = (int)(u & 31); u >>= 5;
+  const int hf = (int)(u & 1); u >>= 1;
+  const int sidx = (int)(u & 1); u >>= 1;
+  const int nt = (int)(u % (Npad >> 5)); u /= (Npad >> 5);
+  const int tt = (int)(u % taps); const int chunk = (int)(u / taps);
+  const int nn = nt * 32 + li, kk0 = chunk * 32 + sidx * 16 + hf * 8;
+  const int t = mode == 2 ? taps - 1 - tt : tt;          // source tap of pack tap tt
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  h8 hi, lo;
+  float mx = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = 0.f;
+    if (nn < N) {
+      const int kk = kk0 + e;
+      // GEMM roles: forward K = Cin (c), N = Cout (n); dgrad K = Cout (n), N = Cin (c)
+      const int n = mode >= 2 ? kk : nn, c = mode >= 2 ? nn : kk;
+      v = mode == 1 ? w[((size_t)n * taps + t) * Cin + c] : w[((size_t)n * Cin + c) * taps + t];
+    }
+    const _Float16 h = (_Float16)v;
+    hi[e] = h;
+    lo[e] = (_Float16)((v - (float)h) * 2048.0f);          // exact in fp32: v - hi has at most 13 significant bits
+    mx = fmaxf(mx, fabsf(v));
+  }
+  _Float16* o = packed + ((((size_t)chunk * taps + tt) * (Npad >> 5) + nt) * 2 + sidx) * 2 * 512 + (size_t)(hf * 32 + li) * 8;
+  *(h8*)o = hi;
+  *(h8*)(o + 512) = lo;
+  if (flag && !(mx < 32768.0f)) *(volatile int*)flag = 1;
 }
 
 extern "C" int64_t coocc_conv_pack_weights_h2_dev(const float* w, int Cout, int Cin, int taps, int mode, void* packed, void* stream) {
@@ -85,12 +106,10 @@ extern "C" int64_t coocc_conv_pack_weights_h2_dev(const float* w, int Cout, int 
   if (!packed) return total_floats;
   if (!w) return coocc_set_error(COOCC_EINVAL, "pack_weights_h2_dev: null weights");
   hipStream_t s = as_stream(stream);
-  if (Npad != N && hipMemsetAsync(packed, 0, (size_t)total_floats * 4, s) != hipSuccess)
-    return coocc_set_error(COOCC_EHIP, "pack_weights_h2_dev: memset failed");
   int* flag = nullptr;
   if (coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
-  hipLaunchKernelGGL(k_pack_weights_h2, dim3(cdiv((long long)Cout * Cin * taps, 256)), dim3(256), 0, s, w, Cout, Cin, taps, mode, Npad,
-                     (_Float16*)packed, flag);
+  const long long units = (long long)(K / 32) * taps * (Npad / 32) * 2 * 2 * 32;       // padding columns are written (as zeros) too
+  hipLaunchKernelGGL(k_pack_weights_h2, dim3(cdiv(units, 256)), dim3(256), 0, s, w, Cout, Cin, taps, mode, Npad, (_Float16*)packed, flag);
   if (hipGetLastError() != hipSuccess) return coocc_set_error(COOCC_EHIP, "pack_weights_h2_dev: launch failed");
   return total_floats;
 }

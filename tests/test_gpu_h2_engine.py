@@ -244,3 +244,29 @@ def test_training_layers_on_the_split_f16_engine_match_torch_at_any_gradient_sca
         assert_close(yd.detach().cpu(), r2d(yr.detach()), what="h2 train fwd " + what)
         assert_close(xd.grad.cpu(), r2d(xr.grad), what="h2 train dgrad " + what)
         assert_close(wd.grad.cpu(), wr.grad, what="h2 train wgrad " + what)
+
+
+@pytest.mark.parametrize("tile,dgrad", [(4, 0), (4, 1), (2, 0)])
+def test_device_made_winograd_h2_pack_matches_host_pack(dev, tile, dgrad):
+    """coocc_wino_pack_weights_h2_dev (training: U = G g G^T in fp64 on the device, one thread per 16-byte unit of the pack) against
+    the host pack of the same weights (core.PackedConv.wino_h2_pack; for dgrad: of the flipped, transposed kernel).  Both split
+    the fp64 products; the two fp64 evaluation orders may differ in the last bit, so the decoded values hi + lo 2^-11 are compared
+    (1e-7 of the largest weight), and the padding columns must be zero."""
+    Cout, Cin = 96, 64
+    g = torch.Generator().manual_seed(17 + tile + dgrad)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.1
+    lib = _lib.load()
+    n = lib.coocc_wino_pack_weights_h2_dev(None, Cout, Cin, tile, dgrad, None, None)
+    assert n > 0
+    got = torch.empty(n, dtype=torch.float32, device=dev)
+    wd = w.to(dev).contiguous()
+    assert lib.coocc_wino_pack_weights_h2_dev(ptr(wd), Cout, Cin, tile, dgrad, ptr(got), _lib.stream(dev)) == n
+    ref_w = w if not dgrad else w.permute(1, 0, 2, 3, 4).flip(2, 3, 4).contiguous()      # dx = conv(dy, W'): W'[c][n][a][b][z] = w[n][c][2-a][2-b][2-z]
+    ref = core.PackedConv(ref_w.to(dev), ksize=3, stride=1, pad=1).wino_h2_pack(tile)
+
+    def decode(t):              # [..., 2 planes, 64 lanes, 8] f16 -> hi + lo / 2048 per (unit, lane, e)
+        h = t.cpu().view(torch.float16).double().view(-1, 2, 512)
+        return h[:, 0] + h[:, 1] / 2048.0
+    a, b = decode(got), decode(ref.contiguous().view(-1))
+    assert a.shape == b.shape
+    assert float((a - b).abs().max()) <= 1e-7 * float(b.abs().max())
