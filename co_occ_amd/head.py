@@ -25,6 +25,9 @@ FINE_LINEAR_FIRST = __import__("os").environ.get("COOCC_FINE_LINEAR_FIRST", "1")
 # (measured at configs[1]: 383 us against 334 us for the three kernels -- the wave-serial phases at 2 waves per SIMD hide less gather
 # latency than the samplers' own launches at 4+; kept off there)
 FINE_FUSED = int(__import__("os").environ.get("COOCC_FINE_FUSED", "1"))
+# pred_f of simple_test written output-major in one pass when the fine points are the head's own (coocc_scatter_fine_grouped);
+# 0 = fill + scatter by coordinates (coocc_scatter_fine[_dev])
+SCATTER_GROUPED = __import__("os").environ.get("COOCC_SCATTER_GROUPED", "1") != "0"
 
 
 def _conv3d(conv_cfg, cin, cout, k, pad):
@@ -183,6 +186,8 @@ class OccHead(nn.Module):
         assert n > 0, 'no foreground in coarse voxel'
         nf = n * r ** 3
         fine_xyz = torch.empty(3, nf, device=dev, dtype=_I64)
+        # what scatter_fine needs to write pred_f output-major (coocc_scatter_fine_grouped): the coarse list these points descend from
+        self._last_fine = dict(xyz=fine_xyz, lin=lin, n=n, cnt=None, coarse=(ovf.X, ovf.Y, ovf.Z))
         cvox = 128 if self.sample_from_voxel else 0
         # one launch for Linear+GN+ReLU -> cat -> Linear+GN+ReLU -> Linear when both samples feed the MLPs
         fused = (FUSED_FINE_MLP and use_img and self.sample_from_voxel and ovf.C == 128 and g.shape[1] == 128
@@ -253,6 +258,7 @@ class OccHead(nn.Module):
         N_i, Hf, Wf = img_dims
         nf = V * r ** 3
         fine_xyz = torch.empty(3 * nf, device=dev, dtype=_I64)
+        self._last_fine = dict(xyz=fine_xyz, lin=lin, n=V, cnt=cnt, coarse=(ovf.X, ovf.Y, ovf.Z))
         P = linear_rows(g, p["img_nb"])
         Q = linear_rows(ovf.t, p["f0_vox_nb"], in_coff=ovf.coff, in_C=128)
         if self._fused_fine_ok(ovf, N_i):
@@ -363,6 +369,15 @@ class OccHead(nn.Module):
         the static fine branch + the device-side count of foreground coarse voxels."""
         ncls = fine_pred.shape[1]
         grid = torch.empty(1, ncls, *out_size, device=fine_pred.device, dtype=_F32)
+        lf, r = getattr(self, "_last_fine", None), self.cascade_ratio
+        if (SCATTER_GROUPED and lf is not None and lf["xyz"].data_ptr() == fine_coord.data_ptr() and (lf["cnt"] is None) == (count_dev is None)
+                and tuple(out_size) == tuple(v * r for v in lf["coarse"]) and fine_pred.shape[0] == lf["n"] * r ** 3):
+            # the head's own points (the ratio^3 children of its foreground list): one output-major pass, no fill + scatter
+            Xc, Yc, Zc = lf["coarse"]
+            ws = torch.empty(Xc * Yc * Zc, device=fine_pred.device, dtype=_I32)
+            call("coocc_scatter_fine_grouped", ptr(fine_pred), ncls, fine_pred.shape[1], ptr(lf["lin"]), lf["n"],
+                 ptr(lf["cnt"]) if lf["cnt"] is not None else None, r, Xc, Yc, Zc, ptr(grid), float(self.empty_idx), ptr(ws))
+            return grid
         if count_dev is not None:
             call("coocc_scatter_fine_dev", ptr(fine_pred), fine_pred.shape[0], ptr(count_dev), self.cascade_ratio ** 3, ncls,
                  fine_pred.shape[1], ptr(fine_coord), ptr(grid), out_size[0], out_size[1], out_size[2], float(self.empty_idx))

@@ -559,6 +559,13 @@ int coocc_fine_mlp_pre_dev(const float* samp64, int samp_stride, const float* vo
                            int ncls, float* out, void* stream);
 int coocc_scatter_fine_dev(const float* fine_logits, int64_t nfine_cap, const int32_t* n_dev, int n_mul, int ncls, int stride,
                            const int64_t* fine_xyz, float* grid, int Xf, int Yf, int Zf, float empty_val, void* stream);
+/* pred_f for the head's own fine points -- the R^3 children of the coarse voxels coarse_lin[0..n) (row f = o n + i, offset
+ * o = (a R + b) R + c; final grid = R x coarse grid) -- in ONE output-major pass: no fill, no scattered stores.  Same grid as
+ * coocc_scatter_fine on the coordinates coocc_fine_sample_voxel produced for that list.  n_dev != NULL: n = min(n_cap, *n_dev) read
+ * on the device (hipGraph form).  map_ws: Xc*Yc*Zc int32 of scratch. */
+int coocc_scatter_fine_grouped(const float* fine_logits, int ncls, int stride, const int32_t* coarse_lin, int n_cap,
+                               const int32_t* n_dev, int R, int Xc, int Yc, int Zc, float* grid, float empty_val,
+                               int32_t* map_ws, void* stream);
 /* nn.GroupNorm on 2-D rows [n,C] (+ReLU), in place (occ_head.py:70-83) */
 int coocc_groupnorm_rows(float* x, int64_t n, int C, int stride, int groups, const float* gamma,
                          const float* beta, float eps, int relu, void* stream);

@@ -91,6 +91,15 @@ def test_decoder_vs_golden(dev, golden, monkeypatch, conv_path):
     dense = head.scatter_fine(res["output_voxels_fine"][0], res["output_coords_fine"][0], list(c["final_occ_size"]))
     want = ref_cpu.scatter_fine(torch.from_numpy(g["fine_output"]), torch.from_numpy(g["fine_coord"]), c["final_occ_size"])
     assert_close(dense.cpu(), want, what="pred_f")
+    # the output-major one-pass form (coocc_scatter_fine_grouped, what the call above took) against fill + scatter by coordinates
+    from co_occ_amd import head as head_mod
+    assert head_mod.SCATTER_GROUPED and head._last_fine["xyz"].data_ptr() == res["output_coords_fine"][0].data_ptr()
+    head_mod.SCATTER_GROUPED = False
+    try:
+        by_coords = head.scatter_fine(res["output_voxels_fine"][0], res["output_coords_fine"][0], list(c["final_occ_size"]))
+    finally:
+        head_mod.SCATTER_GROUPED = True
+    assert torch.equal(dense, by_coords)
 
 
 def test_geometry_and_pooling_vs_golden(dev, golden):
