@@ -810,6 +810,8 @@ def main():
     frames = [frame_of(x) for x in samples]
     if world > 1 and args.ahead <= 0:
         args.ahead = 1          # one search helper thread per rank: 8 ranks x (1 issuing + 1 helper) threads on a CPU-capped node
+    if world > 1:               # ... each rank on its own slice of the host cores (single node: LOCAL_WORLD_SIZE ranks share them)
+        cdist.pin_rank_threads(int(os.environ.get("LOCAL_RANK", rank)), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if args.graph and WITH_POOL[0] and args.api == "serving":
         try:
             gp = model.serving(frames[0], slots=max(2, args.slots), dense_streams=max(1, args.streams if not auto_streams else 3),

@@ -27,6 +27,25 @@ def init(backend=None):
     return rank, world, local
 
 
+def pin_rank_threads(local_rank, local_world):
+    """Give each rank of a node its own slice of the host cores this process may use (its issuing thread + search helper threads
+    then do not migrate onto the cores of the other ranks: 8 ranks x 2-4 threads on a CPU-capped node would otherwise be a
+    stampede).  No-op when there are fewer cores than ranks or the platform has no affinity call.  Returns the cores kept."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except Exception:
+        return None
+    if local_world <= 1 or len(cores) < local_world:
+        return cores
+    per = len(cores) // local_world
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except Exception:
+        return cores
+    return mine
+
+
 def shard_range(n_items, rank, world):
     """Contiguous, balanced [lo, hi) slice of n_items for `rank` (sizes differ by at most 1)."""
     base, rem = divmod(n_items, world)

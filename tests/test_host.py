@@ -95,6 +95,28 @@ def test_shard_range_partitions_everything():
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
 
 
+def test_pin_rank_threads_gives_every_rank_its_own_cores():
+    """The ranks of a node split the host cores this process may use into disjoint slices (multi-GPU bench hardening)."""
+    if not hasattr(os, "sched_getaffinity"):
+        pytest.skip("no affinity call on this platform")
+    before = sorted(os.sched_getaffinity(0))
+    try:
+        seen = []
+        for r in range(2):
+            os.sched_setaffinity(0, before)
+            mine = cdist.pin_rank_threads(r, 2)
+            assert mine and set(mine) <= set(before)
+            if len(before) >= 2:
+                assert sorted(os.sched_getaffinity(0)) == mine and len(mine) == len(before) // 2
+            seen.append(set(mine))
+        if len(before) >= 2:
+            assert not (seen[0] & seen[1])
+        os.sched_setaffinity(0, before)
+        assert cdist.pin_rank_threads(0, 1) == before            # a single rank keeps everything
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_pack_unpack_maps_roundtrip():
     r, d = torch.rand(2, 4, 5, 3), torch.rand(2, 4, 5)
     r2, d2 = cdist.unpack_maps(cdist.pack_maps(r, d))
