@@ -58,6 +58,7 @@ SIGNATURES = {
     "coocc_fuser_prepare": (I, [P, P, P, P, P, I, I, I, P]),
     "coocc_fuser_prepare_rows": (I, [P, I, I, P, I, I, P, P, P, I, I, I, P]),
     "coocc_compact_flags": (I, [P, I, P, P, P, Z, P]),
+    "coocc_compact_flags_ex": (I, [P, I, P, P, P, P, Z, P]),
     "coocc_lin_to_coords": (I, [P, I, I, I, I, P, P, P]),
     "coocc_furthest_point_sampling": (I, [I, I, I, P, P, P, P]),
     "coocc_fps_voxels_ws": (Z, [I, I, I]),

@@ -736,14 +736,16 @@ extern "C" int coocc_scatter_fine_grouped(const float* fine_logits, int ncls, in
                                           int32_t* map_ws, void* stream) {
   COOCC_CHECK_ARG(grid && map_ws && ncls > 0 && R >= 1 && Xc > 0 && Yc > 0 && Zc > 0 && n_cap >= 0 && stride >= ncls,
                   "scatter_fine_grouped: bad args");
-  COOCC_CHECK_ARG(n_cap == 0 || (fine_logits && coarse_lin), "scatter_fine_grouped: null pointer");
+  COOCC_CHECK_ARG(n_cap == 0 || fine_logits, "scatter_fine_grouped: null pointer");
   COOCC_CHECK_ARG((long long)Xc * Yc * Zc < (1ll << 31), "scatter_fine_grouped: coarse grid too large");
   hipStream_t s = as_stream(stream);
   const int V = Xc * Yc * Zc;
-  COOCC_HIP(hipMemsetAsync(map_ws, 0xFF, (size_t)V * 4, s));                      // -1 everywhere
-  if (n_cap > 0) {
-    hipLaunchKernelGGL(k_lin_ordinal_map, dim3(cdiv(n_cap, 256)), dim3(256), 0, s, coarse_lin, n_cap, n_dev, map_ws);
-    COOCC_LAUNCH_CHECK("k_lin_ordinal_map");
+  if (coarse_lin) {                   // coarse_lin == NULL: map_ws already holds the voxel -> ordinal table (coocc_compact_flags_ex)
+    COOCC_HIP(hipMemsetAsync(map_ws, 0xFF, (size_t)V * 4, s));                    // -1 everywhere
+    if (n_cap > 0) {
+      hipLaunchKernelGGL(k_lin_ordinal_map, dim3(cdiv(n_cap, 256)), dim3(256), 0, s, coarse_lin, n_cap, n_dev, map_ws);
+      COOCC_LAUNCH_CHECK("k_lin_ordinal_map");
+    }
   }
   const size_t plane = (size_t)V * R * R * R;
   hipLaunchKernelGGL(k_scatter_fine_grouped, dim3(cdiv(plane, 256)), dim3(256), 0, s, fine_logits, stride, ncls, map_ws, n_cap, n_dev, R,

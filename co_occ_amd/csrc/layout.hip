@@ -353,7 +353,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(int32_t* __restrict__ blk,
 
 __global__ __launch_bounds__(256) void k_flag_write(const uint8_t* __restrict__ flags, int total,
                                                      const int32_t* __restrict__ blk,
-                                                     int32_t* __restrict__ lin) {
+                                                     int32_t* __restrict__ lin, int32_t* __restrict__ map) {
   __shared__ int wsum[4];
   int base = blockIdx.x * CB + threadIdx.x * 4;
   int f[4], c = 0;
@@ -370,19 +370,28 @@ __global__ __launch_bounds__(256) void k_flag_write(const uint8_t* __restrict__ 
   __syncthreads();
   int off = blk[blockIdx.x] + inc - c;
   for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 4; ++j) {
+    if (map && base + j < total) map[base + j] = f[j] ? off : -1;        // the inverse: element -> its ordinal in lin, or -1
     if (f[j]) lin[off++] = base + j;
+  }
 }
 
+extern "C" int coocc_compact_flags_ex(const uint8_t* flags, int total, int32_t* lin, int32_t* count, int32_t* map, void* ws,
+                                      size_t ws_bytes, void* stream);
 extern "C" int coocc_compact_flags(const uint8_t* flags, int total, int32_t* lin, int32_t* count, void* ws,
                                    size_t ws_bytes, void* stream) {
+  return coocc_compact_flags_ex(flags, total, lin, count, nullptr, ws, ws_bytes, stream);
+}
+// ... and, with map != NULL, the inverse table map[element] = ordinal in lin (or -1) written by the same last pass
+extern "C" int coocc_compact_flags_ex(const uint8_t* flags, int total, int32_t* lin, int32_t* count, int32_t* map, void* ws,
+                                      size_t ws_bytes, void* stream) {
   COOCC_CHECK_ARG(flags && lin && count && ws && total > 0, "compact_flags: bad args");
   int nblk = (int)cdiv(total, CB);
   if (ws_bytes < sizeof(int32_t) * (size_t)nblk) return coocc_set_error(COOCC_ENOMEM, "compact_flags: workspace too small");
   int32_t* blk = (int32_t*)ws;
   hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk);
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, as_stream(stream), blk, nblk, count);
-  hipLaunchKernelGGL(k_flag_write, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk, lin);
+  hipLaunchKernelGGL(k_flag_write, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk, lin, map);
   COOCC_LAUNCH_CHECK("compact_flags");
   return COOCC_OK;
 }

@@ -164,7 +164,10 @@ class OccHead(nn.Module):
         lin = torch.empty(V, device=dev, dtype=_I32)
         cnt = torch.empty(1, device=dev, dtype=_I32)
         ws = torch.empty(V // 1024 + 2, device=dev, dtype=_I32)
-        call("coocc_compact_flags", ptr(flags), V, ptr(lin), ptr(cnt), ptr(ws), ws.numel() * 4)
+        # fgmap: coarse voxel -> its ordinal in lin (or -1), from the same pass: scatter_fine looks the children's parents up in it
+        fgmap = torch.empty(V, device=dev, dtype=_I32) if SCATTER_GROUPED else None
+        call("coocc_compact_flags_ex", ptr(flags), V, ptr(lin), ptr(cnt), ptr(fgmap), ptr(ws), ws.numel() * 4)
+        self._fgmap = fgmap
         # everything that does not depend on the foreground count is enqueued BEFORE the host reads it: the
         # image-feature branch (1x1 conv + GroupNorm) and the camera matrices (a dozen tiny torch launches)
         # then run under the device->host round trip instead of after it
@@ -187,7 +190,7 @@ class OccHead(nn.Module):
         nf = n * r ** 3
         fine_xyz = torch.empty(3, nf, device=dev, dtype=_I64)
         # what scatter_fine needs to write pred_f output-major (coocc_scatter_fine_grouped): the coarse list these points descend from
-        self._last_fine = dict(xyz=fine_xyz, lin=lin, n=n, cnt=None, coarse=(ovf.X, ovf.Y, ovf.Z))
+        self._last_fine = dict(xyz=fine_xyz, lin=lin, n=n, cnt=None, coarse=(ovf.X, ovf.Y, ovf.Z), map=self._fgmap)
         cvox = 128 if self.sample_from_voxel else 0
         # one launch for Linear+GN+ReLU -> cat -> Linear+GN+ReLU -> Linear when both samples feed the MLPs
         fused = (FUSED_FINE_MLP and use_img and self.sample_from_voxel and ovf.C == 128 and g.shape[1] == 128
@@ -258,7 +261,7 @@ class OccHead(nn.Module):
         N_i, Hf, Wf = img_dims
         nf = V * r ** 3
         fine_xyz = torch.empty(3 * nf, device=dev, dtype=_I64)
-        self._last_fine = dict(xyz=fine_xyz, lin=lin, n=V, cnt=cnt, coarse=(ovf.X, ovf.Y, ovf.Z))
+        self._last_fine = dict(xyz=fine_xyz, lin=lin, n=V, cnt=cnt, coarse=(ovf.X, ovf.Y, ovf.Z), map=self._fgmap)
         P = linear_rows(g, p["img_nb"])
         Q = linear_rows(ovf.t, p["f0_vox_nb"], in_coff=ovf.coff, in_C=128)
         if self._fused_fine_ok(ovf, N_i):
@@ -374,8 +377,9 @@ class OccHead(nn.Module):
                 and tuple(out_size) == tuple(v * r for v in lf["coarse"]) and fine_pred.shape[0] == lf["n"] * r ** 3):
             # the head's own points (the ratio^3 children of its foreground list): one output-major pass, no fill + scatter
             Xc, Yc, Zc = lf["coarse"]
-            ws = torch.empty(Xc * Yc * Zc, device=fine_pred.device, dtype=_I32)
-            call("coocc_scatter_fine_grouped", ptr(fine_pred), ncls, fine_pred.shape[1], ptr(lf["lin"]), lf["n"],
+            fgmap = lf.get("map")            # written by the compaction pass; else built here from the list
+            ws = fgmap if fgmap is not None else torch.empty(Xc * Yc * Zc, device=fine_pred.device, dtype=_I32)
+            call("coocc_scatter_fine_grouped", ptr(fine_pred), ncls, fine_pred.shape[1], ptr(lf["lin"]) if fgmap is None else None, lf["n"],
                  ptr(lf["cnt"]) if lf["cnt"] is not None else None, r, Xc, Yc, Zc, ptr(grid), float(self.empty_idx), ptr(ws))
             return grid
         if count_dev is not None:

@@ -70,6 +70,10 @@ int coocc_fuser_prepare_rows(const float* img, int img_rows, int img_stride, con
  * (== lexicographic (b,x,y,z)).  lin:[n<=total] i32, count: 1 i32.  ws: >= 4*(total/1024+2) bytes. */
 int coocc_compact_flags(const uint8_t* flags, int total, int32_t* lin, int32_t* count, void* ws,
                         size_t ws_bytes, void* stream);
+/* ... and, with map != NULL, the inverse table map[element] = its ordinal in lin, or -1 (written by the same last pass: what
+ * coocc_scatter_fine_grouped looks the foreground voxels up in) */
+int coocc_compact_flags_ex(const uint8_t* flags, int total, int32_t* lin, int32_t* count, int32_t* map, void* ws,
+                           size_t ws_bytes, void* stream);
 /* lin -> float xyz rows [n,3] and/or int64 (b,x,y,z) rows [n,4] (either may be NULL) */
 int coocc_lin_to_coords(const int32_t* lin, int n, int X, int Y, int Z, float* xyz, int64_t* bxyz,
                         void* stream);
@@ -562,7 +566,8 @@ int coocc_scatter_fine_dev(const float* fine_logits, int64_t nfine_cap, const in
 /* pred_f for the head's own fine points -- the R^3 children of the coarse voxels coarse_lin[0..n) (row f = o n + i, offset
  * o = (a R + b) R + c; final grid = R x coarse grid) -- in ONE output-major pass: no fill, no scattered stores.  Same grid as
  * coocc_scatter_fine on the coordinates coocc_fine_sample_voxel produced for that list.  n_dev != NULL: n = min(n_cap, *n_dev) read
- * on the device (hipGraph form).  map_ws: Xc*Yc*Zc int32 of scratch. */
+ * on the device (hipGraph form).  map_ws: Xc*Yc*Zc int32 of scratch -- or, with coarse_lin == NULL, the finished voxel -> ordinal
+ * table (coocc_compact_flags_ex), which is then used as it is. */
 int coocc_scatter_fine_grouped(const float* fine_logits, int ncls, int stride, const int32_t* coarse_lin, int n_cap,
                                const int32_t* n_dev, int R, int Xc, int Yc, int Zc, float* grid, float empty_val,
                                int32_t* map_ws, void* stream);
