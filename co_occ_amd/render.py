@@ -16,6 +16,18 @@ RENDER_CHUNKS = int(__import__("os").environ.get("COOCC_RENDER_CHUNKS", "1"))
 _render_sides = {}
 
 
+
+_ZVALS = {}
+
+
+def _zvals(D, dev):
+    """linspace(0, D, D) of coocc_ray.py:581 -- a constant per (D, device): kept instead of one launch per sample."""
+    key = (int(D), str(dev))
+    if key not in _ZVALS:
+        _ZVALS[key] = torch.linspace(0, D, D, device=dev)
+    return _ZVALS[key]
+
+
 def _render_side(dev, cur):
     key = (dev.index, cur.cuda_stream)
     if key not in _render_sides:
@@ -188,7 +200,7 @@ def render_block(sigma_head, rgb_head, voxel_feats, gemo, scale=16, depth_only=F
         dev = g.device
     assert vf.B == 1
     table = voxel_table(sigma_head, rgb_head, vf, activate=True)      # sigmoid(rgb) once per voxel, not per ray sample
-    zvals = torch.linspace(0, D, D, device=dev)
+    zvals = _zvals(D, dev)
     maps = torch.empty(N, H, W, 4, device=dev, dtype=_F32)
     from .core import TIMER
     rgbs = torch.empty(N, H * scale, W * scale, 3, device=dev, dtype=_F32)
@@ -235,7 +247,7 @@ def _render_depth_only(sigma_head, voxel_feats, gemo, scale):
     table = voxel_table(sigma_head, None, vf)
     g = gemo.reshape(N, D, H, W, 3).float().contiguous()
     dev = g.device
-    zvals = torch.linspace(0, D, D, device=dev)
+    zvals = _zvals(D, dev)
     maps = torch.empty(N, H, W, 4, device=dev, dtype=_F32)
     depths = torch.empty(N, H * scale, W * scale, device=dev, dtype=_F32)
     call("coocc_render_nearest", ptr(table), vf.X, vf.Y, vf.Z, ptr(g), ptr(zvals), N, D, H, W, host_f32(RENDER_BOUNDS), 1, ptr(maps))
@@ -270,7 +282,7 @@ def render_block_sharded(sigma_head, rgb_head, voxel_feats, gemo, scale=16, rank
 
     mark()
     table = voxel_table(sigma_head, rgb_head, vf, activate=True)
-    zvals = torch.linspace(0, D, D, device=dev)
+    zvals = _zvals(D, dev)
     lo, hi = cdist.shard_range(N * H, rank, world)
     g = gemo.reshape(N, D, H, W, 3).float()
     local = torch.empty(hi - lo, W, 4, device=dev, dtype=_F32)

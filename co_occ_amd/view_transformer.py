@@ -120,9 +120,14 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
 
     def _camera_mats(self, rots, trans, intrins, post_rots, post_trans, bda):
         """Per-camera constants of the geometry chain (COOCC_CAM_FLOATS each) + the frustum axes."""
-        fr = self.frustum.to(trans.device)
-        xs, ys, ds = fr[0, 0, :, 0].contiguous(), fr[0, :, 0, 1].contiguous(), fr[:, 0, 0, 2].contiguous()
-        return camera_mats(rots, trans, intrins, post_rots, post_trans, bda), xs, ys, ds
+        # the three axes depend on the frustum parameter only: kept (three copy launches per sample otherwise, inside every captured graph)
+        key = (self.frustum._version, self.frustum.data_ptr(), trans.device)
+        ax = getattr(self, "_axes_cache", None)
+        if ax is None or ax[0] != key:
+            fr = self.frustum.detach().to(trans.device)
+            ax = (key, fr[0, 0, :, 0].contiguous(), fr[0, :, 0, 1].contiguous(), fr[:, 0, 0, 2].contiguous())
+            self._axes_cache = ax
+        return camera_mats(rots, trans, intrins, post_rots, post_trans, bda), ax[1], ax[2], ax[3]
 
     def get_geometry(self, rots, trans, intrins, post_rots, post_trans, bda):
         """ViewTransformerLSSBEVDepth.py:117-150 -> [B,N,D,fH,fW,3].  The 3x3 inverses and the
