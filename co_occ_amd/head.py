@@ -167,7 +167,6 @@ class OccHead(nn.Module):
         # fgmap: coarse voxel -> its ordinal in lin (or -1), from the same pass: scatter_fine looks the children's parents up in it
         fgmap = torch.empty(V, device=dev, dtype=_I32) if SCATTER_GROUPED else None
         call("coocc_compact_flags_ex", ptr(flags), V, ptr(lin), ptr(cnt), ptr(fgmap), ptr(ws), ws.numel() * 4)
-        self._fgmap = fgmap
         # everything that does not depend on the foreground count is enqueued BEFORE the host reads it: the
         # image-feature branch (1x1 conv + GroupNorm) and the camera matrices (a dozen tiny torch launches)
         # then run under the device->host round trip instead of after it
@@ -183,14 +182,15 @@ class OccHead(nn.Module):
                  ptr(gn.bias.detach()), float(gn.eps), 1)
             params = self._projection_params(transform, ovf, dev)
         if static:
-            return self._fine_static(p, ovf, lin, cnt, g if use_img else None, params if use_img else None, (N_i, Hf, Wf) if use_img else None)
+            return self._fine_static(p, ovf, lin, cnt, g if use_img else None, params if use_img else None, (N_i, Hf, Wf) if use_img else None,
+                                     fgmap=fgmap)
         n = int(_lib.host_read(cnt)[0])
         core_mod.check_h2_overflow()          # the stage's one host read: every conv up to the coarse head has finished
         assert n > 0, 'no foreground in coarse voxel'
         nf = n * r ** 3
         fine_xyz = torch.empty(3, nf, device=dev, dtype=_I64)
         # what scatter_fine needs to write pred_f output-major (coocc_scatter_fine_grouped): the coarse list these points descend from
-        self._last_fine = dict(xyz=fine_xyz, lin=lin, n=n, cnt=None, coarse=(ovf.X, ovf.Y, ovf.Z), map=self._fgmap)
+        self._note_fine(dict(xyz=fine_xyz, lin=lin, n=n, cnt=None, coarse=(ovf.X, ovf.Y, ovf.Z), map=fgmap))
         cvox = 128 if self.sample_from_voxel else 0
         # one launch for Linear+GN+ReLU -> cat -> Linear+GN+ReLU -> Linear when both samples feed the MLPs
         fused = (FUSED_FINE_MLP and use_img and self.sample_from_voxel and ovf.C == 128 and g.shape[1] == 128
@@ -248,7 +248,7 @@ class OccHead(nn.Module):
              ptr(gn.bias.detach()), float(gn.eps), 1)
         return linear_rows(h, p["fine3"]), fine_xyz
 
-    def _fine_static(self, p, ovf, lin, cnt, g, params, img_dims):
+    def _fine_static(self, p, ovf, lin, cnt, g, params, img_dims, fgmap=None):
         """The fused (Linear-first) fine branch with the foreground count on the device; see ``_fine(static=True)``."""
         dev = ovf.t.device
         V, r = ovf.V, self.cascade_ratio
@@ -261,7 +261,7 @@ class OccHead(nn.Module):
         N_i, Hf, Wf = img_dims
         nf = V * r ** 3
         fine_xyz = torch.empty(3 * nf, device=dev, dtype=_I64)
-        self._last_fine = dict(xyz=fine_xyz, lin=lin, n=V, cnt=cnt, coarse=(ovf.X, ovf.Y, ovf.Z), map=self._fgmap)
+        self._note_fine(dict(xyz=fine_xyz, lin=lin, n=V, cnt=cnt, coarse=(ovf.X, ovf.Y, ovf.Z), map=fgmap))
         P = linear_rows(g, p["img_nb"])
         Q = linear_rows(ovf.t, p["f0_vox_nb"], in_coff=ovf.coff, in_C=128)
         if self._fused_fine_ok(ovf, N_i):
@@ -367,12 +367,23 @@ class OccHead(nn.Module):
         self.last_out_voxel_feats = ovf
         return res
 
+    def _note_fine(self, rec):
+        """Remember what ``scatter_fine`` needs for the fine points a ``_fine`` call produced, keyed by the address of their
+        coordinate tensor (kept alive by the record, so the address cannot be reused while the record exists); the last few only."""
+        import collections
+        d = self.__dict__.setdefault("_fine_info", collections.OrderedDict())
+        d[rec["xyz"].data_ptr()] = rec
+        while len(d) > 4:
+            d.popitem(last=False)
+        self._last_fine = rec
+
     def scatter_fine(self, fine_pred, fine_coord, out_size, count_dev=None):
         """``pred_f`` of simple_test (coocc_ray.py:546-550): [1,ncls,Xf,Yf,Zf].  ``count_dev``: the capacity-sized outputs of
         the static fine branch + the device-side count of foreground coarse voxels."""
         ncls = fine_pred.shape[1]
         grid = torch.empty(1, ncls, *out_size, device=fine_pred.device, dtype=_F32)
-        lf, r = getattr(self, "_last_fine", None), self.cascade_ratio
+        # the record of THESE coordinates (several samples may be in flight through one head: host threads of the eager pipeline)
+        lf, r = getattr(self, "_fine_info", {}).get(fine_coord.data_ptr()), self.cascade_ratio
         if (SCATTER_GROUPED and lf is not None and lf["xyz"].data_ptr() == fine_coord.data_ptr() and (lf["cnt"] is None) == (count_dev is None)
                 and tuple(out_size) == tuple(v * r for v in lf["coarse"]) and fine_pred.shape[0] == lf["n"] * r ** 3):
             # the head's own points (the ratio^3 children of its foreground list): one output-major pass, no fill + scatter
