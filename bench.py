@@ -664,7 +664,12 @@ def train_main(args, model, dev, rank, world, seen_world, backend_name):
         gq["ms"] += v["ms"]; gq["launches"] += v["launches"]
     line = dict(metric="training samples/sec (hot path forward + backward), 200x200x16 grid", value=round(world * args.steps / dt, 4), unit="samples/s",
                 n_gpus=world, world_size_seen_by_backend=seen_world, backend=backend_name, steps=args.steps, warmup=args.warmup,
-                ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+                ms_per_step=round(1e3 * dt / args.steps, 3),
+                windows=len(windows), window_ms_per_step=[round(1e3 * w / args.steps, 3) for w in windows],
+                spread_pct=round(100.0 * (max(windows) - min(windows)) / dt, 2),
+                timing=("%d timed windows of %d steps, each bracketed by barrier + torch.cuda.synchronize() (max over ranks); value / "
+                        "ms_per_step = the MEDIAN window" % (len(windows), args.steps)),
+                higher_is_better=True, scaling="weak", vs_baseline=None,
                 dtype=(("f32 (split-f16 products, fp32 accumulate: forward%s%s GEMMs; fp32 MFMA: the rest)"
                         % (" / dgrad" if ag.TRAIN_H2_DGRAD else "", " / Winograd-domain + 1x1x1 wgrad" if ag.TRAIN_H2_WGRAD else ""))
                        if ag.TRAIN_H2 and core.CONV_ENGINE == "h2" else "f32"),
@@ -726,10 +731,16 @@ def main():
                     help="time the TRAINING step of the hot path instead (SURVEY.md 8f rank 1: COOCC_Ray.forward_train_hot_path -- index "
                          "search, G1, con_enc, encoder, neck, coarse + fine head, render block -- forward + backward with batch-statistics "
                          "BatchNorm, surrogate scalar losses closing the graph) and print its own JSON line with a wgrad roofline")
-    ap.add_argument("--api", default="serving", choices=["serving", "simple_test"],
+    ap.add_argument("--api", default="serving", choices=["serving", "simple_test", "pipelined_test"],
                     help="serving (default): COOCC_Ray.serving() -- co_occ_amd.serving.ServingPipeline, --slots samples in flight.  "
                          "simple_test: the reference's per-sample call COOCC_Ray.simple_test(precomputed=...) (coocc_ray.py:520), "
-                         "synchronous, dense stage = one captured hipGraph launch (one slot)")
+                         "synchronous, dense stage = one captured hipGraph launch (one slot).  pipelined_test: the reference's test "
+                         "LOOP (custom_single_gpu_test, P/coocc/apis/test.py:22-60) = co_occ_amd.apis.pipelined_test with ground truth "
+                         "per sample: SC / SSC confusion matrices computed on the device and delivered to the host as numpy arrays, "
+                         "every sample's result dict yielded in order")
+    ap.add_argument("--windows", type=int, default=3,
+                    help="timed windows of --steps steps each (barrier + synchronize on both sides of every window); the line reports the "
+                         "MEDIAN window (value, ms_per_step) and all of them (window_ms_per_step, spread_pct)")
     ap.add_argument("--slots", type=int, default=6, help="--graph 1: samples in flight (1 in its dense stage + slots-1 in the prefetched search)")
     ap.add_argument("--shard", default="samples", choices=["samples", "rays"],
                     help="samples (default): one scene per GPU, weak scaling (configs[3]).  rays: ONE scene over all ranks -- K / G / C "
@@ -850,6 +861,41 @@ def main():
             torch.cuda.synchronize()
         run(3, False)
         st_api = dict(graph=model._pipe1 is not None, eager_reason=(model.graph_unavailable or (None, None))[1])
+    if args.api == "pipelined_test":
+        # the reference's test loop: ONE generator over an endless stream of samples (the pipeline and its captured graphs are made
+        # at its first sample, in the warm-up); a step = one (data, result) pair yielded, metrics on the host as numpy arrays
+        from co_occ_amd import apis
+        model.test_rendering = True
+        c_ = synth.CONFIGS[args.config]
+        gsz = c_.get("final_occ_size", [2 * g for g in c_["grid"]])
+        g_ = torch.Generator().manual_seed(77 + rank)
+        gts = [torch.randint(0, 17, (1,) + tuple(gsz), generator=g_).to(dev) for _ in samples]
+        pt_data = [dict(simple_test_kwargs(x), gt_occ=gt) for x, gt in zip(samples, gts)]
+        for d_ in pt_data:
+            d_.pop("img"), d_.pop("points")
+
+        def endless():
+            i = 0
+            while True:
+                yield pt_data[i % len(pt_data)]
+                i += 1
+        pt_stats = {}
+        pt_gen = apis.pipelined_test(model, endless(), slots=max(2, args.slots), dense_streams=(3 if auto_streams else max(1, args.streams)),
+                                     ahead=args.ahead, stats=pt_stats)
+        auto_streams, S = False, 1
+        run_eager = run
+        pt_seen = [0]
+
+        def run(n, timed, S=1):
+            for _ in range(n):
+                d_, res = next(pt_gen)
+                pt_seen[0] += int(res["SSC_metric_fine" if "SSC_metric_fine" in res else "SSC_metric"].sum() > 0)
+                if world > 1:
+                    _gather(res)
+            drain_gathers()
+            torch.cuda.synchronize()
+        run(2 * max(2, args.slots), False)
+        st_api = dict(graph=True, eager_reason=None, pipelined=True)
     if auto_streams:
         # One or two samples in flight?  Two win by ~8 % when the host keeps up (four Python threads share the GIL) and lose
         # that margin when neighbours saturate the box's CPUs (profiles/r2_streams_ab.txt) -- so ask the box: two untimed
@@ -874,19 +920,24 @@ def main():
         core.TIMER.enabled = 0 if args.no_kernel_timing else (2 if args.kernel_table else 1)
     core.TIMER.only = ("k_conv", "k_gemm", "k_render_nearest", "k_lift_splat")      # what the roofline objects below need
     core.TIMER.reset()
-    cdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for v in DIAG.values():
-        del v[:]
-    if args.diag:
-        TRACE[0], TRACE_T0[0] = [], time.perf_counter()
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    run(args.steps, True)
-    cdist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    windows = []
+    nwin = max(1, args.windows)
+    for wi in range(nwin):
+        cdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if wi == nwin - 1:
+            for v in DIAG.values():
+                del v[:]
+            if args.diag:
+                TRACE[0], TRACE_T0[0] = [], time.perf_counter()
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
+        run(args.steps, True)
+        cdist.barrier()
+        torch.cuda.synchronize()
+        windows.append(cdist.max_over_ranks(time.perf_counter() - t0, dev))
+    dt = sorted(windows)[len(windows) // 2] if len(windows) % 2 else sorted(windows)[len(windows) // 2 - 1]
     if args.diag and rank == 0 and TRACE[0]:
         for i, w, a, b, c, ev in sorted(TRACE[0]):
             print("trace: sample %2d stream %d  host: search ready %.1f  issue %.1f -> %.1f ms   GPU done %.1f ms" % (
@@ -897,7 +948,6 @@ def main():
                                      for k, v in DIAG.items()}, sort_keys=True) + " wall_ms_per_step %.3f" % (1e3 * dt / args.steps),
               file=sys.stderr)
     core.TIMER.enabled = False
-    dt = cdist.max_over_ranks(dt, dev)
 
     c = synth.CONFIGS[args.config]
     graph_info = None
@@ -905,11 +955,15 @@ def main():
         if gp is not None:
             dense_ms = [ev[0].elapsed_time(ev[1]) for ev in gp.dense_ev]
             graph_info = dict(api="COOCC_Ray.serving() -> co_occ_amd.serving.ServingPipeline", slots=gp.n, dense_streams=gp.ndense,
-                              searches_ahead=gp.ahead, eager_fallbacks=gp.fallbacks,
+                              searches_ahead=gp.ahead, eager_fallbacks=gp.fallbacks, recaptures=gp.recaptures,
                               dense_stage_ms=round(sum(dense_ms) / max(1, len(dense_ms)), 3),
                               note="dense stage = ONE hipGraphLaunch per sample (HIP events around every replay inside the timed region: "
                                    "dense_stage_ms); pooling + index search eager on prefetch streams; a new frame's image features and "
                                    "camera matrices are copied into the slot's static tensors")
+        elif st_api.get("pipelined"):
+            graph_info = dict(api="co_occ_amd.apis.pipelined_test(model, data_iter) -- the reference's test loop (custom_single_gpu_test) with "
+                                  "samples in flight; ground truth per sample, SC / SSC confusion matrices on the device, numpy on the host",
+                              slots=max(2, args.slots), samples_with_nonzero_metrics=pt_seen[0], **pt_stats)
         else:
             graph_info = dict(api="COOCC_Ray.simple_test(precomputed=...) -- the reference's per-sample call, synchronous", slots=1,
                               captured_graph=st_api["graph"], eager_reason=st_api["eager_reason"],
@@ -973,7 +1027,12 @@ def main():
     line = dict(metric="samples/sec (6-cam frame + sweep -> occ+render), 200x200x16 grid", value=round(jobs * args.steps / dt, 4),
                 unit="samples/s", n_gpus=world, world_size_seen_by_backend=seen_world, backend=backend_name, steps=args.steps,
                 warmup=args.warmup,
-                ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True, scaling=("strong" if SHARD[0] else "weak"), vs_baseline=None,
+                ms_per_step=round(1e3 * dt / args.steps, 3),
+                windows=len(windows), window_ms_per_step=[round(1e3 * w / args.steps, 3) for w in windows],
+                spread_pct=round(100.0 * (max(windows) - min(windows)) / dt, 2),
+                timing=("%d timed windows of %d steps, each bracketed by barrier + torch.cuda.synchronize() (max over ranks); value / "
+                        "ms_per_step = the MEDIAN window" % (len(windows), args.steps)),
+                higher_is_better=True, scaling=("strong" if SHARD[0] else "weak"), vs_baseline=None,
                 dtype=("f32 (split-f16 products, fp32 accumulate)" if (args.dtype == "f32" and core.CONV_ENGINE == "h2") else args.dtype),
                 data="synthetic",
                 config=dict(workload=("coocc_multi_r50_256x704 hot path" if args.config == "r50" else args.config) +
@@ -984,9 +1043,11 @@ def main():
                             render_maps="%dx%dx%d" % (c["ncam"], c["fmap"][0] * 16, c["fmap"][1] * 16), knum=c["knum"],
                             parallelism=("ray-shard x%d (ONE scene: K/G/C replicated on every rank, render rays sharded, all-gather of the "
                                          "map chunks)" % world if SHARD[0] else "dp%d (1 scene per GPU, RCCL all-gather of maps)" % world),
-                            samples_in_flight=(gp.n if gp is not None else S), prefetched_search=bool(tpool) and st_api is None, weights="random",
+                            samples_in_flight=(gp.n if gp is not None else S), prefetched_search=bool(tpool) and (st_api is None or bool(st_api.get("pipelined"))), weights="random",
                             pipeline=("hipGraph dense stage + eager prefetched search" if gp is not None else
-                                      ("simple_test per sample (synchronous), hipGraph dense stage" if st_api is not None else "eager (Python-issued launches)")),
+                                      "apis.pipelined_test loop (metrics per sample), hipGraph dense stage + prefetched search" if (st_api or {}).get("pipelined") else
+                                      "simple_test per sample (synchronous), hipGraph dense stage" if st_api is not None else
+                                      "eager (Python-issued launches)"),
                             conv_engine=(core.CONV_ENGINE if args.dtype == "f32" else args.dtype),
                             step_starts_from=("lifted depth/context pair (fused lift-splat pooling inside the step)" if WITH_POOL[0]
                                               else "pooled camera volume")),

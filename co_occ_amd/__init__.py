@@ -20,6 +20,7 @@ from .detector import COOCC_Ray, COOCC_Ray_L
 from .view_transformer import get_frustum
 from . import losses
 from .core import invalidate_packs
+from .calibration import calibrate
 from . import apis, evaluation
 from . import lidar
 from .lidar import HardSimpleVFE, SparseLiDAREnc4x, SparseLiDAREnc8x, Voxelization

@@ -80,10 +80,14 @@ def conv_kernel_name(M, Cout, table, hint=0, iters=1 << 30, one_by_one=False):
 class Rows:
     """A dense voxel volume as channels-last rows: t[B*X*Y*Z, stride], C channels at `coff`."""
 
-    __slots__ = ("t", "B", "X", "Y", "Z", "C", "coff", "h16", "h2")
+    __slots__ = ("t", "B", "X", "Y", "Z", "C", "coff", "h16", "h2", "persistent")
 
-    def __init__(self, t, B, X, Y, Z, C, coff=0):
+    def __init__(self, t, B, X, Y, Z, C, coff=0, persistent=False):
         self.t, self.B, self.X, self.Y, self.Z, self.C, self.coff = t, B, X, Y, Z, C, coff
+        # rows of a buffer that this package's kernels REWRITE in place through raw pointers (sample slots of the serving loop,
+        # ``out=`` targets): torch's version counter does not see those writes, so reference-layout views of such rows carry no
+        # back-reference (``as_ncdhw`` / ``to_rows``) and a later consumer converts / re-splits instead of trusting a cached twin
+        self.persistent = persistent
         self.h16 = None       # f16 twin [B*V, C] written by the producing convolution's epilogue (CONV_DTYPE == "f16")
         # H2 twin [B*V, C] (split-f16 operand rows, csrc/h2_rows.h) of these rows: written by the PRODUCER's epilogue when the
         # consumer is a split-f16 layer outside the Winograd path (``conv_rows(twin_for=...)``), else made once by
@@ -109,7 +113,8 @@ class Rows:
         if self.coff or self.stride != self.C:
             v = v[..., self.coff:self.coff + self.C]
         v = v.permute(0, 4, 1, 2, 3)
-        v._coocc_rows = (self, v._version)
+        if not self.persistent:
+            v._coocc_rows = (self, v._version)
         return v
 
 
@@ -569,7 +574,7 @@ def conv_rows(x, pc, relu=True, res=None, res_mode=0, out=None, splitk=0, twin_f
     if out is None:
         out = Rows(torch.empty(M, pc.Cout, device=x.t.device, dtype=_F32), x.B, Xo, Yo, Zo, pc.Cout)
     else:
-        out.h2 = None                  # a caller-provided buffer is overwritten: whatever twin it carried is stale
+        out.h2 = out.h16 = None        # a caller-provided buffer is overwritten: whatever twins it carried are stale
     assert x.C == pc.Cin, "channel mismatch: %d vs %d" % (x.C, pc.Cin)
     rm = res_mode or (1 if res is not None else 0)
     bf16 = CONV_DTYPE == "bf16"
@@ -813,9 +818,45 @@ class PackCache:
         return self._val
 
 
+_PACK_EPOCH = [0]          # bumped by ``invalidate_packs``: part of every ``WeightWatch`` fingerprint
+
+
+class WeightWatch:
+    """Fingerprint of every parameter and buffer under ``module``: (``data_ptr``, ``_version``) per tensor + the global
+    pack epoch.  A captured hipGraph bakes RAW pointers to the weight packs / folded-BN constants that were current at capture
+    time (``PackCache``); the eager path re-packs when a version counter moves, a replay cannot.  Whoever owns a captured
+    graph keeps one of these and re-captures when ``changed()`` (optimizer steps between ``train()`` and ``eval()``,
+    ``load_state_dict``, ``.to()`` / ``.half()``, ``invalidate_packs``).  The (dict, name) slots are listed once, like
+    ``PackCache.get_modules``; one check is ~50 us of host time for the whole detector."""
+
+    def __init__(self, module):
+        self._slots = []
+        for m in module.modules():
+            self._slots += [(m._parameters, k) for k in m._parameters]
+            self._slots += [(m._buffers, k) for k in m._buffers]
+        self.key = self.snapshot()
+
+    def snapshot(self):
+        key = [_PACK_EPOCH[0]]
+        for d, k in self._slots:
+            t = d.get(k)
+            if t is not None:
+                key.append(t.data_ptr())
+                key.append(t._version)
+        return key
+
+    def changed(self):
+        return self.snapshot() != self.key
+
+    def refresh(self):
+        self.key = self.snapshot()
+
+
 def invalidate_packs(module):
     """Drop every cached weight pack / folded-BN constant under ``module`` (call after writing parameters through
-    ``.data`` or any other path that does not bump the tensors' version counters)."""
+    ``.data`` or any other path that does not bump the tensors' version counters).  Captured serving graphs notice through
+    the pack epoch and re-capture at their next submit."""
+    _PACK_EPOCH[0] += 1
     n = 0
     for m in module.modules():
         pc = getattr(m, "_packs", None)

@@ -134,6 +134,7 @@ class COOCC_Ray(nn.Module):
                 self.rgb_head = MLP(input_dim=128, output_dim=3, net_depth=3, skip_layer=None)
         if self.occ_fuser is not None and hasattr(self.occ_fuser, "output_readers"):
             self.occ_fuser.output_readers = _FusedReaders(self)
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: setattr(module, "_pipe1", None))
 
     # ------------------------------------------------------------------ encoders (coocc_ray.py:120-256)
     @property
@@ -194,6 +195,8 @@ class COOCC_Ray(nn.Module):
         """``nn.Module.train`` for everything but the frozen sparse LiDAR encoder, which keeps its eval-mode path (an
         unchanged tools/train.py calls ``model.train()`` on the whole detector)."""
         super().train(mode)
+        if mode:
+            self._pipe1 = None          # the captured eval-mode graph holds the CURRENT weight packs; training rewrites them
         from . import lidar
         enc = getattr(self, "pts_middle_encoder", None)
         if mode and enc is not None and isinstance(enc, tuple(lidar.MIDDLE_ENCODERS.module_dict.values())):
@@ -306,31 +309,40 @@ class COOCC_Ray(nn.Module):
         """coocc_ray.py:423-433."""
         return render_losses(rgbs, depths, rgb_gt, depth_gt, D)
 
-    def _metrics(self, out, gt_occ, visible_mask):
-        """coocc_ray.py:539-554: SC / SSC (/ visible-only SSC) confusion matrices of pred_c and pred_f -- one kernel per
-        prediction; by default one device->host read of the 4 + 2*17*17 counters so the dict holds numpy arrays like
-        upstream (``collect_results_cpu`` pickles them); ``metrics_on_device`` keeps int64 device tensors instead."""
-        from .evaluation import semantic_histograms, split_histograms
-        C = out["pred_c"].shape[1]
+    def _metrics_launch(self, out, gt_occ, visible_mask):
+        """coocc_ray.py:539-554 on the device: SC / SSC (/ visible-only SSC) confusion matrices of pred_c and pred_f, one kernel
+        per prediction on the CURRENT stream -> int64 device tensor [1 or 2, 4 + 2*C*C].  No synchronisation."""
+        from .evaluation import semantic_histograms
         hc = semantic_histograms(out["pred_c"], gt_occ, visible_mask, self.empty_idx)
         hf = semantic_histograms(out["pred_f"], gt_occ, visible_mask, self.empty_idx) if out.get("pred_f") is not None else None
-        if not self.metrics_on_device:
-            both = torch.stack([hc, hf]) if hf is not None else hc[None]
-            both = both.cpu().numpy()
-            hc, hf = both[0], (both[1] if hf is not None else None)
-            split = lambda h: (h[:4].reshape(2, 2), h[4:4 + C * C].reshape(C, C), h[4 + C * C:].reshape(C, C))
-        else:
+        return torch.stack([hc, hf]) if hf is not None else hc[None]
+
+    def _metrics_finish(self, both, C, visible):
+        """``both``: what ``_metrics_launch`` produced -- a numpy array (already on the host: the upstream dict of numpy arrays
+        that ``collect_results_cpu`` pickles) or the device tensor (``metrics_on_device``)."""
+        from .evaluation import split_histograms
+        if torch.is_tensor(both):
             split = lambda h: split_histograms(h, C)
-        sc, ssc, occ = split(hc)
+        else:
+            split = lambda h: (h[:4].reshape(2, 2), h[4:4 + C * C].reshape(C, C), h[4 + C * C:].reshape(C, C))
+        sc, ssc, occ = split(both[0])
         res = dict(SC_metric=sc, SSC_metric=ssc)
-        if visible_mask is not None:
+        if visible:
             res["SSC_occ_metric"] = occ
-        if hf is not None:
-            sc, ssc, occ = split(hf)
+        if both.shape[0] > 1:
+            sc, ssc, occ = split(both[1])
             res.update(SC_metric=sc, SSC_metric_fine=ssc)                    # coocc_ray.py:553-554 overwrites SC_metric
-            if visible_mask is not None:
+            if visible:
                 res["SSC_occ_metric_fine"] = occ
         return res
+
+    def _metrics(self, out, gt_occ, visible_mask):
+        """coocc_ray.py:539-554: by default one device->host read of the 4 + 2*17*17 counters per prediction so the dict holds
+        numpy arrays like upstream; ``metrics_on_device`` keeps int64 device tensors instead (no synchronisation)."""
+        both = self._metrics_launch(out, gt_occ, visible_mask)
+        if not self.metrics_on_device:
+            both = both.cpu().numpy()
+        return self._metrics_finish(both, out["pred_c"].shape[1], visible_mask is not None)
 
     # ------------------------------------------------------------------ serving (co_occ_amd.serving)
     def serving(self, example, **kw):
@@ -374,11 +386,20 @@ class COOCC_Ray(nn.Module):
         if self._pipe1 is None or self._pipe1[0] != key:
             if self.graph_unavailable is not None and self.graph_unavailable[0] == key:
                 return None
+            self._pipe1 = None                                # frees the old slot + graph before the new capture
             try:
                 self._pipe1 = (key, self.serving(fr, slots=1, dense_streams=1, render=do_render))
-            except (_lib.CooccError, NotImplementedError, AssertionError, RuntimeError) as e:
-                self.graph_unavailable = (key, "%s: %s" % (type(e).__name__, e))
-                self._pipe1 = None
+            except _lib.CooccError:
+                raise                                         # a kernel / range-guard error is a bug report, not a fallback
+            except (NotImplementedError, AssertionError, RuntimeError) as e:
+                import warnings
+                why = "%s: %s" % (type(e).__name__, e)
+                transient = isinstance(e, torch.cuda.OutOfMemoryError) or "out of memory" in str(e).lower()
+                warnings.warn("COOCC_Ray.simple_test: the captured (hipGraph) dense stage is unavailable for this input "
+                              "signature, running eager launches instead (about half the throughput)%s -- %s"
+                              % ("" if transient else "; not retried for this signature", why))
+                if not transient:                             # out-of-memory during warm-up + capture may not repeat: try again
+                    self.graph_unavailable = (key, why)
                 return None
         pipe = self._pipe1[1]
         X, Y, Z = pipe.grid

@@ -225,7 +225,7 @@ class SearchSlot:
 
     def img_rows(self):
         X, Y, Z = self.grid
-        return Rows(self.cat4, 1, X, Y, Z, self.C, 0)
+        return Rows(self.cat4, 1, X, Y, Z, self.C, 0, persistent=True)     # rewritten per frame by lift_splat(out=) / the search
 
     def native_desc(self):
         """coocc_search_desc over this slot's buffers (csrc/search.hip), workspace included; built once."""
@@ -289,6 +289,14 @@ class BiFuser_N(nn.Module):
         self.output_readers = None
 
     # ---------------------------------------------------------------- packing
+    def set_conenc_tiles(self, tiles):
+        """Winograd tile sizes (m of F(m x m, 3x3)) of con_enc.0 / con_enc.3 for THIS model: (4, 4) = the split-f16 engine's
+        default (fastest), (2, 2) = the accuracy preset (voxel_feats 2x closer to fp64 than the CPU fp32 reference, r50 rgb maps
+        2.9e-5 instead of 7.4e-5 from the oracle, ~5 % slower); None = environment / default again.  ``co_occ_amd.calibrate``
+        measures both on a user's checkpoint.  Captured serving graphs re-capture at their next submit."""
+        self.conenc_tiles = None if tiles is None else (int(tiles[0]), int(tiles[1]))
+        _core_mod.invalidate_packs(self)
+
     def _packed(self):
         def build():
             d = build_packs()
@@ -308,14 +316,15 @@ class BiFuser_N(nn.Module):
             import os
             from . import core as _core
             default = "4,4" if _core.CONV_ENGINE == "h2" else "2,2"
-            t0, t3 = [int(v) for v in os.environ.get("COOCC_CONENC_TILES", default).split(",")]
+            forced = getattr(self, "conenc_tiles", None)            # set_conenc_tiles(): per model, wins over the environment
+            t0, t3 = forced if forced is not None else [int(v) for v in os.environ.get("COOCC_CONENC_TILES", default).split(",")]
             d["c0"].wino_tile, d["c3"].wino_tile = t0, t3
             d["c0_dense"].wino_tile = t0
             # ... on the grids it is validated on: the OpenOccupancy scene (163 840 voxels, 6x896x1600 maps) renders 1.09e-4 /
             # 1.98e-4 (rgb abs / depth rel) from the CPU oracle with (4,4) and holds 1e-4 with (2,2) (tests/test_gpu_openocc.py),
             # so grids above DENSE_C0_MAX_VOXELS keep (2,2) unless COOCC_CONENC_TILES says otherwise (con_enc0 applies it per call)
             d["conenc_tiles"] = (t0, t3)
-            d["conenc_tiles_large"] = (t0, t3) if "COOCC_CONENC_TILES" in os.environ else (2, 2)
+            d["conenc_tiles_large"] = (t0, t3) if ("COOCC_CONENC_TILES" in os.environ or forced is not None) else (2, 2)
             return d
 
         def build_packs():

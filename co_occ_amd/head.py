@@ -3,6 +3,9 @@ of scope).  Same kwargs, ``forward`` signature/result dict a
 keys (``occ_convs.{i}.{0,1}.*``, ``occ_pred_conv.{0,1,3}.*``, ``voxel_soft_weights.{0,1,3}.*``,
 ``img_mlp_0.*``, ``img_mlp.*``, ``fine_mlp.*``).
 """
+import collections
+import threading
+
 import numpy as np
 import torch
 from torch import nn
@@ -15,6 +18,7 @@ from .core import PackCache, PackedConv, Rows, conv_rows, linear_rows, to_rows
 from .registry import HEADS
 
 _I32, _F32, _I64 = torch.int32, torch.float32, torch.int64
+_FINE_LOCK = threading.Lock()       # guards OccHead._fine_info (insert + evict vs lookup from other host threads)
 # fine branch: the three Linear layers and two GroupNorms in one launch (coocc_fine_mlp); 0 = layer-by-layer path
 FUSED_FINE_MLP = __import__("os").environ.get("COOCC_FUSED_FINE_MLP", "1") != "0"
 # ... and the two Linear layers that precede a resampling applied before it, on the (much smaller) source grids
@@ -370,12 +374,12 @@ class OccHead(nn.Module):
     def _note_fine(self, rec):
         """Remember what ``scatter_fine`` needs for the fine points a ``_fine`` call produced, keyed by the address of their
         coordinate tensor (kept alive by the record, so the address cannot be reused while the record exists); the last few only."""
-        import collections
-        d = self.__dict__.setdefault("_fine_info", collections.OrderedDict())
-        d[rec["xyz"].data_ptr()] = rec
-        while len(d) > 4:
-            d.popitem(last=False)
-        self._last_fine = rec
+        with _FINE_LOCK:                # several host threads (serving helper / issuer, the eager pipeline) share one head
+            d = self.__dict__.setdefault("_fine_info", collections.OrderedDict())
+            d[rec["xyz"].data_ptr()] = rec
+            while len(d) > 4:
+                d.popitem(last=False)
+            self._last_fine = rec
 
     def scatter_fine(self, fine_pred, fine_coord, out_size, count_dev=None):
         """``pred_f`` of simple_test (coocc_ray.py:546-550): [1,ncls,Xf,Yf,Zf].  ``count_dev``: the capacity-sized outputs of
@@ -383,7 +387,9 @@ class OccHead(nn.Module):
         ncls = fine_pred.shape[1]
         grid = torch.empty(1, ncls, *out_size, device=fine_pred.device, dtype=_F32)
         # the record of THESE coordinates (several samples may be in flight through one head: host threads of the eager pipeline)
-        lf, r = getattr(self, "_fine_info", {}).get(fine_coord.data_ptr()), self.cascade_ratio
+        with _FINE_LOCK:
+            lf = getattr(self, "_fine_info", {}).get(fine_coord.data_ptr())
+        r = self.cascade_ratio
         if (SCATTER_GROUPED and lf is not None and lf["xyz"].data_ptr() == fine_coord.data_ptr() and (lf["cnt"] is None) == (count_dev is None)
                 and tuple(out_size) == tuple(v * r for v in lf["coarse"]) and fine_pred.shape[0] == lf["n"] * r ** 3):
             # the head's own points (the ratio^3 children of its foreground list): one output-major pass, no fill + scatter

@@ -108,7 +108,12 @@ class ServingPipeline:
         self._submitted = self._issued = 0
         self._issued_of_slot = [0] * n
         self._dispatched_of_slot = [0] * n
+        self._example = example
+        self.recaptures = 0
         self._capture(example)
+        # the captured launches hold raw pointers to the weight packs that were current just now: re-capture when any
+        # parameter / buffer of the model has been rewritten or replaced since (checked at every submit)
+        self._watch = core.WeightWatch(model)
 
     # ------------------------------------------------------------------ static inputs of the dense stage
     def _make_static(self, fr):
@@ -200,7 +205,11 @@ class ServingPipeline:
         """``frame``: dict(depth [N,D,fH,fW], ctx [N,C,fH,fW], cams=(rots, trans, intrins, post_rots, post_trans, bda),
         pts [1,C,X,Y,Z], img_feats=[[1,N,512,fH,fW]], transform=img_inputs[1:]) -- or ``img_voxel_feats`` [1,C,X,Y,Z] instead
         of depth / ctx, and / or raw LiDAR ``points`` [n,F] instead of ``pts`` (the LiDAR producer then runs in the search stage).  Shapes as the example's.  Returns a ``Ticket``.  The frame's tensors are read by the prefetched
-        search: do not overwrite them before ``Ticket.result()``."""
+        search: do not overwrite them before ``Ticket.result()``.  If the model's weights changed since the capture (optimizer
+        step, ``load_state_dict``, ``.to()``, ``invalidate_packs``) everything in flight is drained and the slots are captured
+        again first -- result tensors of earlier tickets must have been consumed by then."""
+        if self._watch.changed():
+            self._recapture()
         with self._lock:
             i = self._submitted
             self._submitted += 1
@@ -282,6 +291,17 @@ class ServingPipeline:
         self.slot_done[k] = ev
         t.out, t.done = out, ev
         t.frame = t.pts_vol = None                 # the search has consumed the frame's tensors (stream-ordered before `ev`)
+
+    def _recapture(self):
+        """The model's weights moved under the captured graphs: finish what is in flight (those frames were submitted under the
+        old weights and the eager prefetch of a pending one may already have run), drop the graphs and capture again."""
+        assert not self.model.training, "ServingPipeline serves the eval-mode (folded-BN) path"
+        self.drain()
+        torch.cuda.synchronize(self.dev)
+        self.graphs = [None] * self.n
+        self._capture(self._example)
+        self._watch.refresh()
+        self.recaptures += 1
 
     def drain(self):
         """Issue everything submitted so far and wait for it."""

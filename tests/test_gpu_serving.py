@@ -132,3 +132,108 @@ def test_pipeline_takes_raw_lidar_points_and_matches_the_volume_it_would_have_be
     for i, (a, b) in enumerate(zip(*outs)):
         for k in a:
             assert torch.equal(a[k], b[k]), "frame %d: %s differs" % (i, k)
+
+
+def test_simple_test_recaptures_when_the_weights_change(dev):
+    """the captured dense stage bakes pointers to the weight packs of capture time.  After an in-place update
+    (an optimizer step between ``train()`` and ``eval()``), ``load_state_dict`` or ``invalidate_packs`` the next ``simple_test``
+    must serve the NEW weights: re-capture, then equal the eager path bit for bit."""
+    import co_occ_amd
+    bench, model, samples, gts = _setup(dev, n=2)
+    kws = [dict(bench.simple_test_kwargs(s), gt_occ=g) for s, g in zip(samples, gts)]
+    with torch.no_grad():
+        model.graph_simple_test = True
+        before = _grab(model.simple_test(**kws[0]))
+        pipe = model._pipe1[1]
+        assert pipe.recaptures == 0
+        again = _grab(model.simple_test(**kws[0]))
+        assert pipe.recaptures == 0, "an unchanged model must not re-capture (a buffer is rewritten by the forward pass?)"
+        _same(before, again, "unchanged weights")
+        # 1. in-place parameter updates, as an optimizer does them (version counters move)
+        for name, p in model.named_parameters():
+            if name.endswith("weight") and p.dim() >= 2 and ("con_enc" in name or "occ_convs" in name or "sigma_head" in name):
+                p.mul_(1.03)
+        got = _grab(model.simple_test(**kws[0]))
+        assert model._pipe1[1] is pipe and pipe.recaptures == 1
+        model.graph_simple_test = False
+        want = _grab(model.simple_test(**kws[0]))
+        _same(want, got, "after in-place weight update")
+        assert not torch.equal(before["pred_c"], got["pred_c"])
+        # 2. load_state_dict drops the pipeline altogether
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        for k in sd:
+            if k.endswith("fine_mlp.0.weight") or "lateral_convs.0" in k and k.endswith("weight"):
+                sd[k] = sd[k] * 0.9
+        model.load_state_dict(sd)
+        assert model._pipe1 is None
+        model.graph_simple_test = True
+        got2 = _grab(model.simple_test(**kws[1]))
+        model.graph_simple_test = False
+        want2 = _grab(model.simple_test(**kws[1]))
+        _same(want2, got2, "after load_state_dict")
+        # 3. writes that bypass the version counters + invalidate_packs
+        model.graph_simple_test = True
+        pipe = model._pipe1[1]
+        for name, p in model.named_parameters():
+            if "occ_pred_conv" in name and name.endswith("weight"):
+                p.data.mul_(1.1)
+        co_occ_amd.invalidate_packs(model)
+        got3 = _grab(model.simple_test(**kws[1]))
+        assert pipe.recaptures == 1
+        model.graph_simple_test = False
+        want3 = _grab(model.simple_test(**kws[1]))
+        _same(want3, got3, "after .data surgery + invalidate_packs")
+        # 4. train() drops the captured eval-mode graph
+        model.graph_simple_test = True
+        model.simple_test(**kws[0])
+        assert model._pipe1 is not None
+        model.train()
+        assert model._pipe1 is None
+        model.eval()
+
+
+def test_pipelined_test_routes_an_odd_ground_truth_grid_through_simple_test_and_trims_the_fine_outputs(dev):
+    """a sample whose ``gt_occ`` is not cascade_ratio x the coarse grid takes the eager decode (as
+    ``simple_test`` does); fine outputs come back at their exact size; breaking out of the loop closes the pipeline."""
+    from co_occ_amd import apis
+    bench, model, samples, gts = _setup(dev, n=3)
+    odd = torch.randint(0, 17, (1, 100, 100, 8), generator=torch.Generator().manual_seed(9)).to(dev)
+    data = [dict(precomputed=bench.simple_test_kwargs(s)["precomputed"], gt_occ=g) for s, g in zip(samples, gts)]
+    data[1]["gt_occ"] = odd
+    with torch.no_grad():
+        model.graph_simple_test = False
+        ref = [model.simple_test(img=None, **d) for d in data]
+        ref = [dict(_grab(r), nfine=r["output_voxels_fine"][0].shape[0]) for r in ref]
+    stats = {}
+    for i, (d, res) in enumerate(apis.pipelined_test(model, iter(data), slots=3, dense_streams=1, stats=stats)):
+        got = dict(_grab(res), nfine=res["output_voxels_fine"][0].shape[0])
+        assert got["nfine"] == ref[i]["nfine"] and got["fine"].shape == ref[i]["fine"].shape
+        assert got.pop("nfine") == ref[i]["nfine"]
+        _same({k: v for k, v in ref[i].items() if k != "nfine"}, got, "sample %d" % i)
+    assert stats == dict(fallbacks=0, recaptures=0, eager_samples=1), stats
+    gen = apis.pipelined_test(model, iter(data * 3), slots=3, dense_streams=1, stats=stats)
+    next(gen)
+    gen.close()                       # the consumer breaks out: the finally clause drains and closes the pipeline
+    assert stats["eager_samples"] >= 0
+
+
+def test_calibrate_reports_both_con_enc_presets_against_the_exact_fp32_kernels(dev):
+    """``co_occ_amd.calibrate(model, frames)``: both tile presets inside the tolerance on the synthetic
+    checkpoint, (2, 2) closer to the exact-fp32 anchor than (4, 4) at the fuser's output, the model's configuration restored."""
+    import co_occ_amd
+    from co_occ_amd import calibration, core
+    bench, model, samples, gts = _setup(dev, n=2)
+    frames = [bench.simple_test_kwargs(s) for s in samples]
+    with torch.no_grad():
+        before = model.simple_test(**frames[0])["pred_c"].clone()
+    rep = co_occ_amd.calibrate(model, frames, reps=1)
+    print(calibration.format_report(rep))
+    p44, p22 = rep["presets"][(4, 4)], rep["presets"][(2, 2)]
+    assert p44["within_tol"] and p22["within_tol"], rep
+    assert p22["voxel_feats"][1] < p44["voxel_feats"][1]
+    assert min(p44["label_agreement"], p22["label_agreement"]) > 0.999
+    assert rep["recommended"] in ((4, 4), (2, 2))
+    assert core.CONV_ENGINE == "h2" and model.occ_fuser.conenc_tiles is None
+    with torch.no_grad():
+        after = model.simple_test(**frames[0])["pred_c"]
+    assert torch.equal(before, after)
