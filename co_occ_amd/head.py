@@ -29,6 +29,9 @@ FINE_LINEAR_FIRST = __import__("os").environ.get("COOCC_FINE_LINEAR_FIRST", "1")
 # (measured at configs[1]: 383 us against 334 us for the three kernels -- the wave-serial phases at 2 waves per SIMD hide less gather
 # latency than the samplers' own launches at 4+; kept off there)
 FINE_FUSED = int(__import__("os").environ.get("COOCC_FINE_FUSED", "1"))
+# ratio 2 on the split-f16 engine: ONE launch with lanes = points, samples kept in registers, both Linear layers as three f16 MFMAs
+# per k16 step (csrc/fine2_h2.hip, round 5); 0 = the three kernels (fp32-MFMA chain)
+FINE2_H2 = __import__("os").environ.get("COOCC_FINE2_H2", "1") != "0"
 # pred_f of simple_test written output-major in one pass when the fine points are the head's own (coocc_scatter_fine_grouped);
 # 0 = fill + scatter by coordinates (coocc_scatter_fine[_dev])
 SCATTER_GROUPED = __import__("os").environ.get("COOCC_SCATTER_GROUPED", "1") != "0"
@@ -117,6 +120,18 @@ class OccHead(nn.Module):
                     d["f0_vox_nb"] = PackedConv(self.fine_mlp[0].weight[:, :128].contiguous())
             if hasattr(self, "img_mlp") and hasattr(self, "fine_mlp"):     # the fused fine-branch kernel loads 16-byte vectors
                 d["mlp_aligned"] = all(q.data_ptr() % 16 == 0 for m in (self.img_mlp, self.fine_mlp) for q in m.parameters())
+                if ("img_nb" in d and self.out_channel <= 32 and self.img_mlp[1].num_groups == 16 and self.fine_mlp[1].num_groups == 16
+                        and self.fine_mlp[0].weight.is_cuda):
+                    # operands of the ratio-2 one-launch kernel on the split-f16 engine (csrc/fine2_h2.hip): both Linear layers of
+                    # the per-point chain as f16 hi / lo fragments in the kernel's k-slot order + the six GroupNorm / bias vectors
+                    dev = self.fine_mlp[0].weight.device
+                    wp = torch.empty(24576, device=dev, dtype=torch.uint8)
+                    cn = torch.empty(416, device=dev, dtype=_F32)
+                    li, gi, l0, g0, l3 = self.img_mlp[0], self.img_mlp[1], self.fine_mlp[0], self.fine_mlp[1], self.fine_mlp[3]
+                    q = lambda t: ptr(t.detach().float().contiguous())
+                    call("coocc_fine2_pack", q(l0.weight), q(l3.weight), self.out_channel, q(li.bias), q(gi.weight), q(gi.bias),
+                         q(l0.bias), q(g0.weight), q(g0.bias), q(l3.bias), ptr(wp), ptr(cn))
+                    d["fine2"] = (wp, cn)
             return d
         return self._packs.get_modules((self,), build)
 
@@ -285,17 +300,30 @@ class OccHead(nn.Module):
              self.out_channel, ptr(logits))
         return logits, fine_xyz, cnt
 
+    def _fine2_h2_ok(self):
+        """Ratio 2 on the split-f16 engine: the points-as-lanes one-launch kernel (csrc/fine2_h2.hip)."""
+        return (FINE2_H2 and self.cascade_ratio == 2 and core_mod.CONV_ENGINE == "h2" and core_mod.CONV_DTYPE == "f32"
+                and "fine2" in self._packed())
+
     def _fused_fine_ok(self, ovf, ncam):
-        """One-launch fine branch (csrc/fine_fused.hip): ratio 2 | 4, final grid = ratio x coarse grid, <= 8 cameras."""
+        """One-launch fine branch: ratio 2 (csrc/fine2_h2.hip on the split-f16 engine; csrc/fine_fused.hip with COOCC_FINE_FUSED=2) |
+        4 (csrc/fine_fused.hip), final grid = ratio x coarse grid, <= 8 cameras."""
         r = self.cascade_ratio
-        return (((FINE_FUSED >= 1 and r == 4) or (FINE_FUSED >= 2 and r == 2)) and ncam <= 8 and self.out_channel <= 32
-                and tuple(int(v) for v in self.final_occ_size) == (r * ovf.X, r * ovf.Y, r * ovf.Z))
+        return (((FINE_FUSED >= 1 and r == 4) or (r == 2 and (FINE_FUSED >= 2 or self._fine2_h2_ok()))) and ncam <= 8
+                and self.out_channel <= 32 and tuple(int(v) for v in self.final_occ_size) == (r * ovf.X, r * ovf.Y, r * ovf.Z))
 
     def _fine_fused(self, p, ovf, Q, P, params, img_dims, lin, n_cap, cnt, fine_xyz, logits):
         N_i, Hf, Wf = img_dims
         gi, l0, g0, l3, li = self.img_mlp[1], self.fine_mlp[0], self.fine_mlp[1], self.fine_mlp[3], self.img_mlp[0]
         d = lambda t: ptr(t.detach())
         nf = n_cap * self.cascade_ratio ** 3
+        if self._fine2_h2_ok() and FINE_FUSED < 2:
+            wp, cn = p["fine2"]
+            with TIMER.region("k_fine2_h2", 2.0 * nf * 64 * (64 + self.out_channel)):
+                call("coocc_fine2_h2", ptr(Q), ovf.X, ovf.Y, ovf.Z, ptr(P), N_i, Hf, Wf, ptr(params), ptr(lin), int(n_cap),
+                     ptr(cnt, _I32) if cnt is not None else None, host_i32(self.final_occ_size), ptr(wp), ptr(cn), float(gi.eps),
+                     float(g0.eps), self.out_channel, ptr(fine_xyz), ptr(logits))
+            return
         with TIMER.region("k_fine_fused", 2.0 * nf * 64 * (64 + self.out_channel)):
             call("coocc_fine_fused", ptr(Q), ovf.X, ovf.Y, ovf.Z, ptr(P), N_i, Hf, Wf, ptr(params), ptr(lin), int(n_cap),
                  ptr(cnt, _I32) if cnt is not None else None, self.cascade_ratio, host_i32(self.final_occ_size), d(li.bias), d(gi.weight),

@@ -545,6 +545,7 @@ def test_fused_fine_branch_equals_three_kernel_path(dev, monkeypatch, ratio):
     img_feats = [synth.image_feats(c["ncam"], c["fmap"], 512, seed=9).to(dev)]
     tr = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synth.rig_transform(rig))
     outs = []
+    monkeypatch.setattr(H, "FINE2_H2", False)            # ratio 2's default since round 5 is csrc/fine2_h2.hip (its own test below)
     with torch.no_grad():
         for fused in (0, 2):
             monkeypatch.setattr(H, "FINE_FUSED", fused)
@@ -553,6 +554,47 @@ def test_fused_fine_branch_equals_three_kernel_path(dev, monkeypatch, ratio):
     assert outs[0][0].shape[0] > 0 and outs[0][0].shape[0] % ratio ** 3 == 0
     assert torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize("grid", [(9, 7, 4), (23, 17, 5)])
+def test_fine2_h2_one_launch_branch_vs_three_kernel_path_and_device_count_form(dev, monkeypatch, grid):
+    """csrc/fine2_h2.hip (cascade ratio 2 on the split-f16 engine: lanes = fine points, samples in registers, both Linear layers as
+    f16 hi / lo MFMAs) against the three-kernel fp32 path: equal fine coordinates; logits equal up to the split-f16 products
+    (2^-22 per product -- the bound is 2e-6 of the logits' scale, 10x tighter than the Linear-first reordering's own bound above);
+    foreground counts that are not a multiple of the 4 coarse voxels a wave / 16 a workgroup owns; the device-count (hipGraph)
+    form writes the same rows; and against the literal oracle (occ_head.py:205-233) at 1e-4."""
+    from co_occ_amd import head as H
+    c = cases.DECODER_CASE
+    final = tuple(v * 2 for v in grid)
+    cfg = synth.model_cfg(C=c["C"], block_inplanes=c["block_inplanes"], out_channels=c["fpn_out"], cascade_ratio=2,
+                          final_occ_size=final, point_cloud_range=c["point_cloud_range"])
+    head, sd = load_seeded(pkg.build_head(cfg["pts_bbox_head"]), 31, dev)
+    g = torch.Generator().manual_seed(11)
+    sem = [torch.randn(1, c["fpn_out"], *[max(1, -(-v // 2 ** l)) for v in grid], generator=g).to(dev) for l in range(4)]
+    rig = synth.camera_rig(c["ncam"], c["input_size"], seed=9)
+    img_feats = [synth.image_feats(c["ncam"], c["fmap"], 512, seed=9).to(dev)]
+    tr = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synth.rig_transform(rig))
+    outs = []
+    with torch.no_grad():
+        for on in (False, True):
+            monkeypatch.setattr(H, "FINE2_H2", on)
+            res = head(voxel_feats=sem, img_feats=img_feats, transform=tr)
+            outs.append((res["output_voxels_fine"][0].clone(), res["output_coords_fine"][0].clone()))
+        res = head(voxel_feats=sem, img_feats=img_feats, transform=tr, static=True)
+        n = int(res["fine_count"].item()) * 8
+        stat = (res["output_voxels_fine"][0][:n].clone(), res["output_coords_fine"][0].reshape(-1)[:3 * n].view(3, n).clone())
+    from co_occ_amd import core
+    core.check_h2_overflow()
+    assert outs[0][0].shape[0] > 0 and outs[0][0].shape[0] % 8 == 0 and (outs[0][0].shape[0] // 8) % 4 != 0
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[1][1], stat[1])
+    assert torch.equal(outs[1][0], stat[0])
+    sc = max(1.0, float(outs[0][0].abs().max()))
+    err = float((outs[1][0] - outs[0][0]).abs().max())
+    assert err <= 2e-6 * sc, (err, sc)
+    want = ref_cpu.occhead_forward({k: v.cpu() for k, v in sd.items()}, [t.cpu() for t in sem], [img_feats[0].cpu()],
+                                   tuple(t.cpu() if torch.is_tensor(t) else t for t in tr), 2, final, c["point_cloud_range"])
+    assert np.array_equal(outs[1][1].cpu().numpy(), want["fine_coord"].numpy())
+    assert_close(outs[1][0].cpu(), want["fine_output"], what="fine (ratio 2, fine2_h2)")
 
 
 def test_predict_labels_and_nuscenes_dump(dev, tmp_path):

@@ -197,7 +197,7 @@ def test_pipelined_test_routes_an_odd_ground_truth_grid_through_simple_test_and_
     ``simple_test`` does); fine outputs come back at their exact size; breaking out of the loop closes the pipeline."""
     from co_occ_amd import apis
     bench, model, samples, gts = _setup(dev, n=3)
-    odd = torch.randint(0, 17, (1, 100, 100, 8), generator=torch.Generator().manual_seed(9)).to(dev)
+    odd = torch.randint(0, 17, (1, 200, 200, 32), generator=torch.Generator().manual_seed(9)).to(dev)     # a taller label grid
     data = [dict(precomputed=bench.simple_test_kwargs(s)["precomputed"], gt_occ=g) for s, g in zip(samples, gts)]
     data[1]["gt_occ"] = odd
     with torch.no_grad():

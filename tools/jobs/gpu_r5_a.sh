@@ -15,4 +15,4 @@ import json,sys
 try:
     d=json.load(open('$f')); print('$f'.split('/')[-1], d['value'], d['ms_per_step'], d.get('window_ms_per_step'), d.get('graph'))
 except Exception as e: print('$f'.split('/')[-1], 'FAILED', e)"; done
-tail -5 $O/*.err
+tail -n 5 $O/*.err
