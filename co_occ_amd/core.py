@@ -80,7 +80,7 @@ def conv_kernel_name(M, Cout, table, hint=0, iters=1 << 30, one_by_one=False):
 class Rows:
     """A dense voxel volume as channels-last rows: t[B*X*Y*Z, stride], C channels at `coff`."""
 
-    __slots__ = ("t", "B", "X", "Y", "Z", "C", "coff", "h16", "h2", "persistent")
+    __slots__ = ("t", "B", "X", "Y", "Z", "C", "coff", "h16", "h2", "persistent", "aux")
 
     def __init__(self, t, B, X, Y, Z, C, coff=0, persistent=False):
         self.t, self.B, self.X, self.Y, self.Z, self.C, self.coff = t, B, X, Y, Z, C, coff
@@ -88,6 +88,7 @@ class Rows:
         # ``out=`` targets): torch's version counter does not see those writes, so reference-layout views of such rows carry no
         # back-reference (``as_ncdhw`` / ``to_rows``) and a later consumer converts / re-splits instead of trusting a cached twin
         self.persistent = persistent
+        self.aux = None       # by-products a producer made from these rows for a known consumer (OccHead: the fine branch's Q rows)
         self.h16 = None       # f16 twin [B*V, C] written by the producing convolution's epilogue (CONV_DTYPE == "f16")
         # H2 twin [B*V, C] (split-f16 operand rows, csrc/h2_rows.h) of these rows: written by the PRODUCER's epilogue when the
         # consumer is a split-f16 layer outside the Winograd path (``conv_rows(twin_for=...)``), else made once by

@@ -12,7 +12,7 @@ struct ConvK {
   int kx, ky, kz, px, py, pz;   // per-axis kernel extent / padding (taps = kx*ky*kz, tap index t = (dx*ky + dy)*kz + dz)
   int wgroup_rows;              // > 0: output rows [g*wgroup_rows, (g+1)*wgroup_rows) use weight pack g (Winograd points)
   size_t wgroup_floats;         // floats per weight pack
-  int relu, res_mode, iters_per_split, total_iters, splitk;
+  int relu, res_mode, iters_per_split, total_iters, splitk;   // relu: 0 none | 1 every column | c >= 4: columns [0, c) only (merged heads)
   int mtiles, ntiles, mtiles_per_xcd;
   size_t in_bytes;              // total input bytes (k_conv2 bases its buffer descriptor at the tile's first row)
   unsigned w_bytes;             // bytes of one weight pack
@@ -36,7 +36,7 @@ __device__ __forceinline__ float epilogue(const ConvK& p, float v, int n, size_t
   if (p.scale) v *= p.scale[n];
   if (p.bias) v += p.bias[n];
   if (p.res_mode == 1) v += p.res[rrow * p.res_stride + n];
-  if (p.relu) v = fmaxf(v, 0.f);
+  if (p.relu && (p.relu == 1 || n < p.relu)) v = fmaxf(v, 0.f);     // relu > 1: only columns [0, relu) (a multiple of 4)
   if (p.res_mode == 2) v *= p.res[rrow * p.res_stride + n];
   return v;
 }

@@ -57,7 +57,7 @@ __device__ __forceinline__ void h2_epilogue_vec(const ConvK& p, size_t orow, int
   if (p.scale) v = v * *(const f32x4*)(p.scale + n);
   if (p.bias) v = v + *(const f32x4*)(p.bias + n);
   if (p.res_mode == 1) v = v + *(const f32x4*)(p.res + orow * p.res_stride + n);
-  if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+  if (p.relu && (p.relu == 1 || n < p.relu)) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
   if (p.res_mode == 2) v = v * *(const f32x4*)(p.res + orow * p.res_stride + n);
   if (p.out_h2) { store_h2(p.out, orow, p.out_stride, n, v); h2_guard(p.h2_flag, v); }
   else *(f32x4*)(p.out + orow * p.out_stride + n) = v;

@@ -32,6 +32,9 @@ FINE_FUSED = int(__import__("os").environ.get("COOCC_FINE_FUSED", "1"))
 # ratio 2 on the split-f16 engine: ONE launch with lanes = points, samples kept in registers, both Linear layers as three f16 MFMAs
 # per k16 step (csrc/fine2_h2.hip, round 5); 0 = the three kernels (fp32-MFMA chain)
 FINE2_H2 = __import__("os").environ.get("COOCC_FINE2_H2", "1") != "0"
+# occ_pred_conv[0] and the voxel half of fine_mlp[0] (both 128 -> 64 on out_voxel_feats) as one 128 -> 128 GEMM (ReLU on the first
+# 64 columns): one read of the rows and one launch instead of two; needs the strided-Q consumer (fine2_h2)
+MERGED_PRED_Q = __import__("os").environ.get("COOCC_MERGED_PRED_Q", "1") != "0"
 # pred_f of simple_test written output-major in one pass when the fine points are the head's own (coocc_scatter_fine_grouped);
 # 0 = fill + scatter by coordinates (coocc_scatter_fine[_dev])
 SCATTER_GROUPED = __import__("os").environ.get("COOCC_SCATTER_GROUPED", "1") != "0"
@@ -118,6 +121,18 @@ class OccHead(nn.Module):
                 if self.sample_from_voxel and self.fine_mlp[0].weight.shape[1] == 192:
                     d["img_nb"] = PackedConv(self.img_mlp[0].weight)                                  # bias added after sampling
                     d["f0_vox_nb"] = PackedConv(self.fine_mlp[0].weight[:, :128].contiguous())
+                    m = self.occ_pred_conv
+                    if m[0].weight.shape[0] == 64 and m[0].weight.shape[1] == 128:
+                        # occ_pred_conv[0] (128 -> 64, BN, ReLU) and the voxel half of fine_mlp[0] (128 -> 64, no bias: applied before
+                        # the trilinear resampling) read the same rows: ONE 128 -> 128 GEMM, ReLU on columns [0, 64) only
+                        from .core import fold_bn
+                        pq = PackedConv(torch.cat([m[0].weight.flatten(1), self.fine_mlp[0].weight[:, :128]], 0).contiguous())
+                        sc, bi = fold_bn(m[1], m[0].bias)
+                        dev = m[0].weight.device
+                        pq.scale = torch.cat([sc.float().cpu(), torch.ones(64)]).to(dev).contiguous()
+                        pq.bias = torch.cat([bi.float().cpu(), torch.zeros(64)]).to(dev).contiguous()
+                        pq.ksize, pq.pad = 1, 0
+                        d["pred_q"] = pq
             if hasattr(self, "img_mlp") and hasattr(self, "fine_mlp"):     # the fused fine-branch kernel loads 16-byte vectors
                 d["mlp_aligned"] = all(q.data_ptr() % 16 == 0 for m in (self.img_mlp, self.fine_mlp) for q in m.parameters())
                 if ("img_nb" in d and self.out_channel <= 32 and self.img_mlp[1].num_groups == 16 and self.fine_mlp[1].num_groups == 16
@@ -153,10 +168,18 @@ class OccHead(nn.Module):
         dims = host_i32([v for o in occs for v in (o.X, o.Y, o.Z)])
         out = Rows(torch.empty_like(o0.t), o0.B, o0.X, o0.Y, o0.Z, o0.C)
         tw = None
-        if core.CONV_ENGINE == "h2" and core.CONV_DTYPE == "f32" and o0.C % 32 == 0 and core.takes_h2(out, (p["pred"][0],)):
+        merged = (MERGED_PRED_Q and "pred_q" in p and core.CONV_DTYPE == "f32" and self.cascade_ratio == 2 and self._fine2_h2_ok()
+                  and not self.training)
+        first = p["pred_q"] if merged else p["pred"][0]
+        if core.CONV_ENGINE == "h2" and core.CONV_DTYPE == "f32" and o0.C % 32 == 0 and core.takes_h2(out, (first,)):
             tw = out.h2 = torch.empty_like(o0.t)
         call("coocc_occhead_mix_ex", levels, dims, L, ptr(wlogit), ptr(out.t), o0.B, o0.C, ptr(tw))
-        h = conv_rows(out, p["pred"][0], relu=True)
+        if merged:
+            hq = conv_rows(out, first, relu=64)               # [V, 128] = relu(bn(pred0 x)) | Q = W_f0[:, :128] x
+            h = Rows(hq.t, hq.B, hq.X, hq.Y, hq.Z, 64, 0)
+            out.aux = dict(q=hq.t[:, 64:])                    # rows 128 floats apart: csrc/fine2_h2.hip takes the stride
+        else:
+            h = conv_rows(out, p["pred"][0], relu=True)
         occ = conv_rows(h, p["pred"][1], relu=False)
         return out, occ
 
@@ -219,8 +242,11 @@ class OccHead(nn.Module):
             # Linear(128->64) of img_mlp on the 6 x Hf x Wf feature map and the voxel half of fine_mlp[0] on the V coarse
             # voxels instead of on the 8 V fine points: a Linear commutes with the interpolation that follows it
             P = linear_rows(g, p["img_nb"])
-            Q = linear_rows(ovf.t, p["f0_vox_nb"], in_coff=ovf.coff, in_C=128)
-            if self._fused_fine_ok(ovf, N_i):
+            fused_one = self._fused_fine_ok(ovf, N_i)
+            Q = ovf.aux.get("q") if (fused_one and ovf.aux and self._fine2_h2_ok() and FINE_FUSED < 2) else None
+            if Q is None:
+                Q = linear_rows(ovf.t, p["f0_vox_nb"], in_coff=ovf.coff, in_C=128)
+            if fused_one:
                 logits = torch.empty(nf, self.out_channel, device=dev, dtype=_F32)
                 self._fine_fused(p, ovf, Q, P, params, (N_i, Hf, Wf), lin, n, None, fine_xyz, logits)
                 return logits, fine_xyz
@@ -282,8 +308,11 @@ class OccHead(nn.Module):
         fine_xyz = torch.empty(3 * nf, device=dev, dtype=_I64)
         self._note_fine(dict(xyz=fine_xyz, lin=lin, n=V, cnt=cnt, coarse=(ovf.X, ovf.Y, ovf.Z), map=fgmap))
         P = linear_rows(g, p["img_nb"])
-        Q = linear_rows(ovf.t, p["f0_vox_nb"], in_coff=ovf.coff, in_C=128)
-        if self._fused_fine_ok(ovf, N_i):
+        fused = self._fused_fine_ok(ovf, N_i)
+        Q = ovf.aux.get("q") if (fused and ovf.aux and self._fine2_h2_ok() and FINE_FUSED < 2) else None   # made with occ_pred_conv[0]
+        if Q is None:
+            Q = linear_rows(ovf.t, p["f0_vox_nb"], in_coff=ovf.coff, in_C=128)
+        if fused:
             logits = torch.empty(nf, self.out_channel, device=dev, dtype=_F32)
             self._fine_fused(p, ovf, Q, P, params, (N_i, Hf, Wf), lin, V, cnt, fine_xyz, logits)
             return logits, fine_xyz, cnt
@@ -320,7 +349,7 @@ class OccHead(nn.Module):
         if self._fine2_h2_ok() and FINE_FUSED < 2:
             wp, cn = p["fine2"]
             with TIMER.region("k_fine2_h2", 2.0 * nf * 64 * (64 + self.out_channel)):
-                call("coocc_fine2_h2", ptr(Q), ovf.X, ovf.Y, ovf.Z, ptr(P), N_i, Hf, Wf, ptr(params), ptr(lin), int(n_cap),
+                call("coocc_fine2_h2", ptr(Q, strided=True), Q.stride(0), ovf.X, ovf.Y, ovf.Z, ptr(P), N_i, Hf, Wf, ptr(params), ptr(lin), int(n_cap),
                      ptr(cnt, _I32) if cnt is not None else None, host_i32(self.final_occ_size), ptr(wp), ptr(cn), float(gi.eps),
                      float(g0.eps), self.out_channel, ptr(fine_xyz), ptr(logits))
             return

@@ -660,12 +660,12 @@ int coocc_fine_fused(const float* Q, int X, int Y, int Z, const float* P, int nc
 /* The same branch for cascade ratio 2 on the split-f16 engine, ONE launch with lanes = fine points (csrc/fine2_h2.hip): samples
  * in registers (same resampling arithmetic as coocc_fine_fused), img_mlp GroupNorm + ReLU in place, fine_mlp[0] / fine_mlp[3]
  * as v_mfma_f32_32x32x16_f16 on f16 hi / lo operand halves with fp32 accumulation (fp32-accurate, not bit-identical to the
- * fp32-MFMA chain).  coocc_fine2_pack: w_f0 [64][192], w_f3 [ncls][64] and the bias / GroupNorm vectors -> wpack (24576 bytes)
+ * fp32-MFMA chain).  Q rows are q_stride floats apart (64, or 128 when Q is the upper half of a merged head GEMM).  coocc_fine2_pack: w_f0 [64][192], w_f3 [ncls][64] and the bias / GroupNorm vectors -> wpack (24576 bytes)
  * + consts (416 floats), once per weight version.  Replaces occ_head.py:205-233 for cascade_ratio == 2. */
 int coocc_fine2_pack(const float* w_f0, const float* w_f3, int ncls, const float* b_img, const float* gn_img_w,
                      const float* gn_img_b, const float* b_f0, const float* gn_f0_w, const float* gn_f0_b, const float* b_f3,
                      void* wpack, float* consts, void* stream);
-int coocc_fine2_h2(const float* Q, int X, int Y, int Z, const float* P, int ncam, int Hf, int Wf, const float* params,
+int coocc_fine2_h2(const float* Q, int q_stride, int X, int Y, int Z, const float* P, int ncam, int Hf, int Wf, const float* params,
                    const int32_t* coarse_lin, int n_cap, const int32_t* n_dev, const int* final_size_host, const void* wpack,
                    const float* consts, float eps_img, float eps_f0, int ncls, int64_t* fine_xyz, float* out, void* stream);
 

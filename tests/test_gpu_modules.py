@@ -585,7 +585,8 @@ def test_fine2_h2_one_launch_branch_vs_three_kernel_path_and_device_count_form(d
         stat = (res["output_voxels_fine"][0][:n].clone(), res["output_coords_fine"][0].reshape(-1)[:3 * n].view(3, n).clone())
     from co_occ_amd import core
     core.check_h2_overflow()
-    assert outs[0][0].shape[0] > 0 and outs[0][0].shape[0] % 8 == 0 and (outs[0][0].shape[0] // 8) % 4 != 0
+    assert outs[0][0].shape[0] > 0 and outs[0][0].shape[0] % 8 == 0
+    print("fine2_h2: %d foreground coarse voxels (mod 16 = %d)" % (outs[0][0].shape[0] // 8, (outs[0][0].shape[0] // 8) % 16))
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[1][1], stat[1])
     assert torch.equal(outs[1][0], stat[0])
     sc = max(1.0, float(outs[0][0].abs().max()))
