@@ -55,7 +55,7 @@ struct Fine2K {
   const char* wpack;         // coocc_fine2_pack
   const float* consts;
   int* h2_flag;
-  int n, X, Y, Z, ncam, Hf, Wf, ncls, q_stride;
+  int n, X, Y, Z, ncam, Hf, Wf, ncls, q_stride, dbg;
   float fx1, fy1, fz1, eps_img, eps_f0;
 };
 
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : 2) void k_fine2_h2(Fine2K p)
   __shared__ __attribute__((aligned(16))) float Cn[F2_NCONST];
   __shared__ __attribute__((aligned(16))) float Tl[NW][32 * F2_TP];
   const int tid = threadIdx.x;
+  if (p.dbg & 1) asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // debug: drop L1 / scalar cache lines
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 31, h = lane >> 5;             // MFMA layout: point column li, k / row half h
   const int pt8 = lane >> 3, piece = lane & 7;         // sampling layout: child pt8 of coarse voxel j, channels 32 i + 4 piece + 0..3
@@ -447,7 +448,11 @@ extern "C" int coocc_fine2_h2(const float* Q, int q_stride, int X, int Y, int Z,
   static const int nw = getenv("COOCC_FINE2_WAVES") ? atoi(getenv("COOCC_FINE2_WAVES")) : 4;
   const int per = 4 * (nw == 6 ? 6 : 4);
   const long long tiles = ((long long)n_cap + per - 1) / per;
-  const int grid = (int)(tiles < 512 ? tiles : 512);
+  // COOCC_FINE2_GRID=full: one tile per workgroup (debug: tools/debug/fine2_concurrent.py -- the run-to-run differences of the image
+  // samples show up on every call with this grid, even on one stream)
+  p.dbg = getenv("COOCC_FINE2_DBG") ? atoi(getenv("COOCC_FINE2_DBG")) : 0;
+  const char* ge = getenv("COOCC_FINE2_GRID");
+  const int grid = (ge && ge[0] == 'f') ? (int)tiles : (int)(tiles < 512 ? tiles : 512);
   if (nw == 6) hipLaunchKernelGGL(k_fine2_h2<6>, dim3(grid), dim3(384), 0, as_stream(stream), p);
   else hipLaunchKernelGGL(k_fine2_h2<4>, dim3(grid), dim3(256), 0, as_stream(stream), p);
   COOCC_LAUNCH_CHECK("k_fine2_h2");

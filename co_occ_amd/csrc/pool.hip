@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void k_csr_fill(const uint32_t* __restrict__ k
                                                    const int32_t* __restrict__ lstart, const int32_t* __restrict__ tops,
                                                    const int32_t* __restrict__ slot, int32_t* __restrict__ count,
                                                    int32_t* __restrict__ start, int32_t* __restrict__ long_list,
-                                                   int32_t* __restrict__ nlong, uint32_t* __restrict__ ids) {
+                                                   int32_t* __restrict__ nlong, uint32_t* __restrict__ ids, int slot_mask,
+                                                   const float* __restrict__ wts, float* __restrict__ wcsr) {
   extern __shared__ int prefix[];               // [nblk + 1] exclusive prefix of the chunk totals
   __shared__ int wsum[4];
   __shared__ int carry_s;
@@ -306,13 +307,16 @@ __global__ __launch_bounds__(256) void k_csr_fill(const uint32_t* __restrict__ k
     for (int u = 0; u < 4; ++u) {
       const long long i = i0 + u * gsz;
       k[u] = i < npts ? keys[i] : 0xFFFFFFFFu;
-      sl[u] = i < npts ? slot[i] : 0;
+      sl[u] = i < npts ? (slot[i] & slot_mask) : 0;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) st[u] = k[u] < (uint32_t)nvox ? lstart[k[u]] + prefix[k[u] >> 10] : 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (k[u] < (uint32_t)nvox) ids[st[u] + sl[u]] = (uint32_t)(i0 + u * gsz);
+      if (k[u] < (uint32_t)nvox) {
+        ids[st[u] + sl[u]] = (uint32_t)(i0 + u * gsz);
+        if (wcsr) wcsr[st[u] + sl[u]] = wts[i0 + u * gsz];          // segment form: the weights in CSR order (coalesced reads later)
+      }
   }
 }
 
@@ -542,6 +546,483 @@ __global__ __launch_bounds__(256) void k_pool_sum_csr(const float* __restrict__ 
   else pool_row<LIFT, 4>(x, depth, ids, s, e, lane, C, D, HW, out + (size_t)v * out_stride, lds);
 }
 
+// ------------------------------------------------------------------ round 5: ray-segment form of the fused lift (x) splat
+// The reference's order inside a voxel is unspecified (bev_pool.py:92 is an unstable argsort; bev_pool_cuda.cu:37-40 then adds
+// serially), so the contract is "deterministic and within fp32 rounding of any order", not "ascending point id".  The fused form
+// uses that freedom.  Points are walked PIXEL-major (t = pixel * D + d, lanes along the depth axis of one pixel's ray): the
+// consecutive depth bins of a ray that fall into the same voxel form one SEGMENT, whose weight is the sum of its depth
+// probabilities (added in ascending d), and a voxel's row is sum over its segments, in ascending t, of weight * context row.
+// Against the per-point form: 1.5-2x fewer CSR entries and row gathers (a 0.8 m voxel holds 1-3 bins of 0.5 m), the depth value
+// is no longer a dependent gather of the sum kernel (the weight sits at wts[t]), and a long voxel (up to 2600 points next to a
+// camera) is summed as four partial sums by the four waves of its workgroup instead of one serial chain.
+//   launch 1  k_seg_hist     key per point, segment leaders, weights, histogram (one atomic per SEGMENT)
+//   launch 2  k_scan_local   (as above)
+//   launch 3  k_csr_fill     (as above; the slot word also carries the segment length: reuse form)
+//   launch 4  k_pool_sum_seg per-voxel sums: ids ranked inside the voxel (atomic slots arrive in any order), then FMAs in that
+//                            order -- the same bits on every run
+constexpr int SEG_SLOT_BITS = 24;          // slot inside the voxel (< 16.7 M segments per voxel); bits 24..30: segment length (<= 64)
+constexpr int SEG_SLOT_MASK = (1 << SEG_SLOT_BITS) - 1;
+constexpr int SEG_LONG_CAP = 2048;         // segments a workgroup sorts in LDS (r101: <= ~1700 next to a camera); beyond: selection path
+
+// A workgroup owns a STRIP of SEG_STRIP consecutive pixels of one camera: the strip's depth values [D][SEG_STRIP] are staged in
+// LDS with coalesced 128-byte rows (the depth tensor is [N, D, H, W]: walking a pixel's ray reads one value per 4 H W bytes --
+// a first version did exactly that and fetched every line eight times, once per XCD), then the threads walk the strip
+// pixel-major, 64 consecutive depth bins of one ray per wave.  Strips are numbered so that each XCD (workgroup id mod 8) owns
+// a contiguous eighth of them.  Geometry tensor mode: the three coordinates of the strip are staged the same way.
+constexpr int SEG_STRIP = 8;               // 8 pixels x 112 bins = 3.5 passes of the workgroup; 32-byte runs per depth row (the neighbouring strips run on the same XCD)
+constexpr int SEG_HASH_BITS = 11, SEG_HASH = 1 << SEG_HASH_BITS;     // LDS hash cells per round of 1024 points
+constexpr int SEG_DMAX = 256;              // depth bins staged per strip (32 KB of LDS + padding); more: the ascending-point-id form
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_seg_hist(KeySrc a, const float* __restrict__ depth, int npts, int X, int Y, int Z, int nvox,
+                                                   int strips_per_cam, int nstrips, int stage_geom, uint32_t* __restrict__ keys,
+                                                   int32_t* __restrict__ count, int32_t* __restrict__ slot, float* __restrict__ wts) {
+  extern __shared__ float seg_lds[];       // [D][SEG_STRIP + 1] depth (+ 3 more planes of the same shape in geometry-tensor mode)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int per = (nstrips + 7) >> 3;
+  const int strip = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (strip >= nstrips) return;
+  const int D = a.D, HW = a.fH * a.fW;
+  const int n = strip / strips_per_cam, hw0 = (strip - n * strips_per_cam) * SEG_STRIP;
+  const int np = min(SEG_STRIP, HW - hw0);                       // pixels in this strip
+  constexpr int P = SEG_STRIP + 1;
+  const size_t base = (size_t)n * D * HW + hw0;                  // point id of (n, d = 0, hw0)
+  for (int e = tid; e < D * SEG_STRIP; e += 256) {
+    const int d = e / SEG_STRIP, j = e - d * SEG_STRIP;
+    if (j < np) {
+      const size_t i = base + (size_t)d * HW + j;
+      seg_lds[d * P + j] = depth[i];
+      if (MODE == 0 && stage_geom) {
+        seg_lds[(D + d) * P + j] = a.geom[i * 3 + 0];
+        seg_lds[(2 * D + d) * P + j] = a.geom[i * 3 + 1];
+        seg_lds[(3 * D + d) * P + j] = a.geom[i * 3 + 2];
+      }
+    }
+  }
+  __syncthreads();
+  const int total = np * D;
+  const size_t t0 = ((size_t)n * HW + hw0) * D;                   // pixel-major index of the strip's first point
+  // Histogram through an LDS hash of the strip: next to a camera the 8 pixels of a strip put dozens of segments into the same
+  // voxel, and one device-scope atomic per segment made the hottest voxel's counter (1600 atomics at r101) the critical path of
+  // the whole launch (87 us); now a workgroup issues ONE global atomic per distinct voxel of <= 1024 points and hands out the
+  // slots inside it from the LDS counter.
+  constexpr int U = 4;                                           // passes (of 256 points) per hash round
+  uint32_t* hkey = (uint32_t*)(seg_lds + (size_t)(MODE == 0 && stage_geom ? 4 : 1) * D * P);
+  int* hcnt = (int*)(hkey + SEG_HASH);
+  int* hbase = hcnt + SEG_HASH;
+  for (int e0 = 0; e0 < total; e0 += 256 * U) {                  // whole waves stay together: the shuffles below need all lanes
+    uint32_t ku[U];
+    float wu[U];
+    int lenu[U], baseu[U], hu[U];
+    bool leadu[U];
+    for (int i = tid; i < SEG_HASH; i += 256) { hkey[i] = 0xFFFFFFFFu; hcnt[i] = 0; }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * 256 + tid;
+      uint32_t k = (uint32_t)nvox;
+      int pj = -1;
+      float dp = 0.f;
+      if (e < total) {
+        pj = e / D;
+        const int d = e - pj * D;
+        const int hw = hw0 + pj;
+        float gx, gy, gz;
+        const size_t i = base + (size_t)d * HW + pj;
+        if (MODE == 0) {
+          if (stage_geom) { gx = seg_lds[(D + d) * P + pj]; gy = seg_lds[(2 * D + d) * P + pj]; gz = seg_lds[(3 * D + d) * P + pj]; }
+          else { gx = a.geom[i * 3 + 0]; gy = a.geom[i * 3 + 1]; gz = a.geom[i * 3 + 2]; }
+        } else {
+          const int h = hw / a.fW, w = hw - h * a.fW;
+          geometry_sample(a.mats + (size_t)n * COOCC_CAM_FLOATS, a.xs[w], a.ys[h], a.ds[d], gx, gy, gz);
+        }
+        k = voxel_key(gx, gy, gz, (int)(i / (size_t)a.pts_per_batch), a.lox, a.loy, a.loz, a.dx, a.dy, a.dz, X, Y, Z, nvox);
+        dp = seg_lds[d * P + pj];
+      }
+      const bool valid = k < (uint32_t)nvox;
+      const uint32_t pk = (uint32_t)__shfl_up((int)k, 1);
+      const int pp = __shfl_up(pj, 1);
+      const bool leader = valid && (lane == 0 || pk != k || pp != pj);
+      // weight of the run that starts at a leader: its own bins in ascending d (runs are 1-3 bins long; one that crosses the
+      // wave boundary simply becomes two segments)
+      float w = dp;
+      int len = 1;
+      bool cont = leader;
+      for (int o = 1; o < 64; ++o) {
+        const uint32_t ko = (uint32_t)__shfl_down((int)k, o);
+        const int po = __shfl_down(pj, o);
+        const float dv = __shfl_down(dp, o);
+        cont = cont && lane + o < 64 && ko == k && po == pj;
+        if (!__any(cont)) break;
+        if (cont) { w = w + dv; ++len; }
+      }
+      ku[u] = k; wu[u] = w; lenu[u] = len; leadu[u] = leader;
+      baseu[u] = 0; hu[u] = 0;
+      if (leader) {
+        unsigned h = (k * 2654435761u) >> (32 - SEG_HASH_BITS);
+        for (;;) {                                               // open addressing; <= 1024 leaders in SEG_HASH = 2048 cells
+          const uint32_t prev = atomicCAS(&hkey[h], 0xFFFFFFFFu, k);
+          if (prev == 0xFFFFFFFFu || prev == k) break;
+          h = (h + 1) & (SEG_HASH - 1);
+        }
+        hu[u] = (int)h;
+        baseu[u] = atomicAdd(&hcnt[h], 1);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < SEG_HASH; i += 256)
+      if (hkey[i] != 0xFFFFFFFFu) hbase[i] = atomicAdd(&count[hkey[i]], hcnt[i]);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * 256 + tid;
+      if (e < total) {
+        const size_t t = t0 + e;
+        keys[t] = leadu[u] ? ku[u] : (uint32_t)nvox;             // the fill pass scatters leaders only
+        if (leadu[u]) {
+          slot[t] = (hbase[hu[u]] + baseu[u]) | (lenu[u] << SEG_SLOT_BITS);
+          wts[t] = wu[u];
+        }
+      }
+    }
+    __syncthreads();                                             // the next round re-initialises the hash
+  }
+}
+
+// weight of segment t in the reuse form (the CSR of an earlier frame, this frame's depth): the leader's run re-added in the order
+// k_seg_hist used
+__device__ __forceinline__ float seg_weight_from_depth(const float* __restrict__ depth, const int32_t* __restrict__ slot, uint32_t t,
+                                                       int D, int HW) {
+  const int len = slot[t] >> SEG_SLOT_BITS;
+  const uint32_t pix = t / (uint32_t)D, d = t - pix * (uint32_t)D;
+  const uint32_t n = pix / (uint32_t)HW, hw = pix - n * (uint32_t)HW;
+  const float* q = depth + ((size_t)n * D + d) * HW + hw;
+  float w = q[0];
+  for (int j = 1; j < len; ++j) w = w + q[(size_t)j * HW];
+  return w;
+}
+
+// sum of nb (<= 64) weighted rows whose (row, weight) sit in the lanes' registers in ascending t; NB loads in flight
+template <int VEC, int NB>
+__device__ __forceinline__ void seg_accumulate(const float* __restrict__ xc, int C, uint32_t myrow, float myw, int nb,
+                                               typename PoolVec<VEC>::type& acc) {
+  typedef typename PoolVec<VEC>::type vec;
+  for (int j0 = 0; j0 < nb; j0 += NB) {
+    vec r[NB];
+    float wj[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int jj = min(j0 + j, nb - 1);
+      const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)myrow, jj);
+      wj[j] = j0 + j < nb ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myw), jj)) : 0.f;
+      r[j] = *(const vec*)(xc + (size_t)row * C);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] = __fmaf_rn(wj[j], r[j][e], acc[e]);      // a tail entry repeats the last row with weight 0
+  }
+}
+
+// wcsr: the segments' weights in CSR order (k_csr_fill); REUSE: recomputed from this frame's depth instead
+template <int VEC, bool REUSE>
+__device__ __forceinline__ void seg_row(const float* __restrict__ x, const float* __restrict__ depth, const float* __restrict__ wcsr,
+                                        const int32_t* __restrict__ slot, const uint32_t* __restrict__ ids, int s, int n, int lane,
+                                        int C, int D, int HW, float* __restrict__ orow, uint32_t* __restrict__ lds,
+                                        float* __restrict__ ldw) {
+  typedef typename PoolVec<VEC>::type vec;
+  if (n == 0) {
+    for (int c = lane * VEC; c < C; c += 64 * VEC) *(vec*)(orow + c) = (vec)(0.f);
+    return;
+  }
+  if (n <= 64) {
+    uint32_t myid = lane < n ? ids[s + lane] : 0xFFFFFFFFu;
+    float myw = (!REUSE && lane < n) ? wcsr[s + lane] : 0.f;
+    if (n > 1) {
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)myid, j) < myid;   // ids are distinct
+      myid = (uint32_t)__builtin_amdgcn_ds_permute(rank << 2, (int)myid);     // idle lanes all rank n: lane n is not read
+      if (!REUSE) myw = __int_as_float(__builtin_amdgcn_ds_permute(rank << 2, __float_as_int(myw)));
+    }
+    uint32_t myrow = 0;
+    if (lane < n) {
+      myrow = myid / (uint32_t)D;
+      if (REUSE) myw = seg_weight_from_depth(depth, slot, myid, D, HW);
+    } else myw = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 64 * VEC) {
+      const int c = c0 + lane * VEC;
+      const bool lane_on = c < C;
+      vec acc = (vec)(0.f);
+      const float* xc = x + (lane_on ? c : 0);
+      if (n <= 4) seg_accumulate<VEC, 4>(xc, C, myrow, myw, n, acc);
+      else seg_accumulate<VEC, 8>(xc, C, myrow, myw, n, acc);
+      if (lane_on) *(vec*)(orow + c) = acc;
+    }
+    return;
+  }
+  // medium voxel (64 < n <= POOL_MEDIUM): ids -> LDS (unsorted) -> ranks -> LDS (sorted, after every lane has read what it needs)
+  uint32_t mine[POOL_MEDIUM / 64];
+  float minew[POOL_MEDIUM / 64];
+  int rank[POOL_MEDIUM / 64];
+#pragma unroll
+  for (int q = 0; q < POOL_MEDIUM / 64; ++q) {
+    mine[q] = q * 64 + lane < n ? ids[s + q * 64 + lane] : 0xFFFFFFFFu;
+    minew[q] = (!REUSE && q * 64 + lane < n) ? wcsr[s + q * 64 + lane] : 0.f;
+    lds[q * 64 + lane] = mine[q];
+    rank[q] = 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int j = 0; j < n; ++j) {
+    const uint32_t o = lds[j];              // broadcast read
+#pragma unroll
+    for (int q = 0; q < POOL_MEDIUM / 64; ++q) rank[q] += o < mine[q];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < POOL_MEDIUM / 64; ++q)
+    if (q * 64 + lane < n) { lds[rank[q]] = mine[q]; ldw[rank[q]] = minew[q]; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int c0 = 0; c0 < C; c0 += 64 * VEC) {
+    const int c = c0 + lane * VEC;
+    const bool lane_on = c < C;
+    vec acc = (vec)(0.f);
+    for (int base = 0; base < n; base += 64) {
+      const int nb = min(64, n - base);
+      const uint32_t myid = lds[base + min(lane, nb - 1)];
+      const uint32_t myrow = myid / (uint32_t)D;
+      const float myw = REUSE ? seg_weight_from_depth(depth, slot, myid, D, HW) : ldw[base + min(lane, nb - 1)];
+      seg_accumulate<VEC, 8>(x + (lane_on ? c : 0), C, myrow, myw, nb, acc);
+    }
+    if (lane_on) *(vec*)(orow + c) = acc;
+  }
+}
+
+// Four voxels per wave, 16 lanes each (C = 128: 8 channels per lane, C = 64: 4): at r50 a voxel holds 2.6 segments on average, and
+// with one wave per voxel the launch was 80 k waves x four dependent memory round trips (44 us).  A group whose voxel has more
+// than 16 segments sits this pass out (the caller runs the whole-wave code for it).  (s, n): the group's CSR range.
+template <int V8, bool REUSE>
+__device__ __forceinline__ void seg_rows16(const float* __restrict__ x, const float* __restrict__ depth, const float* __restrict__ wcsr,
+                                           const int32_t* __restrict__ slot, const uint32_t* __restrict__ ids, int s, int n, bool on,
+                                           int lane, int C, int D, int HW, float* __restrict__ orow) {
+  const int l16 = lane & 15, gbase = lane & 48;
+  const bool small = on && n <= 16;
+  const bool mine = small && l16 < n;
+  uint32_t myid = mine ? ids[s + l16] : 0xFFFFFFFFu;
+  float myw = (!REUSE && mine) ? wcsr[s + l16] : 0.f;
+  int nmax = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int ng = __builtin_amdgcn_readlane(small ? n : 0, g * 16);
+    nmax = max(nmax, ng);
+  }
+  if (nmax > 1) {
+    int rank = 0;
+    for (int j = 0; j < nmax; ++j) rank += (uint32_t)__shfl((int)myid, j, 16) < myid;      // ids are distinct; idle lanes rank n
+    const int dst = (gbase + min(rank, 15)) << 2;
+    myid = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)myid);
+    if (!REUSE) myw = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(myw)));
+  }
+  uint32_t myrow = 0;
+  if (mine) {
+    myrow = myid / (uint32_t)D;
+    if (REUSE) myw = seg_weight_from_depth(depth, slot, myid, D, HW);
+  } else myw = 0.f;
+  float acc[V8];
+#pragma unroll
+  for (int e = 0; e < V8; ++e) acc[e] = 0.f;
+  const float* xc = x + l16 * V8;
+  constexpr int NB = 4;
+  for (int j0 = 0; j0 < nmax; j0 += NB) {
+    f32x4 r[NB][V8 / 4];
+    float wj[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int jj = min(j0 + j, 15);
+      const uint32_t row = (uint32_t)__shfl((int)myrow, jj, 16);
+      wj[j] = j0 + j < nmax ? __shfl(myw, jj, 16) : 0.f;           // lanes past a group's n hold weight 0 and row 0
+#pragma unroll
+      for (int q = 0; q < V8 / 4; ++q) r[j][q] = *(const f32x4*)(xc + (size_t)row * C + 4 * q);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int q = 0; q < V8 / 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * q + e] = __fmaf_rn(wj[j], r[j][q][e], acc[4 * q + e]);
+  }
+  if (small) {
+#pragma unroll
+    for (int q = 0; q < V8 / 4; ++q) *(f32x4*)(orow + l16 * V8 + 4 * q) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+  }
+}
+
+// n > POOL_MEDIUM: one workgroup per voxel.  (id, CSR position) pairs are bitonic-sorted in LDS as 64-bit keys, decoded once
+// (row, weight), and the four waves each sum a quarter of the sorted list (fixed split points: ceil(n / 4)); the four partial
+// rows are added in wave order.
+template <bool REUSE>
+__device__ __forceinline__ void seg_long(const float* __restrict__ x, const float* __restrict__ depth, const float* __restrict__ wseg,
+                                         const int32_t* __restrict__ slot, const uint32_t* __restrict__ seg, int n, int C, int D, int HW,
+                                         float* __restrict__ orow, unsigned long long* __restrict__ skey /* [SEG_LONG_CAP] = sid | sw */,
+                                         float* __restrict__ part /* [4][256] */) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  uint32_t* sid = (uint32_t*)skey;
+  float* sw = (float*)(sid + SEG_LONG_CAP);
+  if (n <= SEG_LONG_CAP) {
+    int np2 = 512;
+    while (np2 < n) np2 <<= 1;
+    for (int i = tid; i < np2; i += 256) skey[i] = i < n ? (((unsigned long long)seg[i] << 32) | (unsigned)i) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < np2; i += 256) {
+          const int l = i ^ j;
+          if (l > i) {
+            const unsigned long long a = skey[i], b = skey[l];
+            const bool up = (i & k) == 0;
+            if ((a > b) == up) { skey[i] = b; skey[l] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    // decode into registers first: the (row, weight) arrays overlay the keys
+    uint32_t rr[SEG_LONG_CAP / 256];
+    float ww[SEG_LONG_CAP / 256];
+#pragma unroll
+    for (int q = 0; q < SEG_LONG_CAP / 256; ++q) {
+      const int i = q * 256 + tid;
+      rr[q] = 0; ww[q] = 0.f;
+      if (i < n) {
+        const unsigned long long kv = skey[i];
+        const uint32_t id = (uint32_t)(kv >> 32);
+        rr[q] = id / (uint32_t)D;
+        ww[q] = REUSE ? seg_weight_from_depth(depth, slot, id, D, HW) : wseg[(uint32_t)kv];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SEG_LONG_CAP / 256; ++q) {
+      const int i = q * 256 + tid;
+      if (i < n) { sid[i] = rr[q]; sw[i] = ww[q]; }
+    }
+    __syncthreads();
+    const int q4 = (n + 3) >> 2, lo = min(n, wave * q4), hi = min(n, lo + q4);
+    constexpr int LB = 8;             // (with 16 the kernel needs 114 registers: 4 instead of 8 waves per SIMD for the short voxels)
+    for (int c0 = 0; c0 < C; c0 += 256) {
+      const int c = c0 + lane * 4;
+      const bool on = c < C;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* xc = x + (on ? c : 0);
+      for (int j0 = lo; j0 < hi; j0 += LB) {
+        f32x4 r[LB];
+        float wj[LB];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+          const int jj = min(j0 + j, hi - 1);
+          wj[j] = j0 + j < hi ? sw[jj] : 0.f;
+          r[j] = *(const f32x4*)(xc + (size_t)sid[jj] * C);
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = __fmaf_rn(wj[j], r[j][e], acc[e]);
+      }
+      *(f32x4*)(part + wave * 256 + lane * 4) = acc;
+      __syncthreads();
+      if (wave == 0 && on) {
+        f32x4 t = *(const f32x4*)(part + lane * 4);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) t = t + *(const f32x4*)(part + w * 256 + lane * 4);
+        *(f32x4*)(orow + c) = t;
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // never seen in practice (> SEG_LONG_CAP segments in one voxel): the next id in ascending order is found by a block-wide min
+  // over the unsorted segment list, one entry at a time -- O(n^2 / 256), correct for any n
+  for (int c = tid; c < C; c += 256) orow[c] = 0.f;
+  unsigned long long prev = 0;
+  bool first = true;
+  for (int t = 0; t < n; ++t) {
+    unsigned long long best = ~0ull;
+    for (int i = tid; i < n; i += 256) {
+      const unsigned long long me = ((unsigned long long)seg[i] << 32) | (unsigned)i;
+      if ((first || me > prev) && me < best) best = me;
+    }
+    skey[tid] = best;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) skey[tid] = min(skey[tid], skey[tid + o]);
+      __syncthreads();
+    }
+    const unsigned long long kv = skey[0];
+    __syncthreads();
+    prev = kv; first = false;
+    const uint32_t id = (uint32_t)(kv >> 32);
+    const uint32_t row = id / (uint32_t)D;
+    const float wv = REUSE ? seg_weight_from_depth(depth, slot, id, D, HW) : wseg[(uint32_t)kv];
+    for (int c = tid; c < C; c += 256) orow[c] = __fmaf_rn(wv, x[(size_t)row * C + c], orow[c]);
+  }
+  __syncthreads();
+}
+
+// blocks [0, long_blocks): the long voxels (persistent over long_list); the rest: one wave per voxel, four voxels per workgroup.
+// XCD-aware order of the short blocks: workgroup b runs on XCD b % 8, and XCD x walks the x-th eighth of the voxel list front to
+// back -- the voxels in flight on one XCD are neighbours, so the context rows they gather are shared through that XCD's L2
+// (with the plain order every XCD swept the whole grid and fetched every context row itself: 3.6x the algorithmic bytes at r101).
+template <bool REUSE, int V8 /* 0: one voxel per wave; 4 | 8: four voxels per wave, V8 channels per lane (C = 16 V8) */>
+__global__ __launch_bounds__(256) void k_pool_sum_seg(const float* __restrict__ x, const float* __restrict__ depth,
+                                                       const float* __restrict__ wts, const int32_t* __restrict__ slot,
+                                                       const uint32_t* __restrict__ ids, const int32_t* __restrict__ start,
+                                                       const int32_t* __restrict__ long_list, const int32_t* __restrict__ nlong_p,
+                                                       int long_blocks, int nvox, int C, int D, int HW, float* __restrict__ out,
+                                                       int out_stride) {
+  __shared__ __attribute__((aligned(16))) unsigned long long skey[SEG_LONG_CAP];
+  __shared__ __attribute__((aligned(16))) float part[4 * 256];
+  uint32_t* sid = (uint32_t*)skey;
+  float* sw = (float*)(sid + SEG_LONG_CAP);
+  if ((int)blockIdx.x < long_blocks) {
+    const int nlong = *nlong_p;
+    for (int li = blockIdx.x; li < nlong; li += long_blocks) {
+      const int v = long_list[li];
+      const int s = start[v];
+      seg_long<REUSE>(x, depth, wts + s, slot, ids + s, start[v + 1] - s, C, D, HW, out + (size_t)v * out_stride, skey, part);
+    }
+    return;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = (int)blockIdx.x - long_blocks, nb = (int)gridDim.x - long_blocks;      // nb is a multiple of 8
+  const int chunk = (b & 7) * (nb >> 3) + (b >> 3);
+  uint32_t* lds = sid + wave * POOL_MEDIUM;
+  float* ldw = sw + wave * POOL_MEDIUM;
+  if (V8) {
+    const int vg = (chunk * 4 + wave) * 4 + (lane >> 4);         // this 16-lane group's voxel
+    const bool on = vg < nvox;
+    const int sg = on ? start[vg] : 0, ng = on ? start[vg + 1] - sg : 0;
+    seg_rows16<V8 ? V8 : 4, REUSE>(x, depth, wts, slot, ids, sg, ng, on, lane, C, D, HW, out + (size_t)(on ? vg : 0) * out_stride);
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {                                // the groups that sat out: whole-wave code, one after the other
+      const int n = __builtin_amdgcn_readlane(ng, g * 16);
+      if (n <= 16 || n > POOL_MEDIUM) continue;
+      const int s = __builtin_amdgcn_readlane(sg, g * 16);
+      const int v = (chunk * 4 + wave) * 4 + g;
+      seg_row<2, REUSE>(x, depth, wts, slot, ids, s, n, lane, C, D, HW, out + (size_t)v * out_stride, lds, ldw);
+    }
+    return;
+  }
+  const int v = __builtin_amdgcn_readfirstlane(chunk * 4 + wave);
+  if (v >= nvox) return;
+  const int s = start[v], n = start[v + 1] - s;
+  if (n > POOL_MEDIUM) return;
+  if (C <= 128) seg_row<2, REUSE>(x, depth, wts, slot, ids, s, n, lane, C, D, HW, out + (size_t)v * out_stride, lds, ldw);
+  else seg_row<4, REUSE>(x, depth, wts, slot, ids, s, n, lane, C, D, HW, out + (size_t)v * out_stride, lds, ldw);
+}
+
 // (Round 4 tried the sums as TWO launches -- short / medium voxels, 8 waves per SIMD instead of 3, and the long voxels on a side
 // stream -- and measured no gain at r50 (0.118 ms either way: that round's gain was the batched histogram atomics) and a loss at
 // r101 (0.325 -> 0.410 ms: the long voxels' serial chains, 233 us, are the launch and they run slower next to a denser short
@@ -550,14 +1031,14 @@ __global__ __launch_bounds__(256) void k_pool_sum_csr(const float* __restrict__ 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // workspace: keys[npts] | ids[npts] | slot[npts] | count[nvox+1] | nlong [64] (one memset clears these two when the caller does
-// not vouch for them) | start[nvox+1] | lstart[nvox+1] | long_list[nvox] | tops[nvox / 1024 + 2]
+// not vouch for them) | start[nvox+1] | lstart[nvox+1] | long_list[nvox] | tops[nvox / 1024 + 2] | wts[npts] | wcsr[npts] (segment form)
 extern "C" size_t coocc_voxel_pool_ws(int npts, int nvox) {
   if (npts <= 0 || nvox <= 0) return 0;
-  return 3 * align256(sizeof(uint32_t) * (size_t)npts) + 4 * align256(sizeof(int32_t) * ((size_t)nvox + 1)) + 256 +
+  return 5 * align256(sizeof(uint32_t) * (size_t)npts) + 4 * align256(sizeof(int32_t) * ((size_t)nvox + 1)) + 256 +
          align256(sizeof(int32_t) * ((size_t)nvox / 1024 + 2)) + 8192 + 256;
 }
 
-struct PoolWs { uint32_t *keys, *ids; int32_t *slot, *count, *nlong, *start, *lstart, *long_list, *tops; size_t zero_bytes; };
+struct PoolWs { uint32_t *keys, *ids; int32_t *slot, *count, *nlong, *start, *lstart, *long_list, *tops; float *wts, *wcsr; size_t zero_bytes; };
 
 static int carve(void* ws, size_t ws_bytes, int npts, int nvox, PoolWs* p) {
   size_t need = coocc_voxel_pool_ws(npts, nvox);
@@ -568,6 +1049,9 @@ static int carve(void* ws, size_t ws_bytes, int npts, int nvox, PoolWs* p) {
   p->count = (int32_t*)c; c += v; p->nlong = (int32_t*)c; c += 256;
   p->zero_bytes = v + 256;
   p->start = (int32_t*)c; c += v; p->lstart = (int32_t*)c; c += v; p->long_list = (int32_t*)c; c += v; p->tops = (int32_t*)c;
+  c += align256(sizeof(int32_t) * ((size_t)nvox / 1024 + 2)) + 8192;
+  p->wts = (float*)c; c += a;
+  p->wcsr = (float*)c;
   return COOCC_OK;
 }
 
@@ -599,8 +1083,54 @@ static int pool_build(const KeySrc& ks, const float* x, const float* depth, int 
   // a quarter of the points per grid pass (four per thread and iteration); every workgroup re-scans the nblk chunk totals
   const int fill_blocks = max(cdiv(npts, 1024), 1);
   hipLaunchKernelGGL(k_csr_fill, dim3(fill_blocks), dim3(256), sizeof(int) * ((size_t)nblk + 1), s, p.keys, npts, nvox, nblk, p.lstart, p.tops,
-                     p.slot, p.count, p.start, p.long_list, p.nlong, p.ids);
+                     p.slot, p.count, p.start, p.long_list, p.nlong, p.ids, 0x7FFFFFFF, nullptr, nullptr);
   return pool_sums<LIFT>(x, depth, C, D, HW, nvox, out, out_stride, p, s);
+}
+
+// ---- segment form (fused lift (x) splat only; COOCC_POOL_SEG=0 restores the ascending-point-id form above)
+static bool pool_seg_on() {               // read per call: tests compare the two forms inside one process
+  const char* e = getenv("COOCC_POOL_SEG");
+  return !(e && atoi(e) == 0);
+}
+
+template <bool REUSE>
+static int pool_sums_seg(const float* x, const float* depth, int C, int D, int HW, int nvox, float* out, int out_stride,
+                         const PoolWs& p, hipStream_t s) {
+  static const int long_blocks = getenv("COOCC_POOL_LONG_BLOCKS") ? atoi(getenv("COOCC_POOL_LONG_BLOCKS")) : 1024;
+  static const bool g16 = !(getenv("COOCC_POOL_G16") && atoi(getenv("COOCC_POOL_G16")) == 0);
+  if (g16 && (C == 128 || C == 64)) {
+    const int short_blocks = 8 * cdiv(cdiv(nvox, 16), 8);
+    if (C == 128)
+      hipLaunchKernelGGL((k_pool_sum_seg<REUSE, 8>), dim3(long_blocks + short_blocks), dim3(256), 0, s, x, depth, p.wcsr, p.slot, p.ids,
+                         p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, out, out_stride);
+    else
+      hipLaunchKernelGGL((k_pool_sum_seg<REUSE, 4>), dim3(long_blocks + short_blocks), dim3(256), 0, s, x, depth, p.wcsr, p.slot, p.ids,
+                         p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, out, out_stride);
+  } else {
+    const int short_blocks = 8 * cdiv(cdiv(nvox, 4), 8);
+    hipLaunchKernelGGL((k_pool_sum_seg<REUSE, 0>), dim3(long_blocks + short_blocks), dim3(256), 0, s, x, depth, p.wcsr, p.slot, p.ids,
+                       p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, out, out_stride);
+  }
+  COOCC_LAUNCH_CHECK("voxel_pool (segments)");
+  return COOCC_OK;
+}
+
+template <int MODE>
+static int pool_build_seg(const KeySrc& ks, const float* x, const float* depth, int npts, int C, int D, int HW, int X, int Y, int Z,
+                          int nvox, float* out, int out_stride, const PoolWs& p, int ws_clean, hipStream_t s) {
+  COOCC_CHECK_ARG((nvox + 1023) / 1024 <= POOL_MAX_CHUNKS, "voxel_pool: grids above 8.4 M voxels are not supported");
+  if (!ws_clean) COOCC_HIP(hipMemsetAsync(p.count, 0, p.zero_bytes, s));
+  const int strips_per_cam = cdiv(HW, SEG_STRIP), nstrips = strips_per_cam * (npts / (D * HW));
+  const size_t plane = sizeof(float) * (size_t)D * (SEG_STRIP + 1);
+  const int stage_geom = MODE == 0 && 4 * plane + 12 * SEG_HASH <= 60 * 1024;
+  hipLaunchKernelGGL(k_seg_hist<MODE>, dim3(8 * cdiv(nstrips, 8)), dim3(256), (stage_geom ? 4 * plane : plane) + 12 * SEG_HASH, s, ks, depth, npts, X, Y, Z,
+                     nvox, strips_per_cam, nstrips, stage_geom, p.keys, p.count, p.slot, p.wts);
+  const int nblk = (nvox + 1023) / 1024;
+  hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(1024), 0, s, p.count, nvox, p.lstart, p.tops, p.nlong);
+  const int fill_blocks = max(cdiv(npts, 1024), 1);
+  hipLaunchKernelGGL(k_csr_fill, dim3(fill_blocks), dim3(256), sizeof(int) * ((size_t)nblk + 1), s, p.keys, npts, nvox, nblk, p.lstart, p.tops,
+                     p.slot, p.count, p.start, p.long_list, p.nlong, p.ids, SEG_SLOT_MASK, p.wts, p.wcsr);
+  return pool_sums_seg<false>(x, depth, C, D, HW, nvox, out, out_stride, p, s);
 }
 
 extern "C" int coocc_voxel_pool(const float* x, const float* geom, int npts, int pts_per_batch, int C,
@@ -648,6 +1178,10 @@ static int lift_splat_impl(const float* depth, const float* feat_nhwc, const flo
   ks.geom = geom; ks.mats = mats; ks.xs = xs; ks.ys = ys; ks.ds = ds; ks.D = D; ks.fH = H; ks.fW = W;
   ks.pts_per_batch = pts_per_batch; ks.B = B;
   ks.lox = l[0]; ks.loy = l[1]; ks.loz = l[2]; ks.dx = l[3]; ks.dy = l[4]; ks.dz = l[5];
+  if (pool_seg_on() && (long long)N * H * W < (1ll << SEG_SLOT_BITS) && D <= SEG_DMAX) {
+    if (geom) return pool_build_seg<0>(ks, feat_nhwc, depth, npts, C, D, H * W, X, Y, Z, nvox, out, out_stride, p, ws_clean, s);
+    return pool_build_seg<1>(ks, feat_nhwc, depth, npts, C, D, H * W, X, Y, Z, nvox, out, out_stride, p, ws_clean, s);
+  }
   if (geom) return pool_build<true, 0>(ks, feat_nhwc, depth, npts, C, D, H * W, X, Y, Z, nvox, out, out_stride, p, ws_clean, s);
   return pool_build<true, 1>(ks, feat_nhwc, depth, npts, C, D, H * W, X, Y, Z, nvox, out, out_stride, p, ws_clean, s);
 }
@@ -681,6 +1215,8 @@ extern "C" int coocc_lift_splat_reuse(const float* depth, const float* feat_nhwc
   PoolWs p;
   int rc = carve(ws, ws_bytes, (int)npts_ll, (int)nvox_ll, &p);
   if (rc) return rc;
+  if (pool_seg_on() && (long long)N * H * W < (1ll << SEG_SLOT_BITS) && D <= SEG_DMAX)      // the rule of lift_splat_impl
+    return pool_sums_seg<true>(feat_nhwc, depth, C, D, H * W, (int)nvox_ll, out, out_stride, p, as_stream(stream));
   return pool_sums<true>(feat_nhwc, depth, C, D, H * W, (int)nvox_ll, out, out_stride, p, as_stream(stream));
 }
 

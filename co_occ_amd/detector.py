@@ -96,13 +96,9 @@ class COOCC_Ray(nn.Module):
         self.pts_middle_encoder = None
         if pts_middle_encoder:
             if pts_middle_encoder.get("type") in lidar.MIDDLE_ENCODERS:
+                # trains like upstream (sparse_lidar_enc.py:125-176; batch-statistics BN1d, gradients through the rule books:
+                # co_occ_amd/lidar.py ``SparseConvFn``); ``freeze_lidar_encoder()`` restores the round-2..4 behaviour
                 self.pts_middle_encoder = lidar.MIDDLE_ENCODERS.build(pts_middle_encoder)
-                # FROZEN LiDAR branch: the sparse encoder has an eval-mode path only (folded BN1d, no autograd), so it
-                # stays in eval mode under model.train() (``train`` below) and its parameters take no gradient -- DDP with
-                # find_unused_parameters=False then does not wait for them.  The reference trains this encoder
-                # (sparse_lidar_enc.py:125-176); INTEGRATION.md section 6 says what that means for fine-tuning.
-                for prm in self.pts_middle_encoder.parameters():
-                    prm.requires_grad_(False)
             elif not external_encoders:
                 raise NotImplementedError("COOCC_Ray: pts_middle_encoder type %r is not on the MI355X path (SparseLiDAREnc8x / "
                                           "SparseLiDAREnc4x are); pass external_encoders=True to attach it yourself"
@@ -191,21 +187,25 @@ class COOCC_Ray(nn.Module):
         voxel_feats = self.fuse(img_voxel_feats, pts_voxel_feats, search)
         return voxel_feats, img_feats, pts_feats, depth, geom, img_voxel_feats
 
+    def freeze_lidar_encoder(self, frozen=True):
+        """Optional (fine-tuning with a fixed LiDAR branch): the sparse encoder keeps its eval-mode path (folded BN1d running
+        statistics, split-f16 rule-book GEMMs) under ``train()`` and its parameters take no gradient."""
+        self._lidar_frozen = bool(frozen)
+        if self.pts_middle_encoder is not None:
+            for prm in self.pts_middle_encoder.parameters():
+                prm.requires_grad_(not frozen)
+            if frozen:
+                self.pts_middle_encoder.eval()
+        return self
+
     def train(self, mode=True):
-        """``nn.Module.train`` for everything but the frozen sparse LiDAR encoder, which keeps its eval-mode path (an
-        unchanged tools/train.py calls ``model.train()`` on the whole detector)."""
+        """``nn.Module.train`` (an unchanged tools/train.py calls ``model.train()`` on the whole detector); a LiDAR encoder
+        frozen with ``freeze_lidar_encoder()`` stays in eval mode."""
         super().train(mode)
         if mode:
             self._pipe1 = None          # the captured eval-mode graph holds the CURRENT weight packs; training rewrites them
-        from . import lidar
-        enc = getattr(self, "pts_middle_encoder", None)
-        if mode and enc is not None and isinstance(enc, tuple(lidar.MIDDLE_ENCODERS.module_dict.values())):
-            enc.eval()
-            if not getattr(self, "_warned_frozen_lidar", False):
-                self._warned_frozen_lidar = True
-                import warnings
-                warnings.warn("COOCC_Ray: the sparse LiDAR encoder (pts_middle_encoder) is frozen on this path: eval-mode "
-                              "statistics, no gradients (co_occ_amd/lidar.py); the rest of the detector trains")
+        if mode and getattr(self, "_lidar_frozen", False) and getattr(self, "pts_middle_encoder", None) is not None:
+            self.pts_middle_encoder.eval()
         return self
 
     def fuse(self, img_voxel_feats, pts_voxel_feats, search=None):

@@ -30,8 +30,12 @@ FINE_LINEAR_FIRST = __import__("os").environ.get("COOCC_FINE_LINEAR_FIRST", "1")
 # latency than the samplers' own launches at 4+; kept off there)
 FINE_FUSED = int(__import__("os").environ.get("COOCC_FINE_FUSED", "1"))
 # ratio 2 on the split-f16 engine: ONE launch with lanes = points, samples kept in registers, both Linear layers as three f16 MFMAs
-# per k16 step (csrc/fine2_h2.hip, round 5); 0 = the three kernels (fp32-MFMA chain)
-FINE2_H2 = __import__("os").environ.get("COOCC_FINE2_H2", "1") != "0"
+# per k16 step (csrc/fine2_h2.hip, round 5; 0.33 -> 0.17 ms at configs[1]).  OFF by default: with two or more dense graphs in
+# flight the kernel's IMAGE samples of children 6 / 7 (lanes 48..63 of the sampling layout) differ from run to run in a few
+# hundred of 640 k rows (tests/test_gpu_serving.py::test_pipelined_test_loop_equals_per_sample_calls caught it; single-stream
+# runs are bit-stable and pass every parity test).  tools/debug/fine2_concurrent.py reproduces it without the pipeline; what was
+# ruled out is in DESIGN.md 3.2d.  COOCC_FINE2_H2=1 switches it on (the merged occ_pred_conv[0] + Q GEMM below comes with it).
+FINE2_H2 = __import__("os").environ.get("COOCC_FINE2_H2", "0") == "1"
 # occ_pred_conv[0] and the voxel half of fine_mlp[0] (both 128 -> 64 on out_voxel_feats) as one 128 -> 128 GEMM (ReLU on the first
 # 64 columns): one read of the rows and one launch instead of two; needs the strided-Q consumer (fine2_h2)
 MERGED_PRED_Q = __import__("os").environ.get("COOCC_MERGED_PRED_Q", "1") != "0"

@@ -168,6 +168,96 @@ def sparse_conv(feats, Cin, pc, table, relu=True, res=None, out=None, out_rows=N
     return (out, out_h2) if twin else out
 
 
+# ----------------------------------------------------------------------------- training path (round 5)
+# The reference trains this encoder (projects/configs/coocc_nusc/coocc_multi_r50_256x704.py:127-134: norm_cfg SyncBN,
+# requires_grad=True; sparse_lidar_enc.py:17-62 puts a BatchNorm1d behind every sparse convolution).  Under ``train()`` every
+# sparse convolution is a torch.autograd.Function over the same rule books:
+#   forward  y[o]       = sum_t W_t . x[table[t][o]] (+ b)                       row-table GEMM (coocc_conv_fwd, as inference)
+#   dgrad    dx[i]      = sum_t W_t^T . dy[inverse[t][i]]                        the same GEMM over the TRANSPOSED rule book
+#                         (SubMConv3d: inverse[t] = table[26 - t] -- the active set is its own mirror image; SparseConv3d:
+#                         inverse[t][table[t][o]] = o, built once per rule book)
+#   wgrad    dW_t[n][c] = sum_o dy[o][n] . x[table[t][o]][c]                     coocc_conv_wgrad with the forward table
+# BatchNorm1d runs on the [M, C] rows of the ACTIVE voxels with batch statistics (torch's batch_norm: running statistics are
+# updated exactly as nn.BatchNorm1d does), GroupNorm / the dense scatter through the row Functions of autograd.py.
+def _inverse_table(table, n_in):
+    """[taps, Mo] forward rule book (input row of output o for tap t, or -1) -> [taps, n_in]: the output row that reads input
+    i through tap t, or -1 (for a fixed tap the map o -> i is injective)."""
+    taps, Mo = table.shape
+    inv = torch.full((taps, n_in), -1, device=table.device, dtype=_I32)
+    m = table >= 0
+    t_idx = torch.arange(taps, device=table.device).view(-1, 1).expand(taps, Mo)[m]
+    o_idx = torch.arange(Mo, device=table.device, dtype=_I32).view(1, -1).expand(taps, Mo)[m]
+    inv[t_idx, table[m].long()] = o_idx
+    return inv
+
+
+def _table_launch(x2d, in_C, w_packed, out2d, Cout, table, bias=None, tag="sparse"):
+    from .autograd import _conv_launch
+    n_in = x2d.shape[0]
+    _conv_launch(x2d, in_C, w_packed, out2d, Cout, table.shape[0], (1, n_in, 1, 1), (1, out2d.shape[0], 1, 1), 1, 1, 0, None, bias,
+                 None, False, table=table, tag=tag)
+
+
+class SparseConvFn(torch.autograd.Function):
+    """y = sparse_conv(x; W, table) (+ bias): SubMConv3d / SparseConv3d of spconv 2.x on rows, differentiable in x, W, b.
+    ``weight``: [Cout, k, k, k, Cin] (the reference's state_dict layout); x: [n_in, pad4(Cin)]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, table, table_bwd):
+        from .autograd import pack_weights_dev
+        Cout, Cin = weight.shape[0], weight.shape[-1]
+        taps, Mo = table.shape
+        Cp = x.shape[1]
+        w3 = weight.detach().float().reshape(Cout, taps, Cin)
+        if Cp != Cin:
+            w3 = torch.cat([w3, w3.new_zeros(Cout, taps, Cp - Cin)], 2)
+        w3 = w3.contiguous()
+        out = torch.empty(Mo, Cout, device=x.device, dtype=_F32)
+        if Mo:
+            _table_launch(x, Cp, pack_weights_dev(w3, Cout, Cp, taps, 1), out, Cout, table,
+                          bias=bias.detach().float().contiguous() if bias is not None else None, tag="sparse_fwd")
+        ctx.save_for_backward(x, w3, table, table_bwd)
+        ctx.cfg = (Cin, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .autograd import pack_weights_dev, _pad4 as pad4
+        x, w3, table, table_bwd = ctx.saved_tensors
+        Cin, has_bias = ctx.cfg
+        Cout, taps, Cp = w3.shape
+        Mo, n_in = table.shape[1], x.shape[0]
+        dev = x.device
+        dout = dout.float().contiguous()
+        Co4 = pad4(Cout)
+        dacc = dout
+        if Co4 != Cout:
+            dacc = torch.zeros(Mo, Co4, device=dev, dtype=_F32)
+            dacc[:, :Cout] = dout
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros(n_in, Cp, device=dev, dtype=_F32)
+            if Mo and n_in:
+                wp = pack_weights_dev(w3.permute(0, 2, 1).contiguous(), Cout, Cp, taps, 3)        # W'[c][n][t] = w[n][c][t]
+                _table_launch(dacc, Co4, wp, dx, Cp, table_bwd, tag="sparse_dgrad")
+        if ctx.needs_input_grad[1]:
+            dw3 = torch.zeros(Cout, Cp, taps, device=dev, dtype=_F32)
+            if Mo:
+                ws = workspace(dev)
+                with _lib.TIMER.region("k_wgrad<sparse table>", 2.0 * Mo * Cp * Cout * taps):
+                    call("coocc_conv_wgrad", ptr(x), n_in, Cp, ptr(dacc), Co4, ptr(table), Mo, Cp, Cout, taps, ptr(dw3), 0, ptr(ws),
+                         ws.numel())
+            k = round(taps ** (1.0 / 3))
+            dw = dw3[:, :Cin, :].permute(0, 2, 1).reshape(Cout, k, k, k, Cin).contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dout.sum(0)
+        return dx, dw, db, None, None
+
+
+def sparse_conv_train(x, conv, table, table_bwd):
+    return SparseConvFn.apply(x.contiguous(), conv.weight, conv.bias, table, table_bwd)
+
+
 class _SpConv(nn.Module):
     """Parameter holder with spconv 2.x's weight layout [Cout, k, k, k, Cin] (key ``weight``)."""
 
@@ -245,20 +335,62 @@ class _SparseEncoderBase(nn.Module):
             return d
         return self._packs.get_modules((self,), build)
 
+    def _forward_train(self, voxel_features, coors):
+        """sparse_lidar_enc.py:125-176 with gradients: BatchNorm1d on the active rows with BATCH statistics (as
+        ``model.train()`` does upstream; eval-mode BN under ``eval()`` + grad), every convolution a ``SparseConvFn``."""
+        from . import autograd as ag
+        import torch.nn.functional as F
+        dev = voxel_features.device
+        M, Cin = voxel_features.shape
+        cin_p = _pad4(Cin)
+        x = voxel_features.float()
+        if cin_p != Cin:
+            x = torch.cat([x, x.new_zeros(M, cin_p - Cin)], 1)
+        cur = SparseRows(None, coors, self.sparse_shape_xyz[::-1])
+
+        def subm(x_, conv, cur_, key):
+            tb = cur_.subm_table(key)
+            kb = key + "/bwd"
+            if kb not in cur_.books:
+                cur_.books[kb] = tb.flip(0).contiguous()             # the voxel at -offset: tap 26 - t of the same book
+            return sparse_conv_train(x_, conv, tb, cur_.books[kb])
+
+        def bn(x_, m):
+            return F.batch_norm(x_, m.running_mean, m.running_var, m.weight, m.bias, self.training, m.momentum if m.momentum is not None else 0.1, m.eps)
+
+        def gn(x_, m):
+            return ag.GroupNormRowsFn.apply(x_.contiguous(), m.weight, m.bias, m.num_groups, float(m.eps), True)
+
+        f = gn(subm(x, self.conv_input[0], cur, "in"), self.conv_input[1])
+        for si, st in enumerate((self.conv1, self.conv2, self.conv3)):
+            for m in st:
+                if isinstance(m, _PostActBlock):
+                    coors_o, shape_o, table = cur.downsample(3, 2, 1)
+                    f = torch.relu(bn(sparse_conv_train(f, m[0], table, _inverse_table(table, f.shape[0])), m[1]))
+                    cur = SparseRows(None, coors_o, shape_o)
+                else:
+                    key = "res%d" % si
+                    h = torch.relu(bn(subm(f, m.net[0], cur, key), m.net[1]))
+                    f = torch.relu(bn(subm(h, m.net[3], cur, key), m.net[4]) + f)
+        f = gn(subm(f, self.conv_out[0], cur, "out"), self.conv_out[1])
+        cur.feats = f
+        D, H, W = cur.shape
+        rows = ((cur.coors[:, 2].long() * H + cur.coors[:, 1]) * D + cur.coors[:, 0]).int().contiguous()   # (x*H + y)*D + z
+        dense = ag.ScatterRowsFn.apply(f, rows, W * H * D)
+        vol = Rows(dense, 1, W, H, D, f.shape[1])
+        return {'x': vol.as_ncdhw(), 'pts_feats': [cur]}
+
     def forward(self, voxel_features, coors, batch_size=1):
         """voxel_features [M,Cin], coors [M,3] (z,y,x) or [M,4] (b,z,y,x) -> dict(x=[1,C,W,H,D] dense volume (channels-last
-        memory), pts_feats=[SparseRows])."""
+        memory), pts_feats=[SparseRows]).  ``train()``: the differentiable path (``_forward_train``)."""
         if not voxel_features.is_cuda:
             raise _lib.CooccError("the sparse LiDAR encoder runs on the GPU only (no CPU fallback)")
-        if self.training:
-            # BN1d is folded from its running statistics and the rule-book GEMMs carry no autograd: this is the
-            # inference path.  The reference trains this encoder (batch statistics); refuse rather than return eval numbers.
-            raise RuntimeError("%s: only the eval-mode path is implemented (folded BN1d, no autograd); call .eval() -- "
-                               "training the LiDAR encoder is outside the hot path (SURVEY.md 8f rank 3)" % type(self).__name__)
         if coors.shape[1] == 4:
             assert int(batch_size) == 1, "batch size 1 (hard-coded upstream, sparse_lidar_enc.py:109)"
             coors = coors[:, 1:]
         coors = coors.int().contiguous()
+        if self.training:
+            return self._forward_train(voxel_features, coors)
         p = self._packed()
         dev = voxel_features.device
         M, Cin = voxel_features.shape

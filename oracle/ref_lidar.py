@@ -72,7 +72,7 @@ def vfe_mean(voxels, num_points, num_features):
 
 def _to_dense(feats, coors, shape):
     D, H, W = shape
-    vol = torch.zeros(1, feats.shape[1], D, H, W)
+    vol = torch.zeros(1, feats.shape[1], D, H, W, dtype=feats.dtype)
     mask = torch.zeros(1, 1, D, H, W, dtype=torch.bool)
     z, y, x = coors[:, 0].long(), coors[:, 1].long(), coors[:, 2].long()
     vol[0, :, z, y, x] = feats.t()
@@ -85,8 +85,14 @@ def _w(sd, key):
     return sd[key].permute(0, 4, 1, 2, 3).contiguous()
 
 
-def _bn1d(x, mask, sd, prefix, eps=1e-5):
+def _bn1d(x, mask, sd, prefix, eps=1e-5, train=False):
+    """BatchNorm1d over the [N, C] rows of the active voxels (sparse_lidar_enc.py:17-62 applies it to ``x.features``).
+    ``train``: batch statistics over the active rows (biased variance), as ``model.train()`` does upstream."""
     m, v = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    if train:
+        n = mask.sum()
+        m = (x * mask).sum(dim=(0, 2, 3, 4)) / n
+        v = (((x - m.view(1, -1, 1, 1, 1)) * mask) ** 2).sum(dim=(0, 2, 3, 4)) / n
     y = (x - m.view(1, -1, 1, 1, 1)) / torch.sqrt(v.view(1, -1, 1, 1, 1) + eps) * sd[prefix + ".weight"].view(1, -1, 1, 1, 1) + \
         sd[prefix + ".bias"].view(1, -1, 1, 1, 1)
     return y * mask
@@ -119,9 +125,11 @@ def sparse_conv3d(feats, coors, shape_zyx, weight_2x, k=3, s=2, p=1):
     return y[0][:, idx[:, 0], idx[:, 1], idx[:, 2]].t(), idx, list(y.shape[2:])
 
 
-def sparse_encoder_forward(sd, feats, coors, shape_zyx, variant="8x", bn_eps=1e-5):
-    """-> dense [1, C, W, H, D] (= x.dense().permute(0,1,4,3,2)) and the final active mask."""
-    x, mask = _to_dense(torch.as_tensor(feats).float(), torch.as_tensor(coors), shape_zyx)
+def sparse_encoder_forward(sd, feats, coors, shape_zyx, variant="8x", bn_eps=1e-5, train_bn=False):
+    """-> dense [1, C, W, H, D] (= x.dense().permute(0,1,4,3,2)) and the final active mask.  ``train_bn``: BatchNorm1d with batch
+    statistics (training mode); every operation is a torch op, so the result is differentiable in ``sd`` and ``feats``.
+    Evaluated in the dtype of ``sd`` (float64 state dict = the fp64 anchor of the training-mode test)."""
+    x, mask = _to_dense(torch.as_tensor(feats).to(sd["conv_input.0.weight"].dtype), torch.as_tensor(coors), shape_zyx)
     subm = lambda x_, key, bias=None: F.conv3d(x_, _w(sd, key), sd.get(bias) if bias else None, padding=1) * mask
     x = F.relu(_gn_active(subm(x, "conv_input.0.weight", "conv_input.0.bias"), mask, sd, "conv_input.1")) * mask
     for stage in ("conv1", "conv2", "conv3"):
@@ -130,12 +138,12 @@ def sparse_encoder_forward(sd, feats, coors, shape_zyx, variant="8x", bn_eps=1e-
             newmask = F.max_pool3d(mask.float(), 3, 2, 1) > 0
             x = F.conv3d(x, _w(sd, stage + ".0.0.weight"), stride=2, padding=1)
             mask = newmask
-            x = F.relu(_bn1d(x, mask, sd, stage + ".0.1", bn_eps)) * mask
+            x = F.relu(_bn1d(x, mask, sd, stage + ".0.1", bn_eps, train_bn)) * mask
             i = 1
         for b in (i, i + 1):                                   # two SparseBasicBlocks
             p = "%s.%d.net." % (stage, b)
-            h = F.relu(_bn1d(F.conv3d(x, _w(sd, p + "0.weight"), padding=1) * mask, mask, sd, p + "1", bn_eps)) * mask
-            h = _bn1d(F.conv3d(h, _w(sd, p + "3.weight"), padding=1) * mask, mask, sd, p + "4", bn_eps)
+            h = F.relu(_bn1d(F.conv3d(x, _w(sd, p + "0.weight"), padding=1) * mask, mask, sd, p + "1", bn_eps, train_bn)) * mask
+            h = _bn1d(F.conv3d(h, _w(sd, p + "3.weight"), padding=1) * mask, mask, sd, p + "4", bn_eps, train_bn)
             x = F.relu(h + x) * mask
     x = F.conv3d(x, _w(sd, "conv_out.0.weight"), sd.get("conv_out.0.bias"), padding=1) * mask
     x = F.relu(_gn_active(x, mask, sd, "conv_out.1")) * mask

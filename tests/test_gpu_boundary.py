@@ -162,14 +162,19 @@ def out_sc_coarse(model, out, gt):
 def test_forward_train_with_the_reference_call_signature(dev):
     """tools/train.py path: ``model(return_loss=True, points=, img_metas=, img_inputs=, gt_occ=)`` -> the reference's loss
     dict (coocc_ray.py:339-434); training-mode BN (batch statistics, running stats updated); gradients reach every
-    hot-path parameter and flow back into the upstream encoders."""
+    hot-path parameter -- the sparse LiDAR encoder included (round 5: it trains like upstream, batch-statistics BN1d) -- and
+    flow back into the upstream encoders; ``freeze_lidar_encoder()`` keeps the LiDAR branch fixed."""
     model = _full_model(dev)
-    with pytest.warns(UserWarning, match="frozen"):
-        model.train()                        # what an unchanged tools/train.py does: the frozen LiDAR encoder stays in eval mode
-    assert not model.pts_middle_encoder.training and model.semantic_encoder.training
-    assert all(not prm.requires_grad for prm in model.pts_middle_encoder.parameters())
+    model.freeze_lidar_encoder()
+    model.train()
+    assert not model.pts_middle_encoder.training and all(not prm.requires_grad for prm in model.pts_middle_encoder.parameters())
+    model.freeze_lidar_encoder(False)
+    model.train()                        # what an unchanged tools/train.py does
+    assert model.pts_middle_encoder.training and model.semantic_encoder.training
+    assert all(prm.requires_grad for prm in model.pts_middle_encoder.parameters())
     img_inputs, points, gt = _sample(dev)
     rm0 = model.semantic_encoder.layers[0][0].bn1.running_mean.clone()
+    lrm0 = model.pts_middle_encoder.conv1[0][1].running_mean.clone()
     losses = model(return_loss=True, points=points, img_metas=None, img_inputs=img_inputs, gt_occ=gt,
                    generator=torch.Generator(device=dev).manual_seed(0))
     want = {"loss_depth", "loss_depth_render", "loss_rgb"} | {"loss_voxel_%s_%s" % (a, b) for a in ("ce", "sem_scal", "geo_scal", "lovasz")
@@ -177,9 +182,11 @@ def test_forward_train_with_the_reference_call_signature(dev):
     assert set(losses) == want, sorted(set(losses) ^ want)
     assert all(torch.isfinite(v).all() for v in losses.values())
     sum(losses.values()).backward()
-    missing = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None and not n.startswith("pts_")
+    missing = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None
                and "frustum" not in n and n.split(".")[-1] not in ("dx", "bx", "nx")]
     assert not missing, missing[:8]
+    assert float(model.pts_middle_encoder.conv_input[0].weight.grad.abs().sum()) > 0     # ... and the first sparse convolution
+    assert not torch.equal(lrm0, model.pts_middle_encoder.conv1[0][1].running_mean)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     assert float(model.img_backbone.conv.weight.grad.abs().sum()) > 0          # lift (x) splat backward reaches the image branch
     assert float(model.img_view_transformer.depth_net.conv.weight.grad.abs().sum()) > 0

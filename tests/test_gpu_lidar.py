@@ -127,3 +127,118 @@ def test_sparse_layers_match_hand_computed_fixture(dev):
     assert np.array_equal(coors_o.cpu().numpy(), np.asarray(fx["sparse_k3_s2_p1"]["coors_zyx"]))
     got = L.sparse_conv(x, 4, pc, table, relu=False)
     assert np.array_equal(got.cpu().numpy(), np.asarray(fx["sparse_k3_s2_p1"]["out"], np.float32))
+
+
+def _grad_close(got, want, what, tol=2e-4):
+    """Gradient tensors: error relative to the tensor's own largest entry (gradients of this encoder span 1e-6 .. 1e2)."""
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    sc = float(want.abs().max())
+    err = float((got - want).abs().max())
+    assert err <= tol * max(sc, 1e-12) + 1e-9, "%s: max |d| %.3e of scale %.3e" % (what, err, sc)
+
+
+@pytest.mark.parametrize("kind", ["subm", "down", "subm_4_to_16"])
+def test_sparse_conv_fn_gradients_vs_dense_autograd(dev, kind):
+    """``SparseConvFn`` (round 5: the LiDAR encoder trains): forward, dgrad through the transposed rule book and wgrad through
+    the forward rule book of one SubMConv3d / SparseConv3d(k3, s2, p1), against torch autograd through the oracle's masked-dense
+    restatement (oracle/ref_lidar.py)."""
+    g = np.random.default_rng(5)
+    W, H, D = 14, 11, 9
+    M, Cin, Cout = 400, 8, 20
+    if kind == "subm_4_to_16":            # conv_input's shape: the dgrad GEMM has 4 output columns
+        kind, Cin, Cout = "subm", 4, 16
+    lin = g.choice(W * H * D, M, replace=False)
+    coors = np.stack([lin // (W * H), (lin // W) % H, lin % W], 1).astype(np.int32)
+    feats = torch.from_numpy(g.standard_normal((M, Cin)).astype(np.float32))
+    w = torch.from_numpy((g.standard_normal((Cout, 3, 3, 3, Cin)) * 0.1).astype(np.float32))
+    b = torch.from_numpy(g.standard_normal(Cout).astype(np.float32))
+    # oracle
+    fo, wo, bo = feats.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    if kind == "subm":
+        want = ref_lidar.subm_conv3d(fo, coors, (D, H, W), wo, bo)
+        want_coors = torch.from_numpy(coors).long()
+    else:
+        want, want_coors, _ = ref_lidar.sparse_conv3d(fo, coors, (D, H, W), wo)
+        want = want + bo
+    # HIP
+    fx, wx, bx = feats.to(dev).requires_grad_(), w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    conv = L._SpConv(Cin, Cout, 3, bias=True).to(dev)
+    cur = L.SparseRows(None, torch.from_numpy(coors).to(dev), (D, H, W))
+    if kind == "subm":
+        tb = cur.subm_table("k")
+        got = L.SparseConvFn.apply(fx, wx, bx, tb, tb.flip(0).contiguous())
+        got_coors = torch.from_numpy(coors).long()
+    else:
+        co, shape_o, tb = cur.downsample(3, 2, 1)
+        got = L.SparseConvFn.apply(fx, wx, bx, tb, L._inverse_table(tb, M))
+        got_coors = co.cpu().long()
+    # rows may come in another order: compare through the coordinates
+    def keyed(rows, cc):
+        k = (cc[:, 0] * 1000 + cc[:, 1]) * 1000 + cc[:, 2]
+        return rows[torch.argsort(k)]
+    assert got.shape == want.shape
+    assert_close(keyed(got.detach().cpu(), got_coors), keyed(want.detach(), want_coors), what="sparse conv forward (%s)" % kind)
+    up = torch.from_numpy(g.standard_normal(tuple(want.shape)).astype(np.float32))
+    # the same upstream gradient per output voxel (match rows by coordinate)
+    kw = (want_coors[:, 0] * 1000 + want_coors[:, 1]) * 1000 + want_coors[:, 2]
+    kg = (got_coors[:, 0] * 1000 + got_coors[:, 1]) * 1000 + got_coors[:, 2]
+    pos = {int(k): i for i, k in enumerate(kw.tolist())}
+    perm = torch.tensor([pos[int(k)] for k in kg.tolist()])
+    (want * up).sum().backward()
+    (got * up[perm].to(dev)).sum().backward()
+    _grad_close(fx.grad, fo.grad, "d input")
+    _grad_close(wx.grad, wo.grad, "d weight")
+    _grad_close(bx.grad, bo.grad, "d bias")
+
+
+@pytest.mark.parametrize("variant", ["8x", "4x"])
+def test_sparse_encoder_trains_forward_and_backward_vs_oracle(dev, variant):
+    """``SparseLiDAREnc{8x,4x}`` under ``train()`` (sparse_lidar_enc.py:125-176 as ``tools/train.py`` runs it): BatchNorm1d with
+    the batch statistics of the active rows, running statistics updated, gradients of every parameter and of the input features
+    against torch autograd through the oracle's dense restatement with training-mode BN."""
+    g = np.random.default_rng(7)
+    shape_xyz = (32, 24, 16)
+    W, H, D = shape_xyz
+    M = 900
+    lin = g.choice(W * H * D, M, replace=False)
+    coors = np.stack([lin // (W * H), (lin // W) % H, lin % W], 1).astype(np.int32)
+    feats = g.standard_normal((M, 4)).astype(np.float32)
+    cls = L.SparseLiDAREnc8x if variant == "8x" else L.SparseLiDAREnc4x
+    enc, sd = _seeded_encoder(cls, shape_xyz, 17, dev)
+    enc.train()
+    rm0 = enc.conv2[0][1].running_mean.clone()
+    fx = torch.from_numpy(feats).to(dev).requires_grad_()
+    out = enc(fx, torch.from_numpy(coors).to(dev), 1)["x"]
+    osd = {k: (v.cpu().clone().requires_grad_() if v.dtype.is_floating_point and "running" not in k else v.cpu().clone()) for k, v in sd.items()}
+    fo = torch.from_numpy(feats).requires_grad_()
+    want, mask = ref_lidar.sparse_encoder_forward(osd, fo, coors, (D, H, W), variant, train_bn=True)
+    assert tuple(out.shape) == tuple(want.shape)
+    # batch-statistics BN over the few hundred active rows of the deep stages amplifies fp32 rounding (the fp32 oracle itself is
+    # 1e-4 .. 1e-3 of the scale away from its fp64 evaluation here): judged against the fp64 anchor, as the fine branch is
+    sd64 = {k: (v.cpu().double() if v.dtype.is_floating_point else v.cpu()) for k, v in sd.items()}
+    with torch.no_grad():
+        w64, _ = ref_lidar.sparse_encoder_forward(sd64, torch.from_numpy(feats).double(), coors, (D, H, W), variant, train_bn=True)
+    sc = max(1.0, float(w64.abs().max()))
+    e_hip, e_o32 = float((out.detach().cpu().double() - w64).abs().max()) / sc, float((want.detach().double() - w64).abs().max()) / sc
+    print("lidar encoder (train, %s): HIP vs fp64 %.2e, fp32 oracle vs fp64 %.2e" % (variant, e_hip, e_o32))
+    assert e_hip <= max(3.0 * e_o32, 1e-4)
+    assert not torch.equal(rm0, enc.conv2[0][1].running_mean)            # running statistics move as nn.BatchNorm1d moves them
+    up = torch.from_numpy(g.standard_normal(tuple(want.shape)).astype(np.float32))
+    (want * up).sum().backward()
+    (out * up.to(dev)).sum().backward()
+    bad, n = [], 0
+    for name, got_g, want_g in [("d voxel features", fx.grad, fo.grad)] + [(k, q.grad, osd[k].grad) for k, q in enc.named_parameters()]:
+        assert got_g is not None, name
+        try:
+            _grad_close(got_g, want_g, name, tol=1e-3)
+        except AssertionError as e:
+            bad.append(str(e))
+        n += 1
+    assert not bad, "%d of %d gradients off:\n%s" % (len(bad), n, "\n".join(bad[:12]))
+    assert n >= 40
+    # eval() afterwards is the inference path again (folded running statistics, no autograd)
+    enc.eval()
+    with torch.no_grad():
+        ev = enc(torch.from_numpy(feats).to(dev), torch.from_numpy(coors).to(dev), 1)["x"]
+    assert not ev.requires_grad and tuple(ev.shape) == tuple(want.shape)

@@ -118,9 +118,13 @@ def test_geometry_and_pooling_vs_golden(dev, golden):
     assert_close(pooled[:, nz[:, 0], nz[:, 1], nz[:, 2]].t(), g["pooled_nz_val"], tol=1e-5, what="pooled")
 
 
-def test_fused_lift_splat_equals_materialised_volume(dev):
-    """lift (x) splat without the lifted tensor, bit-equal to the oracle pooling the
-    materialised volume (LSSVoxel.py:135-145)."""
+def test_fused_lift_splat_equals_materialised_volume(dev, monkeypatch):
+    """lift (x) splat without the lifted tensor (LSSVoxel.py:135-145).  The reference's order inside a voxel is
+    unspecified (bev_pool.py:92: unstable argsort), so the contract is determinism + fp32 rounding of ANY order:
+    * the ray-segment form (default since round 5: consecutive depth bins of a pixel's ray in one voxel share one weight, a
+      voxel sums its segments in pixel-major order) is within a few ulp of the oracle pooling the materialised volume in its
+      stable order, bit-equal from run to run, and bit-equal between the geometry tensor and the in-kernel geometry;
+    * ``COOCC_POOL_SEG=0`` (ascending point id, one accumulator) is still bit-equal to the oracle."""
     c = cases.POOL_CASE
     rig = synth.camera_rig(c["ncam"], c["input_size"], seed=c["seed"])
     vt = pkg.ViewTransformerLiftSplatShootVoxel(grid_config=c["grid_config"], data_config=dict(input_size=c["input_size"]),
@@ -134,15 +138,82 @@ def test_fused_lift_splat_equals_materialised_volume(dev):
     volume = (depth.unsqueeze(1) * feat.unsqueeze(2)).view(1, N, C, D, H, W).permute(0, 1, 3, 4, 5, 2)
     dx, bx, nx = ref_cpu.gen_dx_bx(c["grid_config"]["xbound"], c["grid_config"]["ybound"], c["grid_config"]["zbound"])
     want = ref_cpu.voxel_pooling(geom, volume, dx, bx, nx)
+    want64 = ref_cpu.voxel_pooling(geom, volume.double(), dx, bx, nx)
+    monkeypatch.setenv("COOCC_POOL_SEG", "0")
     got = vt.lift_splat(depth.to(dev), feat.to(dev), geom.to(dev))
     assert tuple(got.shape) == tuple(want.shape)
     assert torch.equal(got.cpu(), want)
+    monkeypatch.delenv("COOCC_POOL_SEG")
+    seg = vt.lift_splat(depth.to(dev), feat.to(dev), geom.to(dev)).clone()
+    again = vt.lift_splat(depth.to(dev), feat.to(dev), geom.to(dev))
+    assert torch.equal(seg, again)                                   # atomic slots arrive in another order: same bits
+    assert torch.equal(seg.cpu() != 0, want != 0)                    # the same voxels are hit
+    sc = float(want.abs().max())
+    e_seg, e_ref = float((seg.cpu().double() - want64).abs().max()), float((want.double() - want64).abs().max())
+    print("lift_splat: max |segment form - fp64| %.2e, |oracle fp32 - fp64| %.2e, scale %.2f" % (e_seg, e_ref, sc))
+    assert e_seg <= max(2.0 * e_ref, 1e-6 * sc)                      # no further from fp64 than twice the fp32 oracle itself
+    assert_close(seg.cpu(), want, 1e-5, "lift_splat (segments)")
     # geometry in-kernel == our own get_geometry tensor fed to the same splat, bit for bit
     cams = tuple(rig[k].to(dev) for k in ("rots", "trans", "intrins", "post_rots", "post_trans", "bda"))
     via_tensor = vt.lift_splat(depth.to(dev), feat.to(dev), vt.get_geometry(*cams))
     in_kernel = vt.lift_splat(depth.to(dev), feat.to(dev), cams=cams)
     assert torch.equal(via_tensor, in_kernel)
     assert_close(in_kernel.cpu(), want, 1e-4, "lift_splat_cams")
+
+
+@pytest.mark.parametrize("case", ["ray_down_one_column", "many_pixels_one_voxel", "short_rays", "groups_of_16_c128", "groups_of_16_c64"])
+def test_segment_pooling_long_runs_and_long_voxels(dev, monkeypatch, case):
+    """The ray-segment pooling's edge cases, against the ascending-point-id form (which is bit-equal to the oracle):
+    a ray whose 100 depth bins all fall into ONE voxel (runs longer than a wave: split at the wave boundary), a voxel that
+    receives several hundred / several thousand segments (the workgroup path with four partial sums; the medium path), and
+    D < 64 (a wave spans several pixels), and the 16-lane-group form of the sums (C = 128 / 64: four voxels per wave, voxels with
+    more than 16 segments fall back to the whole-wave code in the same launch)."""
+    from co_occ_amd._lib import call, ptr, host_f32
+    from co_occ_amd.ops import _pool_workspace
+    rng = np.random.default_rng(3)
+    if case == "ray_down_one_column":
+        N, D, H, W, C, grid = 1, 100, 4, 5, 8, (3, 3, 2)
+    elif case == "many_pixels_one_voxel":
+        N, D, H, W, C, grid = 2, 70, 40, 50, 128, (2, 2, 1)
+    elif case.startswith("groups_of_16"):       # four voxels per wave: 0 .. ~40 segments per voxel, some groups sit the pass out
+        N, D, H, W, C, grid = 2, 20, 12, 14, (128 if case.endswith("c128") else 64), (12, 10, 4)
+    else:
+        N, D, H, W, C, grid = 3, 9, 7, 11, 132, (6, 5, 3)
+    X, Y, Z = grid
+    npts = N * D * H * W
+    geom = rng.uniform(-0.4, max(grid) + 0.4, (npts, 3)).astype(np.float32)
+    if case == "ray_down_one_column":
+        geom = np.broadcast_to(rng.uniform(0.1, 2.9, (N, 1, H, W, 3)), (N, D, H, W, 3)).reshape(npts, 3).astype(np.float32).copy()
+    if case == "many_pixels_one_voxel":
+        geom[:, 2] = 0.5
+        geom[: npts // 2] = np.array([0.5, 0.5, 0.5], np.float32) + rng.uniform(-0.3, 0.3, (npts // 2, 3)).astype(np.float32)
+    depth = torch.from_numpy(rng.uniform(0, 1, (N, D, H, W)).astype(np.float32)).to(dev)
+    feat = torch.from_numpy(rng.standard_normal((N * H * W, C)).astype(np.float32)).to(dev)
+    g = torch.from_numpy(geom).to(dev)
+    lo = host_f32([0, 0, 0, 1, 1, 1])
+    outs = {}
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("COOCC_POOL_SEG", mode)
+        out = torch.full((X * Y * Z, C), 7.0, device=dev)
+        ws = _pool_workspace(dev, npts, X * Y * Z)
+        call("coocc_lift_splat", ptr(depth), ptr(feat), ptr(g), N, D, H, W, C, npts, lo, 1, X, Y, Z, ptr(out), C, ptr(ws), ws.numel(), 0)
+        outs.setdefault(mode, []).append(out.clone())
+    a, (b, b2) = outs["0"][0], outs["1"]
+    assert torch.equal(b, b2)
+    # fp64 sums of the same products: the segment form may not be further from them than the point-order form (which is
+    # bit-equal to the oracle) by more than a small factor -- a voxel of this case receives 1.4e5 points
+    gi = torch.from_numpy(geom).double()
+    idx = gi.long()                                                   # truncation toward zero, as the kernel's
+    kept = ((gi > -1) & (idx >= 0) & (idx < torch.tensor([X, Y, Z]))).all(1)
+    lin = (idx[:, 0] * Y + idx[:, 1]) * Z + idx[:, 2]
+    pix = torch.arange(npts) // (D * H * W) * (H * W) + torch.arange(npts) % (H * W)
+    prod = depth.cpu().double().reshape(-1, 1) * feat.cpu().double()[pix]
+    ref = torch.zeros(X * Y * Z, C, dtype=torch.float64).index_add_(0, lin[kept], prod[kept])
+    sc = float(ref.abs().max())
+    e_pt, e_seg = float((a.cpu().double() - ref).abs().max()), float((b.cpu().double() - ref).abs().max())
+    print(case, "max |point order - fp64| %.2e, |segment form - fp64| %.2e of scale %.2f" % (e_pt, e_seg, sc))
+    assert e_seg <= max(3.0 * e_pt, 2e-6 * sc)
+    assert torch.equal(a != 0, b != 0)
 
 
 def test_bev_pool_op_and_ext_vs_oracle(dev):

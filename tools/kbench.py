@@ -196,22 +196,26 @@ def bench_pool():
                 return vt.voxel_pooling(geom, vol.permute(0, 1, 3, 4, 5, 2))
             t_m = timeit(materialised, n=5)
             a, b = materialised(), vt.lift_splat(depth, feat, geom)
-            line += "  | materialised volume + voxel_pool %.3f ms, equal=%s" % (t_m, bool(torch.equal(a, b)))
+            b2 = vt.lift_splat(depth, feat, geom)
+            line += "  | materialised volume + voxel_pool (ascending point id) %.3f ms, max |diff| %.1e of %.1f, run-to-run equal=%s" % (
+                t_m, float((a - b).abs().max()), float(a.abs().max()), bool(torch.equal(b, b2)))
         print(line)
 
 
 def bench_poolprof():
-    """lift_splat only (for rocprofv3 --kernel-trace --stats): r101, geometry tensor prebuilt."""
+    """lift_splat only (for rocprofv3 --kernel-trace --stats / --pmc): COOCC_POOLPROF = r50 | r101 (default), geometry in-kernel
+    (the form the step runs)."""
+    which = os.environ.get("COOCC_POOLPROF", "r101")
     cfg = dict(xbound=[-50, 50, 1.0], ybound=[-50, 50, 1.0], zbound=[-5.0, 3.0, 1.0], dbound=[2.0, 58.0, 0.5])
     g = torch.Generator().manual_seed(4)
-    N, D, C, size, (fH, fW) = 6, 112, 128, (896, 1600), (56, 100)
+    N, D, C = 6, 112, 128
+    size, (fH, fW) = ((256, 704), (16, 44)) if which == "r50" else ((896, 1600), (56, 100))
     rig = synth.camera_rig(N, size, seed=7)
     vt = pkg.ViewTransformerLiftSplatShootVoxel(grid_config=cfg, data_config=dict(input_size=size), downsample=16, numC_Trans=C).to(dev)
     cams = tuple(rig[k].to(dev) for k in ("rots", "trans", "intrins", "post_rots", "post_trans", "bda"))
     depth = torch.softmax(torch.randn(N, D, fH, fW, generator=g), 1).to(dev)
     feat = torch.randn(N, C, fH, fW, generator=g).to(dev)
-    geom = vt.get_geometry(*cams)
-    print("lift_splat r101 %.3f ms" % timeit(lambda: vt.lift_splat(depth, feat, geom), n=10))
+    print("lift_splat %s %.3f ms" % (which, timeit(lambda: vt.lift_splat(depth, feat, cams=cams), n=10)))
 
 
 def bench_bwd():
