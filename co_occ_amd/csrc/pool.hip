@@ -562,7 +562,6 @@ __global__ __launch_bounds__(256) void k_pool_sum_csr(const float* __restrict__ 
 //                            order -- the same bits on every run
 constexpr int SEG_SLOT_BITS = 24;          // slot inside the voxel (< 16.7 M segments per voxel); bits 24..30: segment length (<= 64)
 constexpr int SEG_SLOT_MASK = (1 << SEG_SLOT_BITS) - 1;
-constexpr int SEG_LONG_CAP = 2048;         // segments a workgroup sorts in LDS (r101: <= ~1700 next to a camera); beyond: selection path
 
 // A workgroup owns a STRIP of SEG_STRIP consecutive pixels of one camera: the strip's depth values [D][SEG_STRIP] are staged in
 // LDS with coalesced 128-byte rows (the depth tensor is [N, D, H, W]: walking a pixel's ray reads one value per 4 H W bytes --
@@ -571,12 +570,32 @@ constexpr int SEG_LONG_CAP = 2048;         // segments a workgroup sorts in LDS 
 // a contiguous eighth of them.  Geometry tensor mode: the three coordinates of the strip are staged the same way.
 constexpr int SEG_STRIP = 8;               // 8 pixels x 112 bins = 3.5 passes of the workgroup; 32-byte runs per depth row (the neighbouring strips run on the same XCD)
 constexpr int SEG_HASH_BITS = 11, SEG_HASH = 1 << SEG_HASH_BITS;     // LDS hash cells per round of 1024 points
+constexpr int SEG_LDS_ENTRIES = 2048;      // (row, weight) pairs of a long voxel kept in LDS between its two passes
 constexpr int SEG_DMAX = 256;              // depth bins staged per strip (32 KB of LDS + padding); more: the ascending-point-id form
+
+// rowmax[row] = max |x[row][:]| by the 32 lanes of a half-wave
+__device__ __forceinline__ void row_absmax(const float* __restrict__ x, int C, size_t row, int l32, float* __restrict__ rowmax) {
+  const float* r = x + row * (size_t)C;
+  float m = 0.f;
+  for (int c = l32 * 4; c < C; c += 128) {
+    const f32x4 v = *(const f32x4*)(r + c);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+  for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (l32 == 0) rowmax[row] = m;
+}
+
+// the same for every row, for the reuse form (cached binning, this frame's context rows)
+__global__ __launch_bounds__(256) void k_row_absmax(const float* __restrict__ x, int C, int nrows, float* __restrict__ rowmax) {
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row < nrows) row_absmax(x, C, (size_t)row, threadIdx.x & 31, rowmax);
+}
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_seg_hist(KeySrc a, const float* __restrict__ depth, int npts, int X, int Y, int Z, int nvox,
                                                    int strips_per_cam, int nstrips, int stage_geom, uint32_t* __restrict__ keys,
-                                                   int32_t* __restrict__ count, int32_t* __restrict__ slot, float* __restrict__ wts) {
+                                                   int32_t* __restrict__ count, int32_t* __restrict__ slot, float* __restrict__ wts,
+                                                   const float* __restrict__ feat, int C, float* __restrict__ rowmax) {
   extern __shared__ float seg_lds[];       // [D][SEG_STRIP + 1] depth (+ 3 more planes of the same shape in geometry-tensor mode)
   const int tid = threadIdx.x, lane = tid & 63;
   const int per = (nstrips + 7) >> 3;
@@ -599,6 +618,8 @@ __global__ __launch_bounds__(256) void k_seg_hist(KeySrc a, const float* __restr
       }
     }
   }
+  // max |context row| of the strip's pixels: the long voxels' exact sums take their scale from it (seg_long)
+  for (int j = tid >> 5; j < np; j += 8) row_absmax(feat, C, (size_t)n * HW + hw0 + j, tid & 31, rowmax);
   __syncthreads();
   const int total = np * D;
   const size_t t0 = ((size_t)n * HW + hw0) * D;                   // pixel-major index of the strip's first point
@@ -861,114 +882,109 @@ __device__ __forceinline__ void seg_rows16(const float* __restrict__ x, const fl
   }
 }
 
-// n > POOL_MEDIUM: one workgroup per voxel.  (id, CSR position) pairs are bitonic-sorted in LDS as 64-bit keys, decoded once
-// (row, weight), and the four waves each sum a quarter of the sorted list (fixed split points: ceil(n / 4)); the four partial
-// rows are added in wave order.
+// n > POOL_MEDIUM: one workgroup per voxel, NO sort.  The long voxels sit next to the cameras (up to 2600 points / 1700 segments
+// at r101) and ordering their ids -- a 66-stage bitonic network -- was most of the launch (r50: 40 us, r101: 130 us, whatever
+// the shape of the sums).  Instead their sums are made EXACT, and therefore independent of order and of how the list is split:
+//   * bound = max over the voxel's segments of weight * rowmax[row]   (rowmax[pixel] = max |context row|, from k_seg_hist; a
+//     max is order-free), E = its binary exponent, quantum q = 2^(E - bits), bits = 50 - ceil(log2 n);
+//   * every product w * x (rounded to fp32, the input of the short voxels' FMA chain) is snapped to a multiple of q
+//     ((p + 1.5 * 2^52 q) - 1.5 * 2^52 q in fp64) and added in fp64: all partial sums are multiples of q below 2^52 q, so every
+//     addition is exact -- 16 quarter-waves sum sixteenths of the UNSORTED list, their partial rows are added in LDS, one
+//     rounding to fp32 at the end.  The snap costs at most q / 2 = 2^-40 of the bound per term at n = 2048 -- four orders of
+//     magnitude below one fp32 rounding of the result.
+// Same bits on every run for any arrival order of the atomic slots; no cap on n (the list is walked from global memory).
 template <bool REUSE>
 __device__ __forceinline__ void seg_long(const float* __restrict__ x, const float* __restrict__ depth, const float* __restrict__ wseg,
                                          const int32_t* __restrict__ slot, const uint32_t* __restrict__ seg, int n, int C, int D, int HW,
-                                         float* __restrict__ orow, unsigned long long* __restrict__ skey /* [SEG_LONG_CAP] = sid | sw */,
-                                         float* __restrict__ part /* [4][256] */) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  uint32_t* sid = (uint32_t*)skey;
-  float* sw = (float*)(sid + SEG_LONG_CAP);
-  if (n <= SEG_LONG_CAP) {
-    int np2 = 512;
-    while (np2 < n) np2 <<= 1;
-    for (int i = tid; i < np2; i += 256) skey[i] = i < n ? (((unsigned long long)seg[i] << 32) | (unsigned)i) : ~0ull;
-    __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < np2; i += 256) {
-          const int l = i ^ j;
-          if (l > i) {
-            const unsigned long long a = skey[i], b = skey[l];
-            const bool up = (i & k) == 0;
-            if ((a > b) == up) { skey[i] = b; skey[l] = a; }
-          }
-        }
-        __syncthreads();
-      }
-    // decode into registers first: the (row, weight) arrays overlay the keys
-    uint32_t rr[SEG_LONG_CAP / 256];
-    float ww[SEG_LONG_CAP / 256];
+                                         const float* __restrict__ rowmax, float* __restrict__ orow, float* __restrict__ red /* [256] */,
+                                         double* __restrict__ part /* [16][128] */, uint32_t* __restrict__ erow, float* __restrict__ ew) {
+  const int tid = threadIdx.x;
+  // pass 1: the bound; the first SEG_LDS_ENTRIES (row, weight) pairs stay in LDS for pass 2 (one memory round trip per batch of
+  // rows instead of two)
+  float bnd = 0.f;
+  for (int i0 = 0; i0 < n; i0 += 256 * 4) {
+    uint32_t idv[4];
+    float wv[4], rm[4];
 #pragma unroll
-    for (int q = 0; q < SEG_LONG_CAP / 256; ++q) {
-      const int i = q * 256 + tid;
-      rr[q] = 0; ww[q] = 0.f;
-      if (i < n) {
-        const unsigned long long kv = skey[i];
-        const uint32_t id = (uint32_t)(kv >> 32);
-        rr[q] = id / (uint32_t)D;
-        ww[q] = REUSE ? seg_weight_from_depth(depth, slot, id, D, HW) : wseg[(uint32_t)kv];
-      }
+    for (int u = 0; u < 4; ++u) { const int i = i0 + u * 256 + tid; idv[u] = i < n ? seg[i] : 0u; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256 + tid;
+      wv[u] = i < n ? (REUSE ? seg_weight_from_depth(depth, slot, idv[u], D, HW) : wseg[i]) : 0.f;
+      idv[u] = idv[u] / (uint32_t)D;
+      rm[u] = i < n ? rowmax[idv[u]] : 0.f;
     }
-    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < SEG_LONG_CAP / 256; ++q) {
-      const int i = q * 256 + tid;
-      if (i < n) { sid[i] = rr[q]; sw[i] = ww[q]; }
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256 + tid;
+      bnd = fmaxf(bnd, fabsf(wv[u]) * rm[u]);
+      if (i < n && i < SEG_LDS_ENTRIES) { erow[i] = idv[u]; ew[i] = wv[u]; }
     }
-    __syncthreads();
-    const int q4 = (n + 3) >> 2, lo = min(n, wave * q4), hi = min(n, lo + q4);
-    constexpr int LB = 8;             // (with 16 the kernel needs 114 registers: 4 instead of 8 waves per SIMD for the short voxels)
-    for (int c0 = 0; c0 < C; c0 += 256) {
-      const int c = c0 + lane * 4;
-      const bool on = c < C;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float* xc = x + (on ? c : 0);
-      for (int j0 = lo; j0 < hi; j0 += LB) {
-        f32x4 r[LB];
-        float wj[LB];
-#pragma unroll
-        for (int j = 0; j < LB; ++j) {
-          const int jj = min(j0 + j, hi - 1);
-          wj[j] = j0 + j < hi ? sw[jj] : 0.f;
-          r[j] = *(const f32x4*)(xc + (size_t)sid[jj] * C);
-        }
-#pragma unroll
-        for (int j = 0; j < LB; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] = __fmaf_rn(wj[j], r[j][e], acc[e]);
-      }
-      *(f32x4*)(part + wave * 256 + lane * 4) = acc;
-      __syncthreads();
-      if (wave == 0 && on) {
-        f32x4 t = *(const f32x4*)(part + lane * 4);
-#pragma unroll
-        for (int w = 1; w < 4; ++w) t = t + *(const f32x4*)(part + w * 256 + lane * 4);
-        *(f32x4*)(orow + c) = t;
-      }
-      __syncthreads();
-    }
-    return;
   }
-  // never seen in practice (> SEG_LONG_CAP segments in one voxel): the next id in ascending order is found by a block-wide min
-  // over the unsorted segment list, one entry at a time -- O(n^2 / 256), correct for any n
-  for (int c = tid; c < C; c += 256) orow[c] = 0.f;
-  unsigned long long prev = 0;
-  bool first = true;
-  for (int t = 0; t < n; ++t) {
-    unsigned long long best = ~0ull;
-    for (int i = tid; i < n; i += 256) {
-      const unsigned long long me = ((unsigned long long)seg[i] << 32) | (unsigned)i;
-      if ((first || me > prev) && me < best) best = me;
-    }
-    skey[tid] = best;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o) skey[tid] = min(skey[tid], skey[tid + o]);
-      __syncthreads();
-    }
-    const unsigned long long kv = skey[0];
-    __syncthreads();
-    prev = kv; first = false;
-    const uint32_t id = (uint32_t)(kv >> 32);
-    const uint32_t row = id / (uint32_t)D;
-    const float wv = REUSE ? seg_weight_from_depth(depth, slot, id, D, HW) : wseg[(uint32_t)kv];
-    for (int c = tid; c < C; c += 256) orow[c] = __fmaf_rn(wv, x[(size_t)row * C + c], orow[c]);
-  }
+  red[tid] = bnd;
   __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+    __syncthreads();
+  }
+  bnd = red[0];
+  __syncthreads();
+  int ex = 0;
+  frexpf(bnd, &ex);                                              // bnd < 2^ex
+  int lg = 0;
+  while ((1 << lg) < n) ++lg;
+  const double q = ldexp(1.0, ex - (50 - lg));
+  const double magic = 6755399441055744.0 * q;                   // 1.5 * 2^52 * q
+  const int g16 = tid >> 4, l16 = tid & 15;
+  const int q16 = (n + 15) >> 4, lo = min(n, g16 * q16), hi = min(n, lo + q16);
+  for (int c0 = 0; c0 < C; c0 += 128) {                          // 16 lanes x 8 channels per pass
+    const int c = c0 + l16 * 8;
+    const bool on = c < C;                                       // C % 4 == 0: a lane's second quad may be off
+    const bool on2 = c + 4 < C;
+    double acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0;
+    const float* xc = x + (on ? c : 0);
+    constexpr int LB = 4;             // (8: 118 registers for the whole kernel -- the short voxels' waves would drop from 6 to 4 per SIMD)
+    for (int j0 = lo; j0 < hi; j0 += LB) {
+      f32x4 r0[LB], r1[LB];
+      float wj[LB];
+#pragma unroll
+      for (int j = 0; j < LB; ++j) {
+        const int jj = min(j0 + j, hi - 1);
+        uint32_t row;
+        float wv;
+        if (jj < SEG_LDS_ENTRIES) { row = erow[jj]; wv = ew[jj]; }
+        else {
+          const uint32_t id = seg[jj];
+          row = id / (uint32_t)D;
+          wv = REUSE ? seg_weight_from_depth(depth, slot, id, D, HW) : wseg[jj];
+        }
+        wj[j] = (on && j0 + j < hi) ? wv : 0.f;
+        const float* rp = xc + (size_t)row * C;
+        r0[j] = *(const f32x4*)rp;
+        r1[j] = on2 ? *(const f32x4*)(rp + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < LB; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double p0 = (double)__fmul_rn(wj[j], r0[j][e]), p1 = (double)__fmul_rn(wj[j], r1[j][e]);
+          acc[e] = __dadd_rn(acc[e], __dsub_rn(__dadd_rn(p0, magic), magic));
+          acc[4 + e] = __dadd_rn(acc[4 + e], __dsub_rn(__dadd_rn(p1, magic), magic));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[g16 * 128 + l16 * 8 + e] = acc[e];
+    __syncthreads();
+    if (tid < 128 && c0 + tid < C) {
+      double t = part[tid];
+#pragma unroll
+      for (int w = 1; w < 16; ++w) t = __dadd_rn(t, part[w * 128 + tid]);      // exact: any order gives these bits
+      orow[c0 + tid] = (float)t;
+    }
+    __syncthreads();
+  }
 }
 
 // blocks [0, long_blocks): the long voxels (persistent over long_list); the rest: one wave per voxel, four voxels per workgroup.
@@ -980,24 +996,29 @@ __global__ __launch_bounds__(256) void k_pool_sum_seg(const float* __restrict__ 
                                                        const float* __restrict__ wts, const int32_t* __restrict__ slot,
                                                        const uint32_t* __restrict__ ids, const int32_t* __restrict__ start,
                                                        const int32_t* __restrict__ long_list, const int32_t* __restrict__ nlong_p,
-                                                       int long_blocks, int nvox, int C, int D, int HW, float* __restrict__ out,
-                                                       int out_stride) {
-  __shared__ __attribute__((aligned(16))) unsigned long long skey[SEG_LONG_CAP];
-  __shared__ __attribute__((aligned(16))) float part[4 * 256];
-  uint32_t* sid = (uint32_t*)skey;
-  float* sw = (float*)(sid + SEG_LONG_CAP);
+                                                       int long_blocks, int nvox, int C, int D, int HW, const float* __restrict__ rowmax,
+                                                       float* __restrict__ out, int out_stride, int ablate) {
+  __shared__ __attribute__((aligned(16))) double part[16 * 128];      // long voxels: 16 partial rows of 128 channels (16 KB)
+  __shared__ uint32_t erow[SEG_LDS_ENTRIES];                           // ... and their (row, weight) pairs
+  __shared__ float ew[SEG_LDS_ENTRIES];
+  uint32_t* sid = (uint32_t*)part;                                     // short blocks: the waves' medium-voxel id / weight slices
+  float* sw = (float*)(sid + 4 * POOL_MEDIUM);
+  float* red = (float*)(sid + 8 * POOL_MEDIUM);
   if ((int)blockIdx.x < long_blocks) {
     const int nlong = *nlong_p;
     for (int li = blockIdx.x; li < nlong; li += long_blocks) {
       const int v = long_list[li];
       const int s = start[v];
-      seg_long<REUSE>(x, depth, wts + s, slot, ids + s, start[v + 1] - s, C, D, HW, out + (size_t)v * out_stride, skey, part);
+      seg_long<REUSE>(x, depth, wts + s, slot, ids + s, start[v + 1] - s, C, D, HW, rowmax, out + (size_t)v * out_stride, red, part, erow, ew);
     }
     return;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = (int)blockIdx.x - long_blocks, nb = (int)gridDim.x - long_blocks;      // nb is a multiple of 8
-  const int chunk = (b & 7) * (nb >> 3) + (b >> 3);
+  // plain order: a contiguous eighth of the voxel list per XCD (one workgroup id in eight) left the XCDs that own the centre of
+  // the grid with most of the segments -- 134 against 111 us at r101 -- and did not lower the fetched bytes
+  const int chunk = (ablate & 1) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+  if (ablate & 2) D = 0x7fffffff;                                 // timing experiment: every row gather reads row 0
   uint32_t* lds = sid + wave * POOL_MEDIUM;
   float* ldw = sw + wave * POOL_MEDIUM;
   if (V8) {
@@ -1031,14 +1052,14 @@ __global__ __launch_bounds__(256) void k_pool_sum_seg(const float* __restrict__ 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // workspace: keys[npts] | ids[npts] | slot[npts] | count[nvox+1] | nlong [64] (one memset clears these two when the caller does
-// not vouch for them) | start[nvox+1] | lstart[nvox+1] | long_list[nvox] | tops[nvox / 1024 + 2] | wts[npts] | wcsr[npts] (segment form)
+// not vouch for them) | start[nvox+1] | lstart[nvox+1] | long_list[nvox] | tops[nvox / 1024 + 2] | wts[npts] | wcsr[npts] | rowmax[npts / D <= npts] (segment form)
 extern "C" size_t coocc_voxel_pool_ws(int npts, int nvox) {
   if (npts <= 0 || nvox <= 0) return 0;
-  return 5 * align256(sizeof(uint32_t) * (size_t)npts) + 4 * align256(sizeof(int32_t) * ((size_t)nvox + 1)) + 256 +
+  return 6 * align256(sizeof(uint32_t) * (size_t)npts) + 4 * align256(sizeof(int32_t) * ((size_t)nvox + 1)) + 256 +
          align256(sizeof(int32_t) * ((size_t)nvox / 1024 + 2)) + 8192 + 256;
 }
 
-struct PoolWs { uint32_t *keys, *ids; int32_t *slot, *count, *nlong, *start, *lstart, *long_list, *tops; float *wts, *wcsr; size_t zero_bytes; };
+struct PoolWs { uint32_t *keys, *ids; int32_t *slot, *count, *nlong, *start, *lstart, *long_list, *tops; float *wts, *wcsr, *rowmax; size_t zero_bytes; };
 
 static int carve(void* ws, size_t ws_bytes, int npts, int nvox, PoolWs* p) {
   size_t need = coocc_voxel_pool_ws(npts, nvox);
@@ -1051,7 +1072,8 @@ static int carve(void* ws, size_t ws_bytes, int npts, int nvox, PoolWs* p) {
   p->start = (int32_t*)c; c += v; p->lstart = (int32_t*)c; c += v; p->long_list = (int32_t*)c; c += v; p->tops = (int32_t*)c;
   c += align256(sizeof(int32_t) * ((size_t)nvox / 1024 + 2)) + 8192;
   p->wts = (float*)c; c += a;
-  p->wcsr = (float*)c;
+  p->wcsr = (float*)c; c += a;
+  p->rowmax = (float*)c;
   return COOCC_OK;
 }
 
@@ -1094,22 +1116,25 @@ static bool pool_seg_on() {               // read per call: tests compare the tw
 }
 
 template <bool REUSE>
-static int pool_sums_seg(const float* x, const float* depth, int C, int D, int HW, int nvox, float* out, int out_stride,
+static int pool_sums_seg(const float* x, const float* depth, int C, int D, int HW, int nvox, long long npts, float* out, int out_stride,
                          const PoolWs& p, hipStream_t s) {
   static const int long_blocks = getenv("COOCC_POOL_LONG_BLOCKS") ? atoi(getenv("COOCC_POOL_LONG_BLOCKS")) : 1024;
   static const bool g16 = !(getenv("COOCC_POOL_G16") && atoi(getenv("COOCC_POOL_G16")) == 0);
-  if (g16 && (C == 128 || C == 64)) {
+  static const int ablate = getenv("COOCC_POOL_ABLATE") ? atoi(getenv("COOCC_POOL_ABLATE")) : 0;      // timing experiments (results wrong)
+  // four voxels per wave pay when most voxels hold <= 16 segments: r50 has 5.9 points per voxel (2.6 segments per non-empty
+  // voxel), r101 47 (15 segments; there the groups that sit out cost more than the packing saves: 134 against 117 us)
+  if (g16 && (C == 128 || C == 64) && npts < 16ll * nvox) {
     const int short_blocks = 8 * cdiv(cdiv(nvox, 16), 8);
     if (C == 128)
       hipLaunchKernelGGL((k_pool_sum_seg<REUSE, 8>), dim3(long_blocks + short_blocks), dim3(256), 0, s, x, depth, p.wcsr, p.slot, p.ids,
-                         p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, out, out_stride);
+                         p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, p.rowmax, out, out_stride, ablate);
     else
       hipLaunchKernelGGL((k_pool_sum_seg<REUSE, 4>), dim3(long_blocks + short_blocks), dim3(256), 0, s, x, depth, p.wcsr, p.slot, p.ids,
-                         p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, out, out_stride);
+                         p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, p.rowmax, out, out_stride, ablate);
   } else {
     const int short_blocks = 8 * cdiv(cdiv(nvox, 4), 8);
     hipLaunchKernelGGL((k_pool_sum_seg<REUSE, 0>), dim3(long_blocks + short_blocks), dim3(256), 0, s, x, depth, p.wcsr, p.slot, p.ids,
-                       p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, out, out_stride);
+                       p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, p.rowmax, out, out_stride, ablate);
   }
   COOCC_LAUNCH_CHECK("voxel_pool (segments)");
   return COOCC_OK;
@@ -1124,13 +1149,13 @@ static int pool_build_seg(const KeySrc& ks, const float* x, const float* depth, 
   const size_t plane = sizeof(float) * (size_t)D * (SEG_STRIP + 1);
   const int stage_geom = MODE == 0 && 4 * plane + 12 * SEG_HASH <= 60 * 1024;
   hipLaunchKernelGGL(k_seg_hist<MODE>, dim3(8 * cdiv(nstrips, 8)), dim3(256), (stage_geom ? 4 * plane : plane) + 12 * SEG_HASH, s, ks, depth, npts, X, Y, Z,
-                     nvox, strips_per_cam, nstrips, stage_geom, p.keys, p.count, p.slot, p.wts);
+                     nvox, strips_per_cam, nstrips, stage_geom, p.keys, p.count, p.slot, p.wts, x, C, p.rowmax);
   const int nblk = (nvox + 1023) / 1024;
   hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(1024), 0, s, p.count, nvox, p.lstart, p.tops, p.nlong);
   const int fill_blocks = max(cdiv(npts, 1024), 1);
   hipLaunchKernelGGL(k_csr_fill, dim3(fill_blocks), dim3(256), sizeof(int) * ((size_t)nblk + 1), s, p.keys, npts, nvox, nblk, p.lstart, p.tops,
                      p.slot, p.count, p.start, p.long_list, p.nlong, p.ids, SEG_SLOT_MASK, p.wts, p.wcsr);
-  return pool_sums_seg<false>(x, depth, C, D, HW, nvox, out, out_stride, p, s);
+  return pool_sums_seg<false>(x, depth, C, D, HW, nvox, npts, out, out_stride, p, s);
 }
 
 extern "C" int coocc_voxel_pool(const float* x, const float* geom, int npts, int pts_per_batch, int C,
@@ -1215,8 +1240,10 @@ extern "C" int coocc_lift_splat_reuse(const float* depth, const float* feat_nhwc
   PoolWs p;
   int rc = carve(ws, ws_bytes, (int)npts_ll, (int)nvox_ll, &p);
   if (rc) return rc;
-  if (pool_seg_on() && (long long)N * H * W < (1ll << SEG_SLOT_BITS) && D <= SEG_DMAX)      // the rule of lift_splat_impl
-    return pool_sums_seg<true>(feat_nhwc, depth, C, D, H * W, (int)nvox_ll, out, out_stride, p, as_stream(stream));
+  if (pool_seg_on() && (long long)N * H * W < (1ll << SEG_SLOT_BITS) && D <= SEG_DMAX) {    // the rule of lift_splat_impl
+    hipLaunchKernelGGL(k_row_absmax, dim3(cdiv(N * H * W, 8)), dim3(256), 0, as_stream(stream), feat_nhwc, C, N * H * W, p.rowmax);
+    return pool_sums_seg<true>(feat_nhwc, depth, C, D, H * W, (int)nvox_ll, npts_ll, out, out_stride, p, as_stream(stream));
+  }
   return pool_sums<true>(feat_nhwc, depth, C, D, H * W, (int)nvox_ll, out, out_stride, p, as_stream(stream));
 }
 

@@ -227,14 +227,23 @@ def test_sparse_encoder_trains_forward_and_backward_vs_oracle(dev, variant):
     up = torch.from_numpy(g.standard_normal(tuple(want.shape)).astype(np.float32))
     (want * up).sum().backward()
     (out * up.to(dev)).sum().backward()
-    bad, n = [], 0
-    for name, got_g, want_g in [("d voxel features", fx.grad, fo.grad)] + [(k, q.grad, osd[k].grad) for k, q in enc.named_parameters()]:
+    # the same anchor for the gradients: autograd through the oracle in fp64
+    osd64 = {k: (v.clone().requires_grad_() if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd64.items()}
+    fo64 = torch.from_numpy(feats).double().requires_grad_()
+    w64g, _ = ref_lidar.sparse_encoder_forward(osd64, fo64, coors, (D, H, W), variant, train_bn=True)
+    (w64g * up.double()).sum().backward()
+    bad, n, worst = [], 0, (0.0, 0.0)
+    for name, got_g, g32, g64 in [("d voxel features", fx.grad, fo.grad, fo64.grad)] + [(k, q.grad, osd[k].grad, osd64[k].grad)
+                                                                                          for k, q in enc.named_parameters()]:
         assert got_g is not None, name
-        try:
-            _grad_close(got_g, want_g, name, tol=1e-3)
-        except AssertionError as e:
-            bad.append(str(e))
+        sc = max(float(g64.abs().max()), 1e-12)
+        e_hip = float((got_g.detach().cpu().double() - g64).abs().max()) / sc
+        e_o32 = float((g32.double() - g64).abs().max()) / sc
+        worst = max(worst, (e_hip, e_o32))
+        if not e_hip <= max(3.0 * e_o32, 1e-3):
+            bad.append("%s: HIP vs fp64 %.2e, fp32 oracle vs fp64 %.2e" % (name, e_hip, e_o32))
         n += 1
+    print("lidar encoder gradients (%s): worst HIP vs fp64 %.2e (fp32 oracle there: %.2e) over %d tensors" % (variant, worst[0], worst[1], n))
     assert not bad, "%d of %d gradients off:\n%s" % (len(bad), n, "\n".join(bad[:12]))
     assert n >= 40
     # eval() afterwards is the inference path again (folded running statistics, no autograd)

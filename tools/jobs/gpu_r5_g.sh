@@ -8,7 +8,7 @@ cd $R
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_modules.py -x -q -m gpu -k "pool or lift or splat" > $O/pytest_pool.txt 2>&1
 tail -n 15 $O/pytest_pool.txt
-bash tools/jobs/gpu_r5_f.sh
+
 timeout 900 python -m pytest tests/test_gpu_lidar.py -x -q -m gpu > $O/pytest_lidar.txt 2>&1
 tail -n 25 $O/pytest_lidar.txt
 
