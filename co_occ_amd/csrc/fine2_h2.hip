@@ -148,6 +148,10 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : 2) void k_fine2_h2(Fine2K p)
     const int ci0 = (tile * NW + wave) * 4;
     if (ci0 >= n) continue;                            // wave-uniform; no workgroup barrier inside the loop
     const int nc = min(4, n - ci0);
+    if (p.dbg & 6) {                                   // debug: the tile starts from zeros (2) / from 0xFF bytes (4)
+      for (int i = lane; i < 32 * F2_TP; i += 64) ((unsigned*)T)[i] = (p.dbg & 4) ? 0xFFFFFFFFu : 0u;
+      F2_LDS_FENCE();
+    }
     int cx[4], cy[4], cz[4];                           // the wave's coarse voxels (wave-uniform values)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -303,7 +307,14 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : 2) void k_fine2_h2(Fine2K p)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
               const char* rp = img + (unsigned)o4[t];
-              v[jj][t][0] = *(const f32x4*)rp; v[jj][t][1] = *(const f32x4*)(rp + 128);
+              if (p.dbg & 8) {                         // debug: 8-byte loads instead of 16-byte ones
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 a0 = *(const volatile f32x2*)rp, a1 = *(const volatile f32x2*)(rp + 8);
+                const f32x2 b0 = *(const volatile f32x2*)(rp + 128), b1 = *(const volatile f32x2*)(rp + 136);
+                v[jj][t][0] = f32x4{a0[0], a0[1], a1[0], a1[1]}; v[jj][t][1] = f32x4{b0[0], b0[1], b1[0], b1[1]};
+              } else {
+                v[jj][t][0] = *(const f32x4*)rp; v[jj][t][1] = *(const f32x4*)(rp + 128);
+              }
             }
           }
 #pragma unroll
@@ -453,8 +464,13 @@ extern "C" int coocc_fine2_h2(const float* Q, int q_stride, int X, int Y, int Z,
   p.dbg = getenv("COOCC_FINE2_DBG") ? atoi(getenv("COOCC_FINE2_DBG")) : 0;
   const char* ge = getenv("COOCC_FINE2_GRID");
   const int grid = (ge && ge[0] == 'f') ? (int)tiles : (int)(tiles < 512 ? tiles : 512);
-  if (nw == 6) hipLaunchKernelGGL(k_fine2_h2<6>, dim3(grid), dim3(384), 0, as_stream(stream), p);
-  else hipLaunchKernelGGL(k_fine2_h2<4>, dim3(grid), dim3(256), 0, as_stream(stream), p);
+  // COOCC_FINE2_PADLDS: extra (unused) dynamic LDS per workgroup -- debug: keeps other kernels' workgroups off the CU
+  const size_t pad = getenv("COOCC_FINE2_PADLDS") ? (size_t)atoi(getenv("COOCC_FINE2_PADLDS")) : 0;
+  if (pad) {
+    hipFuncSetAttribute((const void*)k_fine2_h2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  }
+  if (nw == 6) hipLaunchKernelGGL(k_fine2_h2<6>, dim3(grid), dim3(384), pad, as_stream(stream), p);
+  else hipLaunchKernelGGL(k_fine2_h2<4>, dim3(grid), dim3(256), pad, as_stream(stream), p);
   COOCC_LAUNCH_CHECK("k_fine2_h2");
   return COOCC_OK;
 }
