@@ -73,7 +73,8 @@ SIGNATURES = {
     "coocc_fine_mlp_pre_dev": (I, [P, I, P, I, L, P, I, P, P, P, F, P, P, P, P, F, P, P, I, P, P]),
     "coocc_fine_fused": (I, [P, I, I, I, P, I, I, I, P, P, I, P, I, P, P, P, P, F, P, P, P, P, F, P, P, I, P, P, P]),
     "coocc_fine2_pack": (I, [P, P, I, P, P, P, P, P, P, P, P, P, P]),
-    "coocc_fine2_h2": (I, [P, I, I, I, I, P, I, I, I, P, P, I, P, P, P, P, F, F, I, P, P, P]),
+    "coocc_fine2_h2": (I, [P, I, I, I, I, P, I, I, I, P, P, I, P, P, P, P, F, F, I, P, P, P, P]),
+    "coocc_fine_sample_img_lin": (I, [P, I, I, I, I, P, P, I, I, I, P, P, I, I, P]),
     "coocc_scatter_fine_dev": (I, [P, L, P, I, I, I, P, P, I, I, I, F, P]),
     "coocc_scatter_fine_grouped": (I, [P, I, I, P, I, P, I, I, I, I, P, F, P, P]),
     "coocc_ball_query_voxels": (I, [I, F, F, I, I, I, I, P, P, P, P, P]),

@@ -420,15 +420,23 @@ __global__ __launch_bounds__(256) void k_fine_sample_img_grp(const float* __rest
                                                               const float* __restrict__ prm,
                                                               const int64_t* __restrict__ fine_xyz, int n,
                                                               float* __restrict__ feat, int out_stride,
-                                                              const int32_t* __restrict__ n_dev) {
+                                                              const int32_t* __restrict__ n_dev,
+                                                              const int32_t* __restrict__ coarse_lin = nullptr, int Yc = 0, int Zc = 0) {
   if (n_dev) n = min(n, *n_dev);
   constexpr int R3 = R * R * R;
   const int i = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   const long long nf = (long long)n * R3;
   // child o = (a*R + b)*R + c of coarse voxel i sits at (child 0) + (a, b, c): three wave-uniform reads instead of
-  // 3 x 48 scattered 8-byte ones per round (f = o*n + i)
-  const long long x00 = fine_xyz[i], y00 = fine_xyz[nf + i], z00 = fine_xyz[2 * nf + i];
+  // 3 x 48 scattered 8-byte ones per round (f = o*n + i); or, with the coarse list (B == 1), child 0 = R x the coarse voxel
+  long long x00, y00, z00;
+  if (coarse_lin) {
+    int l = coarse_lin[i];
+    z00 = (long long)(l % Zc) * R; l /= Zc;
+    y00 = (long long)(l % Yc) * R; x00 = (long long)(l / Yc) * R;
+  } else {
+    x00 = fine_xyz[i]; y00 = fine_xyz[nf + i]; z00 = fine_xyz[2 * nf + i];
+  }
 #pragma unroll 1
   for (int g = 0; g < R3 / 8; ++g) {
     int m = 0, x0 = 0, y0 = 0;
@@ -539,6 +547,25 @@ extern "C" int coocc_fine_sample_img_dev(const float* img_nhwc, int ncam, int Ci
   COOCC_CHECK_ARG(n_dev && (group == 1 || group == 2 || group == 4), "fine_sample_img_dev: needs the device count of COARSE voxels and group 2 | 4");
   return fine_sample_img_impl(img_nhwc, ncam, Ci, Hf, Wf, params, fine_xyz, nfine_cap, n_dev, feat, out_stride, group, stream);
 }
+// The grouped sampler straight from the foreground list: the fine coordinates need not exist yet (cascade ratio 2 | 4, B == 1,
+// final grid = ratio x coarse grid: child 0 of coarse voxel (x, y, z) is fine voxel ratio x (x, y, z)).  n_dev optional.
+extern "C" int coocc_fine_sample_img_lin(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf, const float* params,
+                                         const int32_t* coarse_lin, int Yc, int Zc, int n_cap, const int32_t* n_dev, float* feat,
+                                         int out_stride, int ratio, void* stream) {
+  COOCC_CHECK_ARG(img_nhwc && params && coarse_lin && feat && ncam > 0 && ncam <= 8 && Ci > 0 && Ci % 2 == 0 && Ci <= 512 && Yc > 0 && Zc > 0,
+                  "fine_sample_img_lin: bad args (Ci even, <= 512, <= 8 cameras)");
+  COOCC_CHECK_ARG(ratio == 2 || ratio == 4, "fine_sample_img_lin: cascade ratio 2 | 4");
+  if (n_cap <= 0) return COOCC_OK;
+  if (ratio == 2)
+    hipLaunchKernelGGL(k_fine_sample_img_grp<2>, dim3(cdiv((long long)n_cap * 64, 256)), dim3(256), 0, as_stream(stream), img_nhwc, ncam,
+                       Ci, Hf, Wf, params, (const int64_t*)nullptr, n_cap, feat, out_stride, n_dev, coarse_lin, Yc, Zc);
+  else
+    hipLaunchKernelGGL(k_fine_sample_img_grp<4>, dim3(cdiv((long long)n_cap * 64, 256)), dim3(256), 0, as_stream(stream), img_nhwc, ncam,
+                       Ci, Hf, Wf, params, (const int64_t*)nullptr, n_cap, feat, out_stride, n_dev, coarse_lin, Yc, Zc);
+  COOCC_LAUNCH_CHECK("k_fine_sample_img_grp");
+  return COOCC_OK;
+}
+
 static int fine_sample_img_impl(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf, const float* params, const int64_t* fine_xyz,
                                 int64_t nfine, const int32_t* n_dev, float* feat, int out_stride, int group, void* stream) {
   COOCC_CHECK_ARG(img_nhwc && params && fine_xyz && feat && ncam > 0 && Ci > 0 && Ci % 2 == 0 && Ci <= 512,

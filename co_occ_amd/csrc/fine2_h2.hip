@@ -47,6 +47,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 struct Fine2K {
   const float* Q;            // [X*Y*Z, 64]  W_f0[:, :128] . voxel features
   const float* P;            // [ncam*Hf*Wf, 64]  W_img . image features
+  const float* samp;         // IMG == false: the image samples [8 n, 64] (row f = o n + i) made by coocc_fine_sample_img_lin
   const float* prm;          // coocc_projection_params
   const int32_t* lin;        // foreground coarse voxels (linear ids)
   const int32_t* n_dev;      // optional device-side count
@@ -120,7 +121,10 @@ __device__ __forceinline__ void f2_split8(const f32x16& y, int r0, f16x8& hi, f1
 
 #define F2_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")      // the tile is private to the wave (LDS is in order per wave)
 
-template <int NW>            // waves per workgroup: 4 (two waves per SIMD at two workgroups per CU) | 6 (three; <= 168 registers)
+// IMG: the image samples are made here (phases P and B below); false: they arrive from the grouped sampler's own launch
+// (head.FINE2_IMG_INSIDE: with split-f16 GEMMs of another stream on the chip the in-kernel image samples of children 6 / 7 differ
+// from run to run -- DESIGN.md 3.2d; the sampler kernel does not show it)
+template <int NW, bool IMG = true>            // waves per workgroup: 4 (two waves per SIMD at two workgroups per CU) | 6 (three; <= 168 registers)
 __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : 2) void k_fine2_h2(Fine2K p) {       // (threads, min waves per SIMD)
   __shared__ __attribute__((aligned(16))) char Wl[F2_WBYTES];
   __shared__ __attribute__((aligned(16))) float Cn[F2_NCONST];
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : 2) void k_fine2_h2(Fine2K p)
 #pragma unroll
       for (int qq = 0; qq < F2_MAXCAM / 2; ++qq) {
         vis[qq] = 0ull;
-        if (2 * qq >= ncam) continue;                  // wave-uniform
+        if (!IMG || 2 * qq >= ncam) continue;          // wave-uniform
         const int cam = 2 * qq + h;
         const bool camok = cam < ncam;
         const float* q = prm + F2_HDR + (camok ? cam : 0) * F2_CAM_STRIDE;
@@ -287,7 +291,14 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : 2) void k_fine2_h2(Fine2K p)
     f32x4 ai[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ai[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ai[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    {
+    if (!IMG) {
+      // the finished samples of this lane's four children: rows (pt8 n + ci0 + j), channels 32 i + 4 piece + 0..3
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* sp = p.samp + ((size_t)pt8 * n + ci0 + min(j, nc - 1)) * 64 + 4 * piece;
+        ai[j][0] = *(const f32x4*)sp; ai[j][1] = *(const f32x4*)(sp + 32);
+      }
+    } else {
       const char* img = (const char*)p.P + 16 * piece;
 #pragma unroll
       for (int cam = 0; cam < F2_MAXCAM; ++cam) {
@@ -435,20 +446,23 @@ extern "C" int coocc_fine2_pack(const float* w_f0, const float* w_f3, int ncls, 
 // coocc_fine_fused); lin: the n
 // (with n_dev: at most n_cap) foreground coarse voxels; final_size == 2 * (X, Y, Z); wpack / consts from coocc_fine2_pack.
 // Outputs as coocc_fine_fused: fine_xyz [3][8 n], logits [8 n, ncls] (row o * n + i).
+// img_samples != NULL: [8 n, 64] image samples from coocc_fine_sample_img_lin (P and params are then unused and may be NULL).
 extern "C" int coocc_fine2_h2(const float* Q, int q_stride, int X, int Y, int Z, const float* P, int ncam, int Hf, int Wf, const float* params,
                               const int32_t* coarse_lin, int n_cap, const int32_t* n_dev, const int* final_size_host, const void* wpack,
-                              const float* consts, float eps_img, float eps_f0, int ncls, int64_t* fine_xyz, float* out, void* stream) {
-  COOCC_CHECK_ARG(Q && P && params && coarse_lin && final_size_host && wpack && consts && fine_xyz && out, "fine2_h2: null pointer");
+                              const float* consts, float eps_img, float eps_f0, int ncls, int64_t* fine_xyz, float* out,
+                              const float* img_samples, void* stream) {
+  COOCC_CHECK_ARG(Q && (img_samples || (P && params)) && coarse_lin && final_size_host && wpack && consts && fine_xyz && out, "fine2_h2: null pointer");
   COOCC_CHECK_ARG(n_cap >= 0 && ncls >= 1 && ncls <= 32 && ncam >= 1 && ncam <= F2_MAXCAM && X > 0 && Y > 0 && Z > 0 && Hf > 0 && Wf > 0,
                   "fine2_h2: ncls <= 32, <= 8 cameras");
   COOCC_CHECK_ARG(q_stride >= 64 && q_stride % 4 == 0, "fine2_h2: q_stride (floats per row of Q) >= 64, a multiple of 4");
   COOCC_CHECK_ARG(final_size_host[0] == 2 * X && final_size_host[1] == 2 * Y && final_size_host[2] == 2 * Z,
                   "fine2_h2: final_occ_size must be 2 x the coarse grid");
-  COOCC_CHECK_ARG(f2_aligned16(Q) && f2_aligned16(P) && f2_aligned16(wpack) && f2_aligned16(consts), "fine2_h2: arrays must be 16-byte aligned");
+  COOCC_CHECK_ARG(f2_aligned16(Q) && f2_aligned16(P) && f2_aligned16(wpack) && f2_aligned16(consts) && f2_aligned16(img_samples),
+                  "fine2_h2: arrays must be 16-byte aligned");
   if (n_cap == 0) return COOCC_OK;
   Fine2K p;
   memset(&p, 0, sizeof(p));
-  p.Q = Q; p.P = P; p.prm = params; p.lin = coarse_lin; p.n_dev = n_dev; p.fine_xyz = fine_xyz; p.out = out;
+  p.Q = Q; p.P = P; p.samp = img_samples; p.prm = params ? params : consts; p.lin = coarse_lin; p.n_dev = n_dev; p.fine_xyz = fine_xyz; p.out = out;
   p.wpack = (const char*)wpack; p.consts = consts;
   if (coocc_h2_flag_ptr(&p.h2_flag) != COOCC_OK) return COOCC_EHIP;
   p.q_stride = q_stride;
@@ -469,7 +483,8 @@ extern "C" int coocc_fine2_h2(const float* Q, int q_stride, int X, int Y, int Z,
   if (pad) {
     hipFuncSetAttribute((const void*)k_fine2_h2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   }
-  if (nw == 6) hipLaunchKernelGGL(k_fine2_h2<6>, dim3(grid), dim3(384), pad, as_stream(stream), p);
+  if (img_samples) hipLaunchKernelGGL((k_fine2_h2<4, false>), dim3(grid), dim3(256), pad, as_stream(stream), p);
+  else if (nw == 6) hipLaunchKernelGGL(k_fine2_h2<6>, dim3(grid), dim3(384), pad, as_stream(stream), p);
   else hipLaunchKernelGGL(k_fine2_h2<4>, dim3(grid), dim3(256), pad, as_stream(stream), p);
   COOCC_LAUNCH_CHECK("k_fine2_h2");
   return COOCC_OK;

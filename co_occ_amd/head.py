@@ -29,13 +29,15 @@ FINE_LINEAR_FIRST = __import__("os").environ.get("COOCC_FINE_LINEAR_FIRST", "1")
 # (measured at configs[1]: 383 us against 334 us for the three kernels -- the wave-serial phases at 2 waves per SIMD hide less gather
 # latency than the samplers' own launches at 4+; kept off there)
 FINE_FUSED = int(__import__("os").environ.get("COOCC_FINE_FUSED", "1"))
-# ratio 2 on the split-f16 engine: ONE launch with lanes = points, samples kept in registers, both Linear layers as three f16 MFMAs
-# per k16 step (csrc/fine2_h2.hip, round 5; 0.33 -> 0.17 ms at configs[1]).  OFF by default: with two or more dense graphs in
-# flight the kernel's IMAGE samples of children 6 / 7 (lanes 48..63 of the sampling layout) differ from run to run in a few
-# hundred of 640 k rows (tests/test_gpu_serving.py::test_pipelined_test_loop_equals_per_sample_calls caught it; single-stream
-# runs are bit-stable and pass every parity test).  tools/debug/fine2_concurrent.py reproduces it without the pipeline; what was
-# ruled out is in DESIGN.md 3.2d.  COOCC_FINE2_H2=1 switches it on (the merged occ_pred_conv[0] + Q GEMM below comes with it).
-FINE2_H2 = __import__("os").environ.get("COOCC_FINE2_H2", "0") == "1"
+# ratio 2 on the split-f16 engine (csrc/fine2_h2.hip, round 5): lanes = points, voxel samples kept in registers, both Linear layers
+# as three f16 MFMAs per k16 step; 0 = the three kernels (fp32-MFMA chain).
+FINE2_H2 = __import__("os").environ.get("COOCC_FINE2_H2", "1") != "0"
+# ... with the image samples made INSIDE that launch (0.33 -> 0.17 ms).  OFF: with split-f16 GEMMs of another stream on the chip
+# (two dense graphs in flight) the in-kernel image samples of children 6 / 7 differ from run to run in a few hundred of 640 k
+# rows (tests/test_gpu_serving.py::test_pipelined_test_loop_equals_per_sample_calls; tools/debug/fine2_corunner.py reproduces
+# it; DESIGN.md 3.2d lists what was ruled out).  Default: the grouped sampler's own launch (coocc_fine_sample_img_lin) feeds the
+# kernel -- two launches, bit-stable under the same co-runners.
+FINE2_IMG_INSIDE = __import__("os").environ.get("COOCC_FINE2_IMG_INSIDE", "0") == "1"
 # occ_pred_conv[0] and the voxel half of fine_mlp[0] (both 128 -> 64 on out_voxel_feats) as one 128 -> 128 GEMM (ReLU on the first
 # 64 columns): one read of the rows and one launch instead of two; needs the strided-Q consumer (fine2_h2)
 MERGED_PRED_Q = __import__("os").environ.get("COOCC_MERGED_PRED_Q", "1") != "0"
@@ -352,10 +354,15 @@ class OccHead(nn.Module):
         nf = n_cap * self.cascade_ratio ** 3
         if self._fine2_h2_ok() and FINE_FUSED < 2:
             wp, cn = p["fine2"]
+            samp = None
+            if not FINE2_IMG_INSIDE:
+                samp = torch.empty(nf, 64, device=logits.device, dtype=_F32)
+                call("coocc_fine_sample_img_lin", ptr(P), N_i, 64, Hf, Wf, ptr(params), ptr(lin), ovf.Y, ovf.Z, int(n_cap),
+                     ptr(cnt, _I32) if cnt is not None else None, ptr(samp), 64, 2)
             with TIMER.region("k_fine2_h2", 2.0 * nf * 64 * (64 + self.out_channel)):
                 call("coocc_fine2_h2", ptr(Q, strided=True), Q.stride(0), ovf.X, ovf.Y, ovf.Z, ptr(P), N_i, Hf, Wf, ptr(params), ptr(lin), int(n_cap),
                      ptr(cnt, _I32) if cnt is not None else None, host_i32(self.final_occ_size), ptr(wp), ptr(cn), float(gi.eps),
-                     float(g0.eps), self.out_channel, ptr(fine_xyz), ptr(logits))
+                     float(g0.eps), self.out_channel, ptr(fine_xyz), ptr(logits), ptr(samp))
             return
         with TIMER.region("k_fine_fused", 2.0 * nf * 64 * (64 + self.out_channel)):
             call("coocc_fine_fused", ptr(Q), ovf.X, ovf.Y, ovf.Z, ptr(P), N_i, Hf, Wf, ptr(params), ptr(lin), int(n_cap),

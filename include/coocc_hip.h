@@ -665,9 +665,20 @@ int coocc_fine_fused(const float* Q, int X, int Y, int Z, const float* P, int nc
 int coocc_fine2_pack(const float* w_f0, const float* w_f3, int ncls, const float* b_img, const float* gn_img_w,
                      const float* gn_img_b, const float* b_f0, const float* gn_f0_w, const float* gn_f0_b, const float* b_f3,
                      void* wpack, float* consts, void* stream);
+/* img_samples != NULL: the image samples [8 n, 64] (row f = o n + i) come from coocc_fine_sample_img_lin's own launch and the
+ * kernel runs the voxel resampling + the MLP chain only (P / params may then be NULL).  That is the default composition: with
+ * split-f16 GEMMs of ANOTHER stream on the chip the in-kernel image samples differ from run to run. */
 int coocc_fine2_h2(const float* Q, int q_stride, int X, int Y, int Z, const float* P, int ncam, int Hf, int Wf, const float* params,
                    const int32_t* coarse_lin, int n_cap, const int32_t* n_dev, const int* final_size_host, const void* wpack,
-                   const float* consts, float eps_img, float eps_f0, int ncls, int64_t* fine_xyz, float* out, void* stream);
+                   const float* consts, float eps_img, float eps_f0, int ncls, int64_t* fine_xyz, float* out,
+                   const float* img_samples, void* stream);
+/* The grouped image sampler of the fine branch (project_points_on_img + bilinear samples summed over the seeing cameras,
+ * occ_head.py:211-224, coordinate_transform.py:25-65) straight from the foreground list: child 0 of coarse voxel (x, y, z) is
+ * fine voxel ratio x (x, y, z) (B == 1, final grid = ratio x coarse grid), so the fine coordinates need not exist yet.
+ * feat: [ratio^3 n, Ci] at out_stride floats per row, row f = o n + i; n_dev: optional device-side count (n_cap = capacity). */
+int coocc_fine_sample_img_lin(const float* img_nhwc, int ncam, int Ci, int Hf, int Wf, const float* params,
+                              const int32_t* coarse_lin, int Yc, int Zc, int n_cap, const int32_t* n_dev, float* feat,
+                              int out_stride, int ratio, void* stream);
 
 /* ---------------------------------------------------------------- R1..R3, L1 */
 /* inline render block, one launch for all cameras (P/coocc/detectors/coocc_ray.py:575-616).

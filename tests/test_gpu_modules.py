@@ -627,14 +627,17 @@ def test_fused_fine_branch_equals_three_kernel_path(dev, monkeypatch, ratio):
     assert torch.equal(outs[0][0], outs[1][0])
 
 
+@pytest.mark.parametrize("img_inside", [False, True])
 @pytest.mark.parametrize("grid", [(9, 7, 4), (23, 17, 5)])
-def test_fine2_h2_one_launch_branch_vs_three_kernel_path_and_device_count_form(dev, monkeypatch, grid):
+def test_fine2_h2_one_launch_branch_vs_three_kernel_path_and_device_count_form(dev, monkeypatch, grid, img_inside):
     """csrc/fine2_h2.hip (cascade ratio 2 on the split-f16 engine: lanes = fine points, samples in registers, both Linear layers as
     f16 hi / lo MFMAs) against the three-kernel fp32 path: equal fine coordinates; logits equal up to the split-f16 products
     (2^-22 per product -- the bound is 2e-6 of the logits' scale, 10x tighter than the Linear-first reordering's own bound above);
     foreground counts that are not a multiple of the 4 coarse voxels a wave / 16 a workgroup owns; the device-count (hipGraph)
     form writes the same rows; and against the literal oracle (occ_head.py:205-233) at 1e-4."""
     from co_occ_amd import head as H
+    # img_inside: the image samples made inside the launch | by the grouped sampler's own launch (the default composition)
+    monkeypatch.setattr(H, "FINE2_IMG_INSIDE", img_inside)
     c = cases.DECODER_CASE
     final = tuple(v * 2 for v in grid)
     cfg = synth.model_cfg(C=c["C"], block_inplanes=c["block_inplanes"], out_channels=c["fpn_out"], cascade_ratio=2,
