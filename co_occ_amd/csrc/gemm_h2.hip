@@ -653,6 +653,109 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
   }
 }
 
+// k_gemm_h2p: the pointwise layers (1x1x1, stride 1: input row = output row) with K <= 128 -- occ_pred_conv[0] + Q, input_proj,
+// voxel_soft_weights[0], the level-0 FPN lateral: 80 000 rows x 128 channels each.  They are HBM-bound (41 MB in, 41-123 MB out)
+// and ran at half that bound in k_gemm_h2w (40-65 us against 18-36): with one 16 KB stage in flight per workgroup and two
+// workgroups per CU there are 32 KB of reads outstanding per CU -- not enough to cover HBM latency at 8 TB/s -- and the K loop of
+// four iterations is all prologue.  Here the WHOLE A tile (<= 4 chunks x 128 rows x 128 B = 64 KB) is requested up front by
+// global_load_lds, the weights of all chunks (<= 64 registers per lane: a wave's 32 columns) are loaded once, and the MFMAs run
+// from LDS without further waits; two workgroups per CU = 128 KB in flight.  Same tile, fragments, transposed MFMA order and
+// epilogue as k_gemm_h2w.
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void k_gemm_h2p(ConvK p) {
+  constexpr int BM = 128, TM = 4;
+  constexpr unsigned STAGE = BM * 128;
+  __shared__ __attribute__((aligned(16))) char As[NCH * BM * 128];
+  const int id = blockIdx.x;
+  int mtile, nt, slot_ = id >> 3;
+  if (p.mtiles_per_xcd > 0) {
+    const int xcd = id & 7;
+    const int mt_local = slot_ / p.ntiles;
+    nt = slot_ - mt_local * p.ntiles;
+    mtile = xcd * p.mtiles_per_xcd + mt_local;
+    if (mt_local >= p.mtiles_per_xcd || mtile >= p.mtiles) return;
+  } else {
+    mtile = id / p.ntiles;
+    nt = id - mtile * p.ntiles;
+  }
+  const int m0 = mtile * BM, n0 = nt * 128;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, h = lane >> 5;
+  const int srow = lane >> 3, slot = lane & 7;
+  const long long rowbytes = (long long)p.in_stride * 4;
+  const char* inb = (const char*)p.in;
+  const char* zrow = (const char*)p.zrow;
+  const unsigned aq = (unsigned)((slot ^ ((4 * (wave & 1) + (srow >> 1)) & 7)) * 16);
+  // the whole A tile: chunk c of row r = (4 j + wave) 8 + srow -> stage c, lane-linear (the swizzle sits on the source address)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + (j * 4 + wave) * 8 + srow;
+      const char* src = m < p.M ? inb + ((long long)m * rowbytes + c * 128 + aq) : zrow;
+      glds16_(src, &As[c * STAGE + (j * 4 + wave) * 8 * 128]);
+    }
+  // this wave's weights of every chunk: [chunk][k16 step][plane]
+  f16x8 breg[NCH][2][2];
+  const long long wstep = (long long)(p.Npad >> 5) * 4096;
+  const char* wcur = (const char*)p.w + (long long)((n0 >> 5) + wave) * 4096 + lane * 16;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) breg[c][s2][pl] = *(const f16x8*)(wcur + c * wstep + (s2 * 2 + pl) * 1024);
+  unsigned fragoff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int sl = (q & 1) * 4 + 2 * (q >> 1) + h;                                     // q = 2 s + plane
+    fragoff[q] = li * 128 + ((sl ^ ((li >> 1) & 7)) << 4);
+  }
+  f32x16 hh[TM], xx[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hh[i][r] = 0.f; xx[i][r] = 0.f; }
+  __syncthreads();                       // (carries vmcnt(0): the tile has landed)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f16x8 fhi[TM], flo[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        fhi[i] = *(const f16x8*)&As[fragoff[2 * s2 + 0] + (c * STAGE + i * 4096)];
+        flo[i] = *(const f16x8*)&As[fragoff[2 * s2 + 1] + (c * STAGE + i * 4096)];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) hh[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[c][s2][0], fhi[i], hh[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[c][s2][1], fhi[i], xx[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[c][s2][0], flo[i], xx[i], 0, 0, 0);
+      H2_FENCE();
+    }
+  }
+  // epilogue: lane (li, h) holds, for output row m0 + i*32 + li, the channels n0 + 32 wave + 8 j + 4 h + 0..3 (j = 0..3)
+  const int nb = n0 + wave * 32 + 4 * h;
+  const float alpha = p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha, lo = alpha * (1.f / H2_LO_SCALE);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + i * 32 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nb + 8 * j;
+      if (n >= p.Cout) continue;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo;
+      h2_epilogue_vec(p, (size_t)m, n, v);
+    }
+  }
+}
+
 // One host-mapped word for the whole process (every device sees host-pinned memory at its host address): raised by the H2 / f16
 // writers (h2_guard), read by coocc_h2_overflow without any device synchronisation of its own.
 static int* g_h2_flag = nullptr;
@@ -739,6 +842,20 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   COOCC_CHECK_ARG(k.splitk == 1 || !d->tile_sem || (long long)k.mtiles * k.ntiles <= d->tile_sem_ints,
                   "conv_fwd: tile_sem holds fewer counters than the launch has output tiles");
   dim3 grid(k.mtiles_per_xcd ? 8 * k.mtiles_per_xcd * k.ntiles : k.mtiles * k.ntiles, k.splitk);
+  // pointwise layers with the whole A tile in flight (k_gemm_h2p): 1x1x1 stride 1, K <= 128, one pass, vector epilogue
+  static const bool pointwise_on = !(getenv("COOCC_H2_POINTWISE") && atoi(getenv("COOCC_H2_POINTWISE")) == 0);
+  if (pointwise_on && !zshare && !table && !one && k.taps == 1 && k.stride == 1 && k.px == 0 && k.py == 0 && k.pz == 0 && k.Xo == k.Xi &&
+      k.Yo == k.Yi && k.Zo == k.Zi && k.kchunks <= 4 && k.splitk == 1 && !d->M_dev && !d->out_rows && blocks >= 256 &&
+      (d->Cout & 3) == 0 && (d->out_stride & 3) == 0 && (!d->res || (d->res_stride & 3) == 0)) {
+    switch (k.kchunks) {
+      case 1: hipLaunchKernelGGL(k_gemm_h2p<1>, grid, dim3(256), 0, s, k); break;
+      case 2: hipLaunchKernelGGL(k_gemm_h2p<2>, grid, dim3(256), 0, s, k); break;
+      case 3: hipLaunchKernelGGL(k_gemm_h2p<3>, grid, dim3(256), 0, s, k); break;
+      default: hipLaunchKernelGGL(k_gemm_h2p<4>, grid, dim3(256), 0, s, k); break;
+    }
+    COOCC_LAUNCH_CHECK("k_gemm_h2p");
+    return COOCC_OK;
+  }
   if (!zshare) {
     if (one) {
       if (table) hipLaunchKernelGGL((k_gemm_h2w<true, 1>), grid, dim3(256), 0, s, k);

@@ -54,17 +54,22 @@ def main():
         d = per_launch(sym)
         if d:
             out[alias] = dict(d, symbol=sym)
-    rays, ups = per_launch("void k_render_nearest"), per_launch("k_upsample_maps")
+    rays, ups = per_launch("void k_render_rays_geo") or per_launch("void k_render_nearest"), per_launch("k_upsample_maps")
     if rays and ups:
         out["k_render_nearest+k_upsample_maps"] = {cfg: dict(bytes_per_launch=rays["bytes_per_launch"] + ups["bytes_per_launch"],
                                                              rays=rays, upsample=ups)}
     # the pooling call (roofline_pool): its four launches together, per call
-    parts = [per_launch("void " + sym) or per_launch(sym) for sym in ("k_keys_hist", "k_scan_local", "k_csr_fill", "k_pool_sum_csr<true>")]
-    if all(parts):
+    parts = [per_launch("void " + sym) or per_launch(sym) for sym in ("k_seg_hist", "k_scan_local", "k_csr_fill", "k_pool_sum_seg")]
+    if all(parts):            # round 5: the ray-segment form
         out["coocc_lift_splat_cams"] = {cfg: dict(bytes_per_launch=sum(d["bytes_per_launch"] for d in parts),
-                                                   keys_hist=parts[0], scan_local=parts[1], csr_fill=parts[2], pool_sum_csr=parts[3])}
+                                                   seg_hist=parts[0], scan_local=parts[1], csr_fill=parts[2], pool_sum_seg=parts[3])}
+    else:
+        parts = [per_launch("void " + sym) or per_launch(sym) for sym in ("k_keys_hist", "k_scan_local", "k_csr_fill", "k_pool_sum_csr<true>")]
+        if all(parts):
+            out["coocc_lift_splat_cams"] = {cfg: dict(bytes_per_launch=sum(d["bytes_per_launch"] for d in parts),
+                                                       keys_hist=parts[0], scan_local=parts[1], csr_fill=parts[2], pool_sum_csr=parts[3])}
     for sym in ("k_wino_in_h2<6>", "k_wino_in_h2<4>", "k_rows_to_h2", "k_wino_in<6>", "k_wino_out<6>", "k_wino_in<4>", "k_wino_out<4>", "k_pool_sum_csr<true>", "k_key_hist", "k_fuser_prepare_rows",
-                "k_fine_mlp<true>", "k_fine_sample_img_grp", "k_fine_sample_voxel_r2"):
+                "k_fine_mlp<true>", "k_fine_sample_img_grp", "k_fine_sample_voxel_r2", "k_fine2_h2", "k_gemm_h2p", "k_pool_sum_seg", "k_seg_hist"):
         d = per_launch("void " + sym) or per_launch(sym)
         if d:
             out[sym] = d
