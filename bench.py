@@ -636,6 +636,7 @@ def train_main(args, model, dev, rank, world, seen_world, backend_name):
     core.check_h2_overflow()       # forward and backward operands of the last step stayed inside the f16 range
     core.TIMER.enabled = False
     dt = cdist.max_over_ranks(dt, dev)
+    windows = [dt]                  # the training line times ONE window of --steps steps (a step is 25-30 ms)
     ksum = core.TIMER.summary()
     roof = None
     # weight gradients: the split-f16 kernels (csrc/wgrad_h2.hip: three f16 MFMAs per product) and the fp32-MFMA rest; the
@@ -837,7 +838,7 @@ def main():
         run_eager = run
 
         def run(n, timed, S=1):
-            gp.time_dense = timed
+            gp.time_dense = timed and os.environ.get("COOCC_BENCH_TIME_DENSE", "1") != "0"
             gp.run(frames, n)
             with torch.cuda.stream(gp.dense_streams[0]):
                 drain_gathers()

@@ -140,7 +140,7 @@ SIGNATURES = {
     "coocc_upsample_trilinear_bwd": (I, [P, P, I, I, I, I, I, I, I, I, I, P]),
     "coocc_wino_input": (I, [P, I, I, I, I, I, I, I, P, L, P]),
     "coocc_wino_input_strided": (I, [P, I, I, I, I, I, I, I, P, I, L, P]),
-    "coocc_sparse_tap_sum": (I, [P, P, I, I, I, I, I, P, P, I, P]),
+    "coocc_sparse_tap_sum": (I, [P, P, I, I, I, I, I, P, P, I, I, P]),
     "coocc_wino_output": (I, [P, L, I, I, I, I, I, I, P, I, P, P, P, I, I, P]),
     "coocc_wino_output_ex": (I, [P, L, I, I, I, I, I, I, P, I, P, P, P, I, I, P, P]),
     "coocc_h2_overflow": (I, [I]),

@@ -758,6 +758,13 @@ __global__ __launch_bounds__(256) void k_scatter_fine_grouped(const float* __res
   }
 }
 
+// (a fill KERNEL, not hipMemsetAsync: this entry point is captured into hipGraphs, and a memset NODE in the middle of a captured
+// chain was found unreliable when several graphs replay concurrently -- csrc/knn.hip coocc_voxel_index_map_dev)
+__global__ __launch_bounds__(256) void k_fill_m1(int32_t* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = -1;
+}
+
 extern "C" int coocc_scatter_fine_grouped(const float* fine_logits, int ncls, int stride, const int32_t* coarse_lin, int n_cap,
                                           const int32_t* n_dev, int R, int Xc, int Yc, int Zc, float* grid, float empty_val,
                                           int32_t* map_ws, void* stream) {
@@ -768,7 +775,7 @@ extern "C" int coocc_scatter_fine_grouped(const float* fine_logits, int ncls, in
   hipStream_t s = as_stream(stream);
   const int V = Xc * Yc * Zc;
   if (coarse_lin) {                   // coarse_lin == NULL: map_ws already holds the voxel -> ordinal table (coocc_compact_flags_ex)
-    COOCC_HIP(hipMemsetAsync(map_ws, 0xFF, (size_t)V * 4, s));                    // -1 everywhere
+    hipLaunchKernelGGL(k_fill_m1, dim3(cdiv(V, 256)), dim3(256), 0, s, map_ws, V);   // -1 everywhere
     if (n_cap > 0) {
       hipLaunchKernelGGL(k_lin_ordinal_map, dim3(cdiv(n_cap, 256)), dim3(256), 0, s, coarse_lin, n_cap, n_dev, map_ws);
       COOCC_LAUNCH_CHECK("k_lin_ordinal_map");

@@ -281,10 +281,16 @@ __global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int
 
   for (int j = 1; j < m; ++j) {
     long long c0 = dbg ? clock64() : 0;
-    // (A) dirty test + refresh of the owned buckets
+    // (A) dirty test + refresh of the owned buckets.  Round 5: the dirty buckets of ALL register slots are fetched before the
+    // first one is refreshed (two per slot and round, as before): on the 200x200x16 grid a sample dirties ~64 buckets = ~4 per
+    // wave spread over 5 slots, and walking the slots one after the other put 4-5 L2 round trips in series on the critical
+    // path of every one of the 2047 dependent iterations (4.94 us); now one round trip covers them.
+    u64 bal[FPS_RMAX];
+    bool more = false;
 #pragma unroll
     for (int r = 0; r < FPS_RMAX; ++r) {
-      if (r * 64 * NW >= NB) break;
+      bal[r] = 0;
+      if (r * 64 * NW >= NB) continue;
       bool d = false;
       if (key[r]) {
         int x0 = org[r] & 1023, y0 = (org[r] >> 10) & 1023, z0 = org[r] >> 20;
@@ -293,23 +299,47 @@ __global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int
         int dz = max(max(z0 - sz, sz - (z0 + FT_Z - 1)), 0);
         d = (dx * dx + dy * dy + dz * dz) < (int)(key[r] >> RB);
       }
-      u64 bal = __ballot(d);
-      nd += __popcll(bal);
-      while (bal) {
-        const int s0 = (int)__ffsll((long long)bal) - 1;
-        bal &= bal - 1;
-        const bool two = bal != 0;                                // wave-uniform
-        const int s1 = two ? (int)__ffsll((long long)bal) - 1 : s0;
-        bal &= bal - 1;
+      bal[r] = __ballot(d);
+      nd += __popcll(bal[r]);
+      more = more || bal[r] != 0;
+    }
+    while (more) {                                                // wave-uniform
+      int s0v[FPS_RMAX], s1v[FPS_RMAX];
+      FpsCell ca[FPS_RMAX][2], cb[FPS_RMAX][2];
+      // phase 1: the loads of this round, all slots
+#pragma unroll
+      for (int r = 0; r < FPS_RMAX; ++r) {
+        s0v[r] = s1v[r] = -1;
+        if (!bal[r]) continue;                                    // wave-uniform
+        const int s0 = (int)__ffsll((long long)bal[r]) - 1;
+        bal[r] &= bal[r] - 1;
+        s0v[r] = s0;
+        const FpsCell* cp0 = cell + (size_t)((s0 + 64 * r) * NW + wave) * FT_P;
+        ca[r][0] = cp0[lane]; ca[r][1] = cp0[lane + 64];
+        if (bal[r]) {
+          const int s1 = (int)__ffsll((long long)bal[r]) - 1;
+          bal[r] &= bal[r] - 1;
+          s1v[r] = s1;
+          const FpsCell* cp1 = cell + (size_t)((s1 + 64 * r) * NW + wave) * FT_P;
+          cb[r][0] = cp1[lane]; cb[r][1] = cp1[lane + 64];
+        }
+      }
+      // phase 2: refresh + wave maxima + the owners' registers
+      more = false;
+#pragma unroll
+      for (int r = 0; r < FPS_RMAX; ++r) {
+        more = more || bal[r] != 0;
+        if (s0v[r] < 0) continue;                                 // wave-uniform
+        const int s0 = s0v[r], s1 = s1v[r];
+        const bool two = s1 >= 0;
         FpsCell* cp0 = cell + (size_t)((s0 + 64 * r) * NW + wave) * FT_P;
-        FpsCell* cp1 = cell + (size_t)((s1 + 64 * r) * NW + wave) * FT_P;
-        const FpsCell a0 = cp0[lane], a1 = cp0[lane + 64];
-        FpsCell b0 = a0, b1 = a1;
-        if (two) { b0 = cp1[lane]; b1 = cp1[lane + 64]; }
         KT best0, best1 = 0;
         int bp0, bp1 = 0;
-        refresh(cp0, a0, a1, __builtin_amdgcn_readlane(org[r], s0), best0, bp0);
-        if (two) refresh(cp1, b0, b1, __builtin_amdgcn_readlane(org[r], s1), best1, bp1);
+        refresh(cp0, ca[r][0], ca[r][1], __builtin_amdgcn_readlane(org[r], s0), best0, bp0);
+        if (two) {
+          FpsCell* cp1 = cell + (size_t)((s1 + 64 * r) * NW + wave) * FT_P;
+          refresh(cp1, cb[r][0], cb[r][1], __builtin_amdgcn_readlane(org[r], s1), best1, bp1);
+        }
         const KT wb0 = wave_max_key(best0);
         const KT wb1 = two ? wave_max_key(best1) : (KT)0;
         const int wp0 = __builtin_amdgcn_readlane(bp0, (int)__ffsll((long long)__ballot(best0 == wb0)) - 1);
@@ -597,6 +627,8 @@ extern "C" int coocc_fps_voxels(const int32_t* lin, int n, int X, int Y, int Z, 
     if (R <= 2) FPS_LAUNCH(T, 2, KT);         \
     else if (R <= 3) FPS_LAUNCH(T, 3, KT);    \
     else if (R <= 4) FPS_LAUNCH(T, 4, KT);    \
+    else if (R <= 5) FPS_LAUNCH(T, 5, KT);    \
+    else if (R <= 6) FPS_LAUNCH(T, 6, KT);    \
     else FPS_LAUNCH(T, 8, KT);                \
   } while (0)
 #define FPS_PICK(T)                           \
@@ -771,10 +803,22 @@ __global__ __launch_bounds__(256) void k_index_map_scatter(const int32_t* __rest
   if (i < n) map[lin[i]] = i;
 }
 
+__global__ __launch_bounds__(256) void k_fill_i32(int32_t* __restrict__ p, int n, int32_t v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 // the list length read on the device (n_dev; at most n_cap entries): no host round trip, grid sized for n_cap
 extern "C" int coocc_voxel_index_map_dev(const int32_t* lin, int n_cap, const int32_t* n_dev, int nvox, int32_t* map, void* stream) {
   COOCC_CHECK_ARG(map && nvox > 0 && n_cap > 0 && lin && n_dev, "voxel_index_map_dev: bad args");
-  COOCC_HIP(hipMemsetAsync(map, 0xFF, (size_t)nvox * 4, as_stream(stream)));
+  // -1 everywhere by a KERNEL: this form is captured into the serving hipGraphs (the scatter-form half of con_enc.0), and with
+  // hipMemsetAsync -- a memset NODE in the middle of the captured chain -- k_sparse_tap_sum read stale bytes of the block's
+  // previous tenant instead of -1 once three graphs replayed concurrently for a while (ordinals like 610250240 -> a GPU memory
+  // fault: bench.py --config openocc / stress200 aborted in their second or third timed window; tools/jobs/gpu_r5_n.sh).
+  // COOCC_MAP_MEMSET=1 restores the memset node.
+  static const bool fill_kernel = !(getenv("COOCC_MAP_MEMSET") && atoi(getenv("COOCC_MAP_MEMSET")) == 1);
+  if (fill_kernel) hipLaunchKernelGGL(k_fill_i32, dim3(cdiv(nvox, 256)), dim3(256), 0, as_stream(stream), map, nvox, -1);
+  else COOCC_HIP(hipMemsetAsync(map, 0xFF, (size_t)nvox * 4, as_stream(stream)));
   hipLaunchKernelGGL(k_index_map_scatter, dim3(cdiv(n_cap, 256)), dim3(256), 0, as_stream(stream), lin, n_cap, map, n_dev);
   COOCC_LAUNCH_CHECK("k_index_map_scatter");
   return COOCC_OK;

@@ -16,7 +16,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_sparse_tap_sum(const float* __restrict__ P, const int32_t* __restrict__ map, int X, int Y,
                                                          int Z, int nvox, int Cout, const float* __restrict__ scale,
-                                                         float* __restrict__ S, int s_stride) {
+                                                         float* __restrict__ S, int s_stride, int p_rows) {
   const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   if (v >= nvox) return;
   const int z = v % Z, y = (v / Z) % Y, x = (v / (Z * Y)) % X, b = v / (Z * Y * X);
@@ -33,6 +33,10 @@ __global__ __launch_bounds__(256) void k_sparse_tap_sum(const float* __restrict_
           if ((unsigned)ux >= (unsigned)X || (unsigned)uy >= (unsigned)Y || (unsigned)uz >= (unsigned)Z) continue;
           const int ord = map[((b * X + ux) * Y + uy) * Z + uz];        // wave-uniform
           if (ord < 0) continue;
+          if (p_rows > 0 && ord >= p_rows) {                      // an ordinal past the rows P was sized for is never valid: say so
+            if (lane == 0 && (v & 1023) == 0) printf("k_sparse_tap_sum: voxel %d tap %d ordinal %d >= %d rows\n", v, t, ord, p_rows);
+            continue;                                             // (instead of a GPU memory fault; found the memset-node problem of
+          }                                                       //  coocc_voxel_index_map_dev in round 5)
           if (on) acc = acc + *(const f32x4*)(P + (size_t)ord * prow + (size_t)t * Cout + c);
         }
     if (on) {
@@ -46,14 +50,14 @@ __global__ __launch_bounds__(256) void k_sparse_tap_sum(const float* __restrict_
 }
 
 extern "C" int coocc_sparse_tap_sum(const float* P, const int32_t* map, int B, int X, int Y, int Z, int Cout, const float* scale,
-                                    float* S, int s_stride, void* stream) {
+                                    float* S, int s_stride, int p_rows, void* stream) {
   COOCC_CHECK_ARG(P && map && S && B > 0 && X > 0 && Y > 0 && Z > 0 && Cout > 0 && Cout % 4 == 0 && s_stride % 4 == 0 &&
                       s_stride >= Cout, "sparse_tap_sum: bad args");
   COOCC_CHECK_ARG(((uintptr_t)P & 15) == 0 && ((uintptr_t)S & 15) == 0 && (!scale || ((uintptr_t)scale & 15) == 0), "sparse_tap_sum: alignment");
   const long long nvox = (long long)B * X * Y * Z;
   COOCC_CHECK_ARG(nvox < (1ll << 31), "sparse_tap_sum: grid too large");
   hipLaunchKernelGGL(k_sparse_tap_sum, dim3(cdiv(nvox, 4)), dim3(256), 0, as_stream(stream), P, map, X, Y, Z, (int)nvox, Cout, scale, S,
-                     s_stride);
+                     s_stride, p_rows);
   COOCC_LAUNCH_CHECK("k_sparse_tap_sum");
   return COOCC_OK;
 }

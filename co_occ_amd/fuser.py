@@ -634,6 +634,6 @@ class BiFuser_N(nn.Module):
         else:
             call("coocc_voxel_index_map", ptr(lin_pts), Np, V, ptr(vmap))
         S = core.Rows(torch.empty(V, Co, device=dev, dtype=_F32), cat4.B, cat4.X, cat4.Y, cat4.Z, Co)
-        call("coocc_sparse_tap_sum", ptr(P), ptr(vmap), cat4.B, cat4.X, cat4.Y, cat4.Z, Co, ptr(pd.scale), ptr(S.t), Co)
+        call("coocc_sparse_tap_sum", ptr(P), ptr(vmap), cat4.B, cat4.X, cat4.Y, cat4.Z, Co, ptr(pd.scale), ptr(S.t), Co, int(Np))
         out = core.Rows(torch.empty(V, Co, device=dev, dtype=_F32), cat4.B, cat4.X, cat4.Y, cat4.Z, Co)
         return core.conv_rows_wino(cat4, pd, out, True, S, plan, in_ranges=[(0, C), (3 * C, C)])

@@ -372,7 +372,7 @@ class _SparseEncoderBase(nn.Module):
                     key = "res%d" % si
                     h = torch.relu(bn(subm(f, m.net[0], cur, key), m.net[1]))
                     f = torch.relu(bn(subm(h, m.net[3], cur, key), m.net[4]) + f)
-        f = gn(subm(f, self.conv_out[0], cur, "out"), self.conv_out[1])
+        f = gn(subm(f, self.conv_out[0], cur, "res2"), self.conv_out[1])
         cur.feats = f
         D, H, W = cur.shape
         rows = ((cur.coors[:, 2].long() * H + cur.coors[:, 1]) * D + cur.coors[:, 0]).int().contiguous()   # (x*H + y)*D + z
@@ -411,7 +411,9 @@ class _SparseEncoderBase(nn.Module):
                     tb = cur.subm_table("res%d" % si)
                     h, hh = sparse_conv(f, f.shape[1], item[1], tb, relu=True, feats_h2=fh, twin=True)
                     f, fh = sparse_conv(h, h.shape[1], item[2], tb, relu=True, res=f, feats_h2=hh, twin=True)
-        f = _gn_rows(sparse_conv(f, f.shape[1], p["out"], cur.subm_table("out"), relu=False, feats_h2=fh), self.conv_out[1])
+        # conv_out is a SubMConv3d on the last stage's active set: the rule book of that stage's blocks ("res2") is its own
+        f = _gn_rows(sparse_conv(f, f.shape[1], p["out"], cur.subm_table("res%d" % (len(p["stages"]) - 1)), relu=False, feats_h2=fh),
+                     self.conv_out[1])
         # (the split-f16 range guard is sticky: the flag a layer here may raise is read at the detector's next host read,
         # core.check_h2_overflow -- head.py / serving.py)
         cur.feats = f

@@ -292,9 +292,10 @@ int coocc_wino_input_h2_ex(const float* in, int in_stride, int B, int X, int Y, 
                            int vstride, int64_t group_rows, float scale, const float* scale_dev, void* stream);
 /* Scatter-form sparse half of a dense 3x3x3 convolution (csrc/sparse_taps.hip): P:[Np][27][Cout] = per occupied input voxel
  * and tap the contribution W_t . in[u] (a row-table coocc_conv_fwd with N = 27*Cout), map: voxel -> row of P or -1
- * (coocc_voxel_index_map); S[v][n] = scale[n] * sum_t P[map[v + t - 1]][t][n], taps in order (deterministic). */
+ * (coocc_voxel_index_map); S[v][n] = scale[n] * sum_t P[map[v + t - 1]][t][n], taps in order (deterministic).  p_rows > 0: rows of
+ * P; a map entry >= p_rows is reported (device printf) and skipped instead of dereferenced. */
 int coocc_sparse_tap_sum(const float* P, const int32_t* map, int B, int X, int Y, int Z, int Cout, const float* scale,
-                         float* S, int s_stride, void* stream);
+                         float* S, int s_stride, int p_rows, void* stream);
 int coocc_wino_output(const float* Mb, int64_t group_rows, int B, int X, int Y, int Z, int C, int tile, float* out,
                       int out_stride, const float* scale, const float* bias, const float* res, int res_stride,
                       int relu, void* stream);
