@@ -201,6 +201,26 @@ __device__ __forceinline__ unsigned wave_max_key(unsigned v) {
   return max(max(a, b), max(c, d));
 }
 __device__ __forceinline__ u64 wave_max_key(u64 v) { return wave_max_u64(v); }
+// maximum over each 16-lane row, left in every lane of the row
+__device__ __forceinline__ unsigned row_max_key(unsigned v) {
+  v = max(v, dpp_u32<0xB1>(v));
+  v = max(v, dpp_u32<0x4E>(v));
+  v = max(v, dpp_u32<0x141>(v));
+  v = max(v, dpp_u32<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ u64 row_max_key(u64 v) {
+  u64 o;
+  o = dpp_u64<0xB1>(v); v = U64MAX(v, o);
+  o = dpp_u64<0x4E>(v); v = U64MAX(v, o);
+  o = dpp_u64<0x141>(v); v = U64MAX(v, o);
+  o = dpp_u64<0x140>(v); v = U64MAX(v, o);
+  return v;
+}
+__device__ __forceinline__ unsigned first_lane_key(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 first_lane_key(u64 v) {
+  return ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+}
 
 // Bucket b is owned by lane ((b / NW) % 64) of wave (b % NW), slot (b / NW) / 64: its cached best
 // key, the position of that point and the bucket origin live in that lane's VGPRs, so the dirty
@@ -271,7 +291,7 @@ __global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int
       const int p = lane + 64 * h;
       if (c.r >= 0) {
         int ex = x0 + (p >> 5) - sx, ey = y0 + ((p >> 3) & 3) - sy, ez = z0 + (p & 7) - sz;
-        int t = min(ex * ex + ey * ey + ez * ez, c.temp);
+        int t = min(__mul24(ex, ex) + __mul24(ey, ey) + __mul24(ez, ez), c.temp);
         cp[p].temp = t;
         KT kk = (KT)(((KT)t << RB) | (rmask - (KT)c.r));
         if (kk > best) { best = kk; bp = p; }
@@ -281,65 +301,35 @@ __global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int
 
   for (int j = 1; j < m; ++j) {
     long long c0 = dbg ? clock64() : 0;
-    // (A) dirty test + refresh of the owned buckets.  Round 5: the dirty buckets of ALL register slots are fetched before the
-    // first one is refreshed (two per slot and round, as before): on the 200x200x16 grid a sample dirties ~64 buckets = ~4 per
-    // wave spread over 5 slots, and walking the slots one after the other put 4-5 L2 round trips in series on the critical
-    // path of every one of the 2047 dependent iterations (4.94 us); now one round trip covers them.
-    u64 bal[FPS_RMAX];
-    bool more = false;
+    // (A) dirty test + refresh of the owned buckets (squares as 24-bit multiplies: v_mul_lo_u32 is quarter rate)
 #pragma unroll
     for (int r = 0; r < FPS_RMAX; ++r) {
-      bal[r] = 0;
-      if (r * 64 * NW >= NB) continue;
+      if (r * 64 * NW >= NB) break;
       bool d = false;
       if (key[r]) {
         int x0 = org[r] & 1023, y0 = (org[r] >> 10) & 1023, z0 = org[r] >> 20;
         int dx = max(max(x0 - sx, sx - (x0 + FT_X - 1)), 0);
         int dy = max(max(y0 - sy, sy - (y0 + FT_Y - 1)), 0);
         int dz = max(max(z0 - sz, sz - (z0 + FT_Z - 1)), 0);
-        d = (dx * dx + dy * dy + dz * dz) < (int)(key[r] >> RB);
+        d = (__mul24(dx, dx) + __mul24(dy, dy) + __mul24(dz, dz)) < (int)(key[r] >> RB);
       }
-      bal[r] = __ballot(d);
-      nd += __popcll(bal[r]);
-      more = more || bal[r] != 0;
-    }
-    while (more) {                                                // wave-uniform
-      int s0v[FPS_RMAX], s1v[FPS_RMAX];
-      FpsCell ca[FPS_RMAX][2], cb[FPS_RMAX][2];
-      // phase 1: the loads of this round, all slots
-#pragma unroll
-      for (int r = 0; r < FPS_RMAX; ++r) {
-        s0v[r] = s1v[r] = -1;
-        if (!bal[r]) continue;                                    // wave-uniform
-        const int s0 = (int)__ffsll((long long)bal[r]) - 1;
-        bal[r] &= bal[r] - 1;
-        s0v[r] = s0;
-        const FpsCell* cp0 = cell + (size_t)((s0 + 64 * r) * NW + wave) * FT_P;
-        ca[r][0] = cp0[lane]; ca[r][1] = cp0[lane + 64];
-        if (bal[r]) {
-          const int s1 = (int)__ffsll((long long)bal[r]) - 1;
-          bal[r] &= bal[r] - 1;
-          s1v[r] = s1;
-          const FpsCell* cp1 = cell + (size_t)((s1 + 64 * r) * NW + wave) * FT_P;
-          cb[r][0] = cp1[lane]; cb[r][1] = cp1[lane + 64];
-        }
-      }
-      // phase 2: refresh + wave maxima + the owners' registers
-      more = false;
-#pragma unroll
-      for (int r = 0; r < FPS_RMAX; ++r) {
-        more = more || bal[r] != 0;
-        if (s0v[r] < 0) continue;                                 // wave-uniform
-        const int s0 = s0v[r], s1 = s1v[r];
-        const bool two = s1 >= 0;
+      u64 bal = __ballot(d);
+      nd += __popcll(bal);
+      while (bal) {
+        const int s0 = (int)__ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        const bool two = bal != 0;                                // wave-uniform
+        const int s1 = two ? (int)__ffsll((long long)bal) - 1 : s0;
+        bal &= bal - 1;
         FpsCell* cp0 = cell + (size_t)((s0 + 64 * r) * NW + wave) * FT_P;
+        FpsCell* cp1 = cell + (size_t)((s1 + 64 * r) * NW + wave) * FT_P;
+        const FpsCell a0 = cp0[lane], a1 = cp0[lane + 64];
+        FpsCell b0 = a0, b1 = a1;
+        if (two) { b0 = cp1[lane]; b1 = cp1[lane + 64]; }
         KT best0, best1 = 0;
         int bp0, bp1 = 0;
-        refresh(cp0, ca[r][0], ca[r][1], __builtin_amdgcn_readlane(org[r], s0), best0, bp0);
-        if (two) {
-          FpsCell* cp1 = cell + (size_t)((s1 + 64 * r) * NW + wave) * FT_P;
-          refresh(cp1, cb[r][0], cb[r][1], __builtin_amdgcn_readlane(org[r], s1), best1, bp1);
-        }
+        refresh(cp0, a0, a1, __builtin_amdgcn_readlane(org[r], s0), best0, bp0);
+        if (two) refresh(cp1, b0, b1, __builtin_amdgcn_readlane(org[r], s1), best1, bp1);
         const KT wb0 = wave_max_key(best0);
         const KT wb1 = two ? wave_max_key(best1) : (KT)0;
         const int wp0 = __builtin_amdgcn_readlane(bp0, (int)__ffsll((long long)__ballot(best0 == wb0)) - 1);
@@ -370,16 +360,11 @@ __global__ __launch_bounds__(THREADS) void k_fps_voxels(int n, int m, int Y, int
     // (16 waves x a 15-step compare/select chain was ~1/3 of the per-sample critical path)
     KT g;
     int gl;
-    if constexpr (sizeof(KT) == 4 && NW <= 16) {
+    if constexpr (NW <= 16) {   // both key widths (round 5: the 64-bit keys of the large grids walked a 15-step compare chain here)
       const int li = lane & 15;
       const KT mine = li < NW ? wbest[j & 1][li] : (KT)0;
       const int ml = li < NW ? wloc[j & 1][li] : 0;
-      KT v = mine;
-      v = max(v, (KT)dpp_u32<0xB1>(v));
-      v = max(v, (KT)dpp_u32<0x4E>(v));
-      v = max(v, (KT)dpp_u32<0x141>(v));
-      v = max(v, (KT)dpp_u32<0x140>(v));
-      g = (KT)__builtin_amdgcn_readfirstlane((int)v);
+      g = first_lane_key(row_max_key(mine));
       const u64 own = __ballot(mine == g) & 0xFFFFull;
       gl = __builtin_amdgcn_readlane(ml, (int)__ffsll((long long)own) - 1);
     } else {
@@ -485,7 +470,7 @@ __global__ __launch_bounds__(1024) void k_fps_voxels_reg(FpsRegArgs a) {
       const int dx = max(max(x0 - sx, sx - (x0 + FT_X - 1)), 0);
       const int dy = max(max(y0 - sy, sy - (y0 + FT_Y - 1)), 0);
       const int dz = max(max(z0 - sz, sz - (z0 + FT_Z - 1)), 0);
-      d = (unsigned)(dx * dx + dy * dy + dz * dz) < (key >> RB);
+      d = (unsigned)(__mul24(dx, dx) + __mul24(dy, dy) + __mul24(dz, dz)) < (key >> RB);   // 24-bit multiplies: full rate
     }
     u64 bal = __ballot(d);
     nd += __popcll(bal);
@@ -496,8 +481,8 @@ __global__ __launch_bounds__(1024) void k_fps_voxels_reg(FpsRegArgs a) {
       const int o = __builtin_amdgcn_readlane(org, s0);
       // squared distances of this lane's two positions of the bucket (lane, lane + 64: x + 2) to the new sample
       const int ex = (o & 1023) + exb, ey = ((o >> 10) & 1023) + eyb, ez = (o >> 20) + ezb;
-      const int yz = ey * ey + ez * ez;
-      const unsigned d0 = (unsigned)(ex * ex + yz), d1 = (unsigned)((ex + 2) * (ex + 2) + yz);
+      const int yz = __mul24(ey, ey) + __mul24(ez, ez);
+      const unsigned d0 = (unsigned)(__mul24(ex, ex) + yz), d1 = (unsigned)(__mul24(ex + 2, ex + 2) + yz);
       unsigned k0, k1;
       if (s0 < 32) { k0 = ca0[s0]; k1 = ca1[s0]; }
       else { k0 = cb0[s0 - 32]; k1 = cb1[s0 - 32]; }

@@ -2,6 +2,7 @@
 # Round-5 profile collection on the GPU box (writes under gpurun_out/prof_r5/; copy into profiles/ afterwards).  Every rocprofv3
 # run is bounded by `timeout`; counter passes are separate from the --kernel-trace --stats passes (MI355X guide).
 set -u
+ulimit -c 0
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_r5
 mkdir -p $O
@@ -11,6 +12,7 @@ timeout 300 python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/nu
 timeout 400 python $R/bench.py > $O/r5_bench_default.json 2> $O/r5_bench_default.err        # the driver's command
 timeout 300 python $R/bench.py --steps 40 --warmup 3 --no-cpu-baseline --kernel-table > $O/r5_bench_kernel_table.json 2> $O/r5_bench_kernel_table.txt
 timeout 300 python $R/bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-kernel-timing --api simple_test > $O/r5_bench_api_simple_test.json 2>/dev/null
+timeout 300 python $R/bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-kernel-timing --api pipelined_test > $O/r5_bench_api_pipelined_test.json 2>/dev/null
 timeout 300 python $R/bench.py --steps 40 --warmup 3 --no-cpu-baseline --graph 0 > $O/r5_bench_eager.json 2>/dev/null
 COOCC_CONV_ENGINE=f32 timeout 300 python $R/bench.py --steps 40 --warmup 3 --no-cpu-baseline > $O/r5_bench_engine_f32.json 2>/dev/null
 timeout 300 python $R/bench.py --train --steps 10 --warmup 2 > $O/r5_bench_train.json 2> $O/r5_bench_train.err
@@ -104,6 +106,7 @@ for r in rows[:32]:
 print("sum %.1f us per sample" % tot)
 PY
 timeout 300 python $R/tools/kbench.py fps pool 2>&1 | grep -v amdgpu.ids > $O/r5_kbench_search.txt
+cp $O/r5_kbench_search.txt $O/r5_kbench_fps.txt
 timeout 300 python $R/tools/kbench.py trainfull 2>&1 | grep -v amdgpu.ids > $O/r5_kbench_train.txt
 cut -c1-1500 $O/r5_bench_default.json
 for f in $O/r5_bench_*.json; do python - <<PY

@@ -394,12 +394,13 @@ def bench_fpsdbg():
     import ctypes
     from co_occ_amd import _lib
     lib = _lib.load()
-    li, lp = voxel_lists((100, 100, 8))
+    grid = tuple(int(v) for v in os.environ.get("COOCC_FPSDBG_GRID", "100,100,8").split(","))
+    li, lp = voxel_lists(grid)
     dbg = torch.zeros(16 * 8, device=dev, dtype=torch.int64)
     lib.coocc_fps_voxels_set_debug(ctypes.c_void_p(dbg.data_ptr()))
     for name, lin in (("img", li), ("pts", lp)):
         dbg.zero_()
-        fuser._fps_voxels(lin, (100, 100, 8), 2048)
+        fuser._fps_voxels(lin, grid, 2048)
         torch.cuda.synchronize()
         d = dbg.view(16, 8).cpu()
         print(name, "per-iteration cycles by wave [test+refresh, wave max, barrier, tail | dirty buckets total]")
