@@ -83,6 +83,27 @@ def test_pipelined_test_loop_equals_per_sample_calls(dev):
     assert n == 16
 
 
+def test_scatter_form_con_enc0_survives_three_graphs_in_flight(dev, monkeypatch):
+    """Regression (round 5): grids above ``fuser.DENSE_C0_MAX_VOXELS`` run ``con_enc.0`` split by channel support, whose captured
+    chain resets a voxel -> ordinal map.  As a ``hipMemsetAsync`` NODE that reset left stale bytes when several graphs replayed
+    concurrently (garbage ordinals in ``k_sparse_tap_sum``: ``bench.py --config openocc / stress200`` aborted); it is a fill
+    kernel now.  Forced here on the 100x100x8 grid: 24 samples through 6 slots / 3 dense streams, bit-equal to eager calls."""
+    from co_occ_amd import apis, fuser
+    monkeypatch.setattr(fuser, "DENSE_C0_MAX_VOXELS", 1000)
+    bench, model, samples, gts = _setup(dev)
+    kws = [dict(bench.simple_test_kwargs(s), gt_occ=g) for s, g in zip(samples, gts)]
+    with torch.no_grad():
+        model.graph_simple_test = False
+        ref = [_grab(model.simple_test(**kw)) for kw in kws]
+    data = [dict(precomputed=kw["precomputed"], gt_occ=kw["gt_occ"]) for kw in kws] * 3
+    n = 0
+    for i, (d, res) in enumerate(apis.pipelined_test(model, iter(data), slots=6, dense_streams=3)):
+        got = {k: res[k].clone() for k in KEYS}
+        _same({k: ref[i % 8][k] for k in got}, got, "sample %d" % i)
+        n += 1
+    assert n == 24
+
+
 def test_serving_takes_a_pooled_camera_volume_too(dev):
     """``precomputed=dict(img_voxel_feats=...)`` (the camera volume already pooled) through the captured form."""
     bench, model, samples, gts = _setup(dev, n=2)
