@@ -997,7 +997,7 @@ __global__ __launch_bounds__(256) void k_pool_sum_seg(const float* __restrict__ 
                                                        const uint32_t* __restrict__ ids, const int32_t* __restrict__ start,
                                                        const int32_t* __restrict__ long_list, const int32_t* __restrict__ nlong_p,
                                                        int long_blocks, int nvox, int C, int D, int HW, const float* __restrict__ rowmax,
-                                                       float* __restrict__ out, int out_stride, int ablate) {
+                                                       float* __restrict__ out, int out_stride, int ablate, int gX, int gY, int gZ) {
   __shared__ __attribute__((aligned(16))) double part[16 * 128];      // long voxels: 16 partial rows of 128 channels (16 KB)
   __shared__ uint32_t erow[SEG_LDS_ENTRIES];                           // ... and their (row, weight) pairs
   __shared__ float ew[SEG_LDS_ENTRIES];
@@ -1021,8 +1021,20 @@ __global__ __launch_bounds__(256) void k_pool_sum_seg(const float* __restrict__ 
   if (ablate & 2) D = 0x7fffffff;                                 // timing experiment: every row gather reads row 0
   uint32_t* lds = sid + wave * POOL_MEDIUM;
   float* ldw = sw + wave * POOL_MEDIUM;
+  // gX > 0 (COOCC_POOL_XCD=1, one batch): workgroup b runs on XCD b % 8 and takes its voxels from that XCD's own sector of the
+  // grid -- quadrant (b & 1, (b >> 1) & 1) of the x-y plane, x parity (b >> 2) inside it -- so the context rows an XCD gathers
+  // belong to the two or three cameras that look into its quadrant and stay in its L2; the x parity split keeps the XCDs of
+  // one quadrant equally loaded.  t = position in the sector's own (x / 2, y, z) order.
+  auto sector_voxel = [&](int t) -> int {
+    const int hx = (gX + 1) >> 1, hy = (gY + 1) >> 1, k = b & 7;
+    const int z = t % gZ; int q = t / gZ;
+    const int j = q % hy, i = q / hy;
+    const int x = (k & 1) * hx + 2 * i + (k >> 2), y = ((k >> 1) & 1) * hy + j;
+    const bool ok = x < min(((k & 1) + 1) * hx, gX) && y < min((((k >> 1) & 1) + 1) * hy, gY);
+    return ok ? (x * gY + y) * gZ + z : nvox;
+  };
   if (V8) {
-    const int vg = (chunk * 4 + wave) * 4 + (lane >> 4);         // this 16-lane group's voxel
+    const int vg = gX > 0 ? sector_voxel(((b >> 3) * 4 + wave) * 4 + (lane >> 4)) : (chunk * 4 + wave) * 4 + (lane >> 4);         // this 16-lane group's voxel
     const bool on = vg < nvox;
     const int sg = on ? start[vg] : 0, ng = on ? start[vg + 1] - sg : 0;
     seg_rows16<V8 ? V8 : 4, REUSE>(x, depth, wts, slot, ids, sg, ng, on, lane, C, D, HW, out + (size_t)(on ? vg : 0) * out_stride);
@@ -1031,12 +1043,12 @@ __global__ __launch_bounds__(256) void k_pool_sum_seg(const float* __restrict__ 
       const int n = __builtin_amdgcn_readlane(ng, g * 16);
       if (n <= 16 || n > POOL_MEDIUM) continue;
       const int s = __builtin_amdgcn_readlane(sg, g * 16);
-      const int v = (chunk * 4 + wave) * 4 + g;
+      const int v = __builtin_amdgcn_readlane(vg, g * 16);
       seg_row<2, REUSE>(x, depth, wts, slot, ids, s, n, lane, C, D, HW, out + (size_t)v * out_stride, lds, ldw);
     }
     return;
   }
-  const int v = __builtin_amdgcn_readfirstlane(chunk * 4 + wave);
+  const int v = __builtin_amdgcn_readfirstlane(gX > 0 ? sector_voxel((b >> 3) * 4 + wave) : chunk * 4 + wave);
   if (v >= nvox) return;
   const int s = start[v], n = start[v + 1] - s;
   if (n > POOL_MEDIUM) return;
@@ -1117,24 +1129,28 @@ static bool pool_seg_on() {               // read per call: tests compare the tw
 
 template <bool REUSE>
 static int pool_sums_seg(const float* x, const float* depth, int C, int D, int HW, int nvox, long long npts, float* out, int out_stride,
-                         const PoolWs& p, hipStream_t s) {
+                         const PoolWs& p, hipStream_t s, int X = 0, int Y = 0, int Z = 0) {
+  static const bool xcd = getenv("COOCC_POOL_XCD") && atoi(getenv("COOCC_POOL_XCD")) != 0;
+  const bool sect = xcd && X > 0 && (long long)X * Y * Z == nvox;                   // one batch: the sector order is per grid
+  const int gX = sect ? X : 0, gY = sect ? Y : 0, gZ = sect ? Z : 0;
+  const int sector = sect ? (((X + 1) / 2 + 1) / 2) * ((Y + 1) / 2) * Z : 0;         // voxels per XCD sector
   static const int long_blocks = getenv("COOCC_POOL_LONG_BLOCKS") ? atoi(getenv("COOCC_POOL_LONG_BLOCKS")) : 1024;
   static const bool g16 = !(getenv("COOCC_POOL_G16") && atoi(getenv("COOCC_POOL_G16")) == 0);
   static const int ablate = getenv("COOCC_POOL_ABLATE") ? atoi(getenv("COOCC_POOL_ABLATE")) : 0;      // timing experiments (results wrong)
   // four voxels per wave pay when most voxels hold <= 16 segments: r50 has 5.9 points per voxel (2.6 segments per non-empty
   // voxel), r101 47 (15 segments; there the groups that sit out cost more than the packing saves: 134 against 117 us)
   if (g16 && (C == 128 || C == 64) && npts < 16ll * nvox) {
-    const int short_blocks = 8 * cdiv(cdiv(nvox, 16), 8);
+    const int short_blocks = sect ? 8 * cdiv(sector, 16) : 8 * cdiv(cdiv(nvox, 16), 8);
     if (C == 128)
       hipLaunchKernelGGL((k_pool_sum_seg<REUSE, 8>), dim3(long_blocks + short_blocks), dim3(256), 0, s, x, depth, p.wcsr, p.slot, p.ids,
-                         p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, p.rowmax, out, out_stride, ablate);
+                         p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, p.rowmax, out, out_stride, ablate, gX, gY, gZ);
     else
       hipLaunchKernelGGL((k_pool_sum_seg<REUSE, 4>), dim3(long_blocks + short_blocks), dim3(256), 0, s, x, depth, p.wcsr, p.slot, p.ids,
-                         p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, p.rowmax, out, out_stride, ablate);
+                         p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, p.rowmax, out, out_stride, ablate, gX, gY, gZ);
   } else {
-    const int short_blocks = 8 * cdiv(cdiv(nvox, 4), 8);
+    const int short_blocks = sect ? 8 * cdiv(sector, 4) : 8 * cdiv(cdiv(nvox, 4), 8);
     hipLaunchKernelGGL((k_pool_sum_seg<REUSE, 0>), dim3(long_blocks + short_blocks), dim3(256), 0, s, x, depth, p.wcsr, p.slot, p.ids,
-                       p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, p.rowmax, out, out_stride, ablate);
+                       p.start, p.long_list, p.nlong, long_blocks, nvox, C, D, HW, p.rowmax, out, out_stride, ablate, gX, gY, gZ);
   }
   COOCC_LAUNCH_CHECK("voxel_pool (segments)");
   return COOCC_OK;
@@ -1155,7 +1171,7 @@ static int pool_build_seg(const KeySrc& ks, const float* x, const float* depth, 
   const int fill_blocks = max(cdiv(npts, 1024), 1);
   hipLaunchKernelGGL(k_csr_fill, dim3(fill_blocks), dim3(256), sizeof(int) * ((size_t)nblk + 1), s, p.keys, npts, nvox, nblk, p.lstart, p.tops,
                      p.slot, p.count, p.start, p.long_list, p.nlong, p.ids, SEG_SLOT_MASK, p.wts, p.wcsr);
-  return pool_sums_seg<false>(x, depth, C, D, HW, nvox, npts, out, out_stride, p, s);
+  return pool_sums_seg<false>(x, depth, C, D, HW, nvox, npts, out, out_stride, p, s, X, Y, Z);
 }
 
 extern "C" int coocc_voxel_pool(const float* x, const float* geom, int npts, int pts_per_batch, int C,

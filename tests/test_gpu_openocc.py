@@ -140,7 +140,7 @@ def test_openocc_decoder_fp32_and_bf16_at_full_size(dev, monkeypatch):
         assert e(hf16[i], o64[i]) <= 1.5 * e(of16[i], o64[i]) + 1e-4 and r(hf16[i], o64[i]) <= 1.5 * r(of16[i], o64[i]) + 1e-5, lines[-1]
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    with open(os.path.join(d, "r4_openocc_parity.txt"), "a") as f:
+    with open(os.path.join(d, "r5_openocc_parity.txt"), "a") as f:
         f.write("\n".join(lines) + "\n")
 
 
@@ -285,7 +285,7 @@ def test_openocc_end_to_end_vs_subsampled_oracle(dev, monkeypatch, dtype):
     assert tuple(out["pred_f"].shape) == (1, 17) + tuple(c["final_occ_size"])
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    with open(os.path.join(d, "r4_openocc_parity.txt"), "a") as f:
+    with open(os.path.join(d, "r5_openocc_parity.txt"), "a") as f:
         f.write("\n".join(lines) + "\n")
     for l in lines:
         print(l, flush=True)

@@ -10,7 +10,7 @@
 * one full-size ``configs[1]`` scene (100x100x8x128, 6 cameras 16x44, knum 2, render on) through the default dispatch --
   the dispatch bench.py times -- and the r101 render pair (6 x 56 x 100 rays -> 6 x 896 x 1600 maps).
 
-The sweep table is written to gpurun_out/r4_parity_seed_sweep.txt (copied to profiles/); every line carries the ABSOLUTE errors
+The sweep table is written to gpurun_out/r5_parity_seed_sweep.txt (copied to profiles/); every line carries the ABSOLUTE errors
 and, in parentheses, the same errors as a fraction of the tensor's scale."""
 import os
 
@@ -40,7 +40,7 @@ SMALL_RANGE = (-25, -25, -5.0, 25, 25, 3.0)
 def _log(line):
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    with open(os.path.join(d, "r4_parity_seed_sweep.txt"), "a") as f:
+    with open(os.path.join(d, "r5_parity_seed_sweep.txt"), "a") as f:
         f.write(line + "\n")
     print(line, flush=True)
 
