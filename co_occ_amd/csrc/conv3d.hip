@@ -1276,9 +1276,10 @@ extern "C" int coocc_conv_fwd(const coocc_conv_desc* d, void* stream) {
   int splitk = d->splitk;
   if (splitk <= 0) {
     splitk = 1;
-    if (blocks < 256 && k.total_iters >= 16 && d->ws) {
+    static const int target = getenv("COOCC_SPLITK_TARGET") ? atoi(getenv("COOCC_SPLITK_TARGET")) : 512;
+    if (blocks < target / 2 && k.total_iters >= 16 && d->ws) {
       // fill (at most) one round of 512 resident workgroups: one more would double the time
-      splitk = (int)(512 / blocks);
+      splitk = (int)(target / blocks);
       if (splitk > k.total_iters / 8) splitk = k.total_iters / 8;
       if (splitk > 64) splitk = 64;
       while (splitk > 1 && (long long)splitk * d->M * k.Npad > d->ws_floats) --splitk;

@@ -823,8 +823,10 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
     // without arrival counters the reduction is a second launch; its vector form (k_conv_reduce4) writes the H2 / f16 / twin outputs
     const bool vec4 = (d->Cout & 3) == 0 && (d->out_stride & 3) == 0 && (!d->res || (d->res_stride & 3) == 0) && (((uintptr_t)d->out) & 15) == 0;
     const bool second_pass_ok = vec4 || (!d->out_h2 && !d->out16 && !d->out_h2_twin);
-    if (blocks < 256 && ngroups >= 8 && d->ws && !d->M_dev && (d->tile_sem ? true : (!d->out_rows && second_pass_ok))) {
-      splitk = (int)(512 / blocks);
+    // COOCC_SPLITK_TARGET: workgroups a split layer aims for (512 = two per CU: tuned with the layer alone on the chip)
+    static const int target = getenv("COOCC_SPLITK_TARGET") ? atoi(getenv("COOCC_SPLITK_TARGET")) : 512;
+    if (blocks < target / 2 && ngroups >= 8 && d->ws && !d->M_dev && (d->tile_sem ? true : (!d->out_rows && second_pass_ok))) {
+      splitk = (int)(target / blocks);
       if (splitk > ngroups / 4) splitk = ngroups / 4;
       if (splitk > 64) splitk = 64;
       while (splitk > 1 && (long long)splitk * d->M * k.Npad > d->ws_floats) --splitk;
