@@ -653,6 +653,164 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
   }
 }
 
+// k_gemm_h2n<NCW>: row-table GEMMs with 32 (NCW = 1) or 64 (NCW = 2) output channels -- the 32 -> 32 / 64 -> 64 / 32 -> 64 rule-book
+// layers of the sparse LiDAR encoder.  In k_gemm_h2w every wave owns 32 columns of a 128-column tile, so with Cout = 32 / 64 three /
+// two of the four waves multiply zero-padded weight columns, and the ablations of round 5 (profiles/r5_lidar_h2t_ablate.txt: a three-taps-per-round variant, k_gemm_h2t, since removed) put 63 % of
+// these launches in the MFMA / LDS instruction stream, not in the gathers.  Here the tile is 256 rows x 32 NCW columns: wave w owns
+// column block w % NCW of rows 256 / (4 / NCW) * (w / NCW) ..., i.e. every MFMA is a real one, per tile-row a quarter / half of the
+// MFMAs, weight loads and fragment reads.  Same stages, fragments, MFMA order per wave, tap order and epilogue expressions as
+// k_gemm_h2w<true>: a column's sum is formed in the same order -> the same bits.  No split-K (these layers have >= 256 tiles).
+template <int NCW>
+__global__ __launch_bounds__(256, 2) void k_gemm_h2n(ConvK p) {
+  constexpr int BM = 256, TM = NCW == 2 ? 4 : 2, NJ = BM / 32;        // NJ staging rows per lane and stage
+  constexpr unsigned STAGE = BM * 128;
+  __shared__ __attribute__((aligned(16))) char As[2 * BM * 128];
+
+  const int mtiles = (p.M + BM - 1) / BM;                               // p.M = capacity when the row count is on the device
+  const int mtile = blockIdx.x;
+  if (mtile >= mtiles) return;
+  const int m0 = mtile * BM;
+  if (p.M_dev) {
+    p.M = min(p.M, *p.M_dev);
+    if (m0 >= p.M) return;
+  }
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, h = lane >> 5;
+  const int srow = lane >> 3, slot = lane & 7;
+  const int colblk = NCW == 2 ? (wave & 1) : 0;
+  const int rowbase = NCW == 2 ? (wave >> 1) * 128 : wave * 64;         // first tile row of this wave's accumulators
+  const int taps = p.taps;
+  const long long rowbytes = (long long)p.in_stride * 4;
+  const char* inb = (const char*)p.in;
+  const char* zrow = (const char*)p.zrow;
+  const unsigned aq = (unsigned)((slot ^ ((4 * (wave & 1) + (srow >> 1)) & 7)) * 16);
+  int rix[NJ];                      // this lane's staging rows r = (4 j + wave) 8 + srow
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int m = m0 + (j * 4 + wave) * 8 + srow;
+    rix[j] = m < p.M ? m : -1;
+  }
+  const int nsteps = p.total_iters;
+  int ckc = 0, ct = 0;
+  const long long wstep = (long long)(p.Npad >> 5) * 4096;
+  const char* wcur = (const char*)p.w + (long long)colblk * 4096 + lane * 16;
+  const int gstride = p.gstride;
+  int tnext[NJ];                    // the source rows of the NEXT iteration (fetched one iteration ahead)
+  auto tload = [&]() {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) tnext[j] = rix[j] >= 0 ? p.gather[(size_t)ct * gstride + rix[j]] : -1;
+  };
+  if (nsteps > 0) tload();
+  auto issueA = [&](int buf) {
+    const long long coff = (long long)ckc * 128 + aq;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const char* src = tnext[j] >= 0 ? inb + ((long long)tnext[j] * rowbytes + coff) : zrow;
+      glds16_(src, &As[buf * STAGE + (j * 4 + wave) * 8 * 128]);
+    }
+    if (++ct == taps) { ct = 0; ++ckc; }
+    tload();                       // harmless past the last iteration: ct < taps always
+  };
+  f16x8 breg[2][2][2];        // [register set][k16 step][plane]
+  auto loadB = [&](auto bufc) {
+    constexpr int B_ = decltype(bufc)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) breg[B_][s][pl] = *(const f16x8*)(wcur + (s * 2 + pl) * 1024);
+    wcur += wstep;
+  };
+  unsigned fragoff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int sl = (q & 1) * 4 + 2 * (q >> 1) + h;            // q = 2 s + plane
+    fragoff[q] = (rowbase + li) * 128 + ((sl ^ ((li >> 1) & 7)) << 4);
+  }
+  f16x8 fr[2][TM];
+  auto load_frag = [&](auto bufc, auto stagec, auto qc) {
+    constexpr int BUF = decltype(bufc)::value, ST = decltype(stagec)::value, Q = decltype(qc)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fr[BUF][i] = *(const f16x8*)&As[fragoff[Q] + (ST * STAGE + i * 4096)];
+  };
+  auto load_plane = [&](auto planec, auto stagec, auto sc) {
+    constexpr int PL = decltype(planec)::value, S_ = decltype(sc)::value;
+    load_frag(planec, stagec, std::integral_constant<int, 2 * S_ + PL>{});
+  };
+  f32x16 hh[TM], xx[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hh[i][r] = 0.f; xx[i][r] = 0.f; }
+  auto p01 = [&](auto setc, auto sc) {
+    constexpr int B_ = decltype(setc)::value, S_ = decltype(sc)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) hh[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], fr[0][i], hh[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][1], fr[0][i], xx[i], 0, 0, 0);
+  };
+  auto p2 = [&](auto setc, auto sc) {
+    constexpr int B_ = decltype(setc)::value, S_ = decltype(sc)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(breg[B_][S_][0], fr[1][i], xx[i], 0, 0, 0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  auto step = [&](auto stc, bool more) {
+    constexpr int ST = decltype(stc)::value;
+    using STC = std::integral_constant<int, ST>; using SNC = std::integral_constant<int, ST ^ 1>;
+    if (more) { issueA(ST ^ 1); loadB(SNC{}); }
+    load_plane(I1{}, STC{}, I0{});
+    p01(STC{}, I0{});
+    H2_FENCE();
+    load_plane(I0{}, STC{}, I1{});
+    p2(STC{}, I0{});
+    H2_FENCE();
+    load_plane(I1{}, STC{}, I1{});
+    p01(STC{}, I1{});
+    H2_FENCE();
+    __syncthreads();            // every wave has read this stage for the last time; the next image has landed
+    if (more) load_plane(I0{}, SNC{}, I0{});
+    p2(STC{}, I1{});
+    H2_FENCE();
+  };
+  if (nsteps > 0) {
+    issueA(0);
+    loadB(I0{});
+  }
+  __syncthreads();
+  if (nsteps > 0) load_frag(I0{}, I0{}, I0{});
+  for (int st = 0; st < nsteps; st += 2) {
+    step(I0{}, st + 1 < nsteps);
+    if (st + 1 < nsteps) step(I1{}, st + 2 < nsteps);
+  }
+
+  // epilogue: lane (li, h) holds, for output row m0 + rowbase + i*32 + li, the channels 32 colblk + 8 j + 4 h + 0..3 (j = 0..3)
+  const int nb = colblk * 32 + 4 * h;
+  const float alpha = p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha, lo = alpha * (1.f / H2_LO_SCALE);
+  const bool vec = (p.Cout & 3) == 0 && (p.out_stride & 3) == 0 && (!p.res || (p.res_stride & 3) == 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + rowbase + i * 32 + li;
+    if (m >= p.M) continue;
+    const size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nb + 8 * j;
+      if (n >= p.Cout) continue;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = hh[i][4 * j + e] * alpha + xx[i][4 * j + e] * lo;
+      if (vec) {
+        h2_epilogue_vec(p, orow, n, v);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.Cout) p.out[orow * p.out_stride + n + e] = epilogue(p, v[e], n + e, orow);
+      }
+    }
+  }
+}
+
 // k_gemm_h2p: the pointwise layers (1x1x1, stride 1: input row = output row) with K <= 128 -- occ_pred_conv[0] + Q, input_proj,
 // voxel_soft_weights[0], the level-0 FPN lateral: 80 000 rows x 128 channels each.  They are HBM-bound (41 MB in, 41-123 MB out)
 // and ran at half that bound in k_gemm_h2w (40-65 us against 18-36): with one 16 KB stage in flight per workgroup and two
@@ -863,6 +1021,15 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
       if (table) hipLaunchKernelGGL((k_gemm_h2w<true, 1>), grid, dim3(256), 0, s, k);
       else hipLaunchKernelGGL((k_gemm_h2w<false, 1>), grid, dim3(256), 0, s, k);
     } else {
+      // narrow outputs (Cout <= 64) through a row table: 256-row tiles, every wave on real columns (k_gemm_h2n)
+      static const bool narrow_on = !(getenv("COOCC_H2_NARROW") && atoi(getenv("COOCC_H2_NARROW")) == 0);
+      if (narrow_on && table && k.Cout <= 64 && k.ntiles == 1 && k.splitk == 1 && !d->tile_sem && (long long)k.mtiles >= 512) {
+        const dim3 gridn((unsigned)((k.M + 255) / 256), 1);
+        if (k.Cout <= 32) hipLaunchKernelGGL(k_gemm_h2n<1>, gridn, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL(k_gemm_h2n<2>, gridn, dim3(256), 0, s, k);
+        COOCC_LAUNCH_CHECK("k_gemm_h2n");
+        return COOCC_OK;
+      }
       if (table) hipLaunchKernelGGL(k_gemm_h2w<true>, grid, dim3(256), 0, s, k);
       else hipLaunchKernelGGL(k_gemm_h2w<false>, grid, dim3(256), 0, s, k);
     }
