@@ -268,16 +268,25 @@ class _SpConv(nn.Module):
         nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
-    def packed(self, bn=None):
-        cin_p = _pad4(self.cin)
+    def packed(self, bn=None, cin_to=None, cout_to=None):
+        """``cin_to`` / ``cout_to``: zero-pad the input / output channels (the padded outputs are exact zeros: zero weights, zero
+        bias; only for layers without a folded BN) -- how a 16-channel layer feeds the split-f16 engine's 32-channel rows."""
+        cin_p = max(_pad4(self.cin), cin_to or 0)
         w = self.weight.detach().reshape(self.cout, self.ksize ** 3, self.cin)
         if cin_p != self.cin:       # rows are padded to a multiple of 4 channels for the 16-byte gathers
             w = torch.cat([w, w.new_zeros(self.cout, self.ksize ** 3, cin_p - self.cin)], 2)
-        return PackedConv(w.reshape(self.cout, -1).contiguous(), bn=bn, bias=self.bias, tap_major=True, taps=self.ksize ** 3)
+        bias = self.bias
+        if cout_to and cout_to > self.cout:
+            assert bn is None
+            w = torch.cat([w, w.new_zeros(cout_to - self.cout, self.ksize ** 3, cin_p)], 0)
+            b = self.bias.detach() if self.bias is not None else w.new_zeros(self.cout)
+            bias = torch.cat([b, b.new_zeros(cout_to - self.cout)])
+        return PackedConv(w.reshape(w.shape[0], -1).contiguous(), bn=bn, bias=bias, tap_major=True, taps=self.ksize ** 3)
 
 
-def _gn_rows(x, gn, relu=True):
-    call("coocc_groupnorm_rows", ptr(x), x.shape[0], x.shape[1], x.shape[1], gn.num_groups, ptr(gn.weight.detach()),
+def _gn_rows(x, gn, relu=True, C=None):
+    """In-place GroupNorm (+ ReLU) of the first ``C`` channels of the rows (default: all of them)."""
+    call("coocc_groupnorm_rows", ptr(x), x.shape[0], C or x.shape[1], x.shape[1], gn.num_groups, ptr(gn.weight.detach()),
          ptr(gn.bias.detach()), float(gn.eps), int(relu))
     return x
 
@@ -323,12 +332,19 @@ class _SparseEncoderBase(nn.Module):
 
     def _packed(self):
         def build():
-            d = dict(inp=self.conv_input[0].packed(), out=self.conv_out[0].packed(), stages=[])
+            # split-f16 engine: a base width below 32 (16 upstream) is carried as 32-channel rows whose upper channels are exact
+            # zeros -- conv_input's pack has zero weight rows / bias for them (its 32-column tile computes them anyway), GroupNorm
+            # touches the real channels only, and the first SparseConv3d reads zero-padded input channels -- so that layer runs
+            # the split-f16 rule-book kernel like the rest instead of the fp32-MFMA one (0.30 -> 0.13 ms at 300 k rows)
+            base = self.conv_input[0].cout
+            wide = 32 if (LIDAR_H2 and core.CONV_ENGINE == "h2" and base % 32 != 0 and base < 32
+                          and isinstance(self.conv1[0], _PostActBlock)) else None     # (the 4x encoder's first blocks run at the base width)
+            d = dict(inp=self.conv_input[0].packed(cout_to=wide), out=self.conv_out[0].packed(), stages=[], base=base)
             for st in (self.conv1, self.conv2, self.conv3):
                 ps = []
                 for m in st:
                     if isinstance(m, _PostActBlock):
-                        ps.append(("down", m[0].packed(bn=m[1])))
+                        ps.append(("down", m[0].packed(bn=m[1], cin_to=wide if m[0].cin == base else None)))
                     else:
                         ps.append(("block", m.net[0].packed(bn=m.net[1]), m.net[3].packed(bn=m.net[4])))
                 d["stages"].append(ps)
@@ -399,7 +415,7 @@ class _SparseEncoderBase(nn.Module):
         if cin_p != Cin:
             x = torch.cat([x, x.new_zeros(M, cin_p - Cin)], 1).contiguous()
         cur = SparseRows(None, coors, self.sparse_shape_xyz[::-1])
-        f = _gn_rows(sparse_conv(x, cin_p, p["inp"], cur.subm_table("in"), relu=False), self.conv_input[1])
+        f = _gn_rows(sparse_conv(x, cin_p, p["inp"], cur.subm_table("in"), relu=False), self.conv_input[1], C=p["base"])
         fh = None                      # H2 copy of f when the layer that made f wrote one (split-f16 engine)
         for si, ps in enumerate(p["stages"]):
             for bi, item in enumerate(ps):
