@@ -52,8 +52,8 @@ def test_train_render_losses_vs_reference_forward_train_golden(dev, golden):
     rgbs, depths = ag.render_block_train(sig, rgb, rows, (X, Y, Z), gemo)
     D = gemo.shape[2]
     l = ag.render_losses(rgbs, depths, imgs[0].permute(0, 2, 3, 1).contiguous().to(dev), depth[0].to(dev), D)
-    assert abs(float(l["loss_depth_render"]) - float(g["loss_depth_render"])) < 2e-6
-    assert abs(float(l["loss_rgb"]) - float(g["loss_rgb"])) < 2e-6
+    assert abs(float(l["loss_depth_render"].detach()) - float(g["loss_depth_render"])) < 2e-6
+    assert abs(float(l["loss_rgb"].detach()) - float(g["loss_rgb"])) < 2e-6
     (l["loss_depth_render"] + l["loss_rgb"]).backward()
     assert torch.isfinite(rows.grad).all() and float(rows.grad.abs().sum()) > 0
     # LiDAR-only branch: no colour head, geometry from get_frustum
