@@ -1022,7 +1022,8 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
       else hipLaunchKernelGGL((k_gemm_h2w<false, 1>), grid, dim3(256), 0, s, k);
     } else {
       // narrow outputs (Cout <= 64) through a row table: 256-row tiles, every wave on real columns (k_gemm_h2n)
-      static const bool narrow_on = !(getenv("COOCC_H2_NARROW") && atoi(getenv("COOCC_H2_NARROW")) == 0);
+      const char* narrow_env = getenv("COOCC_H2_NARROW");          // read per call: tests compare the two kernels in one process
+      const bool narrow_on = !(narrow_env && atoi(narrow_env) == 0);
       if (narrow_on && table && k.Cout <= 64 && k.ntiles == 1 && k.splitk == 1 && !d->tile_sem && (long long)k.mtiles >= 512) {
         const dim3 gridn((unsigned)((k.M + 255) / 256), 1);
         if (k.Cout <= 32) hipLaunchKernelGGL(k_gemm_h2n<1>, gridn, dim3(256), 0, s, k);

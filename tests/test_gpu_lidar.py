@@ -129,6 +129,49 @@ def test_sparse_layers_match_hand_computed_fixture(dev):
     assert np.array_equal(got.cpu().numpy(), np.asarray(fx["sparse_k3_s2_p1"]["out"], np.float32))
 
 
+@pytest.mark.parametrize("cin,cout,res", [(32, 32, True), (64, 64, True), (32, 64, False), (64, 32, False)])
+def test_narrow_rule_book_gemm_equals_the_wide_tile_kernel(dev, monkeypatch, cin, cout, res):
+    """``k_gemm_h2n`` (rule-book GEMMs with <= 64 output channels on 256-row tiles, every wave on real columns; taken at >= 512
+    row tiles) against ``k_gemm_h2w<table>`` (``COOCC_H2_NARROW=0``): the same bits -- rows, H2 twin and residual path -- on a
+    random table with a third of its entries empty and a ragged last tile; and against an fp64 gather-matmul on a sample of rows."""
+    if not (L.LIDAR_H2 and L.core.CONV_ENGINE == "h2"):
+        pytest.skip("split-f16 engine off")
+    g = torch.Generator().manual_seed(41)
+    M_in, M_out, taps = 60000, 66003, 27
+    feats = torch.randn(M_in, cin, generator=g).to(dev)
+    table = torch.randint(0, M_in, (taps, M_out), generator=g, dtype=torch.int32)
+    table[torch.rand(taps, M_out, generator=g) < 0.33] = -1
+    table = table.to(dev)
+    conv = L._SpConv(cin, cout, 3).to(dev)
+    bn = torch.nn.BatchNorm1d(cout).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(cout, generator=g) + 0.5); bn.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(cout, generator=g) * 0.1); bn.running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+    pc = conv.packed(bn=bn)
+    r = torch.randn(M_out, cout, generator=g).to(dev) if res else None
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("COOCC_H2_NARROW", flag)
+        o, oh = L.sparse_conv(feats, cin, pc, table, relu=True, res=r, twin=True)
+        torch.cuda.synchronize()
+        outs[flag] = (o.clone(), None if oh is None else oh.clone())
+    assert torch.equal(outs["1"][0], outs["0"][0])
+    if outs["0"][1] is not None:
+        assert torch.equal(outs["1"][1], outs["0"][1])
+    # fp64 reference on 512 sampled rows (incl. the last, ragged tile)
+    rows = torch.cat([torch.randint(0, M_out, (500,), generator=g), torch.arange(M_out - 12, M_out)]).to(dev)
+    w = conv.weight.detach().double().reshape(cout, taps, cin)
+    t = table[:, rows.long()].long()                                              # [taps, n]
+    x = torch.where((t >= 0)[..., None], feats.double()[t.clamp(min=0)], torch.zeros((), device=dev, dtype=torch.float64))
+    y = torch.einsum("tnc,otc->no", x, w)
+    s_ = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).double()
+    y = y * s_ + (bn.bias.double() - bn.running_mean.double() * s_)
+    if res:
+        y = y + r[rows.long()].double()
+    y = torch.relu(y)
+    assert_close(outs["1"][0][rows.long()].cpu(), y.float().cpu(), tol=1e-5, what="narrow rule-book GEMM vs fp64")
+
+
 def _grad_close(got, want, what, tol=2e-4):
     """Gradient tensors: error relative to the tensor's own largest entry (gradients of this encoder span 1e-6 .. 1e2)."""
     got, want = got.detach().cpu().double(), want.detach().cpu().double()
