@@ -660,9 +660,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2w(ConvK p) {
 // column block w % NCW of rows 256 / (4 / NCW) * (w / NCW) ..., i.e. every MFMA is a real one, per tile-row a quarter / half of the
 // MFMAs, weight loads and fragment reads.  Same stages, fragments, MFMA order per wave, tap order and epilogue expressions as
 // k_gemm_h2w<true>: a column's sum is formed in the same order -> the same bits.  No split-K (these layers have >= 256 tiles).
+// NCW = 4: the same wave layout for FULL-width (128-column) layers with few row tiles -- 64-row tiles, wave w on column block w, two
+// row blocks per wave, 16 KB of LDS and <= 168 registers, so three workgroups fit a CU: the 128 -> 128 stage of the encoder (45 k rows)
+// is 352 tiles of 128 rows for 512 workgroup slots -- 96 CUs run two of them, 160 run one -- and 704 tiles of 64 rows for 768 slots.
 template <int NCW>
-__global__ __launch_bounds__(256, 2) void k_gemm_h2n(ConvK p) {
-  constexpr int BM = 256, TM = NCW == 2 ? 4 : 2, NJ = BM / 32;        // NJ staging rows per lane and stage
+__global__ __launch_bounds__(256, NCW == 4 ? 3 : 2) void k_gemm_h2n(ConvK p) {
+  constexpr int BM = NCW == 4 ? 64 : 256, TM = NCW == 2 ? 4 : 2, NJ = BM / 32;        // NJ staging rows per lane and stage
   constexpr unsigned STAGE = BM * 128;
   __shared__ __attribute__((aligned(16))) char As[2 * BM * 128];
 
@@ -678,8 +681,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h2n(ConvK p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 31, h = lane >> 5;
   const int srow = lane >> 3, slot = lane & 7;
-  const int colblk = NCW == 2 ? (wave & 1) : 0;
-  const int rowbase = NCW == 2 ? (wave >> 1) * 128 : wave * 64;         // first tile row of this wave's accumulators
+  const int colblk = NCW == 4 ? wave : (NCW == 2 ? (wave & 1) : 0);
+  const int rowbase = NCW == 4 ? 0 : (NCW == 2 ? (wave >> 1) * 128 : wave * 64);         // first tile row of this wave's accumulators
   const int taps = p.taps;
   const long long rowbytes = (long long)p.in_stride * 4;
   const char* inb = (const char*)p.in;
@@ -1029,6 +1032,13 @@ int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
         if (k.Cout <= 32) hipLaunchKernelGGL(k_gemm_h2n<1>, gridn, dim3(256), 0, s, k);
         else hipLaunchKernelGGL(k_gemm_h2n<2>, gridn, dim3(256), 0, s, k);
         COOCC_LAUNCH_CHECK("k_gemm_h2n");
+        return COOCC_OK;
+      }
+      // full-width row-table layers whose 128-row tiles do not fill the chip evenly: 64-row tiles, three workgroups per CU
+      if (narrow_on && table && k.Cout > 96 && k.ntiles == 1 && k.splitk == 1 && !d->tile_sem && (long long)k.mtiles >= 128 && (long long)k.mtiles < 1024) {
+        const dim3 gridn((unsigned)((k.M + 63) / 64), 1);
+        hipLaunchKernelGGL(k_gemm_h2n<4>, gridn, dim3(256), 0, s, k);
+        COOCC_LAUNCH_CHECK("k_gemm_h2n<4>");
         return COOCC_OK;
       }
       if (table) hipLaunchKernelGGL(k_gemm_h2w<true>, grid, dim3(256), 0, s, k);

@@ -129,15 +129,16 @@ def test_sparse_layers_match_hand_computed_fixture(dev):
     assert np.array_equal(got.cpu().numpy(), np.asarray(fx["sparse_k3_s2_p1"]["out"], np.float32))
 
 
-@pytest.mark.parametrize("cin,cout,res", [(32, 32, True), (64, 64, True), (32, 64, False), (64, 32, False)])
-def test_narrow_rule_book_gemm_equals_the_wide_tile_kernel(dev, monkeypatch, cin, cout, res):
+@pytest.mark.parametrize("cin,cout,res,M_out", [(32, 32, True, 66003), (64, 64, True, 66003), (32, 64, False, 66003), (64, 32, False, 66003),
+                                                 (128, 128, True, 40037), (64, 128, False, 40037)])
+def test_narrow_rule_book_gemm_equals_the_wide_tile_kernel(dev, monkeypatch, cin, cout, res, M_out):
     """``k_gemm_h2n`` (rule-book GEMMs with <= 64 output channels on 256-row tiles, every wave on real columns; taken at >= 512
     row tiles) against ``k_gemm_h2w<table>`` (``COOCC_H2_NARROW=0``): the same bits -- rows, H2 twin and residual path -- on a
     random table with a third of its entries empty and a ragged last tile; and against an fp64 gather-matmul on a sample of rows."""
     if not (L.LIDAR_H2 and L.core.CONV_ENGINE == "h2"):
         pytest.skip("split-f16 engine off")
     g = torch.Generator().manual_seed(41)
-    M_in, M_out, taps = 60000, 66003, 27
+    M_in, taps = 60000, 27            # 128 output channels: the 64-row-tile form (k_gemm_h2n<4>, 128 .. 1023 row tiles)
     feats = torch.randn(M_in, cin, generator=g).to(dev)
     table = torch.randint(0, M_in, (taps, M_out), generator=g, dtype=torch.int32)
     table[torch.rand(taps, M_out, generator=g) < 0.33] = -1
