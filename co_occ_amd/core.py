@@ -733,11 +733,27 @@ def rows_to_h2(x2d, C=None, coff=0, name="h2rows"):
     return xh
 
 
-def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_coff, C, relu=True, count_dev=None):
+def g1_h2_capable(pc, C):
+    """True when ``gather_conv_rows`` runs this pack on the split-f16 engine (and therefore reads H2 source rows)."""
+    return bool(CONV_ENGINE == "h2" and H2_DIRECT and C % 32 == 0 and h2_capable(pc) and pc.h2_pack() is not None)
+
+
+def g1_sources_h2(cat4, C, pc):
+    """The H2 operand rows of BOTH G1 gather GEMMs from one conversion launch: columns [0, 2C) of the concat rows (img | pts)
+    as H2 rows [V, 2C] -- a 32-channel chunk is 128 contiguous bytes, so each slot is a column range of the wider rows
+    (row stride 2C, the pts slot C * 4 bytes in).  None when the layer is not on the split-f16 engine."""
+    if not g1_h2_capable(pc, C) or cat4.shape[1] < 2 * C:
+        return None
+    return rows_to_h2(cat4, 2 * C, 0, name="g1rows2")
+
+
+def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_coff, C, relu=True, count_dev=None, src_h2=None):
     """GSFusion G1: dst[out_rows[m], dst_coff:+C] = relu(sum_k W_k . src[gather[k,m], src_coff:+C] + b)
     * dst[out_rows[m], gate_coff:+C]   (bifuser_n.py:138-169).  src/dst: [rows, stride] tensors.
     ``count_dev``: int32 device tensor holding the number of rows; ``gather`` [K, cap] / ``out_rows`` [cap] are then
-    capacity-sized buffers and nothing about the launch depends on the count (hipGraph replay)."""
+    capacity-sized buffers and nothing about the launch depends on the count (hipGraph replay).
+    ``src_h2``: (H2 rows of ``src``'s columns [c0, c0 + n), c0, n) made by the caller (``g1_sources_h2``: one conversion for
+    both gather GEMMs); without it the source slot is converted here."""
     K, M = gather.shape
     if M == 0:
         return
@@ -760,11 +776,18 @@ def gather_conv_rows(src, src_coff, pc, gather, out_rows, dst, dst_coff, gate_co
     if count_dev is not None:
         d.M_dev, d.gather_stride = ptr(count_dev, torch.int32), M
     kname = conv_kernel_name(M, pc.Cout, True)
-    if CONV_ENGINE == "h2" and H2_DIRECT and C % 32 == 0 and h2_capable(pc) and pc.h2_pack() is not None:
+    if g1_h2_capable(pc, C):
         # split-f16 engine: the source slot is converted once ([rows, C] H2 rows: 13 us for 80 k rows), the row-table kernel
         # gathers 128-byte chunks of it (k_gemm_h2w<TABLE>); 118 -> ~40 us per call at configs[1]
-        sh = rows_to_h2(src, C, src_coff, name="g1rows")
-        d.in_, d.in_stride, d.w, d.mfma_dtype, d.alpha, kname = ptr(sh), C, ptr(pc.h2_pack()), 3, 1.0, "k_gemm_h2w"
+        if src_h2 is not None and src_h2[1] <= src_coff and src_coff + C <= src_h2[1] + src_h2[2] and (src_coff - src_h2[1]) % 32 == 0:
+            sh, c0, n = src_h2
+            hp = _lib.DevPtr(sh.data_ptr() + 4 * (src_coff - c0))
+            hp._keep = sh
+            d.in_, d.in_stride = hp, n
+        else:
+            sh = rows_to_h2(src, C, src_coff, name="g1rows")
+            d.in_, d.in_stride = ptr(sh), C
+        d.w, d.mfma_dtype, d.alpha, kname = ptr(pc.h2_pack()), 3, 1.0, "k_gemm_h2w"
     with TIMER.region(kname, 2.0 * M * C * pc.Cout * K):
         _lib.conv_fwd(d, src.device)
 

@@ -1140,14 +1140,31 @@ __global__ __launch_bounds__(256) void k_conv_reduce4(ConvK p) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   const float* src = p.ws + (size_t)m * p.Npad + n;
   const size_t zs = (size_t)p.M * p.Npad;
-  for (int z = 0; z < p.splitk; ++z) v = v + *(const f32x4*)(src + (size_t)z * zs);
+  // every operand of the epilogue is requested before the slabs are summed, and the slabs four at a time: the launch is a chain
+  // of dependent round trips otherwise (one load, one wait per slab).  The additions keep the slab order (same bits).
   const size_t orow = p.out_rows ? (size_t)p.out_rows[m] : (size_t)m;
-  if (p.res_mode == 3) v = v + *(const f32x4*)(p.res + orow * p.res_stride + n);
-  if (p.scale) v = v * *(const f32x4*)(p.scale + n);
-  if (p.bias) v = v + *(const f32x4*)(p.bias + n);
-  if (p.res_mode == 1) v = v + *(const f32x4*)(p.res + orow * p.res_stride + n);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+  const f32x4 rs = (p.res_mode && p.res) ? *(const f32x4*)(p.res + orow * p.res_stride + n) : zero4;
+  const f32x4 sc = p.scale ? *(const f32x4*)(p.scale + n) : one4;
+  const f32x4 bi = p.bias ? *(const f32x4*)(p.bias + n) : zero4;
+  int z = 0;
+  for (; z + 4 <= p.splitk; z += 4) {
+    const f32x4 a0 = *(const f32x4*)(src + (size_t)z * zs), a1 = *(const f32x4*)(src + (size_t)(z + 1) * zs);
+    const f32x4 a2 = *(const f32x4*)(src + (size_t)(z + 2) * zs), a3 = *(const f32x4*)(src + (size_t)(z + 3) * zs);
+    v = v + a0; v = v + a1; v = v + a2; v = v + a3;
+  }
+  if (z + 2 <= p.splitk) {
+    const f32x4 a0 = *(const f32x4*)(src + (size_t)z * zs), a1 = *(const f32x4*)(src + (size_t)(z + 1) * zs);
+    v = v + a0; v = v + a1;
+    z += 2;
+  }
+  if (z < p.splitk) v = v + *(const f32x4*)(src + (size_t)z * zs);
+  if (p.res_mode == 3) v = v + rs;
+  if (p.scale) v = v * sc;
+  if (p.bias) v = v + bi;
+  if (p.res_mode == 1) v = v + rs;
   if (p.relu && (p.relu == 1 || n < p.relu)) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-  if (p.res_mode == 2) v = v * *(const f32x4*)(p.res + orow * p.res_stride + n);
+  if (p.res_mode == 2) v = v * rs;
   if (p.out_h2) { store_h2(p.out, orow, p.out_stride, n, v); h2_guard(p.h2_flag, v); }
   else *(f32x4*)(p.out + orow * p.out_stride + n) = v;
   if (p.out16) { store_f16(p.out16, orow, p.out16_stride, n, v); h2_guard(p.h2_flag, v); }

@@ -1,6 +1,7 @@
 // Layout conversion at the reference boundary ([B,C,X,Y,Z] <-> channels-last voxel rows),
 // the BiFuser_N prologue (K1) and stream compaction (torch.nonzero replacement).
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -376,22 +377,86 @@ __global__ __launch_bounds__(256) void k_flag_write(const uint8_t* __restrict__ 
   }
 }
 
+// Sum of v over the block's 256 threads, returned to every thread (s: 4 ints of LDS).
+__device__ __forceinline__ int block_sum256(int v, int* s) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();                                  // s may still be read from a previous use
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s[0] + s[1] + s[2] + s[3];
+}
+
+// The last pass with the block's start ordinal computed by the block itself (no scan launch):
+//   FROM_FLAGS: counts the non-zero flags of every earlier block (4 flags per 32-bit word; flags 4-byte aligned, totals up to
+//               ONE_PASS_MAX: at most 127 coalesced word loads per thread) -- the whole compaction is this ONE launch;
+//   otherwise : adds up the earlier blocks' counts left by k_flag_count.
+// The last block also writes the total.  Same lin / map as the three-launch form (integers: no order to differ in).
+#define ONE_PASS_MAX (128 * CB)
+template <bool FROM_FLAGS>
+__global__ __launch_bounds__(256) void k_flag_write_px(const uint8_t* __restrict__ flags, int total,
+                                                        const int32_t* __restrict__ blk, int32_t* __restrict__ count,
+                                                        int32_t* __restrict__ lin, int32_t* __restrict__ map) {
+  __shared__ int wsum[4], psum[4];
+  int before = 0;
+  if (FROM_FLAGS) {
+    const uint32_t* w = (const uint32_t*)flags;
+    int nw = blockIdx.x * (CB / 4);                 // whole words: every earlier block is full
+    for (int i = threadIdx.x; i < nw; i += 256) {
+      uint32_t x = w[i];
+      before += __popc((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);   // non-zero bytes of x
+    }
+  } else {
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) before += blk[i];
+  }
+  before = block_sum256(before, psum);
+  int base = blockIdx.x * CB + threadIdx.x * 4;
+  int f[4], c = 0;
+  for (int j = 0; j < 4; ++j) {
+    f[j] = (base + j < total) && flags[base + j] != 0;
+    c += f[j];
+  }
+  int inc = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    int n = __shfl_up(inc, o);
+    if ((threadIdx.x & 63) >= o) inc += n;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  int off = before + inc - c;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *count = off + c;
+  for (int j = 0; j < 4; ++j) {
+    if (map && base + j < total) map[base + j] = f[j] ? off : -1;        // the inverse: element -> its ordinal in lin, or -1
+    if (f[j]) lin[off++] = base + j;
+  }
+}
+
 extern "C" int coocc_compact_flags_ex(const uint8_t* flags, int total, int32_t* lin, int32_t* count, int32_t* map, void* ws,
                                       size_t ws_bytes, void* stream);
 extern "C" int coocc_compact_flags(const uint8_t* flags, int total, int32_t* lin, int32_t* count, void* ws,
                                    size_t ws_bytes, void* stream) {
   return coocc_compact_flags_ex(flags, total, lin, count, nullptr, ws, ws_bytes, stream);
 }
-// ... and, with map != NULL, the inverse table map[element] = ordinal in lin (or -1) written by the same last pass
+// ... and, with map != NULL, the inverse table map[element] = ordinal in lin (or -1) written by the same last pass.
+// Launches: 1 up to ONE_PASS_MAX flags (the fused grids of every shipped config), 2 above; COOCC_COMPACT_SCAN=1 keeps the
+// count / scan / write form of rounds 1-4 (read per call: the direct test compares the forms).
 extern "C" int coocc_compact_flags_ex(const uint8_t* flags, int total, int32_t* lin, int32_t* count, int32_t* map, void* ws,
                                       size_t ws_bytes, void* stream) {
   COOCC_CHECK_ARG(flags && lin && count && ws && total > 0, "compact_flags: bad args");
   int nblk = (int)cdiv(total, CB);
   if (ws_bytes < sizeof(int32_t) * (size_t)nblk) return coocc_set_error(COOCC_ENOMEM, "compact_flags: workspace too small");
   int32_t* blk = (int32_t*)ws;
-  hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, as_stream(stream), blk, nblk, count);
-  hipLaunchKernelGGL(k_flag_write, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk, lin, map);
+  const char* e = getenv("COOCC_COMPACT_SCAN");
+  if (e && e[0] == '1') {
+    hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, as_stream(stream), blk, nblk, count);
+    hipLaunchKernelGGL(k_flag_write, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk, lin, map);
+  } else if (total <= ONE_PASS_MAX && ((uintptr_t)flags & 3) == 0) {
+    hipLaunchKernelGGL(k_flag_write_px<true>, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk, count, lin, map);
+  } else {
+    hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk);
+    hipLaunchKernelGGL(k_flag_write_px<false>, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk, count, lin, map);
+  }
   COOCC_LAUNCH_CHECK("compact_flags");
   return COOCC_OK;
 }

@@ -504,11 +504,23 @@ class BiFuser_N(nn.Module):
             self.finish_static(sr.slot)
             self.last_near = (sr.near_img, sr.near_pts)
         elif sr.rows is not None:
-            gather_conv_rows(cat4, 0, packs["knn"], sr.rows, sr.lin_pts, cat4, 2 * C, C, C)
             cur.wait_event(sr.done_side)
-            gather_conv_rows(cat4, C, packs["knn"], sr.rows_p, sr.lin_img, cat4, 3 * C, 0, C)
+            h2 = self._g1_h2(cat4, packs)
+            gather_conv_rows(cat4, 0, packs["knn"], sr.rows, sr.lin_pts, cat4, 2 * C, C, C, src_h2=h2)
+            gather_conv_rows(cat4, C, packs["knn"], sr.rows_p, sr.lin_img, cat4, 3 * C, 0, C, src_h2=h2)
             self.last_near = (sr.near_img, sr.near_pts)
         return sr.cat4, (sr.lin_img, sr.lin_pts)
+
+    def _g1_h2(self, cat4, packs):
+        """H2 rows of the img | pts slots for both gather GEMMs (one conversion launch instead of one per GEMM; COOCC_G1_H2_ONCE=0
+        keeps the per-GEMM conversions).  The GEMMs only write the fused slots [2C, 4C), so converting both sources first reads
+        the same values."""
+        import os
+        from . import core
+        if os.environ.get("COOCC_G1_H2_ONCE", "1") == "0":
+            return None
+        sh = core.g1_sources_h2(cat4, self.in_channels, packs["knn"])
+        return None if sh is None else (sh, 0, 2 * self.in_channels)
 
     def finish_static(self, slot):
         """``finish`` over a ``SearchSlot``: the same two gather GEMMs with the row counts read on the device and
@@ -517,8 +529,9 @@ class BiFuser_N(nn.Module):
         C = self.in_channels
         packs = self._packed()
         cat4 = slot.cat4
-        gather_conv_rows(cat4, 0, packs["knn"], slot.rows, slot.lin[1], cat4, 2 * C, C, C, count_dev=slot.counts[1:2])
-        gather_conv_rows(cat4, C, packs["knn"], slot.rows_p, slot.lin[0], cat4, 3 * C, 0, C, count_dev=slot.counts[0:1])
+        h2 = self._g1_h2(cat4, packs)
+        gather_conv_rows(cat4, 0, packs["knn"], slot.rows, slot.lin[1], cat4, 2 * C, C, C, count_dev=slot.counts[1:2], src_h2=h2)
+        gather_conv_rows(cat4, C, packs["knn"], slot.rows_p, slot.lin[0], cat4, 3 * C, 0, C, count_dev=slot.counts[0:1], src_h2=h2)
         X, Y, Z = slot.grid
         return Rows(cat4, 1, X, Y, Z, 4 * C)
 

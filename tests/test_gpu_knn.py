@@ -222,6 +222,39 @@ def test_compaction_property_full_size(dev):
     assert bool((l[1:] > l[:-1]).all()) and bool(flags[l].all())
 
 
+@pytest.mark.parametrize("total,p,offset", [(1, 1.0, 0), (1023, 0.5, 0), (1024, 0.0, 0), (1025, 1.0, 0), (80000, 0.12, 0),
+                                            (80000, 0.65, 4), (131072, 0.5, 0), (131073, 0.5, 0), (80001, 0.3, 1),
+                                            (640000, 0.65, 0), (1500007, 0.02, 0)])
+def test_compaction_forms_equal_nonzero(dev, monkeypatch, total, p, offset):
+    """The compaction (torch.nonzero's replacement) in its three forms -- ONE launch (every earlier block's flags counted by the
+    block itself; up to 131072 flags, 4-byte aligned), two launches (counts + write with the prefix summed in the block), and
+    the count / scan / write form of rounds 1-4 (COOCC_COMPACT_SCAN=1) -- gives nonzero()'s list, count and inverse map:
+    empty / full / ragged tails, totals on both sides of the one-launch limit, an unaligned flag pointer, flag values > 1."""
+    g = torch.Generator().manual_seed(total + offset)
+    buf = torch.zeros(total + 8, dtype=torch.uint8)
+    buf[offset:offset + total] = (torch.rand(total, generator=g) < p).to(torch.uint8) * torch.randint(1, 255, (total,), generator=g).to(torch.uint8)
+    buf[offset + total:] = 7                       # bytes past the end must not be counted
+    dbuf = buf.to(dev)
+    flags = dbuf[offset:offset + total]
+    want = torch.nonzero(buf[offset:offset + total])[:, 0].int()
+    want_map = torch.full((total,), -1, dtype=I32)
+    want_map[want.long()] = torch.arange(want.numel(), dtype=I32)
+    for scan in ("0", "1"):
+        monkeypatch.setenv("COOCC_COMPACT_SCAN", scan)
+        for with_map in (False, True):
+            lin = torch.full((total,), -7, device=dev, dtype=I32)
+            cnt = torch.full((1,), -7, device=dev, dtype=I32)
+            fmap = torch.full((total,), -7, device=dev, dtype=I32)
+            ws = torch.empty(total // 1024 + 2, device=dev, dtype=I32)
+            call("coocc_compact_flags_ex", ptr(flags), total, ptr(lin), ptr(cnt), ptr(fmap if with_map else None), ptr(ws),
+                 ws.numel() * 4)
+            n = int(cnt.item())
+            assert n == want.numel()
+            assert torch.equal(lin[:n].cpu(), want) and bool((lin[n:] == -7).all())
+            if with_map:
+                assert torch.equal(fmap.cpu(), want_map)
+
+
 @pytest.mark.parametrize("grid,pq,pk,K,m", [((40, 40, 4), 0.45, 0.7, 4, 2048), ((100, 100, 8), 0.12, 0.65, 2, 2048),
                                             ((100, 100, 8), 0.65, 0.12, 2, 2048), ((64, 40, 4), 0.65, 0.003, 3, 512),
                                             ((33, 21, 5), 0.5, 0.5, 8, 300), ((50, 50, 1), 0.3, 0.02, 2, 256),

@@ -61,6 +61,27 @@ def test_bifuser_concat_rows_exact_layout(dev):
     assert_close(cat4.t.cpu().view(o["all_feats"].shape), o["all_feats"], tol=1e-5)
 
 
+@pytest.mark.parametrize("C,knum,far", [(32, 2, True), (128, 2, False), (64, 4, False)])
+def test_g1_shared_h2_conversion_gives_the_same_bits(dev, monkeypatch, C, knum, far):
+    """Both G1 gather GEMMs read ONE H2 conversion of the img | pts slots (column ranges of [V, 2C] H2 rows) by default;
+    COOCC_G1_H2_ONCE=0 converts each slot for its own GEMM as rounds 3-4 did.  Same concat rows, bit for bit, and the rows
+    of the oracle (bifuser_n.py:138-169); widths the split-f16 engine takes (C % 32 == 0)."""
+    c = dict(grid=(64, 40, 4), C=C, knum=knum, p_img=0.85, p_pts=0.65, seed=17 + C)
+    if far:
+        c.update(img_x_below=28, pts_x_from=34)
+    img, pts = cases.fuser_inputs(c)
+    f, sd = load_seeded(pkg.BiFuser_N(C, C, knum), c["seed"], dev)
+    assert core.g1_h2_capable(f._packed()["knn"], C) == (core.CONV_ENGINE == "h2" and core.H2_DIRECT)
+    outs = []
+    for once in ("1", "0"):
+        monkeypatch.setenv("COOCC_G1_H2_ONCE", once)
+        cat4, _ = f.fuse(img.to(dev), pts.to(dev))
+        outs.append(cat4.t.clone())
+    assert torch.equal(outs[0], outs[1])
+    o = ref_cpu.bifuser_fuse(sd, img, pts, knum)
+    assert_close(outs[0].cpu().view(o["all_feats"].shape), o["all_feats"])
+
+
 @pytest.mark.parametrize("conv_path", ["direct", "winograd"])
 def test_decoder_vs_golden(dev, golden, monkeypatch, conv_path):
     """conv_path=winograd forces every eligible 3x3x3 stride-1 layer through csrc/winograd.hip (the production
