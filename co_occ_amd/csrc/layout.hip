@@ -386,9 +386,13 @@ __device__ __forceinline__ int block_sum256(int v, int* s) {
   return s[0] + s[1] + s[2] + s[3];
 }
 
+__device__ __forceinline__ int nonzero_bytes(uint32_t x) {
+  return __popc((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);
+}
+
 // The last pass with the block's start ordinal computed by the block itself (no scan launch):
-//   FROM_FLAGS: counts the non-zero flags of every earlier block (4 flags per 32-bit word; flags 4-byte aligned, totals up to
-//               ONE_PASS_MAX: at most 127 coalesced word loads per thread) -- the whole compaction is this ONE launch;
+//   FROM_FLAGS: counts the non-zero flags of every earlier block (16 flags per load; flags 16-byte aligned, totals up to
+//               ONE_PASS_MAX: at most 32 coalesced loads per thread, eight in flight) -- the whole compaction is this ONE launch;
 //   otherwise : adds up the earlier blocks' counts left by k_flag_count.
 // The last block also writes the total.  Same lin / map as the three-launch form (integers: no order to differ in).
 #define ONE_PASS_MAX (128 * CB)
@@ -399,11 +403,14 @@ __global__ __launch_bounds__(256) void k_flag_write_px(const uint8_t* __restrict
   __shared__ int wsum[4], psum[4];
   int before = 0;
   if (FROM_FLAGS) {
-    const uint32_t* w = (const uint32_t*)flags;
-    int nw = blockIdx.x * (CB / 4);                 // whole words: every earlier block is full
-    for (int i = threadIdx.x; i < nw; i += 256) {
-      uint32_t x = w[i];
-      before += __popc((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);   // non-zero bytes of x
+    const uint4* w = (const uint4*)flags;
+    const int nw = blockIdx.x * (CB / 16);          // whole 16-byte words: every earlier block is full
+    for (int i0 = threadIdx.x; i0 < nw; i0 += 256 * 8) {
+      uint4 x[8];                                   // eight independent loads per round trip (at most four round trips)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = i0 + k * 256 < nw ? w[i0 + k * 256] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) before += nonzero_bytes(x[k].x) + nonzero_bytes(x[k].y) + nonzero_bytes(x[k].z) + nonzero_bytes(x[k].w);
     }
   } else {
     for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) before += blk[i];
@@ -451,7 +458,7 @@ extern "C" int coocc_compact_flags_ex(const uint8_t* flags, int total, int32_t* 
     hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, as_stream(stream), blk, nblk, count);
     hipLaunchKernelGGL(k_flag_write, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk, lin, map);
-  } else if (total <= ONE_PASS_MAX && ((uintptr_t)flags & 3) == 0) {
+  } else if (total <= ONE_PASS_MAX && ((uintptr_t)flags & 15) == 0) {
     hipLaunchKernelGGL(k_flag_write_px<true>, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk, count, lin, map);
   } else {
     hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk);
