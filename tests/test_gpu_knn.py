@@ -231,7 +231,7 @@ def test_compaction_forms_equal_nonzero(dev, monkeypatch, total, p, offset):
     the count / scan / write form of rounds 1-4 (COOCC_COMPACT_SCAN=1) -- gives nonzero()'s list, count and inverse map:
     empty / full / ragged tails, totals on both sides of the one-launch limit, an unaligned flag pointer, flag values > 1."""
     g = torch.Generator().manual_seed(total + offset)
-    buf = torch.zeros(total + 8, dtype=torch.uint8)
+    buf = torch.zeros(total + 32, dtype=torch.uint8)
     buf[offset:offset + total] = (torch.rand(total, generator=g) < p).to(torch.uint8) * torch.randint(1, 255, (total,), generator=g).to(torch.uint8)
     buf[offset + total:] = 7                       # bytes past the end must not be counted
     dbuf = buf.to(dev)
