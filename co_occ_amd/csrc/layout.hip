@@ -396,6 +396,7 @@ __device__ __forceinline__ int nonzero_bytes(uint32_t x) {
 //   otherwise : adds up the earlier blocks' counts left by k_flag_count.
 // The last block also writes the total.  Same lin / map as the three-launch form (integers: no order to differ in).
 #define ONE_PASS_MAX (128 * CB)
+#define TWO_PASS_MAX_BLOCKS 2048                     // 2 M flags: at most 8 count loads per thread in the last block
 template <bool FROM_FLAGS>
 __global__ __launch_bounds__(256) void k_flag_write_px(const uint8_t* __restrict__ flags, int total,
                                                         const int32_t* __restrict__ blk, int32_t* __restrict__ count,
@@ -445,7 +446,7 @@ extern "C" int coocc_compact_flags(const uint8_t* flags, int total, int32_t* lin
   return coocc_compact_flags_ex(flags, total, lin, count, nullptr, ws, ws_bytes, stream);
 }
 // ... and, with map != NULL, the inverse table map[element] = ordinal in lin (or -1) written by the same last pass.
-// Launches: 1 up to ONE_PASS_MAX flags (the fused grids of every shipped config), 2 above; COOCC_COMPACT_SCAN=1 keeps the
+// Launches: 1 up to ONE_PASS_MAX flags (the fused grids of every shipped config), 2 up to 2 M flags, 3 above; COOCC_COMPACT_SCAN=1 keeps the
 // count / scan / write form of rounds 1-4 (read per call: the direct test compares the forms).
 extern "C" int coocc_compact_flags_ex(const uint8_t* flags, int total, int32_t* lin, int32_t* count, int32_t* map, void* ws,
                                       size_t ws_bytes, void* stream) {
@@ -460,9 +461,13 @@ extern "C" int coocc_compact_flags_ex(const uint8_t* flags, int total, int32_t* 
     hipLaunchKernelGGL(k_flag_write, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk, lin, map);
   } else if (total <= ONE_PASS_MAX && ((uintptr_t)flags & 15) == 0) {
     hipLaunchKernelGGL(k_flag_write_px<true>, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk, count, lin, map);
-  } else {
+  } else if (nblk <= TWO_PASS_MAX_BLOCKS) {
     hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk);
     hipLaunchKernelGGL(k_flag_write_px<false>, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk, count, lin, map);
+  } else {                                          // the per-block prefix sums are quadratic in the block count: scan launch
+    hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, as_stream(stream), blk, nblk, count);
+    hipLaunchKernelGGL(k_flag_write, dim3(nblk), dim3(256), 0, as_stream(stream), flags, total, blk, lin, map);
   }
   COOCC_LAUNCH_CHECK("compact_flags");
   return COOCC_OK;

@@ -224,11 +224,12 @@ def test_compaction_property_full_size(dev):
 
 @pytest.mark.parametrize("total,p,offset", [(1, 1.0, 0), (1023, 0.5, 0), (1024, 0.0, 0), (1025, 1.0, 0), (80000, 0.12, 0),
                                             (80000, 0.65, 4), (80000, 0.65, 16), (131072, 0.5, 0), (131073, 0.5, 0), (80001, 0.3, 1),
-                                            (640000, 0.65, 0), (1500007, 0.02, 0)])
+                                            (640000, 0.65, 0), (1500007, 0.02, 0), (2200001, 0.3, 0)])
 def test_compaction_forms_equal_nonzero(dev, monkeypatch, total, p, offset):
     """The compaction (torch.nonzero's replacement) in its three forms -- ONE launch (every earlier block's flags counted by the
-    block itself; up to 131072 flags, 16-byte aligned), two launches (counts + write with the prefix summed in the block), and
-    the count / scan / write form of rounds 1-4 (COOCC_COMPACT_SCAN=1) -- gives nonzero()'s list, count and inverse map:
+    block itself; up to 131072 flags, 16-byte aligned), two launches (counts + write with the prefix summed in the block; up to
+    2 M flags), and the count / scan / write form of rounds 1-4 (above, or COOCC_COMPACT_SCAN=1) -- gives nonzero()'s list, count
+    and inverse map:
     empty / full / ragged tails, totals on both sides of the one-launch limit, an unaligned flag pointer, flag values > 1."""
     g = torch.Generator().manual_seed(total + offset)
     buf = torch.zeros(total + 32, dtype=torch.uint8)
