@@ -2,6 +2,8 @@
 // FPN3D top-down add, OccHead multi-level softmax mix, render-map x16 upsample.
 // Source index rule (ATen area_pixel_compute_source_index): src = max(0, scale*(dst+0.5)-0.5),
 // scale = in/out (fp32), i0 = floor(src), i1 = i0 + (i0 < in-1), lambda = src - i0.
+#include <stdlib.h>
+
 #include "conv_k.h"
 #include "h2_rows.h"
 
@@ -33,6 +35,82 @@ __device__ __forceinline__ f32x4 tri_sample(const float* __restrict__ vol, int b
          lx.w1 * (ly.w0 * (lz.w0 * v100 + lz.w1 * v101) + ly.w1 * (lz.w0 * v110 + lz.w1 * v111));
 }
 
+// ---- z-column forms (one thread = the ZF voxels of one (x, y) column, four channels) ----------------------------------------
+// The per-voxel kernels below issue eight 16-byte loads per output and coarse level; a column of ZF fine voxels only needs the
+// four coarse corner columns (4 x ZC loads for ZF outputs).  For ZF = 2^k ZC the z source rule is exact in fp32 (scale a power
+// of two), so the corner INDICES are compile-time constants and the columns stay in registers; the WEIGHTS are still computed by
+// lin_src at run time and the sample is the same expression as tri_sample, so the results are the same bits as the per-voxel
+// kernels' (tests: test_interp_column_forms_equal_the_per_voxel_kernels).
+template <int ZF, int ZC> struct ZSrc {
+  static_assert(ZF % ZC == 0 && ((ZF / ZC) & (ZF / ZC - 1)) == 0, "power-of-two z ratio");
+  // lin_src(z, ZC, ZF) in integers: src = max(0, (2z + 1 - R) / (2R)), R = ZF / ZC
+  static constexpr int R = ZF / ZC;
+  static constexpr int i0(int z) { return ZF == ZC ? z : (2 * z + 1 - R < 0 ? 0 : (2 * z + 1 - R) / (2 * R)); }
+  static constexpr int i1(int z) { return ZF == ZC ? z : i0(z) + (i0(z) < ZC - 1 ? 1 : 0); }
+};
+
+template <int ZC>
+__device__ __forceinline__ void load_corner_columns(f32x4 (&q)[4][ZC], const float* __restrict__ vol, int b, int C, int X, int Y,
+                                                     const Lin1& lx, const Lin1& ly, int c) {
+  const float* base = vol + (size_t)b * X * Y * ZC * C + c;
+  const float* p[4] = {base + ((size_t)lx.i0 * Y + ly.i0) * ZC * C, base + ((size_t)lx.i0 * Y + ly.i1) * ZC * C,
+                       base + ((size_t)lx.i1 * Y + ly.i0) * ZC * C, base + ((size_t)lx.i1 * Y + ly.i1) * ZC * C};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < ZC; ++k) q[j][k] = *(const f32x4*)(p[j] + (size_t)k * C);
+}
+
+// tri_sample's expression on the register columns: q[0] = (x0, y0), q[1] = (x0, y1), q[2] = (x1, y0), q[3] = (x1, y1)
+template <int ZF, int ZC, int Z>
+__device__ __forceinline__ f32x4 column_sample(const f32x4 (&q)[4][ZC], const Lin1& lx, const Lin1& ly, const Lin1& lz) {
+  constexpr int a = ZSrc<ZF, ZC>::i0(Z), e = ZSrc<ZF, ZC>::i1(Z);
+  const f32x4 v000 = q[0][a], v001 = q[0][e], v010 = q[1][a], v011 = q[1][e];
+  const f32x4 v100 = q[2][a], v101 = q[2][e], v110 = q[3][a], v111 = q[3][e];
+  return lx.w0 * (ly.w0 * (lz.w0 * v000 + lz.w1 * v001) + ly.w1 * (lz.w0 * v010 + lz.w1 * v011)) +
+         lx.w1 * (ly.w0 * (lz.w0 * v100 + lz.w1 * v101) + ly.w1 * (lz.w0 * v110 + lz.w1 * v111));
+}
+
+template <int ZF, int ZC, int Z>
+struct UpAddZ {
+  static __device__ __forceinline__ void run(const f32x4 (&q)[4][ZC], const f32x4 (&f)[ZF], const Lin1& lx, const Lin1& ly, int Zc,
+                                             float* __restrict__ o, size_t row0, int C, int c, void* __restrict__ twin,
+                                             int* __restrict__ flag) {
+    const Lin1 lz = lin_src(Z, Zc, ZF);
+    const f32x4 r = f[Z] + column_sample<ZF, ZC, Z>(q, lx, ly, lz);
+    *(f32x4*)(o + (size_t)Z * C) = r;
+    if (twin) { store_h2(twin, row0 + Z, C, c, r); h2_guard(flag, r); }
+    if constexpr (Z + 1 < ZF) UpAddZ<ZF, ZC, Z + 1>::run(q, f, lx, ly, Zc, o, row0, C, c, twin, flag);
+  }
+};
+
+template <int ZF, int ZC>
+__global__ __launch_bounds__(256) void k_upsample_add_col(const float* __restrict__ coarse, float* __restrict__ fine, int B, int C,
+                                                           int Xc, int Yc, int Zc, int Xf, int Yf, void* __restrict__ twin,
+                                                           int* __restrict__ flag) {
+  const int c4 = C >> 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * Xf * Yf * c4) return;
+  const int c = (int)(i % c4) * 4;
+  size_t v = i / c4;
+  const size_t row0 = v * ZF;
+  const int y = (int)(v % Yf); v /= Yf;
+  const int x = (int)(v % Xf);
+  const int b = (int)(v / Xf);
+  const Lin1 lx = lin_src(x, Xc, Xf), ly = lin_src(y, Yc, Yf);
+  f32x4 q[4][ZC], f[ZF];
+  float* o = fine + row0 * C + c;
+#pragma unroll
+  for (int z = 0; z < ZF; ++z) f[z] = *(const f32x4*)(o + (size_t)z * C);
+  load_corner_columns<ZC>(q, coarse, b, C, Xc, Yc, lx, ly, c);
+  UpAddZ<ZF, ZC, 0>::run(q, f, lx, ly, Zc, o, row0, C, c, twin, flag);
+}
+
+static bool interp_column_enabled() {
+  const char* e = getenv("COOCC_INTERP_COLUMN");
+  return !(e && e[0] == '0');
+}
+
 // fpn3d.py:88-92  laterals[i-1] += interpolate(laterals[i], size=prev_shape, trilinear)
 __global__ __launch_bounds__(256) void k_upsample_add(const float* __restrict__ coarse, float* __restrict__ fine,
                                                        int B, int C, int Xc, int Yc, int Zc, int Xf, int Yf, int Zf,
@@ -62,6 +140,19 @@ extern "C" int coocc_upsample_add_trilinear_ex(const float* coarse, float* fine,
   int* flag = nullptr;
   if (fine_h2_twin && coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
   size_t total = (size_t)B * Xf * Yf * Zf * (C / 4);
+  // z-column form for the z ratios of the shipped grids (COOCC_INTERP_COLUMN=0: the per-voxel kernel everywhere; read per call)
+  const size_t cols = (size_t)B * Xf * Yf * (C / 4);
+#define UPADD_COL(ZF_, ZC_)                                                                                                     \
+  if (Zf == ZF_ && Zc == ZC_) {                                                                                                 \
+    hipLaunchKernelGGL((k_upsample_add_col<ZF_, ZC_>), dim3(cdiv(cols, 256)), dim3(256), 0, as_stream(stream), coarse, fine, B, \
+                       C, Xc, Yc, Zc, Xf, Yf, fine_h2_twin, flag);                                                              \
+    COOCC_LAUNCH_CHECK("k_upsample_add_col");                                                                                   \
+    return COOCC_OK;                                                                                                            \
+  }
+  if (interp_column_enabled()) {
+    UPADD_COL(8, 4) UPADD_COL(4, 2) UPADD_COL(2, 1)
+  }
+#undef UPADD_COL
   hipLaunchKernelGGL(k_upsample_add, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), coarse, fine, B, C, Xc,
                      Yc, Zc, Xf, Yf, Zf, fine_h2_twin, flag);
   COOCC_LAUNCH_CHECK("k_upsample_add");
@@ -113,6 +204,79 @@ __global__ __launch_bounds__(256) void k_occhead_mix(MixLevels lv, const float* 
   if (twin) { store_h2(twin, row, C, c, acc); h2_guard(flag, acc); }     // H2 twin for occ_pred_conv's first 1x1x1 layer
 }
 
+// z-column form of the mix: four levels, level 0 on the output grid, levels 1-3 coarser in z by powers of two
+template <int Z0, int ZL, int LV, int Z>
+struct MixZ {
+  static __device__ __forceinline__ void run(const f32x4 (&q)[4][ZL], const Lin1& lx, const Lin1& ly, int Zl, const float (&wn)[Z0][4],
+                                             f32x4 (&acc)[Z0]) {
+    const Lin1 lz = lin_src(Z, Zl, Z0);
+    const f32x4 s = column_sample<Z0, ZL, Z>(q, lx, ly, lz);
+    acc[Z] = acc[Z] + s * wn[Z][LV];
+    __builtin_amdgcn_sched_barrier(0);             // one voxel's sample at a time: eight in flight is ~220 registers of temporaries
+    if constexpr (Z + 1 < Z0) MixZ<Z0, ZL, LV, Z + 1>::run(q, lx, ly, Zl, wn, acc);
+  }
+};
+
+template <int Z0, int ZL, int LV>
+__device__ __forceinline__ void mix_level(const MixLevels& lv, int b, int C, int x, int y, int X0, int Y0, int c,
+                                          const float (&wn)[Z0][4], f32x4 (&acc)[Z0]) {
+  const Lin1 lx = lin_src(x, lv.X[LV], X0), ly = lin_src(y, lv.Y[LV], Y0);
+  f32x4 q[4][ZL];
+  load_corner_columns<ZL>(q, lv.p[LV], b, C, lv.X[LV], lv.Y[LV], lx, ly, c);
+  MixZ<Z0, ZL, LV, 0>::run(q, lx, ly, lv.Z[LV], wn, acc);
+}
+
+// (two waves per SIMD)
+template <int Z0, int Z1, int Z2, int Z3>
+__global__ __launch_bounds__(256, 2) void k_occhead_mix_col(MixLevels lv, const float* __restrict__ wlogit, float* __restrict__ out,
+                                                          int B, int C, void* __restrict__ twin, int* __restrict__ flag) {
+  const int c4 = C >> 2;
+  const int X0 = lv.X[0], Y0 = lv.Y[0];
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;                     // host: columns * c4 < 2^31
+  if (i >= (unsigned)(B * X0 * Y0) * (unsigned)c4) return;
+  const int c = (int)(i % (unsigned)c4) * 4;
+  unsigned v = i / (unsigned)c4;
+  const size_t row0 = (size_t)v * Z0;
+  const int y = (int)(v % (unsigned)Y0); v /= (unsigned)Y0;
+  const int x = (int)(v % (unsigned)X0);
+  const int b = (int)(v / (unsigned)X0);
+  float wn[Z0][4];                       // w_l / sum per voxel: the per-voxel kernel's softmax weights, same operations
+  f32x4 acc[Z0];
+  f32x4 wl[Z0];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int z = 0; z < Z0; ++z) {
+    wl[z] = wlogit ? *(const f32x4*)(wlogit + (row0 + z) * 4) : zero;
+    acc[z] = *(const f32x4*)(lv.p[0] + (row0 + z) * C + c);              // level 0: the voxel itself
+  }
+#pragma unroll
+  for (int z = 0; z < Z0; ++z) {
+    float w[4] = {wl[z][0], wl[z][1], wl[z][2], wl[z][3]}, mx = -INFINITY;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) mx = fmaxf(mx, w[l]);
+    float sum = 0.f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { w[l] = expf(w[l] - mx); sum += w[l]; }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) wn[z][l] = w[l] / sum;
+    acc[z] = zero + acc[z] * wn[z][0];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // one level's corner columns at a time (the scheduler otherwise hoists every level's loads and spills)
+  __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory");
+  mix_level<Z0, Z1, 1>(lv, b, C, x, y, X0, Y0, c, wn, acc);
+  __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory");
+  mix_level<Z0, Z2, 2>(lv, b, C, x, y, X0, Y0, c, wn, acc);
+  __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory");
+  mix_level<Z0, Z3, 3>(lv, b, C, x, y, X0, Y0, c, wn, acc);
+  __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory");
+#pragma unroll
+  for (int z = 0; z < Z0; ++z) {
+    *(f32x4*)(out + (row0 + z) * C + c) = acc[z];
+    if (twin) { store_h2(twin, row0 + z, C, c, acc[z]); h2_guard(flag, acc[z]); }
+  }
+}
+
 extern "C" int coocc_occhead_mix_ex(const float* const* levels_host, const int* dims_host, int L, const float* wlogit,
                                     float* out, int B, int C, void* out_h2_twin, void* stream) {
   COOCC_CHECK_ARG(levels_host && dims_host && out && L >= 1 && L <= 4 && C % 4 == 0, "occhead_mix: bad args");
@@ -128,6 +292,18 @@ extern "C" int coocc_occhead_mix_ex(const float* const* levels_host, const int* 
     lv.Z[l] = l < L ? dims_host[l * 3 + 2] : 1;
   }
   size_t total = (size_t)B * lv.X[0] * lv.Y[0] * lv.Z[0] * (C / 4);
+  const size_t cols = (size_t)B * lv.X[0] * lv.Y[0] * (C / 4);
+#define MIX_COL(Z0_, Z1_, Z2_, Z3_)                                                                                              \
+  if (lv.Z[0] == Z0_ && lv.Z[1] == Z1_ && lv.Z[2] == Z2_ && lv.Z[3] == Z3_) {                                                   \
+    hipLaunchKernelGGL((k_occhead_mix_col<Z0_, Z1_, Z2_, Z3_>), dim3(cdiv(cols, 256)), dim3(256), 0, as_stream(stream), lv,     \
+                       wlogit, out, B, C, out_h2_twin, flag);                                                                   \
+    COOCC_LAUNCH_CHECK("k_occhead_mix_col");                                                                                    \
+    return COOCC_OK;                                                                                                            \
+  }
+  if (L == 4 && cols < (1u << 31) && interp_column_enabled()) {
+    MIX_COL(8, 4, 2, 1)
+  }
+#undef MIX_COL
   hipLaunchKernelGGL(k_occhead_mix, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), lv, wlogit, out, B, C, out_h2_twin, flag);
   COOCC_LAUNCH_CHECK("k_occhead_mix");
   return COOCC_OK;

@@ -170,6 +170,59 @@ def test_occhead_mix_softmax_levels(dev):
     assert_close(out.view(1, *sizes[0], 16).permute(0, 4, 1, 2, 3).cpu(), want, tol=1e-5)
 
 
+@pytest.mark.parametrize("cs,fs,C", [((50, 50, 4), (100, 100, 8), 128), ((25, 25, 2), (50, 50, 4), 128), ((13, 13, 1), (25, 25, 2), 128),
+                                     ((5, 4, 2), (10, 8, 4), 32), ((3, 7, 4), (6, 14, 8), 8), ((7, 7, 4), (7, 7, 8), 16)])
+def test_interp_column_forms_equal_the_per_voxel_kernels_upsample_add(dev, monkeypatch, cs, fs, C):
+    """fpn3d.py:88-92 in its z-column form (one thread = the voxels of one (x, y) column: the four coarse corner columns are
+    loaded once per column instead of eight taps per voxel) == the per-voxel kernel (COOCC_INTERP_COLUMN=0), bit for bit, rows
+    and H2 twin; the r50 pyramid's three shapes, a batch of two, odd x / y ratios, an x-y ratio of one; and torch."""
+    g = torch.Generator().manual_seed(sum(cs) + C)
+    c = torch.randn(2, C, *cs, generator=g)
+    f = torch.randn(2, C, *fs, generator=g)
+    outs = []
+    for col in ("1", "0"):
+        monkeypatch.setenv("COOCC_INTERP_COLUMN", col)
+        rc, rf = rows_of(c, dev), rows_of(f, dev)
+        tw = torch.zeros(rf.t.numel(), device=dev) if C % 32 == 0 else None
+        call("coocc_upsample_add_trilinear_ex", ptr(rc.t), ptr(rf.t), 2, C, *cs, *fs, ptr(tw))
+        outs.append((rf.t.clone(), tw))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if outs[0][1] is not None:
+        assert torch.equal(outs[0][1], outs[1][1]) and bool((outs[0][1] != 0).any())
+    want = f + F.interpolate(c, size=fs, mode="trilinear", align_corners=False)
+    assert_close(rf.as_ncdhw().cpu(), want, tol=1e-5)
+
+
+@pytest.mark.parametrize("sizes,C,B", [([(100, 100, 8), (50, 50, 4), (25, 25, 2), (13, 13, 1)], 128, 1),
+                                       ([(12, 10, 8), (6, 5, 4), (3, 3, 2), (2, 2, 1)], 32, 2),
+                                       ([(9, 7, 8), (9, 7, 4), (5, 4, 2), (3, 2, 1)], 16, 1)])
+def test_interp_column_forms_equal_the_per_voxel_kernels_mix(dev, monkeypatch, sizes, C, B):
+    """occ_head.py:155-166 in its z-column form == the per-voxel kernel, bit for bit (output rows and H2 twin), at the r50 head's
+    shapes, with a batch of two and with a level that shares x-y with the output grid; and torch."""
+    import ctypes
+    g = torch.Generator().manual_seed(C + B)
+    lv = [torch.randn(B, C, *s, generator=g) for s in sizes]
+    logit = torch.randn(B, 4, *sizes[0], generator=g) * 3
+    rows = [rows_of(t, dev) for t in lv]
+    wl = rows_of(logit, dev)
+    levels = (ctypes.c_void_p * 4)(*[r.t.data_ptr() for r in rows])
+    outs = []
+    for col in ("1", "0"):
+        monkeypatch.setenv("COOCC_INTERP_COLUMN", col)
+        out = torch.zeros_like(rows[0].t)
+        tw = torch.zeros(out.numel(), device=dev) if C % 32 == 0 else None
+        call("coocc_occhead_mix_ex", levels, host_i32([v for s in sizes for v in s]), 4, ptr(wl.t), ptr(out), B, C, ptr(tw))
+        outs.append((out, tw))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if outs[0][1] is not None:
+        assert torch.equal(outs[0][1], outs[1][1]) and bool((outs[0][1] != 0).any())
+    w = torch.softmax(logit, 1)
+    want = 0
+    for f, wi in zip(lv, torch.unbind(w, 1)):
+        want = want + F.interpolate(f, size=list(sizes[0]), mode="trilinear", align_corners=False) * wi.unsqueeze(1)
+    assert_close(outs[0][0].view(B, *sizes[0], C).permute(0, 4, 1, 2, 3).cpu(), want, tol=1e-5)
+
+
 @pytest.mark.parametrize("wino,tol", [(0, 1e-5), (1, 1e-4)])
 def test_conv_linearity_at_full_grid(dev, monkeypatch, wino, tol):
     """Size-independent property at the BASELINE grid (100x100x8, C=128): conv(a*x + y) ==
