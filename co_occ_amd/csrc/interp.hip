@@ -204,53 +204,63 @@ __global__ __launch_bounds__(256) void k_occhead_mix(MixLevels lv, const float* 
   if (twin) { store_h2(twin, row, C, c, acc); h2_guard(flag, acc); }     // H2 twin for occ_pred_conv's first 1x1x1 layer
 }
 
-// z-column form of the mix: four levels, level 0 on the output grid, levels 1-3 coarser in z by powers of two
-template <int Z0, int ZL, int LV, int Z>
+// z-column form of the mix: four levels, level 0 on the output grid, levels 1-3 coarser in z by powers of two.  A thread takes HALF a
+// column (Z0 / 2 voxels, four channels): the whole column needs ~320 registers (one wave per SIMD, measured slower than the
+// per-voxel kernel), a half ~120; the halves are grid.y, so the plane ranges below are compile-time per wave.
+template <int ZL, int PLO, int NP>
+__device__ __forceinline__ void load_corner_planes(f32x4 (&q)[4][NP], const float* __restrict__ vol, int b, int C, int X, int Y,
+                                                    const Lin1& lx, const Lin1& ly, int c) {
+  const float* base = vol + (size_t)b * X * Y * ZL * C + c + (size_t)PLO * C;
+  const float* p[4] = {base + ((size_t)lx.i0 * Y + ly.i0) * ZL * C, base + ((size_t)lx.i0 * Y + ly.i1) * ZL * C,
+                       base + ((size_t)lx.i1 * Y + ly.i0) * ZL * C, base + ((size_t)lx.i1 * Y + ly.i1) * ZL * C};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < NP; ++k) q[j][k] = *(const f32x4*)(p[j] + (size_t)k * C);
+}
+
+template <int Z0, int ZL, int LV, int ZB, int ZN, int PLO, int NP, int Z>
 struct MixZ {
-  static __device__ __forceinline__ void run(const f32x4 (&q)[4][ZL], const Lin1& lx, const Lin1& ly, int Zl, const float (&wn)[Z0][4],
-                                             f32x4 (&acc)[Z0]) {
+  static __device__ __forceinline__ void run(const f32x4 (&q)[4][NP], const Lin1& lx, const Lin1& ly, int Zl, const float (&wn)[ZN][4],
+                                             f32x4 (&acc)[ZN]) {
     const Lin1 lz = lin_src(Z, Zl, Z0);
-    const f32x4 s = column_sample<Z0, ZL, Z>(q, lx, ly, lz);
-    acc[Z] = acc[Z] + s * wn[Z][LV];
-    __builtin_amdgcn_sched_barrier(0);             // one voxel's sample at a time: eight in flight is ~220 registers of temporaries
-    if constexpr (Z + 1 < Z0) MixZ<Z0, ZL, LV, Z + 1>::run(q, lx, ly, Zl, wn, acc);
+    constexpr int a = ZSrc<Z0, ZL>::i0(Z) - PLO, e = ZSrc<Z0, ZL>::i1(Z) - PLO;
+    static_assert(a >= 0 && e < NP, "plane range");
+    const f32x4 v000 = q[0][a], v001 = q[0][e], v010 = q[1][a], v011 = q[1][e];
+    const f32x4 v100 = q[2][a], v101 = q[2][e], v110 = q[3][a], v111 = q[3][e];
+    const f32x4 s = lx.w0 * (ly.w0 * (lz.w0 * v000 + lz.w1 * v001) + ly.w1 * (lz.w0 * v010 + lz.w1 * v011)) +
+                    lx.w1 * (ly.w0 * (lz.w0 * v100 + lz.w1 * v101) + ly.w1 * (lz.w0 * v110 + lz.w1 * v111));
+    acc[Z - ZB] = acc[Z - ZB] + s * wn[Z - ZB][LV];
+    if constexpr (Z + 1 < ZB + ZN) MixZ<Z0, ZL, LV, ZB, ZN, PLO, NP, Z + 1>::run(q, lx, ly, Zl, wn, acc);
   }
 };
 
-template <int Z0, int ZL, int LV>
+template <int Z0, int ZL, int LV, int ZB, int ZN>
 __device__ __forceinline__ void mix_level(const MixLevels& lv, int b, int C, int x, int y, int X0, int Y0, int c,
-                                          const float (&wn)[Z0][4], f32x4 (&acc)[Z0]) {
+                                          const float (&wn)[ZN][4], f32x4 (&acc)[ZN]) {
+  constexpr int PLO = ZSrc<Z0, ZL>::i0(ZB), NP = ZSrc<Z0, ZL>::i1(ZB + ZN - 1) - PLO + 1;
   const Lin1 lx = lin_src(x, lv.X[LV], X0), ly = lin_src(y, lv.Y[LV], Y0);
-  f32x4 q[4][ZL];
-  load_corner_columns<ZL>(q, lv.p[LV], b, C, lv.X[LV], lv.Y[LV], lx, ly, c);
-  MixZ<Z0, ZL, LV, 0>::run(q, lx, ly, lv.Z[LV], wn, acc);
+  f32x4 q[4][NP];
+  load_corner_planes<ZL, PLO, NP>(q, lv.p[LV], b, C, lv.X[LV], lv.Y[LV], lx, ly, c);
+  MixZ<Z0, ZL, LV, ZB, ZN, PLO, NP, ZB>::run(q, lx, ly, lv.Z[LV], wn, acc);
 }
 
-// (two waves per SIMD)
-template <int Z0, int Z1, int Z2, int Z3>
-__global__ __launch_bounds__(256, 2) void k_occhead_mix_col(MixLevels lv, const float* __restrict__ wlogit, float* __restrict__ out,
-                                                          int B, int C, void* __restrict__ twin, int* __restrict__ flag) {
-  const int c4 = C >> 2;
-  const int X0 = lv.X[0], Y0 = lv.Y[0];
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;                     // host: columns * c4 < 2^31
-  if (i >= (unsigned)(B * X0 * Y0) * (unsigned)c4) return;
-  const int c = (int)(i % (unsigned)c4) * 4;
-  unsigned v = i / (unsigned)c4;
-  const size_t row0 = (size_t)v * Z0;
-  const int y = (int)(v % (unsigned)Y0); v /= (unsigned)Y0;
-  const int x = (int)(v % (unsigned)X0);
-  const int b = (int)(v / (unsigned)X0);
-  float wn[Z0][4];                       // w_l / sum per voxel: the per-voxel kernel's softmax weights, same operations
-  f32x4 acc[Z0];
-  f32x4 wl[Z0];
+template <int Z0, int Z1, int Z2, int Z3, int H>
+__device__ __forceinline__ void mix_half_column(const MixLevels& lv, const float* __restrict__ wlogit, float* __restrict__ out, int b,
+                                                int C, int x, int y, int X0, int Y0, int c, size_t col_row0,
+                                                void* __restrict__ twin, int* __restrict__ flag) {
+  constexpr int ZN = Z0 / 2, ZB = H * ZN;
+  const size_t row0 = col_row0 + ZB;
+  float wn[ZN][4];                       // w_l / sum per voxel: the per-voxel kernel's softmax weights, same operations
+  f32x4 acc[ZN], wl[ZN];
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int z = 0; z < Z0; ++z) {
+  for (int z = 0; z < ZN; ++z) {
     wl[z] = wlogit ? *(const f32x4*)(wlogit + (row0 + z) * 4) : zero;
     acc[z] = *(const f32x4*)(lv.p[0] + (row0 + z) * C + c);              // level 0: the voxel itself
   }
 #pragma unroll
-  for (int z = 0; z < Z0; ++z) {
+  for (int z = 0; z < ZN; ++z) {
     float w[4] = {wl[z][0], wl[z][1], wl[z][2], wl[z][3]}, mx = -INFINITY;
 #pragma unroll
     for (int l = 0; l < 4; ++l) mx = fmaxf(mx, w[l]);
@@ -260,21 +270,33 @@ __global__ __launch_bounds__(256, 2) void k_occhead_mix_col(MixLevels lv, const 
 #pragma unroll
     for (int l = 0; l < 4; ++l) wn[z][l] = w[l] / sum;
     acc[z] = zero + acc[z] * wn[z][0];
-    __builtin_amdgcn_sched_barrier(0);
   }
-  // one level's corner columns at a time (the scheduler otherwise hoists every level's loads and spills)
-  __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory");
-  mix_level<Z0, Z1, 1>(lv, b, C, x, y, X0, Y0, c, wn, acc);
-  __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory");
-  mix_level<Z0, Z2, 2>(lv, b, C, x, y, X0, Y0, c, wn, acc);
-  __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory");
-  mix_level<Z0, Z3, 3>(lv, b, C, x, y, X0, Y0, c, wn, acc);
-  __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory");
+  mix_level<Z0, Z1, 1, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc);
+  mix_level<Z0, Z2, 2, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc);
+  mix_level<Z0, Z3, 3, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc);
 #pragma unroll
-  for (int z = 0; z < Z0; ++z) {
+  for (int z = 0; z < ZN; ++z) {
     *(f32x4*)(out + (row0 + z) * C + c) = acc[z];
     if (twin) { store_h2(twin, row0 + z, C, c, acc[z]); h2_guard(flag, acc[z]); }
   }
+}
+
+template <int Z0, int Z1, int Z2, int Z3>
+__global__ __launch_bounds__(256) void k_occhead_mix_col(MixLevels lv, const float* __restrict__ wlogit, float* __restrict__ out,
+                                                          int B, int C, void* __restrict__ twin, int* __restrict__ flag) {
+  static_assert(Z0 % 2 == 0, "half columns");
+  const int c4 = C >> 2;
+  const int X0 = lv.X[0], Y0 = lv.Y[0];
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;                     // host: columns * c4 < 2^31
+  if (i >= (unsigned)(B * X0 * Y0) * (unsigned)c4) return;
+  const int c = (int)(i % (unsigned)c4) * 4;
+  unsigned v = i / (unsigned)c4;
+  const size_t col_row0 = (size_t)v * Z0;
+  const int y = (int)(v % (unsigned)Y0); v /= (unsigned)Y0;
+  const int x = (int)(v % (unsigned)X0);
+  const int b = (int)(v / (unsigned)X0);
+  if (blockIdx.y == 0) mix_half_column<Z0, Z1, Z2, Z3, 0>(lv, wlogit, out, b, C, x, y, X0, Y0, c, col_row0, twin, flag);
+  else mix_half_column<Z0, Z1, Z2, Z3, 1>(lv, wlogit, out, b, C, x, y, X0, Y0, c, col_row0, twin, flag);
 }
 
 extern "C" int coocc_occhead_mix_ex(const float* const* levels_host, const int* dims_host, int L, const float* wlogit,
@@ -295,7 +317,7 @@ extern "C" int coocc_occhead_mix_ex(const float* const* levels_host, const int* 
   const size_t cols = (size_t)B * lv.X[0] * lv.Y[0] * (C / 4);
 #define MIX_COL(Z0_, Z1_, Z2_, Z3_)                                                                                              \
   if (lv.Z[0] == Z0_ && lv.Z[1] == Z1_ && lv.Z[2] == Z2_ && lv.Z[3] == Z3_) {                                                   \
-    hipLaunchKernelGGL((k_occhead_mix_col<Z0_, Z1_, Z2_, Z3_>), dim3(cdiv(cols, 256)), dim3(256), 0, as_stream(stream), lv,     \
+    hipLaunchKernelGGL((k_occhead_mix_col<Z0_, Z1_, Z2_, Z3_>), dim3(cdiv(cols, 256), 2), dim3(256), 0, as_stream(stream), lv,  \
                        wlogit, out, B, C, out_h2_twin, flag);                                                                   \
     COOCC_LAUNCH_CHECK("k_occhead_mix_col");                                                                                    \
     return COOCC_OK;                                                                                                            \

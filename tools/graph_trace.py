@@ -9,7 +9,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the probe ends with 3 + 20 graph replays back to back: take the kernels of the last 20 replays by counting a kernel
 # that runs exactly once per replay
 marker = "k_occhead_mix"
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(marker)]
+idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"].split("(")[0]]
 n = 20
 start = idx[-n] if len(idx) >= n else 0
 # a replay starts with the first kernel of the dense stage; walk back from the first marker to the previous marker + 1
