@@ -106,9 +106,11 @@ __global__ __launch_bounds__(256) void k_upsample_add_col(const float* __restric
   UpAddZ<ZF, ZC, 0>::run(q, f, lx, ly, Zc, o, row0, C, c, twin, flag);
 }
 
-static bool interp_column_enabled() {
+// COOCC_INTERP_COLUMN: bit 0 = z-column FPN upsample-add, bit 1 = half-z-column OccHead mix (read per call)
+#define INTERP_COLUMN_DEFAULT 3
+static int interp_column_mask() {
   const char* e = getenv("COOCC_INTERP_COLUMN");
-  return !(e && e[0] == '0');
+  return e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : INTERP_COLUMN_DEFAULT;
 }
 
 // fpn3d.py:88-92  laterals[i-1] += interpolate(laterals[i], size=prev_shape, trilinear)
@@ -149,7 +151,7 @@ extern "C" int coocc_upsample_add_trilinear_ex(const float* coarse, float* fine,
     COOCC_LAUNCH_CHECK("k_upsample_add_col");                                                                                   \
     return COOCC_OK;                                                                                                            \
   }
-  if (interp_column_enabled()) {
+  if (interp_column_mask() & 1) {
     UPADD_COL(8, 4) UPADD_COL(4, 2) UPADD_COL(2, 1)
   }
 #undef UPADD_COL
@@ -322,7 +324,7 @@ extern "C" int coocc_occhead_mix_ex(const float* const* levels_host, const int* 
     COOCC_LAUNCH_CHECK("k_occhead_mix_col");                                                                                    \
     return COOCC_OK;                                                                                                            \
   }
-  if (L == 4 && cols < (1u << 31) && interp_column_enabled()) {
+  if (L == 4 && cols < (1u << 31) && (interp_column_mask() & 2)) {
     MIX_COL(8, 4, 2, 1)
   }
 #undef MIX_COL
