@@ -106,8 +106,12 @@ __global__ __launch_bounds__(256) void k_upsample_add_col(const float* __restric
   UpAddZ<ZF, ZC, 0>::run(q, f, lx, ly, Zc, o, row0, C, c, twin, flag);
 }
 
-// COOCC_INTERP_COLUMN: bit 0 = z-column FPN upsample-add, bit 1 = half-z-column OccHead mix (read per call)
-#define INTERP_COLUMN_DEFAULT 3
+// COOCC_INTERP_COLUMN: bit 0 = z-column FPN upsample-add, bit 1 = half-z-column OccHead mix (read per call).  The mix form is OFF by
+// default: alone it gives the per-voxel kernel's bits (output rows and H2 twin, tests/test_gpu_conv.py), but with several captured
+// dense graphs in flight the pipelined loop's pred_c differed from the eager calls in 3 of 3 runs (tools/jobs/gpu_r5_y.sh; the
+// upsample-add form and the per-voxel kernels: 0 of 3) -- the second kernel of this package, after the one-launch ratio-2 fine
+// branch, that is only wrong next to other streams' work.  Not explained; kept for the reproduction.
+#define INTERP_COLUMN_DEFAULT 1
 static int interp_column_mask() {
   const char* e = getenv("COOCC_INTERP_COLUMN");
   return e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : INTERP_COLUMN_DEFAULT;

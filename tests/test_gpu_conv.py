@@ -180,7 +180,7 @@ def test_interp_column_forms_equal_the_per_voxel_kernels_upsample_add(dev, monke
     c = torch.randn(2, C, *cs, generator=g)
     f = torch.randn(2, C, *fs, generator=g)
     outs = []
-    for col in ("1", "0"):
+    for col in ("1", "0"):                       # bit 0: the upsample-add form
         monkeypatch.setenv("COOCC_INTERP_COLUMN", col)
         rc, rf = rows_of(c, dev), rows_of(f, dev)
         tw = torch.zeros(rf.t.numel(), device=dev) if C % 32 == 0 else None
@@ -197,8 +197,9 @@ def test_interp_column_forms_equal_the_per_voxel_kernels_upsample_add(dev, monke
                                        ([(12, 10, 8), (6, 5, 4), (3, 3, 2), (2, 2, 1)], 32, 2),
                                        ([(9, 7, 8), (9, 7, 4), (5, 4, 2), (3, 2, 1)], 16, 1)])
 def test_interp_column_forms_equal_the_per_voxel_kernels_mix(dev, monkeypatch, sizes, C, B):
-    """occ_head.py:155-166 in its z-column form == the per-voxel kernel, bit for bit (output rows and H2 twin), at the r50 head's
-    shapes, with a batch of two and with a level that shares x-y with the output grid; and torch."""
+    """occ_head.py:155-166 in its half-z-column form (COOCC_INTERP_COLUMN bit 1; OFF by default because the pipelined loop differed
+    from eager calls with it, csrc/interp.hip) == the per-voxel kernel, bit for bit (output rows and H2 twin) when it runs alone:
+    the r50 head's shapes, a batch of two, a level that shares x-y with the output grid; and torch."""
     import ctypes
     g = torch.Generator().manual_seed(C + B)
     lv = [torch.randn(B, C, *s, generator=g) for s in sizes]
@@ -207,7 +208,7 @@ def test_interp_column_forms_equal_the_per_voxel_kernels_mix(dev, monkeypatch, s
     wl = rows_of(logit, dev)
     levels = (ctypes.c_void_p * 4)(*[r.t.data_ptr() for r in rows])
     outs = []
-    for col in ("1", "0"):
+    for col in ("2", "0"):                       # bit 1: the mix form (off by default: see csrc/interp.hip)
         monkeypatch.setenv("COOCC_INTERP_COLUMN", col)
         out = torch.zeros_like(rows[0].t)
         tw = torch.zeros(out.numel(), device=dev) if C % 32 == 0 else None
