@@ -1,0 +1,87 @@
+"""Debug: does the half-z-column OccHead mix (COOCC_INTERP_COLUMN bit 1, csrc/interp.hip) differ from its own result when other work
+shares the GPU?  Inside the serving loop it did (profiles/r5_interp_column_bisect.txt: pred_c of the pipelined loop != eager calls in
+3 of 3 runs, the per-voxel kernel 0 of 3).  Here the kernel is called through the C ABI on FIXED buffers (inputs made once, one
+preallocated output per call: no allocator, no graph, no pipeline), stream s0; stream s1 loops a co-runner.  Every output is compared
+with the kernel's own result computed alone.
+
+    python tools/debug/mix_corunner.py            # both forms x every co-runner
+
+Read it next to tools/debug/fine2_corunner.py (the one-launch ratio-2 fine branch): if the column form differs here
+too, the defect is at kernel level (co-residency), not a race between the slots' graphs."""
+import ctypes, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench
+from co_occ_amd import core
+from co_occ_amd._lib import call, ptr, host_i32
+
+dev = torch.device("cuda:0")
+C, sizes = 128, [(100, 100, 8), (50, 50, 4), (25, 25, 2), (13, 13, 1)]
+g = torch.Generator().manual_seed(7)
+levels = [torch.randn(s[0] * s[1] * s[2], C, generator=g).to(dev) for s in sizes]
+wlogit = (torch.randn(sizes[0][0] * sizes[0][1] * sizes[0][2], 4, generator=g) * 3).to(dev)
+arr = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in levels])
+dims = host_i32([v for s in sizes for v in s])
+N = 20
+outs = [torch.empty_like(levels[0]) for _ in range(N)]
+twins = [torch.empty_like(levels[0]) for _ in range(N)]
+
+
+def mix(i):
+    call("coocc_occhead_mix_ex", arr, dims, 4, ptr(wlogit), ptr(outs[i]), 1, C, ptr(twins[i]))
+
+
+bench.CFGNAME[0] = "r50"
+model, _ = bench.build_model("r50", dev)
+s = bench.make_inputs("r50", 4013, dev, model)
+with torch.no_grad():
+    vf = model.fuse(model.img_view_transformer.lift_splat(s["depth"], s["ctx"], cams=s["cams"]), s["pts"])
+    enc, neck, head = model.semantic_encoder, model.semantic_neck, model.pts_bbox_head
+    a, b = torch.randn(4096, 4096, device=dev), torch.randn(4096, 4096, device=dev)
+    big = torch.randn(64 << 20, device=dev)
+    torch.cuda.synchronize()
+
+    def co_conv(engine):
+        def f():
+            keep = core.CONV_ENGINE
+            core.CONV_ENGINE = engine
+            try:
+                for _ in range(2):
+                    neck.forward_rows(enc.forward_rows(vf, readers=neck.lateral_packs()), readers=head.level_readers())
+            finally:
+                core.CONV_ENGINE = keep
+        return f
+
+    def co_mm():
+        for _ in range(6):
+            torch.mm(a, b)
+
+    def co_elem():
+        for _ in range(40):
+            big.mul_(1.0001)
+
+    s0, s1 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    for mask in ("2", "0"):
+        os.environ["COOCC_INTERP_COLUMN"] = mask
+        with torch.cuda.stream(s0):
+            mix(0)
+        torch.cuda.synchronize()
+        ref, ref_tw = outs[0].clone(), twins[0].clone()
+        for name, co in (("nothing", None), ("decoder convolutions, split-f16 engine (global_load_lds GEMMs)", co_conv("h2")),
+                         ("decoder convolutions, fp32-MFMA engine", co_conv("f32")), ("torch.mm 4096^3", co_mm),
+                         ("torch elementwise over 256 MB", co_elem)):
+            for o, t in zip(outs, twins):
+                o.fill_(float("nan")); t.fill_(float("nan"))
+            torch.cuda.synchronize()
+            for i in range(N):
+                if co is not None:
+                    with torch.cuda.stream(s1):
+                        co()
+                with torch.cuda.stream(s0):
+                    mix(i)
+            torch.cuda.synchronize()
+            bad = sum(int(not (torch.equal(o, ref) and torch.equal(t, ref_tw))) for o, t in zip(outs, twins))
+            rows = sorted({int(r) for o in outs for r in torch.nonzero((o != ref).any(1))[:8, 0].tolist()})[:8]
+            print("COOCC_INTERP_COLUMN=%s  co-runner %-70s: %2d of %2d calls differ%s" %
+                  (mask, name, bad, N, ("  first rows " + str(rows)) if rows else ""), flush=True)
