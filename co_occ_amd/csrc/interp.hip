@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_upsample_add_col(const float* __restric
 #define INTERP_COLUMN_DEFAULT 1
 static int interp_column_mask() {
   const char* e = getenv("COOCC_INTERP_COLUMN");
-  return e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : INTERP_COLUMN_DEFAULT;
+  return e && e[0] >= '0' && e[0] <= '7' ? e[0] - '0' : INTERP_COLUMN_DEFAULT;
 }
 
 // fpn3d.py:88-92  laterals[i-1] += interpolate(laterals[i], size=prev_shape, trilinear)
@@ -243,18 +243,19 @@ struct MixZ {
 
 template <int Z0, int ZL, int LV, int ZB, int ZN>
 __device__ __forceinline__ void mix_level(const MixLevels& lv, int b, int C, int x, int y, int X0, int Y0, int c,
-                                          const float (&wn)[ZN][4], f32x4 (&acc)[ZN]) {
+                                          const float (&wn)[ZN][4], f32x4 (&acc)[ZN], int full_wait) {
   constexpr int PLO = ZSrc<Z0, ZL>::i0(ZB), NP = ZSrc<Z0, ZL>::i1(ZB + ZN - 1) - PLO + 1;
   const Lin1 lx = lin_src(x, lv.X[LV], X0), ly = lin_src(y, lv.Y[LV], Y0);
   f32x4 q[4][NP];
   load_corner_planes<ZL, PLO, NP>(q, lv.p[LV], b, C, lv.X[LV], lv.Y[LV], lx, ly, c);
+  if (full_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // diagnostic (COOCC_INTERP_COLUMN bit 2): no partial waits
   MixZ<Z0, ZL, LV, ZB, ZN, PLO, NP, ZB>::run(q, lx, ly, lv.Z[LV], wn, acc);
 }
 
 template <int Z0, int Z1, int Z2, int Z3, int H>
 __device__ __forceinline__ void mix_half_column(const MixLevels& lv, const float* __restrict__ wlogit, float* __restrict__ out, int b,
                                                 int C, int x, int y, int X0, int Y0, int c, size_t col_row0,
-                                                void* __restrict__ twin, int* __restrict__ flag) {
+                                                void* __restrict__ twin, int* __restrict__ flag, int full_wait) {
   constexpr int ZN = Z0 / 2, ZB = H * ZN;
   const size_t row0 = col_row0 + ZB;
   float wn[ZN][4];                       // w_l / sum per voxel: the per-voxel kernel's softmax weights, same operations
@@ -265,6 +266,7 @@ __device__ __forceinline__ void mix_half_column(const MixLevels& lv, const float
     wl[z] = wlogit ? *(const f32x4*)(wlogit + (row0 + z) * 4) : zero;
     acc[z] = *(const f32x4*)(lv.p[0] + (row0 + z) * C + c);              // level 0: the voxel itself
   }
+  if (full_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int z = 0; z < ZN; ++z) {
     float w[4] = {wl[z][0], wl[z][1], wl[z][2], wl[z][3]}, mx = -INFINITY;
@@ -277,9 +279,9 @@ __device__ __forceinline__ void mix_half_column(const MixLevels& lv, const float
     for (int l = 0; l < 4; ++l) wn[z][l] = w[l] / sum;
     acc[z] = zero + acc[z] * wn[z][0];
   }
-  mix_level<Z0, Z1, 1, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc);
-  mix_level<Z0, Z2, 2, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc);
-  mix_level<Z0, Z3, 3, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc);
+  mix_level<Z0, Z1, 1, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc, full_wait);
+  mix_level<Z0, Z2, 2, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc, full_wait);
+  mix_level<Z0, Z3, 3, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc, full_wait);
 #pragma unroll
   for (int z = 0; z < ZN; ++z) {
     *(f32x4*)(out + (row0 + z) * C + c) = acc[z];
@@ -289,7 +291,7 @@ __device__ __forceinline__ void mix_half_column(const MixLevels& lv, const float
 
 template <int Z0, int Z1, int Z2, int Z3>
 __global__ __launch_bounds__(256) void k_occhead_mix_col(MixLevels lv, const float* __restrict__ wlogit, float* __restrict__ out,
-                                                          int B, int C, void* __restrict__ twin, int* __restrict__ flag) {
+                                                          int B, int C, void* __restrict__ twin, int* __restrict__ flag, int full_wait) {
   static_assert(Z0 % 2 == 0, "half columns");
   const int c4 = C >> 2;
   const int X0 = lv.X[0], Y0 = lv.Y[0];
@@ -301,8 +303,8 @@ __global__ __launch_bounds__(256) void k_occhead_mix_col(MixLevels lv, const flo
   const int y = (int)(v % (unsigned)Y0); v /= (unsigned)Y0;
   const int x = (int)(v % (unsigned)X0);
   const int b = (int)(v / (unsigned)X0);
-  if (blockIdx.y == 0) mix_half_column<Z0, Z1, Z2, Z3, 0>(lv, wlogit, out, b, C, x, y, X0, Y0, c, col_row0, twin, flag);
-  else mix_half_column<Z0, Z1, Z2, Z3, 1>(lv, wlogit, out, b, C, x, y, X0, Y0, c, col_row0, twin, flag);
+  if (blockIdx.y == 0) mix_half_column<Z0, Z1, Z2, Z3, 0>(lv, wlogit, out, b, C, x, y, X0, Y0, c, col_row0, twin, flag, full_wait);
+  else mix_half_column<Z0, Z1, Z2, Z3, 1>(lv, wlogit, out, b, C, x, y, X0, Y0, c, col_row0, twin, flag, full_wait);
 }
 
 extern "C" int coocc_occhead_mix_ex(const float* const* levels_host, const int* dims_host, int L, const float* wlogit,
@@ -324,7 +326,7 @@ extern "C" int coocc_occhead_mix_ex(const float* const* levels_host, const int* 
 #define MIX_COL(Z0_, Z1_, Z2_, Z3_)                                                                                              \
   if (lv.Z[0] == Z0_ && lv.Z[1] == Z1_ && lv.Z[2] == Z2_ && lv.Z[3] == Z3_) {                                                   \
     hipLaunchKernelGGL((k_occhead_mix_col<Z0_, Z1_, Z2_, Z3_>), dim3(cdiv(cols, 256), 2), dim3(256), 0, as_stream(stream), lv,  \
-                       wlogit, out, B, C, out_h2_twin, flag);                                                                   \
+                       wlogit, out, B, C, out_h2_twin, flag, (interp_column_mask() >> 2) & 1);                                  \
     COOCC_LAUNCH_CHECK("k_occhead_mix_col");                                                                                    \
     return COOCC_OK;                                                                                                            \
   }

@@ -62,7 +62,7 @@ with torch.no_grad():
             big.mul_(1.0001)
 
     s0, s1 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-    for mask in ("2", "0"):
+    for mask in (sys.argv[1:] or ["2", "6", "0"]):       # 2 = half-column mix, 6 = the same with s_waitcnt vmcnt(0) after every load batch, 0 = per-voxel
         os.environ["COOCC_INTERP_COLUMN"] = mask
         with torch.cuda.stream(s0):
             mix(0)
