@@ -5,6 +5,7 @@ preallocated output per call: no allocator, no graph, no pipeline), stream s0; s
 with the kernel's own result computed alone.
 
     python tools/debug/mix_corunner.py            # both forms x every co-runner
+    python tools/debug/mix_corunner.py --bisect 2 # the column form next to ONE split-f16 kernel family at a time
 
 Read it next to tools/debug/fine2_corunner.py (the one-launch ratio-2 fine branch): if the column form differs here
 too, the defect is at kernel level (co-residency), not a race between the slots' graphs."""
@@ -61,16 +62,49 @@ with torch.no_grad():
         for _ in range(40):
             big.mul_(1.0001)
 
+    # --bisect: one kernel family of the split-f16 engine at a time as the co-runner (not run on the GPU yet: written at the end of
+    # round 5 when the budget was spent).  x: 80 000 rows x 128 channels; WINO / CONV_ENGINE are read per call by conv_rows.
+    gb = torch.Generator().manual_seed(11)
+    xb = core.to_rows(torch.randn(1, 128, 100, 100, 8, generator=gb).to(dev))
+    pc3 = core.PackedConv((torch.randn(128, 128, 3, 3, 3, generator=gb) * 0.02).to(dev), ksize=3, pad=1)
+    pc1 = core.PackedConv((torch.randn(128, 128, 1, 1, 1, generator=gb) * 0.05).to(dev), ksize=1, pad=0)
+
+    def co_layer(pc, engine, wino, n=4):
+        def f():
+            keep = core.CONV_ENGINE, core.WINO
+            core.CONV_ENGINE, core.WINO = engine, wino
+            try:
+                for _ in range(n):
+                    core.conv_rows(xb, pc, relu=False)
+            finally:
+                core.CONV_ENGINE, core.WINO = keep
+        return f
+
+    def co_rows_to_h2():
+        for _ in range(20):
+            core.rows_to_h2(xb.t, 128, 0, name="corunner_h2")
+
+    bisect = [("nothing", None),
+              ("k_rows_to_h2 only (fp32 rows -> H2 rows, no MFMA, no LDS)", co_rows_to_h2),
+              ("1x1x1 128 -> 128, split-f16 engine (k_gemm_h2p / k_gemm_h2w)", co_layer(pc1, "h2", 0)),
+              ("3x3x3 128 -> 128 direct, split-f16 engine (k_gemm_h2z<3,true>: global_load_lds A image)", co_layer(pc3, "h2", 0)),
+              ("3x3x3 128 -> 128 Winograd, split-f16 engine (k_wino_in_h2 + k_gemm_h2z<3,false> + k_wino_out)", co_layer(pc3, "h2", 1)),
+              ("3x3x3 128 -> 128 Winograd, fp32-MFMA engine (k_wino_in + k_conv + k_wino_out)", co_layer(pc3, "f32", 1)),
+              ("3x3x3 128 -> 128 direct, fp32-MFMA engine", co_layer(pc3, "f32", 0))]
+    full = [("nothing", None), ("decoder convolutions, split-f16 engine (global_load_lds GEMMs)", co_conv("h2")),
+            ("decoder convolutions, fp32-MFMA engine", co_conv("f32")), ("torch.mm 4096^3", co_mm),
+            ("torch elementwise over 256 MB", co_elem)]
+    argv = [a for a in sys.argv[1:] if a != "--bisect"]
+    corunners = bisect if "--bisect" in sys.argv else full
+
     s0, s1 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-    for mask in (sys.argv[1:] or ["2", "6", "0"]):       # 2 = half-column mix, 6 = the same with s_waitcnt vmcnt(0) after every load batch, 0 = per-voxel
+    for mask in (argv or ["2", "6", "0"]):       # 2 = half-column mix, 6 = the same with s_waitcnt vmcnt(0) after every load batch, 0 = per-voxel
         os.environ["COOCC_INTERP_COLUMN"] = mask
         with torch.cuda.stream(s0):
             mix(0)
         torch.cuda.synchronize()
         ref, ref_tw = outs[0].clone(), twins[0].clone()
-        for name, co in (("nothing", None), ("decoder convolutions, split-f16 engine (global_load_lds GEMMs)", co_conv("h2")),
-                         ("decoder convolutions, fp32-MFMA engine", co_conv("f32")), ("torch.mm 4096^3", co_mm),
-                         ("torch elementwise over 256 MB", co_elem)):
+        for name, co in corunners:
             for o, t in zip(outs, twins):
                 o.fill_(float("nan")); t.fill_(float("nan"))
             torch.cuda.synchronize()
