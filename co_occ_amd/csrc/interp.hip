@@ -252,7 +252,7 @@ __device__ __forceinline__ void mix_level(const MixLevels& lv, int b, int C, int
   MixZ<Z0, ZL, LV, ZB, ZN, PLO, NP, ZB>::run(q, lx, ly, lv.Z[LV], wn, acc);
 }
 
-template <int Z0, int Z1, int Z2, int Z3, int H>
+template <int Z0, int Z1, int Z2, int Z3, int H, int VAR>
 __device__ __forceinline__ void mix_half_column(const MixLevels& lv, const float* __restrict__ wlogit, float* __restrict__ out, int b,
                                                 int C, int x, int y, int X0, int Y0, int c, size_t col_row0,
                                                 void* __restrict__ twin, int* __restrict__ flag, int full_wait) {
@@ -283,13 +283,14 @@ __device__ __forceinline__ void mix_half_column(const MixLevels& lv, const float
   mix_level<Z0, Z2, 2, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc, full_wait);
   mix_level<Z0, Z3, 3, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc, full_wait);
 #pragma unroll
-  for (int z = 0; z < ZN; ++z) {
+  for (int k = 0; k < ZN; ++k) {
+    const int z = VAR ? ZN - 1 - k : k;            // VAR 1 (diagnostic): the stores in reverse order -- another register assignment
     *(f32x4*)(out + (row0 + z) * C + c) = acc[z];
     if (twin) { store_h2(twin, row0 + z, C, c, acc[z]); h2_guard(flag, acc[z]); }
   }
 }
 
-template <int Z0, int Z1, int Z2, int Z3>
+template <int Z0, int Z1, int Z2, int Z3, int VAR>
 __global__ __launch_bounds__(256) void k_occhead_mix_col(MixLevels lv, const float* __restrict__ wlogit, float* __restrict__ out,
                                                           int B, int C, void* __restrict__ twin, int* __restrict__ flag, int full_wait) {
   static_assert(Z0 % 2 == 0, "half columns");
@@ -303,8 +304,8 @@ __global__ __launch_bounds__(256) void k_occhead_mix_col(MixLevels lv, const flo
   const int y = (int)(v % (unsigned)Y0); v /= (unsigned)Y0;
   const int x = (int)(v % (unsigned)X0);
   const int b = (int)(v / (unsigned)X0);
-  if (blockIdx.y == 0) mix_half_column<Z0, Z1, Z2, Z3, 0>(lv, wlogit, out, b, C, x, y, X0, Y0, c, col_row0, twin, flag, full_wait);
-  else mix_half_column<Z0, Z1, Z2, Z3, 1>(lv, wlogit, out, b, C, x, y, X0, Y0, c, col_row0, twin, flag, full_wait);
+  if (blockIdx.y == 0) mix_half_column<Z0, Z1, Z2, Z3, 0, VAR>(lv, wlogit, out, b, C, x, y, X0, Y0, c, col_row0, twin, flag, full_wait);
+  else mix_half_column<Z0, Z1, Z2, Z3, 1, VAR>(lv, wlogit, out, b, C, x, y, X0, Y0, c, col_row0, twin, flag, full_wait);
 }
 
 extern "C" int coocc_occhead_mix_ex(const float* const* levels_host, const int* dims_host, int L, const float* wlogit,
@@ -325,8 +326,12 @@ extern "C" int coocc_occhead_mix_ex(const float* const* levels_host, const int* 
   const size_t cols = (size_t)B * lv.X[0] * lv.Y[0] * (C / 4);
 #define MIX_COL(Z0_, Z1_, Z2_, Z3_)                                                                                              \
   if (lv.Z[0] == Z0_ && lv.Z[1] == Z1_ && lv.Z[2] == Z2_ && lv.Z[3] == Z3_) {                                                   \
-    hipLaunchKernelGGL((k_occhead_mix_col<Z0_, Z1_, Z2_, Z3_>), dim3(cdiv(cols, 256), 2), dim3(256), 0, as_stream(stream), lv,  \
-                       wlogit, out, B, C, out_h2_twin, flag, (interp_column_mask() >> 2) & 1);                                  \
+    if (getenv("COOCC_MIX_COL_VAR"))                                                                                           \
+      hipLaunchKernelGGL((k_occhead_mix_col<Z0_, Z1_, Z2_, Z3_, 1>), dim3(cdiv(cols, 256), 2), dim3(256), 0, as_stream(stream), \
+                         lv, wlogit, out, B, C, out_h2_twin, flag, (interp_column_mask() >> 2) & 1);                            \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((k_occhead_mix_col<Z0_, Z1_, Z2_, Z3_, 0>), dim3(cdiv(cols, 256), 2), dim3(256), 0, as_stream(stream), \
+                         lv, wlogit, out, B, C, out_h2_twin, flag, (interp_column_mask() >> 2) & 1);                            \
     COOCC_LAUNCH_CHECK("k_occhead_mix_col");                                                                                    \
     return COOCC_OK;                                                                                                            \
   }
