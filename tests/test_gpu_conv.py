@@ -201,6 +201,7 @@ def test_interp_column_forms_equal_the_per_voxel_kernels_mix(dev, monkeypatch, s
     from eager calls with it, csrc/interp.hip) == the per-voxel kernel, bit for bit (output rows and H2 twin) when it runs alone:
     the r50 head's shapes, a batch of two, a level that shares x-y with the output grid; and torch."""
     import ctypes
+    torch.cuda.synchronize()        # ALONE: nothing of an earlier test may still run beside the mix form (it is off for that reason)
     g = torch.Generator().manual_seed(C + B)
     lv = [torch.randn(B, C, *s, generator=g) for s in sizes]
     logit = torch.randn(B, 4, *sizes[0], generator=g) * 3
