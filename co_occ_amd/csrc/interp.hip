@@ -225,7 +225,7 @@ __device__ __forceinline__ void load_corner_planes(f32x4 (&q)[4][NP], const floa
     for (int k = 0; k < NP; ++k) q[j][k] = *(const f32x4*)(p[j] + (size_t)k * C);
 }
 
-template <int Z0, int ZL, int LV, int ZB, int ZN, int PLO, int NP, int Z>
+template <int Z0, int ZL, int LV, int ZB, int ZN, int PLO, int NP, int VAR, int Z>
 struct MixZ {
   static __device__ __forceinline__ void run(const f32x4 (&q)[4][NP], const Lin1& lx, const Lin1& ly, int Zl, const float (&wn)[ZN][4],
                                              f32x4 (&acc)[ZN]) {
@@ -237,11 +237,12 @@ struct MixZ {
     const f32x4 s = lx.w0 * (ly.w0 * (lz.w0 * v000 + lz.w1 * v001) + ly.w1 * (lz.w0 * v010 + lz.w1 * v011)) +
                     lx.w1 * (ly.w0 * (lz.w0 * v100 + lz.w1 * v101) + ly.w1 * (lz.w0 * v110 + lz.w1 * v111));
     acc[Z - ZB] = acc[Z - ZB] + s * wn[Z - ZB][LV];
-    if constexpr (Z + 1 < ZB + ZN) MixZ<Z0, ZL, LV, ZB, ZN, PLO, NP, Z + 1>::run(q, lx, ly, Zl, wn, acc);
+    if constexpr (VAR == 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // diagnostic: wait states after every voxel's update
+    if constexpr (Z + 1 < ZB + ZN) MixZ<Z0, ZL, LV, ZB, ZN, PLO, NP, VAR, Z + 1>::run(q, lx, ly, Zl, wn, acc);
   }
 };
 
-template <int Z0, int ZL, int LV, int ZB, int ZN>
+template <int Z0, int ZL, int LV, int ZB, int ZN, int VAR>
 __device__ __forceinline__ void mix_level(const MixLevels& lv, int b, int C, int x, int y, int X0, int Y0, int c,
                                           const float (&wn)[ZN][4], f32x4 (&acc)[ZN], int full_wait) {
   constexpr int PLO = ZSrc<Z0, ZL>::i0(ZB), NP = ZSrc<Z0, ZL>::i1(ZB + ZN - 1) - PLO + 1;
@@ -249,7 +250,7 @@ __device__ __forceinline__ void mix_level(const MixLevels& lv, int b, int C, int
   f32x4 q[4][NP];
   load_corner_planes<ZL, PLO, NP>(q, lv.p[LV], b, C, lv.X[LV], lv.Y[LV], lx, ly, c);
   if (full_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // diagnostic (COOCC_INTERP_COLUMN bit 2): no partial waits
-  MixZ<Z0, ZL, LV, ZB, ZN, PLO, NP, ZB>::run(q, lx, ly, lv.Z[LV], wn, acc);
+  MixZ<Z0, ZL, LV, ZB, ZN, PLO, NP, VAR, ZB>::run(q, lx, ly, lv.Z[LV], wn, acc);
 }
 
 template <int Z0, int Z1, int Z2, int Z3, int H, int VAR>
@@ -277,14 +278,16 @@ __device__ __forceinline__ void mix_half_column(const MixLevels& lv, const float
     for (int l = 0; l < 4; ++l) { w[l] = expf(w[l] - mx); sum += w[l]; }
 #pragma unroll
     for (int l = 0; l < 4; ++l) wn[z][l] = w[l] / sum;
+    if constexpr (VAR == 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // ... and between the divisions and their first use
     acc[z] = zero + acc[z] * wn[z][0];
+    if constexpr (VAR == 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   }
-  mix_level<Z0, Z1, 1, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc, full_wait);
-  mix_level<Z0, Z2, 2, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc, full_wait);
-  mix_level<Z0, Z3, 3, ZB, ZN>(lv, b, C, x, y, X0, Y0, c, wn, acc, full_wait);
+  mix_level<Z0, Z1, 1, ZB, ZN, VAR>(lv, b, C, x, y, X0, Y0, c, wn, acc, full_wait);
+  mix_level<Z0, Z2, 2, ZB, ZN, VAR>(lv, b, C, x, y, X0, Y0, c, wn, acc, full_wait);
+  mix_level<Z0, Z3, 3, ZB, ZN, VAR>(lv, b, C, x, y, X0, Y0, c, wn, acc, full_wait);
 #pragma unroll
   for (int k = 0; k < ZN; ++k) {
-    const int z = VAR ? ZN - 1 - k : k;            // VAR 1 (diagnostic): the stores in reverse order -- another register assignment
+    const int z = VAR == 1 ? ZN - 1 - k : k;       // VAR 1 (diagnostic): the stores in reverse order -- another register assignment
     *(f32x4*)(out + (row0 + z) * C + c) = acc[z];
     if (twin) { store_h2(twin, row0 + z, C, c, acc[z]); h2_guard(flag, acc[z]); }
   }
@@ -326,12 +329,18 @@ extern "C" int coocc_occhead_mix_ex(const float* const* levels_host, const int* 
   const size_t cols = (size_t)B * lv.X[0] * lv.Y[0] * (C / 4);
 #define MIX_COL(Z0_, Z1_, Z2_, Z3_)                                                                                              \
   if (lv.Z[0] == Z0_ && lv.Z[1] == Z1_ && lv.Z[2] == Z2_ && lv.Z[3] == Z3_) {                                                   \
-    if (getenv("COOCC_MIX_COL_VAR"))                                                                                           \
-      hipLaunchKernelGGL((k_occhead_mix_col<Z0_, Z1_, Z2_, Z3_, 1>), dim3(cdiv(cols, 256), 2), dim3(256), 0, as_stream(stream), \
-                         lv, wlogit, out, B, C, out_h2_twin, flag, (interp_column_mask() >> 2) & 1);                            \
+    const char* var_ = getenv("COOCC_MIX_COL_VAR");    /* diagnostics: 1 = reversed stores, 2 = s_nop fences (DESIGN at-a-glance 6) */  \
+    const dim3 g_(cdiv(cols, 256), 2);                                                                                          \
+    const int fw_ = (interp_column_mask() >> 2) & 1;                                                                            \
+    if (var_ && var_[0] == '1')                                                                                                 \
+      hipLaunchKernelGGL((k_occhead_mix_col<Z0_, Z1_, Z2_, Z3_, 1>), g_, dim3(256), 0, as_stream(stream), lv, wlogit, out, B,   \
+                         C, out_h2_twin, flag, fw_);                                                                            \
+    else if (var_ && var_[0] == '2')                                                                                            \
+      hipLaunchKernelGGL((k_occhead_mix_col<Z0_, Z1_, Z2_, Z3_, 2>), g_, dim3(256), 0, as_stream(stream), lv, wlogit, out, B,   \
+                         C, out_h2_twin, flag, fw_);                                                                            \
     else                                                                                                                        \
-      hipLaunchKernelGGL((k_occhead_mix_col<Z0_, Z1_, Z2_, Z3_, 0>), dim3(cdiv(cols, 256), 2), dim3(256), 0, as_stream(stream), \
-                         lv, wlogit, out, B, C, out_h2_twin, flag, (interp_column_mask() >> 2) & 1);                            \
+      hipLaunchKernelGGL((k_occhead_mix_col<Z0_, Z1_, Z2_, Z3_, 0>), g_, dim3(256), 0, as_stream(stream), lv, wlogit, out, B,   \
+                         C, out_h2_twin, flag, fw_);                                                                            \
     COOCC_LAUNCH_CHECK("k_occhead_mix_col");                                                                                    \
     return COOCC_OK;                                                                                                            \
   }

@@ -6,6 +6,8 @@ with the kernel's own result computed alone.
 
     python tools/debug/mix_corunner.py            # both forms x every co-runner
     python tools/debug/mix_corunner.py --bisect 2 # the column form next to ONE split-f16 kernel family at a time
+    COOCC_MIX_COL_VAR=1 python tools/debug/mix_corunner.py --bisect 2   # the same source with its stores reversed: 0 of 20 (round 5)
+    COOCC_MIX_COL_VAR=2 python tools/debug/mix_corunner.py --bisect 2   # s_nop fences after every division / accumulator update (not run yet)
 
 Read it next to tools/debug/fine2_corunner.py (the one-launch ratio-2 fine branch): if the column form differs here
 too, the defect is at kernel level (co-residency), not a race between the slots' graphs."""
