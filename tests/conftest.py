@@ -29,3 +29,31 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def pytest_collection_finish(session):
+    """Start the CPU-oracle process pool (tests/oracle_jobs.py) for the large parity scenes the selected tests will ask for, so
+    that their fp32 / fp64 oracle evaluations run on the host cores WHILE the GPU tests run."""
+    wanted = []
+    for item in session.items:
+        if item.get_closest_marker("gpu") is None:
+            continue
+        try:
+            import oracle_jobs
+        except Exception:
+            return
+        for pat, keys in oracle_jobs.WANTS.items():
+            if pat in item.nodeid:
+                wanted += keys
+    if not wanted or session.config.option.collectonly:
+        return
+    import torch
+    if torch.cuda.is_available():
+        import oracle_jobs
+        oracle_jobs.start(wanted)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    mod = sys.modules.get("oracle_jobs")
+    if mod is not None:
+        mod.shutdown()

@@ -14,6 +14,7 @@ import torch.nn.functional as F
 import co_occ_amd as pkg
 import co_occ_amd.synth as synth
 from co_occ_amd import core
+import oracle_jobs as J
 from oracle import ref_cpu
 from test_gpu_conv import CASES, bn_like, rows_of
 from util import assert_close, rel_err
@@ -57,15 +58,8 @@ def test_conv_bf16_mfma_equals_conv_on_bf16_rounded_operands(dev, monkeypatch, C
     assert 1e-5 < e < 2e-2, e
 
 
-def _trunk(dev, grid, seed, gain=1.0):
-    cfg = synth.model_cfg_openocc()
-    model = pkg.build_detector(cfg)
-    sd = synth.random_state_dict(model.state_dict(), seed=seed, gain=gain)
-    model.load_state_dict(sd)
-    X, Y, Z = grid
-    g = synth._rng(seed, "cat4")
-    cat4 = torch.from_numpy(g.standard_normal((1, 512, X, Y, Z), dtype=np.float32))
-    cat4 *= torch.from_numpy((g.random((1, 1, X, Y, Z)) < 0.7).astype(np.float32))
+def _trunk(dev):
+    model, sd, cat4 = J.openocc_trunk_scene()
     return model.to(dev).eval(), sd, cat4
 
 
@@ -81,17 +75,6 @@ def _hip_trunk(model, cat4, dev):
     return vf.as_ncdhw().cpu(), occ.as_ncdhw().cpu()
 
 
-def _oracle_trunk(sd, cat4, dtype=None):
-    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
-    x = cat4
-    if dtype is not None:
-        sd, x = ref_cpu.to_dtype(dict(sd), dtype), cat4.to(dtype)
-        sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
-    vf = ref_cpu.con_enc(sub("occ_fuser."), x.permute(0, 2, 3, 4, 1))
-    sem = ref_cpu.fpn3d_forward(sub("semantic_neck."), ref_cpu.resnet3d_forward(sub("semantic_encoder."), vf))
-    return vf, ref_cpu.occhead_coarse(sub("pts_bbox_head."), sem)["occ"]
-
-
 def test_openocc_decoder_fp32_and_bf16_at_full_size(dev, monkeypatch):
     """C0-C3 on the OpenOccupancy fused grid (128 x 128 x 10 x 512 -> 17 classes; 3.56 TFLOP of convolutions).
     fp32 (default dispatch: Winograd F(2x2)/F(4x4) + persistent GEMMs at this size): within 1e-4 of the oracle / the fp64 anchor.
@@ -101,23 +84,17 @@ def test_openocc_decoder_fp32_and_bf16_at_full_size(dev, monkeypatch):
     logits are judged against the fp64 anchor:  err(HIP bf16, fp64) <= 1.5 x err(oracle bf16, fp64)  (both reported; that
     distance IS the price of the reduced precision -- the kernel itself is pinned layer by layer above)."""
     import os
-    grid = synth.CONFIGS["openocc"]["grid"]
-    model, sd, cat4 = _trunk(dev, grid, seed=9, gain=0.85)
-    o32 = _oracle_trunk(sd, cat4)
-    o64 = _oracle_trunk(sd, cat4, torch.float64)
-    monkeypatch.setattr(ref_cpu, "CONV_OPERAND_DTYPE", torch.bfloat16)
-    obf = _oracle_trunk(sd, cat4)
-    monkeypatch.setattr(ref_cpu, "CONV_OPERAND_DTYPE", None)
+    model, sd, cat4 = _trunk(dev)
     h32 = _hip_trunk(model, cat4, dev)
     monkeypatch.setattr(core, "CONV_DTYPE", "bf16")
     hbf = _hip_trunk(model, cat4, dev)
     # the fp16 the config names (one-term f16 MFMA, 16-bit activations written by the producing layer): same judgement against
     # the oracle evaluated with f16-rounded conv operands and the fp64 anchor
-    monkeypatch.setattr(ref_cpu, "CONV_OPERAND_DTYPE", torch.float16)
-    of16 = _oracle_trunk(sd, cat4)
-    monkeypatch.setattr(ref_cpu, "CONV_OPERAND_DTYPE", None)
     monkeypatch.setattr(core, "CONV_DTYPE", "f16")
     hf16 = _hip_trunk(model, cat4, dev)
+    # the four oracle evaluations (fp32, fp64, bf16- and f16-rounded conv operands) come from the oracle process pool
+    o32, o64, obf, of16 = (J.get("openocc_trunk_" + k) for k in ("o32", "o64", "obf", "of16"))
+    J.release(*("openocc_trunk_" + k for k in ("o32", "o64", "obf", "of16")))
     lines = []
     for name, i in (("voxel_feats", 0), ("coarse logits", 1)):
         scale = max(1.0, float(o64[i].abs().max()))
@@ -140,7 +117,7 @@ def test_openocc_decoder_fp32_and_bf16_at_full_size(dev, monkeypatch):
         assert e(hf16[i], o64[i]) <= 1.5 * e(of16[i], o64[i]) + 1e-4 and r(hf16[i], o64[i]) <= 1.5 * r(of16[i], o64[i]) + 1e-5, lines[-1]
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    with open(os.path.join(d, "r5_openocc_parity.txt"), "a") as f:
+    with open(os.path.join(d, "r6_openocc_parity.txt"), "a") as f:
         f.write("\n".join(lines) + "\n")
 
 
@@ -148,26 +125,12 @@ _E2E = {}        # oracle evaluations of the end-to-end scene, shared by the par
 
 
 def _e2e_scene():
+    """The scene and its oracle evaluations (tests/oracle_jobs.py:job_openocc_e2e, run in the oracle process pool): fp32 with the
+    render block in the per-voxel-table form over all rays + the literal form on the strided ray subset, fp64, neighbour tables."""
     if "scene" not in _E2E:
-        c = synth.CONFIGS["openocc"]
-        seed, gain = 5, 0.85
-        model = pkg.build_detector(synth.model_cfg_openocc())
-        sd = synth.random_state_dict(model.state_dict(), seed=seed, gain=gain)
-        img, pts = synth.voxel_inputs(c["grid"], C=c["C"], seed=70 + seed)
-        rig = synth.camera_rig(c["ncam"], c["input_size"], seed=70 + seed)
-        img_feats = [synth.image_feats(c["ncam"], c["fmap"], 512, seed=70 + seed)]
-        tr = synth.rig_transform(rig)
-        fr = ref_cpu.create_frustum(c["input_size"], 16, [2.0, 58.0, 0.5])
-        gemo = ref_cpu.get_geometry(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
-
-        def subset(n):
-            g = torch.Generator().manual_seed(1234)
-            return torch.randperm(n, generator=g)[:60000].sort().values
-        kw = dict(knum=2, cascade_ratio=4, final_occ_size=c["final_occ_size"], point_cloud_range=c["point_cloud_range"], fine_subset=subset)
-        o32 = ref_cpu.hot_path_forward(sd, img, pts, gemo, img_feats, tr, literal_render=True, **kw)
-        o64 = ref_cpu.hot_path_forward(sd, img, pts, gemo, img_feats, tr, dtype=torch.float64, render=False, **kw)
-        fuse = ref_cpu.bifuser_fuse({k[len("occ_fuser."):]: v for k, v in sd.items() if k.startswith("occ_fuser.")}, img, pts, 2)
-        _E2E["scene"] = dict(c=c, sd=sd, img=img, pts=pts, rig=rig, img_feats=img_feats, tr=tr, gemo=gemo, kw=kw, o32=o32, o64=o64, fuse=fuse)
+        S = J.openocc_e2e_scene()
+        S.update(o32=J.get("openocc_e2e_o32"), o64=J.get("openocc_e2e_o64"), fuse=J.get("openocc_e2e_fuse"))
+        _E2E["scene"] = S
     return _E2E["scene"]
 
 
@@ -219,12 +182,7 @@ def test_openocc_end_to_end_vs_subsampled_oracle(dev, monkeypatch, dtype):
     o32, o64 = S["o32"], S["o64"]
     lines = []
     if dtype == "f16":
-        if "o16" not in _E2E:
-            monkeypatch.setattr(ref_cpu, "CONV_OPERAND_DTYPE", torch.float16)
-            # (the per-voxel table form of the render block: equal to the literal gather-then-MLP form to 2e-7, minutes faster)
-            _E2E["o16"] = ref_cpu.hot_path_forward(sd, S["img"], S["pts"], S["gemo"], S["img_feats"], S["tr"], literal_render=False, **S["kw"])
-            monkeypatch.setattr(ref_cpu, "CONV_OPERAND_DTYPE", None)
-        o16 = _E2E["o16"]
+        o16 = J.get("openocc_e2e_o16")          # conv operands rounded to f16 (ref_cpu.CONV_OPERAND_DTYPE), table-form render
     for k_hip, k_ref in (("voxel_feats", "voxel_feats"), ("pred_c", "output_voxels")):
         h, r32, r64 = out[k_hip].detach().cpu().double(), o32[k_ref].double(), o64[k_ref]
         scale = max(1.0, float(r64.abs().max()))
@@ -274,7 +232,9 @@ def test_openocc_end_to_end_vs_subsampled_oracle(dev, monkeypatch, dtype):
     e_rgb = float((out["rgbs"].cpu() - o32["rgbs"]).abs().max())
     e_dep = rel_err(out["depths"].cpu(), o32["depths"])
     if dtype == "f32":
-        lines.append("openocc e2e f32 render 6x896x1600: rgbs abs %.2e depths rel %.2e" % (e_rgb, e_dep))
+        lines.append("openocc e2e f32 render 6x896x1600: rgbs abs %.2e depths rel %.2e ; oracle literal vs table form on the strided rays %.2e / %.2e" % (
+            (e_rgb, e_dep) + tuple(o32["literal_dev"])))
+        assert max(o32["literal_dev"]) <= 2e-6, lines[-1]
         assert e_rgb <= 1e-4 and e_dep <= 1e-4, lines[-1]
     else:
         r_rgb = float((o16["rgbs"] - o32["rgbs"]).abs().max())
@@ -285,7 +245,7 @@ def test_openocc_end_to_end_vs_subsampled_oracle(dev, monkeypatch, dtype):
     assert tuple(out["pred_f"].shape) == (1, 17) + tuple(c["final_occ_size"])
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    with open(os.path.join(d, "r5_openocc_parity.txt"), "a") as f:
+    with open(os.path.join(d, "r6_openocc_parity.txt"), "a") as f:
         f.write("\n".join(lines) + "\n")
     for l in lines:
         print(l, flush=True)

@@ -10,7 +10,7 @@
 * one full-size ``configs[1]`` scene (100x100x8x128, 6 cameras 16x44, knum 2, render on) through the default dispatch --
   the dispatch bench.py times -- and the r101 render pair (6 x 56 x 100 rays -> 6 x 896 x 1600 maps).
 
-The sweep table is written to gpurun_out/r5_parity_seed_sweep.txt (copied to profiles/); every line carries the ABSOLUTE errors
+The sweep table is written to gpurun_out/r6_parity_seed_sweep.txt (copied to profiles/); every line carries the ABSOLUTE errors
 and, in parentheses, the same errors as a fraction of the tensor's scale."""
 import os
 
@@ -21,6 +21,7 @@ import torch
 import co_occ_amd as pkg
 import co_occ_amd.synth as synth
 from co_occ_amd import render as R
+import oracle_jobs as J
 from oracle import ref_cpu
 from util import TOL, rel_err
 
@@ -34,13 +35,14 @@ pytestmark = pytest.mark.gpu
 C_RMS, C_MAX, C_MAX_MEAN = 1.5, 3.0, 1.5
 RATIOS = []               # (tag, max ratio, rms ratio) of every judged scene, for the aggregate test at the end of the file
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL_RANGE = (-25, -25, -5.0, 25, 25, 3.0)
+SMALL_RANGE = J.SMALL_RANGE
+LITERAL_DEV = 2e-6        # literal gather-then-MLP render form vs the per-voxel-table form on the strided ray subset (oracle vs oracle)
 
 
 def _log(line):
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    with open(os.path.join(d, "r5_parity_seed_sweep.txt"), "a") as f:
+    with open(os.path.join(d, "r6_parity_seed_sweep.txt"), "a") as f:
         f.write(line + "\n")
     print(line, flush=True)
 
@@ -63,15 +65,7 @@ def _errs(a, ref):
     return float(d.max()), float((d ** 2).mean().sqrt())
 
 
-def _scene(grid, fmap, ncam, input_size, seed, gain, final_occ, pc_range, knum=2, C=128):
-    cfg = synth.model_cfg(C=C, knum=knum, final_occ_size=final_occ, point_cloud_range=pc_range, input_size=input_size)
-    model = pkg.build_detector(cfg)
-    sd = synth.random_state_dict(model.state_dict(), seed=seed, gain=gain)
-    model.load_state_dict(sd)
-    img, pts = synth.voxel_inputs(grid, C=C, seed=70 + seed)
-    rig = synth.camera_rig(ncam, input_size, seed=70 + seed)
-    img_feats = [synth.image_feats(ncam, fmap, 512, seed=70 + seed)]
-    return model, sd, img, pts, rig, img_feats
+_scene = J.scene
 
 
 def _run_hip(model, dev, img, pts, gemo, img_feats, tr, render):
@@ -115,20 +109,21 @@ def _judge(tag, out, o32, o64, abs_bound=None):
     assert rh <= C_RMS * rr + ulp, "%s fine logits: rms error vs fp64 %.3e > %.1f x the fp32 oracle's %.3e" % (tag, rh, C_RMS, rr)
 
 
-SWEEP = [(seed, 1.0) for seed in (5, 6, 7, 8, 9, 10, 11, 12)] + [(seed, 0.85) for seed in (5, 6, 7, 8)]
+SWEEP = J.SWEEP
 
 
 @pytest.mark.parametrize("seed,gain", SWEEP)
 def test_hot_path_fp64_anchored_seed_sweep(dev, seed, gain):
     """50x50x8 scene, 6 cameras 4x11, every seed of the committed sweep (weights AND inputs change with the seed), default
-    conv dispatch.  gain 0.85 keeps |logit| <= 10: there the well-conditioned outputs also meet the ABSOLUTE 1e-4."""
-    grid = (50, 50, 8)
-    model, sd, img, pts, rig, img_feats = _scene(grid, (4, 11), 6, (64, 176), seed, gain, (100, 100, 16), SMALL_RANGE)
+    conv dispatch.  gain 0.85 keeps |logit| <= 10: there the well-conditioned outputs also meet the ABSOLUTE 1e-4.
+    The fp32 / fp64 oracle evaluations of the scene come from the oracle process pool (tests/oracle_jobs.py:job_sweep)."""
+    model, sd, img, pts, rig, img_feats = J.sweep_scene(seed, gain)
     tr = synth.rig_transform(rig)
     out = _run_hip(model, dev, img, pts, None, img_feats, tr, render=False)
-    kw = dict(knum=2, final_occ_size=(100, 100, 16), point_cloud_range=SMALL_RANGE, render=False)
-    o32 = ref_cpu.hot_path_forward(sd, img, pts, None, img_feats, tr, **kw)
-    o64 = ref_cpu.hot_path_forward(sd, img, pts, None, img_feats, tr, dtype=torch.float64, **kw)
+    key = "sweep_%d_%.2f" % (seed, gain)
+    o = J.get(key)
+    o32, o64 = o["o32"], o["o64"]
+    J.release(key)
     if gain < 1.0:
         assert float(o64["output_voxels"].abs().max()) <= 10.0
     _judge("50x50x8 seed %2d gain %.2f" % (seed, gain), out, o32, o64, abs_bound=1e-4 if gain < 1.0 else None)
@@ -138,18 +133,12 @@ _R50 = {}
 
 
 def _r50_scene():
-    """The full-size configs[1] scene and its oracle evaluations (fp32, fp64, neighbour tables), computed once per session."""
+    """The full-size configs[1] scene and its oracle evaluations (fp32 with the literal render block over all rays, fp64,
+    neighbour tables: three jobs of the oracle pool), fetched once per session."""
     if not _R50:
-        c = synth.CONFIGS["r50"]
-        model, sd, img, pts, rig, img_feats = _scene(c["grid"], c["fmap"], c["ncam"], (256, 704), 3, 1.0, (200, 200, 16),
-                                                     (-50, -50, -5.0, 50, 50, 3.0))
-        tr = synth.rig_transform(rig)
-        fr = ref_cpu.create_frustum((256, 704), 16, [2.0, 58.0, 0.5])
-        gemo = ref_cpu.get_geometry(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
-        o32 = ref_cpu.hot_path_forward(sd, img, pts, gemo, img_feats, tr, knum=2, literal_render=True)
-        fuse = ref_cpu.bifuser_fuse({k[len("occ_fuser."):]: v for k, v in sd.items() if k.startswith("occ_fuser.")}, img, pts, 2)
-        o64 = ref_cpu.hot_path_forward(sd, img, pts, gemo, img_feats, tr, knum=2, dtype=torch.float64, render=False)
-        _R50.update(sd=sd, img=img, pts=pts, img_feats=img_feats, tr=tr, gemo=gemo, o32=o32, o64=o64, fuse=fuse)
+        S = J.r50_scene(want_model=False)
+        _R50.update(sd=S["sd"], img=S["img"], pts=S["pts"], img_feats=S["img_feats"], tr=S["tr"], gemo=S["gemo"],
+                    o32=J.get("r50_o32"), o64=J.get("r50_o64"), fuse=J.get("r50_fuse"))
     return _R50
 
 
@@ -199,36 +188,24 @@ def test_stress200_r101_end_to_end_properties(dev):
     tables BIT-EXACT against the oracle's index search; the fused voxel features against the oracle's two con_enc layers
     evaluated on cropped neighbourhoods (receptive field 5^3) at seeded positions; the rendered maps against the oracle's
     render block fed with the HIP features; finite logits, the scattered fine grid's shape and the fine list's consistency."""
-    c = synth.CONFIGS["stress200_r101"]
-    X, Y, Z = c["grid"]
-    H, W = c["fmap"][0] * 16, c["fmap"][1] * 16
-    model, sd, img, pts, rig, img_feats = _scene(c["grid"], c["fmap"], c["ncam"], (H, W), 2, 1.0, (2 * X, 2 * Y, 2 * Z),
-                                                 (-100, -100, -5.0, 100, 100, 11.0))
-    tr = synth.rig_transform(rig)
-    fr = ref_cpu.create_frustum((H, W), 16, [2.0, 58.0, 0.5])
-    gemo = ref_cpu.get_geometry(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
+    S = J.stress200_scene()
+    (X, Y, Z), (H, W) = S["grid"], S["HW"]
+    model, sd, img, pts, img_feats, tr, gemo = S["model"], S["sd"], S["img"], S["pts"], S["img_feats"], S["tr"], S["gemo"]
     out = _run_hip(model, dev, img, pts, gemo, img_feats, tr, render=True)
     torch.cuda.synchronize()
     from co_occ_amd import core
     core.check_h2_overflow()
-    fsd = {k[len("occ_fuser."):]: v for k, v in sd.items() if k.startswith("occ_fuser.")}
-    fuse = ref_cpu.bifuser_fuse(fsd, img, pts, 2)
+    O = J.get("stress200")                  # neighbour tables + cropped con_enc evaluations (tests/oracle_jobs.py:job_stress200)
+    J.release("stress200")
     near_img, near_pts = model.occ_fuser.last_near
-    assert np.array_equal(near_img.cpu().numpy().reshape(fuse["near_img"].shape), fuse["near_img"].numpy())      # bit-exact
-    assert np.array_equal(near_pts.cpu().numpy().reshape(fuse["near_pts"].shape), fuse["near_pts"].numpy())
+    assert np.array_equal(near_img.cpu().numpy().reshape(O["near_img"].shape), O["near_img"].numpy())      # bit-exact
+    assert np.array_equal(near_pts.cpu().numpy().reshape(O["near_pts"].shape), O["near_pts"].numpy())
     vf = out["voxel_feats"].detach().cpu()
-    allf = fuse["all_feats"]                                      # [1,X,Y,Z,4C]
-    g = np.random.default_rng(3)
-    worst = 0.0
+    g = np.random.default_rng(4)
     scale = max(1.0, float(vf.abs().max()))
-    for _ in range(24):
-        cx, cy, cz = int(g.integers(0, X)), int(g.integers(0, Y)), int(g.integers(0, Z))
-        x0, x1, y0, y1, z0, z1 = max(cx - 2, 0), min(cx + 3, X), max(cy - 2, 0), min(cy + 3, Y), max(cz - 2, 0), min(cz + 3, Z)
-        # crops that touch the volume's border keep the zero padding there; interior crop borders are 2 voxels away from the
-        # centre, i.e. outside the 5^3 receptive field of the two 3x3x3 layers
-        want = ref_cpu.con_enc(fsd, allf[:, x0:x1, y0:y1, z0:z1])[0, :, cx - x0, cy - y0, cz - z0]
-        worst = max(worst, float((vf[0, :, cx, cy, cz] - want).abs().max()))
-    _log("stress200_r101: voxel_feats vs cropped oracle, 24 positions: abs %.2e (of scale %.2e, |x| %.1f)" % (worst, worst / scale, scale))
+    got = torch.stack([vf[0, :, cx, cy, cz] for cx, cy, cz in O["pos"]])
+    worst = float((got - O["want"]).abs().max())
+    _log("stress200_r101: voxel_feats vs cropped oracle, %d positions: abs %.2e (of scale %.2e, |x| %.1f)" % (len(O["pos"]), worst, worst / scale, scale))
     assert worst <= TOL * scale
     assert torch.isfinite(out["pred_c"]).all() and torch.isfinite(out["pred_f"]).all()
     assert tuple(out["pred_c"].shape) == (1, 17, X, Y, Z) and tuple(out["pred_f"].shape) == (1, 17, 2 * X, 2 * Y, 2 * Z)
@@ -250,26 +227,23 @@ def test_stress200_r101_end_to_end_properties(dev):
 
 
 def test_full_size_r101_render_pair_vs_oracle(dev):
-    """configs[2]'s render pair: 6 x 56 x 100 rays x 112 samples -> 6 x 896 x 1600 maps, literal oracle (gather-then-MLP)."""
-    c = synth.CONFIGS["r101"]
-    seed = 4
-    g = synth._rng(seed, "vf")
-    X, Y, Z = c["grid"]
-    vf = torch.from_numpy(g.standard_normal((1, 128, X, Y, Z), dtype=np.float32))
-    rig = synth.camera_rig(6, (896, 1600), seed=seed)
+    """configs[2]'s render pair: 6 x 56 x 100 rays x 112 samples -> 6 x 896 x 1600 maps.  The whole maps against the oracle's
+    per-voxel-table form; the LITERAL form (gather-then-MLP, coocc_ray.py:570-627) is evaluated by the oracle on every 2nd x
+    3rd ray and must equal the table form there (tests/oracle_jobs.py:render_table_with_literal_check)."""
+    S = J.r101_render_scene()
     sig, rgb = R.MLP(128, 1, net_depth=1, skip_layer=None), R.MLP(128, 3, net_depth=3, skip_layer=None)
-    ssd, rsd = synth.random_state_dict(sig.state_dict(), seed), synth.random_state_dict(rgb.state_dict(), seed + 1)
-    sig.load_state_dict(ssd)
-    rgb.load_state_dict(rsd)
-    fr = ref_cpu.create_frustum((896, 1600), 16, [2.0, 58.0, 0.5])
-    gemo = ref_cpu.get_geometry(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"], rig["bda"])
+    sig.load_state_dict(S["ssd"])
+    rgb.load_state_dict(S["rsd"])
     with torch.no_grad():
-        rgbs, depths, _ = R.render_block(sig.to(dev), rgb.to(dev), vf.to(dev), gemo.to(dev), 16)
+        rgbs, depths, _ = R.render_block(sig.to(dev), rgb.to(dev), S["vf"].to(dev), S["gemo"].to(dev), 16)
     assert tuple(rgbs.shape) == (6, 896, 1600, 3) and tuple(depths.shape) == (6, 896, 1600)
-    wr, wd = ref_cpu.render_block(ssd, rsd, vf, gemo, literal=True)
-    e_rgb = float((rgbs.cpu() - wr).abs().max())
-    e_dep = rel_err(depths.cpu(), wd)
-    _log("r101 render pair: rgbs abs %.2e depths rel %.2e" % (e_rgb, e_dep))
+    O = J.get("r101_render")
+    J.release("r101_render")
+    e_rgb = float((rgbs.cpu() - O["rgbs"]).abs().max())
+    e_dep = rel_err(depths.cpu(), O["depths"])
+    _log("r101 render pair: rgbs abs %.2e depths rel %.2e ; oracle literal vs table form on the %dx%d-strided rays: %.2e / %.2e" % (
+        (e_rgb, e_dep) + J.LITERAL_STRIDE + tuple(O["literal_dev"])))
+    assert max(O["literal_dev"]) <= LITERAL_DEV
     assert e_rgb <= TOL and e_dep <= TOL
 
 
