@@ -144,6 +144,7 @@ SIGNATURES = {
     "coocc_wino_output": (I, [P, L, I, I, I, I, I, I, P, I, P, P, P, I, I, P]),
     "coocc_wino_output_ex": (I, [P, L, I, I, I, I, I, I, P, I, P, P, P, I, I, P, P]),
     "coocc_h2_overflow": (I, [I]),
+    "coocc_device_fault": (I, [I]),
     "coocc_render_heads_h2": (I, [P, I, I, I, P, P, P, P, P, P, I, P, P, P, I, P]),
     "coocc_projection_params": (I, [P, P, P, P, P, P, I, P, P, P]),
     "coocc_occhead_mix_bwd": (I, [P, P, I, P, P, P, P, I, I, P]),
@@ -242,12 +243,27 @@ def load():
 
 
 class CooccError(RuntimeError):
-    pass
+    """Any error of the HIP library.  ``code``: the C ABI's COOCC_E* value (include/coocc_hip.h:31-34) when the library
+    returned one, else None."""
+    code = None
+
+
+class CooccArgError(CooccError):
+    """COOCC_EINVAL / COOCC_ENOMEM: the library REFUSED the call (an argument or shape an entry point does not take, a
+    workspace that is too small) before launching anything -- nothing ran, the caller may take another route."""
+
+
+class CooccRangeError(CooccError):
+    """The split-f16 engine's range guard fired (``core.check_h2_overflow``): kernels ran and their result is not trustworthy.
+    Never a reason to fall back silently."""
 
 
 def check(rc):
     if rc != 0:
-        raise CooccError("libcoocc_hip: %s (code %d)" % (load().coocc_last_error().decode(), rc))
+        cls = CooccArgError if rc in (-1, -3) else CooccError          # COOCC_EINVAL, COOCC_ENOMEM | COOCC_EHIP and the rest
+        e = cls("libcoocc_hip: %s (code %d)" % (load().coocc_last_error().decode(), rc))
+        e.code = rc
+        raise e
 
 
 def _device_of(args):

@@ -244,7 +244,7 @@ class PackedConv:
         lane l of step s holds k = 32 chunk + 16 s + 8 (l >> 5) + 0..7 of column 32 nt + (l & 31)."""
         npad, cin, taps = w64.shape
         if w64.numel() and float(w64.abs().max()) >= 32768.0:
-            raise _lib.CooccError("split-f16 engine: a weight of magnitude %.3g does not fit the f16 operand range (|w| < 32768); "
+            raise _lib.CooccRangeError("split-f16 engine: a weight of magnitude %.3g does not fit the f16 operand range (|w| < 32768); "
                                   "set COOCC_CONV_ENGINE=f32 for this model" % float(w64.abs().max()))
         hi = w64.to(torch.float16)
         lo = ((w64 - hi.double()) * 2048.0).to(torch.float16)
@@ -456,8 +456,14 @@ def check_h2_overflow(reset=True):
     """Raise if a kernel of the split-f16 engine wrote a 16-bit operand outside its guarded range since the last check
     (csrc/h2_rows.h h2_guard: |v| >= 32768 after the writer's scale, or NaN).  Call after the stream(s) have been synchronised
     -- the detector does at its own host reads (the fine-branch count, the metrics) and ``serving`` when a result is fetched."""
+    fault = _lib.load().coocc_device_fault(1 if reset else 0)
+    if fault:
+        raise _lib.CooccError("libcoocc_hip: a kernel met an index outside the buffer it addresses and skipped the access (fault code %d: "
+                              "%s) -- the outputs of this sample are not trustworthy" % (
+                                  fault, {1: "coocc_sparse_tap_sum read a voxel -> ordinal map entry past the rows it was sized for "
+                                             "(a stale or corrupted map)"}.get(fault, "unknown")))
     if _lib.load().coocc_h2_overflow(1 if reset else 0):
-        raise _lib.CooccError(
+        raise _lib.CooccRangeError(
             "split-f16 engine: an activation left the f16 operand range (|x| >= 32768, or %g for the F(4x4) Winograd layers whose "
             "transform amplifies by up to 100 at scale 1/8; NaN counts) -- the outputs of this sample are not trustworthy.  "
             "Set COOCC_CONV_ENGINE=f32 (exact-fp32 MFMA kernels, no range limit; ~1.8x slower) or rescale the inputs "
@@ -803,7 +809,14 @@ class PackCache:
         self._val = None
         self._slots = None
         if owner is not None and hasattr(owner, "register_load_state_dict_post_hook"):
-            owner.register_load_state_dict_post_hook(lambda module, incompatible_keys: self.invalidate())
+            owner.register_load_state_dict_post_hook(self._on_load_state_dict)
+
+    def _on_load_state_dict(self, module, incompatible_keys):
+        self.invalidate()
+
+    def __getstate__(self):
+        # pickling a module (torch.save(model), multiprocessing spawn) carries the hook = this object: without its device packs
+        return dict(_key=None, _val=None, _slots=None)
 
     def invalidate(self):
         self._key = self._val = None

@@ -936,6 +936,15 @@ extern "C" int coocc_h2_overflow(int reset) {
   if (reset) *(volatile int*)g_h2_flag = 0;
   return v;
 }
+// Word 1 of the same mapped block: a sticky DEVICE FAULT code (COOCC_FAULT_*) stored by kernels that meet data no valid caller can
+// produce (an index past the buffer it addresses) -- they skip the access instead of faulting the GPU and the host turns the code
+// into an error at its next synchronisation point.
+extern "C" int coocc_device_fault(int reset) {
+  if (!g_h2_flag) return 0;
+  const int v = ((volatile int*)g_h2_flag)[1];
+  if (reset) ((volatile int*)g_h2_flag)[1] = 0;
+  return v;
+}
 
 int coocc_launch_h2(ConvK& k, const coocc_conv_desc* d, hipStream_t s) {
   const bool one = d->mfma_dtype == 4;          // one-term f16 operands ([rows][C] f16), 64 channels per stage

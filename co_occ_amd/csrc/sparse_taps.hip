@@ -12,11 +12,13 @@
 // channels cost inside the F(2x2) GEMM at 12 % occupancy.
 #include "common.h"
 
+int coocc_h2_flag_ptr(int** out);      // gemm_h2.hip: the process-wide host-mapped flag block (word 0 range guard, word 1 fault)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_sparse_tap_sum(const float* __restrict__ P, const int32_t* __restrict__ map, int X, int Y,
                                                          int Z, int nvox, int Cout, const float* __restrict__ scale,
-                                                         float* __restrict__ S, int s_stride, int p_rows) {
+                                                         float* __restrict__ S, int s_stride, int p_rows, int* fault) {
   const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   if (v >= nvox) return;
   const int z = v % Z, y = (v / Z) % Y, x = (v / (Z * Y)) % X, b = v / (Z * Y * X);
@@ -33,10 +35,10 @@ __global__ __launch_bounds__(256) void k_sparse_tap_sum(const float* __restrict_
           if ((unsigned)ux >= (unsigned)X || (unsigned)uy >= (unsigned)Y || (unsigned)uz >= (unsigned)Z) continue;
           const int ord = map[((b * X + ux) * Y + uy) * Z + uz];        // wave-uniform
           if (ord < 0) continue;
-          if (p_rows > 0 && ord >= p_rows) {                      // an ordinal past the rows P was sized for is never valid: say so
-            if (lane == 0 && (v & 1023) == 0) printf("k_sparse_tap_sum: voxel %d tap %d ordinal %d >= %d rows\n", v, t, ord, p_rows);
-            continue;                                             // (instead of a GPU memory fault; found the memset-node problem of
-          }                                                       //  coocc_voxel_index_map_dev in round 5)
+          if (p_rows > 0 && ord >= p_rows) {                      // an ordinal past the rows P was sized for is never valid: raise the
+            if (lane == 0 && fault) *(volatile int*)fault = COOCC_FAULT_SPARSE_ORDINAL;   // sticky fault word (the host's next
+            continue;                                             // coocc_device_fault read raises) instead of a GPU memory fault
+          }                                                       // (found the memset-node problem of coocc_voxel_index_map_dev, round 5)
           if (on) acc = acc + *(const f32x4*)(P + (size_t)ord * prow + (size_t)t * Cout + c);
         }
     if (on) {
@@ -56,8 +58,10 @@ extern "C" int coocc_sparse_tap_sum(const float* P, const int32_t* map, int B, i
   COOCC_CHECK_ARG(((uintptr_t)P & 15) == 0 && ((uintptr_t)S & 15) == 0 && (!scale || ((uintptr_t)scale & 15) == 0), "sparse_tap_sum: alignment");
   const long long nvox = (long long)B * X * Y * Z;
   COOCC_CHECK_ARG(nvox < (1ll << 31), "sparse_tap_sum: grid too large");
+  int* flag = nullptr;
+  if (coocc_h2_flag_ptr(&flag) != COOCC_OK) return COOCC_EHIP;
   hipLaunchKernelGGL(k_sparse_tap_sum, dim3(cdiv(nvox, 4)), dim3(256), 0, as_stream(stream), P, map, X, Y, Z, (int)nvox, Cout, scale, S,
-                     s_stride, p_rows);
+                     s_stride, p_rows, flag + 1);
   COOCC_LAUNCH_CHECK("k_sparse_tap_sum");
   return COOCC_OK;
 }

@@ -48,6 +48,10 @@ def _build_upstream(kind, cfg, external):
     return getattr(m3b, "build_" + kind)(cfg)
 
 
+def _no_detector():
+    return None
+
+
 class _FusedReaders:
     """The layers that read the fuser's output: the encoder's ``input_proj`` and the first layer of each render MLP (callable
     handed to ``BiFuser_N.output_readers``; holds the detector weakly so the module tree stays a tree)."""
@@ -55,6 +59,12 @@ class _FusedReaders:
     def __init__(self, det):
         import weakref
         self._det = weakref.ref(det)
+
+    def __getstate__(self):
+        return {}                     # the weak reference does not pickle; COOCC_Ray.__setstate__ wires a fresh one
+
+    def __setstate__(self, state):
+        self._det = _no_detector
 
     def __call__(self):
         det = self._det()
@@ -69,6 +79,11 @@ class _FusedReaders:
             if h is not None and det.use_rendering:
                 out.append(h._packed()[0])
         return out
+
+
+def _drop_captured_pipeline(module, incompatible_keys):
+    """``load_state_dict`` post-hook (module level, so the detector stays picklable: ``torch.save(model)``, spawn)."""
+    module._pipe1 = None
 
 
 @DETECTORS.register_module()
@@ -130,7 +145,18 @@ class COOCC_Ray(nn.Module):
                 self.rgb_head = MLP(input_dim=128, output_dim=3, net_depth=3, skip_layer=None)
         if self.occ_fuser is not None and hasattr(self.occ_fuser, "output_readers"):
             self.occ_fuser.output_readers = _FusedReaders(self)
-        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: setattr(module, "_pipe1", None))
+        self.register_load_state_dict_post_hook(_drop_captured_pipeline)
+
+    def __getstate__(self):
+        # torch.save(model) / multiprocessing spawn: the captured pipeline (streams, hipGraphs) belongs to this process
+        state = dict(self.__dict__)
+        state["_pipe1"] = None
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        if self.occ_fuser is not None and hasattr(self.occ_fuser, "output_readers"):
+            self.occ_fuser.output_readers = _FusedReaders(self)
 
     # ------------------------------------------------------------------ encoders (coocc_ray.py:120-256)
     @property
@@ -389,8 +415,19 @@ class COOCC_Ray(nn.Module):
             self._pipe1 = None                                # frees the old slot + graph before the new capture
             try:
                 self._pipe1 = (key, self.serving(fr, slots=1, dense_streams=1, render=do_render))
-            except _lib.CooccError:
-                raise                                         # a kernel / range-guard error is a bug report, not a fallback
+            except _lib.CooccError as e:
+                # the range guard (results not trustworthy) and HIP runtime / launch failures are bug reports, not fallbacks;
+                # a call the library REFUSED before launching (COOCC_EINVAL / COOCC_ENOMEM: a shape the static form does not
+                # take, a workspace that is too small) leaves the eager launches as the route, as before
+                if not isinstance(e, _lib.CooccArgError):
+                    raise
+                import warnings
+                why = "%s: %s" % (type(e).__name__, e)
+                warnings.warn("COOCC_Ray.simple_test: the captured (hipGraph) dense stage is unavailable for this input "
+                              "signature, running eager launches instead (about half the throughput); not retried for this "
+                              "signature -- %s" % why)
+                self.graph_unavailable = (key, why)
+                return None
             except (NotImplementedError, AssertionError, RuntimeError) as e:
                 import warnings
                 why = "%s: %s" % (type(e).__name__, e)

@@ -307,7 +307,7 @@ class OccHead(nn.Module):
               and self.out_channel <= 32 and self.img_mlp[1].num_groups == 16 and self.fine_mlp[1].num_groups == 16
               and p.get("mlp_aligned", False) and "img_nb" in p and r in (2, 4))
         if not ok:
-            raise _lib.CooccError("OccHead static fine branch: only the fused Linear-first configuration (cascade 2 / 4, image + "
+            raise _lib.CooccArgError("OccHead static fine branch: only the fused Linear-first configuration (cascade 2 / 4, image + "
                                   "voxel samples, 128-channel features) has device-count kernels")
         N_i, Hf, Wf = img_dims
         nf = V * r ** 3

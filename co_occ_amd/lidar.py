@@ -299,10 +299,13 @@ class _PostActBlock(nn.Sequential):
 
 
 def _bn1d(norm_cfg, c):
+    """The norm layer mmcv's ``build_norm_layer`` makes for ``norm_cfg`` on [rows, C] features: ``SyncBN`` ->
+    ``nn.SyncBatchNorm`` (all-rank statistics once ``torch.distributed`` is initialised, per-rank otherwise -- torch's own
+    rule), every other BN-family type -> ``nn.BatchNorm1d``.  Same state_dict keys either way."""
     cfg = dict(norm_cfg or dict(type="BN1d"))
-    cfg.pop("type", None)
+    t = cfg.pop("type", "BN1d")
     cfg.pop("requires_grad", None)
-    return nn.BatchNorm1d(c, **cfg)
+    return (nn.SyncBatchNorm if t == "SyncBN" else nn.BatchNorm1d)(c, **cfg)
 
 
 class SparseBasicBlock(nn.Module):
@@ -355,7 +358,6 @@ class _SparseEncoderBase(nn.Module):
         """sparse_lidar_enc.py:125-176 with gradients: BatchNorm1d on the active rows with BATCH statistics (as
         ``model.train()`` does upstream; eval-mode BN under ``eval()`` + grad), every convolution a ``SparseConvFn``."""
         from . import autograd as ag
-        import torch.nn.functional as F
         dev = voxel_features.device
         M, Cin = voxel_features.shape
         cin_p = _pad4(Cin)
@@ -372,7 +374,9 @@ class _SparseEncoderBase(nn.Module):
             return sparse_conv_train(x_, conv, tb, cur_.books[kb])
 
         def bn(x_, m):
-            return F.batch_norm(x_, m.running_mean, m.running_var, m.weight, m.bias, self.training, m.momentum if m.momentum is not None else 0.1, m.eps)
+            # the module itself: batch statistics + running-stat / num_batches_tracked updates under train() (momentum=None =
+            # cumulative average, SyncBatchNorm = all-rank statistics, a user's convert_sync_batchnorm), running stats under eval()
+            return m(x_)
 
         def gn(x_, m):
             return ag.GroupNormRowsFn.apply(x_.contiguous(), m.weight, m.bias, m.num_groups, float(m.eps), True)

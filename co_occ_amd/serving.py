@@ -66,6 +66,14 @@ class Ticket:
         return self.out
 
 
+def _clone_frame_item(v):
+    if torch.is_tensor(v):
+        return v.detach().clone()
+    if isinstance(v, (list, tuple)):
+        return type(v)(_clone_frame_item(x) for x in v)
+    return v
+
+
 class ServingPipeline:
     """``model``: a ``COOCC_Ray`` in eval mode.  ``example``: one frame (dict, see ``submit``) that fixes the shapes; it is
     used for the warm-up and the capture of every slot.  ``after_replay(out)`` (optional) runs on the dense stream right after
@@ -108,7 +116,9 @@ class ServingPipeline:
         self._submitted = self._issued = 0
         self._issued_of_slot = [0] * n
         self._dispatched_of_slot = [0] * n
-        self._example = example
+        # a private copy of the example frame for re-captures: the pipeline does not keep the caller's first frame alive, and
+        # a caller that rewrites its tensors in place cannot change what a later re-capture warms up on
+        self._example = {k: _clone_frame_item(v) for k, v in example.items()}
         self.recaptures = 0
         self._capture(example)
         # the captured launches hold raw pointers to the weight packs that were current just now: re-capture when any

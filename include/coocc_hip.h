@@ -332,6 +332,10 @@ int64_t coocc_conv_pack_weights_h2_dev(const float* w, int Cout, int Cin, int ta
  * value reaches half the f16 range (|v| >= 32768 after the writer's own scale; NaN counts).  Returns the flag (0 / 1) and clears it
  * when reset != 0; no synchronisation of its own -- call it after the stream(s) of interest have been synchronised. */
 int coocc_h2_overflow(int reset);
+/* Sticky device-fault word, same rules (no synchronisation of its own; cleared when reset != 0): kernels that meet an index no
+ * valid caller can produce skip the access and store a COOCC_FAULT_* code here instead of faulting the GPU.  0 = none. */
+#define COOCC_FAULT_SPARSE_ORDINAL 1 /* coocc_sparse_tap_sum: a voxel -> ordinal map entry >= p_rows (a corrupted / stale map) */
+int coocc_device_fault(int reset);
 /* Winograd weight packs made on the device (training re-packs every step): w:[Cout,Cin,3,3,3] -> (tile+2)^2 packs
  * U[p] = G g G^T in the layout coocc_conv_fwd reads with wgroup_rows (taps = 3, the z taps).  dgrad != 0: packs of the
  * transposed convolution (W'[c][n] = w[n][c] with all three tap axes flipped; GEMM N = Cin, K = Cout).

@@ -401,3 +401,37 @@ def test_pointwise_conv_persistent_kernel_ragged(dev, use_res):
     assert core.conv_kernel_name(X * Y * Z, Cout, False, 0, 2, True) == "k_conv2p<1x1>"
     out = core.conv_rows(rows_of(x, dev), pc, relu=True, res=rows_of(res, dev) if use_res else None)
     assert_close(out.as_ncdhw().cpu(), ref, what="persistent 1x1 conv")
+
+
+def test_sparse_tap_sum_raises_the_sticky_fault_word_on_a_corrupted_map(dev):
+    """an ordinal past the rows P was sized for (a stale / corrupted voxel -> ordinal map) is skipped by the kernel --
+    no GPU memory fault, no device printf -- and recorded in the host-mapped fault word; ``core.check_h2_overflow`` raises."""
+    import pytest as _pt
+    from co_occ_amd import _lib
+    from co_occ_amd._lib import call, ptr
+    X = Y = Z = 6
+    Co, Np = 8, 5
+    vmap = torch.full((X * Y * Z,), -1, dtype=torch.int32, device=dev)
+    vmap[[3, 40, 77, 100, 200]] = torch.arange(Np, dtype=torch.int32, device=dev)
+    P = torch.randn(Np, 27 * Co, device=dev)
+    S = torch.empty(X * Y * Z, Co, device=dev)
+    call("coocc_sparse_tap_sum", ptr(P), ptr(vmap), 1, X, Y, Z, Co, None, ptr(S), Co, Np)
+    torch.cuda.synchronize()
+    core.check_h2_overflow()                                  # a valid map: no fault
+    good = S.clone()
+    vmap[120] = 9999                                          # no valid caller produces this
+    call("coocc_sparse_tap_sum", ptr(P), ptr(vmap), 1, X, Y, Z, Co, None, ptr(S), Co, Np)
+    torch.cuda.synchronize()
+    with _pt.raises(_lib.CooccError, match="fault code 1"):
+        core.check_h2_overflow()
+    core.check_h2_overflow()                                  # cleared by the read
+    # the bad entry was skipped: voxels outside its 3x3x3 neighbourhood are untouched
+    far = torch.ones(X * Y * Z, dtype=torch.bool, device=dev)
+    z, y, x = 120 % Z, (120 // Z) % Y, 120 // (Z * Y)
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                ux, uy, uz = x + dx, y + dy, z + dz
+                if 0 <= ux < X and 0 <= uy < Y and 0 <= uz < Z:
+                    far[(ux * Y + uy) * Z + uz] = False
+    assert torch.equal(S[far], good[far]) and torch.isfinite(S).all()

@@ -258,3 +258,29 @@ def test_calibrate_reports_both_con_enc_presets_against_the_exact_fp32_kernels(d
     with torch.no_grad():
         after = model.simple_test(**frames[0])["pred_c"]
     assert torch.equal(before, after)
+
+
+def test_simple_test_falls_back_to_eager_when_the_library_refuses_the_captured_form(dev, monkeypatch):
+    """an argument / shape refusal (``CooccArgError``: COOCC_EINVAL, COOCC_ENOMEM, a configuration without
+    device-count kernels) while the dense stage is captured leaves the EAGER launches as the route -- warned once, recorded in
+    ``graph_unavailable``, not retried, same results; only the range guard and HIP failures propagate."""
+    import warnings
+    from co_occ_amd import _lib, head
+    bench, model, samples, gts = _setup(dev, n=2)
+    kws = [dict(bench.simple_test_kwargs(s), gt_occ=g) for s, g in zip(samples, gts)]
+    with torch.no_grad():
+        model.graph_simple_test = False
+        ref = [_grab(model.simple_test(**kw)) for kw in kws]
+        monkeypatch.setattr(head, "FUSED_FINE_MLP", False)          # the static fine branch refuses: no device-count kernels
+        model.graph_simple_test = True
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = [_grab(model.simple_test(**kw)) for kw in kws]
+    assert model._pipe1 is None and model.graph_unavailable is not None and "CooccArgError" in model.graph_unavailable[1]
+    assert sum("hipGraph" in str(x.message) for x in w) == 1        # warned once, not retried for the second frame
+    assert issubclass(_lib.CooccArgError, _lib.CooccError) and not issubclass(_lib.CooccRangeError, _lib.CooccArgError)
+    monkeypatch.setattr(head, "FUSED_FINE_MLP", True)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        for k in ("pred_c", "rgbs", "depths", "SC_metric"):
+            if torch.is_tensor(a[k]):
+                assert torch.equal(a[k], b[k]), (i, k)

@@ -212,3 +212,24 @@ def test_bench_ticket_orders_collectives_across_threads():
     assert gates.wait_for(-1) is None
     gates.post(0, "ev0")
     assert gates.wait_for(0) == "ev0"
+
+
+def test_detector_pickles_and_keeps_its_hooks():
+    """the ``load_state_dict`` hooks are a module-level function / a bound method, the fuser's reader list holds the
+    detector weakly and is re-wired on unpickling -- ``pickle`` / ``torch.save(model)`` / spawn work, and a loaded copy still
+    drops its packs and its captured pipeline on ``load_state_dict``."""
+    import io
+    import pickle
+    import torch
+    import co_occ_amd as pkg
+    import co_occ_amd.synth as synth
+    m = pkg.build_detector(synth.model_cfg(C=32, knum=2, block_inplanes=(32, 32, 64, 64), out_channels=32))
+    m2 = pickle.loads(pickle.dumps(m))
+    assert type(m2) is type(m) and list(m.state_dict()) == list(m2.state_dict())
+    assert m2.occ_fuser.output_readers._det() is m2
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    m2._pipe1 = "stale"
+    m2.semantic_encoder._packs._key = "stale"
+    m2.load_state_dict(m.state_dict())
+    assert m2._pipe1 is None and m2.semantic_encoder._packs._key is None
