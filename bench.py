@@ -828,7 +828,7 @@ def main():
         try:
             gp = model.serving(frames[0], slots=max(2, args.slots), dense_streams=max(1, args.streams if not auto_streams else 3),
                                ahead=args.ahead, search_priority=int(os.environ.get("COOCC_SEARCH_PRIO", "0")),
-                               after_replay=(_gather if world > 1 else None))
+                               after_replay=(_gather if world > 1 else None), reserve_cus=args.reserve_cus)
             gp.run(frames, 2 * gp.n)
         except Exception as e:           # configurations the static form does not cover run the eager pipeline
             print("bench: hipGraph pipeline unavailable for this configuration (%s: %s); eager pipeline" % (type(e).__name__, e), file=sys.stderr)

@@ -80,7 +80,7 @@ class ServingPipeline:
     a frame's dense stage has been issued (bench.py issues its RCCL all-gather there)."""
 
     def __init__(self, model, example, slots=6, dense_streams=3, ahead=0, render=None, search_priority=0, after_replay=None,
-                 time_dense=False):
+                 time_dense=False, reserve_cus=0):
         assert not model.training, "ServingPipeline serves the eval-mode (folded-BN) path"
         self.model = model
         pts = example.get("pts")
@@ -98,8 +98,20 @@ class ServingPipeline:
         most = max(1, n - self.ndense) if n > 1 else 1
         self.ahead = most if ahead <= 0 else max(1, min(int(ahead), most))
         self.after_replay, self.time_dense = after_replay, time_dense
-        self.dense_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ndense)]
-        self.search_streams = [torch.cuda.Stream(device=dev, priority=search_priority) for _ in range(n)]
+        self.reserve_cus = max(0, int(reserve_cus))
+        if self.reserve_cus:
+            # CU partition (co_occ_amd.streams, hipExtStreamCreateWithCUMask): the FPS chains of every search -- two single-workgroup
+            # kernels of 2047 dependent steps, each needing a whole CU's register file -- run on `reserve_cus` CUs nothing else
+            # is scheduled on; the dense graphs and the rest of the search stage share the other CUs.  Without it a chain queued
+            # behind a saturated chip waits for a CU to drain (a search that takes 2.7 ms alone took 5-8 ms in the loop).
+            from . import streams as cstreams
+            parts = [cstreams.partition(dev, reserved=self.reserve_cus, nfps=1) for _ in range(n)]
+            self.search_streams = [p.main for p in parts]
+            self.dense_streams = [parts[i].side("dense") for i in range(self.ndense)]
+            self._parts = parts
+        else:
+            self.dense_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ndense)]
+            self.search_streams = [torch.cuda.Stream(device=dev, priority=search_priority) for _ in range(n)]
         self.slots = [cg.make_slot(model, self.grid, dev) for _ in range(n)]
         self.static = [self._make_static(example) for _ in range(n)]
         self.slot_done = [None] * n            # event: the last replay that read slot k
