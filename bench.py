@@ -747,6 +747,11 @@ def main():
                     help="samples (default): one scene per GPU, weak scaling (configs[3]).  rays: ONE scene over all ranks -- K / G / C "
                          "replicated, the render rays sharded, map chunks all-gathered (configs[4]'s 'per-camera render shard'); "
                          "strong scaling: value = scenes/s of the whole job")
+    ap.add_argument("--also", default="auto",
+                    help="a second, SHORT measurement appended to the JSON line as \"also\": {name: {value, ms_per_step, ...}} -- north_star's literal "
+                         "stress workload (--config stress200_r101: 200x200x16 fused grid + 6 x 896 x 1600 frames), 2 windows x 10 steps in a "
+                         "child process after the main measurement (<= 25 s).  auto: only for the default command's workload (config r50, "
+                         "serving API, one GPU, no --train / --with-lidar / --shard rays); none: never; or a config name")
     ap.add_argument("--diag", action="store_true", help="host-side issue times per sample to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -798,7 +803,7 @@ def main():
             s_["points"] = synth.lidar_points(seed=8 + i + 17 * rank).to(dev)
             with torch.no_grad():
                 s_["pts"] = model.extract_pts_feat(s_["points"])[0]
-    if args.reserve_cus > 0:
+    if args.reserve_cus > 0 and not args.graph:   # (--graph 1: ServingPipeline(reserve_cus=) masks its own streams)
         # CU partition: the FPS chains get private CUs, everything else runs on the remaining ones
         from co_occ_amd import streams as cstreams
         parts = [cstreams.partition(dev, reserved=args.reserve_cus) for _ in range(max(1, args.streams))]
@@ -1073,8 +1078,37 @@ def main():
                                                 "(--streams 1 / 2 fixes it)")
     if world == 1 and not args.no_cpu_baseline and args.config != "openocc":   # cascade 4: ~10 M fine points, hours on the CPU
         line["cpu_baseline"] = cpu_baseline(sd, samples[0], args.config, WITH_POOL[0])
+    also_cfg = None
+    if args.also == "auto":
+        if (world == 1 and args.config == "r50" and args.api == "serving" and args.graph and not args.with_lidar and not SHARD[0]
+                and args.dtype == "f32" and not args.no_cpu_baseline):
+            also_cfg = "stress200_r101"
+    elif args.also not in ("none", "0", ""):
+        also_cfg = args.also
+    if rank == 0 and also_cfg:
+        line["also"] = {also_cfg: also_line(also_cfg, dev)}
     if rank == 0:
         print(json.dumps(line))
+
+
+def also_line(cfg, dev):
+    """A short run of another workload in a CHILD process (its own model, graphs and workspaces; this process's GPU memory is released
+    first), reduced to {value, unit, ms_per_step, window_ms_per_step, steps, config}.  Never raises: a failure is reported in the object."""
+    import subprocess
+    try:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "10", "--warmup", "3", "--windows", "2",
+               "--no-cpu-baseline", "--no-kernel-timing", "--also", "none"]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+        wall = time.perf_counter() - t0
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return dict(value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"], window_ms_per_step=d["window_ms_per_step"],
+                    steps=d["steps"], windows=d["windows"], config=d["config"], wall_s=round(wall, 1),
+                    command=" ".join(["python", "bench.py"] + cmd[2:]))
+    except Exception as e:
+        return dict(error="%s: %s" % (type(e).__name__, str(e)[:300]))
 
 
 if __name__ == "__main__":

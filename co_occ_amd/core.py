@@ -46,7 +46,70 @@ H2_DIRECT = __import__("os").environ.get("COOCC_H2_DIRECT", "1") != "0"     # st
 # same reads over the whole chip -- k_gemm_h2z<1,true> 24 -> 168 us with device-scope loads (200 us with __threadfence()), against
 # a 5 us k_conv_reduce launch (profiles/r4_dense_stage_kernels.txt).  The second pass instead writes the H2 twin.
 INKERNEL_REDUCE = __import__("os").environ.get("COOCC_INKERNEL_REDUCE", "0") != "0"
-H2_DIRECT_MIN_FLOPS = float(__import__("os").environ.get("COOCC_H2_MIN_FLOPS", "1e9"))      # below this the input split + split-K reduce launches cost more than the faster GEMM saves (measured)
+# Direct layers below this many flops stay on the fp32-MFMA kernels.  1e9 through round 5 ("the input split + split-K reduce launches cost
+# more than the faster GEMM saves"); since the producers write the H2 twins in their epilogues there is no input split left, and the
+# stride-2 1x1x1 downsamples, the 1 250- / 169-row laterals and pyramid-top output / OccHead layers (0.09-0.66 GF, 20-43 us each as
+# fp32-MFMA launches at 27-160 workgroups) take 15-25 us on the split-f16 kernels: dense stage 3.669 -> 3.575 ms
+# (profiles/r6_h2_min_flops.txt: 1e9 / 3e8 / 1e8 / 5e7 / 0).  Below 5e7 only the 64 -> 4 soft-weight head is left, whose N pads to 128.
+H2_DIRECT_MIN_FLOPS = float(__import__("os").environ.get("COOCC_H2_MIN_FLOPS", "5e7"))
+
+
+# Independent branches of ONE sample's dense stage on side streams (round 6; OFF by default).  The stage is a chain of ~100 dependent
+# launches, a third of which occupy a fraction of the chip (the 25x25x2 / 13x13x1 pyramid levels, the image branch of the fine head:
+# 27-512 workgroups).  With COOCC_BRANCHES=1 what does not depend on the chain is forked onto a side stream and joined where it is
+# consumed -- the render block, the image branch of the fine head, pyramid levels 1-3 of the FPN / OccHead convolutions beside
+# level 0's -- so a captured graph has parallel branches.  Same kernels on the same operands: same bits (the graph / serving /
+# co-runner tests pass either way).  MEASURED (profiles/r6_graph_branches.txt): one graph alone 3.619 -> 3.528 ms per replay
+# (-2.5 %: the overlapped kernels slow each other, 3.61 -> 4.29 ms of kernel time), but with several graphs in flight -- the
+# serving loop -- every branch is one more hardware queue per replay and the loop collapses: 2 / 3 / 4 graphs in flight 335 / 316 /
+# 351 -> 155 / 261 / 254 samples/s, pipeline 274 -> 188.  The other samples' graphs already fill the gaps the branches aim at.
+BRANCHES = __import__("os").environ.get("COOCC_BRANCHES", "0") != "0"
+_branch_streams = {}
+
+
+class Fork:
+    """``with Fork(i) as b: <launches on side stream i of the current stream>`` ... ``b.join()`` (on the forking stream) before
+    anything reads the branch's results.  Inactive (the body runs in place) when ``BRANCHES`` is off or kernel timing is on."""
+
+    def __init__(self, idx, device=None, enable=True):
+        self.on = bool(BRANCHES and enable and not TIMER.enabled)
+        self.idx, self.device, self._ctx, self.main, self.side = idx, device, None, None, None
+
+    def __enter__(self):
+        if self.on:
+            dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+            self.main = torch.cuda.current_stream(dev)
+            key = (dev.index, self.main.cuda_stream, self.idx)
+            side = _branch_streams.get(key)
+            if side is None:
+                side = _branch_streams[key] = torch.cuda.Stream(device=dev)
+            self.side = side
+            side.wait_stream(self.main)
+            self._ctx = torch.cuda.stream(side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+            self._ctx = None
+        return False
+
+    def join(self, *tensors):
+        """The forking stream waits for the branch; ``tensors``: results allocated inside the branch that the forking stream goes
+        on to use (recorded on it, so the caching allocator does not hand their memory out while it still reads them)."""
+        if self.on and self.side is not None:
+            cur = torch.cuda.current_stream(self.side.device)
+            cur.wait_stream(self.side)
+            for t in tensors:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
+            self.side = None
+
+
+def branch_streams_of(device, stream):
+    """The side streams ``Fork`` made for ``stream`` (a captured graph pins their scratch buffers too)."""
+    return [s for (d, h, _), s in _branch_streams.items() if d == device.index and h == stream.cuda_stream]
 
 
 def conv_kernel_name(M, Cout, table, hint=0, iters=1 << 30, one_by_one=False):

@@ -17,7 +17,7 @@
 //   * MFMA layout: lane (li, h) = point li as the column of v_mfma_f32_32x32x16_f16.  The wave's 8.5 KB LDS tile transposes between
 //     the layouts: the trilinear voxel sum goes through it as fp32 and comes back as the INITIAL ACCUMULATOR of fine_mlp[0]
 //     (Linear commutes with the resampling: Q = W_f0[:, :128] . voxel features, as before); the image activation goes through it as
-//     f16 hi / lo halves (16-byte slots XOR-swizzled by the row) and comes back as B fragments; the logits leave through it as
+//     f16 hi / lo halves (16-byte slots XOR-swizzled by the row, f2_swz) and comes back as B fragments; the logits leave through it as
 //     contiguous runs of rows o n + i .. i + 3;
 //   * both GEMMs of the chain (64 x 64 and ncls x 64 per point) are three MFMAs per k16 step (hi hi, lo hi, hi lo, fp32 accumulate:
 //     gemm_h2.hip's scheme) instead of eight v_mfma_f32_32x32x2_f32; the 24 KB of packed weights sit in LDS, loaded once per
@@ -118,6 +118,15 @@ __device__ __forceinline__ void f2_split8(const f32x16& y, int r0, f16x8& hi, f1
     hi[j] = a; lo[j] = b;
   }
 }
+
+// 16-byte-slot swizzle of the f16 activation tile (32 rows x 128 B hi, + 4096: lo): slot' = slot ^ f2_swz(row).  Round 5's slot ^ (row & 7)
+// left every access 2-way conflicted (99.9 M SQ_LDS_BANK_CONFLICT cycles per launch, profiles/r5_bench_pmc_sq.txt): a ds_read_b128 lane
+// group holds rows {0-3, 12-15, 20-27} (or {4-11, 16-19, 28-31}), whose row & 7 repeats, and the two rows of a ds_write_b64 group differ in
+// bit 0 only, i.e. in one slot, while a write's banks are taken mod 32 (both rows of a 256-byte bank row).  With
+//     f2_swz(r) = (r >> 1 & 3) | ((r >> 4 ^ r) & 1) << 2
+// the 8 even (odd) rows of a read group get 8 distinct slots of their half of the bank row, and rows r, r + 1 of a write group use
+// opposite halves of the 32 banks.  A pure layout change: same values, same bits.
+__device__ __forceinline__ unsigned f2_swz(int r) { return (unsigned)((r >> 1) & 3) | ((unsigned)(((r >> 4) ^ r) & 1) << 2); }
 
 #define F2_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")      // the tile is private to the wave (LDS is in order per wave)
 
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : 2) void k_fine2_h2(Fine2K p)
       }
     }
     F2_LDS_FENCE();                                      // every record has been read: the tile becomes the B operand of fine_mlp[0]
-    // img_mlp's bias + GroupNorm + ReLU in place, split into f16 halves -> tile rows [hi 128 B | lo 128 B at + 4096], slot ^ (row & 7)
+    // img_mlp's bias + GroupNorm + ReLU in place, split into f16 halves -> tile rows [hi 128 B | lo 128 B at + 4096], slot ^ f2_swz(row)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const f32x4 bi = *(const f32x4*)(Cn + 32 * i + 4 * piece), ga = *(const f32x4*)(Cn + 64 + 32 * i + 4 * piece),
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : 2) void k_fine2_h2(Fine2K p)
         f16x4 yh, yl;
 #pragma unroll
         for (int t = 0; t < 4; ++t) { _Float16 a, b; split_h2(y[t], a, b); yh[t] = a; yl[t] = b; }
-        const unsigned slot = (unsigned)(4 * i + (piece >> 1)) ^ (unsigned)pt8;
+        const unsigned slot = (unsigned)(4 * i + (piece >> 1)) ^ f2_swz(8 * j + pt8);
         char* dst = Tb + (8 * j + pt8) * 128 + (slot << 4) + (piece & 1) * 8;
         *(f16x4*)dst = yh;
         *(f16x4*)(dst + 4096) = yl;
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : 2) void k_fine2_h2(Fine2K p)
     // ---- C. fine_mlp[0]: h = Q sample + W_f0[:, 128:] . y1, three MFMAs per k16 step
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const char* src = Tb + li * 128 + (((unsigned)(2 * s + h) ^ (unsigned)(li & 7)) << 4);
+      const char* src = Tb + li * 128 + (((unsigned)(2 * s + h) ^ f2_swz(li)) << 4);
       const f16x8 bhi = *(const f16x8*)src, blo = *(const f16x8*)(src + 4096);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {

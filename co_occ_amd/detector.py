@@ -262,12 +262,23 @@ class COOCC_Ray(nn.Module):
         once the encoder's launches are enqueued (a serving loop with two samples in flight staggers them there).
         ``static``: no host read anywhere (the fine branch keeps its count on the device and returns capacity-sized
         tensors + ``fine_count``): the form ``co_occ_amd.graph`` captures into a hipGraph."""
+        from . import core
         neck, head = self.semantic_neck, self.pts_bbox_head
+        do_render = (self.use_rendering and self.test_rendering) if render is None else render
+        rbranch = rendered = None
+        if do_render:
+            # the render block reads the fused features only: forked beside the encoder / neck / head chain (core.Fork), joined below
+            rbranch = core.Fork(0, voxel_feats.t.device if isinstance(voxel_feats, core.Rows) else voxel_feats.device)
+            with rbranch:
+                rendered = render_block(self.sigma_head, getattr(self, "rgb_head", None), to_rows(voxel_feats), gemo, 16,
+                                        depth_only=depth_only or not hasattr(self, "rgb_head"), cam_geo=cam_geo)
+        ibranch = head.fork_image_branch(img_feats, transform, to_rows(voxel_feats)) if hasattr(head, "fork_image_branch") else None
         mid = self.semantic_encoder.forward_rows(voxel_feats, readers=neck.lateral_packs() if hasattr(neck, "lateral_packs") else None)
         if after_encoder is not None:
             after_encoder()
         sem = neck.forward_rows(mid, readers=head.level_readers() if hasattr(head, "level_readers") else None)
-        output = self.pts_bbox_head(voxel_feats=sem, img_feats=img_feats, transform=transform, static=static)
+        kw = dict(image_branch=ibranch) if ibranch is not None else {}
+        output = self.pts_bbox_head(voxel_feats=sem, img_feats=img_feats, transform=transform, static=static, **kw)
         res = dict(voxel_feats=voxel_feats, pred_c=output['output_voxels'][0], pred_f=None,
                    output_voxels_fine=output['output_voxels_fine'], output_coords_fine=output['output_coords_fine'])
         if output['output_voxels_fine'] is not None and dense_fine:
@@ -278,10 +289,9 @@ class COOCC_Ray(nn.Module):
                                                             output['output_coords_fine'][0], list(size),
                                                             count_dev=output.get('fine_count'))
             res['fine_count'] = output.get('fine_count')
-        do_render = (self.use_rendering and self.test_rendering) if render is None else render
         if do_render:
-            rgbs, depths, maps = render_block(self.sigma_head, getattr(self, "rgb_head", None), to_rows(voxel_feats), gemo, 16,
-                                              depth_only=depth_only or not hasattr(self, "rgb_head"), cam_geo=cam_geo)
+            rgbs, depths, maps = rendered
+            rbranch.join(rgbs, depths, maps)
             res.update(rgbs=rgbs, depths=depths, render_maps=maps)
         return res
 

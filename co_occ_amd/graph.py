@@ -65,7 +65,10 @@ class DenseGraph:
         # counters): keep those tensors alive for as long as the graph exists.  A later eager call on the same stream that
         # needs a larger buffer REPLACES the dict entry (core.scratch / _wino_buffer) -- without this reference the old tensor
         # would be freed, handed to someone else by the caching allocator, and every replay would scribble over it.
-        self._pinned = core.stream_scratch(self.slot.cat4.device, self.stream)
+        dev = self.slot.cat4.device
+        self._pinned = core.stream_scratch(dev, self.stream)
+        for side in core.branch_streams_of(dev, self.stream):          # the stage's forked branches (core.Fork) have their own scratch
+            self._pinned += core.stream_scratch(dev, side)
         return self
 
     def fits(self, counts):

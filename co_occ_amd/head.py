@@ -162,13 +162,18 @@ class OccHead(nn.Module):
         from . import core
         p = self._packed()
         # level 0's output is read by the soft-weight branch's first 1x1x1 layer (a split-f16 GEMM at configs[1]'s size: H2 twin)
-        occs = [conv_rows(to_rows(f), p["occ"][i], relu=True, twin_for=((p["soft"][0],) if (i == 0 and self.soft_weights) else ()))
-                for i, f in enumerate(voxel_feats)]
-        o0 = occs[0]
+        # levels 1.. (10 000 / 1 250 / 169 rows: a fraction of the chip each) on a side stream beside level 0 and the soft-weight branch
+        feats = [to_rows(f) for f in voxel_feats]
+        lbr = core.Fork(2, feats[0].t.device, enable=len(feats) > 1 and not self.training)
+        with lbr:
+            small = [conv_rows(f, p["occ"][i], relu=True) for i, f in enumerate(feats) if i > 0]
+        o0 = conv_rows(feats[0], p["occ"][0], relu=True, twin_for=((p["soft"][0],) if self.soft_weights else ()))
+        occs = [o0] + small
         wlogit = None
         if self.soft_weights:
             h = conv_rows(o0, p["soft"][0], relu=True)
             wlogit = conv_rows(h, p["soft"][1], relu=False).t
+        lbr.join(*[o.t for o in small])
         L = len(occs)
         levels = (_lib.c_void_p * L)(*[o.t.data_ptr() for o in occs])
         dims = host_i32([v for o in occs for v in (o.X, o.Y, o.Z)])
@@ -198,7 +203,35 @@ class OccHead(nn.Module):
         return {'out_voxel_feats': [out.as_ncdhw()], 'occ': [occ.as_ncdhw()]}
 
     # ---------------------------------------------------------------- C4
-    def _fine(self, ovf, occ, img_feats, transform, static=False):
+    def _image_rows(self, p, img_feats, transform, grid_rows, dev):
+        """The part of the fine branch that depends on the image features only (occ_head.py:64, :205-212): NCHW -> rows, the 1x1
+        Conv2d + GroupNorm of ``img_mlp_0``, the projection matrices.  Returns (g [N*Hf*Wf, 128], params, (N, Hf, Wf))."""
+        f = img_feats[0]                                    # [B,N,512,fH,fW]
+        _, N_i, C_i, Hf, Wf = f.shape
+        rows = torch.empty(N_i * Hf * Wf, C_i, device=dev, dtype=_F32)
+        call("coocc_ncdhw_to_ndhwc", ptr(f[0].float().contiguous()), ptr(rows), N_i, C_i, Hf * Wf, C_i, 0)
+        g = linear_rows(rows, p["img0"])                    # Conv2d 1x1 (occ_head.py:64)
+        gn = self.img_mlp_0[1]
+        call("coocc_groupnorm_nhwc", ptr(g), N_i, Hf * Wf, g.shape[1], gn.num_groups, ptr(gn.weight.detach()),
+             ptr(gn.bias.detach()), float(gn.eps), 1)
+        params = self._projection_params(transform, grid_rows, dev)
+        return g, params, (N_i, Hf, Wf)
+
+    def fork_image_branch(self, img_feats, transform, grid_rows):
+        """``_image_rows`` forked onto a side stream (``core.Fork``) BEFORE the encoder / neck / coarse head are issued: 4 small
+        launches (33-96 workgroups, ~80 us) that otherwise sit in the middle of the sample's launch chain.  ``grid_rows``: any
+        Rows on the head's level-0 grid (only its dimensions are read).  Returns a handle for ``forward(image_branch=)``, or None."""
+        if not (self.sample_from_img and img_feats is not None and self.cascade_ratio != 1 and not self.training and core_mod.BRANCHES):
+            return None
+        dev = img_feats[0].device
+        br = core_mod.Fork(1, dev)
+        if not br.on:
+            return None
+        with br:
+            out = self._image_rows(self._packed(), img_feats, transform, grid_rows, dev)
+        return br, out, (grid_rows.X, grid_rows.Y, grid_rows.Z)
+
+    def _fine(self, ovf, occ, img_feats, transform, static=False, image_branch=None):
         """occ_head.py:180-237, eval branch, B == 1.  ``static``: nothing is read back -- the foreground count stays on
         the device (third return value), every buffer has its worst-case size (all V coarse voxels foreground) and the
         launches take the count from the device (``*_dev`` entry points), so the branch can be captured into a hipGraph;
@@ -219,16 +252,13 @@ class OccHead(nn.Module):
         # image-feature branch (1x1 conv + GroupNorm) and the camera matrices (a dozen tiny torch launches)
         # then run under the device->host round trip instead of after it
         use_img = self.sample_from_img and img_feats is not None
-        if use_img:
-            f = img_feats[0]                                    # [B,N,512,fH,fW]
-            _, N_i, C_i, Hf, Wf = f.shape
-            rows = torch.empty(N_i * Hf * Wf, C_i, device=dev, dtype=_F32)
-            call("coocc_ncdhw_to_ndhwc", ptr(f[0].float().contiguous()), ptr(rows), N_i, C_i, Hf * Wf, C_i, 0)
-            g = linear_rows(rows, p["img0"])                    # Conv2d 1x1 (occ_head.py:64)
-            gn = self.img_mlp_0[1]
-            call("coocc_groupnorm_nhwc", ptr(g), N_i, Hf * Wf, g.shape[1], gn.num_groups, ptr(gn.weight.detach()),
-                 ptr(gn.bias.detach()), float(gn.eps), 1)
-            params = self._projection_params(transform, ovf, dev)
+        if use_img and image_branch is not None:
+            br, (g, params, (N_i, Hf, Wf)), grid = image_branch  # issued on a side stream before the encoder (fork_image_branch)
+            br.join(g, params)
+            if grid != (ovf.X, ovf.Y, ovf.Z):                    # the projection matrices carry the level-0 grid: made for another one
+                params = self._projection_params(transform, ovf, dev)
+        elif use_img:
+            g, params, (N_i, Hf, Wf) = self._image_rows(p, img_feats, transform, ovf, dev)
         if static:
             return self._fine_static(p, ovf, lin, cnt, g if use_img else None, params if use_img else None, (N_i, Hf, Wf) if use_img else None,
                                      fgmap=fgmap)
@@ -431,10 +461,10 @@ class OccHead(nn.Module):
         if self.cascade_ratio != 1 and (self.sample_from_img or self.sample_from_voxel):
             if kwargs.get("static"):
                 # capacity-sized outputs + the number of foreground coarse voxels on the device (hipGraph capture)
-                fine, xyz, cnt = self._fine(ovf, occ, img_feats, transform, static=True)
+                fine, xyz, cnt = self._fine(ovf, occ, img_feats, transform, static=True, image_branch=kwargs.get("image_branch"))
                 res['fine_count'] = cnt
             else:
-                fine, xyz = self._fine(ovf, occ, img_feats, transform)
+                fine, xyz = self._fine(ovf, occ, img_feats, transform, image_branch=kwargs.get("image_branch"))
             res['output_voxels_fine'], res['output_coords_fine'] = [fine], [xyz]
         self.last_out_voxel_feats = ovf
         return res

@@ -60,8 +60,15 @@ class FPN3D(nn.Module):
         top = self.num_out - 1
         # only the top lateral reaches its fpn_conv unchanged; the others are updated in place by the top-down pass below,
         # which then writes the H2 twin of the UPDATED rows itself
-        lat = [conv_rows(to_rows(x), p["lat"][i], relu=True, twin_for=((p["out"][i],) if i == top else ()))
-               for i, x in enumerate(inputs)]
+        # levels 1.. (10 000 / 1 250 / 169 rows at configs[1]) on a side stream beside level 0's 80 000-row launches (core.Fork)
+        rows_in = [to_rows(x) for x in inputs]
+        dev = rows_in[0].t.device
+        lbr = core.Fork(3, dev, enable=self.num_out > 1)
+        with lbr:
+            small = [conv_rows(x, p["lat"][i], relu=True, twin_for=((p["out"][i],) if i == top else ()))
+                     for i, x in enumerate(rows_in) if i > 0]
+        lat = [conv_rows(rows_in[0], p["lat"][0], relu=True, twin_for=((p["out"][0],) if top == 0 else ()))] + small
+        lbr.join(*[t for r in small for t in (r.t, r.h2) if t is not None])
         for i in range(self.num_out - 1, 0, -1):
             c, f = lat[i], lat[i - 1]
             f.h16 = f.h2 = None   # the rows change in place: the 16-bit copies the lateral conv's epilogue wrote are stale
@@ -69,8 +76,13 @@ class FPN3D(nn.Module):
             if core.CONV_ENGINE == "h2" and core.CONV_DTYPE == "f32" and f.C % 32 == 0 and core.takes_h2(f, (p["out"][i - 1],)):
                 tw = f.h2 = torch.empty(f.B * f.V, f.C, device=f.t.device, dtype=torch.float32)
             call("coocc_upsample_add_trilinear_ex", ptr(c.t), ptr(f.t), f.B, f.C, c.X, c.Y, c.Z, f.X, f.Y, f.Z, ptr(tw))
-        return [conv_rows(x, p["out"][i], relu=True, twin_for=(readers[i] if readers is not None else ()))
-                for i, x in enumerate(lat)]
+        obr = core.Fork(3, dev, enable=self.num_out > 1)
+        with obr:
+            small = [conv_rows(x, p["out"][i], relu=True, twin_for=(readers[i] if readers is not None else ()))
+                     for i, x in enumerate(lat) if i > 0]
+        out0 = conv_rows(lat[0], p["out"][0], relu=True, twin_for=(readers[0] if readers is not None else ()))
+        obr.join(*[t for r in small for t in (r.t, r.h2) if t is not None])
+        return [out0] + small
 
     def forward(self, inputs):
         """list of [B,C_i,...] -> list of [B,out,...] (fpn3d.py:70-108); training mode: batch-statistics BN + autograd."""

@@ -66,6 +66,11 @@ class Ticket:
         return self.out
 
 
+# DIAGNOSTIC (profiles/r6_pipeline_gap.txt): bits of the search stage left out of every submitted frame -- 1: the copies of the frame's
+# dense-stage inputs into the slot, 2: the pooling (fused lift-splat), 4: the index search (K1-K5).  The outputs are then NOT the frame's.
+_DIAG_SKIP = int(os.environ.get("COOCC_SERVING_DIAG_SKIP", "0"))
+
+
 def _clone_frame_item(v):
     if torch.is_tensor(v):
         return v.detach().clone()
@@ -99,19 +104,20 @@ class ServingPipeline:
         self.ahead = most if ahead <= 0 else max(1, min(int(ahead), most))
         self.after_replay, self.time_dense = after_replay, time_dense
         self.reserve_cus = max(0, int(reserve_cus))
+        self.dense_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ndense)]
+        self.search_streams = [torch.cuda.Stream(device=dev, priority=search_priority) for _ in range(n)]
         if self.reserve_cus:
             # CU partition (co_occ_amd.streams, hipExtStreamCreateWithCUMask): the FPS chains of every search -- two single-workgroup
-            # kernels of 2047 dependent steps, each needing a whole CU's register file -- run on `reserve_cus` CUs nothing else
-            # is scheduled on; the dense graphs and the rest of the search stage share the other CUs.  Without it a chain queued
-            # behind a saturated chip waits for a CU to drain (a search that takes 2.7 ms alone took 5-8 ms in the loop).
+            # kernels of 2047 dependent steps, each needing a CU to itself -- run on `reserve_cus` CUs the dense graphs are masked
+            # away from.  Every masked stream is a hardware queue of its own, and a pipeline with one masked stream per slot
+            # (18 queues) ran 6x SLOWER than the plain one (profiles/r6_pipeline_gap.txt: the queues are time-sliced), so only
+            # the dense streams and ONE FPS stream are masked; the search streams stay plain (their other kernels are short).
             from . import streams as cstreams
-            parts = [cstreams.partition(dev, reserved=self.reserve_cus, nfps=1) for _ in range(n)]
-            self.search_streams = [p.main for p in parts]
-            self.dense_streams = [parts[i].side("dense") for i in range(self.ndense)]
-            self._parts = parts
-        else:
-            self.dense_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ndense)]
-            self.search_streams = [torch.cuda.Stream(device=dev, priority=search_priority) for _ in range(n)]
+            part = cstreams.partition(dev, reserved=self.reserve_cus, nfps=1)
+            self.dense_streams = [part.main] + [part.side(i) for i in range(1, self.ndense)]
+            for st in self.search_streams:
+                cstreams.attach_fps(st, part.fps)
+            self._part = part
         self.slots = [cg.make_slot(model, self.grid, dev) for _ in range(n)]
         self.static = [self._make_static(example) for _ in range(n)]
         self.slot_done = [None] * n            # event: the last replay that read slot k
@@ -130,6 +136,7 @@ class ServingPipeline:
         self._dispatched_of_slot = [0] * n
         # a private copy of the example frame for re-captures: the pipeline does not keep the caller's first frame alive, and
         # a caller that rewrites its tensors in place cannot change what a later re-capture warms up on
+        self._last_sr = [None] * n
         self._example = {k: _clone_frame_item(v) for k, v in example.items()}
         self.recaptures = 0
         self._capture(example)
@@ -185,15 +192,30 @@ class ServingPipeline:
             for v in _tensors_of(fr):
                 if v.is_cuda:
                     v.record_stream(st)            # allocated on the caller's stream, read by this one
-            self._copy_in(k, fr)
+            diag = _DIAG_SKIP if t.index >= 0 else 0          # (never while capturing: the slots must be filled once)
+            if not diag & 1:
+                self._copy_in(k, fr)
             pts = fr.get("pts")
             if pts is None:        # coocc_ray.py:215-234: points -> Voxelization -> HardSimpleVFE -> SparseLiDAREnc8x -> [1,C,X,Y,Z]
                 pts = self.model.extract_pts_feat(fr["points"])[0]
             t.pts_vol = pts
             self._mark(t, "search_native")
             slot = self.slots[k]
-            if fr.get("depth") is not None:
+            if diag & 6 and fr.get("depth") is not None and self._last_sr[k] is not None:
+                # DIAGNOSTIC ONLY (COOCC_SERVING_DIAG_SKIP, tools/pipeline_gap.py): leave out the pooling (2) and / or the index search
+                # (4) of this frame and replay the slot's previous contents -- results are those of the slot's LAST searched frame
+                if not diag & 2:
+                    self.model.img_view_transformer.lift_splat(fr["depth"], fr["ctx"], cams=fr["cams"], out=slot.img_rows())
+                if not diag & 4:
+                    sr = self.model.occ_fuser.search_native(pts, slot)
+                else:
+                    sr = self._last_sr[k]
+                    sr.done_main = torch.cuda.Event()
+                    sr.done_main.record()
+                    sr.done_side = sr.done_main
+            elif fr.get("depth") is not None:
                 sr = cg.search_into_slot(self.model, slot, fr["depth"], fr["ctx"], fr["cams"], pts)
+                self._last_sr[k] = sr
             else:
                 # an already-pooled camera volume: into slot 0 of the concat rows, then the same search
                 vol = fr["img_voxel_feats"]

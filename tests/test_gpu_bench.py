@@ -47,6 +47,17 @@ def test_default_line_is_the_graph_pipeline_with_the_contract_fields():
     assert "measured" in d["roofline"] and isinstance(d["env_knobs"], dict)
 
 
+def test_also_appends_a_short_run_of_another_workload():
+    """``--also CONFIG``: a short child-process run of a second workload inside the same JSON line (the default command appends
+    north_star's stress workload, stress200_r101, this way: VERDICT r5 item 7); here the cheaper r101 frames."""
+    d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "1", "--windows", "1", "--no-cpu-baseline",
+              "--no-kernel-timing", "--also", "r101"])
+    a = d["also"]["r101"]
+    assert "error" not in a, a
+    assert a["value"] > 0 and a["steps"] == 10 and a["windows"] == 2 and len(a["window_ms_per_step"]) == 2
+    assert a["config"]["render_maps"] == "6x896x1600" and "also" not in a
+
+
 def test_eager_line_reports_its_stream_probe():
     """--graph 0: every launch issued from Python; the number of samples in flight is chosen from untimed bursts and reported."""
     d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--graph", "0"])
@@ -166,6 +177,18 @@ def test_ray_shard_mode_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "ray-shard x2" in d["config"]["parallelism"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 0.05 * d["value"]           # scenes/s of the whole job, not x world
     assert 0 < d["ray_shard"]["sharded_fraction_of_step"] < 0.2
+
+
+def test_eight_ranks_on_one_gpu_over_gloo():
+    """The driver's N = 8 command line with every rank on cuda:0 over gloo: what depends on the RANK COUNT
+    -- thread pinning of 8 ranks on the host's cores (dist.pin_rank_threads), the automatic one-search-helper-per-rank setting,
+    the ordered (ticketed) all-gathers across helper threads, 8 x the slots' workspaces in one device's memory -- has run once at
+    N = 8 before an 8-GPU node does it over RCCL."""
+    d = _torchrun(8, ["--same-device", "--backend", "gloo", "--steps", "4", "--warmup", "1", "--windows", "1", "--slots", "3",
+                      "--no-cpu-baseline", "--no-kernel-timing"], timeout=1200)
+    assert d["n_gpus"] == 8 and d["world_size_seen_by_backend"] == 8 and d["backend"] == "gloo" and d["scaling"] == "weak"
+    assert "dp8" in d["config"]["parallelism"] and d["graph"]["searches_ahead"] == 1 and d["graph"]["eager_fallbacks"] == 0
+    assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 0.05 * d["value"]       # whole-job rate: all eight ranks' samples
 
 
 def test_rccl_two_ranks_when_two_gpus_are_present():
