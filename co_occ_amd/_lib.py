@@ -46,6 +46,13 @@ SIGNATURES = {
     "coocc_device_cu_count": (I, [P]),
     "coocc_stream_create_cu_mask": (I, [P, I, P]),
     "coocc_stream_destroy": (I, [P]),
+    "coocc_event_create": (I, [I, P]),
+    "coocc_event_destroy": (I, [P]),
+    "coocc_event_record": (I, [P, P]),
+    "coocc_stream_wait_event": (I, [P, P]),
+    "coocc_event_synchronize": (I, [P]),
+    "coocc_event_query": (I, [P]),
+    "coocc_event_elapsed_ms": (I, [P, P, P]),
     "coocc_ncdhw_to_ndhwc": (I, [P, P, I, I, I, I, I, P]),
     "coocc_rows_to_bf16": (I, [P, I, L, I, P, P]),
     "coocc_rows_to_h2": (I, [P, I, L, I, F, P, P]),

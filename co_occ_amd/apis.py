@@ -104,7 +104,8 @@ def pipelined_test(model, data_iter, slots=6, dense_streams=3, ahead=0, stats=No
                 dev_buf = torch.cat(parts) if len(parts) > 1 else parts[0]
                 host = torch.empty(dev_buf.shape, dtype=torch.int64, pin_memory=True)
                 host.copy_(dev_buf, non_blocking=True)
-            ev = torch.cuda.Event()
+            from . import streams as cstreams
+            ev = cstreams.new_event()           # fires after the pinned-host copy above: a copy command, complete when it does
             ev.record(ds)
         return (data, t, (out, host, both if gt is not None else None), ev)
 

@@ -521,3 +521,54 @@ extern "C" int coocc_stream_destroy(void* stream) {
   COOCC_HIP(hipStreamDestroy(as_stream(stream)));
   return COOCC_OK;
 }
+
+// ------------------------------------------------------------------ device-scope events
+// A default HIP event performs a SYSTEM-scope release when it is recorded (hip_runtime_api.h: "cache writeback and invalidation, and
+// the performance impact of those actions on the execution of following work") -- what a host or another device needs in order to see
+// the stream's writes.  The serving loop records an event after every dense-stage replay and around every search only to order
+// streams of the SAME device, where the kernels' own agent-scope release / acquire suffices; with three dense graphs sharing the chip
+// those fences cost 24 % of the throughput (profiles/r6_serving_probe_events.txt: 277 -> 343 samples/s without them).  These events
+// carry hipEventDisableSystemFence; flags bit 0 keeps the timestamps (hipEventElapsedTime; else hipEventDisableTiming), bit 1 makes
+// coocc_event_synchronize sleep instead of spin (hipEventBlockingSync).
+// A host that reads results still synchronises the STREAM (or copies device -> host, which is stream-ordered).
+extern "C" int coocc_event_create(int flags, void** event_out) {
+  COOCC_CHECK_ARG(event_out && (flags & ~3) == 0, "event_create: bad args");
+  hipEvent_t e = nullptr;
+  COOCC_HIP(hipEventCreateWithFlags(&e, hipEventDisableSystemFence | ((flags & 1) ? 0u : hipEventDisableTiming) |
+                                            ((flags & 2) ? hipEventBlockingSync : 0u)));
+  *event_out = (void*)e;
+  return COOCC_OK;
+}
+extern "C" int coocc_event_destroy(void* event) {
+  COOCC_CHECK_ARG(event, "event_destroy: null");
+  COOCC_HIP(hipEventDestroy((hipEvent_t)event));
+  return COOCC_OK;
+}
+extern "C" int coocc_event_record(void* event, void* stream) {
+  COOCC_CHECK_ARG(event, "event_record: null");
+  COOCC_HIP(hipEventRecord((hipEvent_t)event, as_stream(stream)));
+  return COOCC_OK;
+}
+extern "C" int coocc_stream_wait_event(void* stream, void* event) {
+  COOCC_CHECK_ARG(event, "stream_wait_event: null");
+  COOCC_HIP(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)event, 0));
+  return COOCC_OK;
+}
+extern "C" int coocc_event_synchronize(void* event) {
+  COOCC_CHECK_ARG(event, "event_synchronize: null");
+  COOCC_HIP(hipEventSynchronize((hipEvent_t)event));
+  return COOCC_OK;
+}
+// 1: complete, 0: not yet, negative: error
+extern "C" int coocc_event_query(void* event) {
+  COOCC_CHECK_ARG(event, "event_query: null");
+  const hipError_t e = hipEventQuery((hipEvent_t)event);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+  return coocc_set_error(COOCC_EHIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+}
+extern "C" int coocc_event_elapsed_ms(void* start, void* stop, float* ms) {
+  COOCC_CHECK_ARG(start && stop && ms, "event_elapsed_ms: null");
+  COOCC_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return COOCC_OK;
+}

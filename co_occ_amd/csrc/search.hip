@@ -7,6 +7,7 @@
 // Same kernels, same order and same results as co_occ_amd.fuser.BiFuser_N.search (grid forms of top-K / ball query,
 // bucket-pruned FPS); B == 1, both voxel lists longer than fps_num (the reference's other branch, bifuser_n.py:54-60 /
 // 88-94, stays in Python: the call returns COOCC_SEARCH_SMALL and has launched nothing after the count read).
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -92,8 +93,12 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
   {
     // the one host sync of the stage.  A BLOCKING event: the calling thread sleeps instead of spinning (hipStreamSynchronize may
     // spin), so several prefetch threads per rank -- and 8 ranks per node -- do not burn the host cores the issuing threads need
+    // No system-scope fence on it (layout.hip, "device-scope events"): the two counts reach the host through the memcpy command above,
+    // which is complete -- staged into the caller's host buffer -- before the event fires; nothing a kernel wrote is read by the host
+    // here.  COOCC_SEARCH_COUNT_FENCE=1 restores the default event (one cache writeback / invalidate per sample).
+    static const bool fence = [] { const char* e = getenv("COOCC_SEARCH_COUNT_FENCE"); return e && e[0] == '1'; }();
     hipEvent_t got;
-    COOCC_HIP(hipEventCreateWithFlags(&got, hipEventBlockingSync | hipEventDisableTiming));
+    COOCC_HIP(hipEventCreateWithFlags(&got, hipEventBlockingSync | hipEventDisableTiming | (fence ? 0u : hipEventDisableSystemFence)));
     const hipError_t e1 = hipEventRecord(got, s0);
     const hipError_t e2 = e1 == hipSuccess ? hipEventSynchronize(got) : e1;
     (void)hipEventDestroy(got);
@@ -117,7 +122,7 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
   hipStream_t sf = d->fps_stream && as_stream(d->fps_stream) != s0 ? as_stream(d->fps_stream) : nullptr;
   hipEvent_t fps_ev = nullptr;
   if (sf) {
-    COOCC_HIP(hipEventCreateWithFlags(&fps_ev, hipEventDisableTiming));
+    COOCC_HIP(hipEventCreateWithFlags(&fps_ev, hipEventDisableTiming | hipEventDisableSystemFence));
     if (hipEventRecord(fps_ev, s0) != hipSuccess || hipStreamWaitEvent(sf, fps_ev, 0) != hipSuccess) {
       (void)hipEventDestroy(fps_ev);
       return coocc_set_error(COOCC_EHIP, "fuser_search: forking the FPS stream failed");
@@ -136,8 +141,8 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
   // the events are destroyed before this call returns (a failure in the middle must not leave the caller's side stream forked
   // behind an unjoined event, nor leak two events per failed call).
   hipEvent_t fork = nullptr, join = nullptr;
-  COOCC_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-  if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
+  COOCC_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming | hipEventDisableSystemFence));   // device-side ordering only
+  if (hipEventCreateWithFlags(&join, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
     (void)hipEventDestroy(fork);
     return coocc_set_error(COOCC_EHIP, "fuser_search: hipEventCreate failed");
   }
@@ -157,9 +162,17 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
     int rc__ = (call);                           \
     if (rc__ != COOCC_OK) return finish(rc__);   \
   } while (0)
-  if (hipEventRecord(fork, s0) != hipSuccess || hipStreamWaitEvent(s1, fork, 0) != hipSuccess)
-    return finish(coocc_set_error(COOCC_EHIP, "fuser_search: forking the side stream failed"));
-  forked = true;
+  // Paired FPS (one launch on `stream` for both directions): the img <- pts direction could only start on the side stream once that
+  // launch has finished, i.e. the side QUEUE would sit on an unsatisfied cross-queue wait for the whole 2-8 ms chain -- and a queue
+  // whose head is a pending wait slows the dispatch of every other queue of the device (the serving loop lost 15-20 % to one such
+  // wait per sample, profiles/r6_serving_probe_events.txt).  Both directions then run on `stream`, one after the other (+ ~0.2 ms of
+  // search latency, which is prefetched).  Unpaired (large grids): each direction's own FPS chain runs on its stream, forked first.
+  void* side_q = paired ? stream : side_stream;
+  if (!paired) {
+    if (hipEventRecord(fork, s0) != hipSuccess || hipStreamWaitEvent(s1, fork, 0) != hipSuccess)
+      return finish(coocc_set_error(COOCC_EHIP, "fuser_search: forking the side stream failed"));
+    forked = true;
+  }
 
   // one direction: queries (lin_q, Q, xyz_q, map_q) <- keys (Nk, xyz_k, map_k); near: [K][Q] key ordinals (-1 = none)
   auto direction = [&](int dd, void* st, const int32_t* lin_q, int Q, const float* xyz_q, const int32_t* map_q, int Nk,
@@ -175,9 +188,9 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
   };
   // img queries <- nearest pts keys (bifuser_n.py:150-162) on the side stream; for knum > 1 the reference indexes inds_img
   // with the pts ordinals (:158) -- kept
-  SRF(direction(1, side_stream, lin_img, Ni, xyz_img, map_img, Np, xyz_pts, map_pts, d->near_pts));
+  SRF(direction(1, side_q, lin_img, Ni, xyz_img, map_img, Np, xyz_pts, map_pts, d->near_pts));
   for (int k = 0; k < K; ++k)
-    SRF(coocc_index_rows_i32(K == 1 ? lin_pts : lin_img, K == 1 ? Np : Ni, d->near_pts + (size_t)k * Ni, Ni, d->rows_p + (size_t)k * V, side_stream));
+    SRF(coocc_index_rows_i32(K == 1 ? lin_pts : lin_img, K == 1 ? Np : Ni, d->near_pts + (size_t)k * Ni, Ni, d->rows_p + (size_t)k * V, side_q));
   // pts queries <- nearest img keys (bifuser_n.py:137-148)
   SRF(direction(0, stream, lin_pts, Np, xyz_pts, map_pts, Ni, xyz_img, map_img, d->near_img));
   for (int k = 0; k < K; ++k)

@@ -433,7 +433,7 @@ class BiFuser_N(nn.Module):
                 base, nbase = (lin_pts, Np) if K == 1 else (lin_img, Ni)
                 for k in range(K):
                     call("coocc_index_rows_i32", ptr(base), nbase, ptr(sr.near_pts[k]), Ni, ptr(sr.rows_p[k]))
-                sr.done_side = torch.cuda.Event()
+                sr.done_side = streams.new_event()
                 sr.done_side.record()
             # pts queries <- nearest img keys (bifuser_n.py:137-148)
             sr.near_img = _fps_nn_xyz(xyz_pts, xyz_img, q_lin=lin_pts if vox else None, k_lin=lin_img if vox else None, grid=vox,
@@ -444,7 +444,7 @@ class BiFuser_N(nn.Module):
             sr.keep = (xyz, lin, img, pts)       # referenced by kernels still in flight on the side stream
         elif Np or Ni:
             raise IndexError("BiFuser_N: one modality has no non-empty voxel (the reference fails on empty keys)")
-        sr.done_main = torch.cuda.Event()
+        sr.done_main = streams.new_event()
         sr.done_main.record()
         return sr
 
@@ -484,7 +484,7 @@ class BiFuser_N(nn.Module):
         sr.near_pts = slot.near[1, :K * Ni].view(K, Ni)
         sr.rows, sr.rows_p = slot.rows[:, :Np], slot.rows_p[:, :Ni]
         sr.keep = (keep,)
-        sr.done_main = torch.cuda.Event()
+        sr.done_main = streams.new_event()
         sr.done_main.record()
         sr.done_side = sr.done_main          # the native call joins the side stream before it returns
         return sr
@@ -497,16 +497,16 @@ class BiFuser_N(nn.Module):
         C = self.in_channels
         cur = torch.cuda.current_stream(dev)
         packs = self._packed()
-        cur.wait_event(sr.done_main)
+        sr.done_main.wait(cur)
         for t in sr.tensors():
             t.record_stream(cur)             # allocated on the search stream(s), consumed here
         if sr.rows is not None and sr.slot is not None:
             # the search wrote into a SearchSlot: its tables are capacity-strided views, use the device-count form
-            cur.wait_event(sr.done_side)
+            sr.done_side.wait(cur)
             self.finish_static(sr.slot)
             self.last_near = (sr.near_img, sr.near_pts)
         elif sr.rows is not None:
-            cur.wait_event(sr.done_side)
+            sr.done_side.wait(cur)
             h2 = self._g1_h2(cat4, packs)
             gather_conv_rows(cat4, 0, packs["knn"], sr.rows, sr.lin_pts, cat4, 2 * C, C, C, src_h2=h2)
             gather_conv_rows(cat4, C, packs["knn"], sr.rows_p, sr.lin_img, cat4, 3 * C, 0, C, src_h2=h2)
@@ -547,9 +547,9 @@ class BiFuser_N(nn.Module):
     def finish_bookkeeping(self, sr):
         """Make a SearchResult issued on another stream safe to consume on the current one (training path)."""
         cur = torch.cuda.current_stream(sr.cat4.t.device)
-        cur.wait_event(sr.done_main)
+        sr.done_main.wait(cur)
         if sr.done_side is not None:
-            cur.wait_event(sr.done_side)
+            sr.done_side.wait(cur)
         for t in sr.tensors():
             t.record_stream(cur)
         if sr.rows is not None:

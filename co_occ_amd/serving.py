@@ -27,7 +27,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
-from . import core, graph as cg
+from . import core, graph as cg, streams as cstreams_
 
 CAM_KEYS = ("rots", "trans", "intrins", "post_rots", "post_trans", "bda")
 
@@ -47,20 +47,22 @@ class Ticket:
     """One submitted frame.  ``result()`` issues every dense stage up to this frame (if the caller has not pumped them yet),
     optionally waits for it, and returns the output dict."""
 
-    __slots__ = ("pipe", "index", "slot", "frame", "search", "out", "done", "copy", "events", "fallback", "ready", "pts_vol")
+    __slots__ = ("pipe", "index", "slot", "frame", "search", "out", "done", "copy", "events", "fallback", "ready", "pts_vol", "stream")
 
     def __init__(self, pipe, index, slot, frame, copy):
         self.pipe, self.index, self.slot, self.frame, self.copy = pipe, index, slot, frame, copy
-        self.search = self.out = self.done = self.events = self.pts_vol = None
+        self.search = self.out = self.done = self.events = self.pts_vol = self.stream = None
         self.fallback = False
         # whatever produced the frame's tensors on the submitting thread's stream (the upstream encoders) is waited for by the
         # prefetch stream that reads them
-        self.ready = torch.cuda.Event()
+        self.ready = cstreams_.new_event()      # device-scope ordering only (streams.DeviceEvent): no cache writeback per record
         self.ready.record(torch.cuda.current_stream(pipe.dev))
 
     def result(self, wait=True):
         self.pipe._issue_through(self.index)
         if wait:
+            # a device-scope event (streams.DeviceEvent): once it has fired the replay's kernels have completed and released their
+            # writes at device scope -- any kernel or device -> host copy issued from now on sees them
             self.done.synchronize()
             core.check_h2_overflow()
         return self.out
@@ -69,6 +71,7 @@ class Ticket:
 # DIAGNOSTIC (profiles/r6_pipeline_gap.txt): bits of the search stage left out of every submitted frame -- 1: the copies of the frame's
 # dense-stage inputs into the slot, 2: the pooling (fused lift-splat), 4: the index search (K1-K5).  The outputs are then NOT the frame's.
 _DIAG_SKIP = int(os.environ.get("COOCC_SERVING_DIAG_SKIP", "0"))
+SLOT_WAIT_HOST = os.environ.get("COOCC_SLOT_WAIT", "host") != "device"     # see ServingPipeline._search
 
 
 def _clone_frame_item(v):
@@ -183,11 +186,19 @@ class ServingPipeline:
         self._mark(t, "search_begin")
         st = self.search_streams[k]
         with torch.cuda.stream(st), torch.no_grad():
-            st.wait_event(t.ready)
+            t.ready.wait(st)
             if self.slot_done[k] is not None:
-                st.wait_event(self.slot_done[k])           # the replay that read this slot last
+                # the replay that read this slot last.  Waited for by THIS HOST THREAD (a sleeping wait), not by the stream: a
+                # second queue waiting for an event of a dense stream that has not fired yet cost the loop 15-20 % with three
+                # dense stages in flight -- 274 against 339 samples/s without the search stage, whichever queue waits and
+                # whatever the event's fence flags; a record nobody waits for on the device is free
+                # (profiles/r6_serving_probe_events.txt).  The thread would block on the stage's count read anyway.
+                if SLOT_WAIT_HOST:
+                    self.slot_done[k].synchronize()
+                else:
+                    self.slot_done[k].wait(st)
             if self.time_dense:
-                e0 = torch.cuda.Event(enable_timing=True)
+                e0 = cstreams_.new_event(timing=True)
                 e0.record()
             for v in _tensors_of(fr):
                 if v.is_cuda:
@@ -210,7 +221,7 @@ class ServingPipeline:
                     sr = self.model.occ_fuser.search_native(pts, slot)
                 else:
                     sr = self._last_sr[k]
-                    sr.done_main = torch.cuda.Event()
+                    sr.done_main = cstreams_.new_event()
                     sr.done_main.record()
                     sr.done_side = sr.done_main
             elif fr.get("depth") is not None:
@@ -224,8 +235,8 @@ class ServingPipeline:
                     self.model.occ_fuser.search(slot.img_rows().as_ncdhw(), pts, slot=slot)
             if self.time_dense:
                 if sr.done_side is not None:
-                    st.wait_event(sr.done_side)
-                e1 = torch.cuda.Event(enable_timing=True)
+                    sr.done_side.wait(st)
+                e1 = cstreams_.new_event(timing=True)
                 e1.record()
                 t.events = (e0, e1)
         self._mark(t, "search_end")
@@ -237,9 +248,9 @@ class ServingPipeline:
             t = Ticket(self, -1, k, example, False)
             sr = self._search(t)
             ds = self.dense_streams[k % self.ndense]
-            ds.wait_event(sr.done_main)
+            sr.done_main.wait(ds)
             if sr.done_side is not None:
-                ds.wait_event(sr.done_side)
+                sr.done_side.wait(ds)
             self.graphs[k] = cg.DenseGraph(self.model, self.slots[k], self.static[k], ds, render=self.render).capture()
         torch.cuda.synchronize(self.dev)
         core.check_h2_overflow()
@@ -301,12 +312,12 @@ class ServingPipeline:
     def _issue(self, t, sr):
         k = t.slot
         ds = self.dense_streams[k % self.ndense]
-        ds.wait_event(sr.done_main)
+        sr.done_main.wait(ds)
         if sr.done_side is not None:
-            ds.wait_event(sr.done_side)
+            sr.done_side.wait(ds)
         with torch.cuda.stream(ds), torch.no_grad():
             if self.time_dense:
-                e0 = torch.cuda.Event(enable_timing=True)
+                e0 = cstreams_.new_event(timing=True)
                 e0.record()
             g = self.graphs[k]
             if g.fits(sr.counts):
@@ -322,7 +333,7 @@ class ServingPipeline:
                     cam_geo = (cam_geo[0].reshape(-1, cam_geo[0].shape[-1]),) + tuple(cam_geo[1:])
                 out = self.model.decode(vf, st["gemo"], st["img_feats"], st["transform"], self.render, cam_geo=cam_geo)
             if self.time_dense:
-                e1 = torch.cuda.Event(enable_timing=True)
+                e1 = cstreams_.new_event(timing=True)
                 e1.record()
                 self.dense_ev.append((e0, e1, t.index, t.events))
             if t.copy:                             # own copies of the tensors (lists -- the capacity-sized fine outputs -- by reference)
@@ -330,10 +341,10 @@ class ServingPipeline:
                        for kk, v in out.items()}
             if self.after_replay is not None:
                 self.after_replay(out)
-            ev = torch.cuda.Event()
+            ev = cstreams_.new_event(blocking=True)
             ev.record()
         self.slot_done[k] = ev
-        t.out, t.done = out, ev
+        t.out, t.done, t.stream = out, ev, ds
         t.frame = t.pts_vol = None                 # the search has consumed the frame's tensors (stream-ordered before `ev`)
 
     def _recapture(self):

@@ -43,6 +43,19 @@ int coocc_device_cu_count(int* n);
 int coocc_stream_create_cu_mask(const uint32_t* mask_host, int nwords, void** stream_out);
 int coocc_stream_destroy(void* stream);
 
+/* ---------------------------------------------------------------- device-scope events */
+/* hipEvent wrappers created with hipEventDisableSystemFence (+ hipEventDisableTiming unless flags & 1): ordering between streams of
+ * ONE device without the system-scope cache writeback / invalidate a default event performs at every record (24 % of the serving
+ * loop's throughput with three dense stages in flight).  Not for host-visible or cross-device hand-over: synchronise the stream
+ * (or copy device -> host on it) for that.  The reference has no counterpart: it runs one stream. */
+int coocc_event_create(int flags, void** event_out);   /* flags: 1 = keep timestamps, 2 = blocking (sleeping) synchronize */
+int coocc_event_destroy(void* event);
+int coocc_event_record(void* event, void* stream);
+int coocc_stream_wait_event(void* stream, void* event);
+int coocc_event_synchronize(void* event);
+int coocc_event_query(void* event);                 /* 1 complete, 0 not yet, < 0 error */
+int coocc_event_elapsed_ms(void* start, void* stop, float* ms);
+
 /* ---------------------------------------------------------------- layout / K1 */
 
 /* [B,C,V] (reference NCDHW, V = X*Y*Z) -> rows of `dst_stride` floats at channel

@@ -43,8 +43,8 @@ def test_dense_graph_replay_equals_eager(dev):
     def search(s):
         with torch.no_grad():
             sr = cg.search_into_slot(model, slot, s["depth"], s["ctx"], s["cams"], s["pts"])
-        stream.wait_event(sr.done_main)
-        stream.wait_event(sr.done_side)
+        sr.done_main.wait(stream)
+        sr.done_side.wait(stream)
         return sr
 
     sr = search(a)

@@ -1,7 +1,9 @@
 """ServingPipeline alone (no bench.py around it): frames through model.serving() with the knobs of profiles/r6_pipeline_gap.txt.
 
     python tools/serving_probe.py [slots] [dense_streams] [steps]        env: COOCC_SERVING_DIAG_SKIP, COOCC_SERVING_PROBE=a,b,...
-      probe flags:  nowait   -- _issue does not make the dense stream wait for the search's event (only valid with DIAG_SKIP=7)
+      probe flags:  recnowait / dummywait -- an event is recorded after every replay but the search stream does not wait for it
+                                  (nobody / an idle stream does); with DIAG_SKIP=7
+                    nowait   -- _issue does not make the dense stream wait for the search's event (only valid with DIAG_SKIP=7)
                     noev     -- no event record after a replay (slot_done reuses the previous event; only valid with DIAG_SKIP=7)
                     prequeue -- every search is dispatched and finished before the first replay is issued (host-side ordering)
 """
@@ -23,21 +25,40 @@ model, _ = bench.build_model("r50", dev)
 samples = [bench.make_inputs("r50", 1234 + i, dev, model) for i in range(slots)]
 frames = [bench.frame_of(s) for s in samples]
 gp = model.serving(frames[0], slots=slots, dense_streams=nds)
-if "nowait" in flags or "noev" in flags:
+if flags & {"nowait", "noev", "recnowait", "dummywait", "hostsync"}:
     orig = gp._issue
+    keep = []
+    dummy = torch.cuda.Stream(device=dev)
 
     def _issue(t, sr):
         k = t.slot
         ds = gp.dense_streams[k % gp.ndense]
         if "nowait" not in flags:
-            ds.wait_event(sr.done_main)
+            sr.done_main.wait(ds)
         with torch.cuda.stream(ds), torch.no_grad():
             out = gp.graphs[k].replay()
-            if "noev" not in flags or gp.slot_done[k] is None:
-                ev = torch.cuda.Event()
+            from co_occ_amd import streams as cstreams
+            if gp.slot_done[k] is None:
+                ev = cstreams.new_event()
                 ev.record()
-            else:
+            elif "noev" in flags:
+                ev = gp.slot_done[k]                      # no record at all
+            elif "recnowait" in flags:
+                ev2 = cstreams.new_event()
+                ev2.record()                              # a record nobody waits for; the search keeps waiting for the first event
+                keep.append(ev2)
+                del keep[:-64]
                 ev = gp.slot_done[k]
+            elif "dummywait" in flags:
+                ev2 = cstreams.new_event()
+                ev2.record()
+                ev2.wait(dummy)                           # an idle third stream waits for it, not the search stream
+                keep.append(ev2)
+                del keep[:-64]
+                ev = gp.slot_done[k]
+            else:
+                ev = cstreams.new_event()
+                ev.record()
         gp.slot_done[k] = ev
         t.out, t.done = out, ev
         t.frame = t.pts_vol = None
