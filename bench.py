@@ -241,10 +241,15 @@ WITH_POOL = [True]
 CFGNAME = ["r50"]
 
 
+GATHERER = [None]        # dist.GatherThread of the serving loop at world > 1
+
+
 def drain_gathers():
     out = None
     while _pending:
         out = _pending.pop().wait()
+    if GATHERER[0] is not None:
+        out = GATHERER[0].drain() or out
     return out
 
 
@@ -830,10 +835,13 @@ def main():
     if world > 1:               # ... each rank on its own slice of the host cores (single node: LOCAL_WORLD_SIZE ranks share them)
         cdist.pin_rank_threads(int(os.environ.get("LOCAL_RANK", rank)), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if args.graph and WITH_POOL[0] and args.api == "serving":
+        if world > 1 and GATHERER[0] is None:
+            # the rank's all-gathers from one thread that waits for each replay's completion on the HOST first (dist.GatherThread)
+            GATHERER[0] = cdist.GatherThread(dev)
         try:
             gp = model.serving(frames[0], slots=max(2, args.slots), dense_streams=max(1, args.streams if not auto_streams else 3),
                                ahead=args.ahead, search_priority=int(os.environ.get("COOCC_SEARCH_PRIO", "0")),
-                               after_replay=(_gather if world > 1 else None), reserve_cus=args.reserve_cus)
+                               after_done=(GATHERER[0].submit if world > 1 else None), reserve_cus=args.reserve_cus)
             gp.run(frames, 2 * gp.n)
         except Exception as e:           # configurations the static form does not cover run the eager pipeline
             print("bench: hipGraph pipeline unavailable for this configuration (%s: %s); eager pipeline" % (type(e).__name__, e), file=sys.stderr)

@@ -82,6 +82,10 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
   SearchWs w = carve((char*)d->ws, V, K, d->fps_num, d->max_cluster, d->X, d->Y, d->Z);
   COOCC_CHECK_ARG(d->ws_bytes >= w.total, "fuser_search: workspace smaller than coocc_fuser_search_ws()");
   hipStream_t s0 = as_stream(stream), s1 = as_stream(side_stream);
+  // DIAGNOSTIC ONLY (profiles/r6_serving_probe_events.txt: what of the search costs the serving loop its last 8 %): parts of the stage
+  // left out -- 1: the FPS launch, 2: K3-K5 + row tables of both directions, 4: the count read (the host keeps the previous call's
+  // counts).  The outputs are then NOT this frame's.
+  static const int sdiag = [] { const char* e = getenv("COOCC_SEARCH_DIAG_SKIP"); return e ? atoi(e) : 0; }();
   int32_t* lin_img = d->lin;
   int32_t* lin_pts = d->lin + V;
 
@@ -89,8 +93,8 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
   SRC(coocc_fuser_prepare_rows(d->cat4, 1, 4 * C, d->pts, d->pts_rows, d->pts_stride, d->cat4, w.flags, w.flags + V, 1, C, V, stream));
   SRC(coocc_compact_flags(w.flags, V, lin_img, d->counts, w.cws, (size_t)(V / 1024 + 2) * 4, stream));
   SRC(coocc_compact_flags(w.flags + V, V, lin_pts, d->counts + 1, w.cws + (V / 1024 + 2), (size_t)(V / 1024 + 2) * 4, stream));
-  COOCC_HIP(hipMemcpyAsync(d->counts_host, d->counts, 8, hipMemcpyDeviceToHost, s0));
-  {
+  if (!((sdiag & 4) && d->counts_host[0] > 0)) COOCC_HIP(hipMemcpyAsync(d->counts_host, d->counts, 8, hipMemcpyDeviceToHost, s0));
+  if (!((sdiag & 4) && d->counts_host[0] > 0)) {
     // the one host sync of the stage.  A BLOCKING event: the calling thread sleeps instead of spinning (hipStreamSynchronize may
     // spin), so several prefetch threads per rank -- and 8 ranks per node -- do not burn the host cores the issuing threads need
     // No system-scope fence on it (layout.hip, "device-scope events"): the two counts reach the host through the memcpy command above,
@@ -128,8 +132,9 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
       return coocc_set_error(COOCC_EHIP, "fuser_search: forking the FPS stream failed");
     }
   }
-  const int pair_rc = coocc_fps_voxels_pair(lin_pts, Np, w.rep[0], w.fps[0], lin_img, Ni, w.rep[1], w.fps[1], w.fps_bytes, d->X, d->Y, d->Z,
-                                            d->fps_num, sf ? (void*)sf : stream);
+  const int pair_rc = (sdiag & 1) ? COOCC_OK
+                                  : coocc_fps_voxels_pair(lin_pts, Np, w.rep[0], w.fps[0], lin_img, Ni, w.rep[1], w.fps[1], w.fps_bytes, d->X, d->Y,
+                                                          d->Z, d->fps_num, sf ? (void*)sf : stream);
   if (sf) {
     const bool ok = hipEventRecord(fps_ev, sf) == hipSuccess && hipStreamWaitEvent(s0, fps_ev, 0) == hipSuccess;
     (void)hipEventDestroy(fps_ev);
@@ -177,6 +182,7 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
   // one direction: queries (lin_q, Q, xyz_q, map_q) <- keys (Nk, xyz_k, map_k); near: [K][Q] key ordinals (-1 = none)
   auto direction = [&](int dd, void* st, const int32_t* lin_q, int Q, const float* xyz_q, const int32_t* map_q, int Nk,
                        const float* xyz_k, const int32_t* map_k, int32_t* near) -> int {
+    if (sdiag & 2) return COOCC_OK;
     if (!paired) SRC(coocc_fps_voxels(lin_q, Q, d->X, d->Y, d->Z, d->fps_num, w.rep[dd], w.fps[dd], w.fps_bytes, st));
     hipLaunchKernelGGL(k_gather_xyz, dim3(cdiv(d->fps_num, 256)), dim3(256), 0, as_stream(st), xyz_q, w.rep[dd], d->fps_num, w.rep_xyz[dd]);
     COOCC_LAUNCH_CHECK("k_gather_xyz");
@@ -189,11 +195,11 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
   // img queries <- nearest pts keys (bifuser_n.py:150-162) on the side stream; for knum > 1 the reference indexes inds_img
   // with the pts ordinals (:158) -- kept
   SRF(direction(1, side_q, lin_img, Ni, xyz_img, map_img, Np, xyz_pts, map_pts, d->near_pts));
-  for (int k = 0; k < K; ++k)
+  for (int k = 0; k < K && !(sdiag & 2); ++k)
     SRF(coocc_index_rows_i32(K == 1 ? lin_pts : lin_img, K == 1 ? Np : Ni, d->near_pts + (size_t)k * Ni, Ni, d->rows_p + (size_t)k * V, side_q));
   // pts queries <- nearest img keys (bifuser_n.py:137-148)
   SRF(direction(0, stream, lin_pts, Np, xyz_pts, map_pts, Ni, xyz_img, map_img, d->near_img));
-  for (int k = 0; k < K; ++k)
+  for (int k = 0; k < K && !(sdiag & 2); ++k)
     SRF(coocc_index_rows_i32(lin_img, Ni, d->near_img + (size_t)k * Np, Np, d->rows + (size_t)k * V, stream));
 #undef SRF
   return finish(COOCC_OK);

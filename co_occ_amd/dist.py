@@ -111,6 +111,73 @@ def all_gather_maps_async(rgbs, depths):
     return PendingMaps(dist.all_gather_into_tensor(out, packed, async_op=True), out, None, packed)
 
 
+class GatherThread:
+    """The rank's map all-gathers, issued by ONE host thread that first waits -- on the host, sleeping -- for the completion
+    event of the replay that rendered the maps, then enqueues pack + ``all_gather_into_tensor`` on its own stream.
+
+    Why not ``all_gather_maps_async`` right after the replay is issued: RCCL's stream would then sit on an unsatisfied wait for the
+    replay's event for the whole dense stage (~10 ms), and a queue whose head is a pending cross-queue wait slows the dispatch of
+    every other queue of the device (15-20 % of the serving loop's throughput, profiles/r6_serving_probe_events.txt).  One
+    thread issues every collective of the rank in sample order, so all ranks issue them in the same order; at most one is in
+    flight (the next one's stream waits for it), each overlaps the following samples' dense stages.  ``drain()`` before any
+    collective issued by another thread (barriers, the timing all-reduce)."""
+
+    def __init__(self, device):
+        import queue
+        import threading
+        self.device, self.q, self.err, self.last = device, queue.Queue(), None, None
+        self.t = threading.Thread(target=self._run, daemon=True, name="coocc-gather")
+        self.t.start()
+
+    def submit(self, out, event):
+        self.q.put((out, event))
+
+    def _run(self):
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.Stream(device=self.device)
+        pending = None
+        while True:
+            item = self.q.get()
+            try:
+                if item is None:
+                    return
+                if isinstance(item, tuple) and item[0] == "drain":
+                    with torch.cuda.stream(stream):
+                        if pending is not None:
+                            self.last = pending.wait()
+                            pending = None
+                    stream.synchronize()
+                    item[1].set()
+                    continue
+                out, event = item
+                event.synchronize()                       # host-side: the maps exist (device-scope release done) from here on
+                with torch.cuda.stream(stream):
+                    if pending is not None:
+                        self.last = pending.wait()        # this stream waits for the previous collective (about to finish or done)
+                    pending = all_gather_maps_async(out["rgbs"], out["depths"])
+            except Exception as e:                        # surfaced by drain()
+                self.err = e
+                if isinstance(item, tuple) and item and item[0] == "drain":
+                    item[1].set()
+            finally:
+                self.q.task_done()
+
+    def drain(self):
+        """Every submitted gather has been issued and has completed.  Returns the last gathered (rgbs, depths)."""
+        import threading
+        done = threading.Event()
+        self.q.put(("drain", done))
+        done.wait()
+        if self.err is not None:
+            e, self.err = self.err, None
+            raise e
+        return self.last
+
+    def close(self):
+        self.q.put(None)
+        self.t.join(timeout=10)
+
+
 def gather_ray_shards(local_maps, n_rows_total):
     """Config 5 (ray-sharded render of ONE scene): each rank rendered a contiguous chunk of the
     flattened (camera,row) space; rows are padded to the largest chunk for the collective and

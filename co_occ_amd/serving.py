@@ -84,11 +84,12 @@ def _clone_frame_item(v):
 
 class ServingPipeline:
     """``model``: a ``COOCC_Ray`` in eval mode.  ``example``: one frame (dict, see ``submit``) that fixes the shapes; it is
-    used for the warm-up and the capture of every slot.  ``after_replay(out)`` (optional) runs on the dense stream right after
+    used for the warm-up and the capture of every slot.  ``after_done(out, event)`` (optional) is called on the issuing thread with the completion event of the frame's replay
+    (what a collective should wait for ON THE HOST: ``dist.GatherThread``); ``after_replay(out)`` (optional) runs on the dense stream right after
     a frame's dense stage has been issued (bench.py issues its RCCL all-gather there)."""
 
     def __init__(self, model, example, slots=6, dense_streams=3, ahead=0, render=None, search_priority=0, after_replay=None,
-                 time_dense=False, reserve_cus=0):
+                 time_dense=False, reserve_cus=0, after_done=None):
         assert not model.training, "ServingPipeline serves the eval-mode (folded-BN) path"
         self.model = model
         pts = example.get("pts")
@@ -105,7 +106,7 @@ class ServingPipeline:
         # that read it finished); `ahead` limits it further (concurrent searches contend with each other and with the graphs)
         most = max(1, n - self.ndense) if n > 1 else 1
         self.ahead = most if ahead <= 0 else max(1, min(int(ahead), most))
-        self.after_replay, self.time_dense = after_replay, time_dense
+        self.after_replay, self.after_done, self.time_dense = after_replay, after_done, time_dense
         self.reserve_cus = max(0, int(reserve_cus))
         self.dense_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ndense)]
         self.search_streams = [torch.cuda.Stream(device=dev, priority=search_priority) for _ in range(n)]
@@ -344,6 +345,8 @@ class ServingPipeline:
             ev = cstreams_.new_event(blocking=True)
             ev.record()
         self.slot_done[k] = ev
+        if self.after_done is not None:
+            self.after_done(out, ev)           # e.g. hand (outputs, completion event) to the thread that issues the rank's collectives
         t.out, t.done, t.stream = out, ev, ds
         t.frame = t.pts_vol = None                 # the search has consumed the frame's tensors (stream-ordered before `ev`)
 
