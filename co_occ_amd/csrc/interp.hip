@@ -79,7 +79,7 @@ struct UpAddZ {
     const Lin1 lz = lin_src(Z, Zc, ZF);
     const f32x4 r = f[Z] + column_sample<ZF, ZC, Z>(q, lx, ly, lz);
     *(f32x4*)(o + (size_t)Z * C) = r;
-    if (twin) { store_h2(twin, row0 + Z, C, c, r); h2_guard(flag, r); }
+    if (twin) { store_h2_pair(twin, row0 + Z, C, c, r); h2_guard(flag, r); }
     if constexpr (Z + 1 < ZF) UpAddZ<ZF, ZC, Z + 1>::run(q, f, lx, ly, Zc, o, row0, C, c, twin, flag);
   }
 };
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_upsample_add(const float* __restrict__ 
   f32x4* o = (f32x4*)(fine + ((((size_t)b * Xf + x) * Yf + y) * Zf + z) * C + c);
   const f32x4 r = *o + s;
   *o = r;
-  if (twin) { store_h2(twin, row, C, c, r); h2_guard(flag, r); }      // H2 twin of the updated rows (the fpn_conv that reads them next)
+  if (twin) { store_h2_pair(twin, row, C, c, r); h2_guard(flag, r); }      // H2 twin of the updated rows (the fpn_conv that reads them next)
 }
 
 extern "C" int coocc_upsample_add_trilinear_ex(const float* coarse, float* fine, int B, int C, int Xc, int Yc,
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_occhead_mix(MixLevels lv, const float* 
     acc = acc + s * (w[l] / sum);
   }
   *(f32x4*)(out + row * C + c) = acc;
-  if (twin) { store_h2(twin, row, C, c, acc); h2_guard(flag, acc); }     // H2 twin for occ_pred_conv's first 1x1x1 layer
+  if (twin) { store_h2_pair(twin, row, C, c, acc); h2_guard(flag, acc); }     // H2 twin for occ_pred_conv's first 1x1x1 layer
 }
 
 // z-column form of the mix: four levels, level 0 on the output grid, levels 1-3 coarser in z by powers of two.  A thread takes HALF a

@@ -152,24 +152,17 @@ __global__ __launch_bounds__(256) void k_wino_in_h2(const float* __restrict__ in
 #pragma unroll
     for (int a = 0; a < N; ++a) t[a][e] = q[a];
   }
-  char* o = V + (size_t)row * vstride * 4 + (c >> 5) * 128 + (c & 31) * 2;
 #pragma unroll
   for (int a = 0; a < N; ++a) {
     f32x4 q[N];
     Wino<N>::bt(t[a], q);
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-      f16x4 hi, lo;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float v = q[e][u] * scale;
-        hi[u] = (_Float16)v;
-        lo[u] = (_Float16)((v - (float)hi[u]) * 2048.f);
-      }
-      char* oo = o + (size_t)(a * N + e) * gstride_bytes;
-      *(f16x4*)oo = hi;
-      *(f16x4*)(oo + 64) = lo;
-      h2_guard(flag, q[e] * scale);
+      // lanes l, l ^ 1 hold adjacent channel quads of one row (thread i: quad i % (C / 4) of row i / (C / 4), C % 32 == 0):
+      // 16-byte stores through store_h2_pair (the 8-byte hi / lo pairs of this kernel's 92 MB were its slow half)
+      const f32x4 sv = q[e] * scale;
+      store_h2_pair(V + (size_t)(a * N + e) * gstride_bytes, (size_t)row, vstride, c, sv);
+      h2_guard(flag, sv);
     }
   }
 }
@@ -294,7 +287,7 @@ __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ Mb, 
         if (rr) v = v + *(const f32x4*)rr;
         if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         *(f32x4*)o = v;
-        if (twin) { store_h2(twin, orow, C, c, v); h2_guard(flag, v); }      // the next split-f16 layer's operand, written by the producer
+        if (twin) { store_h2_pair(twin, orow, C, c, v); h2_guard(flag, v); } // the next split-f16 layer's operand, written by the producer (lane pairs: same row, same branch)
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
