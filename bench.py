@@ -808,7 +808,7 @@ def main():
             s_["points"] = synth.lidar_points(seed=8 + i + 17 * rank).to(dev)
             with torch.no_grad():
                 s_["pts"] = model.extract_pts_feat(s_["points"])[0]
-    if args.reserve_cus > 0 and not args.graph:   # (--graph 1: ServingPipeline(reserve_cus=) masks its own streams)
+    if args.reserve_cus > 0 and not args.graph:   # (eager pipeline only; with the graph loop masked streams ran 4-6x slower: profiles/r6_reserve_cus_*.txt)
         # CU partition: the FPS chains get private CUs, everything else runs on the remaining ones
         from co_occ_amd import streams as cstreams
         parts = [cstreams.partition(dev, reserved=args.reserve_cus) for _ in range(max(1, args.streams))]
@@ -841,7 +841,7 @@ def main():
         try:
             gp = model.serving(frames[0], slots=max(2, args.slots), dense_streams=max(1, args.streams if not auto_streams else 3),
                                ahead=args.ahead, search_priority=int(os.environ.get("COOCC_SEARCH_PRIO", "0")),
-                               after_done=(GATHERER[0].submit if world > 1 else None), reserve_cus=args.reserve_cus)
+                               after_done=(GATHERER[0].submit if world > 1 else None))
             gp.run(frames, 2 * gp.n)
         except Exception as e:           # configurations the static form does not cover run the eager pipeline
             print("bench: hipGraph pipeline unavailable for this configuration (%s: %s); eager pipeline" % (type(e).__name__, e), file=sys.stderr)

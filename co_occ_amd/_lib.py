@@ -35,7 +35,7 @@ class SearchDesc(ctypes.Structure):
                [(n, c_int) for n in ("C", "X", "Y", "Z", "K", "fps_num", "max_cluster")] + \
                [("radius", ctypes.c_float), ("dist_thresh", ctypes.c_float), ("offsets", c_void_p), ("noff", c_int)] + \
                [(n, c_void_p) for n in ("lin", "counts", "near_img", "near_pts", "rows", "rows_p", "ws")] + \
-               [("ws_bytes", ctypes.c_size_t), ("counts_host", c_void_p), ("fps_stream", c_void_p)]
+               [("ws_bytes", ctypes.c_size_t), ("counts_host", c_void_p)]
 
 
 P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_int64

@@ -122,24 +122,9 @@ extern "C" int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side
 
   // K2 of BOTH directions as one launch of two workgroups when the grid fits the register-resident kernel (csrc/knn.hip); the
   // rest of each direction then forks onto its own stream.  Otherwise each direction runs its own FPS on its stream.
-  // d->fps_stream: the paired launch on a stream of its own (reserved CUs), forked from s0 and joined back before anything reads rep[]
-  hipStream_t sf = d->fps_stream && as_stream(d->fps_stream) != s0 ? as_stream(d->fps_stream) : nullptr;
-  hipEvent_t fps_ev = nullptr;
-  if (sf) {
-    COOCC_HIP(hipEventCreateWithFlags(&fps_ev, hipEventDisableTiming | hipEventDisableSystemFence));
-    if (hipEventRecord(fps_ev, s0) != hipSuccess || hipStreamWaitEvent(sf, fps_ev, 0) != hipSuccess) {
-      (void)hipEventDestroy(fps_ev);
-      return coocc_set_error(COOCC_EHIP, "fuser_search: forking the FPS stream failed");
-    }
-  }
   const int pair_rc = (sdiag & 1) ? COOCC_OK
                                   : coocc_fps_voxels_pair(lin_pts, Np, w.rep[0], w.fps[0], lin_img, Ni, w.rep[1], w.fps[1], w.fps_bytes, d->X, d->Y,
-                                                          d->Z, d->fps_num, sf ? (void*)sf : stream);
-  if (sf) {
-    const bool ok = hipEventRecord(fps_ev, sf) == hipSuccess && hipStreamWaitEvent(s0, fps_ev, 0) == hipSuccess;
-    (void)hipEventDestroy(fps_ev);
-    if (!ok) return coocc_set_error(COOCC_EHIP, "fuser_search: joining the FPS stream failed");
-  }
+                                                          d->Z, d->fps_num, stream);
   if (pair_rc != COOCC_OK && pair_rc != 2) return pair_rc;
   const bool paired = pair_rc == COOCC_OK;
   // fork / join of the two search directions.  Whatever happens after the fork, the side stream is joined back into `stream` and

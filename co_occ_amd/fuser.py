@@ -469,8 +469,6 @@ class BiFuser_N(nn.Module):
             d.pts, d.pts_rows, d.pts_stride = keep.data_ptr(), 0, 0
         cur = torch.cuda.current_stream(dev)
         side = _side_stream(dev, cur)
-        fstream = streams.fps_stream_for(cur, 0)          # CU-partitioned pipeline: the paired FPS chains on the reserved CUs
-        d.fps_stream = fstream.cuda_stream if fstream is not None else None
         rc = _lib.load().coocc_fuser_search(ctypes.byref(d), ctypes.c_void_p(cur.cuda_stream), ctypes.c_void_p(side.cuda_stream))
         if rc == 1:           # COOCC_SEARCH_SMALL: the reference's other branch
             return self.search(slot.img_rows().as_ncdhw(), pts_voxel_feats, slot=slot)

@@ -68,7 +68,7 @@ class Ticket:
         return self.out
 
 
-# DIAGNOSTIC (profiles/r6_pipeline_gap.txt): bits of the search stage left out of every submitted frame -- 1: the copies of the frame's
+# DIAGNOSTIC (profiles/r6_serving_probe_events.txt): bits of the search stage left out of every submitted frame -- 1: the copies of the frame's
 # dense-stage inputs into the slot, 2: the pooling (fused lift-splat), 4: the index search (K1-K5).  The outputs are then NOT the frame's.
 _DIAG_SKIP = int(os.environ.get("COOCC_SERVING_DIAG_SKIP", "0"))
 SLOT_WAIT_HOST = os.environ.get("COOCC_SLOT_WAIT", "host") != "device"     # see ServingPipeline._search
@@ -89,7 +89,7 @@ class ServingPipeline:
     a frame's dense stage has been issued (bench.py issues its RCCL all-gather there)."""
 
     def __init__(self, model, example, slots=6, dense_streams=3, ahead=0, render=None, search_priority=0, after_replay=None,
-                 time_dense=False, reserve_cus=0, after_done=None):
+                 time_dense=False, after_done=None):
         assert not model.training, "ServingPipeline serves the eval-mode (folded-BN) path"
         self.model = model
         pts = example.get("pts")
@@ -107,21 +107,10 @@ class ServingPipeline:
         most = max(1, n - self.ndense) if n > 1 else 1
         self.ahead = most if ahead <= 0 else max(1, min(int(ahead), most))
         self.after_replay, self.after_done, self.time_dense = after_replay, after_done, time_dense
-        self.reserve_cus = max(0, int(reserve_cus))
+        # (CU-masked streams -- the FPS chains on reserved CUs, the dense graphs masked away from them -- were built and measured in
+        # round 6: 270 -> 44-64 samples/s, profiles/r6_reserve_cus_*.txt; removed.)
         self.dense_streams = [torch.cuda.Stream(device=dev) for _ in range(self.ndense)]
         self.search_streams = [torch.cuda.Stream(device=dev, priority=search_priority) for _ in range(n)]
-        if self.reserve_cus:
-            # CU partition (co_occ_amd.streams, hipExtStreamCreateWithCUMask): the FPS chains of every search -- two single-workgroup
-            # kernels of 2047 dependent steps, each needing a CU to itself -- run on `reserve_cus` CUs the dense graphs are masked
-            # away from.  Every masked stream is a hardware queue of its own, and a pipeline with one masked stream per slot
-            # (18 queues) ran 6x SLOWER than the plain one (profiles/r6_pipeline_gap.txt: the queues are time-sliced), so only
-            # the dense streams and ONE FPS stream are masked; the search streams stay plain (their other kernels are short).
-            from . import streams as cstreams
-            part = cstreams.partition(dev, reserved=self.reserve_cus, nfps=1)
-            self.dense_streams = [part.main] + [part.side(i) for i in range(1, self.ndense)]
-            for st in self.search_streams:
-                cstreams.attach_fps(st, part.fps)
-            self._part = part
         self.slots = [cg.make_slot(model, self.grid, dev) for _ in range(n)]
         self.static = [self._make_static(example) for _ in range(n)]
         self.slot_done = [None] * n            # event: the last replay that read slot k

@@ -114,21 +114,6 @@ def partition(device, reserved=2, nfps=2):
     return p
 
 
-class _FpsOnly:
-    """Registry entry of a plain (unmasked) stream whose FPS chains go to reserved-CU streams: no masked helper streams."""
-
-    def __init__(self, fps):
-        self.fps = fps
-
-    def side(self, which):
-        return None
-
-
-def attach_fps(stream, fps_streams):
-    """``fps_stream_for(stream)`` -> one of ``fps_streams`` from now on; ``stream`` itself stays a plain stream."""
-    _active[stream.cuda_stream] = _FpsOnly(list(fps_streams))
-
-
 def side_stream_for(current, which):
     """Helper stream for a pipeline on `current`: masked like it when partitioned, else None."""
     p = _active.get(current.cuda_stream)

@@ -148,9 +148,6 @@ typedef struct coocc_search_desc {
   void* ws;                /* >= coocc_fuser_search_ws(desc) bytes (device) */
   size_t ws_bytes;
   int32_t* counts_host;    /* out [2] (host): Ni, Np */
-  void* fps_stream;        /* optional: a stream of its own for the paired FPS launch (two single-workgroup chains of 2047 dependent
-                              steps) -- e.g. one masked to reserved CUs (coocc_stream_create_cu_mask) so the chains never wait for a
-                              CU behind the dense stage; forked from / joined into `stream` inside the call.  NULL: `stream` */
 } coocc_search_desc;
 size_t coocc_fuser_search_ws(const coocc_search_desc* d);
 int coocc_fuser_search(coocc_search_desc* d, void* stream, void* side_stream);
