@@ -290,6 +290,19 @@ def _run(key):
     return out, time.time() - t
 
 
+def _usable_cores():
+    """Host cores this process may actually use: affinity mask AND the cgroup CPU quota (the GPU box shows 256 logical CPUs but caps
+    the container at 16: a pool sized for 256 is throttled as a whole, the GPU tests' host thread with it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
 def start(keys):
     """Submit ``keys`` (longest first) to a spawn-context process pool.  Called once by conftest.py."""
     global _POOL
@@ -298,7 +311,7 @@ def start(keys):
         return
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
+    ncpu = _usable_cores()
     threads = 4 if ncpu >= 8 else 2
     workers = int(os.environ.get("COOCC_ORACLE_WORKERS", max(1, min(len(keys), (ncpu - 2) // threads))))
     if _POOL is None:
