@@ -53,7 +53,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, fp32-in
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA (spec; 2:1-sparse figures are not used)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 MFMA: the same rate as bf16 on gfx950 (v_mfma_f32_32x32x16_{f16,bf16})
 HBM_PEAK_GBS = 8000.0          # HBM3E spec
-TRAFFIC_FILE = "r5_traffic.json"
+TRAFFIC_FILE = "r6_traffic.json"
 
 
 def make_inputs(cfgname, seed, dev, model):

@@ -86,6 +86,20 @@ class PendingMaps:
     def __init__(self, work, out, parts, packed):
         self.work, self.out, self.parts, self.packed = work, out, parts, packed
 
+    def host_wait(self, poll_s=50e-6):
+        """Wait for the collective ON THE HOST (sleep-polling ``is_completed``): no stream is made to wait for RCCL's stream, so no
+        queue sits on an unsatisfied cross-queue wait while the collective runs.  Then as ``wait()``."""
+        if self.work is not None:
+            import time
+            try:
+                while not self.work.is_completed():
+                    time.sleep(poll_s)
+            except (RuntimeError, NotImplementedError):      # a backend without completion queries: block the host in wait()
+                self.work.wait()
+                torch.cuda.current_stream().synchronize()
+            self.work = None
+        return self.wait()
+
     def wait(self):
         if self.work is not None:
             self.work.wait()             # the CURRENT stream waits for the collective; no host block with RCCL
@@ -144,7 +158,7 @@ class GatherThread:
                 if isinstance(item, tuple) and item[0] == "drain":
                     with torch.cuda.stream(stream):
                         if pending is not None:
-                            self.last = pending.wait()
+                            self.last = pending.host_wait()
                             pending = None
                     stream.synchronize()
                     item[1].set()
@@ -153,7 +167,7 @@ class GatherThread:
                 event.synchronize()                       # host-side: the maps exist (device-scope release done) from here on
                 with torch.cuda.stream(stream):
                     if pending is not None:
-                        self.last = pending.wait()        # this stream waits for the previous collective (about to finish or done)
+                        self.last = pending.host_wait()   # at most one collective in flight; waited for on the host, not by a stream
                     pending = all_gather_maps_async(out["rgbs"], out["depths"])
             except Exception as e:                        # surfaced by drain()
                 self.err = e
