@@ -272,7 +272,7 @@ __device__ __forceinline__ LinB lin_srcb(int dst, int in, int out) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void k_upsample_maps_bwd(const float* __restrict__ drgbs, const float* __restrict__ ddepths,
+__global__ COOCC_SCALAR_FP32 __launch_bounds__(256) void k_upsample_maps_bwd(const float* __restrict__ drgbs, const float* __restrict__ ddepths,
                                                             int N, int H, int W, int scale, float* __restrict__ dmaps) {
   const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (pix >= N * H * W) return;
@@ -589,7 +589,7 @@ extern "C" int coocc_groupnorm_rows_bwd(const float* x, const float* y, const fl
 // coocc_fine_sample_img backward: adjoint of the per-camera bilinear grid_sample(align_corners=True, zeros) * mask summed
 // over cameras.  Same projection as the forward (fine.hip), one wave per fine point, lanes along channels, fp32 atomics
 // into dimg:[ncam,Hf,Wf,Ci].  params: the block built by coocc_projection_params.
-__global__ __launch_bounds__(256) void k_fine_sample_img_bwd(const float* __restrict__ dfeat, int dfeat_stride, int ncam, int Ci,
+__global__ COOCC_SCALAR_FP32 __launch_bounds__(256) void k_fine_sample_img_bwd(const float* __restrict__ dfeat, int dfeat_stride, int ncam, int Ci,
                                                               int Hf, int Wf, const float* __restrict__ prm,
                                                               const int64_t* __restrict__ fine_xyz, long long nf,
                                                               float* __restrict__ dimg) {

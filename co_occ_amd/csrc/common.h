@@ -31,6 +31,14 @@ int coocc_set_error(int code, const char* fmt, ...);
                              hipGetErrorString(e__));                                     \
   } while (0)
 
+// Kernel attribute: no packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32) in this kernel.
+// gfx950 hazard found in round 6 (profiles/r6_pk_opsel_probe.txt, tools/proto/pk_opsel_probe.hip): a packed-fp32 instruction whose op_sel
+// routes the HIGH dword of src1 into the LOW result (what hipcc emits for `vec * other[1]`) reads that operand as 0.0 in lanes 48-63
+// now and then WHILE a wave of another kernel on the same SIMD runs a 128-bit-operand MFMA (v_mfma_f32_32x32x16_f16 ...): bit-exact
+// alone, wrong next to this package's own split-f16 GEMMs.  Every kernel whose ISA held that form carries this attribute, and
+// tools/isa_lint.py (tests/test_isa_lint.py) checks the built library for it.
+#define COOCC_SCALAR_FP32 __attribute__((target("no-packed-fp32-ops")))
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 

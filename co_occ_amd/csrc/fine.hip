@@ -34,7 +34,7 @@ extern "C" int coocc_argmax_flags(const float* logits, int V, int ncls, int stri
 // volume is out_voxel_feats.permute(0,1,4,3,2) so grid x walks our X axis, y -> Y, z -> Z.
 // grid_sample(bilinear, zeros, align_corners=False): pix = ((g+1)*size - 1)/2.
 // One wave per fine point, two channels per lane per step.
-__global__ __launch_bounds__(256) void k_fine_sample_voxel(const float* __restrict__ vol, int C, int X, int Y, int Z,
+__global__ COOCC_SCALAR_FP32 __launch_bounds__(256) void k_fine_sample_voxel(const float* __restrict__ vol, int C, int X, int Y, int Z,
                                                             const int32_t* __restrict__ coarse_lin, int n, int ratio,
                                                             float fx1, float fy1, float fz1,
                                                             int64_t* __restrict__ fine_xyz, float* __restrict__ feat,
@@ -297,7 +297,7 @@ static int fine_sample_voxel_impl(const float* vol, int C, int X, int Y, int Z, 
 //   then per camera 27: inv(rots)[9], trans[3], intrins[9], post_rots[:2,:2][4], post_trans[:2][2]
 #define FINE_CAM_STRIDE 27
 #define FINE_HDR 17
-__global__ __launch_bounds__(256) void k_fine_sample_img(const float* __restrict__ img, int ncam, int Ci, int Hf, int Wf,
+__global__ COOCC_SCALAR_FP32 __launch_bounds__(256) void k_fine_sample_img(const float* __restrict__ img, int ncam, int Ci, int Hf, int Wf,
                                                           const float* __restrict__ prm,
                                                           const int64_t* __restrict__ fine_xyz, long long nf,
                                                           float* __restrict__ feat, int out_stride,
@@ -416,7 +416,7 @@ extern "C" int coocc_projection_params(const float* rots, const float* trans, co
 // camera) pairs that see the point are walked with wave-uniform readlanes.  Same expressions and accumulation order as
 // k_fine_sample_img.
 template <int R>
-__global__ __launch_bounds__(256) void k_fine_sample_img_grp(const float* __restrict__ img, int ncam, int Ci, int Hf, int Wf,
+__global__ COOCC_SCALAR_FP32 __launch_bounds__(256) void k_fine_sample_img_grp(const float* __restrict__ img, int ncam, int Ci, int Hf, int Wf,
                                                               const float* __restrict__ prm,
                                                               const int64_t* __restrict__ fine_xyz, int n,
                                                               float* __restrict__ feat, int out_stride,

@@ -131,10 +131,10 @@ __device__ __forceinline__ unsigned f2_swz(int r) { return (unsigned)((r >> 1) &
 #define F2_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")      // the tile is private to the wave (LDS is in order per wave)
 
 // IMG: the image samples are made here (phases P and B below); false: they arrive from the grouped sampler's own launch
-// (head.FINE2_IMG_INSIDE: with split-f16 GEMMs of another stream on the chip the in-kernel image samples of children 6 / 7 differ
-// from run to run -- DESIGN.md 3.2d; the sampler kernel does not show it)
+// (head.FINE2_IMG_INSIDE, default 1 since round 6.  The IMG form was off in round 5 -- a few hundred rows wrong next to other streams'
+// split-f16 GEMMs: its sampling code compiled to 132 packed-fp32 instructions with op_sel[src1] = 1, see COOCC_SCALAR_FP32 in common.h)
 template <int NW, bool IMG = true>            // waves per workgroup: 4 (two waves per SIMD at two workgroups per CU) | 6 (three; <= 168 registers)
-__global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : 2) void k_fine2_h2(Fine2K p) {       // (threads, min waves per SIMD)
+__global__ COOCC_SCALAR_FP32 __launch_bounds__(64 * NW, NW == 6 ? 3 : 2) void k_fine2_h2(Fine2K p) {       // (threads, min waves per SIMD)
   __shared__ __attribute__((aligned(16))) char Wl[F2_WBYTES];
   __shared__ __attribute__((aligned(16))) float Cn[F2_NCONST];
   __shared__ __attribute__((aligned(16))) float Tl[NW][32 * F2_TP];

@@ -32,12 +32,12 @@ FINE_FUSED = int(__import__("os").environ.get("COOCC_FINE_FUSED", "1"))
 # ratio 2 on the split-f16 engine (csrc/fine2_h2.hip, round 5): lanes = points, voxel samples kept in registers, both Linear layers
 # as three f16 MFMAs per k16 step; 0 = the three kernels (fp32-MFMA chain).
 FINE2_H2 = __import__("os").environ.get("COOCC_FINE2_H2", "1") != "0"
-# ... with the image samples made INSIDE that launch (0.33 -> 0.17 ms).  OFF: with split-f16 GEMMs of another stream on the chip
-# (two dense graphs in flight) the in-kernel image samples of children 6 / 7 differ from run to run in a few hundred of 640 k
-# rows (tests/test_gpu_serving.py::test_pipelined_test_loop_equals_per_sample_calls; tools/debug/fine2_corunner.py reproduces
-# it; DESIGN.md 3.2d lists what was ruled out).  Default: the grouped sampler's own launch (coocc_fine_sample_img_lin) feeds the
-# kernel -- two launches, bit-stable under the same co-runners.
-FINE2_IMG_INSIDE = __import__("os").environ.get("COOCC_FINE2_IMG_INSIDE", "0") == "1"
+# ... with the image samples made INSIDE that launch (0.33 -> 0.17 ms; 0 = the grouped sampler's own launch feeds the kernel).
+# Rounds 5-6 kept it off: bit-exact alone, a few hundred of 640 k rows different next to other streams' split-f16 GEMMs.  Cause
+# (round 6, profiles/r6_pk_opsel_probe.txt): 132 packed-fp32 instructions with op_sel[src1] = 1 in the sampling code, the form gfx950
+# mis-reads in lanes 48-63 beside a 128-bit-operand MFMA; the kernel is COOCC_SCALAR_FP32 now and bit-stable under those co-runners
+# (tests/test_gpu_corunner.py, tools/debug/fine2_corunner.py).
+FINE2_IMG_INSIDE = __import__("os").environ.get("COOCC_FINE2_IMG_INSIDE", "1") == "1"
 # occ_pred_conv[0] and the voxel half of fine_mlp[0] (both 128 -> 64 on out_voxel_feats) as one 128 -> 128 GEMM (ReLU on the first
 # 64 columns): one read of the rows and one launch instead of two; needs the strided-Q consumer (fine2_h2)
 MERGED_PRED_Q = __import__("os").environ.get("COOCC_MERGED_PRED_Q", "1") != "0"

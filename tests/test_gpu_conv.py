@@ -197,11 +197,11 @@ def test_interp_column_forms_equal_the_per_voxel_kernels_upsample_add(dev, monke
                                        ([(12, 10, 8), (6, 5, 4), (3, 3, 2), (2, 2, 1)], 32, 2),
                                        ([(9, 7, 8), (9, 7, 4), (5, 4, 2), (3, 2, 1)], 16, 1)])
 def test_interp_column_forms_equal_the_per_voxel_kernels_mix(dev, monkeypatch, sizes, C, B):
-    """occ_head.py:155-166 in its half-z-column form (COOCC_INTERP_COLUMN bit 1; OFF by default because the pipelined loop differed
-    from eager calls with it, csrc/interp.hip) == the per-voxel kernel, bit for bit (output rows and H2 twin) when it runs alone:
-    the r50 head's shapes, a batch of two, a level that shares x-y with the output grid; and torch."""
+    """occ_head.py:155-166 in its half-z-column form (COOCC_INTERP_COLUMN bit 1, the default since round 6: csrc/interp.hip) == the
+    per-voxel kernel, bit for bit (output rows and H2 twin): the r50 head's shapes, a batch of two, a level that shares x-y with the
+    output grid; and torch.  (Beside other streams' matrix-core work: tests/test_gpu_corunner.py.)"""
     import ctypes
-    torch.cuda.synchronize()        # ALONE: nothing of an earlier test may still run beside the mix form (it is off for that reason)
+    torch.cuda.synchronize()
     g = torch.Generator().manual_seed(C + B)
     lv = [torch.randn(B, C, *s, generator=g) for s in sizes]
     logit = torch.randn(B, 4, *sizes[0], generator=g) * 3

@@ -1,13 +1,19 @@
-"""Every stage of the shipped dense path, run REPEATEDLY on fixed inputs next to a split-f16 GEMM loop on a second stream, gives the
-bits it gives alone (VERDICT r5 "Next round" 5b).
+"""Every stage of the shipped dense path, run REPEATEDLY on fixed inputs next to matrix-core work of a second stream, gives the bits it
+gives alone (VERDICT r5 "Next round" 5b).
 
-Why: two kernels of this package (the half-z-column OccHead mix, ``COOCC_INTERP_COLUMN`` bit 1; the one-launch ratio-2 fine branch,
-``COOCC_FINE2_IMG_INSIDE=1``) are bit-exact alone and wrong only while a ``k_gemm_h2*`` kernel of ANOTHER stream shares the chip
-(``profiles/r6_corunner_defect.txt``: one 64-byte return beat of a 16-byte-per-lane load -- one dword component, lanes 48-63 -- reads
-as zero).  Both are parked (off); the whole-graph soaks only replay complete graphs.  This file is the per-stage guard for what IS
-shipped: no allocator reuse between the compared calls' inputs, no graph, no pipeline -- a stage, a co-runner, ``N`` calls, bits.
-The two parked forms run under the same harness as ``xfail`` (non-strict: a box where they happen to pass is not an error)."""
+Why: rounds 5-6 had two kernels (the half-z-column OccHead mix; the one-launch ratio-2 fine branch) that were bit-exact alone and
+wrong only while a ``k_gemm_h2*`` kernel of ANOTHER stream shared the chip.  Round 6 found the cause -- a gfx950 hazard, not a race:
+a packed-fp32 instruction whose op_sel routes the HIGH dword of src1 into the LOW result (``v_pk_fma_f32 ... op_sel:[0,1,0]``: what
+hipcc emits for ``vec * other[1]``) reads that operand as 0.0 in lanes 48-63 now and then while a wave of another kernel on the same
+SIMD runs a 128-bit-operand MFMA (``v_mfma_f32_32x32x16_f16``): ``profiles/r6_pk_opsel_probe.txt``, ``tools/proto/pk_opsel_probe.hip``.
+Every kernel whose ISA held the form is compiled without packed fp32 now (``COOCC_SCALAR_FP32``), ``tools/isa_lint.py`` checks the
+built library (``tests/test_isa_lint.py``), and both kernels are the DEFAULT.  This file is the behavioural guard: no allocator
+reuse between the compared calls' inputs, no graph, no pipeline -- a stage, a co-runner, ``N`` calls, bits.  Co-runners: the
+pointwise split-f16 kernel, a Winograd split-f16 layer, and the strongest trigger found -- a 30-line kernel that does nothing but
+``v_mfma_f32_32x32x16_f16`` (``tools/proto/mfma_corunner.hip``, compiled on the spot; it broke 14 000 rows per call of the old mix)."""
+import ctypes
 import os
+import subprocess
 
 import pytest
 import torch
@@ -81,8 +87,26 @@ def _stages(S):
     }
 
 
+_MFMA = {}
+
+
+def _mfma_corunner(tmp_root):
+    """tools/proto/mfma_corunner.hip -> a shared library (hipcc, a few seconds), loaded once per session."""
+    if "lib" not in _MFMA:
+        from conftest import ROOT
+        so = os.path.join(str(tmp_root), "libmfma_co.so")
+        r = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so,
+                            os.path.join(ROOT, "tools", "proto", "mfma_corunner.hip")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lib = ctypes.CDLL(so)
+        lib.mfma_co_launch.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p]
+        _MFMA["lib"] = lib
+    return _MFMA["lib"]
+
+
 def _run_beside(S, fn, n=N_CALLS, corunner="h2p"):
-    """``fn`` alone, then n times on s0 while s1 loops the co-runner; returns (reference tensors, list of n result lists)."""
+    """``fn`` alone, then n times on s0 while s1 loops the co-runner; returns (reference tensors, list of n result lists).
+    ``corunner``: "h2p" / "wino" (this package's layers) or a loaded mfma_corunner library (MFMA-only kernel, 256 VGPRs, 2048 blocks)."""
     s0, s1 = S["s0"], S["s1"]
     with torch.no_grad():
         with torch.cuda.stream(s0):
@@ -92,7 +116,10 @@ def _run_beside(S, fn, n=N_CALLS, corunner="h2p"):
         for _ in range(n):
             with torch.cuda.stream(s1):
                 for _ in range(4):
-                    core.conv_rows(S["xb"], S["pc1"] if corunner == "h2p" else S["pc3"], relu=False)
+                    if isinstance(corunner, str):
+                        core.conv_rows(S["xb"], S["pc1"] if corunner == "h2p" else S["pc3"], relu=False)
+                    else:
+                        assert corunner.mfma_co_launch(0, 256, 2048, 128, 35076, ctypes.c_void_p(s1.cuda_stream)) == 0
             with torch.cuda.stream(s0):
                 got.append([t.clone() for t in _flat(fn())])
         torch.cuda.synchronize()
@@ -135,27 +162,43 @@ def test_shipped_stage_is_bit_stable_beside_a_split_f16_gemm(dev, stage, corunne
     assert bad == 0, "%s: %d of %d calls differ from the stage run alone (co-runner %s)" % (stage, bad, N_CALLS, corunner)
 
 
-@pytest.mark.xfail(strict=False, reason="parked: bit-exact alone, one load beat reads as zero next to k_gemm_h2* (profiles/r6_corunner_defect.txt)")
-def test_parked_half_column_mix_beside_a_split_f16_gemm(dev, monkeypatch):
+@pytest.mark.parametrize("stage", ["head (coarse mix + fine branch)", "decode (head + pred_f scatter + render heads / rays / upsample)",
+                                   "neck (FPN3D, z-column upsample-add)"])
+def test_shipped_stage_is_bit_stable_beside_an_mfma_only_kernel(dev, stage, tmp_path_factory):
+    """The strongest trigger of the packed-fp32 op_sel hazard: a kernel of nothing but v_mfma_f32_32x32x16_f16 on the second stream."""
+    S = _scene(dev)
+    lib = _mfma_corunner(tmp_path_factory.getbasetemp())
+    ref, got = _run_beside(S, _stages(S)[stage], corunner=lib)
+    bad = _count_differing(ref, got)
+    assert bad == 0, "%s: %d of %d calls differ from the stage run alone (co-runner: MFMA-only kernel)" % (stage, bad, N_CALLS)
+
+
+@pytest.mark.parametrize("corunner", ["h2p", "mfma"])
+def test_half_column_mix_beside_matrix_core_work(dev, monkeypatch, corunner, tmp_path_factory):
+    """The half-z-column OccHead mix (default since round 6; 20 of 20 calls wrong beside either co-runner before it was compiled
+    without packed fp32): equal to the per-voxel kernel alone, and to itself beside the co-runner."""
     S = _scene(dev)
     monkeypatch.setenv("COOCC_INTERP_COLUMN", "3")
     head = S["model"].pts_bbox_head
     fn = lambda: head.forward_coarse_rows(S["sem"])
-    ref, got = _run_beside(S, fn)
+    ref, got = _run_beside(S, fn, corunner="h2p" if corunner == "h2p" else _mfma_corunner(tmp_path_factory.getbasetemp()))
     monkeypatch.setenv("COOCC_INTERP_COLUMN", "1")
     with torch.no_grad():
-        alone = [t.clone() for t in _flat(fn())]          # the shipped per-voxel kernel alone: what the parked form must equal
+        alone = [t.clone() for t in _flat(fn())]          # the per-voxel kernel alone
     torch.cuda.synchronize()
-    assert all(_bits_equal(a, b) for a, b in zip(alone, ref)), "the parked form differs from the shipped kernel even alone"
+    assert all(_bits_equal(a, b) for a, b in zip(alone, ref)), "the half-column form differs from the per-voxel kernel even alone"
     assert _count_differing(ref, got) == 0
 
 
-@pytest.mark.xfail(strict=False, reason="parked: bit-exact alone, differs next to k_gemm_h2* (DESIGN 3.2, profiles/r5_fine2_corunner.txt)")
-def test_parked_one_launch_fine_branch_beside_a_split_f16_gemm(dev, monkeypatch):
+@pytest.mark.parametrize("inside", [True, False])
+def test_fine_branch_beside_a_split_f16_gemm(dev, monkeypatch, inside):
+    """The ratio-2 fine branch with its image samples made inside k_fine2_h2 (default since round 6) and with the grouped sampler's own
+    launch: each bit-stable beside the decoder's split-f16 convolutions (the one-launch form: 18 of 20 calls wrong in round 5)."""
     from co_occ_amd import head as H
     S = _scene(dev)
     s, head = S["s"], S["model"].pts_bbox_head
-    monkeypatch.setattr(H, "FINE2_IMG_INSIDE", True)
+    monkeypatch.setattr(H, "FINE2_IMG_INSIDE", inside)
     fn = lambda: head(voxel_feats=S["sem"], img_feats=s["img_feats"], transform=s["transform"])
-    ref, got = _run_beside(S, fn)
-    assert _count_differing(ref, got) == 0
+    for co in ("h2p", "wino"):
+        ref, got = _run_beside(S, fn, corunner=co)
+        assert _count_differing(ref, got) == 0, co
