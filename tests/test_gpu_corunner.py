@@ -149,28 +149,18 @@ STAGES = ["lift_splat (P2 pooling)", "fuser (K1-K5 search, G1 gather GEMMs, con_
           "decode (head + pred_f scatter + render heads / rays / upsample)"]
 
 
-@pytest.mark.parametrize("corunner", ["h2p", "wino"])
+@pytest.mark.parametrize("corunner", ["h2p", "wino", "mfma"])
 @pytest.mark.parametrize("stage", STAGES)
-def test_shipped_stage_is_bit_stable_beside_a_split_f16_gemm(dev, stage, corunner):
-    """20 calls of one stage of the default dispatch on fixed inputs, a split-f16 layer looping on a second stream (``h2p``: the
-    pointwise kernel k_gemm_h2p; ``wino``: k_wino_in_h2 + k_gemm_h2z + k_wino_out): every output tensor (rows, H2 twins, index
-    lists) bit-equal to the stage run alone."""
+def test_shipped_stage_is_bit_stable_beside_matrix_core_work(dev, stage, corunner, tmp_path_factory):
+    """20 calls of one stage of the default dispatch on fixed inputs while a second stream loops ``h2p`` (the pointwise split-f16 kernel
+    k_gemm_h2p), ``wino`` (k_wino_in_h2 + k_gemm_h2z + k_wino_out) or ``mfma`` (a kernel of nothing but v_mfma_f32_32x32x16_f16: the
+    strongest trigger of the packed-fp32 op_sel hazard): every output tensor (rows, H2 twins, index lists) bit-equal to the stage alone."""
     S = _scene(dev)
-    ref, got = _run_beside(S, _stages(S)[stage], corunner=corunner)
+    co = _mfma_corunner(tmp_path_factory.getbasetemp()) if corunner == "mfma" else corunner
+    ref, got = _run_beside(S, _stages(S)[stage], corunner=co)
     assert len(ref) > 0
     bad = _count_differing(ref, got)
     assert bad == 0, "%s: %d of %d calls differ from the stage run alone (co-runner %s)" % (stage, bad, N_CALLS, corunner)
-
-
-@pytest.mark.parametrize("stage", ["head (coarse mix + fine branch)", "decode (head + pred_f scatter + render heads / rays / upsample)",
-                                   "neck (FPN3D, z-column upsample-add)"])
-def test_shipped_stage_is_bit_stable_beside_an_mfma_only_kernel(dev, stage, tmp_path_factory):
-    """The strongest trigger of the packed-fp32 op_sel hazard: a kernel of nothing but v_mfma_f32_32x32x16_f16 on the second stream."""
-    S = _scene(dev)
-    lib = _mfma_corunner(tmp_path_factory.getbasetemp())
-    ref, got = _run_beside(S, _stages(S)[stage], corunner=lib)
-    bad = _count_differing(ref, got)
-    assert bad == 0, "%s: %d of %d calls differ from the stage run alone (co-runner: MFMA-only kernel)" % (stage, bad, N_CALLS)
 
 
 @pytest.mark.parametrize("corunner", ["h2p", "mfma"])
