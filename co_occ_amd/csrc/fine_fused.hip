@@ -253,7 +253,8 @@ __device__ __forceinline__ void ff_sample_img8(const FineFused& p, long long x00
 }
 
 template <int R>
-__global__ COOCC_SCALAR_FP32 __launch_bounds__(256, 2) void k_fine_fused(FineFused p) {
+// (built with -fno-slp-vectorize, co_occ_amd/build.py FILE_FLAGS: the projection block below must not become packed fp32 with op_sel swaps)
+__global__ __launch_bounds__(256, 2) void k_fine_fused(FineFused p) {
   constexpr int R3 = R * R * R, CPW = 64 / R3;          // coarse voxels per wave: 8 (ratio 2) | 1 (ratio 4)
   __shared__ __attribute__((aligned(16))) float tiles[4][64 * FF_PITCH];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
