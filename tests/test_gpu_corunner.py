@@ -24,7 +24,7 @@ from co_occ_amd import core
 from co_occ_amd.core import to_rows
 
 pytestmark = pytest.mark.gpu
-N_CALLS = 20
+N_CALLS = int(os.environ.get("COOCC_CORUNNER_CALLS", "20"))      # a soak raises it (profiles/r6_corunner_soak.txt)
 _S = {}
 
 
